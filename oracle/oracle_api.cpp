@@ -1,0 +1,156 @@
+// TEST INFRASTRUCTURE ONLY (oracle/).  Flat C API over the CPU restatement, for ctypes (oracle/oracle.py).
+#include <cstring>
+#include <string>
+
+#include "fsgen.h"
+#include "oracle_codec.h"
+#include "oracle_lm.h"
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+using namespace oracle;
+
+static thread_local std::string g_err;
+#define GUARD(stmt) \
+    try { stmt; return 0; } catch (const std::exception& e) { g_err = e.what(); return 1; }
+
+extern "C" {
+
+const char* orc_last_error() { return g_err.c_str(); }
+int orc_num_threads() {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
+// ---- generator
+void orc_synth_fill(float* dst, uint64_t n, const char* name, uint64_t seed, float mean, double stdv, int bf16) {
+    fsgen::fill(dst, n, name, seed, mean, stdv, bf16 != 0);
+}
+
+// ---- LM
+void* orc_lm_create(const int* iargs /*11*/, const float* fargs /*2*/, const uint32_t* tok /*5*/) {
+    ModelArgs a;
+    a.dim = iargs[0]; a.n_layer = iargs[1]; a.n_fast_layer = iargs[2]; a.n_head = iargs[3]; a.n_local_heads = iargs[4];
+    a.head_dim = iargs[5]; a.intermediate_size = iargs[6]; a.num_codebooks = iargs[7]; a.codebook_size = iargs[8];
+    a.vocab_size = iargs[9]; a.max_seq_len = iargs[10];
+    a.norm_eps = fargs[0]; a.rope_base = fargs[1];
+    TokenCfg t;
+    t.im_end_id = tok[0]; t.pad_id = tok[1]; t.semantic_start_id = tok[2]; t.semantic_end_id = tok[3];
+    t.has_semantic_end = (int)tok[4];
+    LM* lm = new LM();
+    lm->init(a, t);
+    return lm;
+}
+void orc_lm_destroy(void* p) { delete (LM*)p; }
+int orc_lm_load_synthetic(void* p, uint64_t seed, int bf16) { GUARD(((LM*)p)->load_synthetic(seed, bf16 != 0)) }
+void orc_lm_set_kv_round_bf16(void* p, int on) { ((LM*)p)->kv_round_bf16 = on != 0; }
+int orc_lm_forward_generate(void* p, const uint32_t* toks, int B, int L, int input_pos, float* logits, float* hidden,
+                            int full_head) {
+    GUARD(((LM*)p)->forward_generate(toks, B, L, input_pos, logits, hidden, full_head != 0))
+}
+int orc_lm_forward_generate_fast(void* p, const float* x, int B, int pos, float* logits) {
+    GUARD(((LM*)p)->forward_generate_fast(x, B, pos, logits))
+}
+void orc_lm_clear_fast(void* p) { ((LM*)p)->clear_fast(); }
+void orc_lm_clear_slow(void* p) { ((LM*)p)->clear_slow(); }
+void orc_lm_clear_slow_until(void* p, int pos) { ((LM*)p)->clear_slow_until(pos); }
+int orc_lm_kv_len(void* p) { return ((LM*)p)->kv_len(); }
+const float* orc_lm_fast_embeddings(void* p) { return ((LM*)p)->fast_embeddings.data(); }
+const float* orc_lm_freqs(void* p, int sin) { return sin ? ((LM*)p)->sin_t.data() : ((LM*)p)->cos_t.data(); }
+// tensor access for cross-checks
+const float* orc_lm_tensor(void* p, const char* name, int layer) {
+    LM* lm = (LM*)p;
+    std::string n = name;
+    if (n == "embeddings") return lm->embeddings.data();
+    if (n == "codebook_embeddings") return lm->codebook_embeddings.data();
+    if (n == "output") return lm->output.data();
+    if (n == "fast_output") return lm->fast_output.data();
+    if (n == "norm") return lm->norm.data();
+    if (n == "fast_norm") return lm->fast_norm.data();
+    bool fast = n.rfind("fast.", 0) == 0;
+    if (fast) n = n.substr(5);
+    Block& b = fast ? lm->fast_layers.at(layer) : lm->layers.at(layer);
+    if (n == "wqkv") return b.wqkv.data();
+    if (n == "wo") return b.wo.data();
+    if (n == "w1") return b.w1.data();
+    if (n == "w2") return b.w2.data();
+    if (n == "w3") return b.w3.data();
+    if (n == "ffn_norm") return b.ffn_norm.data();
+    if (n == "attention_norm") return b.attention_norm.data();
+    return nullptr;
+}
+// generate_blocking.  codes_out: (num_codebooks, cap) row-major with row stride = *n_frames after return
+int orc_lm_generate(void* p, const uint32_t* prompt, int L, int max_new_tokens, double temp, double top_p, uint64_t top_k,
+                    float rep_pen, uint64_t seed, int ignore_eos, int max_frames, uint32_t* codes_out, int cap,
+                    int* n_frames, double* prefill_s, double* decode_s) {
+    try {
+        LM* lm = (LM*)p;
+        Sampling s; s.temp = temp; s.top_p = top_p; s.top_k = top_k; s.repetition_penalty = rep_pen;
+        int n = 0;
+        auto out = lm->generate(prompt, L, max_new_tokens, s, seed, ignore_eos != 0, &n, nullptr, prefill_s, decode_s,
+                                max_frames);
+        if (n > cap) { g_err = "codes_out too small"; return 2; }
+        std::memcpy(codes_out, out.data(), sizeof(uint32_t) * out.size());
+        *n_frames = n;
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// ---- weight-free helpers (known-answer tests)
+void orc_get_mask_abs(int s1, int s2, int ctx, uint8_t* m) { get_mask_abs(s1, s2, ctx, m); }
+void* orc_reppen_create(int vocab, int ctx, float amt) { RepPen* r = new RepPen(); r->init(vocab, ctx, amt); return r; }
+void orc_reppen_destroy(void* r) { delete (RepPen*)r; }
+int orc_reppen_apply(void* r, float* logits, int n, int last_token) {
+    try {
+        std::vector<float> l(logits, logits + n);
+        ((RepPen*)r)->apply(l, (size_t)last_token);
+        std::memcpy(logits, l.data(), sizeof(float) * n);
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+void orc_reppen_mask(void* r, float* mask_out) {
+    RepPen* rp = (RepPen*)r;
+    std::memcpy(mask_out, rp->mask.data(), sizeof(float) * rp->mask.size());
+}
+void* orc_sampler_create(uint64_t seed, double temp, double top_p, uint64_t top_k) {
+    Sampling s; s.temp = temp; s.top_p = top_p; s.top_k = top_k;
+    return new LogitsProcessor(seed, s);
+}
+void orc_sampler_destroy(void* s) { delete (LogitsProcessor*)s; }
+uint32_t orc_sampler_sample(void* s, const float* logits, uint64_t n) { return ((LogitsProcessor*)s)->sample(logits, n); }
+
+// ---- codec
+void* orc_codec_create(int tiny) {
+    Codec* c = new Codec();
+    if (tiny) c->init_tiny(); else c->init_fish15();
+    return c;
+}
+void orc_codec_destroy(void* c) { delete (Codec*)c; }
+int orc_codec_load_synthetic(void* c, uint64_t seed) { GUARD(((Codec*)c)->load_synthetic(seed)) }
+int orc_codec_hop(void* c) { return ((Codec*)c)->hop(); }
+void orc_codec_fsq_code(void* c, uint32_t idx, float* code4) { ((Codec*)c)->fsq_code(idx, code4); }
+// pcm_out: (hop*T).  If stage_out != null, stage `stage_idx` (0 = quantizer output, 1..2 upsample, 3 conv_pre,
+// 4..8 HiFiGAN stages) is copied there (caller sizes it).
+int orc_codec_decode(void* c, const uint32_t* codes, int T, float* pcm_out, int stage_idx, float* stage_out) {
+    try {
+        std::vector<std::vector<float>> st;
+        auto pcm = ((Codec*)c)->decode(codes, T, stage_out ? &st : nullptr);
+        std::memcpy(pcm_out, pcm.data(), sizeof(float) * pcm.size());
+        if (stage_out) std::memcpy(stage_out, st.at(stage_idx).data(), sizeof(float) * st.at(stage_idx).size());
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
+}  // extern "C"

@@ -1,0 +1,109 @@
+"""CPU: the oracle restatement vs the weight-free known answers derivable from the reference sources
+(SURVEY.md §8c): FSQ implicit codebook, causal mask, repetition-penalty quirk trace, RoPE table, frame budget,
+host-ArgMax tie rule, synthetic-weight generator spec."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+KA = np.load(os.path.join(os.path.dirname(__file__), "golden", "known_answers.npz"))
+
+
+def test_fsq_codebook():  # fsq.rs:53-58,119-144
+    c = orc.OracleCodec(tiny=True)
+    cb = np.stack([c.fsq_code(i) for i in range(1000)])
+    assert np.array_equal(cb, KA["fsq_codebook"])
+    assert tuple(cb[0]) == (-1, -1, -1, -1) and tuple(cb[999]) == (0.75, 1, 1, 1)
+
+
+def test_mask_abs():  # dual_ar.rs:702-712
+    import ctypes as C
+    m = np.zeros((3, 5), np.uint8)
+    orc.lib().orc_get_mask_abs(3, 5, 8192, m.ctypes.data_as(C.POINTER(C.c_uint8)))
+    assert np.array_equal(m, KA["mask_3_5"])
+    # sliding-window term: size1 + j + context < size2 + i
+    m = np.zeros((1, 6), np.uint8)
+    orc.lib().orc_get_mask_abs(1, 6, 2, m.ctypes.data_as(C.POINTER(C.c_uint8)))
+    assert m.tolist() == [[1, 1, 1, 0, 0, 0]]
+
+
+def test_reppen_quirk_trace():  # rep_pen.rs:37-65
+    import ctypes as C
+    L = orc.lib()
+    r = C.c_void_p(L.orc_reppen_create(16, 3, C.c_float(2.0)))
+    for tok, expect in zip(KA["reppen_tokens"], KA["reppen_penalised"]):
+        logits = np.full(16, 4.0, np.float32)
+        logits[3] = -4.0  # division ignores the logit sign (rep_pen.rs:64)
+        assert L.orc_reppen_apply(r, logits.ctypes.data_as(C.POINTER(C.c_float)), 16, int(tok)) == 0
+        pen = sorted(np.nonzero(logits == 2.0)[0].tolist())
+        assert pen == sorted(int(e) for e in expect if e >= 0), (tok, pen)
+        assert logits[3] == -4.0
+    # out-of-vocab token errors (rep_pen.rs:38-40)
+    assert L.orc_reppen_apply(r, logits.ctypes.data_as(C.POINTER(C.c_float)), 16, 16) != 0
+    L.orc_reppen_destroy(r)
+
+
+def test_rope_table():  # dual_ar.rs:174-185
+    lm = orc.OracleLM(orc.FISH15 | dict(n_layer=0, n_fast_layer=0, vocab_size=8, max_seq_len=64))
+    cos, sin = lm.freqs()
+    theta = KA["rope_theta_fish15"]
+    pos = np.arange(64)[:, None]
+    np.testing.assert_allclose(cos, np.cos(pos * theta), atol=1e-5)
+    np.testing.assert_allclose(sin, np.sin(pos * theta), atol=1e-5)
+    assert cos.shape == (64, 32) and cos[0].tolist() == [1.0] * 32
+
+
+def test_argmax_tie_rule():  # host ArgMax: max_by(total_cmp) -> last maximal index
+    import ctypes as C
+    L = orc.lib()
+    s = C.c_void_p(L.orc_sampler_create(C.c_uint64(1), C.c_double(0.0), C.c_double(1.0), C.c_uint64(0)))
+    v = np.array([0.5, 2.0, -1.0, 2.0, 1.0], np.float32)
+    assert L.orc_sampler_sample(s, v.ctypes.data_as(C.POINTER(C.c_float)), C.c_uint64(5)) == 3
+    L.orc_sampler_destroy(s)
+
+
+@pytest.mark.parametrize("L,M,p0,frames", [tuple(r) for r in KA["budget_cases"].tolist()])
+def test_frame_budget(L, M, p0, frames):  # single_batch.rs:61,77,193-197
+    cfg = orc.TINY | dict(max_seq_len=512)
+    lm = orc.OracleLM(cfg).load_synthetic(1)
+    prompt = np.zeros((9, L), np.uint32)
+    prompt[0] = np.arange(L) % cfg["im_end_id"]
+    out = lm.generate(prompt, M, ignore_eos=True)
+    assert out.shape == (8, frames)
+    assert lm.kv_len() == L + frames - 1
+
+
+def test_synth_generator_spec():
+    """oracle/fsgen.h vs the numpy statement of the same spec (tests/golden/make_golden.py::synth)."""
+    M64 = (1 << 64) - 1
+
+    def fnv(name):
+        h = 0xCBF29CE484222325
+        for b in name.encode():
+            h = ((h ^ b) * 0x100000001B3) & M64
+        return h
+
+    def mix(z):
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M64
+        return z ^ (z >> 31)
+
+    for name, seed, mean, std, bf16 in [("layers.0.attention.wqkv.weight", 0xF15E5EED, 0.0, 0.02, False),
+                                        ("norm.weight", 7, 1.0, 0.1, True)]:
+        got = orc.synth(name, 257, seed, mean, std, bf16)
+        key = fnv(name) ^ seed
+        exp = np.empty(257, np.float32)
+        for i in range(257):
+            h = mix((key + (i + 1) * 0x9E3779B97F4A7C15) & M64)
+            s = (h & 0xFFFF) + ((h >> 16) & 0xFFFF) + ((h >> 32) & 0xFFFF) + (h >> 48) - 131070
+            v = np.float32(mean) + np.float32(s) * np.float32(std / 37837.2272)
+            if bf16:
+                u = int(np.float32(v).view(np.uint32))
+                u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+                v = np.uint32(u).view(np.float32)
+            exp[i] = v
+        assert np.array_equal(got, exp)
+    big = orc.synth("x", 200000, 3, 0.0, 1.0)
+    assert abs(float(big.mean())) < 0.01 and abs(float(big.std()) - 1.0) < 0.01

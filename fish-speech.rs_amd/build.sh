@@ -1,0 +1,18 @@
+#!/bin/bash
+# Builds libfishrt.so (HIP kernels + C ABI) for gfx950, in-tree.  hipcc cross-compiles without a GPU.
+set -e
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+cd "$HERE/csrc"
+mkdir -p "$HERE/build"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -ffp-contract=on"
+pids=()
+for f in lm_kernels.hip lm_engine.hip codec_engine.hip fishrt_api.cpp; do
+  o="$HERE/build/${f%.*}.o"
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ -n "$(find . -name '*.h' -newer "$o" -print -quit)" ] || [ "../../include/fishrt.h" -nt "$o" ]; then
+    ( /opt/rocm/bin/hipcc $FLAGS -x hip -c "$f" -o "$o" ) &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait "$p"; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "$HERE"/build/*.o -o "$HERE/libfishrt.so"
+echo "built $HERE/libfishrt.so"

@@ -1,0 +1,19 @@
+// Host-side engine of the Firefly-GAN-VQ vocoder (FireflyCodec::decode, codec/firefly.rs:42-48).
+#pragma once
+#include <cstdint>
+#include <string>
+
+namespace fs {
+
+class CodecBase {
+  public:
+    virtual ~CodecBase() {}
+    virtual void load_synthetic(uint64_t seed) = 0;
+    virtual void load_safetensors(const std::string& path) = 0;
+    virtual void decode(const uint32_t* codes, int b, int T, float* pcm_out) = 0;
+    virtual int sample_rate() = 0;
+};
+
+CodecBase* make_codec(int device, int channel_div);
+
+}  // namespace fs

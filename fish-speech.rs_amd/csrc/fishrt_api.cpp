@@ -1,0 +1,94 @@
+// extern "C" surface of libfishrt.so (include/fishrt.h).  Thin: argument checks, exception -> status + message.
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "../../include/fishrt.h"
+#include "codec_engine.h"
+#include "fs_common.h"
+#include "lm_engine.h"
+
+static thread_local std::string g_err;
+
+struct fs_lm { fs::LMBase* impl; };
+struct fs_codec { fs::CodecBase* impl; };
+
+#define FS_TRY(body)                                                          \
+    try { body; return FS_OK; }                                               \
+    catch (const std::exception& e) { g_err = e.what(); return FS_ERR; }      \
+    catch (...) { g_err = "unknown error"; return FS_ERR; }
+#define FS_ARG(cond, msg) if (!(cond)) { g_err = msg; return FS_ERR; }
+
+extern "C" {
+
+const char* fs_last_error(void) { return g_err.c_str(); }
+const char* fs_version(void) { return "fishrt 0.1.0 (gfx950)"; }
+int fs_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int fs_lm_create(const fs_model_args* args, const fs_token_cfg* tok, int device_id, fs_dtype dtype, int max_batch, fs_lm_t** out) {
+    FS_ARG(args && tok && out, "null argument");
+    FS_TRY({ *out = nullptr; fs::LMBase* p = fs::make_lm(*args, *tok, device_id, dtype, max_batch); *out = new fs_lm{p}; })
+}
+void fs_lm_destroy(fs_lm_t* lm) {
+    if (!lm) return;
+    delete lm->impl;
+    delete lm;
+}
+int fs_lm_load_safetensors(fs_lm_t* lm, const char* path) { FS_ARG(lm && path, "null argument"); FS_TRY(lm->impl->load_safetensors(path)) }
+int fs_lm_load_synthetic(fs_lm_t* lm, uint64_t seed) { FS_ARG(lm, "null argument"); FS_TRY(lm->impl->load_synthetic(seed)) }
+int fs_lm_forward_generate(fs_lm_t* lm, const uint32_t* toks, int B, int L, int input_pos, float* logits_out, float* hidden_out) {
+    FS_ARG(lm && toks, "null argument");
+    FS_ARG(input_pos >= 0, "negative input_pos");
+    FS_TRY(lm->impl->forward_generate(toks, B, L, input_pos, logits_out, hidden_out))
+}
+int fs_lm_forward_generate_fast(fs_lm_t* lm, const float* x, int B, int input_pos, float* logits_out) {
+    FS_ARG(lm && x && logits_out, "null argument");
+    FS_ARG(input_pos >= 0, "negative input_pos");
+    FS_TRY(lm->impl->forward_generate_fast(x, B, input_pos, logits_out))
+}
+int fs_lm_fast_embed(fs_lm_t* lm, const uint32_t* ids, int n, float* out) {
+    FS_ARG(lm && ids && out && n > 0, "bad argument");
+    FS_TRY(lm->impl->fast_embed(ids, n, out))
+}
+int fs_lm_clear_fast_layer_caches(fs_lm_t* lm) { FS_ARG(lm, "null argument"); FS_TRY(lm->impl->clear_fast()) }
+int fs_lm_clear_slow_layer_caches(fs_lm_t* lm) { FS_ARG(lm, "null argument"); FS_TRY(lm->impl->clear_slow()) }
+int fs_lm_clear_slow_caches_until(fs_lm_t* lm, int pos) { FS_ARG(lm, "null argument"); FS_TRY(lm->impl->clear_slow_until(pos)) }
+int fs_lm_curr_kv_size(fs_lm_t* lm) {
+    if (!lm) { g_err = "null argument"; return -1; }
+    try { return lm->impl->kv_len(); } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int fs_lm_generate(fs_lm_t* lm, const uint32_t* prompt, int L, int max_new_tokens, const fs_sampling* sampling, uint64_t seed,
+                   uint32_t flags, uint32_t* codes_out, size_t cap, size_t* n_frames, fs_frame_cb cb, void* cb_user) {
+    FS_ARG(lm && prompt && sampling && n_frames, "null argument");
+    FS_TRY(lm->impl->generate(prompt, L, max_new_tokens, *sampling, seed, flags, codes_out, cap, n_frames, cb, cb_user))
+}
+int fs_lm_generate_batch(fs_lm_t* lm, const uint32_t* prompts, const int* lens, int n, int max_new_tokens, const fs_sampling* sampling,
+                         uint64_t seed, uint32_t flags, uint32_t* codes_out, size_t cap, size_t* n_frames) {
+    FS_ARG(lm && prompts && lens && sampling && codes_out && n_frames, "null argument");
+    FS_TRY(lm->impl->generate_batch(prompts, lens, n, max_new_tokens, *sampling, seed, flags, codes_out, cap, n_frames))
+}
+int fs_lm_last_stats(fs_lm_t* lm, fs_gen_stats* out) { FS_ARG(lm && out, "null argument"); FS_TRY(*out = lm->impl->last_stats()) }
+void* fs_lm_stream(fs_lm_t* lm) { return lm ? lm->impl->stream() : nullptr; }
+
+int fs_codec_create(int device_id, int channel_div, fs_codec_t** out) {
+    FS_ARG(out, "null argument");
+    FS_TRY({ *out = nullptr; fs::CodecBase* p = fs::make_codec(device_id, channel_div); *out = new fs_codec{p}; })
+}
+void fs_codec_destroy(fs_codec_t* c) {
+    if (!c) return;
+    delete c->impl;
+    delete c;
+}
+int fs_codec_load_safetensors(fs_codec_t* c, const char* path) { FS_ARG(c && path, "null argument"); FS_TRY(c->impl->load_safetensors(path)) }
+int fs_codec_load_synthetic(fs_codec_t* c, uint64_t seed) { FS_ARG(c, "null argument"); FS_TRY(c->impl->load_synthetic(seed)) }
+int fs_codec_decode(fs_codec_t* c, const uint32_t* codes, int b, int T, float* pcm_out) {
+    FS_ARG(c && codes && pcm_out, "null argument");
+    FS_TRY(c->impl->decode(codes, b, T, pcm_out))
+}
+int fs_codec_sample_rate(fs_codec_t* c) { return c ? c->impl->sample_rate() : -1; }
+
+}  // extern "C"

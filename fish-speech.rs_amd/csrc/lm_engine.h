@@ -1,0 +1,36 @@
+// Host-side engine of the dual-AR LM: owns weights, the paged KV cache, the captured frame graph and the
+// generation loop.  One instance == one `DualARTransformer` (dual_ar.rs:443-457) on one GPU.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+
+#include "../../include/fishrt.h"
+
+namespace fs {
+
+class LMBase {
+  public:
+    virtual ~LMBase() {}
+    virtual void load_synthetic(uint64_t seed) = 0;
+    virtual void load_safetensors(const std::string& path) = 0;
+    virtual void forward_generate(const uint32_t* toks, int B, int L, int input_pos, float* logits, float* hidden) = 0;
+    virtual void forward_generate_fast(const float* x, int B, int input_pos, float* logits) = 0;
+    virtual void fast_embed(const uint32_t* ids, int n, float* out) = 0;
+    virtual void clear_fast() = 0;
+    virtual void clear_slow() = 0;
+    virtual void clear_slow_until(int pos) = 0;
+    virtual int kv_len() = 0;
+    virtual void generate(const uint32_t* prompt, int L, int max_new_tokens, const fs_sampling& s, uint64_t seed,
+                          uint32_t flags, uint32_t* codes_out, size_t cap, size_t* n_frames, fs_frame_cb cb,
+                          void* cb_user) = 0;
+    virtual void generate_batch(const uint32_t* prompts, const int* lens, int n, int max_new_tokens,
+                                const fs_sampling& s, uint64_t seed, uint32_t flags, uint32_t* codes_out, size_t cap,
+                                size_t* n_frames) = 0;
+    virtual fs_gen_stats last_stats() = 0;
+    virtual void* stream() = 0;
+};
+
+LMBase* make_lm(const fs_model_args& a, const fs_token_cfg& t, int device, fs_dtype dtype, int max_batch);
+
+}  // namespace fs

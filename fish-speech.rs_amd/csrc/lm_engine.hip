@@ -1,0 +1,626 @@
+// Host-side engine of the dual-AR LM (see lm_engine.h).  All device work goes through the hand-written kernels
+// of lm_kernels.hip on ONE HIP stream; the per-frame inner loop (24 slow blocks + head + sample + 8 x (4 fast blocks
+// + head + sample)) is captured once into a hipGraph and replayed with zero host round trips per frame.
+//
+// Reference call graph implemented here:
+//   generate_blocking               fish_speech_core/lib/lm/generate/single_batch.rs:217-324
+//   SingleBatchGenerator::{new,next} fish_speech_core/lib/lm/generate/single_batch.rs:31-214
+//   DualARTransformer::forward_generate[_fast] / cache lifecycle   fish_speech_core/lib/lm/dual_ar.rs:574-700
+#include "lm_engine.h"
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <type_traits>
+#include <vector>
+
+#include "fs_common.h"
+#include "fs_synth.h"
+#include "lm_kernels.h"
+#include "safetensors.h"
+
+namespace fs {
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t n = 0;
+    void alloc(size_t bytes) {
+        free();
+        n = bytes;
+        if (bytes) FS_HIP(hipMalloc(&p, bytes));
+    }
+    void free() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~DevBuf() { free(); }
+    template <typename T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct TensorDesc {
+    std::string name;      // reference tensor name (dual_ar.rs loader)
+    int64_t rows, cols;
+    bool is_vec;           // f32 norm vector (device f32) vs WT matrix
+    size_t offset;         // byte offset in the arena (destination base of the possibly interleaved slab)
+    int row_mul, row_off;  // destination row = r * row_mul + row_off
+    float mean;
+    double stdv;
+};
+
+// rand_core SeedableRng::seed_from_u64 (PCG32 expansion) -> ChaCha key
+void seed_key(uint64_t state, uint32_t* key) {
+    for (int i = 0; i < 8; ++i) {
+        state = state * 6364136223846793005ull + 11634580027462260723ull;
+        const uint32_t xorshifted = (uint32_t)(((state >> 18) ^ state) >> 27);
+        const uint32_t rot = (uint32_t)(state >> 59);
+        key[i] = (xorshifted >> rot) | (xorshifted << ((32 - rot) & 31));
+    }
+}
+
+constexpr int NSPLIT = 8;  // flash-decoding splits per kv head (grid = Hk * NSPLIT blocks)
+
+}  // namespace
+
+template <typename WT>
+class LM final : public LMBase {
+  public:
+    LM(const fs_model_args& a, const fs_token_cfg& t, int device, int max_batch) : a_(a), t_(t), device_(device), B_(max_batch) {
+        FS_REQUIRE(max_batch >= 1, "max_batch must be >= 1");
+        FS_REQUIRE(a.dim == a.n_head * a.head_dim, "dim must equal n_head * head_dim (dual_ar.rs:173,381)");
+        FS_REQUIRE(a.n_head % a.n_local_heads == 0, "n_head must be a multiple of n_local_heads");
+        FS_REQUIRE(a.head_dim % 8 == 0 && a.num_codebooks + 1 <= 16, "unsupported head_dim / num_codebooks");
+        FS_REQUIRE(t.im_end_id < (uint32_t)a.vocab_size, "im_end_id outside the vocabulary");
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+            throw Error("no HIP device visible: libfishrt has no CPU fallback (MI355X / gfx950 required)");
+        FS_REQUIRE(device >= 0 && device < ndev, "device_id out of range");
+        FS_HIP(hipSetDevice(device));
+        hipDeviceProp_t prop;
+        FS_HIP(hipGetDeviceProperties(&prop, device));
+        if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+            throw Error(std::string("libfishrt kernels are built for gfx950 only; device reports ") + prop.gcnArchName);
+        FS_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+        d_.dim = a.dim; d_.inter = a.intermediate_size; d_.H = a.n_head; d_.Hk = a.n_local_heads; d_.Dh = a.head_dim;
+        d_.n_rep = a.n_head / a.n_local_heads; d_.eps = a.norm_eps;
+        n_audio_ = a.vocab_size - (int)t.im_end_id;
+        plan_tensors();
+        alloc_runtime();
+        for (auto& e : ev_) FS_HIP(hipEventCreate(&e));
+    }
+    ~LM() override {
+        (void)hipSetDevice(device_);
+        (void)hipStreamSynchronize(st_);
+        if (g_frame_) (void)hipGraphExecDestroy(g_frame_);
+        if (g_step_) (void)hipGraphExecDestroy(g_step_);
+        for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
+        if (h_pin_) (void)hipHostFree(h_pin_);
+        if (st_) (void)hipStreamDestroy(st_);
+    }
+
+    // ------------------------------------------------------------------------------------------ weights
+    void load_synthetic(uint64_t seed) override {
+        use_device();
+        const int round_bf16 = std::is_same<WT, bf16_t>::value ? 1 : 0;
+        for (const auto& td : tensors_) {
+            const uint64_t key = synth_fnv1a64(td.name.c_str()) ^ seed;
+            const float sc = synth_scale(td.stdv);
+            if (td.is_vec)
+                launch_synth_fill<float>((float*)(arena_.as<uint8_t>() + td.offset), key, td.rows, td.cols, 1, 0, td.mean, sc,
+                                         round_bf16, st_);
+            else
+                launch_synth_fill<WT>((WT*)(arena_.as<uint8_t>() + td.offset), key, td.rows, td.cols, td.row_mul, td.row_off,
+                                      td.mean, sc, round_bf16, st_);
+        }
+        FS_HIP(hipStreamSynchronize(st_));
+        loaded_ = true;
+    }
+
+    void load_safetensors(const std::string& path) override {
+        use_device();
+        SafeTensors st(path);
+        DevBuf stage;
+        std::vector<float> host;
+        for (const auto& td : tensors_) {
+            std::string name = td.name;
+            if (name == "output.weight" && a_.tie_word_embeddings) name = "embeddings.weight";  // dual_ar.rs:482-486
+            const StTensor* t = st.find(name);
+            if (!t) throw Error("cannot find tensor " + name);  // candle VarBuilder: "cannot find tensor"
+            if (t->numel() != td.rows * td.cols)
+                throw Error("shape mismatch for " + name + ": expected " + std::to_string(td.rows) + "x" + std::to_string(td.cols));
+            host.resize((size_t)t->numel());
+            SafeTensors::to_f32(*t, host.data());
+            if (stage.n < host.size() * 4) stage.alloc(host.size() * 4);
+            FS_HIP(hipMemcpyAsync(stage.p, host.data(), host.size() * 4, hipMemcpyHostToDevice, st_));
+            if (td.is_vec)
+                launch_convert_rows<float>((float*)(arena_.as<uint8_t>() + td.offset), stage.as<float>(), td.rows, td.cols, 1, 0, st_);
+            else
+                launch_convert_rows<WT>((WT*)(arena_.as<uint8_t>() + td.offset), stage.as<float>(), td.rows, td.cols, td.row_mul,
+                                        td.row_off, st_);
+            FS_HIP(hipStreamSynchronize(st_));
+        }
+        loaded_ = true;
+    }
+
+    // ------------------------------------------------------------------------------------------ teacher-forced API
+    void forward_generate(const uint32_t* toks, int B, int L, int input_pos, float* logits, float* hidden) override {
+        use_device();
+        require_loaded();
+        FS_REQUIRE(B >= 1 && B <= B_, "batch size exceeds the handle's max_batch");
+        FS_REQUIRE(L >= 1, "empty input");
+        const int C1 = a_.num_codebooks + 1;
+        for (int b = 1; b < B; ++b) FS_REQUIRE(seq_len_[b] == seq_len_[0], "KV cache length differs across batch rows");
+        if (input_pos + L > a_.max_seq_len) throw Error("input_pos + seq_len exceeds max_seq_len (dual_ar.rs:623-624)");
+        validate_tokens(toks, (size_t)B * C1 * L, B, L);
+        std::vector<float> lg, hd;
+        for (int b = 0; b < B; ++b) {
+            ensure_capacity(b, seq_len_[b] + L);
+            FS_HIP(hipMemcpyAsync(d_prompt_.p, toks + (size_t)b * C1 * L, sizeof(uint32_t) * C1 * L, hipMemcpyHostToDevice, st_));
+            SeqState s = {};
+            s.pos = seq_len_[b]; s.rope_off = input_pos - seq_len_[b]; s.prompt_L = L;
+            FS_HIP(hipMemcpyAsync(state(b), &s, sizeof(s), hipMemcpyHostToDevice, st_));
+            for (int l = 0; l < L; ++l) {
+                LmKernels<WT>::embed(d_, tok_emb_, cb_emb_, a_.num_codebooks, a_.codebook_size, d_cfg_.as<SampleCfg>(),
+                                     d_prompt_.as<uint32_t>(), state(b), x(b), st_);
+                enqueue_slow_layers(b);
+                launch_advance(state(b), st_);
+            }
+            seq_len_[b] += L;
+            if (hidden) FS_HIP(hipMemcpyAsync(hidden + (size_t)b * a_.dim, x(b), sizeof(float) * a_.dim, hipMemcpyDeviceToHost, st_));
+            if (logits) {
+                LmKernels<WT>::head(d_, x(b), norm_w_, out_w_, a_.vocab_size, d_logits_slow_.as<float>(), st_);
+                FS_HIP(hipMemcpyAsync(logits + (size_t)b * a_.vocab_size, d_logits_slow_.p, sizeof(float) * a_.vocab_size,
+                                      hipMemcpyDeviceToHost, st_));
+            }
+            FS_HIP(hipStreamSynchronize(st_));
+        }
+    }
+
+    void forward_generate_fast(const float* xin, int B, int input_pos, float* logits) override {
+        use_device();
+        require_loaded();
+        FS_REQUIRE(B >= 1 && B <= B_, "batch size exceeds the handle's max_batch");
+        if (input_pos >= a_.max_seq_len) throw Error("input_pos exceeds max_seq_len");
+        for (int b = 0; b < B; ++b) {
+            FS_REQUIRE(fast_len_[b] < 8, "fast decoder KV holds at most 8 positions per frame (num_codebooks)");
+            FS_HIP(hipMemcpyAsync(xf(b), xin + (size_t)b * a_.dim, sizeof(float) * a_.dim, hipMemcpyHostToDevice, st_));
+            enqueue_fast_layers(b, fast_len_[b], input_pos);
+            LmKernels<WT>::head(d_, xf(b), fast_norm_w_, fast_out_w_, a_.codebook_size, d_logits_fast_.as<float>(), st_);
+            FS_HIP(hipMemcpyAsync(logits + (size_t)b * a_.codebook_size, d_logits_fast_.p, sizeof(float) * a_.codebook_size,
+                                  hipMemcpyDeviceToHost, st_));
+            FS_HIP(hipStreamSynchronize(st_));
+            fast_len_[b] += 1;
+        }
+    }
+
+    void fast_embed(const uint32_t* ids, int n, float* out) override {
+        use_device();
+        require_loaded();
+        for (int i = 0; i < n; ++i) FS_REQUIRE(ids[i] < (uint32_t)a_.codebook_size, "fast embedding id out of range");
+        DevBuf di, dout;
+        di.alloc(sizeof(uint32_t) * n);
+        dout.alloc(sizeof(float) * n * a_.dim);
+        FS_HIP(hipMemcpyAsync(di.p, ids, sizeof(uint32_t) * n, hipMemcpyHostToDevice, st_));
+        LmKernels<WT>::fast_embed(d_, fast_emb_, di.as<uint32_t>(), n, dout.as<float>(), st_);
+        FS_HIP(hipMemcpyAsync(out, dout.p, sizeof(float) * n * a_.dim, hipMemcpyDeviceToHost, st_));
+        FS_HIP(hipStreamSynchronize(st_));
+    }
+
+    void clear_fast() override { std::fill(fast_len_.begin(), fast_len_.end(), 0); }
+    void clear_slow() override { for (int b = 0; b < B_; ++b) truncate(b, 0); }
+    void clear_slow_until(int pos) override {
+        FS_REQUIRE(pos >= 0, "negative position");
+        for (int b = 0; b < B_; ++b) truncate(b, std::min(seq_len_[b], pos));
+    }
+    int kv_len() override { return seq_len_[0]; }
+    fs_gen_stats last_stats() override { return stats_; }
+    void* stream() override { return (void*)st_; }
+
+    // ------------------------------------------------------------------------------------------ generate_blocking
+    void generate(const uint32_t* prompt, int L, int max_new_tokens, const fs_sampling& s, uint64_t seed, uint32_t flags,
+                  uint32_t* codes_out, size_t cap, size_t* n_frames, fs_frame_cb cb, void* cb_user) override {
+        use_device();
+        require_loaded();
+        const int C = a_.num_codebooks, C1 = C + 1;
+        FS_REQUIRE(L >= 1, "empty prompt");
+        FS_REQUIRE(max_new_tokens >= 0, "negative max_new_tokens");
+        if (!t_.has_semantic_end)
+            throw Error("Fish <= 1.4 slow-token sampling uses an unseeded thread_rng in the reference (sampling/mod.rs:17); "
+                        "only the Fish 1.5 audio-range path is implemented");
+        FS_REQUIRE(t_.im_end_id + 1 == t_.semantic_start_id, "im_end_id must directly precede the semantic range (utils.rs:13)");
+        validate_tokens(prompt, (size_t)C1 * L, 1, L);
+        const int n_cached = seq_len_[0];
+        if (n_cached + L > a_.max_seq_len) throw Error("prompt exceeds max_seq_len (dual_ar.rs:623-624)");
+        // iteration budget (single_batch.rs:61,77,193-197): prefill iteration + one per k with L + k - 1 <= max_new_tokens
+        long long n_iter = 1 + std::max<long long>(0, (long long)max_new_tokens - L + 1);
+        bool clamped = false;
+        const long long room = (long long)a_.max_seq_len - (n_cached + L) + 1;  // iterations that fit the RoPE table / KV
+        if (n_iter > room) { n_iter = room; clamped = true; }
+        FS_REQUIRE(n_iter <= out_cap_, "generation longer than the output staging buffer");
+        ensure_capacity(0, n_cached + L + (int)n_iter - 1);
+        // device-side setup
+        SampleCfg cfg = base_cfg();
+        cfg.temp = (float)s.temp; cfg.top_p = (float)s.top_p;
+        cfg.top_k = (int)std::min<uint64_t>(s.top_k, 1u << 30);
+        cfg.rep_pen = s.repetition_penalty; cfg.ignore_eos = (flags & FS_GEN_IGNORE_EOS) ? 1 : 0;
+        FS_HIP(hipMemcpyAsync(d_cfg_.p, &cfg, sizeof(cfg), hipMemcpyHostToDevice, st_));
+        RngState rng = {};
+        seed_key(seed, rng.key);
+        FS_HIP(hipMemcpyAsync(d_rng_.p, &rng, sizeof(rng), hipMemcpyHostToDevice, st_));
+        SeqState ss = {};
+        ss.pos = n_cached; ss.prompt_L = L;
+        FS_HIP(hipMemcpyAsync(state(0), &ss, sizeof(ss), hipMemcpyHostToDevice, st_));
+        FS_HIP(hipMemcpyAsync(d_prompt_.p, prompt, sizeof(uint32_t) * C1 * L, hipMemcpyHostToDevice, st_));
+        launch_reppen_reset(rp_, C, a_.codebook_size, st_);
+        clear_fast();
+        build_graphs();
+
+        stats_ = {};
+        FS_HIP(hipEventRecord(ev_[0], st_));
+        // prefill: L-1 sequential token steps, then the last prompt token runs as the first frame
+        for (int l = 0; l + 1 < L; ++l) FS_HIP(hipGraphLaunch(g_step_, st_));
+        LmKernels<WT>::embed(d_, tok_emb_, cb_emb_, C, a_.codebook_size, d_cfg_.as<SampleCfg>(), d_prompt_.as<uint32_t>(), state(0),
+                             x(0), st_);
+        FS_HIP(hipGraphLaunch(g_frame_, st_));
+        FS_HIP(hipEventRecord(ev_[1], st_));
+        stats_.graph_launches = (uint64_t)L;
+        // decode: one graph replay per frame; the host only peeks at the done flag every CHUNK frames
+        const int CHUNK = cb ? 8 : 32;
+        long long it = 1;
+        size_t delivered = 0;
+        bool stop = false;
+        SeqState* hs = reinterpret_cast<SeqState*>(h_pin_);
+        auto poll = [&]() {
+            FS_HIP(hipMemcpyAsync(hs, state(0), sizeof(SeqState), hipMemcpyDeviceToHost, st_));
+            FS_HIP(hipStreamSynchronize(st_));
+            if (cb) {
+                const size_t n = (size_t)hs->n_out;
+                if (n > delivered) {
+                    std::vector<uint32_t> tmp((size_t)C * out_cap_);
+                    // column block [delivered, n) of every row
+                    for (int c = 0; c < C; ++c)
+                        FS_HIP(hipMemcpy(tmp.data() + (size_t)c * out_cap_ + delivered, d_out_.as<uint32_t>() + (size_t)c * out_cap_ + delivered,
+                                         sizeof(uint32_t) * (n - delivered), hipMemcpyDeviceToHost));
+                    std::vector<uint32_t> fr(C);
+                    for (size_t f = delivered; f < n && !stop; ++f) {
+                        for (int c = 0; c < C; ++c) fr[c] = tmp[(size_t)c * out_cap_ + f];
+                        if (cb(cb_user, f, fr.data())) stop = true;
+                    }
+                    delivered = n;
+                }
+            }
+            return hs->done != 0;
+        };
+        while (it < n_iter && !stop) {
+            const long long end = std::min<long long>(n_iter, it + CHUNK);
+            for (; it < end; ++it) { FS_HIP(hipGraphLaunch(g_frame_, st_)); stats_.graph_launches += 1; }
+            if (it < n_iter || cb) { if (poll()) break; }
+        }
+        FS_HIP(hipEventRecord(ev_[2], st_));
+        FS_HIP(hipMemcpyAsync(hs, state(0), sizeof(SeqState), hipMemcpyDeviceToHost, st_));
+        FS_HIP(hipStreamSynchronize(st_));
+        if (cb && !stop) poll();
+        const size_t n = (size_t)hs->n_out;
+        seq_len_[0] = hs->pos;
+        float ms01 = 0, ms12 = 0;
+        FS_HIP(hipEventElapsedTime(&ms01, ev_[0], ev_[1]));
+        FS_HIP(hipEventElapsedTime(&ms12, ev_[1], ev_[2]));
+        stats_.prefill_ms = ms01; stats_.decode_ms = ms12; stats_.frames = n; stats_.prompt_tokens = (uint64_t)L;
+        if (clamped && !hs->done && !stop)
+            throw Error("generation ran past max_seq_len without <|im_end|> (the reference fails at dual_ar.rs:623-624)");
+        FS_REQUIRE(n <= cap, "codes_out capacity too small for the generated frames");
+        if (codes_out) {
+            std::vector<uint32_t> tmp((size_t)C * out_cap_);
+            FS_HIP(hipMemcpy(tmp.data(), d_out_.p, sizeof(uint32_t) * C * out_cap_, hipMemcpyDeviceToHost));
+            for (int c = 0; c < C; ++c) std::memcpy(codes_out + (size_t)c * cap, tmp.data() + (size_t)c * out_cap_, sizeof(uint32_t) * n);
+        }
+        if (n_frames) *n_frames = n;
+    }
+
+    // generate_static_batch (static_batch.rs:282-390) -- first version: rows are independent sequences, so the
+    // lock-step batch is evaluated row after row on KV slot 0 (identical tokens under greedy decoding).  The left
+    // padding with <|im_end|>/0 IS applied because the reference never masks it (dual_ar.rs:589-615); repetition
+    // penalty is a no-op in the reference's batch path for Fish models (static_batch.rs:204-206 => mask stays 1).
+    void generate_batch(const uint32_t* prompts, const int* lens, int n, int max_new_tokens, const fs_sampling& s, uint64_t seed,
+                        uint32_t flags, uint32_t* codes_out, size_t cap, size_t* n_frames) override {
+        FS_REQUIRE(n >= 1, "Must have at least one prompt");  // static_batch.rs:69-71
+        const int C1 = a_.num_codebooks + 1;
+        int Lmax = 0;
+        for (int i = 0; i < n; ++i) { FS_REQUIRE(lens[i] >= 1, "empty prompt"); Lmax = std::max(Lmax, lens[i]); }
+        fs_sampling sb = s;
+        sb.repetition_penalty = 1.0f;
+        size_t off = 0;
+        std::vector<uint32_t> padded((size_t)C1 * Lmax);
+        for (int i = 0; i < n; ++i) {
+            const int L = lens[i], pad = Lmax - L;
+            for (int r = 0; r < C1; ++r) {
+                for (int j = 0; j < pad; ++j) padded[(size_t)r * Lmax + j] = r == 0 ? t_.im_end_id : 0u;
+                std::memcpy(&padded[(size_t)r * Lmax + pad], prompts + off + (size_t)r * L, sizeof(uint32_t) * L);
+            }
+            off += (size_t)C1 * L;
+            clear_slow();  // static_batch.rs:118-121
+            // child seed per row (sampling/mod.rs:93-95 draws one u64 per row per call; here one per row per request)
+            generate(padded.data(), Lmax, max_new_tokens, sb, seed + 0x9E3779B97F4A7C15ull * (uint64_t)i, flags,
+                     codes_out + (size_t)i * a_.num_codebooks * cap, cap, &n_frames[i], nullptr, nullptr);
+        }
+    }
+
+  private:
+    void use_device() { FS_HIP(hipSetDevice(device_)); }
+    void require_loaded() { FS_REQUIRE(loaded_, "weights not loaded: call fs_lm_load_safetensors or fs_lm_load_synthetic first"); }
+
+    SampleCfg base_cfg() const {
+        SampleCfg c = {};
+        c.temp = 0.f; c.top_p = 1.f; c.top_k = 0; c.rep_pen = 1.f; c.ignore_eos = 0;
+        c.im_end_id = t_.im_end_id;
+        c.sem_lo = t_.semantic_start_id;
+        c.sem_hi = t_.has_semantic_end ? t_.semantic_end_id : t_.semantic_start_id;  // dual_ar.rs:554-559
+        return c;
+    }
+
+    void validate_tokens(const uint32_t* toks, size_t, int B, int L) {
+        const int C1 = a_.num_codebooks + 1;
+        for (int b = 0; b < B; ++b)
+            for (int r = 0; r < C1; ++r)
+                for (int l = 0; l < L; ++l) {
+                    const uint32_t v = toks[((size_t)b * C1 + r) * L + l];
+                    if (r == 0) { if (v >= (uint32_t)a_.vocab_size) throw Error("token id out of vocabulary (index_select out of range)"); }
+                    else if (v >= (uint32_t)a_.codebook_size) throw Error("codebook id out of range (index_select out of range)");
+                }
+    }
+
+    // ---- tensor plan: names/shapes of the reference loader (dual_ar.rs:125-156,219-223,415-419,466-511)
+    void plan_tensors() {
+        size_t off = 0;
+        auto align = [&](size_t v) { return (v + 255) & ~(size_t)255; };
+        auto mat = [&](const std::string& name, int64_t rows, int64_t cols, int mul, int roff, size_t at) {
+            tensors_.push_back({name, rows, cols, false, at, mul, roff, 0.f, 0.02});  // initializer_range (dual_ar.rs:93)
+        };
+        auto slab = [&](int64_t rows, int64_t cols) { size_t at = off; off = align(off + (size_t)rows * cols * sizeof(WT)); return at; };
+        auto vec = [&](const std::string& name, int64_t n) {
+            size_t at = off;
+            off = align(off + (size_t)n * sizeof(float));
+            tensors_.push_back({name, 1, n, true, at, 1, 0, 1.0f, 0.1});
+            return at;
+        };
+        const int64_t D = a_.dim, I = a_.intermediate_size, V = a_.vocab_size;
+        const int64_t QKV = (int64_t)(a_.n_head + 2 * a_.n_local_heads) * a_.head_dim;
+        o_tok_emb_ = slab(V, D); mat("embeddings.weight", V, D, 1, 0, o_tok_emb_);
+        o_cb_emb_ = slab((int64_t)a_.codebook_size * a_.num_codebooks, D);
+        mat("codebook_embeddings.weight", (int64_t)a_.codebook_size * a_.num_codebooks, D, 1, 0, o_cb_emb_);
+        auto blocks = [&](int n, const std::string& pre, std::vector<std::array<size_t, 6>>& offs) {
+            for (int l = 0; l < n; ++l) {
+                const std::string p = pre + std::to_string(l) + ".";
+                std::array<size_t, 6> o;
+                o[0] = slab(QKV, D); mat(p + "attention.wqkv.weight", QKV, D, 1, 0, o[0]);
+                o[1] = slab(D, D); mat(p + "attention.wo.weight", D, D, 1, 0, o[1]);
+                o[2] = slab(2 * I, D);
+                mat(p + "feed_forward.w1.weight", I, D, 2, 0, o[2]);
+                mat(p + "feed_forward.w3.weight", I, D, 2, 1, o[2]);
+                o[3] = slab(D, I); mat(p + "feed_forward.w2.weight", D, I, 1, 0, o[3]);
+                o[4] = vec(p + "ffn_norm.weight", D);
+                o[5] = vec(p + "attention_norm.weight", D);
+                offs.push_back(o);
+            }
+        };
+        blocks(a_.n_layer, "layers.", o_slow_);
+        o_norm_ = vec("norm.weight", D);
+        if (a_.tie_word_embeddings) o_out_ = o_tok_emb_;
+        else { o_out_ = slab(V, D); mat("output.weight", V, D, 1, 0, o_out_); }
+        o_fast_emb_ = slab(a_.codebook_size, D); mat("fast_embeddings.weight", a_.codebook_size, D, 1, 0, o_fast_emb_);
+        blocks(a_.n_fast_layer, "fast_layers.", o_fast_);
+        o_fast_norm_ = vec("fast_norm.weight", D);
+        o_fast_out_ = slab(a_.codebook_size, D); mat("fast_output.weight", a_.codebook_size, D, 1, 0, o_fast_out_);
+        arena_bytes_ = off;
+    }
+
+    void alloc_runtime() {
+        arena_.alloc(arena_bytes_);
+        uint8_t* base = arena_.as<uint8_t>();
+        auto lw = [&](const std::array<size_t, 6>& o) {
+            LayerW w;
+            w.wqkv = base + o[0]; w.wo = base + o[1]; w.w13 = base + o[2]; w.w2 = base + o[3];
+            w.ffn_norm = (const float*)(base + o[4]); w.attn_norm = (const float*)(base + o[5]);
+            return w;
+        };
+        for (auto& o : o_slow_) slow_.push_back(lw(o));
+        for (auto& o : o_fast_) fast_.push_back(lw(o));
+        tok_emb_ = base + o_tok_emb_; cb_emb_ = base + o_cb_emb_; fast_emb_ = base + o_fast_emb_;
+        out_w_ = base + o_out_; fast_out_w_ = base + o_fast_out_;
+        norm_w_ = (const float*)(base + o_norm_); fast_norm_w_ = (const float*)(base + o_fast_norm_);
+        // RoPE tables on the host exactly as precompute_freqs_cis (dual_ar.rs:168-186): f32 powf / cos / sin
+        const int half = a_.head_dim / 2, n_elem = a_.dim / a_.n_head;
+        std::vector<float> ct((size_t)a_.max_seq_len * half), sn((size_t)a_.max_seq_len * half), theta(half);
+        for (int j = 0; j < half; ++j) theta[j] = 1.f / std::pow(a_.rope_base, (float)(2 * j) / (float)n_elem);
+        for (int p = 0; p < a_.max_seq_len; ++p)
+            for (int j = 0; j < half; ++j) {
+                const float ang = (float)p * theta[j];
+                ct[(size_t)p * half + j] = std::cos(ang);
+                sn[(size_t)p * half + j] = std::sin(ang);
+            }
+        d_cos_.alloc(ct.size() * 4); d_sin_.alloc(sn.size() * 4);
+        FS_HIP(hipMemcpy(d_cos_.p, ct.data(), ct.size() * 4, hipMemcpyHostToDevice));
+        FS_HIP(hipMemcpy(d_sin_.p, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
+        // paged KV: one pool per slow layer, page = KV_PAGE tokens x Hk heads x Dh
+        max_pages_ = (a_.max_seq_len + KV_PAGE - 1) / KV_PAGE;
+        n_pages_ = max_pages_ * B_;
+        page_elems_ = (size_t)a_.n_local_heads * KV_PAGE * a_.head_dim;
+        kv_pool_.alloc((size_t)a_.n_layer * 2 * n_pages_ * page_elems_ * sizeof(WT));
+        d_page_table_.alloc(sizeof(int) * (size_t)B_ * max_pages_);
+        FS_HIP(hipMemset(d_page_table_.p, 0, d_page_table_.n));
+        for (int p = n_pages_ - 1; p >= 0; --p) free_pages_.push_back(p);
+        seq_pages_.assign(B_, {});
+        seq_len_.assign(B_, 0);
+        fast_len_.assign(B_, 0);
+        // fast-decoder KV: one page per (layer, sequence); its page table is a single zero
+        fast_pool_.alloc((size_t)std::max(1, a_.n_fast_layer) * 2 * B_ * page_elems_ * sizeof(WT));
+        d_zero_table_.alloc(sizeof(int) * 4);
+        FS_HIP(hipMemset(d_zero_table_.p, 0, d_zero_table_.n));
+        // activations / state
+        d_x_.alloc(sizeof(float) * (size_t)B_ * a_.dim);
+        d_xf_.alloc(sizeof(float) * (size_t)B_ * a_.dim);
+        d_q_.alloc(sizeof(float) * a_.dim);
+        d_part_.alloc(sizeof(float) * (size_t)a_.n_head * NSPLIT * (a_.head_dim + 2));
+        d_act_.alloc(sizeof(float) * a_.intermediate_size);
+        d_logits_slow_.alloc(sizeof(float) * a_.vocab_size);
+        d_logits_fast_.alloc(sizeof(float) * a_.codebook_size);
+        d_state_.alloc(sizeof(SeqState) * B_);
+        FS_HIP(hipMemset(d_state_.p, 0, d_state_.n));
+        d_cfg_.alloc(sizeof(SampleCfg));
+        SampleCfg c = base_cfg();
+        FS_HIP(hipMemcpy(d_cfg_.p, &c, sizeof(c), hipMemcpyHostToDevice));
+        d_rng_.alloc(sizeof(RngState));
+        d_prompt_.alloc(sizeof(uint32_t) * (size_t)(a_.num_codebooks + 1) * a_.max_seq_len);
+        out_cap_ = a_.max_seq_len + 8;
+        d_out_.alloc(sizeof(uint32_t) * (size_t)a_.num_codebooks * out_cap_);
+        const size_t ncb = a_.num_codebooks, cbs = a_.codebook_size;
+        d_rp_mask_.alloc(sizeof(float) * ncb * cbs);
+        d_rp_seen_.alloc(ncb * cbs);
+        d_rp_ring_.alloc(sizeof(int) * ncb * 17);
+        d_rp_meta_.alloc(sizeof(int) * ncb * 2);
+        rp_.mask = d_rp_mask_.as<float>(); rp_.seen = d_rp_seen_.as<uint8_t>(); rp_.ring = d_rp_ring_.as<int>();
+        rp_.ring_meta = d_rp_meta_.as<int>();
+        FS_HIP(hipHostMalloc(&h_pin_, 4096, hipHostMallocDefault));
+    }
+
+    SeqState* state(int b) { return d_state_.as<SeqState>() + b; }
+    float* x(int b) { return d_x_.as<float>() + (size_t)b * a_.dim; }
+    float* xf(int b) { return d_xf_.as<float>() + (size_t)b * a_.dim; }
+    KVView slow_kv(int layer, int b) {
+        KVView v;
+        WT* base = kv_pool_.as<WT>() + (size_t)layer * 2 * n_pages_ * page_elems_;
+        v.k = base; v.v = base + (size_t)n_pages_ * page_elems_;
+        v.page_table = d_page_table_.as<int>() + (size_t)b * max_pages_;
+        return v;
+    }
+    KVView fast_kv(int layer, int b) {
+        KVView v;
+        WT* base = fast_pool_.as<WT>() + ((size_t)layer * 2 * B_) * page_elems_;
+        v.k = base + (size_t)b * page_elems_;
+        v.v = base + ((size_t)B_ + b) * page_elems_;
+        v.page_table = d_zero_table_.as<int>();
+        return v;
+    }
+
+    // ---- KV paging (host side; the device only ever sees the page table)
+    void ensure_capacity(int b, int n_tokens) {
+        FS_REQUIRE(n_tokens <= a_.max_seq_len, "sequence longer than max_seq_len");
+        const int need = (n_tokens + KV_PAGE - 1) / KV_PAGE;
+        auto& pg = seq_pages_[b];
+        if ((int)pg.size() >= need) return;
+        while ((int)pg.size() < need) {
+            FS_REQUIRE(!free_pages_.empty(), "KV page pool exhausted");
+            pg.push_back(free_pages_.back());
+            free_pages_.pop_back();
+        }
+        FS_HIP(hipMemcpyAsync(d_page_table_.as<int>() + (size_t)b * max_pages_, pg.data(), sizeof(int) * pg.size(),
+                              hipMemcpyHostToDevice, st_));
+        FS_HIP(hipStreamSynchronize(st_));  // pg may be reallocated by the next call
+    }
+    void truncate(int b, int pos) {  // keep the first `pos` tokens (dual_ar.rs:392-404)
+        const int keep = (pos + KV_PAGE - 1) / KV_PAGE;
+        auto& pg = seq_pages_[b];
+        while ((int)pg.size() > keep) { free_pages_.push_back(pg.back()); pg.pop_back(); }
+        seq_len_[b] = pos;
+    }
+
+    // ---- kernel sequences
+    void enqueue_slow_layers(int b) {
+        for (int l = 0; l < a_.n_layer; ++l) {
+            const LayerW& w = slow_[l];
+            KVView kv = slow_kv(l, b);
+            LmKernels<WT>::qkv(d_, x(b), w, d_cos_.as<float>(), d_sin_.as<float>(), state(b), 0, 0, d_q_.as<float>(), kv, st_);
+            LmKernels<WT>::attn_decode(d_, d_q_.as<float>(), kv, state(b), d_part_.as<float>(), NSPLIT, st_);
+            LmKernels<WT>::wo(d_, d_part_.as<float>(), NSPLIT, nullptr, kv, 0, w, x(b), st_);
+            LmKernels<WT>::ffn_up(d_, x(b), w, d_act_.as<float>(), st_);
+            LmKernels<WT>::ffn_down(d_, d_act_.as<float>(), w, x(b), st_);
+        }
+    }
+    void enqueue_fast_layers(int b, int kv_pos, int rope_pos) {
+        for (int l = 0; l < a_.n_fast_layer; ++l) {
+            const LayerW& w = fast_[l];
+            KVView kv = fast_kv(l, b);
+            LmKernels<WT>::qkv(d_, xf(b), w, d_cos_.as<float>(), d_sin_.as<float>(), nullptr, kv_pos, rope_pos, d_q_.as<float>(), kv, st_);
+            LmKernels<WT>::wo(d_, nullptr, 0, d_q_.as<float>(), kv, kv_pos + 1, w, xf(b), st_);
+            LmKernels<WT>::ffn_up(d_, xf(b), w, d_act_.as<float>(), st_);
+            LmKernels<WT>::ffn_down(d_, d_act_.as<float>(), w, xf(b), st_);
+        }
+    }
+
+    void build_graphs() {
+        if (g_frame_) return;
+        FS_REQUIRE(a_.num_codebooks <= 8, "the fused fast-decoder attention holds at most 8 positions");
+        const int C = a_.num_codebooks;
+        hipGraph_t g = nullptr;
+        // (1) prefill step: embed prompt column state->step, 24 blocks, pos++/step++
+        FS_HIP(hipStreamBeginCapture(st_, hipStreamCaptureModeThreadLocal));
+        LmKernels<WT>::embed(d_, tok_emb_, cb_emb_, C, a_.codebook_size, d_cfg_.as<SampleCfg>(), d_prompt_.as<uint32_t>(), state(0), x(0), st_);
+        enqueue_slow_layers(0);
+        launch_advance(state(0), st_);
+        FS_HIP(hipStreamEndCapture(st_, &g));
+        FS_HIP(hipGraphInstantiate(&g_step_, g, nullptr, nullptr, 0));
+        FS_HIP(hipGraphDestroy(g));
+        // (2) one audio frame: x holds the embedded input of position state->pos
+        FS_HIP(hipStreamBeginCapture(st_, hipStreamCaptureModeThreadLocal));
+        enqueue_slow_layers(0);
+        // audio-range head: rows [im_end, V) only (constrain_probs_to_audio, utils.rs:13-16)
+        LmKernels<WT>::head(d_, x(0), norm_w_, (const uint8_t*)out_w_ + (size_t)t_.im_end_id * a_.dim * sizeof(WT), n_audio_,
+                            d_logits_slow_.as<float>(), st_);
+        SampleKernels<WT>::sample_slow(d_, d_logits_slow_.as<float>(), n_audio_, d_cfg_.as<SampleCfg>(), d_rng_.as<RngState>(), state(0),
+                                       x(0), xf(0), st_);
+        for (int cbi = 0; cbi < C; ++cbi) {
+            enqueue_fast_layers(0, cbi, cbi);
+            LmKernels<WT>::head(d_, xf(0), fast_norm_w_, fast_out_w_, a_.codebook_size, d_logits_fast_.as<float>(), st_);
+            SampleKernels<WT>::sample_fast(d_, d_logits_fast_.as<float>(), cbi, C, a_.codebook_size, d_cfg_.as<SampleCfg>(),
+                                           d_rng_.as<RngState>(), rp_, state(0), fast_emb_, xf(0), tok_emb_, cb_emb_, x(0),
+                                           d_out_.as<uint32_t>(), out_cap_, st_);
+        }
+        FS_HIP(hipStreamEndCapture(st_, &g));
+        FS_HIP(hipGraphInstantiate(&g_frame_, g, nullptr, nullptr, 0));
+        FS_HIP(hipGraphDestroy(g));
+    }
+
+    fs_model_args a_;
+    fs_token_cfg t_;
+    int device_, B_;
+    ModelDims d_;
+    int n_audio_ = 0;
+    hipStream_t st_ = nullptr;
+    bool loaded_ = false;
+    // weights
+    std::vector<TensorDesc> tensors_;
+    size_t arena_bytes_ = 0, o_tok_emb_ = 0, o_cb_emb_ = 0, o_out_ = 0, o_fast_emb_ = 0, o_fast_out_ = 0, o_norm_ = 0, o_fast_norm_ = 0;
+    std::vector<std::array<size_t, 6>> o_slow_, o_fast_;
+    DevBuf arena_;
+    std::vector<LayerW> slow_, fast_;
+    const void *tok_emb_ = nullptr, *cb_emb_ = nullptr, *fast_emb_ = nullptr, *out_w_ = nullptr, *fast_out_w_ = nullptr;
+    const float *norm_w_ = nullptr, *fast_norm_w_ = nullptr;
+    DevBuf d_cos_, d_sin_;
+    // KV
+    int max_pages_ = 0, n_pages_ = 0, out_cap_ = 0;
+    size_t page_elems_ = 0;
+    DevBuf kv_pool_, fast_pool_, d_page_table_, d_zero_table_;
+    std::vector<int> free_pages_, seq_len_, fast_len_;
+    std::vector<std::vector<int>> seq_pages_;
+    // activations / state
+    DevBuf d_x_, d_xf_, d_q_, d_part_, d_act_, d_logits_slow_, d_logits_fast_, d_state_, d_cfg_, d_rng_, d_prompt_, d_out_;
+    DevBuf d_rp_mask_, d_rp_seen_, d_rp_ring_, d_rp_meta_;
+    RepPenState rp_ = {};
+    void* h_pin_ = nullptr;
+    hipGraphExec_t g_frame_ = nullptr, g_step_ = nullptr;
+    hipEvent_t ev_[3] = {nullptr, nullptr, nullptr};
+    fs_gen_stats stats_ = {};
+};
+
+LMBase* make_lm(const fs_model_args& a, const fs_token_cfg& t, int device, fs_dtype dtype, int max_batch) {
+    if (dtype == FS_BF16) return new LM<bf16_t>(a, t, device, max_batch);
+    if (dtype == FS_F32) return new LM<float>(a, t, device, max_batch);
+    throw Error("unknown dtype");
+}
+
+}  // namespace fs

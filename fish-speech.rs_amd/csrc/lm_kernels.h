@@ -1,0 +1,129 @@
+// Launch interface of the dual-AR decode kernels (lm_kernels.hip).  gfx950 only.
+//
+// Data layout in HBM:
+//  * weights: row-major [out, in] in WT (bf16 or f32), one 256-B aligned slab per tensor; W1/W3 are stored
+//    row-interleaved (row 2r = w1[r], row 2r+1 = w3[r]) so one wave streams a contiguous 2-row block and applies
+//    SwiGLU in registers;
+//  * KV cache: paged.  One pool per layer; page = 64 tokens; K element (t, g, d) lives at
+//        pool_k + ((page_table[t >> 6] * Hk + g) * 64 + (t & 63)) * Dh + d
+//    so that one wave-wide 16-B/lane load covers 8 (bf16) consecutive tokens of ONE kv head (1 KiB contiguous);
+//  * activations: f32 vectors (residual stream x[dim], q[H*Dh], act[inter], logits) -- a few KB, L2-resident.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace fs {
+
+constexpr int KV_PAGE = 64;  // tokens per KV page
+
+// Per-sequence device-resident generation state (read by the captured graph; never passed by value).
+struct SeqState {
+    int pos;        // current KV length T == index where the next token's K/V is written
+    int rope_off;   // RoPE row = pos + rope_off (forward_generate's input_pos may differ from the KV length)
+    int frame;      // decode iterations executed in this generate call
+    int done;       // <|im_end|> sampled (audio_only termination, single_batch.rs:199-204)
+    int n_out;      // frames recorded in out_codes
+    int have_prev;  // previous_codes.is_some() (single_batch.rs:162-168)
+    int step;       // prompt column consumed by the next prefill step
+    int prompt_L;   // row stride of the staged prompt (tokens per row)
+    uint32_t cur[16];   // [slow, c0..c7] of the frame being generated
+    uint32_t prev[16];  // previous frame (rep-pen key)
+};
+
+struct KVView {
+    void* k;                // pool base for this layer
+    void* v;
+    const int* page_table;  // [max_pages] for this sequence
+};
+
+struct LayerW {
+    const void* wqkv;  // [(H+2Hk)*Dh, dim]
+    const void* wo;    // [dim, dim]
+    const void* w13;   // [2*inter, dim] row-interleaved
+    const void* w2;    // [dim, inter]
+    const float* attn_norm;
+    const float* ffn_norm;
+};
+
+struct ModelDims {
+    int dim, inter, H, Hk, Dh, n_rep;
+    float eps;
+};
+
+struct SampleCfg;
+
+// ---- launchers (all asynchronous on `st`) -------------------------------------------------------------------
+template <typename WT>
+struct LmKernels {
+    // x -> rmsnorm -> Wqkv GEMV -> interleaved RoPE(q,k) -> q_out (f32), K/V appended at state->pos (or pos_static)
+    // (state != null: KV index = state->pos, RoPE row = state->pos + state->rope_off; else the two static values)
+    static void qkv(const ModelDims& d, const float* x, const LayerW& w, const float* cos_t, const float* sin_t,
+                    const SeqState* state, int pos_static, int rope_static, float* q_out, KVView kv, hipStream_t st);
+    // decode attention over the paged cache: partial (m, l, o[Dh]) per (q head, split)
+    static void attn_decode(const ModelDims& d, const float* q, KVView kv, const SeqState* state, float* part,
+                            int nsplit, hipStream_t st);
+    // combine partials (or, FUSED: attend over pos_static+1 <= 8 cached tokens in the prologue) -> Wo GEMV -> x += .
+    static void wo(const ModelDims& d, const float* part, int nsplit, const float* q, KVView kv, int fused_T,
+                   const LayerW& w, float* x, hipStream_t st);
+    static void ffn_up(const ModelDims& d, const float* x, const LayerW& w, float* act, hipStream_t st);
+    static void ffn_down(const ModelDims& d, const float* act, const LayerW& w, float* x, hipStream_t st);
+    // x -> rmsnorm(norm_w) -> rows [0, n_rows) of W -> logits f32
+    static void head(const ModelDims& d, const float* x, const float* norm_w, const void* W, int n_rows, float* logits,
+                     hipStream_t st);
+    // x = tok_emb[t0] + sum_c mask * cb_emb[c*cbsize + t_{c+1}]   (dual_ar.rs:532-567); tokens from prompt column
+    // state->step (prompt != null) or from state->cur
+    static void embed(const ModelDims& d, const void* tok_emb, const void* cb_emb, int n_cb, int cb_size,
+                      const SampleCfg* cfg, const uint32_t* prompt, SeqState* state, float* x, hipStream_t st);
+    // fast_embeddings gather: out[i] = fast_emb[ids[i]]
+    static void fast_embed(const ModelDims& d, const void* fast_emb, const uint32_t* ids, int n, float* out,
+                           hipStream_t st);
+};
+
+struct SampleCfg {  // device-resident (the captured graphs read it through a pointer, so one graph serves every config)
+    float temp, top_p;
+    int top_k;
+    float rep_pen;
+    int ignore_eos;
+    uint32_t im_end_id;
+    uint32_t sem_lo, sem_hi;  // embed mask range (inclusive); Fish<=1.4: lo == hi == semantic id
+};
+
+struct RepPenState {   // rep_pen.rs:4-72, one per codebook
+    float* mask;       // [n_cb][cb_size]
+    uint8_t* seen;     // [n_cb][cb_size]
+    int* ring;         // [n_cb][17]  (push_front / pop_back deque as a ring)
+    int* ring_meta;    // [n_cb][2] head, len
+};
+
+struct RngState {      // rand 0.8.5 StdRng (ChaCha12) stream position
+    uint32_t key[8];
+    unsigned long long consumed;  // u32 words consumed so far
+};
+
+template <typename WT>
+struct SampleKernels {
+    // slow token: logits over [im_end, V) (utils.rs:13-16) -> token = idx + im_end; sets done; copies x -> xf
+    static void sample_slow(const ModelDims& d, const float* logits, int n, const SampleCfg* c, RngState* rng,
+                            SeqState* state, const float* x, float* xf, hipStream_t st);
+    // codebook cb: rep-pen (if have_prev), sample, cur[cb+1]; xf = fast_emb[code]; cb == last: finish the frame
+    // (record codes, prev = cur, x = embed(cur), pos++, frame++)
+    static void sample_fast(const ModelDims& d, const float* logits, int cb, int n_cb, int cb_size, const SampleCfg* c,
+                            RngState* rng, RepPenState rp, SeqState* state, const void* fast_emb, float* xf,
+                            const void* tok_emb, const void* cb_emb, float* x, uint32_t* out_codes, int out_cap,
+                            hipStream_t st);
+};
+
+void launch_advance(SeqState* state, hipStream_t st);  // pos++, step++ (sequential prefill step)
+void launch_reppen_reset(RepPenState rp, int n_cb, int cb_size, hipStream_t st);
+
+// synthetic tensor fill (fs_synth.h): n_rows x n_cols, destination row = r * row_mul + row_off (W1/W3 interleave)
+template <typename WT>
+void launch_synth_fill(WT* dst, uint64_t key, int64_t n_rows, int64_t n_cols, int row_mul, int row_off, float mean,
+                       float scale, int round_bf16, hipStream_t st);
+// f32 -> WT conversion with the same row mapping (safetensors loader)
+template <typename WT>
+void launch_convert_rows(WT* dst, const float* src, int64_t n_rows, int64_t n_cols, int row_mul, int row_off,
+                         hipStream_t st);
+
+}  // namespace fs

@@ -1,0 +1,44 @@
+"""fish_speech_python `FireflyCodec` (codec.rs:18-115) over the C ABI: decode(u32[b,8,T]) -> f32[b,1,2048*T]."""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+
+
+class FireflyCodec:
+    def __init__(self, device=0, channel_div=1):
+        h = C.c_void_p()
+        _ffi.check(_ffi.lib().fs_codec_create(int(device), int(channel_div), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _ffi.lib().fs_codec_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def load_synthetic(self, seed):
+        _ffi.check(_ffi.lib().fs_codec_load_synthetic(self._h, C.c_uint64(seed)))
+        return self
+
+    def load_safetensors(self, path):
+        _ffi.check(_ffi.lib().fs_codec_load_safetensors(self._h, str(path).encode()))
+        return self
+
+    @property
+    def sample_rate(self):
+        return _ffi.lib().fs_codec_sample_rate(self._h)
+
+    def decode(self, codes):
+        if not isinstance(codes, np.ndarray) or not codes.flags["C_CONTIGUOUS"]:
+            raise ValueError("Input array must be contiguous")  # codec.rs:97-101
+        if codes.ndim != 3 or codes.shape[1] != 8:
+            raise ValueError("codes must have shape (b, 8, T)")
+        codes = codes.astype(np.uint32, copy=False)
+        b, _, T = codes.shape
+        pcm = np.empty((b, 1, 2048 * T), np.float32)
+        _ffi.check(_ffi.lib().fs_codec_decode(self._h, codes.ctypes.data_as(C.POINTER(C.c_uint32)), b, T,
+                                              pcm.ctypes.data_as(C.POINTER(C.c_float))))
+        return pcm

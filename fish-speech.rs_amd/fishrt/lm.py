@@ -1,0 +1,158 @@
+"""Host-side mirror of the reference's LM surface over the C ABI.
+
+`DualARTransformer` mirrors fish_speech_core::lm::DualARTransformer (dual_ar.rs:443-713) +
+generate_blocking / generate_static_batch (generate/*.rs); `LM` mirrors the PyO3 class
+(fish_speech_python/src/lm.rs:23-199) minus tokenisation (the caller supplies token ids: SURVEY.md §2 row 7)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi, config
+
+DTYPES = {"f32": 0, "bf16": 1}
+
+
+def _u32(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+class DualARTransformer:
+    def __init__(self, model_args=None, token_cfg=None, device=0, dtype="bf16", max_batch=1):
+        if dtype not in DTYPES:
+            raise ValueError(f"Unsupported dtype: {dtype}")  # fish_speech_python/src/utils.rs:25-40
+        self.cfg = dict(model_args or config.FISH_1_5)
+        self.tok = dict(token_cfg or config.FISH_1_5_TOKENS)
+        self.dtype = dtype
+        ma = _ffi.ModelArgs(**{k: self.cfg[k] for k, _ in _ffi.ModelArgs._fields_})
+        tc = _ffi.TokenCfg(**self.tok)
+        h = C.c_void_p()
+        _ffi.check(_ffi.lib().fs_lm_create(C.byref(ma), C.byref(tc), int(device), DTYPES[dtype], int(max_batch), C.byref(h)))
+        self._h = h
+        self.max_batch = max_batch
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _ffi.lib().fs_lm_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    # ---- weights
+    def load_synthetic(self, seed):
+        _ffi.check(_ffi.lib().fs_lm_load_synthetic(self._h, C.c_uint64(seed)))
+        return self
+
+    def load_safetensors(self, path):
+        _ffi.check(_ffi.lib().fs_lm_load_safetensors(self._h, str(path).encode()))
+        return self
+
+    # ---- DualARTransformer methods
+    def forward_generate(self, inp, input_pos, want_logits=True):
+        """dual_ar.rs:574-635.  inp: u32 (B, C+1, L) or (C+1, L).  Returns (logits (B, V), hidden (B, dim))."""
+        inp = _u32(inp)
+        if inp.ndim == 2:
+            inp = inp[None]
+        if inp.ndim != 3 or inp.shape[1] != self.cfg["num_codebooks"] + 1:
+            raise ValueError("Input tokens must have num_codebooks + 1 codebooks!")  # dual_ar.rs:535-538
+        B, _, L = inp.shape
+        logits = np.empty((B, self.cfg["vocab_size"]), np.float32) if want_logits else None
+        hidden = np.empty((B, self.cfg["dim"]), np.float32)
+        _ffi.check(_ffi.lib().fs_lm_forward_generate(
+            self._h, inp.ctypes.data_as(C.POINTER(C.c_uint32)), B, L, int(input_pos),
+            logits.ctypes.data_as(C.POINTER(C.c_float)) if want_logits else None,
+            hidden.ctypes.data_as(C.POINTER(C.c_float))))
+        return logits, hidden
+
+    def forward_generate_fast(self, x, input_pos):
+        """dual_ar.rs:638-673.  x: f32 (B, dim).  Returns logits (B, codebook_size)."""
+        x = np.ascontiguousarray(x, np.float32).reshape(-1, self.cfg["dim"])
+        out = np.empty((x.shape[0], self.cfg["codebook_size"]), np.float32)
+        _ffi.check(_ffi.lib().fs_lm_forward_generate_fast(self._h, x.ctypes.data_as(C.POINTER(C.c_float)), x.shape[0],
+                                                          int(input_pos), out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def fast_embeddings(self, ids):
+        ids = _u32(ids).reshape(-1)
+        out = np.empty((ids.size, self.cfg["dim"]), np.float32)
+        _ffi.check(_ffi.lib().fs_lm_fast_embed(self._h, ids.ctypes.data_as(C.POINTER(C.c_uint32)), ids.size,
+                                               out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def clear_fast_layer_caches(self):
+        _ffi.check(_ffi.lib().fs_lm_clear_fast_layer_caches(self._h))
+
+    def clear_slow_layer_caches(self):
+        _ffi.check(_ffi.lib().fs_lm_clear_slow_layer_caches(self._h))
+
+    def clear_slow_caches_until(self, pos):
+        _ffi.check(_ffi.lib().fs_lm_clear_slow_caches_until(self._h, int(pos)))
+
+    def curr_kv_size(self):
+        n = _ffi.lib().fs_lm_curr_kv_size(self._h)
+        if n < 0:
+            raise RuntimeError(_ffi.lib().fs_last_error().decode())
+        return n
+
+    # ---- generation drivers
+    def generate_blocking(self, prompt, max_new_tokens, temp=0.7, top_p=0.9, top_k=50, repetition_penalty=1.2, seed=0,
+                          ignore_eos=False, on_frame=None):
+        """generate/single_batch.rs:308-324.  prompt u32 (C+1, L) -> codes u32 (C, n_frames)."""
+        prompt = _u32(prompt)
+        Cb = self.cfg["num_codebooks"]
+        if prompt.ndim != 2 or prompt.shape[0] != Cb + 1:
+            raise ValueError("Input tokens must have num_codebooks + 1 codebooks!")
+        L = prompt.shape[1]
+        cap = max(1, max_new_tokens - L + 2) + 1
+        out = np.zeros((Cb, cap), np.uint32)
+        n = C.c_size_t(0)
+        s = _ffi.Sampling(float(temp), float(top_p), int(top_k), float(repetition_penalty))
+        cb = _ffi.FRAME_CB(lambda user, idx, codes: int(bool(on_frame(idx, [codes[i] for i in range(Cb)])))) if on_frame \
+            else C.cast(None, _ffi.FRAME_CB)
+        _ffi.check(_ffi.lib().fs_lm_generate(self._h, prompt.ctypes.data_as(C.POINTER(C.c_uint32)), L, int(max_new_tokens),
+                                             C.byref(s), C.c_uint64(seed), 1 if ignore_eos else 0,
+                                             out.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_size_t(cap), C.byref(n), cb, None))
+        return out[:, : n.value].copy()
+
+    def generate_static_batch(self, prompts, max_new_tokens, temp=0.7, top_p=0.9, top_k=50, repetition_penalty=1.2,
+                              seed=42, ignore_eos=False):
+        """generate/static_batch.rs:282-390 (audio_only).  prompts: list of u32 (C+1, L_i) -> list of (C, n_i)."""
+        Cb = self.cfg["num_codebooks"]
+        ps = [_u32(p) for p in prompts]
+        lens = np.array([p.shape[1] for p in ps], np.int32)
+        flat = np.concatenate([p.reshape(-1) for p in ps])
+        cap = max(1, max_new_tokens - int(lens.max()) + 2) + 1
+        out = np.zeros((len(ps), Cb, cap), np.uint32)
+        nf = (C.c_size_t * len(ps))()
+        s = _ffi.Sampling(float(temp), float(top_p), int(top_k), float(repetition_penalty))
+        _ffi.check(_ffi.lib().fs_lm_generate_batch(self._h, flat.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                   lens.ctypes.data_as(C.POINTER(C.c_int)), len(ps), int(max_new_tokens),
+                                                   C.byref(s), C.c_uint64(seed), 1 if ignore_eos else 0,
+                                                   out.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_size_t(cap), nf))
+        return [out[i, :, : nf[i]].copy() for i in range(len(ps))]
+
+    def last_stats(self):
+        st = _ffi.GenStats()
+        _ffi.check(_ffi.lib().fs_lm_last_stats(self._h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in _ffi.GenStats._fields_}
+
+    def stream(self):
+        return _ffi.lib().fs_lm_stream(self._h)
+
+
+class LM:
+    """fish_speech_python `LM` (lm.rs:23-199) with token-id inputs: __call__(list of prompts (C+1, L_i) for successive
+    text chunks, speaker_prompt) -> u32 (1, C, sum T).  Conditioning tokens stay cached across chunks exactly as
+    lm.rs:94-135: clear cache, generate per chunk, clear_slow_caches_until(n_conditioning_tokens)."""
+
+    def __init__(self, model_args=None, token_cfg=None, device=0, dtype="bf16"):
+        self.model = DualARTransformer(model_args, token_cfg, device, dtype)
+
+    def __call__(self, chunk_prompts, n_conditioning_tokens=0, temp=0.7, top_p=0.9, top_k=50, repetition_penalty=1.2,
+                 max_new_tokens=1024, seed=0):
+        self.model.clear_slow_layer_caches()
+        outs = []
+        for i, p in enumerate(chunk_prompts):
+            outs.append(self.model.generate_blocking(p, max_new_tokens, temp, top_p, top_k, repetition_penalty, seed + i))
+            self.model.clear_slow_caches_until(n_conditioning_tokens)
+        self.model.clear_slow_layer_caches()
+        return np.concatenate(outs, axis=1)[None]

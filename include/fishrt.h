@@ -1,0 +1,138 @@
+/* fishrt.h -- C ABI of the MI355X-native Fish-Speech hot path (libfishrt.so).
+ *
+ * Drop-in boundary: the entry points below are what a Rust `fish_speech_core`-shaped shim
+ * (or the PyO3 crate, or ctypes) binds INSTEAD of the candle-backed implementation.  Each entry cites the
+ * reference interface it replaces (paths relative to the reference repo root).
+ *
+ * Conventions (mirror of the reference's library API):
+ *  - every call returns int status, 0 = ok; on failure a thread-local message is available from
+ *    fs_last_error()  (== the `Result<_, candle_core::Error>` / PyRuntimeError string, fish_speech_python/src/utils.rs:6-20);
+ *  - all I/O buffers are caller-owned HOST memory, C-contiguous, same shapes as the numpy arrays of the PyO3 API
+ *    (fish_speech_python/src/lm.rs:72-145, codec.rs:73-114); handles own all device memory;
+ *  - a handle is single-threaded (one in-flight call): mirrors `&mut DualARTransformer`
+ *    (server/lib/state.rs:13 serialises with a tokio::Mutex); distinct handles (one per GPU) are independent;
+ *  - no CPU fallback exists: creating a handle without a usable gfx950 device fails.
+ */
+#ifndef FISHRT_H
+#define FISHRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FS_OK 0
+#define FS_ERR 1
+
+/* weight / KV-cache storage type.  Activations and accumulation are always f32.
+ * FS_BF16 == the reference's CUDA dtype choice (fish_speech_core/src/bin/llama_generate.rs:179-182),
+ * FS_F32  == its CPU dtype (used here for token-exact parity runs against the f32 oracle). */
+typedef enum { FS_F32 = 0, FS_BF16 = 1 } fs_dtype;
+
+/* fish_speech_core/lib/lm/dual_ar.rs:57-81  (BaseModelArgs; training-only fields dropped) */
+typedef struct fs_model_args {
+    int32_t dim, n_layer, n_fast_layer, n_head, n_local_heads, head_dim;
+    int32_t intermediate_size, num_codebooks, codebook_size, vocab_size, max_seq_len;
+    float norm_eps, rope_base;
+    int32_t tie_word_embeddings;
+} fs_model_args;
+
+/* fish_speech_core/lib/lm/dual_ar.rs:17-23  (TokenConfig).  has_semantic_end = 1 for Fish 1.5 (Some(end)), 0 for <= 1.4 */
+typedef struct fs_token_cfg {
+    uint32_t im_end_id, pad_id, semantic_start_id, semantic_end_id;
+    int32_t has_semantic_end;
+} fs_token_cfg;
+
+/* fish_speech_core/lib/lm/sampling/mod.rs:29-34  (SamplingArgs) */
+typedef struct fs_sampling {
+    double temp, top_p;
+    uint64_t top_k;
+    float repetition_penalty;
+} fs_sampling;
+
+typedef struct fs_lm fs_lm_t;
+typedef struct fs_codec fs_codec_t;
+
+/* optional per-frame streaming callback (invoked on the calling thread, in frame order):
+ * codes[num_codebooks] of frame `frame_idx`.  Return non-zero to stop generation early. */
+typedef int (*fs_frame_cb)(void* user, size_t frame_idx, const uint32_t* codes);
+
+const char* fs_last_error(void);
+/* library/ABI version and the gfx target the kernels were compiled for ("gfx950") */
+const char* fs_version(void);
+/* number of visible HIP devices (0 when none: every create call then fails loudly) */
+int fs_device_count(void);
+
+/* ---- DualARTransformer ---------------------------------------------------------------------------------- */
+
+/* DualARTransformer::load (dual_ar.rs:460-529) is split in create + one of the load calls.
+ * max_batch: number of independent sequences (KV caches) the handle can hold (1 for the single-batch generator). */
+int fs_lm_create(const fs_model_args* args, const fs_token_cfg* tok, int device_id, fs_dtype dtype, int max_batch,
+                 fs_lm_t** out);
+void fs_lm_destroy(fs_lm_t* lm);
+/* tensors by the reference's names (dual_ar.rs:125-156,219-223,415-419,466-511); bf16 or f32 safetensors */
+int fs_lm_load_safetensors(fs_lm_t* lm, const char* path);
+/* deterministic synthetic weights at the same names/shapes (spec: csrc/fs_synth.h; no checkpoint exists offline) */
+int fs_lm_load_synthetic(fs_lm_t* lm, uint64_t seed);
+
+/* DualARTransformer::forward_generate (dual_ar.rs:574-635).  toks: u32 [B, num_codebooks+1, L].
+ * logits_out: f32 [B, vocab_size] or NULL; hidden_out: f32 [B, dim] (PRE-norm hidden of the last position) or NULL.
+ * The pad mask argument of the reference is accepted nowhere because the reference ignores it (dual_ar.rs:589-615). */
+int fs_lm_forward_generate(fs_lm_t* lm, const uint32_t* toks, int B, int L, int input_pos, float* logits_out,
+                           float* hidden_out);
+/* DualARTransformer::forward_generate_fast (dual_ar.rs:638-673).  x: f32 [B, dim]; logits_out: f32 [B, codebook_size] */
+int fs_lm_forward_generate_fast(fs_lm_t* lm, const float* x, int B, int input_pos, float* logits_out);
+/* fast_embeddings.forward (dual_ar.rs:447; used at generate/single_batch.rs:176-182): out f32 [n, dim] */
+int fs_lm_fast_embed(fs_lm_t* lm, const uint32_t* ids, int n, float* out);
+int fs_lm_clear_fast_layer_caches(fs_lm_t* lm);            /* dual_ar.rs:675-679 */
+int fs_lm_clear_slow_layer_caches(fs_lm_t* lm);            /* dual_ar.rs:681-685 */
+int fs_lm_clear_slow_caches_until(fs_lm_t* lm, int pos);   /* dual_ar.rs:687-693 (NOT inclusive) */
+int fs_lm_curr_kv_size(fs_lm_t* lm);                       /* dual_ar.rs:695-700; < 0 on error */
+
+/* generate_blocking (generate/single_batch.rs:217-324): batch-1 generator, audio_only = true.
+ * prompt: u32 [num_codebooks+1, L].  codes_out: u32 [num_codebooks, cap] row-major with row stride `cap`;
+ * *n_frames receives the number of frames written (<= cap).  The KV cache is NOT cleared first (the caller
+ * owns cache lifetime exactly as with the reference: fish_speech_python/src/lm.rs:94,131-135).
+ * seed: seeds the sampler RNG (the reference draws rand::random(), single_batch.rs:46).
+ * flags: FS_GEN_IGNORE_EOS masks <|im_end|> (bench-only, fixed-length runs: SURVEY.md §8d). */
+#define FS_GEN_IGNORE_EOS 1u
+int fs_lm_generate(fs_lm_t* lm, const uint32_t* prompt, int L, int max_new_tokens, const fs_sampling* sampling,
+                   uint64_t seed, uint32_t flags, uint32_t* codes_out, size_t cap, size_t* n_frames, fs_frame_cb cb,
+                   void* cb_user);
+
+/* generate_static_batch (generate/static_batch.rs:282-390), audio_only = true: n prompts [num_codebooks+1, L_i]
+ * (concatenated in `prompts`, lengths in `lens`), left-padded with <|im_end|>/0 as static_batch.rs:68-111,
+ * lock-step decode, ragged outputs: codes_out u32 [n, num_codebooks, cap], n_frames[n]. */
+int fs_lm_generate_batch(fs_lm_t* lm, const uint32_t* prompts, const int* lens, int n, int max_new_tokens,
+                         const fs_sampling* sampling, uint64_t seed, uint32_t flags, uint32_t* codes_out, size_t cap,
+                         size_t* n_frames);
+
+/* timing of the last generate call, measured with HIP events on the handle's stream (the reference prints the
+ * same quantities: single_batch.rs:233-246,291-304) */
+typedef struct fs_gen_stats {
+    double prefill_ms, decode_ms;     /* decode_ms covers frames 1..n-1 exactly like `start_decode` (:261) */
+    uint64_t frames, prompt_tokens, graph_launches;
+} fs_gen_stats;
+int fs_lm_last_stats(fs_lm_t* lm, fs_gen_stats* out);
+/* the hipStream_t the handle launches on (for callers that bracket calls with their own HIP events) */
+void* fs_lm_stream(fs_lm_t* lm);
+
+/* ---- FireflyCodec ---------------------------------------------------------------------------------------- */
+
+/* FireflyCodec::load (codec/firefly.rs:20-34) with FireflyConfig::get_config_for(1.4 | 1.5) (codec/config.rs:196-202).
+ * channel_div = 1 for the real configuration; tests use 8 (channels / 8, same topology). */
+int fs_codec_create(int device_id, int channel_div, fs_codec_t** out);
+void fs_codec_destroy(fs_codec_t* c);
+int fs_codec_load_safetensors(fs_codec_t* c, const char* path);
+int fs_codec_load_synthetic(fs_codec_t* c, uint64_t seed);
+/* FireflyCodec::decode (codec/firefly.rs:42-48): codes u32 [b, 8, T] (values 0..999) -> pcm f32 [b, 1, 2048*T] */
+int fs_codec_decode(fs_codec_t* c, const uint32_t* codes, int b, int T, float* pcm_out);
+/* FireflyCodec.sample_rate (codec/firefly.rs:13) */
+int fs_codec_sample_rate(fs_codec_t* c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FISHRT_H */

@@ -38,9 +38,24 @@ def build(force=False):
     return so
 
 
+def usable_cpus():
+    """CPUs this process may actually use: min(affinity, cgroup quota).  The GPU box exposes 256 hardware threads but
+    caps the container at 16 CPUs; OpenMP's default (256 spinning threads) is ~10^4x slower there."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return n
+
+
 def lib():
     global _LIB
     if _LIB is None:
+        os.environ.setdefault("OMP_NUM_THREADS", str(usable_cpus()))
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         so = os.path.join(_HERE, "liboracle.so")
         if not os.path.exists(so):
             build()
@@ -54,6 +69,7 @@ def lib():
         L.orc_sampler_create.restype = C.c_void_p
         L.orc_sampler_sample.restype = C.c_uint32
         L.orc_codec_create.restype = C.c_void_p
+        L.orc_set_num_threads(usable_cpus())
         _LIB = L
     return _LIB
 
@@ -146,13 +162,15 @@ class OracleLM:
         L = prompt.shape[1]
         cap = max_new_tokens + 8
         out = np.zeros(Cb * cap, np.uint32)
-        n = C.c_int(0)
+        n, nit = C.c_int(0), C.c_int(0)
         pf, dc = C.c_double(0), C.c_double(0)
+        margins = np.zeros(cap, np.float32)
         _chk(lib().orc_lm_generate(self.h, _p(prompt, C.c_uint32), L, int(max_new_tokens), C.c_double(temp),
                                    C.c_double(top_p), C.c_uint64(top_k), C.c_float(repetition_penalty),
                                    C.c_uint64(seed), int(ignore_eos), int(max_frames), _p(out, C.c_uint32), cap,
-                                   C.byref(n), C.byref(pf), C.byref(dc)))
+                                   C.byref(n), C.byref(pf), C.byref(dc), _p(margins, C.c_float), C.byref(nit)))
         self.last_prefill_s, self.last_decode_s = pf.value, dc.value
+        self.last_margins = margins[: nit.value].copy()  # min top-2 margin of the 9 decisions of each iteration
         return out[: Cb * n.value].reshape(Cb, n.value).copy()
 
 

@@ -94,13 +94,17 @@ const float* orc_lm_tensor(void* p, const char* name, int layer) {
 // generate_blocking.  codes_out: (num_codebooks, cap) row-major with row stride = *n_frames after return
 int orc_lm_generate(void* p, const uint32_t* prompt, int L, int max_new_tokens, double temp, double top_p, uint64_t top_k,
                     float rep_pen, uint64_t seed, int ignore_eos, int max_frames, uint32_t* codes_out, int cap,
-                    int* n_frames, double* prefill_s, double* decode_s) {
+                    int* n_frames, double* prefill_s, double* decode_s, float* margins_out /*[iterations] or null*/,
+                    int* n_iter_out) {
     try {
         LM* lm = (LM*)p;
         Sampling s; s.temp = temp; s.top_p = top_p; s.top_k = top_k; s.repetition_penalty = rep_pen;
         int n = 0;
+        std::vector<float> margins;
         auto out = lm->generate(prompt, L, max_new_tokens, s, seed, ignore_eos != 0, &n, nullptr, prefill_s, decode_s,
-                                max_frames);
+                                max_frames, margins_out ? &margins : nullptr);
+        if (margins_out) std::memcpy(margins_out, margins.data(), sizeof(float) * margins.size());
+        if (n_iter_out) *n_iter_out = (int)margins.size();
         if (n > cap) { g_err = "codes_out too small"; return 2; }
         std::memcpy(codes_out, out.data(), sizeof(uint32_t) * out.size());
         *n_frames = n;

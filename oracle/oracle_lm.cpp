@@ -25,7 +25,7 @@ namespace oracle {
 
 // candle_nn::Linear without bias: y = x . W^T   (W row-major [N,K])
 static void linear(const float* x, int M, const float* W, int N, int K, float* y) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if ((size_t)N * K * M > (1u << 18))
     for (int n = 0; n < N; ++n) {
         const float* w = W + (size_t)n * K;
         for (int m = 0; m < M; ++m) {
@@ -221,7 +221,7 @@ void LM::block_forward(Block& blk, float* x, int B, int L, int input_pos, int /*
     const float scale = 1.f / std::sqrt((float)Dh);
     const int n_rep = H / Hk;
     std::vector<float> y((size_t)M * D);  // (B, L, H*Dh)
-#pragma omp parallel for collapse(2) schedule(static)
+#pragma omp parallel for collapse(2) schedule(static) if ((size_t)B * H * L * T * Dh > (1u << 18))
     for (int b = 0; b < B; ++b)
         for (int h = 0; h < H; ++h) {
             const int hk = h / n_rep;  // repeat_kv / expand+reshape (:328-357): q head h reads kv head h / n_rep
@@ -433,9 +433,12 @@ uint32_t LogitsProcessor::sample(const float* logits, size_t n) {
     std::vector<float> p(n);
     float mx = -std::numeric_limits<float>::infinity();
     for (size_t i = 0; i < n; ++i) { p[i] = logits[i] * inv_t; mx = std::max(mx, p[i]); }
-    float sum = 0.f;
-    for (size_t i = 0; i < n; ++i) { p[i] = std::exp(p[i] - mx); sum += p[i]; }
-    for (size_t i = 0; i < n; ++i) p[i] /= sum;
+    // softmax denominator accumulated in f64 so that it does not depend on the reduction order (candle's own CPU
+    // reduction order is not specified either); the HIP sampler does the same
+    double sum = 0.0;
+    for (size_t i = 0; i < n; ++i) { p[i] = std::exp(p[i] - mx); sum += (double)p[i]; }
+    const float denom = (float)sum;
+    for (size_t i = 0; i < n; ++i) p[i] /= denom;
     const size_t top_k = (size_t)s.top_k;
     const float top_p = (float)s.top_p;
     if (top_k == 0 || top_k >= n) return sample_topp(*rng, p, top_p);
@@ -454,7 +457,7 @@ uint32_t LogitsProcessor::sample(const float* logits, size_t n) {
 // ---------------------------------------------------------------- generate_blocking (single_batch.rs)
 std::vector<uint32_t> LM::generate(const uint32_t* prompt, int L, int max_new_tokens, const Sampling& s, uint64_t seed,
                                    bool ignore_eos, int* n_frames, std::vector<float>* hidden_out, double* prefill_s,
-                                   double* decode_s, int max_frames) {
+                                   double* decode_s, int max_frames, std::vector<float>* margins) {
     const int C = a.num_codebooks, D = a.dim, V = a.vocab_size;
     using clk = std::chrono::steady_clock;
     // SingleBatchGenerator::new (:31-70)
@@ -469,6 +472,13 @@ std::vector<uint32_t> LM::generate(const uint32_t* prompt, int L, int max_new_to
     std::vector<uint32_t> prev_codes;
     std::vector<std::vector<uint32_t>> frames;  // each [C+1]
     std::vector<float> logits((size_t)V), hidden(D), fl(a.codebook_size), x(D);
+    // test aid: smallest top-2 logit margin among the 9 sampling decisions of each iteration (greedy parity tests use
+    // it to tell a kernel bug from a legitimate near-tie flip under reduced-precision storage)
+    auto top2_margin = [](const float* v, size_t n) {
+        float a = -std::numeric_limits<float>::infinity(), b = a;
+        for (size_t i = 0; i < n; ++i) { if (v[i] > a) { b = a; a = v[i]; } else if (v[i] > b) b = v[i]; }
+        return a - b;
+    };
     auto t0 = clk::now();
     auto t_first = t0;
     int it = 0;
@@ -484,6 +494,7 @@ std::vector<uint32_t> LM::generate(const uint32_t* prompt, int L, int max_new_to
             const size_t lo = t.im_end_id;
             std::vector<float> sl(logits.begin() + lo, logits.end());
             if (ignore_eos) sl[0] = -std::numeric_limits<float>::infinity();
+            if (margins) margins->push_back(top2_margin(sl.data(), sl.size()));
             semantic = lp.sample(sl.data(), sl.size()) + t.im_end_id;
         } else {
             throw std::runtime_error("Fish<=1.4 legacy slow sampler uses an unseeded thread_rng (sampling/mod.rs:17); not restated");
@@ -495,6 +506,7 @@ std::vector<uint32_t> LM::generate(const uint32_t* prompt, int L, int max_new_to
             if (semantic == t.im_end_id) { cb.push_back(0); continue; }  // :153-156
             forward_generate_fast(x.data(), 1, ci, fl.data());
             if (have_prev) rp[ci].apply(fl, prev_codes[ci + 1]);  // :162-168
+            if (margins) margins->back() = std::min(margins->back(), top2_margin(fl.data(), fl.size()));
             uint32_t tok = lp.sample(fl.data(), fl.size());
             if (ci != C - 1) std::memcpy(x.data(), &fast_embeddings[(size_t)tok * D], sizeof(float) * D);  // :176-182
             cb.push_back(tok);

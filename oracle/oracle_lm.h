@@ -82,7 +82,8 @@ struct LM {
     std::vector<uint32_t> generate(const uint32_t* prompt, int L, int max_new_tokens, const Sampling& s,
                                    uint64_t seed, bool ignore_eos, int* n_frames,
                                    std::vector<float>* hidden_out = nullptr, double* prefill_s = nullptr,
-                                   double* decode_s = nullptr, int max_frames = -1);
+                                   double* decode_s = nullptr, int max_frames = -1,
+                                   std::vector<float>* margins = nullptr);
 
     void embed(const uint32_t* toks, int B, int L, float* x);  // dual_ar.rs:532-567
     void block_forward(Block& blk, float* x, int B, int L, int input_pos, int T_cached_expected);

@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric on BASELINE.json configs[1]:
+Fish-Speech-1.5 (synthetic weights at the true shapes), bf16, batch=1, default-voice-sized prompt (368 positions),
+256 generated codec frames per request, greedy-free sampling disabled EOS (fixed length).
+
+A "step" is ONE REQUEST through the hot path (prefill of the prompt + 256 decode frames) on each rank; at N GPUs every
+rank serves its own independent request stream (replica fan-out, weak scaling, no data-path collective: SURVEY.md §8e).
+value = frames produced by all ranks / wall time of the timed region (prefill included), max over ranks.
+
+Extra objects on the JSON line:
+  roofline     -- HBM roofline of the decode FRAME (one hipGraph replay = 266 kernels = the unit of the hot loop):
+                  achieved = B_frame(T_avg) / t_frame, t_frame from HIP events recorded on the engine's own stream
+                  (fs_lm_last_stats); B_frame is SURVEY.md §8(d)'s algorithmic-bytes formula.
+  cpu_baseline -- the CPU restatement (oracle/, kind "port": the reference is Rust+candle and cannot be built here) timed
+                  on this host on BASELINE.json configs[0] (rank 0, N=1 only), which also yields the greedy golden
+                  token stream: the GPU f32 path must reproduce it bit-identically (reported under "parity").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "fish-speech.rs_amd"))
+
+import numpy as np
+
+SEED = 0xF15E5EED
+HBM_PEAK = 8.0e12  # MI355X HBM3E spec (guide: ~6.3 TB/s achievable by a copy kernel)
+FRAME_RATE = 21.535  # generate/single_batch.rs:292-295
+
+
+def default_voice_prompt(tok):
+    """configs[1] prompt layout (prompt.rs:53-104): [sys 12][user 48][assistant 4][VQ span 274][im_end][user 24][assistant 4]."""
+    rng = np.random.RandomState(2024)
+    codes = np.load(os.path.join(ROOT, "tests", "golden", "default_voice_codes.npy")).astype(np.uint32)  # (8, 274)
+    segs = []
+
+    def text(n):
+        p = np.zeros((9, n), np.uint32)
+        p[0] = rng.randint(0, tok["im_end_id"], n)
+        return p
+
+    segs += [text(12), text(48), text(4)]
+    vq = np.zeros((9, codes.shape[1]), np.uint32)
+    vq[0] = tok["semantic_start_id"] + codes[0]
+    vq[1:] = codes
+    segs.append(vq)
+    e = np.zeros((9, 1), np.uint32)
+    e[0, 0] = tok["im_end_id"]
+    segs += [e, text(24), text(4)]
+    return np.ascontiguousarray(np.concatenate(segs, 1))
+
+
+def frame_bytes(cfg, tok, T, wbytes=2):
+    """algorithmic HBM bytes of one decode frame at KV length T (every dependent pass streams its
+    weights once; audio-range head only)."""
+    D, I = cfg["dim"], cfg["intermediate_size"]
+    qkv = (cfg["n_head"] + 2 * cfg["n_local_heads"]) * cfg["head_dim"]
+    block = qkv * D + D * D + 3 * I * D + 2 * D
+    n_audio = cfg["vocab_size"] - tok["im_end_id"]
+    slow = wbytes * (cfg["n_layer"] * block + D + n_audio * D)
+    fast = cfg["num_codebooks"] * wbytes * (cfg["n_fast_layer"] * block + D + cfg["codebook_size"] * D)
+    kv_tok = cfg["n_layer"] * 2 * cfg["n_local_heads"] * cfg["head_dim"] * wbytes
+    kv_fast = cfg["num_codebooks"] * cfg["n_fast_layer"] * 2 * cfg["n_local_heads"] * cfg["head_dim"] * wbytes * 4
+    return slow + fast + kv_tok * T + kv_fast
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import fishrt
+    from fishrt import config as fcfg
+    cfg, tok = fcfg.FISH_1_5, fcfg.FISH_1_5_TOKENS
+    lm = fishrt.DualARTransformer(cfg, tok, local_rank, "bf16").load_synthetic(SEED)
+    prompt = default_voice_prompt(tok)
+    L = prompt.shape[1]
+    M = args.frames + L - 2  # budget counts prompt tokens (single_batch.rs:61,77): frames = M - L + 2
+    samp = dict(temp=0.0, top_p=1.0, top_k=0, repetition_penalty=1.2, ignore_eos=True)
+
+    def one_request():
+        lm.clear_slow_layer_caches()
+        out = lm.generate_blocking(prompt, M, **samp)
+        assert out.shape == (8, args.frames), out.shape
+        return out, lm.last_stats()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ref_out, _ = one_request()
+    barrier()
+    t0 = time.perf_counter()
+    stats = []
+    for _ in range(args.steps):
+        out, st = one_request()
+        stats.append(st)
+    barrier()
+    dt = time.perf_counter() - t0
+    if args.warmup:
+        assert np.array_equal(out, ref_out), "non-deterministic greedy tokens across requests"
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    frames_total = args.frames * args.steps * world
+    value = frames_total / dt
+    dec_ms = float(np.mean([s["decode_ms"] for s in stats]))
+    pre_ms = float(np.mean([s["prefill_ms"] for s in stats]))
+    t_frame = dec_ms * 1e-3 / (args.frames - 1)  # events bracket frames 1..n-1 exactly like `start_decode` (:261)
+    T_avg = L + args.frames / 2.0
+    bf = frame_bytes(cfg, tok, T_avg)
+    achieved = bf / t_frame
+    res = {
+        "metric": "codec tokens/sec (frames/s; 1 frame = 1 slow + 8 codebook tokens = 2048 PCM samples), Fish-1.5 batch=1",
+        "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic (deterministic synthetic weights at Fish-1.5 shapes; default-voice-shaped prompt)",
+        "config": {"workload": "BASELINE.json configs[1]: Fish-1.5 bf16 batch=1, default-voice prompt, 256-frame generation, "
+                               "one request per step per GPU (prefill included in the timed region)",
+                   "prompt_positions": L, "frames_per_request": args.frames, "requests_per_step": world,
+                   "parallelism": f"replicas x{world} (no data-path collective)"},
+        "rtf": round((frames_total / FRAME_RATE) / dt, 2),
+        "decode_frames_per_s_per_gpu": round(1.0 / t_frame, 2), "prefill_ms": round(pre_ms, 3),
+        "roofline": {"bound": "hbm", "kernel": "decode frame = one hipGraph replay (24 slow blocks + head + sample + 8 x (4 fast "
+                                               "blocks + head + sample)); HIP-event timed on the engine stream",
+                     "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
+                     "algorithmic_bytes_per_frame": int(bf), "frame_us": round(t_frame * 1e6, 2), "kv_len_avg": T_avg},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res.update(cpu_baseline_and_parity(cfg, tok))
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline_and_parity(cfg, tok):
+    """the Candle-CPU stand-in on configs[0] (f32, prompt (9,16), greedy, rep-pen 1.2, 242 frames) --
+    timed on this host, and its token stream checked bit-for-bit against the GPU f32 path."""
+    from oracle import oracle as orc
+    import fishrt
+    rng = np.random.RandomState(1234)
+    p = np.zeros((9, 16), np.uint32)
+    p[0] = rng.randint(0, tok["im_end_id"], 16)
+    o = orc.OracleLM(orc.FISH15).load_synthetic(SEED, bf16=False)
+    t0 = time.perf_counter()
+    exp = o.generate(p, 256, temp=0.0, repetition_penalty=1.2, ignore_eos=True)
+    wall = time.perf_counter() - t0
+    n = exp.shape[1]
+    cpu_fps = (n - 1) / o.last_decode_s
+    min_margin = float(o.last_margins.min())
+    del o
+    lm32 = fishrt.DualARTransformer(cfg, tok, 0, "f32").load_synthetic(SEED)
+    got = lm32.generate_blocking(p, 256, temp=0.0, top_p=1.0, top_k=0, repetition_penalty=1.2, ignore_eos=True)
+    st = lm32.last_stats()
+    lm32.close()
+    return {
+        "cpu_baseline": {"value": round(cpu_fps, 3), "unit": "frames/s", "cores": orc.usable_cpus(), "kind": "port",
+                         "sample": f"BASELINE.json configs[0] in full: f32, prompt (9,16), greedy, rep-pen 1.2, {n} frames "
+                                   f"({wall:.1f} s wall incl. prefill; OpenMP over {orc.usable_cpus()} usable CPUs)",
+                         "rtf": round(((n - 1) / FRAME_RATE) / o_decode(wall, cpu_fps, n), 3)},
+        "parity": {"config0_greedy_f32_tokens_identical": bool(np.array_equal(got, exp)), "frames": int(n),
+                   "oracle_min_top2_margin": min_margin,
+                   "gpu_f32_decode_frames_per_s": round((st["frames"] - 1) / (st["decode_ms"] * 1e-3), 1)},
+    }
+
+
+def o_decode(wall, fps, n):
+    return (n - 1) / fps
+
+
+if __name__ == "__main__":
+    main()

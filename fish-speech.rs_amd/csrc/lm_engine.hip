@@ -63,7 +63,6 @@ void seed_key(uint64_t state, uint32_t* key) {
     }
 }
 
-constexpr int NSPLIT = 8;  // flash-decoding splits per kv head (grid = Hk * NSPLIT blocks)
 
 }  // namespace
 
@@ -465,7 +464,9 @@ class LM final : public LMBase {
         d_x_.alloc(sizeof(float) * (size_t)B_ * a_.dim);
         d_xf_.alloc(sizeof(float) * (size_t)B_ * a_.dim);
         d_q_.alloc(sizeof(float) * a_.dim);
-        d_part_.alloc(sizeof(float) * (size_t)a_.n_head * NSPLIT * (a_.head_dim + 2));
+        n_chunks_ = (a_.max_seq_len + LmKernels<WT>::attn_chunk() - 1) / LmKernels<WT>::attn_chunk();
+        FS_REQUIRE(n_chunks_ <= 128, "max_seq_len too large for the attention chunking (128 chunks)");
+        d_part_.alloc(sizeof(float) * (size_t)a_.n_head * n_chunks_ * (a_.head_dim + 2));
         d_act_.alloc(sizeof(float) * a_.intermediate_size);
         d_logits_slow_.alloc(sizeof(float) * a_.vocab_size);
         d_logits_fast_.alloc(sizeof(float) * a_.codebook_size);
@@ -535,8 +536,8 @@ class LM final : public LMBase {
             const LayerW& w = slow_[l];
             KVView kv = slow_kv(l, b);
             LmKernels<WT>::qkv(d_, x(b), w, d_cos_.as<float>(), d_sin_.as<float>(), state(b), 0, 0, d_q_.as<float>(), kv, st_);
-            LmKernels<WT>::attn_decode(d_, d_q_.as<float>(), kv, state(b), d_part_.as<float>(), NSPLIT, st_);
-            LmKernels<WT>::wo(d_, d_part_.as<float>(), NSPLIT, nullptr, kv, 0, w, x(b), st_);
+            LmKernels<WT>::attn_decode(d_, d_q_.as<float>(), kv, state(b), d_part_.as<float>(), n_chunks_, st_);
+            LmKernels<WT>::wo(d_, d_part_.as<float>(), n_chunks_, state(b), nullptr, kv, 0, w, x(b), st_);
             LmKernels<WT>::ffn_up(d_, x(b), w, d_act_.as<float>(), st_);
             LmKernels<WT>::ffn_down(d_, d_act_.as<float>(), w, x(b), st_);
         }
@@ -546,7 +547,7 @@ class LM final : public LMBase {
             const LayerW& w = fast_[l];
             KVView kv = fast_kv(l, b);
             LmKernels<WT>::qkv(d_, xf(b), w, d_cos_.as<float>(), d_sin_.as<float>(), nullptr, kv_pos, rope_pos, d_q_.as<float>(), kv, st_);
-            LmKernels<WT>::wo(d_, nullptr, 0, d_q_.as<float>(), kv, kv_pos + 1, w, xf(b), st_);
+            LmKernels<WT>::wo(d_, nullptr, 0, nullptr, d_q_.as<float>(), kv, kv_pos + 1, w, xf(b), st_);
             LmKernels<WT>::ffn_up(d_, xf(b), w, d_act_.as<float>(), st_);
             LmKernels<WT>::ffn_down(d_, d_act_.as<float>(), w, xf(b), st_);
         }
@@ -602,7 +603,7 @@ class LM final : public LMBase {
     const float *norm_w_ = nullptr, *fast_norm_w_ = nullptr;
     DevBuf d_cos_, d_sin_;
     // KV
-    int max_pages_ = 0, n_pages_ = 0, out_cap_ = 0;
+    int max_pages_ = 0, n_pages_ = 0, out_cap_ = 0, n_chunks_ = 0;
     size_t page_elems_ = 0;
     DevBuf kv_pool_, fast_pool_, d_page_table_, d_zero_table_;
     std::vector<int> free_pages_, seq_len_, fast_len_;

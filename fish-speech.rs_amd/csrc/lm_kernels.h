@@ -60,12 +60,15 @@ struct LmKernels {
     // (state != null: KV index = state->pos, RoPE row = state->pos + state->rope_off; else the two static values)
     static void qkv(const ModelDims& d, const float* x, const LayerW& w, const float* cos_t, const float* sin_t,
                     const SeqState* state, int pos_static, int rope_static, float* q_out, KVView kv, hipStream_t st);
-    // decode attention over the paged cache: partial (m, l, o[Dh]) per (q head, split)
+    // decode attention over the paged cache: un-normalised partial {o[Dh], m, l} per (q head, token chunk);
+    // part: [H][n_chunks_max][Dh + 2]; chunk c covers tokens [c * attn_chunk(), (c + 1) * attn_chunk())
+    static int attn_chunk();
     static void attn_decode(const ModelDims& d, const float* q, KVView kv, const SeqState* state, float* part,
-                            int nsplit, hipStream_t st);
-    // combine partials (or, FUSED: attend over pos_static+1 <= 8 cached tokens in the prologue) -> Wo GEMV -> x += .
-    static void wo(const ModelDims& d, const float* part, int nsplit, const float* q, KVView kv, int fused_T,
-                   const LayerW& w, float* x, hipStream_t st);
+                            int n_chunks_max, hipStream_t st);
+    // combine the chunks of state->pos + 1 tokens (or, fused_T > 0: attend over fused_T <= 8 cached tokens in the
+    // prologue) -> Wo GEMV -> x += .
+    static void wo(const ModelDims& d, const float* part, int n_chunks_max, const SeqState* state, const float* q, KVView kv,
+                   int fused_T, const LayerW& w, float* x, hipStream_t st);
     static void ffn_up(const ModelDims& d, const float* x, const LayerW& w, float* act, hipStream_t st);
     static void ffn_down(const ModelDims& d, const float* act, const LayerW& w, float* x, hipStream_t st);
     // x -> rmsnorm(norm_w) -> rows [0, n_rows) of W -> logits f32

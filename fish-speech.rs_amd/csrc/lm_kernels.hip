@@ -58,14 +58,32 @@ __device__ __forceinline__ V ld_stream(const V* p) {  // streamed-once weights: 
     return __builtin_nontemporal_load(p);
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
+// ---- cross-lane reductions: DPP inside a 16-lane row (no LDS crossbar), v_readlane across the four rows.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+constexpr int DPP_XOR1 = 0xB1;         // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;         // quad_perm [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141; // lane i <-> 7-i inside each 8
+constexpr int DPP_MIRROR = 0x140;      // lane i <-> 15-i inside each 16
+__device__ __forceinline__ float readlane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+// sum over the whole wave; the result is wave-uniform (scalar registers)
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_mov<DPP_XOR1>(v);
+    v += dpp_mov<DPP_XOR2>(v);
+    v += dpp_mov<DPP_HALF_MIRROR>(v);
+    v += dpp_mov<DPP_MIRROR>(v);
+    return (readlane(v, 15) + readlane(v, 31)) + (readlane(v, 47) + readlane(v, 63));
+}
+// sum / max over aligned groups of N consecutive lanes (N in {1,2,4,8,16}); every lane of the group gets the result
+template <int N>
+__device__ __forceinline__ float group_sum(float v) {
+    if (N >= 2) v += dpp_mov<DPP_XOR1>(v);
+    if (N >= 4) v += dpp_mov<DPP_XOR2>(v);
+    if (N >= 8) v += dpp_mov<DPP_HALF_MIRROR>(v);
+    if (N >= 16) v += dpp_mov<DPP_MIRROR>(v);
     return v;
 }
 
@@ -114,17 +132,15 @@ struct Row {
         }
         return acc;
     }
-    // in-register RMSNorm of the wave's x slice: x / sqrt(mean(x^2) + eps) * w   (candle_nn::RmsNorm)
-    __device__ static __forceinline__ void rmsnorm(float (&xr)[NX], const float* __restrict__ nw, float eps, int lane) {
+    // in-register RMSNorm of the wave's x slice: x / sqrt(mean(x^2) + eps) * w   (candle_nn::RmsNorm); `nr` = the
+    // lane's slice of the norm weight, loaded by the caller together with x so that no load sits behind the reduction
+    __device__ static __forceinline__ void rmsnorm(float (&xr)[NX], const float (&nr)[NX], float eps) {
         float ss = 0.f;
 #pragma unroll
         for (int i = 0; i < NX; ++i) ss = fmaf(xr[i], xr[i], ss);
-        ss = wave_sum(ss);
-        const float d = sqrtf(ss / (float)K + eps);
-        float wr[NX];
-        load_x(nw, lane, wr);
+        const float d = sqrtf(wave_sum(ss) / (float)K + eps);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) xr[i] = (xr[i] / d) * wr[i];
+        for (int i = 0; i < NX; ++i) xr[i] = (xr[i] / d) * nr[i];
     }
 };
 
@@ -135,7 +151,9 @@ __device__ __forceinline__ WT* kv_addr(void* pool, const int* __restrict__ page_
 }
 
 // ------------------------------------------------------------------------------------------------ qkv + rope + kv append
-// One wave per row PAIR (2p, 2p+1) of Wqkv: the interleaved-RoPE partner is in the same wave.
+// One wave per ROW of Wqkv (maximum memory-level parallelism: 1280 waves for Fish-1.5); the two rows (2p, 2p+1) of an
+// interleaved-RoPE pair sit in adjacent waves of one block and meet through LDS.  Position, page and cos/sin are
+// fetched at kernel entry so the epilogue has no dependent load left.
 template <typename WT, int K, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void k_qkv(const float* __restrict__ x, const float* __restrict__ norm_w, float eps,
                                                     const WT* __restrict__ W, const float* __restrict__ cos_t,
@@ -143,202 +161,306 @@ __global__ __launch_bounds__(WAVES * 64) void k_qkv(const float* __restrict__ x,
                                                     int pos_static, int rope_static, float* __restrict__ q_out, KVView kv,
                                                     int H, int Hk, int Dh) {
     using R = Row<WT, K>;
-    const int lane = threadIdx.x & 63;
-    const int pair = blockIdx.x * WAVES + (threadIdx.x >> 6);
-    const int n_pairs = (H + 2 * Hk) * Dh / 2;
-    if (pair >= n_pairs) return;
-    typename R::vec w0[R::NCH], w1[R::NCH];
-    R::load_w(W + (size_t)(2 * pair) * K, lane, w0);       // issue the weight loads first
-    R::load_w(W + (size_t)(2 * pair + 1) * K, lane, w1);
-    float xr[R::NX];
+    __shared__ float res[WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * WAVES + wave;
+    const int n_rows = (H + 2 * Hk) * Dh;
+    const bool active = row < n_rows;
+    // small L2-resident vectors FIRST (vmcnt retires in order: a load issued after the weight stream would wait for it),
+    // then the weight stream; the RMSNorm math then overlaps the weights' HBM flight
+    float xr[R::NX], nr[R::NX];
     R::load_x(x, lane, xr);
-    R::rmsnorm(xr, norm_w, eps, lane);
-    float a = wave_sum(R::dot(w0, xr));
-    float b = wave_sum(R::dot(w1, xr));
-    if (lane != 0) return;
+    R::load_x(norm_w, lane, nr);
     const int pos = state ? state->pos : pos_static;
-    const int rpos = state ? state->pos + state->rope_off : rope_static;
-    const int r = 2 * pair, qdim = H * Dh, kdim = Hk * Dh, half = Dh / 2;
-    if (r < qdim + kdim) {  // q or k: rope_i on the pair (2j, 2j+1) of its head (dual_ar.rs:246-247)
-        const int j = (r % Dh) / 2;
-        const float c = cos_t[(size_t)rpos * half + j], s = sin_t[(size_t)rpos * half + j];
+    const int rpos = state ? pos + state->rope_off : rope_static;
+    const int r0 = row & ~1, qdim = H * Dh, kdim = Hk * Dh, half = Dh / 2;
+    float c = 1.f, s = 0.f;
+    WT* dst = nullptr;
+    if (active && r0 < qdim + kdim) {
+        const int j = (r0 % Dh) / 2;
+        c = cos_t[(size_t)rpos * half + j];
+        s = sin_t[(size_t)rpos * half + j];
+    }
+    if (active && r0 >= qdim) {
+        const int rk = (r0 - qdim) % kdim, g = rk / Dh, dd = rk % Dh;
+        dst = kv_addr<WT>(r0 < qdim + kdim ? kv.k : kv.v, kv.page_table, pos, g, Hk, Dh) + dd;
+    }
+    typename R::vec wv[R::NCH];
+    if (active) R::load_w(W + (size_t)row * K, lane, wv);
+    R::rmsnorm(xr, nr, eps);
+    const float d = active ? wave_sum(R::dot(wv, xr)) : 0.f;
+    if (lane == 0) res[wave] = d;
+    __syncthreads();
+    if (!active || (wave & 1) || lane != 0) return;
+    const float a = res[wave], b = res[wave + 1];
+    if (r0 < qdim + kdim) {  // rope_i on the pair (2j, 2j+1) of its head (dual_ar.rs:246-247)
         const float o0 = a * c - b * s, o1 = a * s + b * c;
-        if (r < qdim) {
-            q_out[r] = o0; q_out[r + 1] = o1;
-        } else {
-            const int rk = r - qdim, g = rk / Dh, dd = rk % Dh;
-            WT* dst = kv_addr<WT>(kv.k, kv.page_table, pos, g, Hk, Dh) + dd;
-            dst[0] = WTr<WT>::from_f32(o0); dst[1] = WTr<WT>::from_f32(o1);
-        }
+        if (r0 < qdim) { q_out[r0] = o0; q_out[r0 + 1] = o1; }
+        else { dst[0] = WTr<WT>::from_f32(o0); dst[1] = WTr<WT>::from_f32(o1); }
     } else {
-        const int rv = r - qdim - kdim, g = rv / Dh, dd = rv % Dh;
-        WT* dst = kv_addr<WT>(kv.v, kv.page_table, pos, g, Hk, Dh) + dd;
         dst[0] = WTr<WT>::from_f32(a); dst[1] = WTr<WT>::from_f32(b);
     }
 }
 
 // ------------------------------------------------------------------------------------------------ decode attention
-// grid = Hk * nsplit blocks of 256 threads.  Block (g, s) attends the n_rep q heads of kv head g over its slice of
-// the T cached tokens and writes an un-normalised partial {m, l, o[Dh]} per q head (flash-decoding split).
-// LPT lanes cover one token's Dh elements with 16-B loads; a wave covers 64/LPT tokens per iteration.
+// Flash-decoding over the paged cache.  grid = Hk * n_chunks_max blocks of 4 waves; block (g, c) owns the n_rep query
+// heads of kv head g and the ATTN_CHUNK tokens [c*CH, (c+1)*CH); blocks past the current length exit at once, so the
+// captured graph serves every sequence length.  Each wave stages its TW tokens of K and V (one coalesced 16-B/lane
+// load per KiB, all in flight together) into its private LDS tile, then lane GROUPS of LPT lanes (LPT*16 B = one head
+// row) each own one (query head, token subset): scores by DPP group-sums, a two-pass softmax in registers (no rescale
+// chain), P.V accumulated on the group's own dims -- no cross-group reduction of the output.  The block merges its
+// waves in LDS and writes one un-normalised partial {o[Dh], m, l} per (head, chunk); k_wo combines the chunks.
+template <typename WT> struct AttnGeom { static constexpr int TW = 32; };
+template <> struct AttnGeom<float> { static constexpr int TW = 16; };
+
 template <typename WT, int DH, int NREP>
 __global__ __launch_bounds__(256) void k_attn_decode(const float* __restrict__ q, KVView kv,
                                                      const SeqState* __restrict__ state, float* __restrict__ part,
-                                                     int Hk, int nsplit) {
+                                                     int Hk, int n_chunks_max) {
     constexpr int EPL = WTr<WT>::EPL;
-    constexpr int LPT = DH / EPL;   // lanes per token
-    constexpr int TPW = 64 / LPT;   // tokens per wave iteration
+    constexpr int LPT = DH / EPL;            // lanes per head row
+    constexpr int G = 64 / LPT;              // lane groups per wave
+    constexpr int NRP = NREP < G ? NREP : G; // heads served per pass
+    constexpr int NTS = G / NRP;             // token subsets per head
+    constexpr int NHP = NREP / NRP;          // head passes
+    constexpr int TW = AttnGeom<WT>::TW;     // tokens per wave
+    constexpr int CH = 4 * TW;               // tokens per block
+    constexpr int TPG = TW / NTS;            // tokens per group
+    constexpr int NLD = TW * LPT / 64;       // 16-B loads per lane per tile
+    static_assert(TW % NTS == 0 && NLD >= 1, "attention geometry");
     using vec = typename WTr<WT>::vec;
-    const int g = blockIdx.x / nsplit, s = blockIdx.x % nsplit;
+    const int g = blockIdx.x / n_chunks_max, c = blockIdx.x % n_chunks_max;
     const int T = state->pos + 1;  // the current token's K/V were appended by k_qkv
+    if (c * CH >= T) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int sub = lane % LPT, tl = lane / LPT;
-    int chunk = (T + nsplit - 1) / nsplit;
-    chunk = (chunk + TPW * 4 - 1) / (TPW * 4) * (TPW * 4);
-    const int t_lo = s * chunk, t_hi = min(T, t_lo + chunk);
+    __shared__ __attribute__((aligned(16))) WT sk[4][TW * DH];
+    __shared__ __attribute__((aligned(16))) WT sv[4][TW * DH];
+    __shared__ float sp[4][NREP][NTS][DH + 2];
+    const int t_base = c * CH + wave * TW;
+    // stage K/V tiles: lane l of load i covers token (i*64 + l) / LPT, 16-B slice l % LPT (1 KiB contiguous per load)
+    vec kreg[NLD], vreg[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int tl = (i * 64 + lane) / LPT, sl = lane % LPT;
+        const int t = min(t_base + tl, T - 1);
+        kreg[i] = *reinterpret_cast<const vec*>(kv_addr<WT>(kv.k, kv.page_table, t, g, Hk, DH) + sl * EPL);
+        vreg[i] = *reinterpret_cast<const vec*>(kv_addr<WT>(kv.v, kv.page_table, t, g, Hk, DH) + sl * EPL);
+    }
+    const int gi = lane / LPT, sub = lane % LPT;
+    const int rl = gi % NRP, ts = gi / NRP;
+    float qr[NHP][EPL];
+#pragma unroll
+    for (int hp = 0; hp < NHP; ++hp) {
+        const float* qp = q + (size_t)(g * NREP + hp * NRP + rl) * DH + sub * EPL;
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) qr[hp][i] = qp[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        *reinterpret_cast<vec*>(&sk[wave][(size_t)(i * 64 + lane) * EPL]) = kreg[i];
+        *reinterpret_cast<vec*>(&sv[wave][(size_t)(i * 64 + lane) * EPL]) = vreg[i];
+    }
+    // (each wave reads only the tile it wrote: no block barrier needed, the compiler orders the LDS accesses)
     const float scale = 1.0f / sqrtf((float)DH);
-
-    float qr[NREP][EPL], o[NREP][EPL], m[NREP], l[NREP];
 #pragma unroll
-    for (int r = 0; r < NREP; ++r) {
-        const float* qp = q + (size_t)(g * NREP + r) * DH + sub * EPL;
+    for (int hp = 0; hp < NHP; ++hp) {
+        float sc[TPG];
+        float m = -1e30f;
 #pragma unroll
-        for (int i = 0; i < EPL; ++i) { qr[r][i] = qp[i]; o[r][i] = 0.f; }
-        m[r] = -1e30f; l[r] = 0.f;
-    }
-    for (int t0 = t_lo + wave * TPW; t0 < t_hi; t0 += 4 * TPW) {
-        const int t = t0 + tl;
-        const bool valid = t < t_hi;
-        const int tc = valid ? t : t_lo;
-        const vec kvv = *reinterpret_cast<const vec*>(kv_addr<WT>(kv.k, kv.page_table, tc, g, Hk, DH) + sub * EPL);
-        const vec vvv = *reinterpret_cast<const vec*>(kv_addr<WT>(kv.v, kv.page_table, tc, g, Hk, DH) + sub * EPL);
-        float kf[EPL], vf[EPL];
-        WTr<WT>::unpack(kvv, kf);
-        WTr<WT>::unpack(vvv, vf);
+        for (int j = 0; j < TPG; ++j) {
+            const int tl = ts + j * NTS;
+            float kf[EPL];
+            WTr<WT>::unpack(*reinterpret_cast<const vec*>(&sk[wave][(size_t)tl * DH + sub * EPL]), kf);
+            float a = 0.f;
 #pragma unroll
-        for (int i = 0; i < EPL; ++i) kf[i] *= scale;  // q . (k^T * scale)  (dual_ar.rs:260)
-#pragma unroll
-        for (int r = 0; r < NREP; ++r) {
-            float sc = 0.f;
-#pragma unroll
-            for (int i = 0; i < EPL; ++i) sc = fmaf(qr[r][i], kf[i], sc);
-#pragma unroll
-            for (int msk = LPT / 2; msk >= 1; msk >>= 1) sc += __shfl_xor(sc, msk, 64);
-            if (valid) {
-                const float mn = fmaxf(m[r], sc);
-                const float corr = __expf(m[r] - mn), p = __expf(sc - mn);
-                l[r] = l[r] * corr + p;
-#pragma unroll
-                for (int i = 0; i < EPL; ++i) o[r][i] = o[r][i] * corr + p * vf[i];
-                m[r] = mn;
-            }
+            for (int i = 0; i < EPL; ++i) a = fmaf(qr[hp][i], kf[i] * scale, a);  // q . (k^T * scale)  (dual_ar.rs:260)
+            a = group_sum<LPT>(a);
+            sc[j] = (t_base + tl < T) ? a : -1e30f;
+            m = fmaxf(m, sc[j]);
         }
-    }
-    // merge the TPW token groups of the wave (lanes with equal `sub`)
+        float l = 0.f, o[EPL];
 #pragma unroll
-    for (int r = 0; r < NREP; ++r) {
+        for (int i = 0; i < EPL; ++i) o[i] = 0.f;
 #pragma unroll
-        for (int msk = LPT; msk < 64; msk <<= 1) {
-            const float m2 = __shfl_xor(m[r], msk, 64), l2 = __shfl_xor(l[r], msk, 64);
-            const float mn = fmaxf(m[r], m2);
-            const float c1 = __expf(m[r] - mn), c2 = __expf(m2 - mn);
-            l[r] = l[r] * c1 + l2 * c2;
+        for (int j = 0; j < TPG; ++j) {
+            const int tl = ts + j * NTS;
+            const float p = (t_base + tl < T) ? __expf(sc[j] - m) : 0.f;
+            l += p;
+            float vf[EPL];
+            WTr<WT>::unpack(*reinterpret_cast<const vec*>(&sv[wave][(size_t)tl * DH + sub * EPL]), vf);
 #pragma unroll
-            for (int i = 0; i < EPL; ++i) {
-                const float o2 = __shfl_xor(o[r][i], msk, 64);
-                o[r][i] = o[r][i] * c1 + o2 * c2;
-            }
-            m[r] = mn;
+            for (int i = 0; i < EPL; ++i) o[i] = fmaf(p, vf[i], o[i]);
         }
-    }
-    // merge the 4 waves through LDS
-    __shared__ float sm[4][NREP][DH + 2];
-    if (tl == 0) {
+        float* dst = sp[wave][hp * NRP + rl][ts];
 #pragma unroll
-        for (int r = 0; r < NREP; ++r) {
-#pragma unroll
-            for (int i = 0; i < EPL; ++i) sm[wave][r][sub * EPL + i] = o[r][i];
-            if (sub == 0) { sm[wave][r][DH] = m[r]; sm[wave][r][DH + 1] = l[r]; }
-        }
+        for (int i = 0; i < EPL; ++i) dst[sub * EPL + i] = o[i];
+        if (sub == 0) { dst[DH] = m; dst[DH + 1] = l; }
     }
     __syncthreads();
     for (int e = threadIdx.x; e < NREP * DH; e += 256) {
         const int r = e / DH, dd = e % DH;
         float mn = -1e30f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) mn = fmaxf(mn, sm[w][r][DH]);
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+            for (int k = 0; k < NTS; ++k) mn = fmaxf(mn, sp[w][r][k][DH]);
         float L = 0.f, O = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const float c = __expf(sm[w][r][DH] - mn);
-            L += sm[w][r][DH + 1] * c;
-            O += sm[w][r][dd] * c;
-        }
-        float* dst = part + ((size_t)(g * NREP + r) * nsplit + s) * (DH + 2);
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+            for (int k = 0; k < NTS; ++k) {
+                const float cf = __expf(sp[w][r][k][DH] - mn);
+                L += sp[w][r][k][DH + 1] * cf;
+                O += sp[w][r][k][dd] * cf;
+            }
+        float* dst = part + ((size_t)(g * NREP + r) * n_chunks_max + c) * (DH + 2);
         dst[dd] = O;
         if (dd == 0) { dst[DH] = mn; dst[DH + 1] = L; }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ wo + residual
-// Prologue (whole block, result in LDS): either combine the flash-decoding partials of k_attn_decode, or -- FUSED,
-// used by the fast decoder whose KV length is <= 8 -- run the whole attention for all heads redundantly per block.
+// Prologue (whole block, result in LDS): either combine the per-chunk partials of k_attn_decode, or -- FUSED, used by
+// the fast decoder whose KV length is <= 8 -- run the whole attention for all heads redundantly per block.
 // Body: one wave per output row: x[r] += Wo[r,:] . attn   (dual_ar.rs:383,437)
-template <typename WT, int K, int WAVES, bool FUSED>
-__global__ __launch_bounds__(WAVES * 64) void k_wo(const float* __restrict__ part, int nsplit, const float* __restrict__ q,
-                                                   KVView kv, int fused_T, const WT* __restrict__ W, float* __restrict__ x,
-                                                   int H, int Hk, int Dh, int n_rows) {
+template <typename WT, int K, int WAVES, bool FUSED, int DH>
+__global__ __launch_bounds__(WAVES * 64) void k_wo(const float* __restrict__ part, int n_chunks_max, int chunk,
+                                                   const SeqState* __restrict__ state, const float* __restrict__ q, KVView kv,
+                                                   int fused_T, const WT* __restrict__ W, float* __restrict__ x, int H, int Hk,
+                                                   int n_rows) {
     using R = Row<WT, K>;
+    constexpr int NT = WAVES * 64;
+    constexpr int EPL = WTr<WT>::EPL;
+    using vec = typename WTr<WT>::vec;
+    static_assert(K % 4 == 0 && DH % 16 == 0, "geometry");
     __shared__ __attribute__((aligned(16))) float attn[K];
+    __shared__ float wl[FUSED ? 32 * 8 : 32 * 128];
+    __shared__ float ml[FUSED ? 2 : 2 * 32 * 128];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * WAVES + wave;
-    typename R::vec wv[R::NCH];
-    if (row < n_rows) R::load_w(W + (size_t)row * K, lane, wv);  // weights in flight during the prologue
     const int n_rep = H / Hk;
-    for (int e = threadIdx.x; e < K && !FUSED; e += WAVES * 64) {
-        const int h = e / Dh, dd = e % Dh;
-        {
-            const float* p = part + (size_t)h * nsplit * (Dh + 2);
-            float mn = -1e30f;
-            for (int s = 0; s < nsplit; ++s) mn = fmaxf(mn, p[s * (Dh + 2) + Dh]);
-            float L = 0.f, O = 0.f;
-            for (int s = 0; s < nsplit; ++s) {
-                const float c = __expf(p[s * (Dh + 2) + Dh] - mn);
-                L += p[s * (Dh + 2) + Dh + 1] * c;
-                O += p[s * (Dh + 2) + dd] * c;
-            }
-            attn[e] = O / L;
-        }
-    }
-    if (FUSED) {
-        // step 1: scores[h][t] for all H x fused_T pairs (one thread each, 16-B K loads); step 2: softmax . V per (h, dd)
-        __shared__ float sc[32 * 8];
-        const float scale = 1.0f / sqrtf((float)Dh);
-        constexpr int EPL = WTr<WT>::EPL;
-        for (int e = threadIdx.x; e < H * fused_T; e += WAVES * 64) {
-            const int h = e / fused_T, t = e % fused_T, g = h / n_rep;
-            const WT* kp = kv_addr<WT>(kv.k, kv.page_table, t, g, Hk, Dh);
-            float acc = 0.f;
-            for (int i = 0; i < Dh; i += EPL) {
-                float kf[EPL];
-                WTr<WT>::unpack(*reinterpret_cast<const typename WTr<WT>::vec*>(kp + i), kf);
+    typename R::vec wv[R::NCH];
+    const float xres = (row < n_rows && lane == 0) ? x[row] : 0.f;
+    // Few, wide prologue loads (the texture-address unit retires one wave-instruction per ~16 cycles whatever its width),
+    // all issued before the weight stream (vmcnt retires in issue order).
+    if (!FUSED) {
+        const int T = state->pos + 1;
+        const int nc = (T + chunk - 1) / chunk;  // chunks k_attn_decode produced
+        // (a) {m, l} of every (head, chunk) + the first four chunks' o values (float4 per thread per chunk)
+        const int e0 = threadIdx.x;
+        const bool has_ml = e0 < H * nc;
+        float2 mv = make_float2(0.f, 0.f);
+        if (has_ml) mv = *reinterpret_cast<const float2*>(part + ((size_t)(e0 / nc) * n_chunks_max + (e0 % nc)) * (DH + 2) + DH);
+        const int e4 = threadIdx.x * 4;  // this thread's 4 consecutive attn elements (K <= 4 * NT for every supported K here)
+        const bool has_o = e4 < K;
+        const int ho = (has_o ? e4 : 0) / DH, ddo = e4 % DH;
+        const float* po = part + (size_t)ho * n_chunks_max * (DH + 2) + ddo;
+        float4 v[4];
 #pragma unroll
-                for (int j = 0; j < EPL; ++j) acc = fmaf(q[h * Dh + i + j], kf[j] * scale, acc);
-            }
-            sc[h * 8 + t] = acc;
+        for (int j = 0; j < 4; ++j)
+            v[j] = (has_o && j < nc) ? *reinterpret_cast<const float4*>(po + (size_t)j * (DH + 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < n_rows) R::load_w(W + (size_t)row * K, lane, wv);
+        if (has_ml) { ml[2 * ((e0 / nc) * 128 + (e0 % nc))] = mv.x; ml[2 * ((e0 / nc) * 128 + (e0 % nc)) + 1] = mv.y; }
+        for (int e = threadIdx.x + NT; e < H * nc; e += NT) {  // only when H * nc > NT (very long sequences)
+            const int h = e / nc, c = e % nc;
+            const float2 t2 = *reinterpret_cast<const float2*>(part + ((size_t)h * n_chunks_max + c) * (DH + 2) + DH);
+            ml[2 * (h * 128 + c)] = t2.x;
+            ml[2 * (h * 128 + c) + 1] = t2.y;
         }
         __syncthreads();
-        for (int e = threadIdx.x; e < K; e += WAVES * 64) {
-            const int h = e / Dh, dd = e % Dh, g = h / n_rep;
+        // (b) per head: softmax-merge weights wl[h][c] = exp(m_c - M) / sum_c l_c exp(m_c - M)
+        for (int h = threadIdx.x; h < H; h += NT) {
             float mn = -1e30f;
-            for (int t = 0; t < fused_T; ++t) mn = fmaxf(mn, sc[h * 8 + t]);
-            float L = 0.f, O = 0.f;
-            for (int t = 0; t < fused_T; ++t) {
-                const float p = __expf(sc[h * 8 + t] - mn);
-                L += p;
-                O = fmaf(p, WTr<WT>::to_f32(kv_addr<WT>(kv.v, kv.page_table, t, g, Hk, Dh)[dd]), O);
+            for (int c = 0; c < nc; ++c) mn = fmaxf(mn, ml[2 * (h * 128 + c)]);
+            float L = 0.f;
+            for (int c = 0; c < nc; ++c) L += ml[2 * (h * 128 + c) + 1] * __expf(ml[2 * (h * 128 + c)] - mn);
+            const float inv = 1.f / L;
+            for (int c = 0; c < nc; ++c) wl[h * 128 + c] = __expf(ml[2 * (h * 128 + c)] - mn) * inv;
+        }
+        __syncthreads();
+        // (c) attn[e] = sum_c wl[h][c] * o[h][c][dd]
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c0 = 0; c0 < nc; c0 += 4) {
+            if (c0 > 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    v[j] = (has_o && c0 + j < nc) ? *reinterpret_cast<const float4*>(po + (size_t)(c0 + j) * (DH + 2))
+                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            attn[e] = O / L;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (c0 + j < nc) {
+                    const float wj = wl[ho * 128 + c0 + j];
+                    acc.x = fmaf(wj, v[j].x, acc.x); acc.y = fmaf(wj, v[j].y, acc.y);
+                    acc.z = fmaf(wj, v[j].z, acc.z); acc.w = fmaf(wj, v[j].w, acc.w);
+                }
+        }
+        if (has_o) *reinterpret_cast<float4*>(&attn[e4]) = acc;
+    } else {
+        // Fast decoder: <= 8 cached tokens, all in page 0 of this layer's private KV page (no page-table lookup).
+        // step 1: scores[h][t], TWO threads per (h, t) (DH/2 dims each, DPP pair-sum); step 2: softmax . V with one
+        // thread per EPL consecutive dims (one 16-B V load per token).
+        const float scale = 1.0f / sqrtf((float)DH);
+        const WT* kbase = reinterpret_cast<const WT*>(kv.k);
+        const WT* vbase = reinterpret_cast<const WT*>(kv.v);
+        constexpr int QD = DH / 2;  // dims per step-1 thread
+        const int e1 = threadIdx.x >> 1, sl = threadIdx.x & 1;
+        const bool has_s = e1 < H * fused_T;
+        const int h1 = has_s ? e1 / fused_T : 0, t1 = has_s ? e1 % fused_T : 0;
+        vec kvv[QD / EPL];
+        float4 qv[QD / 4];
+        {
+            const WT* kp = kbase + ((size_t)(h1 / n_rep) * KV_PAGE + t1) * DH + sl * QD;
+#pragma unroll
+            for (int i = 0; i < QD / EPL; ++i) kvv[i] = *reinterpret_cast<const vec*>(kp + i * EPL);
+#pragma unroll
+            for (int i = 0; i < QD / 4; ++i) qv[i] = *reinterpret_cast<const float4*>(q + h1 * DH + sl * QD + i * 4);
+        }
+        const int ev = threadIdx.x * EPL;  // this thread's EPL consecutive attn elements
+        const bool has_v = ev < K;
+        const int hv = (has_v ? ev : 0) / DH, ddv = ev % DH;
+        vec vvv[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            vvv[t] = (has_v && t < fused_T) ? *reinterpret_cast<const vec*>(vbase + ((size_t)(hv / n_rep) * KV_PAGE + t) * DH + ddv) : vec(0);
+        if (row < n_rows) R::load_w(W + (size_t)row * K, lane, wv);
+        {
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < QD / EPL; ++i) {
+                float kf[EPL];
+                WTr<WT>::unpack(kvv[i], kf);
+#pragma unroll
+                for (int j = 0; j < EPL; j += 4) {
+                    const float4 qq = qv[(i * EPL + j) / 4];
+                    acc = fmaf(qq.x, kf[j] * scale, acc); acc = fmaf(qq.y, kf[j + 1] * scale, acc);
+                    acc = fmaf(qq.z, kf[j + 2] * scale, acc); acc = fmaf(qq.w, kf[j + 3] * scale, acc);
+                }
+            }
+            acc = group_sum<2>(acc);
+            if (has_s && sl == 0) wl[h1 * 8 + t1] = acc;
+        }
+        __syncthreads();
+        if (has_v) {
+            float mn = -1e30f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) if (t < fused_T) mn = fmaxf(mn, wl[hv * 8 + t]);
+            float L = 0.f, O[EPL];
+#pragma unroll
+            for (int i = 0; i < EPL; ++i) O[i] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                if (t < fused_T) {
+                    const float p = __expf(wl[hv * 8 + t] - mn);
+                    L += p;
+                    float vf[EPL];
+                    WTr<WT>::unpack(vvv[t], vf);
+#pragma unroll
+                    for (int i = 0; i < EPL; ++i) O[i] = fmaf(p, vf[i], O[i]);
+                }
+            const float inv = 1.f / L;
+#pragma unroll
+            for (int i = 0; i < EPL; ++i) attn[ev + i] = O[i] * inv;
         }
     }
     __syncthreads();
@@ -346,76 +468,74 @@ __global__ __launch_bounds__(WAVES * 64) void k_wo(const float* __restrict__ par
     float xr[R::NX];
     R::load_x(attn, lane, xr);
     const float d = wave_sum(R::dot(wv, xr));
-    if (lane == 0) x[row] = x[row] + d;
+    if (lane == 0) x[row] = xres + d;
 }
 
 // ------------------------------------------------------------------------------------------------ SwiGLU up
-// One wave per PAIRS (w1[r], w3[r]) pairs of the row-interleaved W13: act[r] = silu(w1[r].xn) * (w3[r].xn)
-template <typename WT, int K, int WAVES, int PAIRS>
+// One wave per (w1[r], w3[r]) pair of the row-interleaved W13: act[r] = silu(w1[r].xn) * (w3[r].xn)
+template <typename WT, int K, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void k_ffn_up(const float* __restrict__ x, const float* __restrict__ norm_w,
                                                        float eps, const WT* __restrict__ W13, float* __restrict__ act,
                                                        int inter) {
     using R = Row<WT, K>;
     const int lane = threadIdx.x & 63;
-    const int r0 = (blockIdx.x * WAVES + (threadIdx.x >> 6)) * PAIRS;
-    if (r0 >= inter) return;
-    typename R::vec wv[2 * PAIRS][R::NCH];
-#pragma unroll
-    for (int p = 0; p < 2 * PAIRS; ++p) R::load_w(W13 + (size_t)(2 * r0 + p) * K, lane, wv[p]);
-    float xr[R::NX];
+    const int r = blockIdx.x * WAVES + (threadIdx.x >> 6);
+    if (r >= inter) return;
+    float xr[R::NX], nr[R::NX];
     R::load_x(x, lane, xr);
-    R::rmsnorm(xr, norm_w, eps, lane);
-#pragma unroll
-    for (int p = 0; p < PAIRS; ++p) {
-        const float a = wave_sum(R::dot(wv[2 * p], xr));
-        const float b = wave_sum(R::dot(wv[2 * p + 1], xr));
-        if (lane == 0) act[r0 + p] = (a / (1.f + __expf(-a))) * b;  // candle silu = x / (1 + exp(-x))
-    }
+    R::load_x(norm_w, lane, nr);
+    typename R::vec w1[R::NCH], w3[R::NCH];
+    R::load_w(W13 + (size_t)(2 * r) * K, lane, w1);
+    R::load_w(W13 + (size_t)(2 * r + 1) * K, lane, w3);
+    R::rmsnorm(xr, nr, eps);
+    const float a = wave_sum(R::dot(w1, xr));
+    const float b = wave_sum(R::dot(w3, xr));
+    if (lane == 0) act[r] = (a / (1.f + __expf(-a))) * b;  // candle silu = x / (1 + exp(-x))
 }
 
 // ------------------------------------------------------------------------------------------------ down + residual
-// One wave per row of W2 (K = inter): x[r] += W2[r,:] . act.  act (K floats) staged once per block in LDS.
-template <typename WT, int K, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void k_ffn_down(const float* __restrict__ act, const WT* __restrict__ W2,
-                                                         float* __restrict__ x, int n_rows) {
-    using R = Row<WT, K>;
-    __shared__ __attribute__((aligned(16))) float sa[K];
+// x[r] += W2[r,:] . act with K = inter split over the KS waves of a block (one row per block): every wave streams
+// K/KS contiguous weights against its own slice of `act` (registers, straight from L2), the KS partial sums meet in LDS
+// and are added in a fixed order.
+template <typename WT, int K, int KS>
+__global__ __launch_bounds__(KS * 64) void k_ffn_down(const float* __restrict__ act, const WT* __restrict__ W2,
+                                                      float* __restrict__ x, int n_rows) {
+    using R = Row<WT, K / KS>;
+    __shared__ float red[KS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = blockIdx.x * WAVES + wave;
-    typename R::vec wv[R::NCH];
-    if (row < n_rows) R::load_w(W2 + (size_t)row * K, lane, wv);
-    for (int e = threadIdx.x * 4; e < K; e += WAVES * 64 * 4)
-        *reinterpret_cast<float4*>(&sa[e]) = *reinterpret_cast<const float4*>(&act[e]);
-    __syncthreads();
-    if (row >= n_rows) return;
+    const int row = blockIdx.x;
+    const float xres = (threadIdx.x == 0) ? x[row] : 0.f;
     float xr[R::NX];
-    R::load_x(sa, lane, xr);
+    R::load_x(act + wave * (K / KS), lane, xr);
+    typename R::vec wv[R::NCH];
+    R::load_w(W2 + (size_t)row * K + wave * (K / KS), lane, wv);
     const float d = wave_sum(R::dot(wv, xr));
-    if (lane == 0) x[row] = x[row] + d;
+    if (lane == 0) red[wave] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = red[0];
+#pragma unroll
+        for (int i = 1; i < KS; ++i) t += red[i];
+        x[row] = xres + t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ norm + head GEMV
-template <typename WT, int K, int WAVES, int ROWS>
+template <typename WT, int K, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void k_head(const float* __restrict__ x, const float* __restrict__ norm_w, float eps,
                                                      const WT* __restrict__ W, int n_rows, float* __restrict__ logits) {
     using R = Row<WT, K>;
     const int lane = threadIdx.x & 63;
-    const int r0 = (blockIdx.x * WAVES + (threadIdx.x >> 6)) * ROWS;
-    if (r0 >= n_rows) return;
-    typename R::vec wv[ROWS][R::NCH];
-#pragma unroll
-    for (int p = 0; p < ROWS; ++p)
-        if (r0 + p < n_rows) R::load_w(W + (size_t)(r0 + p) * K, lane, wv[p]);
-    float xr[R::NX];
+    const int r = blockIdx.x * WAVES + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    float xr[R::NX], nr[R::NX];
     R::load_x(x, lane, xr);
-    R::rmsnorm(xr, norm_w, eps, lane);
-#pragma unroll
-    for (int p = 0; p < ROWS; ++p) {
-        if (r0 + p < n_rows) {
-            const float d = wave_sum(R::dot(wv[p], xr));
-            if (lane == 0) logits[r0 + p] = d;
-        }
-    }
+    R::load_x(norm_w, lane, nr);
+    typename R::vec wv[R::NCH];
+    R::load_w(W + (size_t)r * K, lane, wv);
+    R::rmsnorm(xr, nr, eps);
+    const float d = wave_sum(R::dot(wv, xr));
+    if (lane == 0) logits[r] = d;
 }
 
 // ------------------------------------------------------------------------------------------------ embedding
@@ -758,9 +878,9 @@ static void dispatch_k(int K, F&& f) {
 template <typename WT>
 void LmKernels<WT>::qkv(const ModelDims& d, const float* x, const LayerW& w, const float* cos_t, const float* sin_t,
                         const SeqState* state, int pos_static, int rope_static, float* q_out, KVView kv, hipStream_t st) {
-    constexpr int WAVES = 2;
-    const int n_pairs = (d.H + 2 * d.Hk) * d.Dh / 2;
-    const int grid = (n_pairs + WAVES - 1) / WAVES;
+    constexpr int WAVES = 4;  // two RoPE pairs per block
+    const int n_rows = (d.H + 2 * d.Hk) * d.Dh;
+    const int grid = (n_rows + WAVES - 1) / WAVES;
     dispatch_k(d.dim, [&](auto Kc) {
         constexpr int K = decltype(Kc)::value;
         hipLaunchKernelGGL((k_qkv<WT, K, WAVES>), dim3(grid), dim3(WAVES * 64), 0, st, x, w.attn_norm, d.eps,
@@ -770,15 +890,19 @@ void LmKernels<WT>::qkv(const ModelDims& d, const float* x, const LayerW& w, con
 }
 
 template <typename WT>
-void LmKernels<WT>::attn_decode(const ModelDims& d, const float* q, KVView kv, const SeqState* state, float* part, int nsplit,
-                                hipStream_t st) {
-    const int grid = d.Hk * nsplit;
+int LmKernels<WT>::attn_chunk() { return 4 * AttnGeom<WT>::TW; }
+
+template <typename WT>
+void LmKernels<WT>::attn_decode(const ModelDims& d, const float* q, KVView kv, const SeqState* state, float* part,
+                                int n_chunks_max, hipStream_t st) {
+    const int grid = d.Hk * n_chunks_max;
+    FS_REQUIRE(n_chunks_max <= 128, "attention supports at most 128 chunks per sequence");
     if (d.Dh == 64 && d.n_rep == 8)
-        hipLaunchKernelGGL((k_attn_decode<WT, 64, 8>), dim3(grid), dim3(256), 0, st, q, kv, state, part, d.Hk, nsplit);
+        hipLaunchKernelGGL((k_attn_decode<WT, 64, 8>), dim3(grid), dim3(256), 0, st, q, kv, state, part, d.Hk, n_chunks_max);
     else if (d.Dh == 32 && d.n_rep == 2)
-        hipLaunchKernelGGL((k_attn_decode<WT, 32, 2>), dim3(grid), dim3(256), 0, st, q, kv, state, part, d.Hk, nsplit);
+        hipLaunchKernelGGL((k_attn_decode<WT, 32, 2>), dim3(grid), dim3(256), 0, st, q, kv, state, part, d.Hk, n_chunks_max);
     else if (d.Dh == 64 && d.n_rep == 2)
-        hipLaunchKernelGGL((k_attn_decode<WT, 64, 2>), dim3(grid), dim3(256), 0, st, q, kv, state, part, d.Hk, nsplit);
+        hipLaunchKernelGGL((k_attn_decode<WT, 64, 2>), dim3(grid), dim3(256), 0, st, q, kv, state, part, d.Hk, n_chunks_max);
     else
         throw Error("unsupported attention geometry (head_dim, n_rep) = (" + std::to_string(d.Dh) + ", " +
                     std::to_string(d.n_rep) + ")");
@@ -786,30 +910,33 @@ void LmKernels<WT>::attn_decode(const ModelDims& d, const float* q, KVView kv, c
 }
 
 template <typename WT>
-void LmKernels<WT>::wo(const ModelDims& d, const float* part, int nsplit, const float* q, KVView kv, int fused_T,
-                       const LayerW& w, float* x, hipStream_t st) {
+void LmKernels<WT>::wo(const ModelDims& d, const float* part, int n_chunks_max, const SeqState* state, const float* q, KVView kv,
+                       int fused_T, const LayerW& w, float* x, hipStream_t st) {
     constexpr int WAVES = 4;
     const int grid = (d.dim + WAVES - 1) / WAVES;
-    FS_REQUIRE(fused_T <= 8, "fused attention supports at most 8 cached tokens");
+    FS_REQUIRE(fused_T <= 8 && d.H <= 32 && d.H * 8 * 2 <= WAVES * 64 && d.dim <= 4 * WAVES * 64, "fused attention supports at most 8 cached tokens and 16 heads");
+    FS_REQUIRE(d.Dh == 64 || d.Dh == 32, "unsupported head_dim");
     dispatch_k(d.dim, [&](auto Kc) {
         constexpr int K = decltype(Kc)::value;
-        if (fused_T > 0)
-            hipLaunchKernelGGL((k_wo<WT, K, WAVES, true>), dim3(grid), dim3(WAVES * 64), 0, st, part, nsplit, q, kv, fused_T,
-                               (const WT*)w.wo, x, d.H, d.Hk, d.Dh, d.dim);
-        else
-            hipLaunchKernelGGL((k_wo<WT, K, WAVES, false>), dim3(grid), dim3(WAVES * 64), 0, st, part, nsplit, q, kv, 0,
-                               (const WT*)w.wo, x, d.H, d.Hk, d.Dh, d.dim);
+        auto go = [&](auto fused, auto dh) {
+            hipLaunchKernelGGL((k_wo<WT, K, WAVES, decltype(fused)::value, decltype(dh)::value>), dim3(grid), dim3(WAVES * 64), 0, st,
+                               part, n_chunks_max, attn_chunk(), state, q, kv, fused_T, (const WT*)w.wo, x, d.H, d.Hk, d.dim);
+        };
+        using T = std::true_type; using F = std::false_type;
+        using D64 = std::integral_constant<int, 64>; using D32 = std::integral_constant<int, 32>;
+        if (fused_T > 0) { if (d.Dh == 64) go(T(), D64()); else go(T(), D32()); }
+        else { if (d.Dh == 64) go(F(), D64()); else go(F(), D32()); }
     });
     FS_LAUNCH_CHECK();
 }
 
 template <typename WT>
 void LmKernels<WT>::ffn_up(const ModelDims& d, const float* x, const LayerW& w, float* act, hipStream_t st) {
-    constexpr int WAVES = 4, PAIRS = 2;
-    const int grid = (d.inter + WAVES * PAIRS - 1) / (WAVES * PAIRS);
+    constexpr int WAVES = 4;
+    const int grid = (d.inter + WAVES - 1) / WAVES;
     dispatch_k(d.dim, [&](auto Kc) {
         constexpr int K = decltype(Kc)::value;
-        hipLaunchKernelGGL((k_ffn_up<WT, K, WAVES, PAIRS>), dim3(grid), dim3(WAVES * 64), 0, st, x, w.ffn_norm, d.eps,
+        hipLaunchKernelGGL((k_ffn_up<WT, K, WAVES>), dim3(grid), dim3(WAVES * 64), 0, st, x, w.ffn_norm, d.eps,
                            (const WT*)w.w13, act, d.inter);
     });
     FS_LAUNCH_CHECK();
@@ -817,11 +944,10 @@ void LmKernels<WT>::ffn_up(const ModelDims& d, const float* x, const LayerW& w, 
 
 template <typename WT>
 void LmKernels<WT>::ffn_down(const ModelDims& d, const float* act, const LayerW& w, float* x, hipStream_t st) {
-    constexpr int WAVES = 4;
-    const int grid = (d.dim + WAVES - 1) / WAVES;
+    constexpr int KS = 4;
     dispatch_k(d.inter, [&](auto Kc) {
         constexpr int K = decltype(Kc)::value;
-        hipLaunchKernelGGL((k_ffn_down<WT, K, WAVES>), dim3(grid), dim3(WAVES * 64), 0, st, act, (const WT*)w.w2, x, d.dim);
+        hipLaunchKernelGGL((k_ffn_down<WT, K, KS>), dim3(d.dim), dim3(KS * 64), 0, st, act, (const WT*)w.w2, x, d.dim);
     });
     FS_LAUNCH_CHECK();
 }
@@ -829,11 +955,11 @@ void LmKernels<WT>::ffn_down(const ModelDims& d, const float* act, const LayerW&
 template <typename WT>
 void LmKernels<WT>::head(const ModelDims& d, const float* x, const float* norm_w, const void* W, int n_rows, float* logits,
                          hipStream_t st) {
-    constexpr int WAVES = 4, ROWS = 2;
-    const int grid = (n_rows + WAVES * ROWS - 1) / (WAVES * ROWS);
+    constexpr int WAVES = 4;
+    const int grid = (n_rows + WAVES - 1) / WAVES;
     dispatch_k(d.dim, [&](auto Kc) {
         constexpr int K = decltype(Kc)::value;
-        hipLaunchKernelGGL((k_head<WT, K, WAVES, ROWS>), dim3(grid), dim3(WAVES * 64), 0, st, x, norm_w, d.eps, (const WT*)W,
+        hipLaunchKernelGGL((k_head<WT, K, WAVES>), dim3(grid), dim3(WAVES * 64), 0, st, x, norm_w, d.eps, (const WT*)W,
                            n_rows, logits);
     });
     FS_LAUNCH_CHECK();

@@ -163,12 +163,7 @@ class LM final : public LMBase {
             SeqState s = {};
             s.pos = seq_len_[b]; s.rope_off = input_pos - seq_len_[b]; s.prompt_L = L;
             FS_HIP(hipMemcpyAsync(state(b), &s, sizeof(s), hipMemcpyHostToDevice, st_));
-            for (int l = 0; l < L; ++l) {
-                LmKernels<WT>::embed(d_, tok_emb_, cb_emb_, a_.num_codebooks, a_.codebook_size, d_cfg_.as<SampleCfg>(),
-                                     d_prompt_.as<uint32_t>(), state(b), x(b), st_);
-                enqueue_slow_layers(b);
-                launch_advance(state(b), st_);
-            }
+            prefill_tokens(b, L, /*use_graph=*/false);
             seq_len_[b] += L;
             if (hidden) FS_HIP(hipMemcpyAsync(hidden + (size_t)b * a_.dim, x(b), sizeof(float) * a_.dim, hipMemcpyDeviceToHost, st_));
             if (logits) {
@@ -261,8 +256,9 @@ class LM final : public LMBase {
 
         stats_ = {};
         FS_HIP(hipEventRecord(ev_[0], st_));
-        // prefill: L-1 sequential token steps, then the last prompt token runs as the first frame
-        for (int l = 0; l + 1 < L; ++l) FS_HIP(hipGraphLaunch(g_step_, st_));
+        // prefill: the first L-1 prompt tokens (MFMA chunks of <= 64 tokens for bf16 weights; sequential token steps for
+        // f32 parity handles), then the last prompt token runs as the first frame
+        prefill_tokens(0, L - 1, /*use_graph=*/true);
         LmKernels<WT>::embed(d_, tok_emb_, cb_emb_, C, a_.codebook_size, d_cfg_.as<SampleCfg>(), d_prompt_.as<uint32_t>(), state(0),
                              x(0), st_);
         FS_HIP(hipGraphLaunch(g_frame_, st_));
@@ -530,6 +526,45 @@ class LM final : public LMBase {
         seq_len_[b] = pos;
     }
 
+    // Runs the next `n` prompt tokens (columns state->step ..) of the staged prompt through the slow transformer,
+    // appending their K/V.  Afterwards x(b) holds the pre-norm hidden state of the last processed token.
+    void prefill_tokens(int b, int n, bool use_graph) {
+        if (n <= 0) return;
+        if (LmKernels<WT>::has_mfma_prefill() && n > 1 && a_.dim % 64 == 0 && a_.intermediate_size % 64 == 0) {
+            ensure_prefill_buffers();
+            for (int done = 0; done < n;) {
+                const int M = std::min(64, n - done);
+                LmKernels<WT>::prefill_embed(d_, tok_emb_, cb_emb_, a_.num_codebooks, a_.codebook_size, d_cfg_.as<SampleCfg>(),
+                                             d_prompt_.as<uint32_t>(), state(b), M, d_pfx_.as<float>(), st_);
+                for (int l = 0; l < a_.n_layer; ++l)
+                    LmKernels<WT>::prefill_layer(d_, M, d_pfx_.as<float>(), slow_[l], d_cos_.as<float>(), d_sin_.as<float>(), state(b),
+                                                 slow_kv(l, b), d_pfq_.as<float>(), d_pfpart_.as<float>(), n_chunks_,
+                                                 d_pfattn_.as<float>(), d_pfact_.as<float>(), st_);
+                launch_advance_n(state(b), M, st_);
+                done += M;
+                if (done == n)
+                    FS_HIP(hipMemcpyAsync(x(b), d_pfx_.as<float>() + (size_t)(M - 1) * a_.dim, sizeof(float) * a_.dim,
+                                          hipMemcpyDeviceToDevice, st_));
+            }
+            return;
+        }
+        for (int l = 0; l < n; ++l) {
+            if (use_graph && b == 0) { FS_HIP(hipGraphLaunch(g_step_, st_)); continue; }
+            LmKernels<WT>::embed(d_, tok_emb_, cb_emb_, a_.num_codebooks, a_.codebook_size, d_cfg_.as<SampleCfg>(),
+                                 d_prompt_.as<uint32_t>(), state(b), x(b), st_);
+            enqueue_slow_layers(b);
+            launch_advance(state(b), st_);
+        }
+    }
+    void ensure_prefill_buffers() {
+        if (d_pfx_.p) return;
+        d_pfx_.alloc(sizeof(float) * 64 * a_.dim);
+        d_pfq_.alloc(sizeof(float) * 64 * a_.dim);
+        d_pfattn_.alloc(sizeof(float) * 64 * a_.dim);
+        d_pfact_.alloc(sizeof(float) * 64 * a_.intermediate_size);
+        d_pfpart_.alloc(sizeof(float) * 64 * (size_t)a_.n_head * n_chunks_ * (a_.head_dim + 2));
+    }
+
     // ---- kernel sequences
     void enqueue_slow_layers(int b) {
         for (int l = 0; l < a_.n_layer; ++l) {
@@ -611,6 +646,7 @@ class LM final : public LMBase {
     // activations / state
     DevBuf d_x_, d_xf_, d_q_, d_part_, d_act_, d_logits_slow_, d_logits_fast_, d_state_, d_cfg_, d_rng_, d_prompt_, d_out_;
     DevBuf d_rp_mask_, d_rp_seen_, d_rp_ring_, d_rp_meta_;
+    DevBuf d_pfx_, d_pfq_, d_pfattn_, d_pfact_, d_pfpart_;  // chunked-prefill activations (64 tokens)
     RepPenState rp_ = {};
     void* h_pin_ = nullptr;
     hipGraphExec_t g_frame_ = nullptr, g_step_ = nullptr;

@@ -78,6 +78,17 @@ struct LmKernels {
     // state->step (prompt != null) or from state->cur
     static void embed(const ModelDims& d, const void* tok_emb, const void* cb_emb, int n_cb, int cb_size,
                       const SampleCfg* cfg, const uint32_t* prompt, SeqState* state, float* x, hipStream_t st);
+    // ---- chunked prefill (M <= 64 prompt tokens per pass; MFMA skinny GEMMs, bf16 weights only)
+    static bool has_mfma_prefill();
+    // X[m] = embed(prompt column state->step + m), m < M
+    static void prefill_embed(const ModelDims& d, const void* tok_emb, const void* cb_emb, int n_cb, int cb_size,
+                              const SampleCfg* cfg, const uint32_t* prompt, const SeqState* state, int M, float* X,
+                              hipStream_t st);
+    // one transformer block over the M tokens at positions state->pos .. state->pos + M - 1 (X updated in place):
+    // rmsnorm+Wqkv+rope+KV append | causal attention over the paged cache | Wo + residual | rmsnorm+W13+SwiGLU | W2 + residual
+    static void prefill_layer(const ModelDims& d, int M, float* X, const LayerW& w, const float* cos_t, const float* sin_t,
+                              const SeqState* state, KVView kv, float* Q, float* part, int n_chunks_max, float* attn,
+                              float* act, hipStream_t st);
     // fast_embeddings gather: out[i] = fast_emb[ids[i]]
     static void fast_embed(const ModelDims& d, const void* fast_emb, const uint32_t* ids, int n, float* out,
                            hipStream_t st);
@@ -118,6 +129,7 @@ struct SampleKernels {
 };
 
 void launch_advance(SeqState* state, hipStream_t st);  // pos++, step++ (sequential prefill step)
+void launch_advance_n(SeqState* state, int n, hipStream_t st);  // pos += n, step += n (chunked prefill)
 void launch_reppen_reset(RepPenState rp, int n_cb, int cb_size, hipStream_t st);
 
 // synthetic tensor fill (fs_synth.h): n_rows x n_cols, destination row = r * row_mul + row_off (W1/W3 interleave)

@@ -214,9 +214,12 @@ template <typename WT> struct AttnGeom { static constexpr int TW = 32; };
 template <> struct AttnGeom<float> { static constexpr int TW = 16; };
 
 template <typename WT, int DH, int NREP>
-__global__ __launch_bounds__(256) void k_attn_decode(const float* __restrict__ q, KVView kv,
-                                                     const SeqState* __restrict__ state, float* __restrict__ part,
+__global__ __launch_bounds__(256) void k_attn_decode(const float* __restrict__ q_all, KVView kv,
+                                                     const SeqState* __restrict__ state, float* __restrict__ part_all,
                                                      int Hk, int n_chunks_max) {
+    // blockIdx.y = query token m of a prefill chunk (0 for decode): it sees the KV prefix of length pos + 1 + m
+    const float* q = q_all + (size_t)blockIdx.y * Hk * NREP * DH;
+    float* part = part_all + (size_t)blockIdx.y * Hk * NREP * n_chunks_max * (DH + 2);
     constexpr int EPL = WTr<WT>::EPL;
     constexpr int LPT = DH / EPL;            // lanes per head row
     constexpr int G = 64 / LPT;              // lane groups per wave
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(256) void k_attn_decode(const float* __restrict__ q
     static_assert(TW % NTS == 0 && NLD >= 1, "attention geometry");
     using vec = typename WTr<WT>::vec;
     const int g = blockIdx.x / n_chunks_max, c = blockIdx.x % n_chunks_max;
-    const int T = state->pos + 1;  // the current token's K/V were appended by k_qkv
+    const int T = state->pos + 1 + (int)blockIdx.y;  // the current token's K/V were appended by k_qkv
     if (c * CH >= T) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __shared__ __attribute__((aligned(16))) WT sk[4][TW * DH];
@@ -575,6 +578,199 @@ __global__ void k_fast_embed(const WT* __restrict__ fast_emb, int dim, const uin
 __global__ void k_advance(SeqState* state) {
     state->pos += 1;
     state->step += 1;
+}
+
+// ------------------------------------------------------------------------------------------------ chunked prefill (MFMA)
+// Prompt tokens are processed M <= 64 at a time with the SAME fused stages as the decode step, but the GEMVs become
+// skinny GEMMs on the matrix cores: Y[M, N] = f(A[M, K]) . W[N, K]^T with bf16 weights streamed once per chunk.
+// Numerics: activations stay f32 end to end -- each K-slice of A is split into bf16 hi + bf16 lo parts (a = hi + lo up
+// to 2^-17 relative) and both parts go through v_mfma_f32_16x16x32_bf16 with f32 accumulation, so prefill agrees with
+// the f32-activation decode path far below bf16 resolution (the reference's own CUDA path rounds activations to bf16).
+// Tile: block = 4 waves x 16 weight rows = 64 rows of W, all <= 64 tokens (4 MFMA column tiles); A-operand = weights
+// straight from global (lane l: row l&15, 16 B at k = (l>>4)*8), B-operand = staged activations from LDS.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+constexpr int PF_M = 64;    // max tokens per chunk
+constexpr int PF_BK = 64;   // K-slice
+constexpr int PF_LD = PF_BK + 8;
+
+enum { EPI_STORE = 0, EPI_RESIDUAL = 1, EPI_SWIGLU = 2, EPI_QKV = 3 };
+
+template <int EPI, bool NORM>
+__global__ __launch_bounds__(256) void k_gemm_skinny(const float* __restrict__ A, int lda, int M, int K,
+                                                     const float* __restrict__ norm_w, float eps,
+                                                     const bf16_t* __restrict__ W, int N, float* __restrict__ Y, int ldy,
+                                                     const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                                                     const SeqState* __restrict__ state, KVView kv, int H, int Hk, int Dh) {
+    __shared__ __attribute__((aligned(16))) bf16_t xs_hi[PF_M * PF_LD];
+    __shared__ __attribute__((aligned(16))) bf16_t xs_lo[PF_M * PF_LD];
+    __shared__ float rinv[PF_M];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n0 = blockIdx.x * 64 + wave * 16;  // this wave's 16 weight rows
+    if (NORM) {
+        for (int m = wave; m < PF_M; m += 4) {
+            float ss = 0.f;
+            if (m < M)
+                for (int k = lane * 4; k < K; k += 256) {
+                    const float4 t = *reinterpret_cast<const float4*>(A + (size_t)m * lda + k);
+                    ss = fmaf(t.x, t.x, ss); ss = fmaf(t.y, t.y, ss); ss = fmaf(t.z, t.z, ss); ss = fmaf(t.w, t.w, ss);
+                }
+            ss = wave_sum(ss);
+            if (lane == 0) rinv[m] = 1.0f / sqrtf(ss / (float)K + eps);
+        }
+        __syncthreads();
+    }
+    f32x4v acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    const int wrow = min(n0 + (lane & 15), N - 1);
+    const bf16_t* wp = W + (size_t)wrow * K + (lane >> 4) * 8;
+    u32x4 wf[2], wn[2];
+    wf[0] = ld_stream(reinterpret_cast<const u32x4*>(wp));
+    wf[1] = ld_stream(reinterpret_cast<const u32x4*>(wp + 32));
+    const int sm = threadIdx.x >> 2, sk = (threadIdx.x & 3) * 16;  // staging: token sm, 16 consecutive k
+    for (int kb = 0; kb < K; kb += PF_BK) {
+        // stage A[:, kb : kb + 64] as bf16 hi / lo
+        {
+            float a[16];
+#pragma unroll
+            for (int i = 0; i < 16; i += 4) {
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (sm < M) t = *reinterpret_cast<const float4*>(A + (size_t)sm * lda + kb + sk + i);
+                a[i] = t.x; a[i + 1] = t.y; a[i + 2] = t.z; a[i + 3] = t.w;
+            }
+            if (NORM) {
+                const float r = rinv[sm];
+#pragma unroll
+                for (int i = 0; i < 16; i += 4) {
+                    const float4 nw = *reinterpret_cast<const float4*>(norm_w + kb + sk + i);
+                    a[i] = (a[i] * r) * nw.x; a[i + 1] = (a[i + 1] * r) * nw.y;
+                    a[i + 2] = (a[i + 2] * r) * nw.z; a[i + 3] = (a[i + 3] * r) * nw.w;
+                }
+            }
+            bf16_t hi[16], lo[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                hi[i] = WTr<bf16_t>::from_f32(a[i]);
+                lo[i] = WTr<bf16_t>::from_f32(a[i] - WTr<bf16_t>::to_f32(hi[i]));
+            }
+            u32x4* dh = reinterpret_cast<u32x4*>(&xs_hi[sm * PF_LD + sk]);
+            u32x4* dl = reinterpret_cast<u32x4*>(&xs_lo[sm * PF_LD + sk]);
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                u32x4 ph, pl;
+                ph.x = hi[v * 8] | ((uint32_t)hi[v * 8 + 1] << 16); ph.y = hi[v * 8 + 2] | ((uint32_t)hi[v * 8 + 3] << 16);
+                ph.z = hi[v * 8 + 4] | ((uint32_t)hi[v * 8 + 5] << 16); ph.w = hi[v * 8 + 6] | ((uint32_t)hi[v * 8 + 7] << 16);
+                pl.x = lo[v * 8] | ((uint32_t)lo[v * 8 + 1] << 16); pl.y = lo[v * 8 + 2] | ((uint32_t)lo[v * 8 + 3] << 16);
+                pl.z = lo[v * 8 + 4] | ((uint32_t)lo[v * 8 + 5] << 16); pl.w = lo[v * 8 + 6] | ((uint32_t)lo[v * 8 + 7] << 16);
+                dh[v] = ph; dl[v] = pl;
+            }
+        }
+        if (kb + PF_BK < K) {  // prefetch the next slice's weight fragments
+            wn[0] = ld_stream(reinterpret_cast<const u32x4*>(wp + kb + PF_BK));
+            wn[1] = ld_stream(reinterpret_cast<const u32x4*>(wp + kb + PF_BK + 32));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 af = __builtin_bit_cast(bf16x8, wf[ks]);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int off = (mt * 16 + (lane & 15)) * PF_LD + ks * 32 + (lane >> 4) * 8;
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&xs_hi[off]));
+                const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&xs_lo[off]));
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bh, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bl, acc[mt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        wf[0] = wn[0]; wf[1] = wn[1];
+    }
+    // epilogue: lane holds C[row = n0 + (lane>>4)*4 + i][token = mt*16 + (lane&15)], i = 0..3
+    const int r0 = n0 + (lane >> 4) * 4;
+    if (r0 >= N) return;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = mt * 16 + (lane & 15);
+        if (m >= M) continue;
+        const f32x4v c = acc[mt];
+        if (EPI == EPI_STORE) {
+            *reinterpret_cast<float4*>(Y + (size_t)m * ldy + r0) = make_float4(c.x, c.y, c.z, c.w);
+        } else if (EPI == EPI_RESIDUAL) {
+            float4* yp = reinterpret_cast<float4*>(Y + (size_t)m * ldy + r0);
+            const float4 o = *yp;
+            *yp = make_float4(o.x + c.x, o.y + c.y, o.z + c.z, o.w + c.w);
+        } else if (EPI == EPI_SWIGLU) {  // interleaved rows (2r, 2r+1) = (w1[r], w3[r])
+            float2 o;
+            o.x = (c.x / (1.f + __expf(-c.x))) * c.y;
+            o.y = (c.z / (1.f + __expf(-c.z))) * c.w;
+            *reinterpret_cast<float2*>(Y + (size_t)m * ldy + r0 / 2) = o;
+        } else {  // EPI_QKV: rope_i + scatter (q -> Y[m][r], k/v -> paged cache at pos + m)
+            const int pos = state->pos + m, rpos = pos + state->rope_off;
+            const int qdim = H * Dh, kdim = Hk * Dh, half = Dh / 2;
+            const float vals[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const int r = r0 + 2 * pr;
+                const float a = vals[2 * pr], b = vals[2 * pr + 1];
+                if (r < qdim + kdim) {
+                    const int j = (r % Dh) / 2;
+                    const float cs = cos_t[(size_t)rpos * half + j], sn = sin_t[(size_t)rpos * half + j];
+                    const float o0 = a * cs - b * sn, o1 = a * sn + b * cs;
+                    if (r < qdim) { Y[(size_t)m * ldy + r] = o0; Y[(size_t)m * ldy + r + 1] = o1; }
+                    else {
+                        const int rk = r - qdim;
+                        bf16_t* dst = kv_addr<bf16_t>(kv.k, kv.page_table, pos, rk / Dh, Hk, Dh) + rk % Dh;
+                        dst[0] = WTr<bf16_t>::from_f32(o0); dst[1] = WTr<bf16_t>::from_f32(o1);
+                    }
+                } else {
+                    const int rv = r - qdim - kdim;
+                    bf16_t* dst = kv_addr<bf16_t>(kv.v, kv.page_table, pos, rv / Dh, Hk, Dh) + rv % Dh;
+                    dst[0] = WTr<bf16_t>::from_f32(a); dst[1] = WTr<bf16_t>::from_f32(b);
+                }
+            }
+        }
+    }
+}
+
+// combine the per-chunk attention partials of M query tokens: attn[m][h*DH + dd]
+template <int DH>
+__global__ __launch_bounds__(256) void k_attn_combine(const float* __restrict__ part_all, int n_chunks_max, int chunk,
+                                                      const SeqState* __restrict__ state, float* __restrict__ attn, int H) {
+    const int m = blockIdx.x;
+    const int T = state->pos + 1 + m, nc = (T + chunk - 1) / chunk;
+    const float* part = part_all + (size_t)m * H * n_chunks_max * (DH + 2);
+    __shared__ float wl[32 * 128];
+    for (int h = threadIdx.x; h < H; h += 256) {
+        const float* p = part + (size_t)h * n_chunks_max * (DH + 2);
+        float mn = -1e30f;
+        for (int c = 0; c < nc; ++c) mn = fmaxf(mn, p[c * (DH + 2) + DH]);
+        float L = 0.f;
+        for (int c = 0; c < nc; ++c) L += p[c * (DH + 2) + DH + 1] * __expf(p[c * (DH + 2) + DH] - mn);
+        const float inv = 1.f / L;
+        for (int c = 0; c < nc; ++c) wl[h * 128 + c] = __expf(p[c * (DH + 2) + DH] - mn) * inv;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < H * DH; e += 256) {
+        const int h = e / DH, dd = e % DH;
+        const float* p = part + (size_t)h * n_chunks_max * (DH + 2) + dd;
+        float O = 0.f;
+        for (int c = 0; c < nc; ++c) O = fmaf(wl[h * 128 + c], p[c * (DH + 2)], O);
+        attn[(size_t)m * H * DH + e] = O;
+    }
+}
+
+template <typename WT>
+__global__ void k_embed_rows(const WT* __restrict__ tok_emb, const WT* __restrict__ cb_emb, int dim, int n_cb, int cb_size,
+                             const SampleCfg* __restrict__ cfg, const uint32_t* __restrict__ prompt,
+                             const SeqState* __restrict__ state, float* __restrict__ X) {
+    embed_tokens<WT>(tok_emb, cb_emb, dim, n_cb, cb_size, cfg->sem_lo, cfg->sem_hi, prompt + state->step + blockIdx.x,
+                     state->prompt_L, X + (size_t)blockIdx.x * dim, threadIdx.x, blockDim.x);
+}
+
+__global__ void k_advance_n(SeqState* state, int n) {
+    state->pos += n;
+    state->step += n;
 }
 
 // ------------------------------------------------------------------------------------------------ sampling
@@ -1023,6 +1219,62 @@ void launch_convert_rows(WT* dst, const float* src, int64_t n_rows, int64_t n_co
     const int grid = (int)std::min<long long>((n + 255) / 256, 4096);
     hipLaunchKernelGGL((k_convert_rows<WT>), dim3(grid), dim3(256), 0, st, dst, src, (long long)n_rows, (long long)n_cols,
                        row_mul, row_off);
+    FS_LAUNCH_CHECK();
+}
+
+// ---- chunked prefill launchers (bf16 weights only; f32 handles take the sequential decode-kernel path)
+template <typename WT>
+bool LmKernels<WT>::has_mfma_prefill() { return std::is_same<WT, bf16_t>::value; }
+
+template <typename WT>
+void LmKernels<WT>::prefill_embed(const ModelDims& d, const void* tok_emb, const void* cb_emb, int n_cb, int cb_size,
+                                  const SampleCfg* cfg, const uint32_t* prompt, const SeqState* state, int M, float* X,
+                                  hipStream_t st) {
+    hipLaunchKernelGGL((k_embed_rows<WT>), dim3(M), dim3(256), 0, st, (const WT*)tok_emb, (const WT*)cb_emb, d.dim, n_cb, cb_size,
+                       cfg, prompt, state, X);
+    FS_LAUNCH_CHECK();
+}
+
+template <typename WT>
+void LmKernels<WT>::prefill_layer(const ModelDims& d, int M, float* X, const LayerW& w, const float* cos_t, const float* sin_t,
+                                  const SeqState* state, KVView kv, float* Q, float* part, int n_chunks_max, float* attn,
+                                  float* act, hipStream_t st) {
+    if constexpr (!std::is_same<WT, bf16_t>::value) {
+        throw Error("MFMA prefill is implemented for bf16 weights only");
+    } else {
+        FS_REQUIRE(M >= 1 && M <= PF_M, "prefill chunk larger than 64 tokens");
+        FS_REQUIRE(d.dim % PF_BK == 0 && d.inter % PF_BK == 0, "prefill needs dim and intermediate_size multiples of 64");
+        const int qkv_rows = (d.H + 2 * d.Hk) * d.Dh;
+        const bf16_t* nul = nullptr;
+        (void)nul;
+        hipLaunchKernelGGL((k_gemm_skinny<EPI_QKV, true>), dim3((qkv_rows + 63) / 64), dim3(256), 0, st, X, d.dim, M, d.dim,
+                           w.attn_norm, d.eps, (const bf16_t*)w.wqkv, qkv_rows, Q, d.dim, cos_t, sin_t, state, kv, d.H, d.Hk, d.Dh);
+        const dim3 ga(d.Hk * n_chunks_max, M);
+        if (d.Dh == 64 && d.n_rep == 8)
+            hipLaunchKernelGGL((k_attn_decode<WT, 64, 8>), ga, dim3(256), 0, st, Q, kv, state, part, d.Hk, n_chunks_max);
+        else if (d.Dh == 32 && d.n_rep == 2)
+            hipLaunchKernelGGL((k_attn_decode<WT, 32, 2>), ga, dim3(256), 0, st, Q, kv, state, part, d.Hk, n_chunks_max);
+        else if (d.Dh == 64 && d.n_rep == 2)
+            hipLaunchKernelGGL((k_attn_decode<WT, 64, 2>), ga, dim3(256), 0, st, Q, kv, state, part, d.Hk, n_chunks_max);
+        else
+            throw Error("unsupported attention geometry");
+        if (d.Dh == 64)
+            hipLaunchKernelGGL((k_attn_combine<64>), dim3(M), dim3(256), 0, st, part, n_chunks_max, attn_chunk(), state, attn, d.H);
+        else
+            hipLaunchKernelGGL((k_attn_combine<32>), dim3(M), dim3(256), 0, st, part, n_chunks_max, attn_chunk(), state, attn, d.H);
+        KVView nokv = {};
+        hipLaunchKernelGGL((k_gemm_skinny<EPI_RESIDUAL, false>), dim3((d.dim + 63) / 64), dim3(256), 0, st, attn, d.dim, M, d.dim,
+                           nullptr, 0.f, (const bf16_t*)w.wo, d.dim, X, d.dim, nullptr, nullptr, nullptr, nokv, 0, 0, 0);
+        hipLaunchKernelGGL((k_gemm_skinny<EPI_SWIGLU, true>), dim3((2 * d.inter + 63) / 64), dim3(256), 0, st, X, d.dim, M, d.dim,
+                           w.ffn_norm, d.eps, (const bf16_t*)w.w13, 2 * d.inter, act, d.inter, nullptr, nullptr, nullptr, nokv, 0, 0, 0);
+        hipLaunchKernelGGL((k_gemm_skinny<EPI_RESIDUAL, false>), dim3((d.dim + 63) / 64), dim3(256), 0, st, act, d.inter, M, d.inter,
+                           nullptr, 0.f, (const bf16_t*)w.w2, d.dim, X, d.dim, nullptr, nullptr, nullptr, nokv, 0, 0, 0);
+        FS_LAUNCH_CHECK();
+    }
+}
+
+void launch_advance_n(SeqState* state, int n, hipStream_t st) {
+    hipLaunchKernelGGL(k_advance_n, dim3(1), dim3(1), 0, st, state, n);
     FS_LAUNCH_CHECK();
 }
 

@@ -6,7 +6,7 @@ cd "$HERE/csrc"
 mkdir -p "$HERE/build"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -ffp-contract=on"
 pids=()
-for f in lm_kernels.hip lm_engine.hip codec_engine.hip fishrt_api.cpp; do
+for f in lm_kernels.hip lm_engine.hip codec_kernels.hip codec_engine.hip fishrt_api.cpp; do
   o="$HERE/build/${f%.*}.o"
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ -n "$(find . -name '*.h' -newer "$o" -print -quit)" ] || [ "../../include/fishrt.h" -nt "$o" ]; then
     ( /opt/rocm/bin/hipcc $FLAGS -x hip -c "$f" -o "$o" ) &

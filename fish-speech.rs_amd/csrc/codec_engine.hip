@@ -1,8 +1,250 @@
-// Firefly vocoder engine -- placeholder until the HIP kernels land (next milestone); fails loudly, never falls back.
+// Host-side engine of the Firefly-GAN-VQ vocoder: FireflyCodec::decode (fish_speech_core/lib/codec/firefly.rs:42-48)
+//   -> FireflyDecoder::decode (decoder.rs:37-68) -> quantizer.decode (quantizer.rs:135-146) -> upsample (:126-133)
+//   -> HiFiGAN::forward (hifi_gan.rs:208-216).  Configuration = FireflyConfig::get_config_for(1.4 | 1.5)
+//   (codec/config.rs:155-167,98-113,196-202); `channel_div` scales every channel count down for tests.
 #include "codec_engine.h"
 
+#include <cmath>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "codec_kernels.h"
 #include "fs_common.h"
+#include "fs_synth.h"
+#include "safetensors.h"
 
 namespace fs {
-CodecBase* make_codec(int, int) { throw Error("fs_codec: HIP vocoder kernels not built into this libfishrt yet"); }
+
+namespace {
+struct DBuf {
+    void* p = nullptr;
+    size_t n = 0;
+    void alloc(size_t bytes) { free(); n = bytes; if (bytes) FS_HIP(hipMalloc(&p, bytes)); }
+    void ensure(size_t bytes) { if (bytes > n) alloc(bytes); }
+    void free() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    ~DBuf() { free(); }
+    float* f() const { return (float*)p; }
+};
+struct Tensor {  // one checkpoint tensor
+    std::string name;
+    std::vector<int64_t> shape;
+    float mean;
+    double stdv;
+    size_t off;  // float offset in the raw arena
+    size_t numel() const { size_t n = 1; for (auto s : shape) n *= (size_t)s; return n; }
+};
+struct ConvSpec { int raw, relaid, bias, cout, cin_g, k; bool transposed; };
+}  // namespace
+
+class Codec final : public CodecBase {
+  public:
+    Codec(int device, int channel_div) : device_(device) {
+        FS_REQUIRE(channel_div >= 1 && 512 % channel_div == 0 && (512 / channel_div) % 64 == 0 || channel_div == 8,
+                   "channel_div must keep the width a multiple of 64");
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+            throw Error("no HIP device visible: libfishrt has no CPU fallback (MI355X / gfx950 required)");
+        FS_REQUIRE(device >= 0 && device < ndev, "device_id out of range");
+        FS_HIP(hipSetDevice(device));
+        hipDeviceProp_t prop;
+        FS_HIP(hipGetDeviceProperties(&prop, device));
+        if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+            throw Error(std::string("libfishrt kernels are built for gfx950 only; device reports ") + prop.gcnArchName);
+        FS_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+        C_ = 512 / channel_div;  // quantizer input_dim == HiFiGAN upsample_initial_channel (config.rs:98-113,155-167)
+        plan();
+        raw_.alloc(raw_floats_ * sizeof(float));
+        relaid_.alloc(relaid_floats_ * sizeof(float));
+    }
+    ~Codec() override {
+        (void)hipSetDevice(device_);
+        if (st_) { (void)hipStreamSynchronize(st_); (void)hipStreamDestroy(st_); }
+    }
+
+    void load_synthetic(uint64_t seed) override {
+        FS_HIP(hipSetDevice(device_));
+        for (const auto& t : tensors_)
+            codec_synth_fill(raw_.f() + t.off, synth_fnv1a64(t.name.c_str()) ^ seed, t.numel(), t.mean, synth_scale(t.stdv), st_);
+        relayout();
+        loaded_ = true;
+    }
+    void load_safetensors(const std::string& path) override {
+        FS_HIP(hipSetDevice(device_));
+        SafeTensors sf(path);
+        std::vector<float> host;
+        for (const auto& t : tensors_) {
+            const StTensor* s = sf.find(t.name);
+            if (!s) throw Error("cannot find tensor " + t.name);
+            if ((size_t)s->numel() != t.numel()) throw Error("shape mismatch for " + t.name);
+            host.resize(t.numel());
+            SafeTensors::to_f32(*s, host.data());
+            FS_HIP(hipMemcpyAsync(raw_.f() + t.off, host.data(), host.size() * 4, hipMemcpyHostToDevice, st_));
+            FS_HIP(hipStreamSynchronize(st_));
+        }
+        relayout();
+        loaded_ = true;
+    }
+    int sample_rate() override { return 44100; }  // SpecTransformConfig (config.rs:13-22)
+
+    void decode(const uint32_t* codes, int B, int T, float* pcm_out) override {
+        FS_HIP(hipSetDevice(device_));
+        FS_REQUIRE(loaded_, "weights not loaded: call fs_codec_load_safetensors or fs_codec_load_synthetic first");
+        FS_REQUIRE(B >= 1 && T >= 1, "empty input");
+        const int G = 8;
+        for (size_t i = 0; i < (size_t)B * G * T; ++i)
+            if (codes[i] >= 1000u) throw Error("FSQ index out of range (gather out of bounds)");
+        const size_t max_elems = (size_t)B * C_ * 4 * T * 8;  // largest activation: (C/2) x 32T .. (C/32) x 2048T = C*64*T
+        (void)max_elems;
+        const size_t act = (size_t)B * (size_t)C_ * 64 * T;   // every HiFiGAN stage holds C * 64 * T / 2^(i+1) * 2^... <= C*64*T... see stages
+        for (auto& b : buf_) b.ensure(act * sizeof(float));
+        dcodes_.ensure(sizeof(uint32_t) * B * G * T);
+        FS_HIP(hipMemcpyAsync(dcodes_.p, codes, sizeof(uint32_t) * B * G * T, hipMemcpyHostToDevice, st_));
+        float *x = buf_[0].f(), *t1 = buf_[1].f(), *t2 = buf_[2].f(), *r = buf_[3].f(), *acc0 = buf_[4].f(), *acc1 = buf_[5].f(),
+              *acc2 = buf_[6].f();
+        // quantizer.decode: FSQ lookup + project_out, concat groups -> (B, C, T)
+        codec_fsq_project((const uint32_t*)dcodes_.p, B, G, T, R(proj_w_), R(proj_b_), C_ / G, x, st_);
+        int Tc = T;
+        // upsample.0 then upsample.1 (quantizer.rs:126-133): transposed conv (k = s = 2) + ConvNeXt block
+        for (int i = 0; i < 2; ++i) {
+            codec_tconv1d(x, B, C_, Tc, conv(up_conv_[i]), 2, false, t1, st_);
+            Tc *= 2;
+            const CnxSpec& c = cnx_[i];
+            codec_dwconv_ln(t1, B, C_, Tc, R(c.dw), R(c.db), R(c.lnw), R(c.lnb), t2, st_);
+            codec_conv1d(t2, B, C_, Tc, conv(c.pw1), 1, false, CODEC_EPI_GELU, nullptr, nullptr, r, st_);
+            codec_conv1d(r, B, 4 * C_, Tc, conv(c.pw2), 1, false, CODEC_EPI_GAMMA_RES, t1, R(c.gamma), x, st_);
+        }
+        // HiFiGAN (hifi_gan.rs:208-216)
+        codec_conv1d(x, B, C_, Tc, conv(conv_pre_), 1, false, CODEC_EPI_NONE, nullptr, nullptr, t1, st_);
+        std::swap(x, t1);
+        const int rates[5] = {8, 8, 2, 2, 2}, dils[3] = {1, 3, 5};
+        int ch = C_;
+        for (int s = 0; s < 5; ++s) {
+            codec_tconv1d(x, B, ch, Tc, conv(ups_[s]), rates[s], true, t1, st_);  // ups[i](silu(x))
+            ch /= 2; Tc *= rates[s];
+            float* accs[3] = {acc0, acc1, acc2};
+            for (int j = 0; j < 3; ++j) {  // ResBlock1 (hifi_gan.rs:74-85): x += c2(silu(c1(silu(x)))), both convs dilated
+                const float* cur = t1;
+                for (int m = 0; m < 3; ++m) {
+                    codec_conv1d(cur, B, ch, Tc, conv(res_[s][j][0][m]), dils[m], true, CODEC_EPI_NONE, nullptr, nullptr, t2, st_);
+                    codec_conv1d(t2, B, ch, Tc, conv(res_[s][j][1][m]), dils[m], true, CODEC_EPI_RES, cur, nullptr, accs[j], st_);
+                    cur = accs[j];
+                }
+            }
+            codec_mean3(acc0, acc1, acc2, x, (size_t)B * ch * Tc, st_);
+        }
+        codec_conv1d(x, B, ch, Tc, conv(conv_post_), 1, true, CODEC_EPI_TANH, nullptr, nullptr, t1, st_);
+        FS_HIP(hipMemcpyAsync(pcm_out, t1, sizeof(float) * (size_t)B * Tc, hipMemcpyDeviceToHost, st_));
+        FS_HIP(hipStreamSynchronize(st_));
+    }
+
+  private:
+    struct CnxSpec { int dw, db, lnw, lnb, pw1, pw2, gamma; };
+
+    const float* R(int tensor_idx) const { return raw_.f() + tensors_[tensor_idx].off; }
+    ConvW conv(int spec_idx) const {
+        const ConvSpec& s = convs_[spec_idx];
+        ConvW w;
+        w.wt = relaid_.f() + relaid_off_[spec_idx];
+        w.b = R(s.bias);
+        w.cout = s.cout; w.k = s.k;
+        return w;
+    }
+    int add_tensor(const std::string& name, std::vector<int64_t> shape, float mean, double stdv) {
+        Tensor t{name, std::move(shape), mean, stdv, raw_floats_};
+        raw_floats_ += (t.numel() + 63) & ~(size_t)63;
+        tensors_.push_back(t);
+        return (int)tensors_.size() - 1;
+    }
+    // Conv1d `name.conv.weight [cout, cin_g, k]` / ConvTranspose1d `[cin, cout, k]` + `name.conv.bias [cout]`
+    // (1.4+ names: codec/utils/mod.rs:28-40,84-96).  Synthetic init: N(0, 1/fan_in), bias N(0, 0.02^2).
+    int add_conv(const std::string& name, int cout, int cin_g, int k, bool transposed, double fan_in) {
+        ConvSpec s;
+        s.raw = transposed ? add_tensor(name + ".conv.weight", {cin_g, cout, k}, 0.f, 1.0 / std::sqrt(fan_in))
+                           : add_tensor(name + ".conv.weight", {cout, cin_g, k}, 0.f, 1.0 / std::sqrt(fan_in));
+        s.bias = add_tensor(name + ".conv.bias", {cout}, 0.f, 0.02);
+        s.cout = cout; s.cin_g = cin_g; s.k = k; s.transposed = transposed;
+        relaid_off_.push_back(relaid_floats_);
+        relaid_floats_ += ((size_t)cout * cin_g * k + 63) & ~(size_t)63;
+        convs_.push_back(s);
+        return (int)convs_.size() - 1;
+    }
+    int add_linear_as_conv(const std::string& name, int cout, int cin, double fan_in) {  // pwconv{1,2}.{weight,bias}
+        ConvSpec s;
+        s.raw = add_tensor(name + ".weight", {cout, cin}, 0.f, 1.0 / std::sqrt(fan_in));
+        s.bias = add_tensor(name + ".bias", {cout}, 0.f, 0.02);
+        s.cout = cout; s.cin_g = cin; s.k = 1; s.transposed = false;
+        relaid_off_.push_back(relaid_floats_);
+        relaid_floats_ += ((size_t)cout * cin + 63) & ~(size_t)63;
+        convs_.push_back(s);
+        return (int)convs_.size() - 1;
+    }
+    void plan() {
+        const int G = 8, dg = C_ / G;
+        // project_out of every group packed as [G][dg][4] / [G][dg]: one tensor per group in the checkpoint
+        proj_w_ = (int)tensors_.size();
+        for (int g = 0; g < G; ++g)
+            add_tensor("quantizer.residual_fsq.rvqs." + std::to_string(g) + ".project_out.weight", {dg, 4}, 0.f, 0.5);
+        proj_b_ = (int)tensors_.size();
+        for (int g = 0; g < G; ++g) add_tensor("quantizer.residual_fsq.rvqs." + std::to_string(g) + ".project_out.bias", {dg}, 0.f, 0.02);
+        // the packed views require contiguity: [dg*4] and [dg] are multiples of 64 floats only when dg % 16 == 0 / dg % 64 == 0,
+        // so the group tensors are packed without padding instead:
+        repack_groups(proj_w_, G, (size_t)dg * 4);
+        repack_groups(proj_b_, G, (size_t)dg);
+        for (int i = 0; i < 2; ++i) {
+            const std::string p = "quantizer.upsample." + std::to_string(i);
+            up_conv_[i] = add_conv(p + ".0", C_, C_, 2, true, (double)C_);
+            CnxSpec c;
+            const std::string q = p + ".1";
+            c.dw = add_tensor(q + ".dwconv.conv.weight", {C_, 1, 7}, 0.f, 1.0 / std::sqrt(7.0));
+            c.db = add_tensor(q + ".dwconv.conv.bias", {C_}, 0.f, 0.02);
+            c.lnw = add_tensor(q + ".norm.weight", {C_}, 1.f, 0.1);
+            c.lnb = add_tensor(q + ".norm.bias", {C_}, 0.f, 0.02);
+            c.pw1 = add_linear_as_conv(q + ".pwconv1", 4 * C_, C_, (double)C_);
+            c.pw2 = add_linear_as_conv(q + ".pwconv2", C_, 4 * C_, 4.0 * C_);
+            c.gamma = add_tensor(q + ".gamma", {C_}, 0.1f, 0.02);
+            cnx_[i] = c;
+        }
+        conv_pre_ = add_conv("head.conv_pre", C_, C_, 13, false, (double)C_ * 13);
+        const int rates[5] = {8, 8, 2, 2, 2}, ks[5] = {16, 16, 4, 4, 4}, rk[3] = {3, 7, 11};
+        for (int s = 0; s < 5; ++s) {
+            const int cin = C_ >> s, cout = C_ >> (s + 1);
+            ups_[s] = add_conv("head.ups." + std::to_string(s), cout, cin, ks[s], true, (double)cin * ks[s] / rates[s]);
+            for (int j = 0; j < 3; ++j)
+                for (int m = 0; m < 3; ++m) {
+                    const std::string q = "head.resblocks." + std::to_string(s) + ".blocks." + std::to_string(j);
+                    res_[s][j][0][m] = add_conv(q + ".convs1." + std::to_string(m), cout, cout, rk[j], false, (double)cout * rk[j]);
+                    res_[s][j][1][m] = add_conv(q + ".convs2." + std::to_string(m), cout, cout, rk[j], false, (double)cout * rk[j]);
+                }
+        }
+        conv_post_ = add_conv("head.conv_post", 1, C_ >> 5, 13, false, (double)(C_ >> 5) * 13);
+    }
+    void repack_groups(int first, int G, size_t each) {  // make G consecutive tensors contiguous (no padding between them)
+        size_t off = tensors_[first].off;
+        for (int g = 0; g < G; ++g) { tensors_[first + g].off = off; off += each; }
+        raw_floats_ = std::max(raw_floats_, (off + 63) & ~(size_t)63);
+    }
+    void relayout() {
+        for (size_t i = 0; i < convs_.size(); ++i) {
+            const ConvSpec& s = convs_[i];
+            codec_relayout(R(s.raw), relaid_.f() + relaid_off_[i], s.cout, s.cin_g, s.k, s.transposed, st_);
+        }
+        FS_HIP(hipStreamSynchronize(st_));
+    }
+
+    int device_, C_ = 512;
+    hipStream_t st_ = nullptr;
+    bool loaded_ = false;
+    std::vector<Tensor> tensors_;
+    std::vector<ConvSpec> convs_;
+    std::vector<size_t> relaid_off_;
+    size_t raw_floats_ = 0, relaid_floats_ = 0;
+    DBuf raw_, relaid_, dcodes_, buf_[7];
+    int proj_w_ = 0, proj_b_ = 0, up_conv_[2] = {0, 0}, conv_pre_ = 0, conv_post_ = 0, ups_[5] = {0, 0, 0, 0, 0};
+    int res_[5][3][2][3] = {};
+    CnxSpec cnx_[2] = {};
+};
+
+CodecBase* make_codec(int device, int channel_div) { return new Codec(device, channel_div); }
+
 }  // namespace fs

@@ -1,0 +1,30 @@
+// Launch interface of the Firefly vocoder kernels (codec_kernels.hip).  gfx950 only, f32.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace fs {
+
+struct ConvW {
+    const float* wt;  // re-laid weight [Cin/groups][K][Cout]
+    const float* b;   // [Cout]
+    int cout, k;
+};
+
+enum { CODEC_EPI_NONE = 0, CODEC_EPI_GELU = 1, CODEC_EPI_GAMMA_RES = 2, CODEC_EPI_RES = 3, CODEC_EPI_TANH = 4 };
+
+void codec_fsq_project(const uint32_t* codes, int B, int G, int T, const float* pw, const float* pb, int dg, float* z, hipStream_t st);
+// causal conv1d, stride 1: y = epi(bias + W * pre(x)); x (B, Cin, T) -> y (B, Cout, T)
+void codec_conv1d(const float* x, int B, int Cin, int T, const ConvW& w, int dil, bool pre_silu, int epi, const float* res,
+                  const float* gamma, float* y, hipStream_t st);
+// transposed conv1d with right trim: x (B, Cin, Tin) -> y (B, Cout, Tin * stride)
+void codec_tconv1d(const float* x, int B, int Cin, int Tin, const ConvW& w, int stride, bool pre_silu, float* y, hipStream_t st);
+void codec_dwconv_ln(const float* x, int B, int C, int T, const float* dw, const float* db, const float* lnw, const float* lnb, float* y,
+                     hipStream_t st);
+void codec_mean3(const float* a, const float* b, const float* c, float* y, size_t n, hipStream_t st);
+void codec_relayout(const float* src, float* dst, int Cout, int CinG, int K, bool transposed, hipStream_t st);
+void codec_synth_fill(float* dst, uint64_t key, size_t n, float mean, float scale, hipStream_t st);
+
+}  // namespace fs

@@ -1,0 +1,285 @@
+// Firefly-GAN-VQ vocoder kernels for gfx950 (FireflyCodec::decode, fish_speech_core/lib/codec/*.rs).
+//
+// Precision: f32 end to end (the reference server runs the codec in f32, server/lib/utils/load.rs:161-164, and the
+// acceptance bound is PCM within 1e-4 RMS of the f32 oracle), so every convolution is an exact-f32 FMA chain.
+// Layout: activations (C, T) row-major per batch item (the reference's (b, C, T)); weights are re-laid at load time to
+// [Cin/groups][K][Cout] (output channel fastest) so that a block stages a contiguous [ICH][K][OT] weight tile.
+// Every conv of the 1.4+/1.5 codec is CAUSAL (left zero pad (k-1)*dil, utils/mod.rs:53-62) and every transposed conv
+// trims k - stride samples on the right (utils/mod.rs:110-122); SiLU pre-activations, bias, GELU, gamma/residual and the
+// final tanh are fused into the producing / consuming convolution.
+#include <hip/hip_runtime.h>
+
+#include "codec_kernels.h"
+#include "fs_common.h"
+#include "fs_synth.h"
+
+namespace fs {
+
+__device__ __forceinline__ float dsilu(float x) { return x / (1.f + __expf(-x)); }
+// candle Tensor::gelu == tanh approximation (convnext.rs:115)
+__device__ __forceinline__ float dgelu(float x) {
+    return 0.5f * x * (1.f + tanhf(0.7978845608028654f * x * (1.f + 0.044715f * x * x)));
+}
+
+// ------------------------------------------------------------------------------------------------ FSQ lookup + project_out
+// quantizer.rs:135-146 + grouped_residual_fsq.rs:95-114,175-185 + fsq.rs:119-159: per group g, token t:
+//   code[k] = ((idx / basis_k) % levels_k - hw_k) / hw_k, levels (8,5,5,5), basis (1,8,40,200), hw (4,2,2,2)
+//   z[g*dg + o][t] = sum_k code[k] * Wout_g[o][k] + b_g[o]
+// `rows`: the source row of (batch b', group slot g') is r = g'*B + b' of the (B*G, T) index matrix -- the reference's raw
+// reshape (b, g, t) -> (g, b, t, 1) (quantizer.rs:138-143), which is the identity only for B == 1.
+__global__ void k_fsq_project(const uint32_t* __restrict__ codes, int B, int G, int T, const float* __restrict__ pw /*[G][dg][4]*/,
+                              const float* __restrict__ pb /*[G][dg]*/, int dg, float* __restrict__ z /*[B][G*dg][T]*/) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = blockIdx.y, b = blockIdx.z;
+    if (t >= T) return;
+    const int r = g * B + b;
+    const uint32_t idx = codes[(size_t)r * T + t];
+    float code[4];
+    const int levels[4] = {8, 5, 5, 5}, basis[4] = {1, 8, 40, 200};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float hw = (float)(levels[k] / 2);
+        code[k] = ((float)((idx / basis[k]) % levels[k]) - hw) / hw;
+    }
+    for (int o = 0; o < dg; ++o) {
+        const float* w = pw + ((size_t)g * dg + o) * 4;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc += code[k] * w[k];
+        z[((size_t)b * G * dg + g * dg + o) * T + t] = acc + pb[g * dg + o];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ causal conv1d
+// y[o][t] = epi( b[o] + sum_i sum_k W[o][i][k] * pre(x[i][t + k*dil - (K-1)*dil]) ),  stride 1.
+// Block = 256 threads computes OT output channels x TT = 32*TPT time steps; thread (ty = tid/32, tx = tid%32) owns
+// channels ty*CPT .. +CPT and times tx + 32*j (lanes of a wave read consecutive LDS words: conflict-free, weights are
+// wave-broadcast reads).  Input channels are staged ICH at a time: x tile [ICH][TT + halo], weight tile [ICH][K][OT].
+enum { CEPI_NONE = 0, CEPI_GELU = 1, CEPI_GAMMA_RES = 2, CEPI_RES = 3, CEPI_TANH = 4 };
+
+template <int CPT, int TPT, int ICH>
+__global__ __launch_bounds__(256) void k_conv1d(const float* __restrict__ x, int Cin, int T, const float* __restrict__ wt /*[Cin][K][Cout]*/,
+                                                const float* __restrict__ bias, int Cout, int K, int dil, int pre_silu, int epi,
+                                                const float* __restrict__ res, const float* __restrict__ gamma, float* __restrict__ y) {
+    constexpr int OT = 8 * CPT, TT = 32 * TPT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int halo = (K - 1) * dil;
+    const int XS = TT + halo;
+    float* xs = smem;                 // [ICH][XS]
+    float* ws = smem + ICH * XS;      // [ICH][K][OT]
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int t0 = blockIdx.x * TT, o0 = blockIdx.y * OT;
+    const size_t boff_in = (size_t)blockIdx.z * Cin * T, boff_out = (size_t)blockIdx.z * Cout * T;
+    float acc[CPT][TPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c)
+#pragma unroll
+        for (int j = 0; j < TPT; ++j) acc[c][j] = 0.f;
+    for (int i0 = 0; i0 < Cin; i0 += ICH) {
+        const int nic = min(ICH, Cin - i0);
+        for (int e = threadIdx.x; e < nic * XS; e += 256) {
+            const int i = e / XS, tl = e % XS;
+            const int t = t0 + tl - halo;
+            float v = (t >= 0 && t < T) ? x[boff_in + (size_t)(i0 + i) * T + t] : 0.f;
+            if (pre_silu) v = dsilu(v);
+            xs[i * XS + tl] = v;
+        }
+        for (int e = threadIdx.x; e < nic * K * OT; e += 256) {
+            const int o = e % OT, ik = e / OT;
+            ws[e] = (o0 + o < Cout) ? wt[((size_t)(i0 + ik / K) * K + ik % K) * Cout + o0 + o] : 0.f;
+        }
+        __syncthreads();
+        for (int i = 0; i < nic; ++i)
+            for (int k = 0; k < K; ++k) {
+                float xv[TPT], wv[CPT];
+                const float* xp = xs + i * XS + tx + k * dil;
+#pragma unroll
+                for (int j = 0; j < TPT; ++j) xv[j] = xp[32 * j];
+                const float* wp = ws + (i * K + k) * OT + ty * CPT;
+#pragma unroll
+                for (int c = 0; c < CPT; ++c) wv[c] = wp[c];
+#pragma unroll
+                for (int c = 0; c < CPT; ++c)
+#pragma unroll
+                    for (int j = 0; j < TPT; ++j) acc[c][j] = fmaf(wv[c], xv[j], acc[c][j]);
+            }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+        const int o = o0 + ty * CPT + c;
+        if (o >= Cout) continue;
+        const float b = bias[o];
+#pragma unroll
+        for (int j = 0; j < TPT; ++j) {
+            const int t = t0 + tx + 32 * j;
+            if (t >= T) continue;
+            float v = acc[c][j] + b;
+            const size_t oi = boff_out + (size_t)o * T + t;
+            if (epi == CEPI_GELU) v = dgelu(v);
+            else if (epi == CEPI_GAMMA_RES) v = res[oi] + gamma[o] * v;
+            else if (epi == CEPI_RES) v = res[oi] + v;
+            else if (epi == CEPI_TANH) v = tanhf(v);
+            y[oi] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ transposed conv1d
+// candle conv_transpose1d (weight [Cin][Cout][K], stride s) + right trim of K - s (utils/mod.rs:110-122):
+//   y[o][u] = b[o] + sum_i sum_{k : (u - k) % s == 0, 0 <= (u-k)/s < Tin} pre(x[i][(u-k)/s]) * W[i][o][k],  u < Tin * s
+// One thread per (8 output channels, 1 output time); weights re-laid [Cin][K][Cout].
+template <int CPT>
+__global__ __launch_bounds__(256) void k_tconv1d(const float* __restrict__ x, int Cin, int Tin, const float* __restrict__ wt,
+                                                 const float* __restrict__ bias, int Cout, int K, int stride, int pre_silu,
+                                                 float* __restrict__ y) {
+    const int Tout = Tin * stride;
+    const int u = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int o0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * CPT;
+    if (u >= Tout || o0 >= Cout) return;
+    const size_t boff_in = (size_t)blockIdx.z * Cin * Tin, boff_out = (size_t)blockIdx.z * Cout * Tout;
+    float acc[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) acc[c] = 0.f;
+    const int ph = u % stride;
+    for (int i = 0; i < Cin; ++i) {
+        const float* xi = x + boff_in + (size_t)i * Tin;
+        for (int k = ph; k < K; k += stride) {
+            const int t = (u - k) / stride;
+            if (u - k < 0 || t >= Tin) continue;
+            float xv = xi[t];
+            if (pre_silu) xv = dsilu(xv);
+            const float* wp = wt + ((size_t)i * K + k) * Cout + o0;
+#pragma unroll
+            for (int c = 0; c < CPT; ++c)
+                if (o0 + c < Cout) acc[c] = fmaf(xv, wp[c], acc[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CPT; ++c)
+        if (o0 + c < Cout) y[boff_out + (size_t)(o0 + c) * Tout + u] = acc[c] + bias[o0 + c];
+}
+
+// ------------------------------------------------------------------------------------------------ ConvNeXt: dwconv k7 + LayerNorm
+// convnext.rs:110-115: depthwise causal conv (k = 7) then LayerNorm over channels (eps 1e-6, biased variance).
+// One block per time step (C <= 1024 threads-strided); output stays (C, T) for the pointwise convs (k = 1) that follow.
+__global__ __launch_bounds__(256) void k_dwconv_ln(const float* __restrict__ x, int C, int T, const float* __restrict__ dw /*[C][7]*/,
+                                                   const float* __restrict__ db, const float* __restrict__ lnw,
+                                                   const float* __restrict__ lnb, float* __restrict__ y) {
+    __shared__ float red[256];
+    __shared__ float vals[1024];
+    const int t = blockIdx.x;
+    const size_t boff = (size_t)blockIdx.y * C * T;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const int tt = t + k - 6;
+            if (tt >= 0) a = fmaf(dw[c * 7 + k], x[boff + (size_t)c * T + tt], a);
+        }
+        a += db[c];
+        vals[c] = a;
+        s += a;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k >= 1; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
+    const float mean = red[0] / (float)C;
+    __syncthreads();
+    float v = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) { const float d = vals[c] - mean; v = fmaf(d, d, v); }
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int k = 128; k >= 1; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
+    const float inv = 1.0f / sqrtf(red[0] / (float)C + 1e-6f);
+    for (int c = threadIdx.x; c < C; c += 256) y[boff + (size_t)c * T + t] = (vals[c] - mean) * inv * lnw[c] + lnb[c];
+}
+
+// ParallelBlock mean (hifi_gan.rs:114-117): stack(...).mean(0) == (a + b + c) * (1/3)
+__global__ void k_mean3(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c, float* __restrict__ y, size_t n) {
+    const float third = (float)(1.0 / 3.0);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = ((a[i] + b[i]) + c[i]) * third;
+}
+
+// weight re-layout [A][B][K] -> [.. see callers ..]: dst[(i*K + k)*Cout + o] = src[src_index(o, i, k)]
+__global__ void k_relayout_conv(const float* __restrict__ src, float* __restrict__ dst, int Cout, int CinG, int K, int transposed) {
+    const size_t n = (size_t)Cout * CinG * K;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const int o = (int)(e % Cout);
+        const int k = (int)((e / Cout) % K);
+        const int i = (int)(e / ((size_t)Cout * K));
+        const size_t si = transposed ? ((size_t)i * Cout + o) * K + k   // ConvTranspose1d weight [Cin][Cout][K]
+                                     : ((size_t)o * CinG + i) * K + k;  // Conv1d weight [Cout][Cin/g][K]
+        dst[e] = src[si];
+    }
+}
+
+__global__ void k_synth_f32(float* __restrict__ dst, uint64_t key, size_t n, float mean, float scale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = synth_elem(key, (uint64_t)i, mean, scale);
+}
+
+// ================================================================================================ launchers
+#define FS_LAUNCH_CHECK() FS_HIP(hipGetLastError())
+
+void codec_fsq_project(const uint32_t* codes, int B, int G, int T, const float* pw, const float* pb, int dg, float* z, hipStream_t st) {
+    hipLaunchKernelGGL(k_fsq_project, dim3((T + 63) / 64, G, B), dim3(64), 0, st, codes, B, G, T, pw, pb, dg, z);
+    FS_LAUNCH_CHECK();
+}
+
+void codec_conv1d(const float* x, int B, int Cin, int T, const ConvW& w, int dil, bool pre_silu, int epi, const float* res,
+                  const float* gamma, float* y, hipStream_t st) {
+    const int K = w.k, Cout = w.cout;
+    const int halo = (K - 1) * dil;
+    auto launch = [&](auto cpt, auto tpt, auto ich) {
+        constexpr int CPT = decltype(cpt)::value, TPT = decltype(tpt)::value, ICH = decltype(ich)::value;
+        constexpr int OT = 8 * CPT, TT = 32 * TPT;
+        const size_t smem = sizeof(float) * ((size_t)ICH * (TT + halo) + (size_t)ICH * K * OT);
+        FS_REQUIRE(smem <= 64 * 1024, "conv tile does not fit LDS");
+        hipLaunchKernelGGL((k_conv1d<CPT, TPT, ICH>), dim3((T + TT - 1) / TT, (Cout + OT - 1) / OT, B), dim3(256), smem, st, x, Cin, T,
+                           w.wt, w.b, Cout, K, dil, pre_silu ? 1 : 0, epi, res, gamma, y);
+    };
+    using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I4 = std::integral_constant<int, 4>;
+    using I8 = std::integral_constant<int, 8>; using I16 = std::integral_constant<int, 16>;
+    if (Cout >= 64) launch(I8(), I4(), I8());          // 64 ch x 128 t
+    else if (Cout >= 32) launch(I4(), I4(), I8());     // 32 ch x 128 t
+    else if (Cout >= 16) launch(I2(), I8(), I16());    // 16 ch x 256 t
+    else launch(I1(), I8(), I16());                    // <= 8 ch x 256 t (conv_post: 1 channel)
+    FS_LAUNCH_CHECK();
+}
+
+void codec_tconv1d(const float* x, int B, int Cin, int Tin, const ConvW& w, int stride, bool pre_silu, float* y, hipStream_t st) {
+    const int Tout = Tin * stride;
+    constexpr int CPT = 8;
+    hipLaunchKernelGGL((k_tconv1d<CPT>), dim3((Tout + 63) / 64, (w.cout + 4 * CPT - 1) / (4 * CPT), B), dim3(256), 0, st, x, Cin, Tin, w.wt,
+                       w.b, w.cout, w.k, stride, pre_silu ? 1 : 0, y);
+    FS_LAUNCH_CHECK();
+}
+
+void codec_dwconv_ln(const float* x, int B, int C, int T, const float* dw, const float* db, const float* lnw, const float* lnb, float* y,
+                     hipStream_t st) {
+    FS_REQUIRE(C <= 1024, "ConvNeXt width above 1024 channels");
+    hipLaunchKernelGGL(k_dwconv_ln, dim3(T, B), dim3(256), 0, st, x, C, T, dw, db, lnw, lnb, y);
+    FS_LAUNCH_CHECK();
+}
+
+void codec_mean3(const float* a, const float* b, const float* c, float* y, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(k_mean3, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, st, a, b, c, y, n);
+    FS_LAUNCH_CHECK();
+}
+
+void codec_relayout(const float* src, float* dst, int Cout, int CinG, int K, bool transposed, hipStream_t st) {
+    const size_t n = (size_t)Cout * CinG * K;
+    hipLaunchKernelGGL(k_relayout_conv, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, st, src, dst, Cout, CinG, K,
+                       transposed ? 1 : 0);
+    FS_LAUNCH_CHECK();
+}
+
+void codec_synth_fill(float* dst, uint64_t key, size_t n, float mean, float scale, hipStream_t st) {
+    hipLaunchKernelGGL(k_synth_f32, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, st, dst, key, n, mean, scale);
+    FS_LAUNCH_CHECK();
+}
+
+}  // namespace fs

@@ -1,0 +1,90 @@
+"""GPU parity tests of the Firefly-GAN-VQ vocoder (fs_codec_decode) vs the CPU oracle and the committed goldens.
+Tolerance: PCM within 1e-4 RMS (BASELINE.json north_star); measured agreement is ~1e-6 (f32 FMA chains on both sides)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import fishrt
+from oracle import oracle as orc
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+CG = np.load(os.path.join(G, "codec_tiny.npz"))
+
+
+def rms(a, b):
+    return float(np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)))
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    return fishrt.FireflyCodec(0, channel_div=8).load_synthetic(int(CG["seed"]))
+
+
+def test_tiny_vs_golden_and_oracle(tiny):
+    codes = CG["codes"]
+    pcm = tiny.decode(np.ascontiguousarray(codes[None]))
+    assert pcm.shape == (1, 1, 2048 * codes.shape[1]) and tiny.sample_rate == 44100
+    assert rms(pcm[0, 0], CG["pcm"]) < 1e-6
+    o = orc.OracleCodec(tiny=True).load_synthetic(int(CG["seed"]))
+    assert rms(pcm[0, 0], o.decode(codes)) < 1e-6
+    assert np.abs(pcm).max() <= 1.0
+
+
+def test_tiny_edge_cases(tiny):
+    o = orc.OracleCodec(tiny=True).load_synthetic(int(CG["seed"]))
+    rng = np.random.RandomState(3)
+    for T in (1, 2, 33, 70):  # single frame, tile boundaries of the 128/256-sample conv tiles
+        codes = rng.randint(0, 1000, (8, T)).astype(np.uint32)
+        codes[:, 0] = [0, 999, 7, 8, 39, 40, 199, 200]  # FSQ level boundaries (fsq.rs:137-144)
+        pcm = tiny.decode(np.ascontiguousarray(codes[None]))[0, 0]
+        assert rms(pcm, o.decode(codes)) < 1e-6, T
+    with pytest.raises(RuntimeError):
+        tiny.decode(np.full((1, 8, 4), 1000, np.uint32))  # gather out of range
+    with pytest.raises(ValueError):
+        tiny.decode(np.zeros((1, 8, 8), np.uint32)[:, :, ::2])  # non-contiguous (codec.rs:97-101)
+
+
+def test_batch_follows_reference_raw_reshape(tiny):
+    """quantizer.rs:138-143: (b, g, t) is RESHAPED (not permuted) to (g, b, t, 1): group slot g' of batch item b' reads
+    row g'*B + b' of the flattened (B*8, T) index matrix.  Identity for B == 1."""
+    o = orc.OracleCodec(tiny=True).load_synthetic(int(CG["seed"]))
+    rng = np.random.RandomState(11)
+    B, T = 2, 5
+    codes = rng.randint(0, 1000, (B, 8, T)).astype(np.uint32)
+    pcm = tiny.decode(codes)
+    flat = codes.reshape(B * 8, T)
+    for b in range(B):
+        eff = np.stack([flat[g * B + b] for g in range(8)])
+        assert rms(pcm[b, 0], o.decode(eff)) < 1e-6
+
+
+@pytest.fixture(scope="module")
+def full():
+    return fishrt.FireflyCodec(0).load_synthetic(0xC0DEC)
+
+
+def test_fullsize_vs_oracle(full):
+    o = orc.OracleCodec(tiny=False).load_synthetic(0xC0DEC)
+    voice = np.load(os.path.join(G, "default_voice_codes.npy")).astype(np.uint32)  # (8, 274) in [3, 999]
+    codes = np.ascontiguousarray(voice[:, :12])
+    pcm = full.decode(codes[None])[0, 0]
+    ref = o.decode(codes)
+    assert pcm.shape == ref.shape == (2048 * 12,)
+    r = rms(pcm, ref)
+    sig = float(np.sqrt(np.mean(ref.astype(np.float64) ** 2)))
+    print(f"full-size vocoder: PCM rms diff {r:.2e} at signal rms {sig:.3f}")
+    assert r < 1e-4 and sig > 1e-3
+
+
+def test_fullsize_causality_property(full):
+    """Every conv of the 1.4+/1.5 codec is causal (utils/mod.rs:53-62,110-122): the PCM of a code prefix is the prefix
+    of the PCM, bit for bit (size-independent property at the full default-voice length, 274 frames = 12.7 s)."""
+    voice = np.ascontiguousarray(np.load(os.path.join(G, "default_voice_codes.npy")).astype(np.uint32))
+    pcm = full.decode(voice[None])[0, 0]
+    assert pcm.shape == (2048 * 274,) and np.isfinite(pcm).all() and np.abs(pcm).max() <= 1.0
+    for T1 in (1, 37, 200):
+        part = full.decode(np.ascontiguousarray(voice[None, :, :T1]))[0, 0]
+        assert np.array_equal(part, pcm[: 2048 * T1]), T1

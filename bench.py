@@ -77,19 +77,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", 0))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
     import torch
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    import fishrt
+    from fishrt import config as fcfg, fanout
+    rank, local_rank, world = fanout.env_rank()
+    dist = fanout.init("nccl" if world > 1 else None)  # RCCL; control plane only (barrier + max-reduce)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    import fishrt
-    from fishrt import config as fcfg
     cfg, tok = fcfg.FISH_1_5, fcfg.FISH_1_5_TOKENS
     lm = fishrt.DualARTransformer(cfg, tok, local_rank, "bf16").load_synthetic(SEED)
     prompt = default_voice_prompt(tok)
@@ -104,8 +98,7 @@ def main():
         return out, lm.last_stats()
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        fanout.barrier(dist)
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -120,10 +113,7 @@ def main():
     dt = time.perf_counter() - t0
     if args.warmup:
         assert np.array_equal(out, ref_out), "non-deterministic greedy tokens across requests"
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = fanout.max_over_ranks(dist, dt)
 
     frames_total = args.frames * args.steps * world
     value = frames_total / dt

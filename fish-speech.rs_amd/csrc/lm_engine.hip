@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <array>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <type_traits>
@@ -424,7 +425,7 @@ class LM final : public LMBase {
             return w;
         };
         for (auto& o : o_slow_) slow_.push_back(lw(o));
-        for (auto& o : o_fast_) fast_.push_back(lw(o));
+        for (auto& o : o_fast_) { fast_.push_back(lw(o)); fast_.back().cache_resident = getenv("FISHRT_FAST_NT") == nullptr; }
         tok_emb_ = base + o_tok_emb_; cb_emb_ = base + o_cb_emb_; fast_emb_ = base + o_fast_emb_;
         out_w_ = base + o_out_; fast_out_w_ = base + o_fast_out_;
         norm_w_ = (const float*)(base + o_norm_); fast_norm_w_ = (const float*)(base + o_fast_norm_);

@@ -44,6 +44,9 @@ struct LayerW {
     const void* w2;    // [dim, inter]
     const float* attn_norm;
     const float* ffn_norm;
+    // false: weights are streamed once per frame -> non-temporal loads (slow transformer, 717 MB / frame);
+    // true: re-read 8x per frame and small enough for the 256 MB Infinity Cache (fast decoder, 122 MB) -> default policy
+    bool cache_resident = false;
 };
 
 struct ModelDims {

@@ -89,7 +89,7 @@ __device__ __forceinline__ float group_sum(float v) {
 
 // A wave's view of a length-K vector / weight row: chunk c covers elements [c*64*EPL, (c+1)*64*EPL), lane l owns
 // EPL consecutive elements starting at c*64*EPL + l*EPL.
-template <typename WT, int K>
+template <typename WT, int K, bool NT = true>
 struct Row {
     static constexpr int EPL = WTr<WT>::EPL;
     static constexpr int CH = 64 * EPL;
@@ -117,7 +117,7 @@ struct Row {
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int base = c * CH + lane * EPL;
-            if (base < K) wv[c] = ld_stream(reinterpret_cast<const vec*>(row + base));
+            if (base < K) wv[c] = NT ? ld_stream(reinterpret_cast<const vec*>(row + base)) : *reinterpret_cast<const vec*>(row + base);
             else wv[c] = vec(0);
         }
     }
@@ -154,13 +154,13 @@ __device__ __forceinline__ WT* kv_addr(void* pool, const int* __restrict__ page_
 // One wave per ROW of Wqkv (maximum memory-level parallelism: 1280 waves for Fish-1.5); the two rows (2p, 2p+1) of an
 // interleaved-RoPE pair sit in adjacent waves of one block and meet through LDS.  Position, page and cos/sin are
 // fetched at kernel entry so the epilogue has no dependent load left.
-template <typename WT, int K, int WAVES>
+template <typename WT, int K, int WAVES, bool NT>
 __global__ __launch_bounds__(WAVES * 64) void k_qkv(const float* __restrict__ x, const float* __restrict__ norm_w, float eps,
                                                     const WT* __restrict__ W, const float* __restrict__ cos_t,
                                                     const float* __restrict__ sin_t, const SeqState* __restrict__ state,
                                                     int pos_static, int rope_static, float* __restrict__ q_out, KVView kv,
                                                     int H, int Hk, int Dh) {
-    using R = Row<WT, K>;
+    using R = Row<WT, K, NT>;
     __shared__ float res[WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * WAVES + wave;
@@ -326,13 +326,13 @@ __global__ __launch_bounds__(256) void k_attn_decode(const float* __restrict__ q
 // Prologue (whole block, result in LDS): either combine the per-chunk partials of k_attn_decode, or -- FUSED, used by
 // the fast decoder whose KV length is <= 8 -- run the whole attention for all heads redundantly per block.
 // Body: one wave per output row: x[r] += Wo[r,:] . attn   (dual_ar.rs:383,437)
-template <typename WT, int K, int WAVES, bool FUSED, int DH>
+template <typename WT, int K, int WAVES, bool FUSED, int DH, bool NT>
 __global__ __launch_bounds__(WAVES * 64) void k_wo(const float* __restrict__ part, int n_chunks_max, int chunk,
                                                    const SeqState* __restrict__ state, const float* __restrict__ q, KVView kv,
                                                    int fused_T, const WT* __restrict__ W, float* __restrict__ x, int H, int Hk,
                                                    int n_rows) {
-    using R = Row<WT, K>;
-    constexpr int NT = WAVES * 64;
+    using R = Row<WT, K, NT>;
+    constexpr int NTH = WAVES * 64;
     constexpr int EPL = WTr<WT>::EPL;
     using vec = typename WTr<WT>::vec;
     static_assert(K % 4 == 0 && DH % 16 == 0, "geometry");
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_wo(const float* __restrict__ par
         const bool has_ml = e0 < H * nc;
         float2 mv = make_float2(0.f, 0.f);
         if (has_ml) mv = *reinterpret_cast<const float2*>(part + ((size_t)(e0 / nc) * n_chunks_max + (e0 % nc)) * (DH + 2) + DH);
-        const int e4 = threadIdx.x * 4;  // this thread's 4 consecutive attn elements (K <= 4 * NT for every supported K here)
+        const int e4 = threadIdx.x * 4;  // this thread's 4 consecutive attn elements (K <= 4 * NTH for every supported K here)
         const bool has_o = e4 < K;
         const int ho = (has_o ? e4 : 0) / DH, ddo = e4 % DH;
         const float* po = part + (size_t)ho * n_chunks_max * (DH + 2) + ddo;
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_wo(const float* __restrict__ par
             v[j] = (has_o && j < nc) ? *reinterpret_cast<const float4*>(po + (size_t)j * (DH + 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
         if (row < n_rows) R::load_w(W + (size_t)row * K, lane, wv);
         if (has_ml) { ml[2 * ((e0 / nc) * 128 + (e0 % nc))] = mv.x; ml[2 * ((e0 / nc) * 128 + (e0 % nc)) + 1] = mv.y; }
-        for (int e = threadIdx.x + NT; e < H * nc; e += NT) {  // only when H * nc > NT (very long sequences)
+        for (int e = threadIdx.x + NTH; e < H * nc; e += NTH) {  // only when H * nc > NTH (very long sequences)
             const int h = e / nc, c = e % nc;
             const float2 t2 = *reinterpret_cast<const float2*>(part + ((size_t)h * n_chunks_max + c) * (DH + 2) + DH);
             ml[2 * (h * 128 + c)] = t2.x;
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_wo(const float* __restrict__ par
         }
         __syncthreads();
         // (b) per head: softmax-merge weights wl[h][c] = exp(m_c - M) / sum_c l_c exp(m_c - M)
-        for (int h = threadIdx.x; h < H; h += NT) {
+        for (int h = threadIdx.x; h < H; h += NTH) {
             float mn = -1e30f;
             for (int c = 0; c < nc; ++c) mn = fmaxf(mn, ml[2 * (h * 128 + c)]);
             float L = 0.f;
@@ -476,11 +476,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_wo(const float* __restrict__ par
 
 // ------------------------------------------------------------------------------------------------ SwiGLU up
 // One wave per (w1[r], w3[r]) pair of the row-interleaved W13: act[r] = silu(w1[r].xn) * (w3[r].xn)
-template <typename WT, int K, int WAVES>
+template <typename WT, int K, int WAVES, bool NT>
 __global__ __launch_bounds__(WAVES * 64) void k_ffn_up(const float* __restrict__ x, const float* __restrict__ norm_w,
                                                        float eps, const WT* __restrict__ W13, float* __restrict__ act,
                                                        int inter) {
-    using R = Row<WT, K>;
+    using R = Row<WT, K, NT>;
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * WAVES + (threadIdx.x >> 6);
     if (r >= inter) return;
@@ -500,10 +500,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_ffn_up(const float* __restrict__
 // x[r] += W2[r,:] . act with K = inter split over the KS waves of a block (one row per block): every wave streams
 // K/KS contiguous weights against its own slice of `act` (registers, straight from L2), the KS partial sums meet in LDS
 // and are added in a fixed order.
-template <typename WT, int K, int KS>
+template <typename WT, int K, int KS, bool NT>
 __global__ __launch_bounds__(KS * 64) void k_ffn_down(const float* __restrict__ act, const WT* __restrict__ W2,
                                                       float* __restrict__ x, int n_rows) {
-    using R = Row<WT, K / KS>;
+    using R = Row<WT, K / KS, NT>;
     __shared__ float red[KS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x;
@@ -1079,8 +1079,12 @@ void LmKernels<WT>::qkv(const ModelDims& d, const float* x, const LayerW& w, con
     const int grid = (n_rows + WAVES - 1) / WAVES;
     dispatch_k(d.dim, [&](auto Kc) {
         constexpr int K = decltype(Kc)::value;
-        hipLaunchKernelGGL((k_qkv<WT, K, WAVES>), dim3(grid), dim3(WAVES * 64), 0, st, x, w.attn_norm, d.eps,
-                           (const WT*)w.wqkv, cos_t, sin_t, state, pos_static, rope_static, q_out, kv, d.H, d.Hk, d.Dh);
+        if (w.cache_resident)
+            hipLaunchKernelGGL((k_qkv<WT, K, WAVES, false>), dim3(grid), dim3(WAVES * 64), 0, st, x, w.attn_norm, d.eps,
+                               (const WT*)w.wqkv, cos_t, sin_t, state, pos_static, rope_static, q_out, kv, d.H, d.Hk, d.Dh);
+        else
+            hipLaunchKernelGGL((k_qkv<WT, K, WAVES, true>), dim3(grid), dim3(WAVES * 64), 0, st, x, w.attn_norm, d.eps,
+                               (const WT*)w.wqkv, cos_t, sin_t, state, pos_static, rope_static, q_out, kv, d.H, d.Hk, d.Dh);
     });
     FS_LAUNCH_CHECK();
 }
@@ -1115,8 +1119,12 @@ void LmKernels<WT>::wo(const ModelDims& d, const float* part, int n_chunks_max, 
     dispatch_k(d.dim, [&](auto Kc) {
         constexpr int K = decltype(Kc)::value;
         auto go = [&](auto fused, auto dh) {
-            hipLaunchKernelGGL((k_wo<WT, K, WAVES, decltype(fused)::value, decltype(dh)::value>), dim3(grid), dim3(WAVES * 64), 0, st,
-                               part, n_chunks_max, attn_chunk(), state, q, kv, fused_T, (const WT*)w.wo, x, d.H, d.Hk, d.dim);
+            if (w.cache_resident)
+                hipLaunchKernelGGL((k_wo<WT, K, WAVES, decltype(fused)::value, decltype(dh)::value, false>), dim3(grid), dim3(WAVES * 64), 0,
+                                   st, part, n_chunks_max, attn_chunk(), state, q, kv, fused_T, (const WT*)w.wo, x, d.H, d.Hk, d.dim);
+            else
+                hipLaunchKernelGGL((k_wo<WT, K, WAVES, decltype(fused)::value, decltype(dh)::value, true>), dim3(grid), dim3(WAVES * 64), 0,
+                                   st, part, n_chunks_max, attn_chunk(), state, q, kv, fused_T, (const WT*)w.wo, x, d.H, d.Hk, d.dim);
         };
         using T = std::true_type; using F = std::false_type;
         using D64 = std::integral_constant<int, 64>; using D32 = std::integral_constant<int, 32>;
@@ -1132,8 +1140,12 @@ void LmKernels<WT>::ffn_up(const ModelDims& d, const float* x, const LayerW& w, 
     const int grid = (d.inter + WAVES - 1) / WAVES;
     dispatch_k(d.dim, [&](auto Kc) {
         constexpr int K = decltype(Kc)::value;
-        hipLaunchKernelGGL((k_ffn_up<WT, K, WAVES>), dim3(grid), dim3(WAVES * 64), 0, st, x, w.ffn_norm, d.eps,
-                           (const WT*)w.w13, act, d.inter);
+        if (w.cache_resident)
+            hipLaunchKernelGGL((k_ffn_up<WT, K, WAVES, false>), dim3(grid), dim3(WAVES * 64), 0, st, x, w.ffn_norm, d.eps,
+                               (const WT*)w.w13, act, d.inter);
+        else
+            hipLaunchKernelGGL((k_ffn_up<WT, K, WAVES, true>), dim3(grid), dim3(WAVES * 64), 0, st, x, w.ffn_norm, d.eps,
+                               (const WT*)w.w13, act, d.inter);
     });
     FS_LAUNCH_CHECK();
 }
@@ -1143,7 +1155,10 @@ void LmKernels<WT>::ffn_down(const ModelDims& d, const float* act, const LayerW&
     constexpr int KS = 4;
     dispatch_k(d.inter, [&](auto Kc) {
         constexpr int K = decltype(Kc)::value;
-        hipLaunchKernelGGL((k_ffn_down<WT, K, KS>), dim3(d.dim), dim3(KS * 64), 0, st, act, (const WT*)w.w2, x, d.dim);
+        if (w.cache_resident)
+            hipLaunchKernelGGL((k_ffn_down<WT, K, KS, false>), dim3(d.dim), dim3(KS * 64), 0, st, act, (const WT*)w.w2, x, d.dim);
+        else
+            hipLaunchKernelGGL((k_ffn_down<WT, K, KS, true>), dim3(d.dim), dim3(KS * 64), 0, st, act, (const WT*)w.w2, x, d.dim);
     });
     FS_LAUNCH_CHECK();
 }

@@ -176,3 +176,34 @@ def test_static_batch_greedy_rows_match_padded_single(tiny32):
         o.clear_slow()
         exp = o.generate(pp, 30, temp=0.0, repetition_penalty=1.0, ignore_eos=True)  # batch rep-pen is a no-op (static_batch.rs:204-206)
         assert np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("temp,top_p,top_k", [(0.7, 0.8, 0), (0.7, 0.8, 16), (1.0, 1.0, 0), (0.5, 0.9, 50)])
+def test_sampled_decode_matches_oracle_stream(tiny32, temp, top_p, top_k):
+    """temp > 0: softmax(logits/temp) -> top-k -> top-p -> WeightedIndex draw from the StdRng (ChaCha12) stream seeded by
+    `seed` (sampling/mod.rs:51-132; candle LogitsProcessor::TopKThenTopP).  Device sampler and oracle share the RNG stream
+    and the decision procedure, so the sampled tokens are expected to be identical (expf differs by <= 1 ulp between the
+    two, which can move a cumulative-probability boundary across the uniform draw only with probability ~1e-6/sample)."""
+    lm = tiny32
+    o = orc.OracleLM(orc.TINY).load_synthetic(SEED)
+    p = LMG["prompt"]
+    agree, total = 0, 0
+    for seed in (1, 42, 12345):
+        lm.clear_slow_layer_caches(); o.clear_slow()
+        M = 30 + p.shape[1] - 2
+        got = lm.generate_blocking(p, M, temp=temp, top_p=top_p, top_k=top_k, repetition_penalty=1.2, seed=seed, ignore_eos=True)
+        exp = o.generate(p, M, temp=temp, top_p=top_p, top_k=top_k, repetition_penalty=1.2, seed=seed, ignore_eos=True)
+        assert got.shape == exp.shape == (8, 30)
+        same = (got == exp).all(0)
+        first_bad = int(np.argmin(same)) if not same.all() else 30
+        agree += first_bad; total += 30
+        assert first_bad >= 10, (seed, first_bad, got[:, :first_bad + 1], exp[:, :first_bad + 1])
+    print(f"sampled (temp={temp}, top_p={top_p}, top_k={top_k}): identical prefix {agree}/{total} frames")
+    # different seeds give different streams; same seed is reproducible
+    lm.clear_slow_layer_caches()
+    a = lm.generate_blocking(p, 30, temp=temp, top_p=top_p, top_k=top_k, seed=7, ignore_eos=True)
+    lm.clear_slow_layer_caches()
+    b = lm.generate_blocking(p, 30, temp=temp, top_p=top_p, top_k=top_k, seed=7, ignore_eos=True)
+    lm.clear_slow_layer_caches()
+    c = lm.generate_blocking(p, 30, temp=temp, top_p=top_p, top_k=top_k, seed=8, ignore_eos=True)
+    assert np.array_equal(a, b) and not np.array_equal(a, c)

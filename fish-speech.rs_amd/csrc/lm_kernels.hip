@@ -210,11 +210,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_qkv(const float* __restrict__ x,
 // row) each own one (query head, token subset): scores by DPP group-sums, a two-pass softmax in registers (no rescale
 // chain), P.V accumulated on the group's own dims -- no cross-group reduction of the output.  The block merges its
 // waves in LDS and writes one un-normalised partial {o[Dh], m, l} per (head, chunk); k_wo combines the chunks.
-template <typename WT> struct AttnGeom { static constexpr int TW = 32; };
-template <> struct AttnGeom<float> { static constexpr int TW = 16; };
+template <typename WT> struct AttnGeom { static constexpr int TW = 16, NW = 8; };   // bf16: 8 waves x 16 tokens = 128-token chunks
+template <> struct AttnGeom<float> { static constexpr int TW = 16, NW = 4; };     // f32 : 4 waves x 16 tokens =  64-token chunks
 
 template <typename WT, int DH, int NREP>
-__global__ __launch_bounds__(256) void k_attn_decode(const float* __restrict__ q_all, KVView kv,
+__global__ __launch_bounds__(AttnGeom<WT>::NW * 64) void k_attn_decode(const float* __restrict__ q_all, KVView kv,
                                                      const SeqState* __restrict__ state, float* __restrict__ part_all,
                                                      int Hk, int n_chunks_max) {
     // blockIdx.y = query token m of a prefill chunk (0 for decode): it sees the KV prefix of length pos + 1 + m
@@ -227,7 +227,8 @@ __global__ __launch_bounds__(256) void k_attn_decode(const float* __restrict__ q
     constexpr int NTS = G / NRP;             // token subsets per head
     constexpr int NHP = NREP / NRP;          // head passes
     constexpr int TW = AttnGeom<WT>::TW;     // tokens per wave
-    constexpr int CH = 4 * TW;               // tokens per block
+    constexpr int NW = AttnGeom<WT>::NW;     // waves per block
+    constexpr int CH = NW * TW;              // tokens per block
     constexpr int TPG = TW / NTS;            // tokens per group
     constexpr int NLD = TW * LPT / 64;       // 16-B loads per lane per tile
     static_assert(TW % NTS == 0 && NLD >= 1, "attention geometry");
@@ -236,18 +237,25 @@ __global__ __launch_bounds__(256) void k_attn_decode(const float* __restrict__ q
     const int T = state->pos + 1 + (int)blockIdx.y;  // the current token's K/V were appended by k_qkv
     if (c * CH >= T) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __shared__ __attribute__((aligned(16))) WT sk[4][TW * DH];
-    __shared__ __attribute__((aligned(16))) WT sv[4][TW * DH];
-    __shared__ float sp[4][NREP][NTS][DH + 2];
+    __shared__ __attribute__((aligned(16))) WT sk[NW][TW * DH];
+    __shared__ __attribute__((aligned(16))) WT sv[NW][TW * DH];
+    __shared__ float sp[NW][NREP][NTS][DH + 2];
     const int t_base = c * CH + wave * TW;
     // stage K/V tiles: lane l of load i covers token (i*64 + l) / LPT, 16-B slice l % LPT (1 KiB contiguous per load)
+    // all TW tokens of a wave live in ONE page (TW divides KV_PAGE, t_base is TW-aligned): a single wave-uniform
+    // (scalar) page-table read, then 1 KiB-contiguous tile loads
+    static_assert(KV_PAGE % TW == 0, "a wave's tokens must not straddle a KV page");
+    const int t_base_u = __builtin_amdgcn_readfirstlane(t_base);
+    const int page = kv.page_table[min(t_base_u, T - 1) / KV_PAGE];
+    const WT* kpage = reinterpret_cast<const WT*>(kv.k) + (size_t)(page * Hk + g) * KV_PAGE * DH;
+    const WT* vpage = reinterpret_cast<const WT*>(kv.v) + (size_t)(page * Hk + g) * KV_PAGE * DH;
     vec kreg[NLD], vreg[NLD];
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
         const int tl = (i * 64 + lane) / LPT, sl = lane % LPT;
-        const int t = min(t_base + tl, T - 1);
-        kreg[i] = *reinterpret_cast<const vec*>(kv_addr<WT>(kv.k, kv.page_table, t, g, Hk, DH) + sl * EPL);
-        vreg[i] = *reinterpret_cast<const vec*>(kv_addr<WT>(kv.v, kv.page_table, t, g, Hk, DH) + sl * EPL);
+        const int t = min(t_base + tl, T - 1);  // clamped rows are masked below
+        kreg[i] = *reinterpret_cast<const vec*>(kpage + (size_t)(t % KV_PAGE) * DH + sl * EPL);
+        vreg[i] = *reinterpret_cast<const vec*>(vpage + (size_t)(t % KV_PAGE) * DH + sl * EPL);
     }
     const int gi = lane / LPT, sub = lane % LPT;
     const int rl = gi % NRP, ts = gi / NRP;
@@ -300,16 +308,16 @@ __global__ __launch_bounds__(256) void k_attn_decode(const float* __restrict__ q
         if (sub == 0) { dst[DH] = m; dst[DH + 1] = l; }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < NREP * DH; e += 256) {
+    for (int e = threadIdx.x; e < NREP * DH; e += NW * 64) {
         const int r = e / DH, dd = e % DH;
         float mn = -1e30f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w)
+        for (int w = 0; w < NW; ++w)
 #pragma unroll
             for (int k = 0; k < NTS; ++k) mn = fmaxf(mn, sp[w][r][k][DH]);
         float L = 0.f, O = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w)
+        for (int w = 0; w < NW; ++w)
 #pragma unroll
             for (int k = 0; k < NTS; ++k) {
                 const float cf = __expf(sp[w][r][k][DH] - mn);
@@ -1090,7 +1098,7 @@ void LmKernels<WT>::qkv(const ModelDims& d, const float* x, const LayerW& w, con
 }
 
 template <typename WT>
-int LmKernels<WT>::attn_chunk() { return 4 * AttnGeom<WT>::TW; }
+int LmKernels<WT>::attn_chunk() { return AttnGeom<WT>::NW * AttnGeom<WT>::TW; }
 
 template <typename WT>
 void LmKernels<WT>::attn_decode(const ModelDims& d, const float* q, KVView kv, const SeqState* state, float* part,
@@ -1098,11 +1106,11 @@ void LmKernels<WT>::attn_decode(const ModelDims& d, const float* q, KVView kv, c
     const int grid = d.Hk * n_chunks_max;
     FS_REQUIRE(n_chunks_max <= 128, "attention supports at most 128 chunks per sequence");
     if (d.Dh == 64 && d.n_rep == 8)
-        hipLaunchKernelGGL((k_attn_decode<WT, 64, 8>), dim3(grid), dim3(256), 0, st, q, kv, state, part, d.Hk, n_chunks_max);
+        hipLaunchKernelGGL((k_attn_decode<WT, 64, 8>), dim3(grid), dim3(AttnGeom<WT>::NW * 64), 0, st, q, kv, state, part, d.Hk, n_chunks_max);
     else if (d.Dh == 32 && d.n_rep == 2)
-        hipLaunchKernelGGL((k_attn_decode<WT, 32, 2>), dim3(grid), dim3(256), 0, st, q, kv, state, part, d.Hk, n_chunks_max);
+        hipLaunchKernelGGL((k_attn_decode<WT, 32, 2>), dim3(grid), dim3(AttnGeom<WT>::NW * 64), 0, st, q, kv, state, part, d.Hk, n_chunks_max);
     else if (d.Dh == 64 && d.n_rep == 2)
-        hipLaunchKernelGGL((k_attn_decode<WT, 64, 2>), dim3(grid), dim3(256), 0, st, q, kv, state, part, d.Hk, n_chunks_max);
+        hipLaunchKernelGGL((k_attn_decode<WT, 64, 2>), dim3(grid), dim3(AttnGeom<WT>::NW * 64), 0, st, q, kv, state, part, d.Hk, n_chunks_max);
     else
         throw Error("unsupported attention geometry (head_dim, n_rep) = (" + std::to_string(d.Dh) + ", " +
                     std::to_string(d.n_rep) + ")");
@@ -1266,11 +1274,11 @@ void LmKernels<WT>::prefill_layer(const ModelDims& d, int M, float* X, const Lay
                            w.attn_norm, d.eps, (const bf16_t*)w.wqkv, qkv_rows, Q, d.dim, cos_t, sin_t, state, kv, d.H, d.Hk, d.Dh);
         const dim3 ga(d.Hk * n_chunks_max, M);
         if (d.Dh == 64 && d.n_rep == 8)
-            hipLaunchKernelGGL((k_attn_decode<WT, 64, 8>), ga, dim3(256), 0, st, Q, kv, state, part, d.Hk, n_chunks_max);
+            hipLaunchKernelGGL((k_attn_decode<WT, 64, 8>), ga, dim3(AttnGeom<WT>::NW * 64), 0, st, Q, kv, state, part, d.Hk, n_chunks_max);
         else if (d.Dh == 32 && d.n_rep == 2)
-            hipLaunchKernelGGL((k_attn_decode<WT, 32, 2>), ga, dim3(256), 0, st, Q, kv, state, part, d.Hk, n_chunks_max);
+            hipLaunchKernelGGL((k_attn_decode<WT, 32, 2>), ga, dim3(AttnGeom<WT>::NW * 64), 0, st, Q, kv, state, part, d.Hk, n_chunks_max);
         else if (d.Dh == 64 && d.n_rep == 2)
-            hipLaunchKernelGGL((k_attn_decode<WT, 64, 2>), ga, dim3(256), 0, st, Q, kv, state, part, d.Hk, n_chunks_max);
+            hipLaunchKernelGGL((k_attn_decode<WT, 64, 2>), ga, dim3(AttnGeom<WT>::NW * 64), 0, st, Q, kv, state, part, d.Hk, n_chunks_max);
         else
             throw Error("unsupported attention geometry");
         if (d.Dh == 64)

@@ -96,8 +96,10 @@ class LM final : public LMBase {
     ~LM() override {
         (void)hipSetDevice(device_);
         (void)hipStreamSynchronize(st_);
-        if (g_frame_) (void)hipGraphExecDestroy(g_frame_);
-        if (g_step_) (void)hipGraphExecDestroy(g_step_);
+        for (auto& kvp : graphs_) {
+            if (kvp.second.first) (void)hipGraphExecDestroy(kvp.second.first);
+            if (kvp.second.second) (void)hipGraphExecDestroy(kvp.second.second);
+        }
         for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
         if (h_pin_) (void)hipHostFree(h_pin_);
         if (st_) (void)hipStreamDestroy(st_);
@@ -253,7 +255,6 @@ class LM final : public LMBase {
         FS_HIP(hipMemcpyAsync(d_prompt_.p, prompt, sizeof(uint32_t) * C1 * L, hipMemcpyHostToDevice, st_));
         launch_reppen_reset(rp_, C, a_.codebook_size, st_);
         clear_fast();
-        build_graphs();
 
         stats_ = {};
         FS_HIP(hipEventRecord(ev_[0], st_));
@@ -262,7 +263,13 @@ class LM final : public LMBase {
         prefill_tokens(0, L - 1, /*use_graph=*/true);
         LmKernels<WT>::embed(d_, tok_emb_, cb_emb_, C, a_.codebook_size, d_cfg_.as<SampleCfg>(), d_prompt_.as<uint32_t>(), state(0),
                              x(0), st_);
-        FS_HIP(hipGraphLaunch(g_frame_, st_));
+        // frame `it` runs at KV length T = n_cached + L + it: pick the graph captured for that attention chunk bucket
+        auto launch_frame = [&](long long it_) {
+            set_bucket(n_cached + L + (int)it_);
+            use_graphs_for_bucket();
+            FS_HIP(hipGraphLaunch(g_frame_, st_));
+        };
+        launch_frame(0);
         FS_HIP(hipEventRecord(ev_[1], st_));
         stats_.graph_launches = (uint64_t)L;
         // decode: one graph replay per frame; the host only peeks at the done flag every CHUNK frames
@@ -294,7 +301,7 @@ class LM final : public LMBase {
         };
         while (it < n_iter && !stop) {
             const long long end = std::min<long long>(n_iter, it + CHUNK);
-            for (; it < end; ++it) { FS_HIP(hipGraphLaunch(g_frame_, st_)); stats_.graph_launches += 1; }
+            for (; it < end; ++it) { launch_frame(it); stats_.graph_launches += 1; }
             if (it < n_iter || cb) { if (poll()) break; }
         }
         FS_HIP(hipEventRecord(ev_[2], st_));
@@ -531,16 +538,16 @@ class LM final : public LMBase {
     // appending their K/V.  Afterwards x(b) holds the pre-norm hidden state of the last processed token.
     void prefill_tokens(int b, int n, bool use_graph) {
         if (n <= 0) return;
-        if (LmKernels<WT>::has_mfma_prefill() && n > 1 && a_.dim % 64 == 0 && a_.intermediate_size % 64 == 0) {
+        if (LmKernels<WT>::has_mfma_prefill() && n > 1 && a_.dim % 64 == 0 && a_.intermediate_size % 256 == 0) {
             ensure_prefill_buffers();
+            RowsCtx c = rows_ctx(state(b), /*pos_step=*/1, /*pt_stride=*/0);
             for (int done = 0; done < n;) {
                 const int M = std::min(64, n - done);
+                c.nc_launch = chunk_bucket(seq_len_[b] + done + M);
                 LmKernels<WT>::prefill_embed(d_, tok_emb_, cb_emb_, a_.num_codebooks, a_.codebook_size, d_cfg_.as<SampleCfg>(),
                                              d_prompt_.as<uint32_t>(), state(b), M, d_pfx_.as<float>(), st_);
-                for (int l = 0; l < a_.n_layer; ++l)
-                    LmKernels<WT>::prefill_layer(d_, M, d_pfx_.as<float>(), slow_[l], d_cos_.as<float>(), d_sin_.as<float>(), state(b),
-                                                 slow_kv(l, b), d_pfq_.as<float>(), d_pfpart_.as<float>(), n_chunks_,
-                                                 d_pfattn_.as<float>(), d_pfact_.as<float>(), st_);
+                for (int l = 0; l < a_.n_layer; ++l) LmKernels<WT>::rows_layer(d_, M, c, slow_[l], slow_kv(l, b), l == 0, st_);
+                LmKernels<WT>::rows_finish(d_, M, c, nullptr, st_);
                 launch_advance_n(state(b), M, st_);
                 done += M;
                 if (done == n)
@@ -550,7 +557,8 @@ class LM final : public LMBase {
             return;
         }
         for (int l = 0; l < n; ++l) {
-            if (use_graph && b == 0) { FS_HIP(hipGraphLaunch(g_step_, st_)); continue; }
+            set_bucket(seq_len_[b] + l + 1);
+            if (use_graph && b == 0) { use_graphs_for_bucket(); FS_HIP(hipGraphLaunch(g_step_, st_)); continue; }
             LmKernels<WT>::embed(d_, tok_emb_, cb_emb_, a_.num_codebooks, a_.codebook_size, d_cfg_.as<SampleCfg>(),
                                  d_prompt_.as<uint32_t>(), state(b), x(b), st_);
             enqueue_slow_layers(b);
@@ -561,9 +569,21 @@ class LM final : public LMBase {
         if (d_pfx_.p) return;
         d_pfx_.alloc(sizeof(float) * 64 * a_.dim);
         d_pfq_.alloc(sizeof(float) * 64 * a_.dim);
-        d_pfattn_.alloc(sizeof(float) * 64 * a_.dim);
-        d_pfact_.alloc(sizeof(float) * 64 * a_.intermediate_size);
+        d_pfslab_.alloc(sizeof(float) * 4 * 64 * a_.dim);
+        d_pfa_.alloc(sizeof(uint16_t) * 2 * 64 * a_.dim);
+        d_pfc_.alloc(sizeof(uint16_t) * 2 * 64 * a_.intermediate_size);
         d_pfpart_.alloc(sizeof(float) * 64 * (size_t)a_.n_head * n_chunks_ * (a_.head_dim + 2));
+        FS_HIP(hipMemsetAsync(d_pfa_.p, 0, d_pfa_.n, st_));
+        FS_HIP(hipMemsetAsync(d_pfc_.p, 0, d_pfc_.n, st_));
+    }
+    RowsCtx rows_ctx(const SeqState* st, int pos_step, int pt_stride) {
+        RowsCtx c;
+        c.X = d_pfx_.as<float>(); c.Q = d_pfq_.as<float>(); c.part = d_pfpart_.as<float>(); c.P = d_pfslab_.as<float>();
+        c.Ahi = d_pfa_.as<uint16_t>(); c.Alo = c.Ahi + (size_t)64 * a_.dim;
+        c.Chi = d_pfc_.as<uint16_t>(); c.Clo = c.Chi + (size_t)64 * a_.intermediate_size;
+        c.cos_t = d_cos_.as<float>(); c.sin_t = d_sin_.as<float>();
+        c.state = st; c.n_chunks_max = n_chunks_; c.nc_launch = n_chunks_; c.pos_step = pos_step; c.pt_stride = pt_stride;
+        return c;
     }
 
     // ---- kernel sequences
@@ -572,7 +592,7 @@ class LM final : public LMBase {
             const LayerW& w = slow_[l];
             KVView kv = slow_kv(l, b);
             LmKernels<WT>::qkv(d_, x(b), w, d_cos_.as<float>(), d_sin_.as<float>(), state(b), 0, 0, d_q_.as<float>(), kv, st_);
-            LmKernels<WT>::attn_decode(d_, d_q_.as<float>(), kv, state(b), d_part_.as<float>(), n_chunks_, st_);
+            LmKernels<WT>::attn_decode(d_, d_q_.as<float>(), kv, state(b), d_part_.as<float>(), n_chunks_, nc_launch_, st_);
             LmKernels<WT>::wo(d_, d_part_.as<float>(), n_chunks_, state(b), nullptr, kv, 0, w, x(b), st_);
             LmKernels<WT>::ffn_up(d_, x(b), w, d_act_.as<float>(), st_);
             LmKernels<WT>::ffn_down(d_, d_act_.as<float>(), w, x(b), st_);
@@ -589,6 +609,25 @@ class LM final : public LMBase {
         }
     }
 
+    // smallest power-of-two chunk count covering KV length T (the host knows every frame's position in advance)
+    int chunk_bucket(int T) const {
+        const int need = (T + LmKernels<WT>::attn_chunk() - 1) / LmKernels<WT>::attn_chunk();
+        int b = 1;
+        while (b < need) b <<= 1;
+        return std::min(b, n_chunks_);
+    }
+    void set_bucket(int T) { nc_launch_ = chunk_bucket(T); }
+    // graphs for the bucket currently in nc_launch_ (captured on first use)
+    void use_graphs_for_bucket() {
+        auto it = graphs_.find(nc_launch_);
+        if (it == graphs_.end()) {
+            g_frame_ = nullptr; g_step_ = nullptr;
+            build_graphs();
+            graphs_[nc_launch_] = {g_frame_, g_step_};
+        } else {
+            g_frame_ = it->second.first; g_step_ = it->second.second;
+        }
+    }
     void build_graphs() {
         if (g_frame_) return;
         FS_REQUIRE(a_.num_codebooks <= 8, "the fused fast-decoder attention holds at most 8 positions");
@@ -639,7 +678,8 @@ class LM final : public LMBase {
     const float *norm_w_ = nullptr, *fast_norm_w_ = nullptr;
     DevBuf d_cos_, d_sin_;
     // KV
-    int max_pages_ = 0, n_pages_ = 0, out_cap_ = 0, n_chunks_ = 0;
+    int max_pages_ = 0, n_pages_ = 0, out_cap_ = 0, n_chunks_ = 0, nc_launch_ = 1;
+    std::map<int, std::pair<hipGraphExec_t, hipGraphExec_t>> graphs_;  // attention chunk bucket -> (frame, prefill-step) graphs
     size_t page_elems_ = 0;
     DevBuf kv_pool_, fast_pool_, d_page_table_, d_zero_table_;
     std::vector<int> free_pages_, seq_len_, fast_len_;
@@ -647,7 +687,7 @@ class LM final : public LMBase {
     // activations / state
     DevBuf d_x_, d_xf_, d_q_, d_part_, d_act_, d_logits_slow_, d_logits_fast_, d_state_, d_cfg_, d_rng_, d_prompt_, d_out_;
     DevBuf d_rp_mask_, d_rp_seen_, d_rp_ring_, d_rp_meta_;
-    DevBuf d_pfx_, d_pfq_, d_pfattn_, d_pfact_, d_pfpart_;  // chunked-prefill activations (64 tokens)
+    DevBuf d_pfx_, d_pfq_, d_pfslab_, d_pfa_, d_pfc_, d_pfpart_;  // MFMA row-path activations (64 rows)
     RepPenState rp_ = {};
     void* h_pin_ = nullptr;
     hipGraphExec_t g_frame_ = nullptr, g_step_ = nullptr;

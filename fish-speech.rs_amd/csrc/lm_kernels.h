@@ -56,6 +56,22 @@ struct ModelDims {
 
 struct SampleCfg;
 
+// Buffers + row mapping of the MFMA row path (prefill chunks / batched decode).  All activation buffers hold 64 rows.
+struct RowsCtx {
+    float* X;            // [64][dim]   residual stream (f32)
+    float* Q;            // [64][dim]   rope'd queries (f32)
+    float* part;         // [64][H][n_chunks_max][Dh + 2] attention partials
+    float* P;            // [4][64][dim] down-projection split-K slabs
+    uint16_t *Ahi, *Alo; // [64][dim]   bf16 hi/lo GEMM input (normed x / attention output)
+    uint16_t *Chi, *Clo; // [64][inter] bf16 hi/lo SwiGLU activations
+    const float *cos_t, *sin_t;
+    const SeqState* state;  // position source (row m sits at state->pos + m * pos_step)
+    int n_chunks_max;    // stride of `part`
+    int nc_launch;       // attention chunks launched (covers the longest row of this pass)
+    int pos_step;        // 1: rows = consecutive tokens of one sequence (prefill); 0: rows = sequences (batched decode)
+    int pt_stride;       // page-table stride between rows (0 for prefill)
+};
+
 // ---- launchers (all asynchronous on `st`) -------------------------------------------------------------------
 template <typename WT>
 struct LmKernels {
@@ -66,8 +82,10 @@ struct LmKernels {
     // decode attention over the paged cache: un-normalised partial {o[Dh], m, l} per (q head, token chunk);
     // part: [H][n_chunks_max][Dh + 2]; chunk c covers tokens [c * attn_chunk(), (c + 1) * attn_chunk())
     static int attn_chunk();
+    // nc_launch: chunks actually launched (>= ceil(T / attn_chunk()) for every T the launch will see; the host knows
+    // the position of every frame, so graphs are captured per power-of-two bucket of nc_launch)
     static void attn_decode(const ModelDims& d, const float* q, KVView kv, const SeqState* state, float* part,
-                            int n_chunks_max, hipStream_t st);
+                            int n_chunks_max, int nc_launch, hipStream_t st);
     // combine the chunks of state->pos + 1 tokens (or, fused_T > 0: attend over fused_T <= 8 cached tokens in the
     // prologue) -> Wo GEMV -> x += .
     static void wo(const ModelDims& d, const float* part, int n_chunks_max, const SeqState* state, const float* q, KVView kv,
@@ -87,11 +105,11 @@ struct LmKernels {
     static void prefill_embed(const ModelDims& d, const void* tok_emb, const void* cb_emb, int n_cb, int cb_size,
                               const SampleCfg* cfg, const uint32_t* prompt, const SeqState* state, int M, float* X,
                               hipStream_t st);
-    // one transformer block over the M tokens at positions state->pos .. state->pos + M - 1 (X updated in place):
-    // rmsnorm+Wqkv+rope+KV append | causal attention over the paged cache | Wo + residual | rmsnorm+W13+SwiGLU | W2 + residual
-    static void prefill_layer(const ModelDims& d, int M, float* X, const LayerW& w, const float* cos_t, const float* sin_t,
-                              const SeqState* state, KVView kv, float* Q, float* part, int n_chunks_max, float* attn,
-                              float* act, hipStream_t st);
+    // one transformer block over M <= 64 activation rows (X updated in place up to the down-projection, whose split-K
+    // slabs are folded in by the NEXT rows_layer / rows_finish):
+    //   x += slabs | rmsnorm+Wqkv+rope+KV append | attention over the paged cache | Wo + residual | rmsnorm+W13+SwiGLU | W2 slabs
+    static void rows_layer(const ModelDims& d, int M, const RowsCtx& c, const LayerW& w, KVView kv, bool first, hipStream_t st);
+    static void rows_finish(const ModelDims& d, int M, const RowsCtx& c, const float* norm_w, hipStream_t st);
     // fast_embeddings gather: out[i] = fast_emb[ids[i]]
     static void fast_embed(const ModelDims& d, const void* fast_emb, const uint32_t* ids, int n, float* out,
                            hipStream_t st);

@@ -216,8 +216,10 @@ template <> struct AttnGeom<float> { static constexpr int TW = 16, NW = 4; };   
 template <typename WT, int DH, int NREP>
 __global__ __launch_bounds__(AttnGeom<WT>::NW * 64) void k_attn_decode(const float* __restrict__ q_all, KVView kv,
                                                      const SeqState* __restrict__ state, float* __restrict__ part_all,
-                                                     int Hk, int n_chunks_max) {
-    // blockIdx.y = query token m of a prefill chunk (0 for decode): it sees the KV prefix of length pos + 1 + m
+                                                     int Hk, int n_chunks_max, int nc_launch, int pos_step, int pt_stride) {
+    // blockIdx.y = activation row m (0 for the batch-1 decode step): prefill -> token pos + m of one sequence (pos_step 1,
+    // pt_stride 0); batched decode -> sequence m at pos (pos_step 0, pt_stride = page-table stride)
+    kv.page_table += (size_t)blockIdx.y * pt_stride;
     const float* q = q_all + (size_t)blockIdx.y * Hk * NREP * DH;
     float* part = part_all + (size_t)blockIdx.y * Hk * NREP * n_chunks_max * (DH + 2);
     constexpr int EPL = WTr<WT>::EPL;
@@ -233,8 +235,8 @@ __global__ __launch_bounds__(AttnGeom<WT>::NW * 64) void k_attn_decode(const flo
     constexpr int NLD = TW * LPT / 64;       // 16-B loads per lane per tile
     static_assert(TW % NTS == 0 && NLD >= 1, "attention geometry");
     using vec = typename WTr<WT>::vec;
-    const int g = blockIdx.x / n_chunks_max, c = blockIdx.x % n_chunks_max;
-    const int T = state->pos + 1 + (int)blockIdx.y;  // the current token's K/V were appended by k_qkv
+    const int g = blockIdx.x / nc_launch, c = blockIdx.x % nc_launch;  // nc_launch <= n_chunks_max chunks are launched
+    const int T = state->pos + 1 + (int)blockIdx.y * pos_step;  // the row's own K/V were appended by the qkv stage
     if (c * CH >= T) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __shared__ __attribute__((aligned(16))) WT sk[NW][TW * DH];
@@ -588,113 +590,163 @@ __global__ void k_advance(SeqState* state) {
     state->step += 1;
 }
 
-// ------------------------------------------------------------------------------------------------ chunked prefill (MFMA)
-// Prompt tokens are processed M <= 64 at a time with the SAME fused stages as the decode step, but the GEMVs become
-// skinny GEMMs on the matrix cores: Y[M, N] = f(A[M, K]) . W[N, K]^T with bf16 weights streamed once per chunk.
-// Numerics: activations stay f32 end to end -- each K-slice of A is split into bf16 hi + bf16 lo parts (a = hi + lo up
-// to 2^-17 relative) and both parts go through v_mfma_f32_16x16x32_bf16 with f32 accumulation, so prefill agrees with
-// the f32-activation decode path far below bf16 resolution (the reference's own CUDA path rounds activations to bf16).
-// Tile: block = 4 waves x 16 weight rows = 64 rows of W, all <= 64 tokens (4 MFMA column tiles); A-operand = weights
-// straight from global (lane l: row l&15, 16 B at k = (l>>4)*8), B-operand = staged activations from LDS.
+// ------------------------------------------------------------------------------------------------ skinny GEMMs (MFMA)
+// M <= 64 rows of activations against bf16 weights streamed ONCE: used by the chunked prefill (rows = consecutive
+// prompt tokens of one sequence) and by the batched decode step (rows = sequences).  Y[M, N] = f(A[M, K]) . W[N, K]^T.
+// Numerics: activations stay f32-grade end to end -- every GEMM input is split once into bf16 hi + bf16 lo parts
+// (a = hi + lo up to 2^-17 relative; k_prep / producer epilogues) and both parts go through v_mfma_f32_16x16x32_bf16 with
+// f32 accumulation, so the MFMA path agrees with the f32-activation GEMV path far below bf16 resolution (the reference's
+// own CUDA path rounds activations to bf16).
+// Tile: block = 4 waves x 16 weight rows = 64 rows of W, all 64 activation rows (4 MFMA column tiles), K range =
+// [blockIdx.y * K/ksplit, ...).  A-operand = weights straight from global (lane l: row l&15, 16 B at k = (l>>4)*8,
+// non-temporal), B-operand = activation hi/lo slices double-buffered in LDS; one barrier per 64-wide K slice, the next
+// slice's global loads are issued before the current slice's MFMAs.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
-constexpr int PF_M = 64;    // max tokens per chunk
+constexpr int PF_M = 64;    // activation rows per pass
 constexpr int PF_BK = 64;   // K-slice
 constexpr int PF_LD = PF_BK + 8;
 
 enum { EPI_STORE = 0, EPI_RESIDUAL = 1, EPI_SWIGLU = 2, EPI_QKV = 3 };
 
-template <int EPI, bool NORM>
-__global__ __launch_bounds__(256) void k_gemm_skinny(const float* __restrict__ A, int lda, int M, int K,
-                                                     const float* __restrict__ norm_w, float eps,
-                                                     const bf16_t* __restrict__ W, int N, float* __restrict__ Y, int ldy,
-                                                     const float* __restrict__ cos_t, const float* __restrict__ sin_t,
-                                                     const SeqState* __restrict__ state, KVView kv, int H, int Hk, int Dh) {
-    __shared__ __attribute__((aligned(16))) bf16_t xs_hi[PF_M * PF_LD];
-    __shared__ __attribute__((aligned(16))) bf16_t xs_lo[PF_M * PF_LD];
-    __shared__ float rinv[PF_M];
+struct RowMap {       // how activation row m maps onto sequences / positions
+    int pos_step;     // prefill: 1 (row m = token at pos + m of ONE sequence); batched decode: 0 (every row at pos)
+    int pt_stride;    // prefill: 0 (one page table); batched decode: page-table stride between sequences
+};
+
+__device__ __forceinline__ void split_bf16(float a, bf16_t& hi, bf16_t& lo) {
+    hi = WTr<bf16_t>::from_f32(a);
+    lo = WTr<bf16_t>::from_f32(a - WTr<bf16_t>::to_f32(hi));
+}
+
+// X[m] (+= sum_s P[s][m], fixed order) ; optional RMSNorm ; emit bf16 hi/lo [PF_M][D].  One block per row.
+__global__ __launch_bounds__(256) void k_prep(float* __restrict__ X, int D, const float* __restrict__ P, int S, size_t slab_stride,
+                                              const float* __restrict__ norm_w, float eps, bf16_t* __restrict__ Ohi,
+                                              bf16_t* __restrict__ Olo) {
+    __shared__ float red[4];
+    const int m = blockIdx.x;
+    float* xm = X + (size_t)m * D;
+    float ss = 0.f;
+    for (int e = threadIdx.x * 4; e < D; e += 1024) {
+        float4 v = *reinterpret_cast<const float4*>(xm + e);
+        for (int sI = 0; sI < S; ++sI) {
+            const float4 p = *reinterpret_cast<const float4*>(P + (size_t)sI * slab_stride + (size_t)m * D + e);
+            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        }
+        if (S > 0) *reinterpret_cast<float4*>(xm + e) = v;
+        ss = fmaf(v.x, v.x, ss); ss = fmaf(v.y, v.y, ss); ss = fmaf(v.z, v.z, ss); ss = fmaf(v.w, v.w, ss);
+    }
+    if (!Ohi) return;
+    float d = 1.f;
+    if (norm_w) {
+        ss = wave_sum(ss);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+        __syncthreads();
+        d = sqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)D + eps);
+    }
+    for (int e = threadIdx.x * 4; e < D; e += 1024) {
+        const float4 v = *reinterpret_cast<const float4*>(xm + e);  // own earlier write (same thread)
+        float a[4] = {v.x, v.y, v.z, v.w};
+        if (norm_w) {
+            const float4 w = *reinterpret_cast<const float4*>(norm_w + e);
+            a[0] = (a[0] / d) * w.x; a[1] = (a[1] / d) * w.y; a[2] = (a[2] / d) * w.z; a[3] = (a[3] / d) * w.w;
+        }
+        bf16_t hi[4], lo[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) split_bf16(a[i], hi[i], lo[i]);
+        uint2 ph, pl;
+        ph.x = hi[0] | ((uint32_t)hi[1] << 16); ph.y = hi[2] | ((uint32_t)hi[3] << 16);
+        pl.x = lo[0] | ((uint32_t)lo[1] << 16); pl.y = lo[2] | ((uint32_t)lo[3] << 16);
+        *reinterpret_cast<uint2*>(Ohi + (size_t)m * D + e) = ph;
+        *reinterpret_cast<uint2*>(Olo + (size_t)m * D + e) = pl;
+    }
+}
+
+constexpr int G_BK = 256;            // K slice held in LDS (per buffer: 2 parts x 64 rows x (256 + 8) bf16 = 67.6 KB)
+constexpr int G_LD = G_BK + 8;
+constexpr int G_NS = 4;              // max slices per block => K per block <= 1024 (larger K is split over blockIdx.y)
+constexpr size_t G_LDS_BYTES = (size_t)2 * 2 * PF_M * G_LD * sizeof(bf16_t);
+
+template <int EPI, int BK>
+__global__ __launch_bounds__(256) void k_gemm2(const bf16_t* __restrict__ Xhi, const bf16_t* __restrict__ Xlo, int M, int K, int ksplit,
+                                               const bf16_t* __restrict__ W, int N, float* __restrict__ Y, int ldy,
+                                               bf16_t* __restrict__ Ohi, bf16_t* __restrict__ Olo, int ldo,
+                                               const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                                               const SeqState* __restrict__ state, KVView kv, int H, int Hk, int Dh, RowMap rm) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t xs_dyn[];  // [2 buffers][2 parts][PF_M][G_LD]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n0 = blockIdx.x * 64 + wave * 16;  // this wave's 16 weight rows
-    if (NORM) {
-        for (int m = wave; m < PF_M; m += 4) {
-            float ss = 0.f;
-            if (m < M)
-                for (int k = lane * 4; k < K; k += 256) {
-                    const float4 t = *reinterpret_cast<const float4*>(A + (size_t)m * lda + k);
-                    ss = fmaf(t.x, t.x, ss); ss = fmaf(t.y, t.y, ss); ss = fmaf(t.z, t.z, ss); ss = fmaf(t.w, t.w, ss);
-                }
-            ss = wave_sum(ss);
-            if (lane == 0) rinv[m] = 1.0f / sqrtf(ss / (float)K + eps);
-        }
-        __syncthreads();
-    }
+    const int Kb = K / ksplit, kbeg = blockIdx.y * Kb;
+    constexpr int bk = BK;
+    const int ns = Kb / bk;  // host guarantees Kb % BK == 0, ns <= G_NS
     f32x4v acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    // ---- the block's whole weight panel goes in flight at once (GEMV-style: <= 32 x 16 B per lane), X slices follow
+    // one slice ahead through a double-buffered LDS tile shared by the 4 waves
     const int wrow = min(n0 + (lane & 15), N - 1);
-    const bf16_t* wp = W + (size_t)wrow * K + (lane >> 4) * 8;
-    u32x4 wf[2], wn[2];
-    wf[0] = ld_stream(reinterpret_cast<const u32x4*>(wp));
-    wf[1] = ld_stream(reinterpret_cast<const u32x4*>(wp + 32));
-    const int sm = threadIdx.x >> 2, sk = (threadIdx.x & 3) * 16;  // staging: token sm, 16 consecutive k
-    for (int kb = 0; kb < K; kb += PF_BK) {
-        // stage A[:, kb : kb + 64] as bf16 hi / lo
-        {
-            float a[16];
+    const bf16_t* wp = W + (size_t)wrow * K + kbeg + (lane >> 4) * 8;
+    // staging map (coalesced): part = tid >> 7 (0 = hi, 1 = lo); vector v = i * 128 + (tid & 127) of the part's
+    // [64 rows][bk / 8] grid of 16-B vectors -> consecutive lanes read consecutive 16-B pieces of one activation row
+    const int spart = threadIdx.x >> 7, su = threadIdx.x & 127;
+    constexpr int vpr = bk / 8;      // 16-B vectors per row per slice
+    constexpr int nvx = vpr / 2;         // vectors per thread per slice (64 rows * vpr / 128 threads), <= 16
+    const bf16_t* xg = (spart ? Xlo : Xhi) + kbeg;
+    auto xoff = [&](int i) { const int v = i * 128 + su; return (size_t)(v / vpr) * K + (size_t)(v % vpr) * 8; };   // global element offset
+    auto loff = [&](int i) { const int v = i * 128 + su; return (v / vpr) * G_LD + (v % vpr) * 8; };                 // LDS element offset
+    u32x4 xr[16];
 #pragma unroll
-            for (int i = 0; i < 16; i += 4) {
-                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (sm < M) t = *reinterpret_cast<const float4*>(A + (size_t)sm * lda + kb + sk + i);
-                a[i] = t.x; a[i + 1] = t.y; a[i + 2] = t.z; a[i + 3] = t.w;
+    for (int i = 0; i < 16; ++i)
+        if (i < nvx) xr[i] = *reinterpret_cast<const u32x4*>(xg + xoff(i));
+    u32x4 wf[G_NS][8];
+#pragma unroll
+    for (int sI = 0; sI < G_NS; ++sI)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+            if (sI < ns && ks * 32 < bk) wf[sI][ks] = ld_stream(reinterpret_cast<const u32x4*>(wp + (size_t)sI * bk + ks * 32));
+    auto xbuf = [&](int buf, int part) { return xs_dyn + ((size_t)(buf * 2 + part) * PF_M) * G_LD; };
+    {
+        bf16_t* dst = xbuf(0, spart);
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i < nvx) *reinterpret_cast<u32x4*>(dst + loff(i)) = xr[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int sI = 0; sI < G_NS; ++sI) {
+        if (sI < ns) {
+            const int cur = sI & 1;
+            if (sI + 1 < ns) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (i < nvx) xr[i] = *reinterpret_cast<const u32x4*>(xg + (size_t)(sI + 1) * bk + xoff(i));
             }
-            if (NORM) {
-                const float r = rinv[sm];
+            const bf16_t* bh0 = xbuf(cur, 0);
+            const bf16_t* bl0 = xbuf(cur, 1);
 #pragma unroll
-                for (int i = 0; i < 16; i += 4) {
-                    const float4 nw = *reinterpret_cast<const float4*>(norm_w + kb + sk + i);
-                    a[i] = (a[i] * r) * nw.x; a[i + 1] = (a[i + 1] * r) * nw.y;
-                    a[i + 2] = (a[i + 2] * r) * nw.z; a[i + 3] = (a[i + 3] * r) * nw.w;
+            for (int ks = 0; ks < 8; ++ks) {
+                if (ks * 32 < bk) {
+                    const bf16x8 af = __builtin_bit_cast(bf16x8, wf[sI][ks]);
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        const int off = (mt * 16 + (lane & 15)) * G_LD + ks * 32 + (lane >> 4) * 8;
+                        const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bh0 + off));
+                        const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bl0 + off));
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bh, acc[mt], 0, 0, 0);
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bl, acc[mt], 0, 0, 0);
+                    }
                 }
             }
-            bf16_t hi[16], lo[16];
+            if (sI + 1 < ns) {
+                bf16_t* dst = xbuf(cur ^ 1, spart);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                hi[i] = WTr<bf16_t>::from_f32(a[i]);
-                lo[i] = WTr<bf16_t>::from_f32(a[i] - WTr<bf16_t>::to_f32(hi[i]));
+                for (int i = 0; i < 16; ++i)
+                    if (i < nvx) *reinterpret_cast<u32x4*>(dst + loff(i)) = xr[i];
             }
-            u32x4* dh = reinterpret_cast<u32x4*>(&xs_hi[sm * PF_LD + sk]);
-            u32x4* dl = reinterpret_cast<u32x4*>(&xs_lo[sm * PF_LD + sk]);
-#pragma unroll
-            for (int v = 0; v < 2; ++v) {
-                u32x4 ph, pl;
-                ph.x = hi[v * 8] | ((uint32_t)hi[v * 8 + 1] << 16); ph.y = hi[v * 8 + 2] | ((uint32_t)hi[v * 8 + 3] << 16);
-                ph.z = hi[v * 8 + 4] | ((uint32_t)hi[v * 8 + 5] << 16); ph.w = hi[v * 8 + 6] | ((uint32_t)hi[v * 8 + 7] << 16);
-                pl.x = lo[v * 8] | ((uint32_t)lo[v * 8 + 1] << 16); pl.y = lo[v * 8 + 2] | ((uint32_t)lo[v * 8 + 3] << 16);
-                pl.z = lo[v * 8 + 4] | ((uint32_t)lo[v * 8 + 5] << 16); pl.w = lo[v * 8 + 6] | ((uint32_t)lo[v * 8 + 7] << 16);
-                dh[v] = ph; dl[v] = pl;
-            }
+            __syncthreads();
         }
-        if (kb + PF_BK < K) {  // prefetch the next slice's weight fragments
-            wn[0] = ld_stream(reinterpret_cast<const u32x4*>(wp + kb + PF_BK));
-            wn[1] = ld_stream(reinterpret_cast<const u32x4*>(wp + kb + PF_BK + 32));
-        }
-        __syncthreads();
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const bf16x8 af = __builtin_bit_cast(bf16x8, wf[ks]);
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const int off = (mt * 16 + (lane & 15)) * PF_LD + ks * 32 + (lane >> 4) * 8;
-                const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&xs_hi[off]));
-                const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&xs_lo[off]));
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bh, acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bl, acc[mt], 0, 0, 0);
-            }
-        }
-        __syncthreads();
-        wf[0] = wn[0]; wf[1] = wn[1];
     }
-    // epilogue: lane holds C[row = n0 + (lane>>4)*4 + i][token = mt*16 + (lane&15)], i = 0..3
+    // epilogue: lane holds C[row = n0 + (lane>>4)*4 + i][m = mt*16 + (lane&15)], i = 0..3
     const int r0 = n0 + (lane >> 4) * 4;
     if (r0 >= N) return;
 #pragma unroll
@@ -702,19 +754,21 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(const float* __restrict__ A
         const int m = mt * 16 + (lane & 15);
         if (m >= M) continue;
         const f32x4v c = acc[mt];
-        if (EPI == EPI_STORE) {
-            *reinterpret_cast<float4*>(Y + (size_t)m * ldy + r0) = make_float4(c.x, c.y, c.z, c.w);
+        if (EPI == EPI_STORE) {  // split-K slab blockIdx.y
+            *reinterpret_cast<float4*>(Y + (size_t)blockIdx.y * PF_M * ldy + (size_t)m * ldy + r0) = make_float4(c.x, c.y, c.z, c.w);
         } else if (EPI == EPI_RESIDUAL) {
             float4* yp = reinterpret_cast<float4*>(Y + (size_t)m * ldy + r0);
             const float4 o = *yp;
             *yp = make_float4(o.x + c.x, o.y + c.y, o.z + c.z, o.w + c.w);
-        } else if (EPI == EPI_SWIGLU) {  // interleaved rows (2r, 2r+1) = (w1[r], w3[r])
-            float2 o;
-            o.x = (c.x / (1.f + __expf(-c.x))) * c.y;
-            o.y = (c.z / (1.f + __expf(-c.z))) * c.w;
-            *reinterpret_cast<float2*>(Y + (size_t)m * ldy + r0 / 2) = o;
-        } else {  // EPI_QKV: rope_i + scatter (q -> Y[m][r], k/v -> paged cache at pos + m)
-            const int pos = state->pos + m, rpos = pos + state->rope_off;
+        } else if (EPI == EPI_SWIGLU) {  // interleaved rows (2r, 2r+1) = (w1[r], w3[r]) -> act hi/lo for the down GEMM
+            const float a0 = (c.x / (1.f + __expf(-c.x))) * c.y, a1 = (c.z / (1.f + __expf(-c.z))) * c.w;
+            bf16_t h0, l0, h1, l1;
+            split_bf16(a0, h0, l0); split_bf16(a1, h1, l1);
+            *reinterpret_cast<uint32_t*>(Ohi + (size_t)m * ldo + r0 / 2) = h0 | ((uint32_t)h1 << 16);
+            *reinterpret_cast<uint32_t*>(Olo + (size_t)m * ldo + r0 / 2) = l0 | ((uint32_t)l1 << 16);
+        } else {  // EPI_QKV: rope_i + scatter (q -> Y[m][r], k/v -> paged cache of row m's sequence)
+            const int pos = state->pos + m * rm.pos_step, rpos = pos + state->rope_off;
+            const int* ptab = kv.page_table + (size_t)m * rm.pt_stride;
             const int qdim = H * Dh, kdim = Hk * Dh, half = Dh / 2;
             const float vals[4] = {c.x, c.y, c.z, c.w};
 #pragma unroll
@@ -728,12 +782,12 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(const float* __restrict__ A
                     if (r < qdim) { Y[(size_t)m * ldy + r] = o0; Y[(size_t)m * ldy + r + 1] = o1; }
                     else {
                         const int rk = r - qdim;
-                        bf16_t* dst = kv_addr<bf16_t>(kv.k, kv.page_table, pos, rk / Dh, Hk, Dh) + rk % Dh;
+                        bf16_t* dst = kv_addr<bf16_t>(kv.k, ptab, pos, rk / Dh, Hk, Dh) + rk % Dh;
                         dst[0] = WTr<bf16_t>::from_f32(o0); dst[1] = WTr<bf16_t>::from_f32(o1);
                     }
                 } else {
                     const int rv = r - qdim - kdim;
-                    bf16_t* dst = kv_addr<bf16_t>(kv.v, kv.page_table, pos, rv / Dh, Hk, Dh) + rv % Dh;
+                    bf16_t* dst = kv_addr<bf16_t>(kv.v, ptab, pos, rv / Dh, Hk, Dh) + rv % Dh;
                     dst[0] = WTr<bf16_t>::from_f32(a); dst[1] = WTr<bf16_t>::from_f32(b);
                 }
             }
@@ -741,12 +795,13 @@ __global__ __launch_bounds__(256) void k_gemm_skinny(const float* __restrict__ A
     }
 }
 
-// combine the per-chunk attention partials of M query tokens: attn[m][h*DH + dd]
+// combine the per-chunk attention partials of M rows -> attn hi/lo bf16 [PF_M][H*DH] (input of the Wo GEMM)
 template <int DH>
 __global__ __launch_bounds__(256) void k_attn_combine(const float* __restrict__ part_all, int n_chunks_max, int chunk,
-                                                      const SeqState* __restrict__ state, float* __restrict__ attn, int H) {
+                                                      const SeqState* __restrict__ state, int pos_step, bf16_t* __restrict__ Ohi,
+                                                      bf16_t* __restrict__ Olo, int H) {
     const int m = blockIdx.x;
-    const int T = state->pos + 1 + m, nc = (T + chunk - 1) / chunk;
+    const int T = state->pos + 1 + m * pos_step, nc = (T + chunk - 1) / chunk;
     const float* part = part_all + (size_t)m * H * n_chunks_max * (DH + 2);
     __shared__ float wl[32 * 128];
     for (int h = threadIdx.x; h < H; h += 256) {
@@ -764,7 +819,10 @@ __global__ __launch_bounds__(256) void k_attn_combine(const float* __restrict__ 
         const float* p = part + (size_t)h * n_chunks_max * (DH + 2) + dd;
         float O = 0.f;
         for (int c = 0; c < nc; ++c) O = fmaf(wl[h * 128 + c], p[c * (DH + 2)], O);
-        attn[(size_t)m * H * DH + e] = O;
+        bf16_t hi, lo;
+        split_bf16(O, hi, lo);
+        Ohi[(size_t)m * H * DH + e] = hi;
+        Olo[(size_t)m * H * DH + e] = lo;
     }
 }
 
@@ -1102,15 +1160,16 @@ int LmKernels<WT>::attn_chunk() { return AttnGeom<WT>::NW * AttnGeom<WT>::TW; }
 
 template <typename WT>
 void LmKernels<WT>::attn_decode(const ModelDims& d, const float* q, KVView kv, const SeqState* state, float* part,
-                                int n_chunks_max, hipStream_t st) {
-    const int grid = d.Hk * n_chunks_max;
+                                int n_chunks_max, int nc_launch, hipStream_t st) {
+    FS_REQUIRE(nc_launch >= 1 && nc_launch <= n_chunks_max, "bad attention chunk count");
+    const int grid = d.Hk * nc_launch;
     FS_REQUIRE(n_chunks_max <= 128, "attention supports at most 128 chunks per sequence");
     if (d.Dh == 64 && d.n_rep == 8)
-        hipLaunchKernelGGL((k_attn_decode<WT, 64, 8>), dim3(grid), dim3(AttnGeom<WT>::NW * 64), 0, st, q, kv, state, part, d.Hk, n_chunks_max);
+        hipLaunchKernelGGL((k_attn_decode<WT, 64, 8>), dim3(grid), dim3(AttnGeom<WT>::NW * 64), 0, st, q, kv, state, part, d.Hk, n_chunks_max, nc_launch, 0, 0);
     else if (d.Dh == 32 && d.n_rep == 2)
-        hipLaunchKernelGGL((k_attn_decode<WT, 32, 2>), dim3(grid), dim3(AttnGeom<WT>::NW * 64), 0, st, q, kv, state, part, d.Hk, n_chunks_max);
+        hipLaunchKernelGGL((k_attn_decode<WT, 32, 2>), dim3(grid), dim3(AttnGeom<WT>::NW * 64), 0, st, q, kv, state, part, d.Hk, n_chunks_max, nc_launch, 0, 0);
     else if (d.Dh == 64 && d.n_rep == 2)
-        hipLaunchKernelGGL((k_attn_decode<WT, 64, 2>), dim3(grid), dim3(AttnGeom<WT>::NW * 64), 0, st, q, kv, state, part, d.Hk, n_chunks_max);
+        hipLaunchKernelGGL((k_attn_decode<WT, 64, 2>), dim3(grid), dim3(AttnGeom<WT>::NW * 64), 0, st, q, kv, state, part, d.Hk, n_chunks_max, nc_launch, 0, 0);
     else
         throw Error("unsupported attention geometry (head_dim, n_rep) = (" + std::to_string(d.Dh) + ", " +
                     std::to_string(d.n_rep) + ")");
@@ -1258,42 +1317,84 @@ void LmKernels<WT>::prefill_embed(const ModelDims& d, const void* tok_emb, const
     FS_LAUNCH_CHECK();
 }
 
+template <int EPI>
+static void launch_gemm2(dim3 grid, hipStream_t st, const bf16_t* Xhi, const bf16_t* Xlo, int M, int K, int ksplit, const bf16_t* W, int N,
+                         float* Y, int ldy, bf16_t* Ohi, bf16_t* Olo, int ldo, const float* cos_t, const float* sin_t,
+                         const SeqState* state, KVView kv, int H, int Hk, int Dh, RowMap rm) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2<EPI, G_BK>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)G_LDS_BYTES));
+        FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2<EPI, 64>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)G_LDS_BYTES));
+        attr_set = true;
+    }
+    const int Kb = K / ksplit;
+    FS_REQUIRE(K % ksplit == 0 && Kb % 64 == 0, "unsupported GEMM depth for the MFMA row path");
+    if (Kb % G_BK == 0) {
+        FS_REQUIRE(Kb / G_BK <= G_NS, "GEMM depth per block above 1024: raise the K split");
+        hipLaunchKernelGGL((k_gemm2<EPI, G_BK>), grid, dim3(256), G_LDS_BYTES, st, Xhi, Xlo, M, K, ksplit, W, N, Y, ldy, Ohi, Olo, ldo, cos_t,
+                           sin_t, state, kv, H, Hk, Dh, rm);
+    } else {  // small test configurations
+        FS_REQUIRE(Kb / 64 <= G_NS, "GEMM depth per block above 256 must be a multiple of 256");
+        hipLaunchKernelGGL((k_gemm2<EPI, 64>), grid, dim3(256), G_LDS_BYTES, st, Xhi, Xlo, M, K, ksplit, W, N, Y, ldy, Ohi, Olo, ldo, cos_t,
+                           sin_t, state, kv, H, Hk, Dh, rm);
+    }
+}
+
 template <typename WT>
-void LmKernels<WT>::prefill_layer(const ModelDims& d, int M, float* X, const LayerW& w, const float* cos_t, const float* sin_t,
-                                  const SeqState* state, KVView kv, float* Q, float* part, int n_chunks_max, float* attn,
-                                  float* act, hipStream_t st) {
+void LmKernels<WT>::rows_layer(const ModelDims& d, int M, const RowsCtx& c, const LayerW& w, KVView kv, bool first, hipStream_t st) {
     if constexpr (!std::is_same<WT, bf16_t>::value) {
-        throw Error("MFMA prefill is implemented for bf16 weights only");
+        throw Error("the MFMA row path is implemented for bf16 weights only");
     } else {
-        FS_REQUIRE(M >= 1 && M <= PF_M, "prefill chunk larger than 64 tokens");
-        FS_REQUIRE(d.dim % PF_BK == 0 && d.inter % PF_BK == 0, "prefill needs dim and intermediate_size multiples of 64");
+        FS_REQUIRE(M >= 1 && M <= PF_M, "at most 64 activation rows per pass");
+        FS_REQUIRE(d.dim % 256 == 0 && d.inter % 256 == 0 || (d.dim % PF_BK == 0 && d.inter % (PF_BK * 4) == 0),
+                   "row path needs dim % 64 == 0 and intermediate_size % 256 == 0");
         const int qkv_rows = (d.H + 2 * d.Hk) * d.Dh;
-        const bf16_t* nul = nullptr;
-        (void)nul;
-        hipLaunchKernelGGL((k_gemm_skinny<EPI_QKV, true>), dim3((qkv_rows + 63) / 64), dim3(256), 0, st, X, d.dim, M, d.dim,
-                           w.attn_norm, d.eps, (const bf16_t*)w.wqkv, qkv_rows, Q, d.dim, cos_t, sin_t, state, kv, d.H, d.Hk, d.Dh);
-        const dim3 ga(d.Hk * n_chunks_max, M);
+        const RowMap rm{c.pos_step, c.pt_stride};
+        const RowMap none{0, 0};
+        KVView nokv = {};
+        const size_t slab = (size_t)PF_M * d.dim;
+        constexpr int DOWN_SPLIT = 4;
+        // (1) x += previous layer's down-proj slabs ; RMSNorm(attention_norm) -> hi/lo
+        hipLaunchKernelGGL(k_prep, dim3(M), dim3(256), 0, st, c.X, d.dim, c.P, first ? 0 : DOWN_SPLIT, slab, w.attn_norm, d.eps, c.Ahi, c.Alo);
+        // (2) Wqkv + rope + KV scatter
+        launch_gemm2<EPI_QKV>(dim3((qkv_rows + 63) / 64, 1), st, c.Ahi, c.Alo, M, d.dim, 1, (const bf16_t*)w.wqkv, qkv_rows, c.Q, d.dim,
+                              nullptr, nullptr, 0, c.cos_t, c.sin_t, c.state, kv, d.H, d.Hk, d.Dh, rm);
+        // (3) attention over each row's KV prefix + chunk combine -> hi/lo
+        const dim3 ga(d.Hk * c.nc_launch, M);
+        const dim3 ta(AttnGeom<WT>::NW * 64);
         if (d.Dh == 64 && d.n_rep == 8)
-            hipLaunchKernelGGL((k_attn_decode<WT, 64, 8>), ga, dim3(AttnGeom<WT>::NW * 64), 0, st, Q, kv, state, part, d.Hk, n_chunks_max);
+            hipLaunchKernelGGL((k_attn_decode<WT, 64, 8>), ga, ta, 0, st, c.Q, kv, c.state, c.part, d.Hk, c.n_chunks_max, c.nc_launch, c.pos_step, c.pt_stride);
         else if (d.Dh == 32 && d.n_rep == 2)
-            hipLaunchKernelGGL((k_attn_decode<WT, 32, 2>), ga, dim3(AttnGeom<WT>::NW * 64), 0, st, Q, kv, state, part, d.Hk, n_chunks_max);
+            hipLaunchKernelGGL((k_attn_decode<WT, 32, 2>), ga, ta, 0, st, c.Q, kv, c.state, c.part, d.Hk, c.n_chunks_max, c.nc_launch, c.pos_step, c.pt_stride);
         else if (d.Dh == 64 && d.n_rep == 2)
-            hipLaunchKernelGGL((k_attn_decode<WT, 64, 2>), ga, dim3(AttnGeom<WT>::NW * 64), 0, st, Q, kv, state, part, d.Hk, n_chunks_max);
+            hipLaunchKernelGGL((k_attn_decode<WT, 64, 2>), ga, ta, 0, st, c.Q, kv, c.state, c.part, d.Hk, c.n_chunks_max, c.nc_launch, c.pos_step, c.pt_stride);
         else
             throw Error("unsupported attention geometry");
         if (d.Dh == 64)
-            hipLaunchKernelGGL((k_attn_combine<64>), dim3(M), dim3(256), 0, st, part, n_chunks_max, attn_chunk(), state, attn, d.H);
+            hipLaunchKernelGGL((k_attn_combine<64>), dim3(M), dim3(256), 0, st, c.part, c.n_chunks_max, attn_chunk(), c.state, c.pos_step, c.Ahi, c.Alo, d.H);
         else
-            hipLaunchKernelGGL((k_attn_combine<32>), dim3(M), dim3(256), 0, st, part, n_chunks_max, attn_chunk(), state, attn, d.H);
-        KVView nokv = {};
-        hipLaunchKernelGGL((k_gemm_skinny<EPI_RESIDUAL, false>), dim3((d.dim + 63) / 64), dim3(256), 0, st, attn, d.dim, M, d.dim,
-                           nullptr, 0.f, (const bf16_t*)w.wo, d.dim, X, d.dim, nullptr, nullptr, nullptr, nokv, 0, 0, 0);
-        hipLaunchKernelGGL((k_gemm_skinny<EPI_SWIGLU, true>), dim3((2 * d.inter + 63) / 64), dim3(256), 0, st, X, d.dim, M, d.dim,
-                           w.ffn_norm, d.eps, (const bf16_t*)w.w13, 2 * d.inter, act, d.inter, nullptr, nullptr, nullptr, nokv, 0, 0, 0);
-        hipLaunchKernelGGL((k_gemm_skinny<EPI_RESIDUAL, false>), dim3((d.dim + 63) / 64), dim3(256), 0, st, act, d.inter, M, d.inter,
-                           nullptr, 0.f, (const bf16_t*)w.w2, d.dim, X, d.dim, nullptr, nullptr, nullptr, nokv, 0, 0, 0);
+            hipLaunchKernelGGL((k_attn_combine<32>), dim3(M), dim3(256), 0, st, c.part, c.n_chunks_max, attn_chunk(), c.state, c.pos_step, c.Ahi, c.Alo, d.H);
+        // (4) Wo + residual (each output element owned by one lane: deterministic)
+        launch_gemm2<EPI_RESIDUAL>(dim3((d.dim + 63) / 64, 1), st, c.Ahi, c.Alo, M, d.dim, 1, (const bf16_t*)w.wo, d.dim, c.X, d.dim, nullptr,
+                                   nullptr, 0, nullptr, nullptr, nullptr, nokv, 0, 0, 0, none);
+        // (5) RMSNorm(ffn_norm) -> hi/lo ; W1||W3 + SwiGLU -> act hi/lo ; W2 split-K slabs (summed by the next k_prep)
+        hipLaunchKernelGGL(k_prep, dim3(M), dim3(256), 0, st, c.X, d.dim, (const float*)nullptr, 0, slab, w.ffn_norm, d.eps, c.Ahi, c.Alo);
+        launch_gemm2<EPI_SWIGLU>(dim3((2 * d.inter + 63) / 64, 1), st, c.Ahi, c.Alo, M, d.dim, 1, (const bf16_t*)w.w13, 2 * d.inter, nullptr, 0,
+                                 c.Chi, c.Clo, d.inter, nullptr, nullptr, nullptr, nokv, 0, 0, 0, none);
+        launch_gemm2<EPI_STORE>(dim3((d.dim + 63) / 64, DOWN_SPLIT), st, c.Chi, c.Clo, M, d.inter, DOWN_SPLIT, (const bf16_t*)w.w2, d.dim, c.P,
+                                d.dim, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nokv, 0, 0, 0, none);
         FS_LAUNCH_CHECK();
     }
+}
+
+// x += last layer's down-proj slabs (closes a rows_layer chain); optionally RMSNorm -> hi/lo for a head GEMM
+template <typename WT>
+void LmKernels<WT>::rows_finish(const ModelDims& d, int M, const RowsCtx& c, const float* norm_w, hipStream_t st) {
+    hipLaunchKernelGGL(k_prep, dim3(M), dim3(256), 0, st, c.X, d.dim, c.P, 4, (size_t)PF_M * d.dim, norm_w, d.eps,
+                       norm_w ? c.Ahi : (bf16_t*)nullptr, norm_w ? c.Alo : (bf16_t*)nullptr);
+    FS_LAUNCH_CHECK();
 }
 
 void launch_advance_n(SeqState* state, int n, hipStream_t st) {

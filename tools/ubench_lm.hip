@@ -67,7 +67,7 @@ int main(int argc, char** argv) {
     std::vector<int> pt(max_pages); for (int i = 0; i < max_pages; ++i) pt[i] = i;
     int* d_pt; CK(hipMalloc(&d_pt, max_pages * 4)); CK(hipMemcpy(d_pt, pt.data(), max_pages * 4, hipMemcpyHostToDevice));
     auto kv = [&](int l) { KVView v; v.k = kvpool + (size_t)l * 2 * max_pages * page_elems; v.v = (WT*)v.k + max_pages * page_elems; v.page_table = d_pt; return v; };
-    const int N = 240, R = 20, NC = 8192 / LmKernels<WT>::attn_chunk();
+    const int N = 240, R = 20, NC = 8192 / LmKernels<WT>::attn_chunk(); int NCL = 1; while (NCL * LmKernels<WT>::attn_chunk() < T) NCL <<= 1;
     auto report = [&](const char* name, double bytes, float us) { printf("%-34s %7.2f us/node  %8.1f GB/s (%.2f MB)\n", name, us, bytes / us / 1e3, bytes / 1e6); };
     printf("KV length T = %d\n", T);
     report("graph floor (k_advance)", 0, time_graph(st, N, R, [&](int) { launch_advance(state, st); }));
@@ -75,7 +75,7 @@ int main(int argc, char** argv) {
     report("qkv  (rmsnorm+GEMV 1280x1024+rope+kv)", QKV * 1024 * 2.0, time_graph(st, N, R, [&](int i) {
         LmKernels<WT>::qkv(d, x, lw[i % NL], cos_t, sin_t, state, 0, 0, q, kv(i % NL), st); }));
     report("attn_decode (paged, T tokens)", T * 512.0, time_graph(st, N, R, [&](int i) {
-        LmKernels<WT>::attn_decode(d, q, kv(i % NL), state, part, NC, st); }));
+        LmKernels<WT>::attn_decode(d, q, kv(i % NL), state, part, NC, NCL, st); }));
     report("wo   (combine + GEMV 1024x1024 + res)", 1024 * 1024 * 2.0, time_graph(st, N, R, [&](int i) {
         LmKernels<WT>::wo(d, part, NC, state, nullptr, kv(i % NL), 0, lw[i % NL], x, st); }));
     report("wo fused attn T=4 (fast decoder)", 1024 * 1024 * 2.0, time_graph(st, N, R, [&](int i) {
@@ -92,7 +92,7 @@ int main(int argc, char** argv) {
     float us_slow = time_graph(st, NL, R, [&](int i) {
         const LayerW& w = lw[i % NL]; KVView k = kv(i % NL);
         LmKernels<WT>::qkv(d, x, w, cos_t, sin_t, state, 0, 0, q, k, st);
-        LmKernels<WT>::attn_decode(d, q, k, state, part, NC, st);
+        LmKernels<WT>::attn_decode(d, q, k, state, part, NC, NCL, st);
         LmKernels<WT>::wo(d, part, NC, state, nullptr, k, 0, w, x, st);
         LmKernels<WT>::ffn_up(d, x, w, act, st);
         LmKernels<WT>::ffn_down(d, act, w, x, st);

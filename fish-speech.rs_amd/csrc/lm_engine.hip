@@ -65,6 +65,8 @@ void seed_key(uint64_t state, uint32_t* key) {
 }
 
 
+constexpr int kRows = 32;  // activation rows per MFMA pass (lm_kernels.hip PF_M)
+
 }  // namespace
 
 template <typename WT>
@@ -96,6 +98,7 @@ class LM final : public LMBase {
     ~LM() override {
         (void)hipSetDevice(device_);
         (void)hipStreamSynchronize(st_);
+        for (auto& kvp : batch_graphs_) if (kvp.second) (void)hipGraphExecDestroy(kvp.second);
         for (auto& kvp : graphs_) {
             if (kvp.second.first) (void)hipGraphExecDestroy(kvp.second.first);
             if (kvp.second.second) (void)hipGraphExecDestroy(kvp.second.second);
@@ -332,6 +335,124 @@ class LM final : public LMBase {
     void generate_batch(const uint32_t* prompts, const int* lens, int n, int max_new_tokens, const fs_sampling& s, uint64_t seed,
                         uint32_t flags, uint32_t* codes_out, size_t cap, size_t* n_frames) override {
         FS_REQUIRE(n >= 1, "Must have at least one prompt");  // static_batch.rs:69-71
+        if (LmKernels<WT>::has_mfma_prefill() && n <= kRows && n <= B_ && a_.dim % 64 == 0 && a_.intermediate_size % 256 == 0 &&
+            a_.num_codebooks <= 8) {
+            generate_batch_rows(prompts, lens, n, max_new_tokens, s, seed, flags, codes_out, cap, n_frames);
+            return;
+        }
+        generate_batch_sequential(prompts, lens, n, max_new_tokens, s, seed, flags, codes_out, cap, n_frames);
+    }
+
+    // generate_static_batch on the MFMA row path: the B sequences are the rows of every GEMM (weights streamed once per
+    // step for the whole batch), per-row paged KV, per-row on-device sampling, one captured graph per (B, chunk bucket).
+    void generate_batch_rows(const uint32_t* prompts, const int* lens, int n, int max_new_tokens, const fs_sampling& s, uint64_t seed,
+                             uint32_t flags, uint32_t* codes_out, size_t cap, size_t* n_frames) {
+        use_device();
+        require_loaded();
+        const int C = a_.num_codebooks, C1 = C + 1, B = n;
+        FS_REQUIRE(t_.has_semantic_end && t_.im_end_id + 1 == t_.semantic_start_id, "only the Fish 1.5 audio-range path is implemented");
+        int Lmax = 0;
+        for (int i = 0; i < n; ++i) { FS_REQUIRE(lens[i] >= 1, "empty prompt"); Lmax = std::max(Lmax, lens[i]); }
+        if (Lmax > a_.max_seq_len) throw Error("prompt exceeds max_seq_len (dual_ar.rs:623-624)");
+        long long n_iter = 1 + std::max<long long>(0, (long long)max_new_tokens - Lmax + 1);  // static_batch.rs:122,262-267
+        bool clamped = false;
+        const long long room = (long long)a_.max_seq_len - Lmax + 1;
+        if (n_iter > room) { n_iter = room; clamped = true; }
+        FS_REQUIRE(n_iter <= out_cap_, "generation longer than the output staging buffer");
+        clear_slow();  // static_batch.rs:118-121
+        clear_fast();
+        ensure_prefill_buffers();
+        ensure_batch_buffers();
+        SampleCfg cfg = base_cfg();
+        cfg.temp = (float)s.temp; cfg.top_p = (float)s.top_p;
+        cfg.top_k = (int)std::min<uint64_t>(s.top_k, 1u << 30);
+        cfg.rep_pen = 1.0f; cfg.ignore_eos = (flags & FS_GEN_IGNORE_EOS) ? 1 : 0;
+        FS_HIP(hipMemcpyAsync(d_cfg_.p, &cfg, sizeof(cfg), hipMemcpyHostToDevice, st_));
+        RngState rng = {};
+        seed_key(seed, rng.key);  // BatchedLogitsProcessor::new(seed) (the reference passes 42, static_batch.rs:63)
+        FS_HIP(hipMemcpyAsync(d_rng_.p, &rng, sizeof(rng), hipMemcpyHostToDevice, st_));
+        stats_ = {};
+        FS_HIP(hipEventRecord(ev_[0], st_));
+        // left-pad with <|im_end|>/0 (static_batch.rs:68-111; the pad mask is built but never applied, dual_ar.rs:589-615)
+        std::vector<uint32_t> padded((size_t)C1 * Lmax);
+        size_t off = 0;
+        for (int b = 0; b < B; ++b) {
+            const int L = lens[b], pad = Lmax - L;
+            for (int r = 0; r < C1; ++r) {
+                for (int j = 0; j < pad; ++j) padded[(size_t)r * Lmax + j] = r == 0 ? t_.im_end_id : 0u;
+                std::memcpy(&padded[(size_t)r * Lmax + pad], prompts + off + (size_t)r * L, sizeof(uint32_t) * L);
+            }
+            off += (size_t)C1 * L;
+            validate_tokens(padded.data(), padded.size(), 1, Lmax);
+            ensure_capacity(b, Lmax + (int)n_iter - 1);
+            FS_HIP(hipMemcpyAsync(d_prompt_.p, padded.data(), sizeof(uint32_t) * padded.size(), hipMemcpyHostToDevice, st_));
+            SeqState ss = {};
+            ss.prompt_L = Lmax;
+            FS_HIP(hipMemcpyAsync(state(b), &ss, sizeof(ss), hipMemcpyHostToDevice, st_));
+            prefill_tokens(b, Lmax - 1, /*use_graph=*/false);
+            FS_HIP(hipStreamSynchronize(st_));  // `padded` / d_prompt_ are reused by the next row
+            seq_len_[b] = Lmax - 1;
+        }
+        // first-frame inputs: the rows of d_pfx_ are scratch during prefill, so the last prompt column of every row is
+        // embedded only now (through the state's `cur` slots)
+        for (int b = 0; b < B; ++b) {
+            const int L = lens[b];
+            SeqState ss = {};
+            ss.pos = Lmax - 1; ss.prompt_L = Lmax; ss.step = Lmax - 1;
+            const uint32_t* src = prompts;  // find row b's prompt start
+            size_t o2 = 0;
+            for (int j = 0; j < b; ++j) o2 += (size_t)C1 * lens[j];
+            for (int r = 0; r < C1; ++r) ss.cur[r] = src[o2 + (size_t)r * L + (L - 1)];
+            FS_HIP(hipMemcpyAsync(state(b), &ss, sizeof(ss), hipMemcpyHostToDevice, st_));
+            LmKernels<WT>::embed(d_, tok_emb_, cb_emb_, C, a_.codebook_size, d_cfg_.as<SampleCfg>(), nullptr, state(b),
+                                 d_pfx_.as<float>() + (size_t)b * a_.dim, st_);
+            FS_HIP(hipStreamSynchronize(st_));
+        }
+        auto launch_frame = [&](long long it_) {
+            set_bucket(Lmax + (int)it_);
+            hipGraphExec_t g = batch_graph(B);
+            FS_HIP(hipGraphLaunch(g, st_));
+        };
+        launch_frame(0);
+        FS_HIP(hipEventRecord(ev_[1], st_));
+        std::vector<SeqState> hs(B);
+        auto all_done = [&]() {
+            FS_HIP(hipMemcpyAsync(hs.data(), state(0), sizeof(SeqState) * B, hipMemcpyDeviceToHost, st_));
+            FS_HIP(hipStreamSynchronize(st_));
+            for (int b = 0; b < B; ++b) if (!hs[b].done) return false;
+            return true;
+        };
+        long long it = 1;
+        while (it < n_iter) {
+            const long long end = std::min<long long>(n_iter, it + 16);
+            for (; it < end; ++it) launch_frame(it);
+            if (it < n_iter && all_done()) break;  // prompt = None once every row is dead (:255-258)
+        }
+        FS_HIP(hipEventRecord(ev_[2], st_));
+        const bool done_all = all_done();
+        float ms01 = 0, ms12 = 0;
+        FS_HIP(hipEventElapsedTime(&ms01, ev_[0], ev_[1]));
+        FS_HIP(hipEventElapsedTime(&ms12, ev_[1], ev_[2]));
+        stats_.prefill_ms = ms01; stats_.decode_ms = ms12; stats_.prompt_tokens = (uint64_t)Lmax * B; stats_.graph_launches = (uint64_t)it;
+        if (clamped && !done_all)
+            throw Error("generation ran past max_seq_len without <|im_end|> on every row (the reference fails at dual_ar.rs:623-624)");
+        std::vector<uint32_t> tmp((size_t)B * C * out_cap_);
+        FS_HIP(hipMemcpy(tmp.data(), d_out_.p, sizeof(uint32_t) * tmp.size(), hipMemcpyDeviceToHost));
+        uint64_t total = 0;
+        for (int b = 0; b < B; ++b) {
+            const size_t nb = (size_t)hs[b].n_out;
+            FS_REQUIRE(nb <= cap, "codes_out capacity too small for the generated frames");
+            for (int c = 0; c < C; ++c)
+                std::memcpy(codes_out + ((size_t)b * C + c) * cap, tmp.data() + ((size_t)b * C + c) * out_cap_, sizeof(uint32_t) * nb);
+            n_frames[b] = nb;
+            total += nb;
+            seq_len_[b] = hs[b].pos;
+        }
+        stats_.frames = total;
+    }
+
+    void generate_batch_sequential(const uint32_t* prompts, const int* lens, int n, int max_new_tokens, const fs_sampling& s, uint64_t seed,
+                                   uint32_t flags, uint32_t* codes_out, size_t cap, size_t* n_frames) {
         const int C1 = a_.num_codebooks + 1;
         int Lmax = 0;
         for (int i = 0; i < n; ++i) { FS_REQUIRE(lens[i] >= 1, "empty prompt"); Lmax = std::max(Lmax, lens[i]); }
@@ -482,7 +603,7 @@ class LM final : public LMBase {
         d_rng_.alloc(sizeof(RngState));
         d_prompt_.alloc(sizeof(uint32_t) * (size_t)(a_.num_codebooks + 1) * a_.max_seq_len);
         out_cap_ = a_.max_seq_len + 8;
-        d_out_.alloc(sizeof(uint32_t) * (size_t)a_.num_codebooks * out_cap_);
+        d_out_.alloc(sizeof(uint32_t) * (size_t)B_ * a_.num_codebooks * out_cap_);
         const size_t ncb = a_.num_codebooks, cbs = a_.codebook_size;
         d_rp_mask_.alloc(sizeof(float) * ncb * cbs);
         d_rp_seen_.alloc(ncb * cbs);
@@ -542,7 +663,7 @@ class LM final : public LMBase {
             ensure_prefill_buffers();
             RowsCtx c = rows_ctx(state(b), /*pos_step=*/1, /*pt_stride=*/0);
             for (int done = 0; done < n;) {
-                const int M = std::min(64, n - done);
+                const int M = std::min(kRows, n - done);
                 c.nc_launch = chunk_bucket(seq_len_[b] + done + M);
                 LmKernels<WT>::prefill_embed(d_, tok_emb_, cb_emb_, a_.num_codebooks, a_.codebook_size, d_cfg_.as<SampleCfg>(),
                                              d_prompt_.as<uint32_t>(), state(b), M, d_pfx_.as<float>(), st_);
@@ -567,20 +688,84 @@ class LM final : public LMBase {
     }
     void ensure_prefill_buffers() {
         if (d_pfx_.p) return;
-        d_pfx_.alloc(sizeof(float) * 64 * a_.dim);
-        d_pfq_.alloc(sizeof(float) * 64 * a_.dim);
-        d_pfslab_.alloc(sizeof(float) * 4 * 64 * a_.dim);
-        d_pfa_.alloc(sizeof(uint16_t) * 2 * 64 * a_.dim);
-        d_pfc_.alloc(sizeof(uint16_t) * 2 * 64 * a_.intermediate_size);
-        d_pfpart_.alloc(sizeof(float) * 64 * (size_t)a_.n_head * n_chunks_ * (a_.head_dim + 2));
+        d_pfx_.alloc(sizeof(float) * kRows * a_.dim);
+        d_pfq_.alloc(sizeof(float) * kRows * a_.dim);
+        d_pfslab_.alloc(sizeof(float) * 4 * kRows * a_.dim);
+        d_pfa_.alloc(sizeof(uint16_t) * 2 * kRows * a_.dim);
+        d_pfc_.alloc(sizeof(uint16_t) * 2 * kRows * a_.intermediate_size);
+        d_pfpart_.alloc(sizeof(float) * kRows * (size_t)a_.n_head * n_chunks_ * (a_.head_dim + 2));
         FS_HIP(hipMemsetAsync(d_pfa_.p, 0, d_pfa_.n, st_));
         FS_HIP(hipMemsetAsync(d_pfc_.p, 0, d_pfc_.n, st_));
     }
+    void ensure_batch_buffers() {
+        if (d_xfrows_.p) return;
+        ld_slow_ = ((n_audio_ + 63) / 64) * 64;
+        d_xfrows_.alloc(sizeof(float) * kRows * a_.dim);
+        d_lrows_.alloc(sizeof(float) * kRows * ld_slow_);
+        d_lfast_.alloc(sizeof(float) * kRows * a_.codebook_size);
+        std::vector<SeqState> fs(8);
+        for (int i = 0; i < 8; ++i) { fs[i] = SeqState{}; fs[i].pos = i; }
+        d_fast_state_.alloc(sizeof(SeqState) * 8);
+        FS_HIP(hipMemcpy(d_fast_state_.p, fs.data(), sizeof(SeqState) * 8, hipMemcpyHostToDevice));
+        std::vector<int> tb(B_);
+        for (int i = 0; i < B_; ++i) tb[i] = i;
+        d_fast_table_.alloc(sizeof(int) * B_);
+        FS_HIP(hipMemcpy(d_fast_table_.p, tb.data(), sizeof(int) * B_, hipMemcpyHostToDevice));
+    }
+    // one static-batch frame for B rows: x rows (d_pfx_) hold the embedded inputs of position state(0)->pos
+    void enqueue_batch_frame(int B) {
+        const int C = a_.num_codebooks;
+        RowsCtx cs = rows_ctx(state(0), /*pos_step=*/0, /*pt_stride=*/max_pages_);
+        cs.nc_launch = nc_launch_;
+        for (int l = 0; l < a_.n_layer; ++l) LmKernels<WT>::rows_layer(d_, B, cs, slow_[l], slow_kv(l, 0), l == 0, st_);
+        LmKernels<WT>::rows_finish(d_, B, cs, norm_w_, st_);
+        LmKernels<WT>::rows_head(d_, B, cs, (const uint8_t*)out_w_ + (size_t)t_.im_end_id * a_.dim * sizeof(WT), n_audio_,
+                                 d_lrows_.as<float>(), ld_slow_, st_);
+        SampleKernels<WT>::sample_slow_rows(d_, d_lrows_.as<float>(), ld_slow_, n_audio_, d_cfg_.as<SampleCfg>(), d_rng_.as<RngState>(), B,
+                                            C + 1, state(0), cs.X, d_xfrows_.as<float>(), st_);
+        for (int cbi = 0; cbi < C; ++cbi) {
+            RowsCtx cf = cs;
+            cf.X = d_xfrows_.as<float>();
+            cf.state = d_fast_state_.as<SeqState>() + cbi;
+            cf.pt_stride = 1;
+            cf.nc_launch = 1;
+            for (int l = 0; l < a_.n_fast_layer; ++l) {
+                KVView kv;
+                WT* base = fast_pool_.as<WT>() + ((size_t)l * 2 * B_) * page_elems_;
+                kv.k = base; kv.v = base + (size_t)B_ * page_elems_; kv.page_table = d_fast_table_.as<int>();
+                LmKernels<WT>::rows_layer(d_, B, cf, fast_[l], kv, l == 0, st_);
+            }
+            LmKernels<WT>::rows_finish(d_, B, cf, fast_norm_w_, st_);
+            LmKernels<WT>::rows_head(d_, B, cf, fast_out_w_, a_.codebook_size, d_lfast_.as<float>(), a_.codebook_size, st_);
+            SampleKernels<WT>::sample_fast_rows(d_, d_lfast_.as<float>(), cbi, C, a_.codebook_size, d_cfg_.as<SampleCfg>(),
+                                                d_rng_.as<RngState>(), B, state(0), fast_emb_, d_xfrows_.as<float>(), tok_emb_, cb_emb_,
+                                                cs.X, d_out_.as<uint32_t>(), out_cap_, st_);
+        }
+    }
+    hipGraphExec_t batch_graph(int B) {
+        const int key = B * 1024 + nc_launch_;
+        auto it = batch_graphs_.find(key);
+        if (it != batch_graphs_.end()) return it->second;
+        hipGraph_t g = nullptr;
+        hipGraphExec_t ge = nullptr;
+        // warm every kernel once outside capture (function attributes are set lazily on first launch)
+        if (!batch_warm_) { enqueue_batch_frame_dry(B); batch_warm_ = true; }
+        FS_HIP(hipStreamBeginCapture(st_, hipStreamCaptureModeThreadLocal));
+        enqueue_batch_frame(B);
+        FS_HIP(hipStreamEndCapture(st_, &g));
+        FS_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        FS_HIP(hipGraphDestroy(g));
+        batch_graphs_[key] = ge;
+        return ge;
+    }
+    // hipFuncSetAttribute (dynamic LDS of the GEMM) is not capturable: issue it before the first capture
+    void enqueue_batch_frame_dry(int) { LmKernels<WT>::rows_warmup(); }
+
     RowsCtx rows_ctx(const SeqState* st, int pos_step, int pt_stride) {
         RowsCtx c;
         c.X = d_pfx_.as<float>(); c.Q = d_pfq_.as<float>(); c.part = d_pfpart_.as<float>(); c.P = d_pfslab_.as<float>();
-        c.Ahi = d_pfa_.as<uint16_t>(); c.Alo = c.Ahi + (size_t)64 * a_.dim;
-        c.Chi = d_pfc_.as<uint16_t>(); c.Clo = c.Chi + (size_t)64 * a_.intermediate_size;
+        c.Ahi = d_pfa_.as<uint16_t>(); c.Alo = c.Ahi + (size_t)kRows * a_.dim;
+        c.Chi = d_pfc_.as<uint16_t>(); c.Clo = c.Chi + (size_t)kRows * a_.intermediate_size;
         c.cos_t = d_cos_.as<float>(); c.sin_t = d_sin_.as<float>();
         c.state = st; c.n_chunks_max = n_chunks_; c.nc_launch = n_chunks_; c.pos_step = pos_step; c.pt_stride = pt_stride;
         return c;
@@ -687,7 +872,11 @@ class LM final : public LMBase {
     // activations / state
     DevBuf d_x_, d_xf_, d_q_, d_part_, d_act_, d_logits_slow_, d_logits_fast_, d_state_, d_cfg_, d_rng_, d_prompt_, d_out_;
     DevBuf d_rp_mask_, d_rp_seen_, d_rp_ring_, d_rp_meta_;
-    DevBuf d_pfx_, d_pfq_, d_pfslab_, d_pfa_, d_pfc_, d_pfpart_;  // MFMA row-path activations (64 rows)
+    DevBuf d_pfx_, d_pfq_, d_pfslab_, d_pfa_, d_pfc_, d_pfpart_;  // MFMA row-path activations (32 rows)
+    DevBuf d_xfrows_, d_lrows_, d_lfast_, d_fast_state_, d_fast_table_;  // static-batch generator
+    int ld_slow_ = 0;
+    bool batch_warm_ = false;
+    std::map<int, hipGraphExec_t> batch_graphs_;
     RepPenState rp_ = {};
     void* h_pin_ = nullptr;
     hipGraphExec_t g_frame_ = nullptr, g_step_ = nullptr;

@@ -56,14 +56,14 @@ struct ModelDims {
 
 struct SampleCfg;
 
-// Buffers + row mapping of the MFMA row path (prefill chunks / batched decode).  All activation buffers hold 64 rows.
+// Buffers + row mapping of the MFMA row path (prefill chunks / batched decode).  All activation buffers hold 32 rows.
 struct RowsCtx {
-    float* X;            // [64][dim]   residual stream (f32)
-    float* Q;            // [64][dim]   rope'd queries (f32)
-    float* part;         // [64][H][n_chunks_max][Dh + 2] attention partials
-    float* P;            // [4][64][dim] down-projection split-K slabs
-    uint16_t *Ahi, *Alo; // [64][dim]   bf16 hi/lo GEMM input (normed x / attention output)
-    uint16_t *Chi, *Clo; // [64][inter] bf16 hi/lo SwiGLU activations
+    float* X;            // [32][dim]   residual stream (f32)
+    float* Q;            // [32][dim]   rope'd queries (f32)
+    float* part;         // [32][H][n_chunks_max][Dh + 2] attention partials
+    float* P;            // [4][32][dim] down-projection split-K slabs
+    uint16_t *Ahi, *Alo; // [32][dim]   bf16 hi/lo GEMM input (normed x / attention output)
+    uint16_t *Chi, *Clo; // [32][inter] bf16 hi/lo SwiGLU activations
     const float *cos_t, *sin_t;
     const SeqState* state;  // position source (row m sits at state->pos + m * pos_step)
     int n_chunks_max;    // stride of `part`
@@ -99,17 +99,19 @@ struct LmKernels {
     // state->step (prompt != null) or from state->cur
     static void embed(const ModelDims& d, const void* tok_emb, const void* cb_emb, int n_cb, int cb_size,
                       const SampleCfg* cfg, const uint32_t* prompt, SeqState* state, float* x, hipStream_t st);
-    // ---- chunked prefill (M <= 64 prompt tokens per pass; MFMA skinny GEMMs, bf16 weights only)
+    // ---- chunked prefill (M <= 32 prompt tokens per pass; MFMA skinny GEMMs, bf16 weights only)
     static bool has_mfma_prefill();
     // X[m] = embed(prompt column state->step + m), m < M
     static void prefill_embed(const ModelDims& d, const void* tok_emb, const void* cb_emb, int n_cb, int cb_size,
                               const SampleCfg* cfg, const uint32_t* prompt, const SeqState* state, int M, float* X,
                               hipStream_t st);
-    // one transformer block over M <= 64 activation rows (X updated in place up to the down-projection, whose split-K
+    // one transformer block over M <= 32 activation rows (X updated in place up to the down-projection, whose split-K
     // slabs are folded in by the NEXT rows_layer / rows_finish):
     //   x += slabs | rmsnorm+Wqkv+rope+KV append | attention over the paged cache | Wo + residual | rmsnorm+W13+SwiGLU | W2 slabs
     static void rows_layer(const ModelDims& d, int M, const RowsCtx& c, const LayerW& w, KVView kv, bool first, hipStream_t st);
     static void rows_finish(const ModelDims& d, int M, const RowsCtx& c, const float* norm_w, hipStream_t st);
+    static void rows_warmup();
+    static void rows_head(const ModelDims& d, int M, const RowsCtx& c, const void* W, int n_rows, float* logits, int ld, hipStream_t st);
     // fast_embeddings gather: out[i] = fast_emb[ids[i]]
     static void fast_embed(const ModelDims& d, const void* fast_emb, const uint32_t* ids, int n, float* out,
                            hipStream_t st);
@@ -147,6 +149,12 @@ struct SampleKernels {
                             RngState* rng, RepPenState rp, SeqState* state, const void* fast_emb, float* xf,
                             const void* tok_emb, const void* cb_emb, float* x, uint32_t* out_codes, int out_cap,
                             hipStream_t st);
+    // static-batch generator (static_batch.rs): one block per batch row, child StdRng per (call, row)
+    static void sample_slow_rows(const ModelDims& d, const float* logits, int ld, int n, const SampleCfg* c, const RngState* master, int B,
+                                 int calls_per_frame, SeqState* states, const float* X, float* XF, hipStream_t st);
+    static void sample_fast_rows(const ModelDims& d, const float* logits, int cb, int n_cb, int cb_size, const SampleCfg* c,
+                                 const RngState* master, int B, SeqState* states, const void* fast_emb, float* XF, const void* tok_emb,
+                                 const void* cb_emb, float* X, uint32_t* out_codes, int out_cap, hipStream_t st);
 };
 
 void launch_advance(SeqState* state, hipStream_t st);  // pos++, step++ (sequential prefill step)

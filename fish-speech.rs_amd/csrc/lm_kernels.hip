@@ -603,7 +603,7 @@ __global__ void k_advance(SeqState* state) {
 // slice's global loads are issued before the current slice's MFMAs.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
-constexpr int PF_M = 64;    // activation rows per pass
+constexpr int PF_M = 32;    // activation rows per pass
 constexpr int PF_BK = 64;   // K-slice
 constexpr int PF_LD = PF_BK + 8;
 
@@ -662,95 +662,92 @@ __global__ __launch_bounds__(256) void k_prep(float* __restrict__ X, int D, cons
     }
 }
 
-constexpr int G_BK = 256;            // K slice held in LDS (per buffer: 2 parts x 64 rows x (256 + 8) bf16 = 67.6 KB)
-constexpr int G_LD = G_BK + 8;
-constexpr int G_NS = 4;              // max slices per block => K per block <= 1024 (larger K is split over blockIdx.y)
-constexpr size_t G_LDS_BYTES = (size_t)2 * 2 * PF_M * G_LD * sizeof(bf16_t);
+// One block = 64 weight rows (4 waves x 16) x KB <= 1024 of K x all 32 activation rows.  The block's activation panel
+// (hi + lo, 32 x KB bf16 each) is staged ONCE into LDS; each wave's whole weight panel (16 rows x KB) goes in flight at
+// kernel entry (GEMV-style, <= 32 x 16 B per lane), so the kernel costs one HBM round trip plus KB/32 MFMA steps whose
+// B fragments are double-buffered out of LDS.
+template <int KB> struct GemmGeom {
+    static constexpr int LD = KB + 8;                                   // padded LDS row (bf16 elements)
+    static constexpr size_t LDS = (size_t)2 * PF_M * LD * sizeof(bf16_t); // hi + lo panels
+    static constexpr int NKS = KB / 32;                                  // MFMA k-steps
+    static constexpr int VPR = KB / 8;                                   // 16-B vectors per activation row
+    static constexpr int NVX = 2 * PF_M * VPR / 256;                     // staging vectors per thread (both parts)
+};
 
-template <int EPI, int BK>
-__global__ __launch_bounds__(256) void k_gemm2(const bf16_t* __restrict__ Xhi, const bf16_t* __restrict__ Xlo, int M, int K, int ksplit,
+template <int EPI, int KB>
+__global__ __launch_bounds__(256) void k_gemm2(const bf16_t* __restrict__ Xhi, const bf16_t* __restrict__ Xlo, int M, int K,
                                                const bf16_t* __restrict__ W, int N, float* __restrict__ Y, int ldy,
                                                bf16_t* __restrict__ Ohi, bf16_t* __restrict__ Olo, int ldo,
                                                const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                const SeqState* __restrict__ state, KVView kv, int H, int Hk, int Dh, RowMap rm) {
-    extern __shared__ __attribute__((aligned(16))) bf16_t xs_dyn[];  // [2 buffers][2 parts][PF_M][G_LD]
+    using GG = GemmGeom<KB>;
+    extern __shared__ __attribute__((aligned(16))) bf16_t xs_dyn[];  // [2 parts][PF_M][LD]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n0 = blockIdx.x * 64 + wave * 16;  // this wave's 16 weight rows
-    const int Kb = K / ksplit, kbeg = blockIdx.y * Kb;
-    constexpr int bk = BK;
-    const int ns = Kb / bk;  // host guarantees Kb % BK == 0, ns <= G_NS
-    f32x4v acc[4];
+    const int kbeg = blockIdx.y * KB;            // split-K: blockIdx.y-th K range (K == gridDim.y * KB)
+    // ---- activation panel -> LDS.  Vector v = i * 256 + tid of the [2 parts][PF_M rows][VPR] grid: consecutive lanes read
+    // consecutive 16-B pieces of one row (coalesced) and write consecutive LDS words (conflict-free).
+    constexpr int NVX = GG::NVX, VPR = GG::VPR, HALF = (NVX + 1) / 2;
+    auto xsrc = [&](int i) {
+        const int v = i * 256 + (int)threadIdx.x, part = v / (PF_M * VPR), r = (v / VPR) % PF_M, cv = v % VPR;
+        return (part ? Xlo : Xhi) + (size_t)r * K + kbeg + cv * 8;
+    };
+    auto xdst = [&](int i) {
+        const int v = i * 256 + (int)threadIdx.x, part = v / (PF_M * VPR), r = (v / VPR) % PF_M, cv = v % VPR;
+        return xs_dyn + ((size_t)part * PF_M + r) * GG::LD + cv * 8;
+    };
+    u32x4 xr[HALF];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = f32x4v{0.f, 0.f, 0.f, 0.f};
-    // ---- the block's whole weight panel goes in flight at once (GEMV-style: <= 32 x 16 B per lane), X slices follow
-    // one slice ahead through a double-buffered LDS tile shared by the 4 waves
+    for (int i = 0; i < HALF; ++i) xr[i] = *reinterpret_cast<const u32x4*>(xsrc(i));
+    // ---- the wave's whole weight panel in flight (non-temporal, straight to VGPRs)
     const int wrow = min(n0 + (lane & 15), N - 1);
     const bf16_t* wp = W + (size_t)wrow * K + kbeg + (lane >> 4) * 8;
-    // staging map (coalesced): part = tid >> 7 (0 = hi, 1 = lo); vector v = i * 128 + (tid & 127) of the part's
-    // [64 rows][bk / 8] grid of 16-B vectors -> consecutive lanes read consecutive 16-B pieces of one activation row
-    const int spart = threadIdx.x >> 7, su = threadIdx.x & 127;
-    constexpr int vpr = bk / 8;      // 16-B vectors per row per slice
-    constexpr int nvx = vpr / 2;         // vectors per thread per slice (64 rows * vpr / 128 threads), <= 16
-    const bf16_t* xg = (spart ? Xlo : Xhi) + kbeg;
-    auto xoff = [&](int i) { const int v = i * 128 + su; return (size_t)(v / vpr) * K + (size_t)(v % vpr) * 8; };   // global element offset
-    auto loff = [&](int i) { const int v = i * 128 + su; return (v / vpr) * G_LD + (v % vpr) * 8; };                 // LDS element offset
-    u32x4 xr[16];
+    u32x4 wf[GG::NKS];
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
-        if (i < nvx) xr[i] = *reinterpret_cast<const u32x4*>(xg + xoff(i));
-    u32x4 wf[G_NS][8];
+    for (int ks = 0; ks < GG::NKS; ++ks) wf[ks] = ld_stream(reinterpret_cast<const u32x4*>(wp + ks * 32));
 #pragma unroll
-    for (int sI = 0; sI < G_NS; ++sI)
+    for (int i = 0; i < HALF; ++i) *reinterpret_cast<u32x4*>(xdst(i)) = xr[i];
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks)
-            if (sI < ns && ks * 32 < bk) wf[sI][ks] = ld_stream(reinterpret_cast<const u32x4*>(wp + (size_t)sI * bk + ks * 32));
-    auto xbuf = [&](int buf, int part) { return xs_dyn + ((size_t)(buf * 2 + part) * PF_M) * G_LD; };
-    {
-        bf16_t* dst = xbuf(0, spart);
+    for (int i = 0; i < NVX - HALF; ++i) xr[i] = *reinterpret_cast<const u32x4*>(xsrc(HALF + i));
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-            if (i < nvx) *reinterpret_cast<u32x4*>(dst + loff(i)) = xr[i];
-    }
+    for (int i = 0; i < NVX - HALF; ++i) *reinterpret_cast<u32x4*>(xdst(HALF + i)) = xr[i];
     __syncthreads();
+    // ---- MFMA loop: B fragments (2 column tiles x hi/lo) double-buffered out of LDS
+    f32x4v acc[2];
+    acc[0] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    acc[1] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    const bf16_t* bbase = xs_dyn + (size_t)(lane & 15) * GG::LD + (lane >> 4) * 8;
+    auto ldb = [&](int ks, u32x4 (&f)[4]) {
 #pragma unroll
-    for (int sI = 0; sI < G_NS; ++sI) {
-        if (sI < ns) {
-            const int cur = sI & 1;
-            if (sI + 1 < ns) {
+        for (int mt = 0; mt < 2; ++mt) {
+            f[mt * 2] = *reinterpret_cast<const u32x4*>(bbase + (size_t)mt * 16 * GG::LD + ks * 32);                       // hi
+            f[mt * 2 + 1] = *reinterpret_cast<const u32x4*>(bbase + ((size_t)PF_M + mt * 16) * GG::LD + ks * 32);         // lo
+        }
+    };
+    u32x4 bf0[4], bf1[4];
+    ldb(0, bf0);
 #pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    if (i < nvx) xr[i] = *reinterpret_cast<const u32x4*>(xg + (size_t)(sI + 1) * bk + xoff(i));
-            }
-            const bf16_t* bh0 = xbuf(cur, 0);
-            const bf16_t* bl0 = xbuf(cur, 1);
+    for (int ks = 0; ks < GG::NKS; ks += 2) {
+        if (ks + 1 < GG::NKS) ldb(ks + 1, bf1);
+        {
+            const bf16x8 af = __builtin_bit_cast(bf16x8, wf[ks]);
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                if (ks * 32 < bk) {
-                    const bf16x8 af = __builtin_bit_cast(bf16x8, wf[sI][ks]);
+            for (int j = 0; j < 4; ++j)
+                acc[j >> 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, bf0[j]), acc[j >> 1], 0, 0, 0);
+        }
+        if (ks + 2 < GG::NKS) ldb(ks + 2, bf0);
+        if (ks + 1 < GG::NKS) {
+            const bf16x8 af = __builtin_bit_cast(bf16x8, wf[ks + 1]);
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) {
-                        const int off = (mt * 16 + (lane & 15)) * G_LD + ks * 32 + (lane >> 4) * 8;
-                        const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bh0 + off));
-                        const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bl0 + off));
-                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bh, acc[mt], 0, 0, 0);
-                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bl, acc[mt], 0, 0, 0);
-                    }
-                }
-            }
-            if (sI + 1 < ns) {
-                bf16_t* dst = xbuf(cur ^ 1, spart);
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    if (i < nvx) *reinterpret_cast<u32x4*>(dst + loff(i)) = xr[i];
-            }
-            __syncthreads();
+            for (int j = 0; j < 4; ++j)
+                acc[j >> 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, bf1[j]), acc[j >> 1], 0, 0, 0);
         }
     }
     // epilogue: lane holds C[row = n0 + (lane>>4)*4 + i][m = mt*16 + (lane&15)], i = 0..3
     const int r0 = n0 + (lane >> 4) * 4;
     if (r0 >= N) return;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+    for (int mt = 0; mt < 2; ++mt) {
         const int m = mt * 16 + (lane & 15);
         if (m >= M) continue;
         const f32x4v c = acc[mt];
@@ -875,7 +872,7 @@ constexpr int SAMPLE_MAXN = 4096;  // candidates handled by the sampler (audio r
 //             oracle::LogitsProcessor::sample; the softmax denominator is accumulated in f64 on both sides so that
 //             the result does not depend on reduction order.
 __device__ int block_sample(float* lg /*LDS [n]*/, int n, const SampleCfg& c, RngState* rng, float* sp /*LDS [SAMPLE_MAXN]*/,
-                            int* si /*LDS [SAMPLE_MAXN]*/, double* red /*LDS [SAMPLE_THREADS]*/) {
+                            int* si /*LDS [SAMPLE_MAXN]*/, double* red /*LDS [SAMPLE_THREADS]*/, bool first_max = false) {
     const int tid = threadIdx.x;
     __shared__ int s_result;
     if (c.temp == 0.f) {
@@ -883,7 +880,7 @@ __device__ int block_sample(float* lg /*LDS [n]*/, int n, const SampleCfg& c, Rn
         int bi = -1;
         for (int i = tid; i < n; i += SAMPLE_THREADS) {
             const float v = lg[i];
-            if (bi < 0 || !(v < bv)) { bv = v; bi = i; }  // ascending i per thread: >= keeps the last
+            if (bi < 0 || (first_max ? (v > bv) : !(v < bv))) { bv = v; bi = i; }  // ascending i per thread: >= keeps the last
         }
         float* rv = reinterpret_cast<float*>(red);
         int* ri = reinterpret_cast<int*>(red) + SAMPLE_THREADS;
@@ -895,7 +892,7 @@ __device__ int block_sample(float* lg /*LDS [n]*/, int n, const SampleCfg& c, Rn
                 const int i2 = ri[tid + s];
                 const float v1 = rv[tid];
                 const int i1 = ri[tid];
-                const bool take2 = (i1 < 0) || (i2 >= 0 && (v2 > v1 || (v2 == v1 && i2 > i1)));
+                const bool take2 = (i1 < 0) || (i2 >= 0 && (v2 > v1 || (v2 == v1 && (first_max ? i2 < i1 : i2 > i1))));
                 if (take2) { rv[tid] = v2; ri[tid] = i2; }
             }
             __syncthreads();
@@ -1095,6 +1092,106 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_fast(const float* __r
     embed_tokens<WT>(tok_emb, cb_emb, dim, n_cb, cb_size, c.sem_lo, c.sem_hi, cur, 1, x, tid, SAMPLE_THREADS);
 }
 
+// ------------------------------------------------------------------------------------------------ batched (static-batch) sampling
+// generate/static_batch.rs:117-274 + sampling/mod.rs:77-109: one block per batch row.  temp <= 1e-7 -> device argmax
+// (FIRST maximal index); else softmax(logits / temp) and, per sample() call, every row draws from its OWN child StdRng
+// seeded with the next u64 of the master StdRng (sampling/mod.rs:93-95): call c of the request, row b uses master u64
+// number c * B + b, and the single WeightedIndex draw consumes word 0 of the child stream.
+__device__ inline void child_rng(const RngState* master, unsigned long long n64, RngState* out) {
+    const unsigned long long lo = chacha12_word(master->key, 2 * n64), hi = chacha12_word(master->key, 2 * n64 + 1);
+    unsigned long long state = (hi << 32) | lo;
+    for (int i = 0; i < 8; ++i) {  // rand_core seed_from_u64 (PCG32 expansion)
+        state = state * 6364136223846793005ull + 11634580027462260723ull;
+        const uint32_t xorshifted = (uint32_t)(((state >> 18) ^ state) >> 27);
+        const uint32_t rot = (uint32_t)(state >> 59);
+        out->key[i] = (xorshifted >> rot) | (xorshifted << ((32 - rot) & 31));
+    }
+    out->consumed = 0;
+}
+
+template <typename WT>
+__global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_slow_rows(const float* __restrict__ logits, int ld, int n,
+                                                                     const SampleCfg* __restrict__ cp, const RngState* __restrict__ master,
+                                                                     int B, int calls_per_frame, SeqState* __restrict__ states,
+                                                                     const float* __restrict__ X, float* __restrict__ XF, int dim) {
+    __shared__ float lg[SAMPLE_MAXN];
+    __shared__ float sp[SAMPLE_MAXN];
+    __shared__ int si[SAMPLE_MAXN];
+    __shared__ double red[SAMPLE_THREADS];
+    __shared__ RngState lrng;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    SeqState* st = states + b;
+    SampleCfg c = *cp;
+    if (c.temp <= 1e-7f) c.temp = 0.f;  // sampling/mod.rs:80
+    for (int i = tid; i < n; i += SAMPLE_THREADS) lg[i] = logits[(size_t)b * ld + i];
+    for (int i = tid; i < dim; i += SAMPLE_THREADS) XF[(size_t)b * dim + i] = X[(size_t)b * dim + i];  // hidden_states (:175)
+    if (tid == 0 && c.temp != 0.f) child_rng(master, (unsigned long long)st->frame * calls_per_frame * B + b, &lrng);
+    __syncthreads();
+    if (c.ignore_eos && tid == 0) lg[0] = -INFINITY;
+    __syncthreads();
+    const int idx = block_sample(lg, n, c, &lrng, sp, si, red, /*first_max=*/true);
+    if (tid == 0) {
+        const uint32_t tok = (uint32_t)idx + c.im_end_id;  // rescale_semantic_tokens (utils.rs:45-46)
+        st->cur[0] = tok;
+        if (tok == c.im_end_id) st->done = 1;  // batch_item_is_dead |= newly dead (:160-173)
+    }
+}
+
+template <typename WT>
+__global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_fast_rows(const float* __restrict__ logits, int cb, int n_cb, int cb_size,
+                                                                     const SampleCfg* __restrict__ cp, const RngState* __restrict__ master,
+                                                                     int B, SeqState* __restrict__ states, const WT* __restrict__ fast_emb,
+                                                                     float* __restrict__ XF, const WT* __restrict__ tok_emb,
+                                                                     const WT* __restrict__ cb_emb, float* __restrict__ X, int dim,
+                                                                     uint32_t* __restrict__ out_codes, int out_cap) {
+    __shared__ float lg[SAMPLE_MAXN];
+    __shared__ float sp[SAMPLE_MAXN];
+    __shared__ int si[SAMPLE_MAXN];
+    __shared__ double red[SAMPLE_THREADS];
+    __shared__ RngState lrng;
+    const int tid = threadIdx.x, b = blockIdx.x, n = cb_size;
+    SeqState* st = states + b;
+    SampleCfg c = *cp;
+    if (c.temp <= 1e-7f) c.temp = 0.f;
+    // the batch repetition-penalty mask is never updated for Fish models (static_batch.rs:204-206): logits / 1.0
+    for (int i = tid; i < n; i += SAMPLE_THREADS) lg[i] = logits[(size_t)b * n + i];
+    if (tid == 0 && c.temp != 0.f)
+        child_rng(master, ((unsigned long long)st->frame * (n_cb + 1) + 1 + cb) * B + b, &lrng);
+    __syncthreads();
+    const int code = block_sample(lg, n, c, &lrng, sp, si, red, /*first_max=*/true);
+    if (tid == 0) st->cur[cb + 1] = (uint32_t)code;
+    if (cb != n_cb - 1) {
+        for (int d = tid; d < dim; d += SAMPLE_THREADS) XF[(size_t)b * dim + d] = WTr<WT>::to_f32(fast_emb[(size_t)code * dim + d]);
+        return;
+    }
+    // ---- end of frame (static_batch.rs:224-267 + generate_static_batch :305-338)
+    __syncthreads();
+    __shared__ uint32_t cur[16];
+    if (tid <= n_cb) {
+        const uint32_t slow = st->cur[0];
+        const bool is_audio = slow >= c.sem_lo;  // :229 (non-audio rows carry zero codes)
+        uint32_t v = tid == 0 ? slow : (tid == n_cb ? (uint32_t)code : st->cur[tid]);
+        if (tid > 0 && !is_audio) v = 0;
+        cur[tid] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int frame = st->frame;
+        if (frame == 0 || !st->done) {  // first position unconditionally, then only while the row is active
+            const int o = st->n_out;
+            uint32_t* oc = out_codes + (size_t)b * n_cb * out_cap;
+            if (o < out_cap)
+                for (int cc = 0; cc < n_cb; ++cc) oc[(size_t)cc * out_cap + o] = cur[cc + 1];
+            st->n_out = o + 1;
+        }
+        for (int i = 0; i <= n_cb; ++i) { st->prev[i] = cur[i]; st->cur[i] = cur[i]; }
+        st->have_prev = 1;
+        st->pos += 1;  // dead rows keep stepping in lock-step (:255-261)
+        st->frame = frame + 1;
+    }
+    embed_tokens<WT>(tok_emb, cb_emb, dim, n_cb, cb_size, c.sem_lo, c.sem_hi, cur, 1, X + (size_t)b * dim, tid, SAMPLE_THREADS);
+}
+
 __global__ void k_reppen_reset(RepPenState rp, int n_cb, int cb_size) {
     const int n = n_cb * cb_size;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { rp.mask[i] = 1.0f; rp.seen[i] = 0; }
@@ -1277,6 +1374,25 @@ void SampleKernels<WT>::sample_fast(const ModelDims& d, const float* logits, int
     FS_LAUNCH_CHECK();
 }
 
+template <typename WT>
+void SampleKernels<WT>::sample_slow_rows(const ModelDims& d, const float* logits, int ld, int n, const SampleCfg* c, const RngState* master,
+                                         int B, int calls_per_frame, SeqState* states, const float* X, float* XF, hipStream_t st) {
+    FS_REQUIRE(n <= SAMPLE_MAXN, "audio-range vocabulary larger than the sampler capacity");
+    hipLaunchKernelGGL((k_sample_slow_rows<WT>), dim3(B), dim3(SAMPLE_THREADS), 0, st, logits, ld, n, c, master, B, calls_per_frame, states,
+                       X, XF, d.dim);
+    FS_LAUNCH_CHECK();
+}
+template <typename WT>
+void SampleKernels<WT>::sample_fast_rows(const ModelDims& d, const float* logits, int cb, int n_cb, int cb_size, const SampleCfg* c,
+                                         const RngState* master, int B, SeqState* states, const void* fast_emb, float* XF,
+                                         const void* tok_emb, const void* cb_emb, float* X, uint32_t* out_codes, int out_cap,
+                                         hipStream_t st) {
+    FS_REQUIRE(cb_size <= SAMPLE_MAXN, "codebook larger than the sampler capacity");
+    hipLaunchKernelGGL((k_sample_fast_rows<WT>), dim3(B), dim3(SAMPLE_THREADS), 0, st, logits, cb, n_cb, cb_size, c, master, B, states,
+                       (const WT*)fast_emb, XF, (const WT*)tok_emb, (const WT*)cb_emb, X, d.dim, out_codes, out_cap);
+    FS_LAUNCH_CHECK();
+}
+
 void launch_advance(SeqState* state, hipStream_t st) {
     hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, st, state);
     FS_LAUNCH_CHECK();
@@ -1318,28 +1434,36 @@ void LmKernels<WT>::prefill_embed(const ModelDims& d, const void* tok_emb, const
 }
 
 template <int EPI>
-static void launch_gemm2(dim3 grid, hipStream_t st, const bf16_t* Xhi, const bf16_t* Xlo, int M, int K, int ksplit, const bf16_t* W, int N,
-                         float* Y, int ldy, bf16_t* Ohi, bf16_t* Olo, int ldo, const float* cos_t, const float* sin_t,
-                         const SeqState* state, KVView kv, int H, int Hk, int Dh, RowMap rm) {
+static void gemm2_set_attr() {
     static bool attr_set = false;
     if (!attr_set) {
-        FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2<EPI, G_BK>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)G_LDS_BYTES));
-        FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2<EPI, 64>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)G_LDS_BYTES));
+        FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2<EPI, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)GemmGeom<1024>::LDS));
         attr_set = true;
     }
-    const int Kb = K / ksplit;
-    FS_REQUIRE(K % ksplit == 0 && Kb % 64 == 0, "unsupported GEMM depth for the MFMA row path");
-    if (Kb % G_BK == 0) {
-        FS_REQUIRE(Kb / G_BK <= G_NS, "GEMM depth per block above 1024: raise the K split");
-        hipLaunchKernelGGL((k_gemm2<EPI, G_BK>), grid, dim3(256), G_LDS_BYTES, st, Xhi, Xlo, M, K, ksplit, W, N, Y, ldy, Ohi, Olo, ldo, cos_t,
-                           sin_t, state, kv, H, Hk, Dh, rm);
-    } else {  // small test configurations
-        FS_REQUIRE(Kb / 64 <= G_NS, "GEMM depth per block above 256 must be a multiple of 256");
-        hipLaunchKernelGGL((k_gemm2<EPI, 64>), grid, dim3(256), G_LDS_BYTES, st, Xhi, Xlo, M, K, ksplit, W, N, Y, ldy, Ohi, Olo, ldo, cos_t,
-                           sin_t, state, kv, H, Hk, Dh, rm);
+}
+
+template <int EPI>
+static void launch_gemm2(int n_blocks_n, int ksplit, hipStream_t st, const bf16_t* Xhi, const bf16_t* Xlo, int M, int K, const bf16_t* W, int N,
+                         float* Y, int ldy, bf16_t* Ohi, bf16_t* Olo, int ldo, const float* cos_t, const float* sin_t,
+                         const SeqState* state, KVView kv, int H, int Hk, int Dh, RowMap rm) {
+    gemm2_set_attr<EPI>();
+    FS_REQUIRE(K % ksplit == 0, "GEMM depth not divisible by the K split");
+    const int KB = K / ksplit;
+    const dim3 grid(n_blocks_n, ksplit);
+#define FS_GEMM_CASE(kb)                                                                                                          \
+    case kb:                                                                                                                      \
+        hipLaunchKernelGGL((k_gemm2<EPI, kb>), grid, dim3(256), GemmGeom<kb>::LDS, st, Xhi, Xlo, M, K, W, N, Y, ldy, Ohi, Olo, ldo, cos_t, \
+                           sin_t, state, kv, H, Hk, Dh, rm);                                                                       \
+        break;
+    switch (KB) {
+        FS_GEMM_CASE(1024)
+        FS_GEMM_CASE(256)
+        FS_GEMM_CASE(128)
+        FS_GEMM_CASE(64)
+        default: throw Error("unsupported per-block GEMM depth " + std::to_string(KB) + " (supported: 1024, 256, 128, 64)");
     }
+#undef FS_GEMM_CASE
 }
 
 template <typename WT>
@@ -1347,7 +1471,7 @@ void LmKernels<WT>::rows_layer(const ModelDims& d, int M, const RowsCtx& c, cons
     if constexpr (!std::is_same<WT, bf16_t>::value) {
         throw Error("the MFMA row path is implemented for bf16 weights only");
     } else {
-        FS_REQUIRE(M >= 1 && M <= PF_M, "at most 64 activation rows per pass");
+        FS_REQUIRE(M >= 1 && M <= PF_M, "at most 32 activation rows per pass");
         FS_REQUIRE(d.dim % 256 == 0 && d.inter % 256 == 0 || (d.dim % PF_BK == 0 && d.inter % (PF_BK * 4) == 0),
                    "row path needs dim % 64 == 0 and intermediate_size % 256 == 0");
         const int qkv_rows = (d.H + 2 * d.Hk) * d.Dh;
@@ -1359,7 +1483,7 @@ void LmKernels<WT>::rows_layer(const ModelDims& d, int M, const RowsCtx& c, cons
         // (1) x += previous layer's down-proj slabs ; RMSNorm(attention_norm) -> hi/lo
         hipLaunchKernelGGL(k_prep, dim3(M), dim3(256), 0, st, c.X, d.dim, c.P, first ? 0 : DOWN_SPLIT, slab, w.attn_norm, d.eps, c.Ahi, c.Alo);
         // (2) Wqkv + rope + KV scatter
-        launch_gemm2<EPI_QKV>(dim3((qkv_rows + 63) / 64, 1), st, c.Ahi, c.Alo, M, d.dim, 1, (const bf16_t*)w.wqkv, qkv_rows, c.Q, d.dim,
+        launch_gemm2<EPI_QKV>((qkv_rows + 63) / 64, 1, st, c.Ahi, c.Alo, M, d.dim, (const bf16_t*)w.wqkv, qkv_rows, c.Q, d.dim,
                               nullptr, nullptr, 0, c.cos_t, c.sin_t, c.state, kv, d.H, d.Hk, d.Dh, rm);
         // (3) attention over each row's KV prefix + chunk combine -> hi/lo
         const dim3 ga(d.Hk * c.nc_launch, M);
@@ -1377,16 +1501,22 @@ void LmKernels<WT>::rows_layer(const ModelDims& d, int M, const RowsCtx& c, cons
         else
             hipLaunchKernelGGL((k_attn_combine<32>), dim3(M), dim3(256), 0, st, c.part, c.n_chunks_max, attn_chunk(), c.state, c.pos_step, c.Ahi, c.Alo, d.H);
         // (4) Wo + residual (each output element owned by one lane: deterministic)
-        launch_gemm2<EPI_RESIDUAL>(dim3((d.dim + 63) / 64, 1), st, c.Ahi, c.Alo, M, d.dim, 1, (const bf16_t*)w.wo, d.dim, c.X, d.dim, nullptr,
+        launch_gemm2<EPI_RESIDUAL>((d.dim + 63) / 64, 1, st, c.Ahi, c.Alo, M, d.dim, (const bf16_t*)w.wo, d.dim, c.X, d.dim, nullptr,
                                    nullptr, 0, nullptr, nullptr, nullptr, nokv, 0, 0, 0, none);
         // (5) RMSNorm(ffn_norm) -> hi/lo ; W1||W3 + SwiGLU -> act hi/lo ; W2 split-K slabs (summed by the next k_prep)
         hipLaunchKernelGGL(k_prep, dim3(M), dim3(256), 0, st, c.X, d.dim, (const float*)nullptr, 0, slab, w.ffn_norm, d.eps, c.Ahi, c.Alo);
-        launch_gemm2<EPI_SWIGLU>(dim3((2 * d.inter + 63) / 64, 1), st, c.Ahi, c.Alo, M, d.dim, 1, (const bf16_t*)w.w13, 2 * d.inter, nullptr, 0,
+        launch_gemm2<EPI_SWIGLU>((2 * d.inter + 63) / 64, 1, st, c.Ahi, c.Alo, M, d.dim, (const bf16_t*)w.w13, 2 * d.inter, nullptr, 0,
                                  c.Chi, c.Clo, d.inter, nullptr, nullptr, nullptr, nokv, 0, 0, 0, none);
-        launch_gemm2<EPI_STORE>(dim3((d.dim + 63) / 64, DOWN_SPLIT), st, c.Chi, c.Clo, M, d.inter, DOWN_SPLIT, (const bf16_t*)w.w2, d.dim, c.P,
+        launch_gemm2<EPI_STORE>((d.dim + 63) / 64, DOWN_SPLIT, st, c.Chi, c.Clo, M, d.inter, (const bf16_t*)w.w2, d.dim, c.P,
                                 d.dim, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nokv, 0, 0, 0, none);
         FS_LAUNCH_CHECK();
     }
+}
+
+// one-time function attributes (dynamic LDS) -- must happen outside stream capture
+template <typename WT>
+void LmKernels<WT>::rows_warmup() {
+    gemm2_set_attr<EPI_STORE>(); gemm2_set_attr<EPI_RESIDUAL>(); gemm2_set_attr<EPI_SWIGLU>(); gemm2_set_attr<EPI_QKV>();
 }
 
 // x += last layer's down-proj slabs (closes a rows_layer chain); optionally RMSNorm -> hi/lo for a head GEMM
@@ -1395,6 +1525,21 @@ void LmKernels<WT>::rows_finish(const ModelDims& d, int M, const RowsCtx& c, con
     hipLaunchKernelGGL(k_prep, dim3(M), dim3(256), 0, st, c.X, d.dim, c.P, 4, (size_t)PF_M * d.dim, norm_w, d.eps,
                        norm_w ? c.Ahi : (bf16_t*)nullptr, norm_w ? c.Alo : (bf16_t*)nullptr);
     FS_LAUNCH_CHECK();
+}
+
+// head GEMM of the MFMA row path: logits[m][0..n_rows) = W[n_rows, dim] . (hi + lo)[m]  (input = rows_finish(norm_w) output)
+template <typename WT>
+void LmKernels<WT>::rows_head(const ModelDims& d, int M, const RowsCtx& c, const void* W, int n_rows, float* logits, int ld, hipStream_t st) {
+    if constexpr (!std::is_same<WT, bf16_t>::value) {
+        throw Error("the MFMA row path is implemented for bf16 weights only");
+    } else {
+        FS_REQUIRE(ld % 4 == 0 && ld >= ((n_rows + 3) / 4) * 4, "logits row stride must cover n_rows rounded up to 4");
+        KVView nokv = {};
+        // EPI_STORE with one K range writes slab 0 == the logits matrix itself (row stride ld)
+        launch_gemm2<EPI_STORE>((n_rows + 63) / 64, 1, st, c.Ahi, c.Alo, M, d.dim, (const bf16_t*)W, n_rows, logits, ld, nullptr, nullptr, 0,
+                                nullptr, nullptr, nullptr, nokv, 0, 0, 0, RowMap{0, 0});
+        FS_LAUNCH_CHECK();
+    }
 }
 
 void launch_advance_n(SeqState* state, int n, hipStream_t st) {

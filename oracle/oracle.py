@@ -174,6 +174,24 @@ class OracleLM:
         return out[: Cb * n.value].reshape(Cb, n.value).copy()
 
 
+def _generate_batch(self, prompts, max_new_tokens, temp=0.0, top_p=1.0, top_k=0, seed=42, ignore_eos=False):
+    """generate_static_batch (static_batch.rs:282-390): list of (C+1, L_i) -> list of (C, n_i)."""
+    Cb = self.cfg["num_codebooks"]
+    ps = [np.ascontiguousarray(p, np.uint32) for p in prompts]
+    lens = np.array([p.shape[1] for p in ps], np.int32)
+    flat = np.concatenate([p.reshape(-1) for p in ps])
+    cap = max_new_tokens + 8
+    out = np.zeros((len(ps), Cb, cap), np.uint32)
+    nf = np.zeros(len(ps), np.int32)
+    _chk(lib().orc_lm_generate_batch(self.h, _p(flat, C.c_uint32), _p(lens, C.c_int), len(ps), int(max_new_tokens), C.c_double(temp),
+                                     C.c_double(top_p), C.c_uint64(top_k), C.c_uint64(seed), int(ignore_eos), _p(out, C.c_uint32), cap,
+                                     _p(nf, C.c_int)))
+    return [out[i, :, : nf[i]].copy() for i in range(len(ps))]
+
+
+OracleLM.generate_batch = _generate_batch
+
+
 class OracleCodec:
     def __init__(self, tiny=False):
         self.h = C.c_void_p(lib().orc_codec_create(int(tiny)))

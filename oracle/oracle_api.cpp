@@ -112,6 +112,29 @@ int orc_lm_generate(void* p, const uint32_t* prompt, int L, int max_new_tokens, 
     } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }
 
+// generate_static_batch.  prompts concatenated [(C+1) x L_i]; codes_out: [n][C][cap] row-major; n_frames[n]
+int orc_lm_generate_batch(void* p, const uint32_t* prompts, const int* lens, int n, int max_new_tokens, double temp, double top_p,
+                          uint64_t top_k, uint64_t seed, int ignore_eos, uint32_t* codes_out, int cap, int* n_frames) {
+    try {
+        LM* lm = (LM*)p;
+        Sampling s; s.temp = temp; s.top_p = top_p; s.top_k = top_k; s.repetition_penalty = 1.0f;
+        const int C1 = lm->a.num_codebooks + 1, C = lm->a.num_codebooks;
+        std::vector<std::vector<uint32_t>> ps(n);
+        std::vector<int> ls(lens, lens + n);
+        size_t off = 0;
+        for (int i = 0; i < n; ++i) { ps[i].assign(prompts + off, prompts + off + (size_t)C1 * lens[i]); off += (size_t)C1 * lens[i]; }
+        std::vector<int> nf;
+        auto out = lm->generate_batch(ps, ls, max_new_tokens, s, seed, ignore_eos != 0, &nf);
+        for (int i = 0; i < n; ++i) {
+            if (nf[i] > cap) { g_err = "codes_out too small"; return 2; }
+            for (int c = 0; c < C; ++c)
+                std::memcpy(codes_out + ((size_t)i * C + c) * cap, out[i].data() + (size_t)c * nf[i], sizeof(uint32_t) * nf[i]);
+            n_frames[i] = nf[i];
+        }
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
 // ---- weight-free helpers (known-answer tests)
 void orc_get_mask_abs(int s1, int s2, int ctx, uint8_t* m) { get_mask_abs(s1, s2, ctx, m); }
 void* orc_reppen_create(int vocab, int ctx, float amt) { RepPen* r = new RepPen(); r->init(vocab, ctx, amt); return r; }

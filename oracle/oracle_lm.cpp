@@ -422,6 +422,57 @@ static uint32_t sample_topp(ChaCha12Rng& rng, std::vector<float>& probs, float t
 // Tie rule of the host ArgMax: `iter().enumerate().max_by(total_cmp)` => the LAST maximal index wins.
 // top-k: the reference uses `select_nth_unstable_by`, whose output ORDER is unspecified; this restatement
 // (and the HIP path) fix the order to ascending token index, which leaves the sampling distribution unchanged.
+// top-k then top-p then WeightedIndex draw on a probability vector (shared by the single and the batched processor)
+static uint32_t sample_probs(ChaCha12Rng& rng, std::vector<float>& p, size_t top_k, float top_p) {
+    const size_t n = p.size();
+    if (top_k == 0 || top_k >= n) return sample_topp(rng, p, top_p);
+    std::vector<size_t> idx(n);
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](size_t i, size_t j) { return p[i] > p[j]; });
+    std::vector<size_t> keep(idx.begin(), idx.begin() + top_k);
+    std::sort(keep.begin(), keep.end());
+    std::vector<float> tk(top_k);
+    float sum_p = 0.f;
+    for (size_t i = 0; i < top_k; ++i) { tk[i] = p[keep[i]]; sum_p += tk[i]; }
+    uint32_t j = (top_p <= 0.f || top_p >= sum_p) ? weighted_index_sample(rng, tk) : sample_topp(rng, tk, top_p);
+    return (uint32_t)keep[j];
+}
+
+static void softmax_temp(const float* logits, size_t n, float inv_t, std::vector<float>& p) {
+    p.resize(n);
+    float mx = -std::numeric_limits<float>::infinity();
+    for (size_t i = 0; i < n; ++i) { p[i] = logits[i] * inv_t; mx = std::max(mx, p[i]); }
+    double sum = 0.0;  // f64 denominator: independent of reduction order (see LogitsProcessor::sample)
+    for (size_t i = 0; i < n; ++i) { p[i] = std::exp(p[i] - mx); sum += (double)p[i]; }
+    const float denom = (float)sum;
+    for (size_t i = 0; i < n; ++i) p[i] /= denom;
+}
+
+// BatchedLogitsProcessor::sample (sampling/mod.rs:77-109): rows (B, n).  temp <= 1e-7 -> device argmax (FIRST max);
+// else per-row child StdRng seeded from the master's next u64 (:93-95).
+std::vector<uint32_t> batched_sample(ChaCha12Rng& master, const Sampling& s, const float* logits, size_t B, size_t n, size_t ld) {
+    std::vector<uint32_t> out(B);
+    if (s.temp <= 1e-7) {
+        for (size_t b = 0; b < B; ++b) {
+            const float* l = logits + b * ld;
+            size_t best = 0;
+            for (size_t i = 1; i < n; ++i) if (l[i] > l[best]) best = i;
+            out[b] = (uint32_t)best;
+        }
+        return out;
+    }
+    std::vector<uint64_t> seeds(B);
+    for (size_t b = 0; b < B; ++b) seeds[b] = master.next_u64();
+    const float inv_t = (float)(1.0 / s.temp);
+    for (size_t b = 0; b < B; ++b) {
+        ChaCha12Rng child(seeds[b]);
+        std::vector<float> p;
+        softmax_temp(logits + b * ld, n, inv_t, p);
+        out[b] = sample_probs(child, p, (size_t)s.top_k, (float)s.top_p);
+    }
+    return out;
+}
+
 uint32_t LogitsProcessor::sample(const float* logits, size_t n) {
     if (s.temp == 0.0) {
         size_t best = 0;
@@ -532,6 +583,84 @@ std::vector<uint32_t> LM::generate(const uint32_t* prompt, int L, int max_new_to
     std::vector<uint32_t> out((size_t)C * n);  // drop row 0 (:280-284)
     for (int f = 0; f < n; ++f)
         for (int c = 0; c < C; ++c) out[(size_t)c * n + f] = frames[f][c + 1];
+    return out;
+}
+
+// ---------------------------------------------------------------- generate_static_batch (static_batch.rs:17-390), audio_only
+std::vector<std::vector<uint32_t>> LM::generate_batch(const std::vector<std::vector<uint32_t>>& prompts, const std::vector<int>& lens,
+                                                      int max_new_tokens, const Sampling& s, uint64_t seed, bool ignore_eos,
+                                                      std::vector<int>* n_frames) {
+    const int C = a.num_codebooks, C1 = C + 1, D = a.dim, V = a.vocab_size, B = (int)prompts.size();
+    if (B == 0) throw std::runtime_error("Must have at least one prompt");
+    if (!t.has_semantic_end || t.im_end_id != t.semantic_start_id - 1) throw std::runtime_error("only the Fish 1.5 contiguous audio range is restated");
+    int Lmax = 0;
+    for (int l : lens) Lmax = std::max(Lmax, l);
+    // pad_prompts (:68-111): left pad with [im_end; 0...]; the mask is built but never applied (dual_ar.rs:589-615)
+    std::vector<uint32_t> cur((size_t)B * C1 * Lmax);
+    for (int b = 0; b < B; ++b)
+        for (int r = 0; r < C1; ++r) {
+            const int pad = Lmax - lens[b];
+            for (int j = 0; j < pad; ++j) cur[((size_t)b * C1 + r) * Lmax + j] = r == 0 ? t.im_end_id : 0u;
+            for (int j = 0; j < lens[b]; ++j) cur[((size_t)b * C1 + r) * Lmax + pad + j] = prompts[b][(size_t)r * lens[b] + j];
+        }
+    ChaCha12Rng master(seed);  // BatchedLogitsProcessor::new(seed) (:63 passes 42)
+    std::vector<bool> dead(B, false);
+    std::vector<std::vector<std::vector<uint32_t>>> frames(B);
+    std::vector<float> logits((size_t)B * V), hidden((size_t)B * D), fl((size_t)B * a.codebook_size), x((size_t)B * D);
+    size_t input_pos = 0;
+    int curL = Lmax;
+    bool have_prompt = true, first = true;
+    const size_t lo = t.im_end_id, na = (size_t)V - lo;
+    while (true) {
+        if (input_pos == 0) clear_slow();                                 // :118-121
+        if (!have_prompt || input_pos > (size_t)max_new_tokens) break;    // :122
+        forward_generate(cur.data(), B, curL, (int)input_pos, logits.data(), hidden.data(), true);
+        std::vector<float> sl((size_t)B * na);
+        for (int b = 0; b < B; ++b) {
+            std::memcpy(&sl[(size_t)b * na], &logits[(size_t)b * V + lo], sizeof(float) * na);
+            if (ignore_eos) sl[(size_t)b * na] = -std::numeric_limits<float>::infinity();
+        }
+        std::vector<uint32_t> slow = batched_sample(master, s, sl.data(), B, na, na);
+        for (auto& v : slow) v += t.im_end_id;                             // rescale_semantic_tokens
+        for (int b = 0; b < B; ++b) dead[b] = dead[b] || slow[b] == t.im_end_id;  // :160-173
+        x = hidden;
+        clear_fast();
+        std::vector<std::vector<uint32_t>> ids(B, std::vector<uint32_t>{});
+        for (int b = 0; b < B; ++b) ids[b].push_back(slow[b]);
+        for (int ci = 0; ci < C; ++ci) {
+            forward_generate_fast(x.data(), B, ci, fl.data());
+            // rep_pen.apply_mask: the mask is never updated for Fish models (:204-206) -> logits / 1.0
+            std::vector<uint32_t> tok = batched_sample(master, s, fl.data(), B, a.codebook_size, a.codebook_size);
+            for (int b = 0; b < B; ++b) {
+                std::memcpy(&x[(size_t)b * D], &fast_embeddings[(size_t)tok[b] * D], sizeof(float) * D);
+                ids[b].push_back(tok[b]);
+            }
+        }
+        std::vector<uint32_t> next((size_t)B * C1);
+        bool all_dead = true;
+        for (int b = 0; b < B; ++b) {
+            const bool is_audio = ids[b][0] >= t.semantic_start_id;        // :229
+            std::vector<uint32_t> vq = ids[b];
+            if (!is_audio) for (int c = 1; c <= C; ++c) vq[c] = 0;
+            if (first || !dead[b]) frames[b].push_back(vq);                // generate_static_batch :305-338
+            for (int r = 0; r < C1; ++r) next[(size_t)b * C1 + r] = vq[r];
+            all_dead = all_dead && dead[b];
+        }
+        have_prompt = !all_dead;                                          // :255-261
+        cur = next; 
+        input_pos += first ? (size_t)Lmax : 1;                            // :262-267
+        curL = 1;
+        first = false;
+    }
+    std::vector<std::vector<uint32_t>> out(B);
+    if (n_frames) n_frames->assign(B, 0);
+    for (int b = 0; b < B; ++b) {
+        const int n = (int)frames[b].size();
+        out[b].resize((size_t)C * n);
+        for (int f = 0; f < n; ++f)
+            for (int c = 0; c < C; ++c) out[b][(size_t)c * n + f] = frames[b][f][c + 1];  // drop row 0 (:371-374)
+        if (n_frames) (*n_frames)[b] = n;
+    }
     return out;
 }
 

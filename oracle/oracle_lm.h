@@ -85,6 +85,11 @@ struct LM {
                                    double* decode_s = nullptr, int max_frames = -1,
                                    std::vector<float>* margins = nullptr);
 
+    // generate/static_batch.rs:282-390 (generate_static_batch, audio_only): per-row codes (num_codebooks, n_b)
+    std::vector<std::vector<uint32_t>> generate_batch(const std::vector<std::vector<uint32_t>>& prompts, const std::vector<int>& lens,
+                                                      int max_new_tokens, const Sampling& s, uint64_t seed, bool ignore_eos,
+                                                      std::vector<int>* n_frames);
+
     void embed(const uint32_t* toks, int B, int L, float* x);  // dual_ar.rs:532-567
     void block_forward(Block& blk, float* x, int B, int L, int input_pos, int T_cached_expected);
 };

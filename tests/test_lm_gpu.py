@@ -207,3 +207,42 @@ def test_sampled_decode_matches_oracle_stream(tiny32, temp, top_p, top_k):
     lm.clear_slow_layer_caches()
     c = lm.generate_blocking(p, 30, temp=temp, top_p=top_p, top_k=top_k, seed=8, ignore_eos=True)
     assert np.array_equal(a, b) and not np.array_equal(a, c)
+
+
+def _batch_prompts(seed, lens):
+    rng = np.random.RandomState(seed)
+    out = []
+    for L in lens:
+        p = np.zeros((9, L), np.uint32)
+        p[0] = rng.randint(0, 400, L)
+        if L >= 6:  # a VQ span so that codebook embeddings are exercised
+            codes = rng.randint(0, 64, (8, 3))
+            p[0, 2:5] = 401 + codes[0]
+            p[1:, 2:5] = codes
+        out.append(p)
+    return out
+
+
+@pytest.mark.parametrize("sampling", [dict(temp=0.0, top_p=1.0, top_k=0), dict(temp=0.7, top_p=0.8, top_k=32)])
+def test_static_batch_mfma_rows_vs_oracle(sampling):
+    """generate_static_batch on the MFMA row path (bf16 handle; rows = sequences, weights streamed once per step) vs the
+    oracle's restatement of static_batch.rs on the same bf16-rounded weights with bf16-rounded K/V: ragged prompts,
+    left padding, per-row EOS, child-RNG sampling (seed 42 like static_batch.rs:63)."""
+    lm = _tiny("bf16", 8)
+    o = orc.OracleLM(orc.TINY).load_synthetic(SEED, bf16=True)
+    o.set_kv_round_bf16(True)
+    prompts = _batch_prompts(5, (5, 11, 8, 3, 7))
+    M = 40
+    got = lm.generate_static_batch(prompts, M, seed=42, repetition_penalty=1.3, ignore_eos=True, **sampling)
+    exp = o.generate_batch(prompts, M, seed=42, ignore_eos=True, **sampling)
+    assert [g.shape for g in got] == [e.shape for e in exp] == [(8, M - 11 + 2)] * 5
+    agree = [int(np.argmin((g == e).all(0))) if not (g == e).all() else g.shape[1] for g, e in zip(got, exp)]
+    print("static batch", sampling, "identical frame prefix per row:", agree, "of", got[0].shape[1])
+    assert min(agree) >= 8, agree  # bf16 near-ties may flip late in a free run; a kernel bug shows at frame 0-1
+    # EOS path: rows finish at different frames; dead rows are stepped but not recorded (static_batch.rs:160-173,328-331)
+    got = lm.generate_static_batch(prompts, 150, seed=42, **sampling)
+    exp = o.generate_batch(prompts, 150, seed=42, **sampling)
+    for g, e in zip(got, exp):
+        n = min(g.shape[1], e.shape[1], 8)
+        assert np.array_equal(g[:, :n], e[:, :n])
+    assert lm.last_stats()["frames"] == sum(g.shape[1] for g in got)

@@ -91,3 +91,29 @@ def test_codec_tiny_stages_and_pcm():
         exp = CG[f"stage{i}"]
         _, st = c.decode(codes, stage=i, stage_size=exp.size)
         np.testing.assert_allclose(st.reshape(exp.shape), exp, rtol=1e-4, atol=2e-5)
+
+
+def test_static_batch_rows_equal_padded_single_under_greedy(lm_tag):
+    """static_batch.rs: rows are independent sequences; the left padding is NOT masked (dual_ar.rs:589-615) and batch
+    rep-pen is a no-op (static_batch.rs:204-206), so under greedy decoding row i == generate_blocking(padded prompt i)."""
+    lm, _ = lm_tag
+    rng = np.random.RandomState(21)
+    prompts = []
+    for L in (4, 9, 6):
+        p = np.zeros((9, L), np.uint32)
+        p[0] = rng.randint(0, 400, L)
+        prompts.append(p)
+    outs = lm.generate_batch(prompts, 20, temp=0.0, ignore_eos=True)
+    assert [o.shape for o in outs] == [(8, 13)] * 3  # frames = M - Lmax + 2
+    for p, got in zip(prompts, outs):
+        pad = 9 - p.shape[1]
+        pp = np.concatenate([np.zeros((9, pad), np.uint32), p], 1)
+        pp[0, :pad] = 400
+        lm.clear_slow()
+        exp = lm.generate(pp, 20, temp=0.0, repetition_penalty=1.0, ignore_eos=True)
+        assert np.array_equal(got, exp)
+    # sampled: reproducible per seed, different across seeds
+    a = lm.generate_batch(prompts, 20, temp=0.8, top_p=0.9, top_k=32, seed=42, ignore_eos=True)
+    b = lm.generate_batch(prompts, 20, temp=0.8, top_p=0.9, top_k=32, seed=42, ignore_eos=True)
+    c = lm.generate_batch(prompts, 20, temp=0.8, top_p=0.9, top_k=32, seed=43, ignore_eos=True)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b)) and not all(np.array_equal(x, y) for x, y in zip(a, c))

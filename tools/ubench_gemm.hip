@@ -23,7 +23,7 @@ static float time_graph(hipStream_t st, int nodes, int reps, const std::function
     return ms * 1e3f / (reps * nodes);
 }
 int main(int argc, char** argv) {
-    const int M = argc > 1 ? atoi(argv[1]) : 64;
+    const int M = argc > 1 ? atoi(argv[1]) : 32;
     typedef bf16_t WT;
     ModelDims d{1024, 4096, 16, 2, 64, 8, 1e-6f};
     const int NL = 24, QKV = 1280;

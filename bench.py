@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed configs[2] / vocoder side measurements")
     args = ap.parse_args()
 
     import torch
@@ -140,12 +141,51 @@ def main():
                      "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
                      "algorithmic_bytes_per_frame": int(bf), "frame_us": round(t_frame * 1e6, 2), "kv_len_avg": T_avg},
     }
+    if rank == 0 and world == 1 and not args.no_extras:
+        res["extras"] = extras(cfg, tok)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res.update(cpu_baseline_and_parity(cfg, tok))
     if rank == 0:
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def extras(cfg, tok):
+    """Side measurements outside the timed region (not part of `value`): BASELINE.json configs[2] (static batch of 32 on the
+    MFMA row path) and the Firefly vocoder on the 256 frames of one request."""
+    import fishrt
+    out = {}
+    B, frames = 32, 64
+    lmb = fishrt.DualARTransformer(cfg, tok, 0, "bf16", max_batch=B).load_synthetic(SEED)
+    rng = np.random.RandomState(77)
+    prompts = []
+    for L in rng.randint(64, 385, B):  # SURVEY.md §8d configs[2]: prompt lengths U{64..384}, seed 77
+        p = np.zeros((9, int(L)), np.uint32)
+        p[0] = rng.randint(0, tok["im_end_id"], int(L))
+        prompts.append(p)
+    Lmax = max(p.shape[1] for p in prompts)
+    outs = lmb.generate_static_batch(prompts, frames + Lmax - 2, temp=0.7, top_p=0.8, top_k=256, seed=42, ignore_eos=True)
+    st = lmb.last_stats()
+    step_s = st["decode_ms"] * 1e-3 / (frames - 1)
+    bytes_step = frame_bytes(cfg, tok, 0) + B * 12288 * (Lmax + frames / 2)
+    out["static_batch32"] = {"workload": "BASELINE.json configs[2] shape: B=32, temp 0.7 / top-p 0.8 / top-k 256, prompts U{64..384}, "
+                                         f"{frames} frames (decode steps HIP-event timed; prefill excluded)",
+                             "decode_frames_per_s": round(B / step_s, 1), "step_us": round(step_s * 1e6, 1),
+                             "roofline_frac": round(bytes_step / step_s / HBM_PEAK, 4),
+                             "frames_out": int(sum(o.shape[1] for o in outs)), "prefill_ms_all_rows": round(st["prefill_ms"], 1)}
+    lmb.close()
+    codec = fishrt.FireflyCodec(0).load_synthetic(0xC0DEC)
+    codes = np.random.RandomState(1).randint(0, 1000, (1, 8, 256)).astype(np.uint32)
+    codec.decode(codes)
+    t0 = time.perf_counter()
+    pcm = codec.decode(codes)
+    dt = time.perf_counter() - t0
+    out["vocoder"] = {"workload": "FireflyCodec.decode of 256 frames (11.9 s of 44.1 kHz audio), f32, host buffers in/out",
+                      "ms": round(dt * 1e3, 2), "rtf": round((256 / FRAME_RATE) / dt, 1), "tflops_f32": round(2.65e9 * 256 / dt / 1e12, 2),
+                      "pcm_finite": bool(np.isfinite(pcm).all())}
+    codec.close()
+    return out
 
 
 def cpu_baseline_and_parity(cfg, tok):

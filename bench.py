@@ -138,7 +138,10 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "decode frame = one hipGraph replay (24 slow blocks + head + sample + 8 x (4 fast "
                                                "blocks + head + sample)); HIP-event timed on the engine stream",
                      "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK, 4),
+                     # HBM bytes per frame from the PMC passes of profiles/r01_pmc_hbm_traffic.csv (FETCH_SIZE x2 gfx950 correction
+                     # + WRITE_SIZE, summed over the frame's 266 launches); collected offline, not in this run
+                     "traffic": 1.66e9, "traffic_source": "profiles/r01_pmc_hbm_traffic.csv (offline rocprofv3 --pmc passes)",
                      "algorithmic_bytes_per_frame": int(bf), "frame_us": round(t_frame * 1e6, 2), "kv_len_avg": T_avg},
     }
     if rank == 0 and world == 1 and not args.no_extras:

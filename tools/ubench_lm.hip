@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <functional>
 #include <vector>
 
@@ -67,7 +68,8 @@ int main(int argc, char** argv) {
     std::vector<int> pt(max_pages); for (int i = 0; i < max_pages; ++i) pt[i] = i;
     int* d_pt; CK(hipMalloc(&d_pt, max_pages * 4)); CK(hipMemcpy(d_pt, pt.data(), max_pages * 4, hipMemcpyHostToDevice));
     auto kv = [&](int l) { KVView v; v.k = kvpool + (size_t)l * 2 * max_pages * page_elems; v.v = (WT*)v.k + max_pages * page_elems; v.page_table = d_pt; return v; };
-    const int N = 240, R = 20, NC = 8192 / LmKernels<WT>::attn_chunk(); int NCL = 1; while (NCL * LmKernels<WT>::attn_chunk() < T) NCL <<= 1;
+    const bool quick = getenv("UBENCH_QUICK") != nullptr;  // few dispatches: for rocprofv3 --pmc passes
+    const int N = quick ? 24 : 240, R = quick ? 1 : 20, NC = 8192 / LmKernels<WT>::attn_chunk(); int NCL = 1; while (NCL * LmKernels<WT>::attn_chunk() < T) NCL <<= 1;
     auto report = [&](const char* name, double bytes, float us) { printf("%-34s %7.2f us/node  %8.1f GB/s (%.2f MB)\n", name, us, bytes / us / 1e3, bytes / 1e6); };
     printf("KV length T = %d\n", T);
     report("graph floor (k_advance)", 0, time_graph(st, N, R, [&](int) { launch_advance(state, st); }));

@@ -1,0 +1,126 @@
+"""GPU: the safetensors loaders (fs_lm_load_safetensors / fs_codec_load_safetensors) bind tensors by the reference's names
+(dual_ar.rs:125-156,219-223,415-419,466-511; codec/utils/mod.rs:28-40,84-96) and re-lay them for the kernels.
+A checkpoint is written with the `safetensors` package from the oracle's synthetic weights (f32 and bf16 storage); a handle
+loaded from the file must behave exactly like the one initialised with fs_*_load_synthetic."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import fishrt
+from fishrt import config as fcfg
+from oracle import oracle as orc
+
+SEED = 99
+
+
+def _lm_tensors(cfg, bf16):
+    D, I, V = cfg["dim"], cfg["intermediate_size"], cfg["vocab_size"]
+    qkv = (cfg["n_head"] + 2 * cfg["n_local_heads"]) * cfg["head_dim"]
+    t = {}
+
+    def mat(name, shape):
+        t[name] = orc.synth(name, int(np.prod(shape)), SEED, 0.0, 0.02, bf16).reshape(shape)
+
+    def nrm(name):
+        t[name] = orc.synth(name, D, SEED, 1.0, 0.1, bf16)
+
+    mat("embeddings.weight", (V, D))
+    mat("codebook_embeddings.weight", (cfg["codebook_size"] * cfg["num_codebooks"], D))
+    for pre, n in (("layers.", cfg["n_layer"]), ("fast_layers.", cfg["n_fast_layer"])):
+        for l in range(n):
+            p = f"{pre}{l}."
+            mat(p + "attention.wqkv.weight", (qkv, D)); mat(p + "attention.wo.weight", (D, D))
+            mat(p + "feed_forward.w1.weight", (I, D)); mat(p + "feed_forward.w2.weight", (D, I)); mat(p + "feed_forward.w3.weight", (I, D))
+            nrm(p + "ffn_norm.weight"); nrm(p + "attention_norm.weight")
+    nrm("norm.weight"); mat("output.weight", (V, D)); mat("fast_embeddings.weight", (cfg["codebook_size"], D))
+    nrm("fast_norm.weight"); mat("fast_output.weight", (cfg["codebook_size"], D))
+    return t
+
+
+def _save(tensors, path, as_bf16):
+    from safetensors.numpy import save_file
+    if not as_bf16:
+        save_file({k: np.ascontiguousarray(v, np.float32) for k, v in tensors.items()}, path)
+        return
+    # bf16 storage: write the raw file by hand (numpy has no bfloat16): header JSON + u16 payload
+    import json, struct
+    hdr, blobs, off = {}, [], 0
+    for k, v in tensors.items():
+        u = (np.ascontiguousarray(v, np.float32).view(np.uint32) >> 16).astype(np.uint16)  # values are already bf16-representable
+        b = u.tobytes()
+        hdr[k] = {"dtype": "BF16", "shape": list(v.shape), "data_offsets": [off, off + len(b)]}
+        off += len(b); blobs.append(b)
+    hdr["__metadata__"] = {"format": "pt"}
+    hj = json.dumps(hdr).encode()
+    with open(path, "wb") as f:
+        f.write(struct.pack("<Q", len(hj))); f.write(hj)
+        for b in blobs:
+            f.write(b)
+
+
+@pytest.mark.parametrize("dtype,store_bf16", [("f32", False), ("bf16", True), ("bf16", False)])
+def test_lm_checkpoint_equals_synthetic(tmp_path, dtype, store_bf16):
+    cfg, tok = fcfg.TINY, fcfg.TINY_TOKENS
+    path = str(tmp_path / "model.safetensors")
+    _save(_lm_tensors(cfg, bf16=(dtype == "bf16")), path, store_bf16)
+    a = fishrt.DualARTransformer(cfg, tok, 0, dtype).load_safetensors(path)
+    b = fishrt.DualARTransformer(cfg, tok, 0, dtype).load_synthetic(SEED)
+    p = np.zeros((9, 7), np.uint32)
+    p[0] = [3, 401, 17, 464, 399, 12, 250]
+    p[1:, 1] = np.arange(8); p[1:, 3] = 63 - np.arange(8)
+    la, ha = a.forward_generate(p, 0)
+    lb, hb = b.forward_generate(p, 0)
+    assert np.array_equal(la, lb) and np.array_equal(ha, hb)
+    ga = a.generate_blocking(p[:, :3], 20, temp=0.0, top_p=1.0, top_k=0, repetition_penalty=1.2, ignore_eos=True)
+    gb = b.generate_blocking(p[:, :3], 20, temp=0.0, top_p=1.0, top_k=0, repetition_penalty=1.2, ignore_eos=True)
+    assert np.array_equal(ga, gb)
+    # missing tensor / wrong shape -> error naming the tensor (candle VarBuilder behaviour)
+    bad = _lm_tensors(cfg, False)
+    del bad["layers.1.feed_forward.w3.weight"]
+    _save(bad, path, False)
+    with pytest.raises(RuntimeError, match="layers.1.feed_forward.w3.weight"):
+        fishrt.DualARTransformer(cfg, tok, 0, dtype).load_safetensors(path)
+
+
+def test_codec_checkpoint_equals_synthetic(tmp_path):
+    import math
+    C, seed = 64, 1234
+    t = {}
+
+    def put(name, shape, mean, std):
+        t[name] = orc.synth(name, int(np.prod(shape)), seed, mean, std).reshape(shape)
+
+    for g in range(8):
+        put(f"quantizer.residual_fsq.rvqs.{g}.project_out.weight", (C // 8, 4), 0.0, 0.5)
+        put(f"quantizer.residual_fsq.rvqs.{g}.project_out.bias", (C // 8,), 0.0, 0.02)
+    for i in range(2):
+        p = f"quantizer.upsample.{i}"
+        put(p + ".0.conv.weight", (C, C, 2), 0.0, 1 / math.sqrt(C)); put(p + ".0.conv.bias", (C,), 0.0, 0.02)
+        q = p + ".1"
+        put(q + ".dwconv.conv.weight", (C, 1, 7), 0.0, 1 / math.sqrt(7)); put(q + ".dwconv.conv.bias", (C,), 0.0, 0.02)
+        put(q + ".norm.weight", (C,), 1.0, 0.1); put(q + ".norm.bias", (C,), 0.0, 0.02)
+        put(q + ".pwconv1.weight", (4 * C, C), 0.0, 1 / math.sqrt(C)); put(q + ".pwconv1.bias", (4 * C,), 0.0, 0.02)
+        put(q + ".pwconv2.weight", (C, 4 * C), 0.0, 1 / math.sqrt(4 * C)); put(q + ".pwconv2.bias", (C,), 0.0, 0.02)
+        put(q + ".gamma", (C,), 0.1, 0.02)
+    put("head.conv_pre.conv.weight", (C, C, 13), 0.0, 1 / math.sqrt(C * 13)); put("head.conv_pre.conv.bias", (C,), 0.0, 0.02)
+    rates, ks = [8, 8, 2, 2, 2], [16, 16, 4, 4, 4]
+    for s in range(5):
+        cin, cout = C >> s, C >> (s + 1)
+        put(f"head.ups.{s}.conv.weight", (cin, cout, ks[s]), 0.0, 1 / math.sqrt(cin * ks[s] / rates[s])); put(f"head.ups.{s}.conv.bias", (cout,), 0.0, 0.02)
+        for j, k in enumerate((3, 7, 11)):
+            for m in range(3):
+                for cv in ("convs1", "convs2"):
+                    q = f"head.resblocks.{s}.blocks.{j}.{cv}.{m}"
+                    put(q + ".conv.weight", (cout, cout, k), 0.0, 1 / math.sqrt(cout * k)); put(q + ".conv.bias", (cout,), 0.0, 0.02)
+    put("head.conv_post.conv.weight", (1, C >> 5, 13), 0.0, 1 / math.sqrt((C >> 5) * 13)); put("head.conv_post.conv.bias", (1,), 0.0, 0.02)
+    path = str(tmp_path / "firefly.safetensors")
+    _save(t, path, False)
+    a = fishrt.FireflyCodec(0, channel_div=8).load_safetensors(path)
+    b = fishrt.FireflyCodec(0, channel_div=8).load_synthetic(seed)
+    codes = np.random.RandomState(0).randint(0, 1000, (1, 8, 9)).astype(np.uint32)
+    assert np.array_equal(a.decode(codes), b.decode(codes))
+    o = orc.OracleCodec(tiny=True).load_synthetic(seed)
+    assert float(np.sqrt(np.mean((a.decode(codes)[0, 0] - o.decode(codes[0])) ** 2))) < 1e-6

@@ -151,9 +151,9 @@ __device__ __forceinline__ WT* kv_addr(void* pool, const int* __restrict__ page_
 }
 
 // ------------------------------------------------------------------------------------------------ qkv + rope + kv append
-// One wave per ROW of Wqkv (maximum memory-level parallelism: 1280 waves for Fish-1.5); the two rows (2p, 2p+1) of an
-// interleaved-RoPE pair sit in adjacent waves of one block and meet through LDS.  Position, page and cos/sin are
-// fetched at kernel entry so the epilogue has no dependent load left.
+// One wave per interleaved-RoPE row PAIR (2p, 2p+1) of Wqkv, both rows' loads in flight together, so the pair meets in
+// registers (no LDS, no block barrier).  Position, page and cos/sin are fetched at kernel entry so the epilogue has no
+// dependent load left.
 template <typename WT, int K, int WAVES, bool NT>
 __global__ __launch_bounds__(WAVES * 64) void k_qkv(const float* __restrict__ x, const float* __restrict__ norm_w, float eps,
                                                     const WT* __restrict__ W, const float* __restrict__ cos_t,
@@ -161,11 +161,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_qkv(const float* __restrict__ x,
                                                     int pos_static, int rope_static, float* __restrict__ q_out, KVView kv,
                                                     int H, int Hk, int Dh) {
     using R = Row<WT, K, NT>;
-    __shared__ float res[WAVES];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = blockIdx.x * WAVES + wave;
-    const int n_rows = (H + 2 * Hk) * Dh;
-    const bool active = row < n_rows;
+    const int lane = threadIdx.x & 63;
+    const int pair = blockIdx.x * WAVES + (threadIdx.x >> 6);
+    const int n_pairs = (H + 2 * Hk) * Dh / 2;
+    if (pair >= n_pairs) return;
     // small L2-resident vectors FIRST (vmcnt retires in order: a load issued after the weight stream would wait for it),
     // then the weight stream; the RMSNorm math then overlaps the weights' HBM flight
     float xr[R::NX], nr[R::NX];
@@ -173,26 +172,25 @@ __global__ __launch_bounds__(WAVES * 64) void k_qkv(const float* __restrict__ x,
     R::load_x(norm_w, lane, nr);
     const int pos = state ? state->pos : pos_static;
     const int rpos = state ? pos + state->rope_off : rope_static;
-    const int r0 = row & ~1, qdim = H * Dh, kdim = Hk * Dh, half = Dh / 2;
+    const int r0 = 2 * pair, qdim = H * Dh, kdim = Hk * Dh, half = Dh / 2;
     float c = 1.f, s = 0.f;
     WT* dst = nullptr;
-    if (active && r0 < qdim + kdim) {
+    if (r0 < qdim + kdim) {
         const int j = (r0 % Dh) / 2;
         c = cos_t[(size_t)rpos * half + j];
         s = sin_t[(size_t)rpos * half + j];
     }
-    if (active && r0 >= qdim) {
+    if (r0 >= qdim) {
         const int rk = (r0 - qdim) % kdim, g = rk / Dh, dd = rk % Dh;
         dst = kv_addr<WT>(r0 < qdim + kdim ? kv.k : kv.v, kv.page_table, pos, g, Hk, Dh) + dd;
     }
-    typename R::vec wv[R::NCH];
-    if (active) R::load_w(W + (size_t)row * K, lane, wv);
+    typename R::vec w0[R::NCH], w1[R::NCH];
+    R::load_w(W + (size_t)r0 * K, lane, w0);
+    R::load_w(W + (size_t)(r0 + 1) * K, lane, w1);
     R::rmsnorm(xr, nr, eps);
-    const float d = active ? wave_sum(R::dot(wv, xr)) : 0.f;
-    if (lane == 0) res[wave] = d;
-    __syncthreads();
-    if (!active || (wave & 1) || lane != 0) return;
-    const float a = res[wave], b = res[wave + 1];
+    const float a = wave_sum(R::dot(w0, xr));
+    const float b = wave_sum(R::dot(w1, xr));
+    if (lane != 0) return;
     if (r0 < qdim + kdim) {  // rope_i on the pair (2j, 2j+1) of its head (dual_ar.rs:246-247)
         const float o0 = a * c - b * s, o1 = a * s + b * c;
         if (r0 < qdim) { q_out[r0] = o0; q_out[r0 + 1] = o1; }
@@ -876,28 +874,41 @@ __device__ int block_sample(float* lg /*LDS [n]*/, int n, const SampleCfg& c, Rn
     const int tid = threadIdx.x;
     __shared__ int s_result;
     if (c.temp == 0.f) {
+        // argmax with the host rule (LAST maximal index) or the device rule (FIRST): per-thread scan, DPP/readlane wave
+        // reduction of the value, ballot-free index pick, then one LDS hop across the waves
         float bv = -INFINITY;
         int bi = -1;
         for (int i = tid; i < n; i += SAMPLE_THREADS) {
             const float v = lg[i];
-            if (bi < 0 || (first_max ? (v > bv) : !(v < bv))) { bv = v; bi = i; }  // ascending i per thread: >= keeps the last
+            if (bi < 0 || (first_max ? (v > bv) : !(v < bv))) { bv = v; bi = i; }  // ascending i per thread
+        }
+        float wm = bv;
+        wm = fmaxf(wm, dpp_mov<DPP_XOR1>(wm)); wm = fmaxf(wm, dpp_mov<DPP_XOR2>(wm));
+        wm = fmaxf(wm, dpp_mov<DPP_HALF_MIRROR>(wm)); wm = fmaxf(wm, dpp_mov<DPP_MIRROR>(wm));
+        wm = fmaxf(fmaxf(readlane(wm, 15), readlane(wm, 31)), fmaxf(readlane(wm, 47), readlane(wm, 63)));
+        int cand = (bi >= 0 && bv == wm) ? bi : (first_max ? 0x7FFFFFFF : -1);
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const int o = __shfl_xor(cand, m, 64);
+            cand = first_max ? min(cand, o) : max(cand, o);
         }
         float* rv = reinterpret_cast<float*>(red);
-        int* ri = reinterpret_cast<int*>(red) + SAMPLE_THREADS;
-        rv[tid] = bv; ri[tid] = bi;
+        int* ri = reinterpret_cast<int*>(red) + 64;
+        const int wv = tid >> 6;
+        if ((tid & 63) == 0) { rv[wv] = wm; ri[wv] = cand; }
         __syncthreads();
-        for (int s = SAMPLE_THREADS / 2; s >= 1; s >>= 1) {
-            if (tid < s) {
-                const float v2 = rv[tid + s];
-                const int i2 = ri[tid + s];
-                const float v1 = rv[tid];
-                const int i1 = ri[tid];
-                const bool take2 = (i1 < 0) || (i2 >= 0 && (v2 > v1 || (v2 == v1 && (first_max ? i2 < i1 : i2 > i1))));
-                if (take2) { rv[tid] = v2; ri[tid] = i2; }
+        if (tid == 0) {
+            float gv = rv[0];
+            int gi = ri[0];
+            for (int w2 = 1; w2 < SAMPLE_THREADS / 64; ++w2) {
+                const float v2 = rv[w2];
+                const int i2 = ri[w2];
+                if (v2 > gv || (v2 == gv && (first_max ? i2 < gi : i2 > gi))) { gv = v2; gi = i2; }
             }
-            __syncthreads();
+            s_result = gi;
         }
-        const int res = ri[0];
+        __syncthreads();
+        const int res = s_result;
         __syncthreads();
         return res;
     }
@@ -940,23 +951,43 @@ __device__ int block_sample(float* lg /*LDS [n]*/, int n, const SampleCfg& c, Rn
             __syncthreads();
         }
     }
-    // serial tail on one lane: few elements survive top-k / top-p in practice; order and f32 rounding identical to
-    // the oracle restatement.
+    // ---- tail.  Decision procedure and f32 rounding identical to the oracle restatement: kept probabilities live in lg[]
+    // by token index (0 elsewhere); sums and the WeightedIndex scan run in ascending index order, the top-p cut in
+    // descending probability order.  With top-k the kept set is re-sorted by index (small bitonic sort in `red`) so the
+    // single-lane loops touch top_k entries instead of n.
+    const bool use_k = c.top_k > 0 && c.top_k < n;
+    const int kk = use_k ? c.top_k : n;
+    int kp2 = 1;
+    while (kp2 < kk) kp2 <<= 1;
+    const bool idx_sorted = use_k && kp2 <= 2 * SAMPLE_THREADS;  // fits the 8 KB `red` scratch as ints
+    int* ki = reinterpret_cast<int*>(red);
+    for (int i = tid; i < n; i += SAMPLE_THREADS) lg[i] = 0.f;
+    __syncthreads();
+    for (int r = tid; r < kk; r += SAMPLE_THREADS) lg[si[r]] = sp[r];
+    if (idx_sorted) {
+        for (int r = tid; r < kp2; r += SAMPLE_THREADS) ki[r] = r < kk ? si[r] : 0x7FFFFFFF;
+        __syncthreads();
+        for (int k2 = 2; k2 <= kp2; k2 <<= 1)
+            for (int j = k2 >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < kp2; i += SAMPLE_THREADS) {
+                    const int ixj = i ^ j;
+                    if (ixj > i) {
+                        const int a0 = ki[i], a1 = ki[ixj];
+                        const bool up = (i & k2) == 0;
+                        if ((a0 > a1) == up) { ki[i] = a1; ki[ixj] = a0; }
+                    }
+                }
+                __syncthreads();
+            }
+    }
+    __syncthreads();
     if (tid == 0) {
-        const bool use_k = c.top_k > 0 && c.top_k < n;
-        const int kk = use_k ? c.top_k : n;
-        // sum over the kept set in ascending index order == f32 sum over all n with zeros elsewhere
-        // mark kept probabilities back into lg[] by index (0 elsewhere)
-        for (int i = 0; i < n; ++i) lg[i] = 0.f;
         bool do_topp = true;
         if (use_k) {
-            // sum_p in ascending index order: need the kept set sorted by index -> accumulate through lg[]
-            for (int r = 0; r < kk; ++r) lg[si[r]] = sp[r];
             float sum_p = 0.f;
-            for (int i = 0; i < n; ++i) if (lg[i] != 0.f) sum_p += lg[i];
+            if (idx_sorted) { for (int j = 0; j < kk; ++j) sum_p += lg[ki[j]]; }
+            else { for (int i = 0; i < n; ++i) if (lg[i] != 0.f) sum_p += lg[i]; }
             do_topp = !(c.top_p <= 0.f || c.top_p >= sum_p);
-        } else {
-            for (int r = 0; r < kk; ++r) lg[si[r]] = sp[r];
         }
         if (do_topp) {  // zero every prob once the running cumsum (descending order) reached top_p
             float cumsum = 0.f;
@@ -965,9 +996,10 @@ __device__ int block_sample(float* lg /*LDS [n]*/, int n, const SampleCfg& c, Rn
                 cumsum += lg[si[r]];
             }
         }
-        // WeightedIndex::new + sample over lg[0..n) (ascending index; within top-k: position among kept entries)
+        // WeightedIndex::new + sample (ascending index; zero weights do not move the cumulative sum)
         float total = 0.f;
-        for (int i = 0; i < n; ++i) if (lg[i] != 0.f) total += lg[i];
+        if (idx_sorted) { for (int j = 0; j < kk; ++j) total += lg[ki[j]]; }
+        else { for (int i = 0; i < n; ++i) if (lg[i] != 0.f) total += lg[i]; }
         int res = 0;
         if (total > 0.f) {
             const float max_rand = __uint_as_float((0xFFFFFFFFu >> 9) | (127u << 23)) - 1.0f;
@@ -976,13 +1008,14 @@ __device__ int block_sample(float* lg /*LDS [n]*/, int n, const SampleCfg& c, Rn
             const uint32_t w = chacha12_word(rng->key, rng->consumed);
             rng->consumed += 1;
             const float chosen = (__uint_as_float((w >> 9) | (127u << 23)) - 1.0f) * scale + 0.f;
-            // first kept item whose cumulative weight (exclusive prefix) is > chosen; zero-weight items are skipped by
-            // construction (cum does not move), matching partition_point over the full cumulative array only when the
-            // chosen item has non-zero weight -- which WeightedIndex guarantees as chosen < total.
+            // first kept item whose inclusive cumulative weight is > chosen (== partition_point over the exclusive
+            // cumulative array of WeightedIndex, since chosen < total)
             float cum = 0.f;
             int last_nz = 0;
             res = -1;
-            for (int i = 0; i < n; ++i) {
+            const int cnt = idx_sorted ? kk : n;
+            for (int j = 0; j < cnt; ++j) {
+                const int i = idx_sorted ? ki[j] : j;
                 if (lg[i] == 0.f) continue;
                 last_nz = i;
                 cum += lg[i];
@@ -1036,29 +1069,50 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_fast(const float* __r
     const int tid = threadIdx.x;
     const int n = cb_size;
     const SampleCfg c = *cp;
-    const bool eos = state->cur[0] == c.im_end_id;  // single_batch.rs:153-156: push 0, skip the fast step
+    // one round trip for everything the decision needs: state words, the repetition-penalty ring, logits and mask
+    __shared__ int s_ring[17], s_meta[2];
+    __shared__ uint32_t s_prev, s_cur0, s_have_prev;
+    if (tid < 17) s_ring[tid] = rp.ring[cb * 17 + tid];
+    else if (tid < 19) s_meta[tid - 17] = rp.ring_meta[cb * 2 + tid - 17];
+    else if (tid == 19) s_prev = state->prev[cb + 1];
+    else if (tid == 20) s_cur0 = state->cur[0];
+    else if (tid == 21) s_have_prev = (uint32_t)state->have_prev;
     float* mask = rp.mask + (size_t)cb * cb_size;
+    float lv[SAMPLE_MAXN / SAMPLE_THREADS], mv[SAMPLE_MAXN / SAMPLE_THREADS];
+#pragma unroll
+    for (int j = 0; j < SAMPLE_MAXN / SAMPLE_THREADS; ++j) {
+        const int i = tid + j * SAMPLE_THREADS;
+        lv[j] = i < n ? logits[i] : 0.f;
+        mv[j] = i < n ? mask[i] : 1.f;
+    }
+    __syncthreads();
+    const bool eos = s_cur0 == c.im_end_id;  // single_batch.rs:153-156: push 0, skip the fast step
     if (!eos) {
-        if (state->have_prev && tid == 0) {  // SingleBatchedRepPenProcessor::apply (rep_pen.rs:37-65)
-            const int last = (int)state->prev[cb + 1];
-            uint8_t* seen = rp.seen + (size_t)cb * cb_size;
-            int* ring = rp.ring + cb * 17;
-            int* meta = rp.ring_meta + cb * 2;  // head (index of front), len
-            seen[last] = 1;
-            mask[last] = c.rep_pen;
-            int head = (meta[0] + 16) % 17, len = meta[1] + 1;  // push_front
-            ring[head] = last;
-            if (len > 16) {
-                const int back = (head + len - 1) % 17;
-                const int dropped = ring[back];
-                len -= 1;
-                if (seen[dropped]) { seen[dropped] = 0; mask[dropped] = 1.0f; }
-            }
-            meta[0] = head; meta[1] = len;
+        const bool pen = s_have_prev != 0;
+        // SingleBatchedRepPenProcessor::apply (rep_pen.rs:37-65) on the register copy of the mask.  "token in tokens_seen"
+        // == "mask[token] == penalty" (set on insert, reset to 1 on removal; with penalty == 1 the mask never changes).
+        int last = -1, dropped = -1;
+        if (pen) {
+            last = (int)s_prev;
+            const int head = (s_meta[0] + 16) % 17, len = s_meta[1] + 1;  // push_front
+            const bool drop = len > 16;
+            if (drop) dropped = s_ring[(head + len - 1) % 17];            // pop_back (never the slot just written)
+            if (tid == 0) { rp.ring[cb * 17 + head] = last; rp.ring_meta[cb * 2] = head; rp.ring_meta[cb * 2 + 1] = drop ? 16 : len; }
         }
-        __syncthreads();
-        const bool pen = state->have_prev != 0;
-        for (int i = tid; i < n; i += SAMPLE_THREADS) lg[i] = pen ? logits[i] / mask[i] : logits[i];
+#pragma unroll
+        for (int j = 0; j < SAMPLE_MAXN / SAMPLE_THREADS; ++j) {
+            const int i = tid + j * SAMPLE_THREADS;
+            if (i < n) {
+                float m = mv[j];
+                if (pen) {
+                    const float m0 = m;
+                    if (i == last) m = c.rep_pen;
+                    if (i == dropped && m == c.rep_pen) m = 1.0f;
+                    if (m != m0) mask[i] = m;
+                }
+                lg[i] = pen ? lv[j] / m : lv[j];
+            }
+        }
         __syncthreads();
     }
     int code = 0;
@@ -1237,9 +1291,9 @@ static void dispatch_k(int K, F&& f) {
 template <typename WT>
 void LmKernels<WT>::qkv(const ModelDims& d, const float* x, const LayerW& w, const float* cos_t, const float* sin_t,
                         const SeqState* state, int pos_static, int rope_static, float* q_out, KVView kv, hipStream_t st) {
-    constexpr int WAVES = 4;  // two RoPE pairs per block
-    const int n_rows = (d.H + 2 * d.Hk) * d.Dh;
-    const int grid = (n_rows + WAVES - 1) / WAVES;
+    constexpr int WAVES = 2;  // one RoPE row pair per wave
+    const int n_pairs = (d.H + 2 * d.Hk) * d.Dh / 2;
+    const int grid = (n_pairs + WAVES - 1) / WAVES;
     dispatch_k(d.dim, [&](auto Kc) {
         constexpr int K = decltype(Kc)::value;
         if (w.cache_resident)

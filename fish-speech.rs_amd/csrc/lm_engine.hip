@@ -90,7 +90,9 @@ class LM final : public LMBase {
         FS_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
         d_.dim = a.dim; d_.inter = a.intermediate_size; d_.H = a.n_head; d_.Hk = a.n_local_heads; d_.Dh = a.head_dim;
         d_.n_rep = a.n_head / a.n_local_heads; d_.eps = a.norm_eps;
-        n_audio_ = a.vocab_size - (int)t.im_end_id;
+        legacy_ = !t.has_semantic_end;  // Fish <= 1.4: slow token is a 2-way {pad, im_end} draw (single_batch.rs:104-124)
+        n_audio_ = legacy_ ? 2 : a.vocab_size - (int)t.im_end_id;
+        if (legacy_) FS_REQUIRE(t.pad_id < (uint32_t)a.vocab_size, "pad_id outside the vocabulary");
         plan_tensors();
         alloc_runtime();
         for (auto& e : ev_) FS_HIP(hipEventCreate(&e));
@@ -124,6 +126,7 @@ class LM final : public LMBase {
         }
         FS_HIP(hipStreamSynchronize(st_));
         loaded_ = true;
+        refresh_legacy_head();
     }
 
     void load_safetensors(const std::string& path) override {
@@ -150,6 +153,7 @@ class LM final : public LMBase {
             FS_HIP(hipStreamSynchronize(st_));
         }
         loaded_ = true;
+        refresh_legacy_head();
     }
 
     // ------------------------------------------------------------------------------------------ teacher-forced API
@@ -229,10 +233,8 @@ class LM final : public LMBase {
         const int C = a_.num_codebooks, C1 = C + 1;
         FS_REQUIRE(L >= 1, "empty prompt");
         FS_REQUIRE(max_new_tokens >= 0, "negative max_new_tokens");
-        if (!t_.has_semantic_end)
-            throw Error("Fish <= 1.4 slow-token sampling uses an unseeded thread_rng in the reference (sampling/mod.rs:17); "
-                        "only the Fish 1.5 audio-range path is implemented");
-        FS_REQUIRE(t_.im_end_id + 1 == t_.semantic_start_id, "im_end_id must directly precede the semantic range (utils.rs:13)");
+        if (!legacy_)
+            FS_REQUIRE(t_.im_end_id + 1 == t_.semantic_start_id, "im_end_id must directly precede the semantic range (utils.rs:13)");
         validate_tokens(prompt, (size_t)C1 * L, 1, L);
         const int n_cached = seq_len_[0];
         if (n_cached + L > a_.max_seq_len) throw Error("prompt exceeds max_seq_len (dual_ar.rs:623-624)");
@@ -336,7 +338,7 @@ class LM final : public LMBase {
                         uint32_t flags, uint32_t* codes_out, size_t cap, size_t* n_frames) override {
         FS_REQUIRE(n >= 1, "Must have at least one prompt");  // static_batch.rs:69-71
         if (LmKernels<WT>::has_mfma_prefill() && n <= kRows && n <= B_ && a_.dim % 64 == 0 && a_.intermediate_size % 256 == 0 &&
-            a_.num_codebooks <= 8) {
+            a_.num_codebooks <= 8 && !legacy_) {
             generate_batch_rows(prompts, lens, n, max_new_tokens, s, seed, flags, codes_out, cap, n_frames);
             return;
         }
@@ -453,6 +455,7 @@ class LM final : public LMBase {
 
     void generate_batch_sequential(const uint32_t* prompts, const int* lens, int n, int max_new_tokens, const fs_sampling& s, uint64_t seed,
                                    uint32_t flags, uint32_t* codes_out, size_t cap, size_t* n_frames) {
+        if (legacy_) throw Error("generate_static_batch samples the slow token over the full vocabulary for Fish <= 1.4 (static_batch.rs:132-141); not implemented");
         const int C1 = a_.num_codebooks + 1;
         int Lmax = 0;
         for (int i = 0; i < n; ++i) { FS_REQUIRE(lens[i] >= 1, "empty prompt"); Lmax = std::max(Lmax, lens[i]); }
@@ -484,6 +487,8 @@ class LM final : public LMBase {
         c.im_end_id = t_.im_end_id;
         c.sem_lo = t_.semantic_start_id;
         c.sem_hi = t_.has_semantic_end ? t_.semantic_end_id : t_.semantic_start_id;  // dual_ar.rs:554-559
+        c.legacy = legacy_ ? 1 : 0;
+        c.pad_id = t_.pad_id;
         return c;
     }
 
@@ -614,6 +619,18 @@ class LM final : public LMBase {
         FS_HIP(hipHostMalloc(&h_pin_, 4096, hipHostMallocDefault));
     }
 
+    // rows of output.weight read by the generator's slow head: [im_end, V) for Fish 1.5 (utils.rs:13-16); the gathered
+    // {pad_id, im_end_id} pair for Fish <= 1.4
+    const void* slow_head_w() {
+        if (!legacy_) return (const uint8_t*)out_w_ + (size_t)t_.im_end_id * a_.dim * sizeof(WT);
+        if (!d_legacy_head_.p) d_legacy_head_.alloc(sizeof(WT) * 2 * a_.dim);
+        return d_legacy_head_.p;
+    }
+    void refresh_legacy_head() {
+        if (!legacy_) return;
+        launch_gather_rows<WT>(out_w_, a_.dim, t_.pad_id, t_.im_end_id, const_cast<void*>(slow_head_w()), st_);
+        FS_HIP(hipStreamSynchronize(st_));
+    }
     SeqState* state(int b) { return d_state_.as<SeqState>() + b; }
     float* x(int b) { return d_x_.as<float>() + (size_t)b * a_.dim; }
     float* xf(int b) { return d_xf_.as<float>() + (size_t)b * a_.dim; }
@@ -830,7 +847,7 @@ class LM final : public LMBase {
         FS_HIP(hipStreamBeginCapture(st_, hipStreamCaptureModeThreadLocal));
         enqueue_slow_layers(0);
         // audio-range head: rows [im_end, V) only (constrain_probs_to_audio, utils.rs:13-16)
-        LmKernels<WT>::head(d_, x(0), norm_w_, (const uint8_t*)out_w_ + (size_t)t_.im_end_id * a_.dim * sizeof(WT), n_audio_,
+        LmKernels<WT>::head(d_, x(0), norm_w_, slow_head_w(), n_audio_,
                             d_logits_slow_.as<float>(), st_);
         SampleKernels<WT>::sample_slow(d_, d_logits_slow_.as<float>(), n_audio_, d_cfg_.as<SampleCfg>(), d_rng_.as<RngState>(), state(0),
                                        x(0), xf(0), st_);
@@ -851,6 +868,8 @@ class LM final : public LMBase {
     int device_, B_;
     ModelDims d_;
     int n_audio_ = 0;
+    bool legacy_ = false;
+    DevBuf d_legacy_head_;
     hipStream_t st_ = nullptr;
     bool loaded_ = false;
     // weights

@@ -124,6 +124,10 @@ struct SampleCfg {  // device-resident (the captured graphs read it through a po
     int ignore_eos;
     uint32_t im_end_id;
     uint32_t sem_lo, sem_hi;  // embed mask range (inclusive); Fish<=1.4: lo == hi == semantic id
+    // Fish <= 1.4 slow token (single_batch.rs:104-124, sampling/mod.rs:8-26): 2-way softmax over {pad_id, im_end_id},
+    // temperature ignored; logits[0] = pad logit, logits[1] = im_end logit
+    int legacy;
+    uint32_t pad_id;
 };
 
 struct RepPenState {   // rep_pen.rs:4-72, one per codebook
@@ -157,6 +161,9 @@ struct SampleKernels {
                                  const void* cb_emb, float* X, uint32_t* out_codes, int out_cap, hipStream_t st);
 };
 
+// dst[0] = src[r0], dst[1] = src[r1] (rows of `dim` elements): the 2-row head of the Fish <= 1.4 slow-token sampler
+template <typename WT>
+void launch_gather_rows(const void* src, int dim, uint32_t r0, uint32_t r1, void* dst, hipStream_t st);
 void launch_advance(SeqState* state, hipStream_t st);  // pos++, step++ (sequential prefill step)
 void launch_advance_n(SeqState* state, int n, hipStream_t st);  // pos += n, step += n (chunked prefill)
 void launch_reppen_reset(RepPenState rp, int n_cb, int cb_size, hipStream_t st);

@@ -583,6 +583,14 @@ __global__ void k_fast_embed(const WT* __restrict__ fast_emb, int dim, const uin
     for (int d = threadIdx.x; d < dim; d += blockDim.x) out[(size_t)blockIdx.x * dim + d] = WTr<WT>::to_f32(fast_emb[(size_t)id * dim + d]);
 }
 
+template <typename WT>
+__global__ void k_gather_rows(const WT* __restrict__ src, int dim, uint32_t r0, uint32_t r1, WT* __restrict__ dst) {
+    for (int d = threadIdx.x; d < dim; d += blockDim.x) {
+        dst[d] = src[(size_t)r0 * dim + d];
+        dst[dim + d] = src[(size_t)r1 * dim + d];
+    }
+}
+
 __global__ void k_advance(SeqState* state) {
     state->pos += 1;
     state->step += 1;
@@ -1044,6 +1052,24 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_slow(const float* __r
     for (int i = tid; i < n; i += SAMPLE_THREADS) lg[i] = logits[i];
     for (int i = tid; i < dim; i += SAMPLE_THREADS) xf[i] = x[i];  // hidden_states -> fast decoder input (:149)
     __syncthreads();
+    if (c.legacy) {
+        // legacy_softmax_sample (sampling/mod.rs:8-26): P(pad) = softmax([pad, eos])[0]; u ~ U[0,1) = (next_u32 >> 8) * 2^-24
+        // (rand Standard<f32>).  The reference draws from an unseeded thread_rng; here the draw comes from the request's
+        // seeded StdRng stream so that runs are reproducible.
+        if (tid == 0) {
+            const float pad = lg[0], eos = lg[1], m = fmaxf(pad, eos);
+            const float e_pad = expf(pad - m), e_eos = expf(eos - m);
+            const float p_pad = e_pad / (e_pad + e_eos);
+            const uint32_t w = chacha12_word(rng->key, rng->consumed);
+            rng->consumed += 1;
+            const float u = (float)(w >> 8) * (1.0f / 16777216.0f);
+            uint32_t tok = (u < p_pad || c.ignore_eos) ? c.pad_id : c.im_end_id;
+            if (state->done) tok = c.im_end_id;
+            state->cur[0] = tok;
+            if (tok == c.im_end_id && state->done == 0) state->done = 1;
+        }
+        return;
+    }
     if (c.ignore_eos && tid == 0) lg[0] = -INFINITY;
     __syncthreads();
     const int idx = block_sample(lg, n, c, rng, sp, si, red);
@@ -1446,6 +1472,14 @@ void SampleKernels<WT>::sample_fast_rows(const ModelDims& d, const float* logits
                        (const WT*)fast_emb, XF, (const WT*)tok_emb, (const WT*)cb_emb, X, d.dim, out_codes, out_cap);
     FS_LAUNCH_CHECK();
 }
+
+template <typename WT>
+void launch_gather_rows(const void* src, int dim, uint32_t r0, uint32_t r1, void* dst, hipStream_t st) {
+    hipLaunchKernelGGL((k_gather_rows<WT>), dim3(1), dim3(256), 0, st, (const WT*)src, dim, r0, r1, (WT*)dst);
+    FS_LAUNCH_CHECK();
+}
+template void launch_gather_rows<bf16_t>(const void*, int, uint32_t, uint32_t, void*, hipStream_t);
+template void launch_gather_rows<float>(const void*, int, uint32_t, uint32_t, void*, hipStream_t);
 
 void launch_advance(SeqState* state, hipStream_t st) {
     hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, st, state);

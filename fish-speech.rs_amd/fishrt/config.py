@@ -29,3 +29,9 @@ def from_config_json(path):
         out["intermediate_size"] = out["dim"] * 4  # dual_ar.rs:129
     out["tie_word_embeddings"] = int(bool(c.get("tie_word_embeddings", False)))
     return out
+
+# Fish-Speech 1.4 (BASELINE configs[4] shapes): same backbone, 32k vocabulary, single <|semantic|> id, no semantic range
+# (TokenConfig: semantic_end_id = None, pad_id == semantic id; dual_ar.rs:34-46)
+FISH_1_4 = dict(FISH_1_5, vocab_size=32000, max_seq_len=8192)  # RoPE table 8192 for the 4096-frame long-form run
+FISH_1_4_TOKENS = dict(im_end_id=4, pad_id=5, semantic_start_id=5, semantic_end_id=0, has_semantic_end=0)
+TINY_1_4_TOKENS = dict(im_end_id=4, pad_id=5, semantic_start_id=5, semantic_end_id=0, has_semantic_end=0)

@@ -548,7 +548,15 @@ std::vector<uint32_t> LM::generate(const uint32_t* prompt, int L, int max_new_to
             if (margins) margins->push_back(top2_margin(sl.data(), sl.size()));
             semantic = lp.sample(sl.data(), sl.size()) + t.im_end_id;
         } else {
-            throw std::runtime_error("Fish<=1.4 legacy slow sampler uses an unseeded thread_rng (sampling/mod.rs:17); not restated");
+            // Fish <= 1.4 (single_batch.rs:104-124): legacy_softmax_sample over {pad_id, im_end_id}, temperature ignored
+            // (sampling/mod.rs:8-26).  The reference draws `rng.gen::<f32>()` from an unseeded thread_rng; the restatement
+            // draws the same Standard<f32> ((next_u32 >> 8) * 2^-24) from the request's seeded StdRng instead.
+            const float pad = logits[t.pad_id], eos = logits[t.im_end_id], m = std::max(pad, eos);
+            const float e_pad = std::exp(pad - m), e_eos = std::exp(eos - m);
+            const float p_pad = e_pad / (e_pad + e_eos);
+            const float u = (float)(lp.rng->next_u32() >> 8) * (1.0f / 16777216.0f);
+            semantic = (u < p_pad || ignore_eos) ? t.pad_id : t.im_end_id;
+            if (margins) margins->push_back(std::fabs(u - p_pad));
         }
         std::vector<uint32_t> cb = {semantic};
         clear_fast();  // :146

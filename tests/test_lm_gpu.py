@@ -246,3 +246,34 @@ def test_static_batch_mfma_rows_vs_oracle(sampling):
         n = min(g.shape[1], e.shape[1], 8)
         assert np.array_equal(g[:, :n], e[:, :n])
     assert lm.last_stats()["frames"] == sum(g.shape[1] for g in got)
+
+
+def test_fish14_legacy_slow_sampler_vs_oracle():
+    """Fish <= 1.4 (single_batch.rs:104-124, sampling/mod.rs:8-26): the slow token is a 2-way {pad, <|im_end|>} draw that
+    ignores the temperature; codebook embeddings are added only where the slow token == <|semantic|> (dual_ar.rs:558).
+    Device and oracle draw the uniform from the same seeded StdRng stream, so token streams (incl. where EOS falls) agree."""
+    tok14 = fcfg.TINY_1_4_TOKENS
+    lm = fishrt.DualARTransformer(fcfg.TINY, tok14, 0, "f32").load_synthetic(SEED)
+    o = orc.OracleLM(orc.TINY | tok14).load_synthetic(SEED)
+    rng = np.random.RandomState(2)
+    p = np.zeros((9, 9), np.uint32)
+    p[0] = rng.randint(6, 400, 9)
+    p[0, 3:6] = 5                                # a VQ span: slow token == <|semantic|>
+    p[1:, 3:6] = rng.randint(0, 64, (8, 3))
+    lg, hg = lm.forward_generate(p, 0)
+    lo, ho = o.forward_generate(p, 0)
+    np.testing.assert_allclose(hg, ho, **TOL32)
+    n_eos = 0
+    for seed in range(6):
+        for kw in (dict(temp=0.0, top_p=1.0, top_k=0), dict(temp=0.8, top_p=0.9, top_k=16)):
+            lm.clear_slow_layer_caches(); o.clear_slow()
+            got = lm.generate_blocking(p, 60, repetition_penalty=1.2, seed=seed, **kw)
+            exp = o.generate(p, 60, repetition_penalty=1.2, seed=seed, **kw)
+            assert np.array_equal(got, exp), (seed, kw)
+            assert lm.curr_kv_size() == o.kv_len()
+            n_eos += exp.shape[1] < 60 - 9 + 2
+    assert n_eos > 0, "the fixture never hit <|im_end|>: EOS path untested"
+    lm.clear_slow_layer_caches(); o.clear_slow()
+    got = lm.generate_blocking(p, 40, temp=0.0, top_p=1.0, top_k=0, repetition_penalty=1.0, seed=3, ignore_eos=True)
+    assert got.shape == (8, 40 - 9 + 2)
+    assert np.array_equal(got, o.generate(p, 40, temp=0.0, repetition_penalty=1.0, seed=3, ignore_eos=True))

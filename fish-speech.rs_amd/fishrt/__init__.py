@@ -4,5 +4,6 @@ from . import config
 from ._ffi import LIB_PATH, SYMBOLS, lib
 from .codec import FireflyCodec
 from .lm import LM, DualARTransformer
+from .stream import StreamingSynth, decode_chunk
 
-__all__ = ["config", "lib", "LIB_PATH", "SYMBOLS", "DualARTransformer", "LM", "FireflyCodec"]
+__all__ = ["config", "lib", "LIB_PATH", "SYMBOLS", "DualARTransformer", "LM", "FireflyCodec", "StreamingSynth", "decode_chunk"]

@@ -88,3 +88,33 @@ def test_fullsize_causality_property(full):
     for T1 in (1, 37, 200):
         part = full.decode(np.ascontiguousarray(voice[None, :, :T1]))[0, 0]
         assert np.array_equal(part, pcm[: 2048 * T1]), T1
+
+
+def test_chunked_streaming_decode_is_bit_identical(full):
+    """Streaming vocoder (BASELINE configs[4]): chunks of 64 frames with a 24-frame left halo reproduce the one-shot PCM
+    bit for bit (causal convs, receptive field ~14.5 frames: fishrt/stream.py)."""
+    from fishrt import decode_chunk
+    voice = np.ascontiguousarray(np.load(os.path.join(G, "default_voice_codes.npy")).astype(np.uint32))
+    ref = full.decode(voice[None])[0, 0]
+    parts = [decode_chunk(full, voice, a, min(a + 64, 274)) for a in range(0, 274, 64)]
+    assert np.array_equal(np.concatenate(parts), ref)
+    # a halo shorter than the receptive field is NOT exact (the bound is real)
+    short = decode_chunk(full, voice, 128, 192, halo=4)
+    assert not np.array_equal(short, ref[2048 * 128: 2048 * 192])
+
+
+def test_overlapped_lm_vocoder_pipeline(tiny):
+    """LM generation with the vocoder consuming 16-frame chunks in a worker thread == generate then decode."""
+    from fishrt import StreamingSynth, config as fcfg
+    lm = fishrt.DualARTransformer(fcfg.TINY, fcfg.TINY_TOKENS, 0, "f32").load_synthetic(7)
+    p = np.zeros((9, 6), np.uint32)
+    p[0] = [1, 2, 3, 4, 5, 6]
+    synth = StreamingSynth(lm, tiny, chunk=16)
+    codes, pcm = synth(p, 80, temp=0.0, top_p=1.0, top_k=0, repetition_penalty=1.2, ignore_eos=True)
+    codes = np.minimum(codes, 999)  # tiny LM codebook (64) is already < 1000
+    lm.clear_slow_layer_caches()
+    ref_codes = lm.generate_blocking(p, 80, temp=0.0, top_p=1.0, top_k=0, repetition_penalty=1.2, ignore_eos=True)
+    assert np.array_equal(codes, ref_codes) and codes.shape == (8, 76)
+    ref_pcm = tiny.decode(np.ascontiguousarray(ref_codes[None]))[0, 0]
+    assert pcm.shape == ref_pcm.shape and np.array_equal(pcm, ref_pcm)
+    assert synth.stats["frames"] == 76

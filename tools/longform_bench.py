@@ -1,0 +1,32 @@
+"""BASELINE.json configs[4] (bf16 variant): Fish-1.4 shapes (V = 32000, single <|semantic|> id, legacy 2-way slow sampler),
+one stream of 4096 frames (KV grows to 4096 + L; RoPE table 8192 -- the reference would fail past its max_seq_len 4096,
+dual_ar.rs:179,623), Firefly vocoder on a second stream consuming 64-frame chunks (+24-frame halo) while the LM continues.
+Reports LM-only RTF, end-to-end RTF and overlap efficiency.  (The fp8-weight variant of configs[4] is not implemented yet.)"""
+import sys, time
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/fish-speech.rs_amd")
+import numpy as np, fishrt
+from fishrt import config as fcfg
+frames = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+lm = fishrt.DualARTransformer(fcfg.FISH_1_4, fcfg.FISH_1_4_TOKENS, 0, "bf16").load_synthetic(0xF15E5EED)
+codec = fishrt.FireflyCodec(0).load_synthetic(0xC0DEC)
+rng = np.random.RandomState(4)
+L = 64
+p = np.zeros((9, L), np.uint32); p[0] = rng.randint(6, 32000, L)
+kw = dict(temp=0.7, top_p=0.8, top_k=256, repetition_penalty=1.2, seed=1, ignore_eos=True)
+M = frames + L - 2
+# fast codes may exceed the FSQ range (codebook 1024 vs 1000 FSQ entries) with random weights: clamp for the vocoder
+class Clamp:
+    def __init__(s, c): s.c = c
+    def decode(s, codes): return s.c.decode(np.minimum(codes, 999))
+for rep in range(2):
+    lm.clear_slow_layer_caches()
+    t = time.perf_counter(); codes = lm.generate_blocking(p, M, **kw); t_lm = time.perf_counter() - t
+    t = time.perf_counter(); pcm = Clamp(codec).decode(np.ascontiguousarray(codes[None])); t_voc = time.perf_counter() - t
+    lm.clear_slow_layer_caches()
+    synth = fishrt.StreamingSynth(lm, Clamp(codec), chunk=64)
+    c2, pcm2 = synth(p, M, **kw)
+    st = synth.stats
+    audio_s = frames / 21.535
+    print(f"frames={codes.shape[1]}: LM alone {t_lm:.3f}s (RTF {audio_s/t_lm:.1f}), vocoder alone (one shot) {t_voc:.3f}s, sequential {t_lm+t_voc:.3f}s | "
+          f"overlapped total {st['total_s']:.3f}s (RTF {audio_s/st['total_s']:.1f}), vocoder busy {st['vocoder_busy_s']:.3f}s, "
+          f"overlap efficiency {st['overlap_efficiency']:.2f}, same codes {np.array_equal(codes, c2)}, pcm identical {np.array_equal(pcm[0,0], pcm2)}")

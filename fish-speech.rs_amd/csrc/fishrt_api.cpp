@@ -29,6 +29,12 @@ int fs_device_count(void) {
     return n;
 }
 
+int fs_fp8_quantize_rows(int device_id, const float* w, int64_t rows, int64_t cols, uint8_t* q_out, float* scales_out) {
+    FS_ARG(w && q_out && scales_out, "null argument");
+    FS_TRY(fs::fp8_quantize_rows(device_id, w, rows, cols, q_out, scales_out))
+}
+int fs_fp8_decode_table(int device_id, float* out) { FS_ARG(out, "null argument"); FS_TRY(fs::fp8_decode_table(device_id, out)) }
+
 int fs_lm_create(const fs_model_args* args, const fs_token_cfg* tok, int device_id, fs_dtype dtype, int max_batch, fs_lm_t** out) {
     FS_ARG(args && tok && out, "null argument");
     FS_TRY({ *out = nullptr; fs::LMBase* p = fs::make_lm(*args, *tok, device_id, dtype, max_batch); *out = new fs_lm{p}; })

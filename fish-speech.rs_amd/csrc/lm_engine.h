@@ -31,6 +31,10 @@ class LMBase {
     virtual void* stream() = 0;
 };
 
+// FS_FP8 storage format helpers (run on the device; used by offline quantisation tools and the parity tests)
+void fp8_quantize_rows(int device, const float* w, int64_t rows, int64_t cols, uint8_t* q_out, float* scales_out);
+void fp8_decode_table(int device, float* out /*16 * 256*/);
+
 LMBase* make_lm(const fs_model_args& a, const fs_token_cfg& t, int device, fs_dtype dtype, int max_batch);
 
 }  // namespace fs

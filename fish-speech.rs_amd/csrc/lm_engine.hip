@@ -48,7 +48,9 @@ struct TensorDesc {
     std::string name;      // reference tensor name (dual_ar.rs loader)
     int64_t rows, cols;
     bool is_vec;           // f32 norm vector (device f32) vs WT matrix
+    bool is_emb;           // embedding table: stored in KVT<WT> (bf16 when the matrices are fp8)
     size_t offset;         // byte offset in the arena (destination base of the possibly interleaved slab)
+    size_t scale_off;      // fp8 matrices: byte offset of the per-row f32 scale slab (same row mapping)
     int row_mul, row_off;  // destination row = r * row_mul + row_off
     float mean;
     double stdv;
@@ -71,6 +73,9 @@ constexpr int kRows = 32;  // activation rows per MFMA pass (lm_kernels.hip PF_M
 
 template <typename WT>
 class LM final : public LMBase {
+    using KT = KVT<WT>;  // KV cache / embedding storage type
+    static constexpr bool kFp8 = std::is_same<WT, fp8_t>::value;
+
   public:
     LM(const fs_model_args& a, const fs_token_cfg& t, int device, int max_batch) : a_(a), t_(t), device_(device), B_(max_batch) {
         FS_REQUIRE(max_batch >= 1, "max_batch must be >= 1");
@@ -113,16 +118,21 @@ class LM final : public LMBase {
     // ------------------------------------------------------------------------------------------ weights
     void load_synthetic(uint64_t seed) override {
         use_device();
-        const int round_bf16 = std::is_same<WT, bf16_t>::value ? 1 : 0;
+        // a bf16 (or fp8) checkpoint holds bf16-rounded vectors / embeddings; fp8 matrices are quantised from the raw values
+        const int round_bf16 = std::is_same<WT, float>::value ? 0 : 1;
+        uint8_t* base = arena_.as<uint8_t>();
         for (const auto& td : tensors_) {
             const uint64_t key = synth_fnv1a64(td.name.c_str()) ^ seed;
             const float sc = synth_scale(td.stdv);
             if (td.is_vec)
-                launch_synth_fill<float>((float*)(arena_.as<uint8_t>() + td.offset), key, td.rows, td.cols, 1, 0, td.mean, sc,
-                                         round_bf16, st_);
+                launch_synth_fill<float>((float*)(base + td.offset), key, td.rows, td.cols, 1, 0, td.mean, sc, round_bf16, st_);
+            else if (td.is_emb)
+                launch_synth_fill<KT>((KT*)(base + td.offset), key, td.rows, td.cols, td.row_mul, td.row_off, td.mean, sc, round_bf16, st_);
+            else if constexpr (kFp8)
+                launch_synth_quant_fp8(base + td.offset, (float*)(base + td.scale_off), key, td.rows, td.cols, td.row_mul, td.row_off,
+                                       td.mean, sc, st_);
             else
-                launch_synth_fill<WT>((WT*)(arena_.as<uint8_t>() + td.offset), key, td.rows, td.cols, td.row_mul, td.row_off,
-                                      td.mean, sc, round_bf16, st_);
+                launch_synth_fill<WT>((WT*)(base + td.offset), key, td.rows, td.cols, td.row_mul, td.row_off, td.mean, sc, round_bf16, st_);
         }
         FS_HIP(hipStreamSynchronize(st_));
         loaded_ = true;
@@ -145,11 +155,16 @@ class LM final : public LMBase {
             SafeTensors::to_f32(*t, host.data());
             if (stage.n < host.size() * 4) stage.alloc(host.size() * 4);
             FS_HIP(hipMemcpyAsync(stage.p, host.data(), host.size() * 4, hipMemcpyHostToDevice, st_));
+            uint8_t* base = arena_.as<uint8_t>();
             if (td.is_vec)
-                launch_convert_rows<float>((float*)(arena_.as<uint8_t>() + td.offset), stage.as<float>(), td.rows, td.cols, 1, 0, st_);
+                launch_convert_rows<float>((float*)(base + td.offset), stage.as<float>(), td.rows, td.cols, 1, 0, st_);
+            else if (td.is_emb)
+                launch_convert_rows<KT>((KT*)(base + td.offset), stage.as<float>(), td.rows, td.cols, td.row_mul, td.row_off, st_);
+            else if constexpr (kFp8)
+                launch_quant_rows_fp8(base + td.offset, (float*)(base + td.scale_off), stage.as<float>(), td.rows, td.cols, td.row_mul,
+                                      td.row_off, st_);
             else
-                launch_convert_rows<WT>((WT*)(arena_.as<uint8_t>() + td.offset), stage.as<float>(), td.rows, td.cols, td.row_mul,
-                                        td.row_off, st_);
+                launch_convert_rows<WT>((WT*)(base + td.offset), stage.as<float>(), td.rows, td.cols, td.row_mul, td.row_off, st_);
             FS_HIP(hipStreamSynchronize(st_));
         }
         loaded_ = true;
@@ -177,7 +192,7 @@ class LM final : public LMBase {
             seq_len_[b] += L;
             if (hidden) FS_HIP(hipMemcpyAsync(hidden + (size_t)b * a_.dim, x(b), sizeof(float) * a_.dim, hipMemcpyDeviceToHost, st_));
             if (logits) {
-                LmKernels<WT>::head(d_, x(b), norm_w_, out_w_, a_.vocab_size, d_logits_slow_.as<float>(), st_);
+                LmKernels<WT>::head(d_, x(b), norm_w_, out_w_, out_s_, a_.vocab_size, d_logits_slow_.as<float>(), st_);
                 FS_HIP(hipMemcpyAsync(logits + (size_t)b * a_.vocab_size, d_logits_slow_.p, sizeof(float) * a_.vocab_size,
                                       hipMemcpyDeviceToHost, st_));
             }
@@ -194,7 +209,7 @@ class LM final : public LMBase {
             FS_REQUIRE(fast_len_[b] < 8, "fast decoder KV holds at most 8 positions per frame (num_codebooks)");
             FS_HIP(hipMemcpyAsync(xf(b), xin + (size_t)b * a_.dim, sizeof(float) * a_.dim, hipMemcpyHostToDevice, st_));
             enqueue_fast_layers(b, fast_len_[b], input_pos);
-            LmKernels<WT>::head(d_, xf(b), fast_norm_w_, fast_out_w_, a_.codebook_size, d_logits_fast_.as<float>(), st_);
+            LmKernels<WT>::head(d_, xf(b), fast_norm_w_, fast_out_w_, fast_out_s_, a_.codebook_size, d_logits_fast_.as<float>(), st_);
             FS_HIP(hipMemcpyAsync(logits + (size_t)b * a_.codebook_size, d_logits_fast_.p, sizeof(float) * a_.codebook_size,
                                   hipMemcpyDeviceToHost, st_));
             FS_HIP(hipStreamSynchronize(st_));
@@ -507,41 +522,56 @@ class LM final : public LMBase {
     void plan_tensors() {
         size_t off = 0;
         auto align = [&](size_t v) { return (v + 255) & ~(size_t)255; };
-        auto mat = [&](const std::string& name, int64_t rows, int64_t cols, int mul, int roff, size_t at) {
-            tensors_.push_back({name, rows, cols, false, at, mul, roff, 0.f, 0.02});  // initializer_range (dual_ar.rs:93)
+        auto mat = [&](const std::string& name, int64_t rows, int64_t cols, int mul, int roff, std::pair<size_t, size_t> at) {
+            tensors_.push_back({name, rows, cols, false, false, at.first, at.second, mul, roff, 0.f, 0.02});  // initializer_range (dual_ar.rs:93)
         };
-        auto slab = [&](int64_t rows, int64_t cols) { size_t at = off; off = align(off + (size_t)rows * cols * sizeof(WT)); return at; };
+        auto emb = [&](const std::string& name, int64_t rows, int64_t cols) {
+            size_t at = off;
+            off = align(off + (size_t)rows * cols * sizeof(KT));
+            tensors_.push_back({name, rows, cols, false, true, at, 0, 1, 0, 0.f, 0.02});
+            return at;
+        };
+        // matrix slab (+ per-row f32 scale slab for fp8 weights): {weights offset, scales offset}
+        auto slab = [&](int64_t rows, int64_t cols) {
+            std::pair<size_t, size_t> at{off, 0};
+            off = align(off + (size_t)rows * cols * sizeof(WT));
+            if (kFp8) { at.second = off; off = align(off + (size_t)rows * sizeof(float)); }
+            return at;
+        };
         auto vec = [&](const std::string& name, int64_t n) {
             size_t at = off;
             off = align(off + (size_t)n * sizeof(float));
-            tensors_.push_back({name, 1, n, true, at, 1, 0, 1.0f, 0.1});
+            tensors_.push_back({name, 1, n, true, false, at, 0, 1, 0, 1.0f, 0.1});
             return at;
         };
         const int64_t D = a_.dim, I = a_.intermediate_size, V = a_.vocab_size;
         const int64_t QKV = (int64_t)(a_.n_head + 2 * a_.n_local_heads) * a_.head_dim;
-        o_tok_emb_ = slab(V, D); mat("embeddings.weight", V, D, 1, 0, o_tok_emb_);
-        o_cb_emb_ = slab((int64_t)a_.codebook_size * a_.num_codebooks, D);
-        mat("codebook_embeddings.weight", (int64_t)a_.codebook_size * a_.num_codebooks, D, 1, 0, o_cb_emb_);
-        auto blocks = [&](int n, const std::string& pre, std::vector<std::array<size_t, 6>>& offs) {
+        o_tok_emb_ = emb("embeddings.weight", V, D);
+        o_cb_emb_ = emb("codebook_embeddings.weight", (int64_t)a_.codebook_size * a_.num_codebooks, D);
+        auto blocks = [&](int n, const std::string& pre, std::vector<std::array<size_t, 10>>& offs) {
             for (int l = 0; l < n; ++l) {
                 const std::string p = pre + std::to_string(l) + ".";
-                std::array<size_t, 6> o;
-                o[0] = slab(QKV, D); mat(p + "attention.wqkv.weight", QKV, D, 1, 0, o[0]);
-                o[1] = slab(D, D); mat(p + "attention.wo.weight", D, D, 1, 0, o[1]);
-                o[2] = slab(2 * I, D);
-                mat(p + "feed_forward.w1.weight", I, D, 2, 0, o[2]);
-                mat(p + "feed_forward.w3.weight", I, D, 2, 1, o[2]);
-                o[3] = slab(D, I); mat(p + "feed_forward.w2.weight", D, I, 1, 0, o[3]);
+                std::array<size_t, 10> o;
+                auto s0 = slab(QKV, D); mat(p + "attention.wqkv.weight", QKV, D, 1, 0, s0);
+                auto s1 = slab(D, D); mat(p + "attention.wo.weight", D, D, 1, 0, s1);
+                auto s2 = slab(2 * I, D);
+                mat(p + "feed_forward.w1.weight", I, D, 2, 0, s2);
+                mat(p + "feed_forward.w3.weight", I, D, 2, 1, s2);
+                auto s3 = slab(D, I); mat(p + "feed_forward.w2.weight", D, I, 1, 0, s3);
+                o[0] = s0.first; o[1] = s1.first; o[2] = s2.first; o[3] = s3.first;
                 o[4] = vec(p + "ffn_norm.weight", D);
                 o[5] = vec(p + "attention_norm.weight", D);
+                o[6] = s0.second; o[7] = s1.second; o[8] = s2.second; o[9] = s3.second;
                 offs.push_back(o);
             }
         };
         blocks(a_.n_layer, "layers.", o_slow_);
         o_norm_ = vec("norm.weight", D);
-        if (a_.tie_word_embeddings) o_out_ = o_tok_emb_;
-        else { o_out_ = slab(V, D); mat("output.weight", V, D, 1, 0, o_out_); }
-        o_fast_emb_ = slab(a_.codebook_size, D); mat("fast_embeddings.weight", a_.codebook_size, D, 1, 0, o_fast_emb_);
+        // tied head (dual_ar.rs:482-486): the embedding table itself, except with fp8 matrices, where the head is the fp8
+        // quantisation of the same checkpoint tensor (the table stays bf16 for the lookups)
+        if (a_.tie_word_embeddings && !kFp8) o_out_ = {o_tok_emb_, 0};
+        else { o_out_ = slab(V, D); mat(a_.tie_word_embeddings ? "embeddings.weight" : "output.weight", V, D, 1, 0, o_out_); }
+        o_fast_emb_ = emb("fast_embeddings.weight", a_.codebook_size, D);
         blocks(a_.n_fast_layer, "fast_layers.", o_fast_);
         o_fast_norm_ = vec("fast_norm.weight", D);
         o_fast_out_ = slab(a_.codebook_size, D); mat("fast_output.weight", a_.codebook_size, D, 1, 0, o_fast_out_);
@@ -551,16 +581,21 @@ class LM final : public LMBase {
     void alloc_runtime() {
         arena_.alloc(arena_bytes_);
         uint8_t* base = arena_.as<uint8_t>();
-        auto lw = [&](const std::array<size_t, 6>& o) {
+        auto lw = [&](const std::array<size_t, 10>& o) {
             LayerW w;
             w.wqkv = base + o[0]; w.wo = base + o[1]; w.w13 = base + o[2]; w.w2 = base + o[3];
             w.ffn_norm = (const float*)(base + o[4]); w.attn_norm = (const float*)(base + o[5]);
+            if (kFp8) {
+                w.s_qkv = (const float*)(base + o[6]); w.s_o = (const float*)(base + o[7]);
+                w.s_13 = (const float*)(base + o[8]); w.s_2 = (const float*)(base + o[9]);
+            }
             return w;
         };
         for (auto& o : o_slow_) slow_.push_back(lw(o));
         for (auto& o : o_fast_) { fast_.push_back(lw(o)); fast_.back().cache_resident = getenv("FISHRT_FAST_NT") == nullptr; }
         tok_emb_ = base + o_tok_emb_; cb_emb_ = base + o_cb_emb_; fast_emb_ = base + o_fast_emb_;
-        out_w_ = base + o_out_; fast_out_w_ = base + o_fast_out_;
+        out_w_ = base + o_out_.first; fast_out_w_ = base + o_fast_out_.first;
+        if (kFp8) { out_s_ = (const float*)(base + o_out_.second); fast_out_s_ = (const float*)(base + o_fast_out_.second); }
         norm_w_ = (const float*)(base + o_norm_); fast_norm_w_ = (const float*)(base + o_fast_norm_);
         // RoPE tables on the host exactly as precompute_freqs_cis (dual_ar.rs:168-186): f32 powf / cos / sin
         const int half = a_.head_dim / 2, n_elem = a_.dim / a_.n_head;
@@ -579,7 +614,7 @@ class LM final : public LMBase {
         max_pages_ = (a_.max_seq_len + KV_PAGE - 1) / KV_PAGE;
         n_pages_ = max_pages_ * B_;
         page_elems_ = (size_t)a_.n_local_heads * KV_PAGE * a_.head_dim;
-        kv_pool_.alloc((size_t)a_.n_layer * 2 * n_pages_ * page_elems_ * sizeof(WT));
+        kv_pool_.alloc((size_t)a_.n_layer * 2 * n_pages_ * page_elems_ * sizeof(KT));
         d_page_table_.alloc(sizeof(int) * (size_t)B_ * max_pages_);
         FS_HIP(hipMemset(d_page_table_.p, 0, d_page_table_.n));
         for (int p = n_pages_ - 1; p >= 0; --p) free_pages_.push_back(p);
@@ -587,7 +622,7 @@ class LM final : public LMBase {
         seq_len_.assign(B_, 0);
         fast_len_.assign(B_, 0);
         // fast-decoder KV: one page per (layer, sequence); its page table is a single zero
-        fast_pool_.alloc((size_t)std::max(1, a_.n_fast_layer) * 2 * B_ * page_elems_ * sizeof(WT));
+        fast_pool_.alloc((size_t)std::max(1, a_.n_fast_layer) * 2 * B_ * page_elems_ * sizeof(KT));
         d_zero_table_.alloc(sizeof(int) * 4);
         FS_HIP(hipMemset(d_zero_table_.p, 0, d_zero_table_.n));
         // activations / state
@@ -623,12 +658,20 @@ class LM final : public LMBase {
     // {pad_id, im_end_id} pair for Fish <= 1.4
     const void* slow_head_w() {
         if (!legacy_) return (const uint8_t*)out_w_ + (size_t)t_.im_end_id * a_.dim * sizeof(WT);
-        if (!d_legacy_head_.p) d_legacy_head_.alloc(sizeof(WT) * 2 * a_.dim);
+        if (!d_legacy_head_.p) d_legacy_head_.alloc(sizeof(WT) * 2 * a_.dim + 256);
         return d_legacy_head_.p;
+    }
+    // per-row scales of the same rows (fp8 weights only)
+    const float* slow_head_s() {
+        if (!kFp8) return nullptr;
+        if (!legacy_) return out_s_ + t_.im_end_id;
+        slow_head_w();
+        return (const float*)(d_legacy_head_.as<uint8_t>() + (((sizeof(WT) * 2 * a_.dim) + 15) & ~(size_t)15));
     }
     void refresh_legacy_head() {
         if (!legacy_) return;
         launch_gather_rows<WT>(out_w_, a_.dim, t_.pad_id, t_.im_end_id, const_cast<void*>(slow_head_w()), st_);
+        if (kFp8) launch_gather_rows<float>(out_s_, 1, t_.pad_id, t_.im_end_id, const_cast<float*>(slow_head_s()), st_);
         FS_HIP(hipStreamSynchronize(st_));
     }
     SeqState* state(int b) { return d_state_.as<SeqState>() + b; }
@@ -636,14 +679,14 @@ class LM final : public LMBase {
     float* xf(int b) { return d_xf_.as<float>() + (size_t)b * a_.dim; }
     KVView slow_kv(int layer, int b) {
         KVView v;
-        WT* base = kv_pool_.as<WT>() + (size_t)layer * 2 * n_pages_ * page_elems_;
+        KT* base = kv_pool_.as<KT>() + (size_t)layer * 2 * n_pages_ * page_elems_;
         v.k = base; v.v = base + (size_t)n_pages_ * page_elems_;
         v.page_table = d_page_table_.as<int>() + (size_t)b * max_pages_;
         return v;
     }
     KVView fast_kv(int layer, int b) {
         KVView v;
-        WT* base = fast_pool_.as<WT>() + ((size_t)layer * 2 * B_) * page_elems_;
+        KT* base = fast_pool_.as<KT>() + ((size_t)layer * 2 * B_) * page_elems_;
         v.k = base + (size_t)b * page_elems_;
         v.v = base + ((size_t)B_ + b) * page_elems_;
         v.page_table = d_zero_table_.as<int>();
@@ -748,7 +791,7 @@ class LM final : public LMBase {
             cf.nc_launch = 1;
             for (int l = 0; l < a_.n_fast_layer; ++l) {
                 KVView kv;
-                WT* base = fast_pool_.as<WT>() + ((size_t)l * 2 * B_) * page_elems_;
+                KT* base = fast_pool_.as<KT>() + ((size_t)l * 2 * B_) * page_elems_;
                 kv.k = base; kv.v = base + (size_t)B_ * page_elems_; kv.page_table = d_fast_table_.as<int>();
                 LmKernels<WT>::rows_layer(d_, B, cf, fast_[l], kv, l == 0, st_);
             }
@@ -847,13 +890,12 @@ class LM final : public LMBase {
         FS_HIP(hipStreamBeginCapture(st_, hipStreamCaptureModeThreadLocal));
         enqueue_slow_layers(0);
         // audio-range head: rows [im_end, V) only (constrain_probs_to_audio, utils.rs:13-16)
-        LmKernels<WT>::head(d_, x(0), norm_w_, slow_head_w(), n_audio_,
-                            d_logits_slow_.as<float>(), st_);
+        LmKernels<WT>::head(d_, x(0), norm_w_, slow_head_w(), slow_head_s(), n_audio_, d_logits_slow_.as<float>(), st_);
         SampleKernels<WT>::sample_slow(d_, d_logits_slow_.as<float>(), n_audio_, d_cfg_.as<SampleCfg>(), d_rng_.as<RngState>(), state(0),
                                        x(0), xf(0), st_);
         for (int cbi = 0; cbi < C; ++cbi) {
             enqueue_fast_layers(0, cbi, cbi);
-            LmKernels<WT>::head(d_, xf(0), fast_norm_w_, fast_out_w_, a_.codebook_size, d_logits_fast_.as<float>(), st_);
+            LmKernels<WT>::head(d_, xf(0), fast_norm_w_, fast_out_w_, fast_out_s_, a_.codebook_size, d_logits_fast_.as<float>(), st_);
             SampleKernels<WT>::sample_fast(d_, d_logits_fast_.as<float>(), cbi, C, a_.codebook_size, d_cfg_.as<SampleCfg>(),
                                            d_rng_.as<RngState>(), rp_, state(0), fast_emb_, xf(0), tok_emb_, cb_emb_, x(0),
                                            d_out_.as<uint32_t>(), out_cap_, st_);
@@ -874,12 +916,13 @@ class LM final : public LMBase {
     bool loaded_ = false;
     // weights
     std::vector<TensorDesc> tensors_;
-    size_t arena_bytes_ = 0, o_tok_emb_ = 0, o_cb_emb_ = 0, o_out_ = 0, o_fast_emb_ = 0, o_fast_out_ = 0, o_norm_ = 0, o_fast_norm_ = 0;
-    std::vector<std::array<size_t, 6>> o_slow_, o_fast_;
+    size_t arena_bytes_ = 0, o_tok_emb_ = 0, o_cb_emb_ = 0, o_fast_emb_ = 0, o_norm_ = 0, o_fast_norm_ = 0;
+    std::pair<size_t, size_t> o_out_ = {0, 0}, o_fast_out_ = {0, 0};
+    std::vector<std::array<size_t, 10>> o_slow_, o_fast_;
     DevBuf arena_;
     std::vector<LayerW> slow_, fast_;
     const void *tok_emb_ = nullptr, *cb_emb_ = nullptr, *fast_emb_ = nullptr, *out_w_ = nullptr, *fast_out_w_ = nullptr;
-    const float *norm_w_ = nullptr, *fast_norm_w_ = nullptr;
+    const float *norm_w_ = nullptr, *fast_norm_w_ = nullptr, *out_s_ = nullptr, *fast_out_s_ = nullptr;
     DevBuf d_cos_, d_sin_;
     // KV
     int max_pages_ = 0, n_pages_ = 0, out_cap_ = 0, n_chunks_ = 0, nc_launch_ = 1;
@@ -903,9 +946,30 @@ class LM final : public LMBase {
     fs_gen_stats stats_ = {};
 };
 
+void fp8_quantize_rows(int device, const float* w, int64_t rows, int64_t cols, uint8_t* q_out, float* scales_out) {
+    FS_REQUIRE(rows >= 1 && cols >= 1 && rows < (1ll << 31), "bad matrix shape");
+    FS_HIP(hipSetDevice(device));
+    DevBuf src, q, sc;
+    src.alloc((size_t)rows * cols * 4); q.alloc((size_t)rows * cols); sc.alloc((size_t)rows * 4);
+    FS_HIP(hipMemcpy(src.p, w, (size_t)rows * cols * 4, hipMemcpyHostToDevice));
+    launch_quant_rows_fp8(q.as<uint8_t>(), sc.as<float>(), src.as<float>(), rows, cols, 1, 0, nullptr);
+    FS_HIP(hipDeviceSynchronize());
+    FS_HIP(hipMemcpy(q_out, q.p, (size_t)rows * cols, hipMemcpyDeviceToHost));
+    FS_HIP(hipMemcpy(scales_out, sc.p, (size_t)rows * 4, hipMemcpyDeviceToHost));
+}
+void fp8_decode_table(int device, float* out) {
+    FS_HIP(hipSetDevice(device));
+    DevBuf t;
+    t.alloc(16 * 256 * 4);
+    launch_fp8_decode_table(t.as<float>(), nullptr);
+    FS_HIP(hipDeviceSynchronize());
+    FS_HIP(hipMemcpy(out, t.p, 16 * 256 * 4, hipMemcpyDeviceToHost));
+}
+
 LMBase* make_lm(const fs_model_args& a, const fs_token_cfg& t, int device, fs_dtype dtype, int max_batch) {
     if (dtype == FS_BF16) return new LM<bf16_t>(a, t, device, max_batch);
     if (dtype == FS_F32) return new LM<float>(a, t, device, max_batch);
+    if (dtype == FS_FP8) return new LM<fp8_t>(a, t, device, max_batch);
     throw Error("unknown dtype");
 }
 

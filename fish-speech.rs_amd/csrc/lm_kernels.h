@@ -1,7 +1,8 @@
 // Launch interface of the dual-AR decode kernels (lm_kernels.hip).  gfx950 only.
 //
 // Data layout in HBM:
-//  * weights: row-major [out, in] in WT (bf16 or f32), one 256-B aligned slab per tensor; W1/W3 are stored
+//  * weights: row-major [out, in] in WT (bf16, f32, or OCP e4m3fn bytes + one f32 scale per row), one 256-B aligned slab
+//    per tensor; with fp8 weights the embedding tables and the KV cache stay bf16 (KVT<WT>); W1/W3 are stored
 //    row-interleaved (row 2r = w1[r], row 2r+1 = w3[r]) so one wave streams a contiguous 2-row block and applies
 //    SwiGLU in registers;
 //  * KV cache: paged.  One pool per layer; page = 64 tokens; K element (t, g, d) lives at
@@ -13,7 +14,14 @@
 
 #include <cstdint>
 
+#include "fs_common.h"
+
 namespace fs {
+
+// storage type of the KV cache and the embedding tables for a given weight type (fp8 weights keep bf16 KV / embeddings)
+template <typename WT> struct KVOf { using type = WT; };
+template <> struct KVOf<fp8_t> { using type = bf16_t; };
+template <typename WT> using KVT = typename KVOf<WT>::type;
 
 constexpr int KV_PAGE = 64;  // tokens per KV page
 
@@ -44,6 +52,11 @@ struct LayerW {
     const void* w2;    // [dim, inter]
     const float* attn_norm;
     const float* ffn_norm;
+    // fp8 (e4m3fn) weights only: one f32 dequantisation scale per output row of each matrix (null otherwise)
+    const float* s_qkv = nullptr;
+    const float* s_o = nullptr;
+    const float* s_13 = nullptr;  // interleaved like w13
+    const float* s_2 = nullptr;
     // false: weights are streamed once per frame -> non-temporal loads (slow transformer, 717 MB / frame);
     // true: re-read 8x per frame and small enough for the 256 MB Infinity Cache (fast decoder, 122 MB) -> default policy
     bool cache_resident = false;
@@ -92,9 +105,9 @@ struct LmKernels {
                    int fused_T, const LayerW& w, float* x, hipStream_t st);
     static void ffn_up(const ModelDims& d, const float* x, const LayerW& w, float* act, hipStream_t st);
     static void ffn_down(const ModelDims& d, const float* act, const LayerW& w, float* x, hipStream_t st);
-    // x -> rmsnorm(norm_w) -> rows [0, n_rows) of W -> logits f32
-    static void head(const ModelDims& d, const float* x, const float* norm_w, const void* W, int n_rows, float* logits,
-                     hipStream_t st);
+    // x -> rmsnorm(norm_w) -> rows [0, n_rows) of W (x wscale[row] for fp8 weights) -> logits f32
+    static void head(const ModelDims& d, const float* x, const float* norm_w, const void* W, const float* wscale, int n_rows,
+                     float* logits, hipStream_t st);
     // x = tok_emb[t0] + sum_c mask * cb_emb[c*cbsize + t_{c+1}]   (dual_ar.rs:532-567); tokens from prompt column
     // state->step (prompt != null) or from state->cur
     static void embed(const ModelDims& d, const void* tok_emb, const void* cb_emb, int n_cb, int cb_size,
@@ -176,5 +189,13 @@ void launch_synth_fill(WT* dst, uint64_t key, int64_t n_rows, int64_t n_cols, in
 template <typename WT>
 void launch_convert_rows(WT* dst, const float* src, int64_t n_rows, int64_t n_cols, int row_mul, int row_off,
                          hipStream_t st);
+// fp8 quantisers: per-row absmax scale (amax / 448, 1 for an all-zero row), e4m3fn RNE bytes; same row mapping for the
+// bytes and the scales.  synth: elements come from the generator (fs_synth.h); rows: from a staged f32 matrix.
+void launch_synth_quant_fp8(uint8_t* dst, float* scales, uint64_t key, int64_t n_rows, int64_t n_cols, int row_mul, int row_off,
+                            float mean, float scale, hipStream_t st);
+void launch_quant_rows_fp8(uint8_t* dst, float* scales, const float* src, int64_t n_rows, int64_t n_cols, int row_mul,
+                           int row_off, hipStream_t st);
+// out[slot * 256 + b] = f32 value the fp8 GEMV unpack path gives byte b at lane-slot `slot` (16 x 256 floats)
+void launch_fp8_decode_table(float* out, hipStream_t st);
 
 }  // namespace fs

@@ -53,6 +53,29 @@ struct WTr<float> {
     __device__ static __forceinline__ float from_f32(float f) { return f; }
 };
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <>
+struct WTr<fp8_t> {
+    static constexpr int EPL = 16;  // OCP e4m3fn weights: 16 per 16-byte lane load
+    using vec = u32x4;
+    __device__ static __forceinline__ void unpack(const u32x4& v, float* f) {
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8(w[i], false), hi = __builtin_amdgcn_cvt_pk_f32_fp8(w[i], true);
+            f[4 * i] = lo.x; f[4 * i + 1] = lo.y; f[4 * i + 2] = hi.x; f[4 * i + 3] = hi.y;
+        }
+    }
+    __device__ static __forceinline__ float to_f32(fp8_t h) { return e4m3_to_f32(h.v); }
+    __device__ static __forceinline__ fp8_t from_f32(float f) { return fp8_t{f32_to_e4m3(f)}; }
+};
+// per-row dequantisation scale (fp8 only; other weight types carry none)
+template <typename WT>
+__device__ __forceinline__ float row_scale(const float* __restrict__ ws, int row) {
+    if constexpr (std::is_same<WT, fp8_t>::value) return ws[row];
+    else return 1.0f;
+}
+
 template <typename V>
 __device__ __forceinline__ V ld_stream(const V* p) {  // streamed-once weights: non-temporal (guide: nt-weights)
     return __builtin_nontemporal_load(p);
@@ -159,8 +182,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_qkv(const float* __restrict__ x,
                                                     const WT* __restrict__ W, const float* __restrict__ cos_t,
                                                     const float* __restrict__ sin_t, const SeqState* __restrict__ state,
                                                     int pos_static, int rope_static, float* __restrict__ q_out, KVView kv,
-                                                    int H, int Hk, int Dh) {
+                                                    int H, int Hk, int Dh, const float* __restrict__ wscale) {
     using R = Row<WT, K, NT>;
+    using KT = KVT<WT>;
     const int lane = threadIdx.x & 63;
     const int pair = blockIdx.x * WAVES + (threadIdx.x >> 6);
     const int n_pairs = (H + 2 * Hk) * Dh / 2;
@@ -174,7 +198,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_qkv(const float* __restrict__ x,
     const int rpos = state ? pos + state->rope_off : rope_static;
     const int r0 = 2 * pair, qdim = H * Dh, kdim = Hk * Dh, half = Dh / 2;
     float c = 1.f, s = 0.f;
-    WT* dst = nullptr;
+    KT* dst = nullptr;
     if (r0 < qdim + kdim) {
         const int j = (r0 % Dh) / 2;
         c = cos_t[(size_t)rpos * half + j];
@@ -182,21 +206,22 @@ __global__ __launch_bounds__(WAVES * 64) void k_qkv(const float* __restrict__ x,
     }
     if (r0 >= qdim) {
         const int rk = (r0 - qdim) % kdim, g = rk / Dh, dd = rk % Dh;
-        dst = kv_addr<WT>(r0 < qdim + kdim ? kv.k : kv.v, kv.page_table, pos, g, Hk, Dh) + dd;
+        dst = kv_addr<KT>(r0 < qdim + kdim ? kv.k : kv.v, kv.page_table, pos, g, Hk, Dh) + dd;
     }
+    const float s0 = row_scale<WT>(wscale, r0), s1 = row_scale<WT>(wscale, r0 + 1);
     typename R::vec w0[R::NCH], w1[R::NCH];
     R::load_w(W + (size_t)r0 * K, lane, w0);
     R::load_w(W + (size_t)(r0 + 1) * K, lane, w1);
     R::rmsnorm(xr, nr, eps);
-    const float a = wave_sum(R::dot(w0, xr));
-    const float b = wave_sum(R::dot(w1, xr));
+    const float a = wave_sum(R::dot(w0, xr)) * s0;
+    const float b = wave_sum(R::dot(w1, xr)) * s1;
     if (lane != 0) return;
     if (r0 < qdim + kdim) {  // rope_i on the pair (2j, 2j+1) of its head (dual_ar.rs:246-247)
         const float o0 = a * c - b * s, o1 = a * s + b * c;
         if (r0 < qdim) { q_out[r0] = o0; q_out[r0 + 1] = o1; }
-        else { dst[0] = WTr<WT>::from_f32(o0); dst[1] = WTr<WT>::from_f32(o1); }
+        else { dst[0] = WTr<KT>::from_f32(o0); dst[1] = WTr<KT>::from_f32(o1); }
     } else {
-        dst[0] = WTr<WT>::from_f32(a); dst[1] = WTr<WT>::from_f32(b);
+        dst[0] = WTr<KT>::from_f32(a); dst[1] = WTr<KT>::from_f32(b);
     }
 }
 
@@ -338,11 +363,12 @@ template <typename WT, int K, int WAVES, bool FUSED, int DH, bool NT>
 __global__ __launch_bounds__(WAVES * 64) void k_wo(const float* __restrict__ part, int n_chunks_max, int chunk,
                                                    const SeqState* __restrict__ state, const float* __restrict__ q, KVView kv,
                                                    int fused_T, const WT* __restrict__ W, float* __restrict__ x, int H, int Hk,
-                                                   int n_rows) {
+                                                   int n_rows, const float* __restrict__ wscale) {
     using R = Row<WT, K, NT>;
+    using KT = KVT<WT>;
     constexpr int NTH = WAVES * 64;
-    constexpr int EPL = WTr<WT>::EPL;
-    using vec = typename WTr<WT>::vec;
+    constexpr int EPL = WTr<KT>::EPL;   // the prologue reads the KV cache (KT), the body streams W (WT)
+    using vec = typename WTr<KT>::vec;
     static_assert(K % 4 == 0 && DH % 16 == 0, "geometry");
     __shared__ __attribute__((aligned(16))) float attn[K];
     __shared__ float wl[FUSED ? 32 * 8 : 32 * 128];
@@ -412,8 +438,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_wo(const float* __restrict__ par
         // step 1: scores[h][t], TWO threads per (h, t) (DH/2 dims each, DPP pair-sum); step 2: softmax . V with one
         // thread per EPL consecutive dims (one 16-B V load per token).
         const float scale = 1.0f / sqrtf((float)DH);
-        const WT* kbase = reinterpret_cast<const WT*>(kv.k);
-        const WT* vbase = reinterpret_cast<const WT*>(kv.v);
+        const KT* kbase = reinterpret_cast<const KT*>(kv.k);
+        const KT* vbase = reinterpret_cast<const KT*>(kv.v);
         constexpr int QD = DH / 2;  // dims per step-1 thread
         const int e1 = threadIdx.x >> 1, sl = threadIdx.x & 1;
         const bool has_s = e1 < H * fused_T;
@@ -421,7 +447,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_wo(const float* __restrict__ par
         vec kvv[QD / EPL];
         float4 qv[QD / 4];
         {
-            const WT* kp = kbase + ((size_t)(h1 / n_rep) * KV_PAGE + t1) * DH + sl * QD;
+            const KT* kp = kbase + ((size_t)(h1 / n_rep) * KV_PAGE + t1) * DH + sl * QD;
 #pragma unroll
             for (int i = 0; i < QD / EPL; ++i) kvv[i] = *reinterpret_cast<const vec*>(kp + i * EPL);
 #pragma unroll
@@ -440,7 +466,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_wo(const float* __restrict__ par
 #pragma unroll
             for (int i = 0; i < QD / EPL; ++i) {
                 float kf[EPL];
-                WTr<WT>::unpack(kvv[i], kf);
+                WTr<KT>::unpack(kvv[i], kf);
 #pragma unroll
                 for (int j = 0; j < EPL; j += 4) {
                     const float4 qq = qv[(i * EPL + j) / 4];
@@ -465,7 +491,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_wo(const float* __restrict__ par
                     const float p = __expf(wl[hv * 8 + t] - mn);
                     L += p;
                     float vf[EPL];
-                    WTr<WT>::unpack(vvv[t], vf);
+                    WTr<KT>::unpack(vvv[t], vf);
 #pragma unroll
                     for (int i = 0; i < EPL; ++i) O[i] = fmaf(p, vf[i], O[i]);
                 }
@@ -478,7 +504,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_wo(const float* __restrict__ par
     if (row >= n_rows) return;
     float xr[R::NX];
     R::load_x(attn, lane, xr);
-    const float d = wave_sum(R::dot(wv, xr));
+    const float d = wave_sum(R::dot(wv, xr)) * row_scale<WT>(wscale, row);
     if (lane == 0) x[row] = xres + d;
 }
 
@@ -487,7 +513,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_wo(const float* __restrict__ par
 template <typename WT, int K, int WAVES, bool NT>
 __global__ __launch_bounds__(WAVES * 64) void k_ffn_up(const float* __restrict__ x, const float* __restrict__ norm_w,
                                                        float eps, const WT* __restrict__ W13, float* __restrict__ act,
-                                                       int inter) {
+                                                       int inter, const float* __restrict__ wscale) {
     using R = Row<WT, K, NT>;
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * WAVES + (threadIdx.x >> 6);
@@ -499,8 +525,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_ffn_up(const float* __restrict__
     R::load_w(W13 + (size_t)(2 * r) * K, lane, w1);
     R::load_w(W13 + (size_t)(2 * r + 1) * K, lane, w3);
     R::rmsnorm(xr, nr, eps);
-    const float a = wave_sum(R::dot(w1, xr));
-    const float b = wave_sum(R::dot(w3, xr));
+    const float a = wave_sum(R::dot(w1, xr)) * row_scale<WT>(wscale, 2 * r);
+    const float b = wave_sum(R::dot(w3, xr)) * row_scale<WT>(wscale, 2 * r + 1);
     if (lane == 0) act[r] = (a / (1.f + __expf(-a))) * b;  // candle silu = x / (1 + exp(-x))
 }
 
@@ -510,7 +536,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_ffn_up(const float* __restrict__
 // and are added in a fixed order.
 template <typename WT, int K, int KS, bool NT>
 __global__ __launch_bounds__(KS * 64) void k_ffn_down(const float* __restrict__ act, const WT* __restrict__ W2,
-                                                      float* __restrict__ x, int n_rows) {
+                                                      float* __restrict__ x, int n_rows, const float* __restrict__ wscale) {
     using R = Row<WT, K / KS, NT>;
     __shared__ float red[KS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -527,14 +553,15 @@ __global__ __launch_bounds__(KS * 64) void k_ffn_down(const float* __restrict__ 
         float t = red[0];
 #pragma unroll
         for (int i = 1; i < KS; ++i) t += red[i];
-        x[row] = xres + t;
+        x[row] = xres + t * row_scale<WT>(wscale, row);
     }
 }
 
 // ------------------------------------------------------------------------------------------------ norm + head GEMV
 template <typename WT, int K, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void k_head(const float* __restrict__ x, const float* __restrict__ norm_w, float eps,
-                                                     const WT* __restrict__ W, int n_rows, float* __restrict__ logits) {
+                                                     const WT* __restrict__ W, int n_rows, float* __restrict__ logits,
+                                                     const float* __restrict__ wscale) {
     using R = Row<WT, K>;
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * WAVES + (threadIdx.x >> 6);
@@ -545,7 +572,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_head(const float* __restrict__ x
     typename R::vec wv[R::NCH];
     R::load_w(W + (size_t)r * K, lane, wv);
     R::rmsnorm(xr, nr, eps);
-    const float d = wave_sum(R::dot(wv, xr));
+    const float d = wave_sum(R::dot(wv, xr)) * row_scale<WT>(wscale, r);
     if (lane == 0) logits[r] = d;
 }
 
@@ -959,21 +986,21 @@ __device__ int block_sample(float* lg /*LDS [n]*/, int n, const SampleCfg& c, Rn
             __syncthreads();
         }
     }
-    // ---- tail.  Decision procedure and f32 rounding identical to the oracle restatement: kept probabilities live in lg[]
-    // by token index (0 elsewhere); sums and the WeightedIndex scan run in ascending index order, the top-p cut in
-    // descending probability order.  With top-k the kept set is re-sorted by index (small bitonic sort in `red`) so the
-    // single-lane loops touch top_k entries instead of n.
+    // ---- tail.  Decision procedure and f32 rounding identical to the oracle restatement: sums and the WeightedIndex scan
+    // run in ascending token-index order, the top-p cut in descending probability order, every sum is a sequential f32
+    // chain.  To keep those chains short and free of dependent LDS indirections, the kept set (top_k entries, or all n)
+    // is materialised as CONTIGUOUS arrays: kp[j] = probability of the j-th kept token in index order, ki[j] = its index.
     const bool use_k = c.top_k > 0 && c.top_k < n;
     const int kk = use_k ? c.top_k : n;
-    int kp2 = 1;
-    while (kp2 < kk) kp2 <<= 1;
-    const bool idx_sorted = use_k && kp2 <= 2 * SAMPLE_THREADS;  // fits the 8 KB `red` scratch as ints
-    int* ki = reinterpret_cast<int*>(red);
-    for (int i = tid; i < n; i += SAMPLE_THREADS) lg[i] = 0.f;
-    __syncthreads();
-    for (int r = tid; r < kk; r += SAMPLE_THREADS) lg[si[r]] = sp[r];
-    if (idx_sorted) {
-        for (int r = tid; r < kp2; r += SAMPLE_THREADS) ki[r] = r < kk ? si[r] : 0x7FFFFFFF;
+    int* ki = reinterpret_cast<int*>(red);  // 8 KB scratch: up to 2048 ints
+    float* kp = lg;                          // the by-index array is no longer needed once (sp, si) are sorted
+    const bool small = use_k && kk <= 2 * SAMPLE_THREADS;
+    int cnt;                                 // entries of (ki, kp)
+    if (small) {
+        int kp2 = 1;
+        while (kp2 < kk) kp2 <<= 1;
+        __syncthreads();
+        for (int r = tid; r < kp2; r += SAMPLE_THREADS) { ki[r] = r < kk ? si[r] : 0x7FFFFFFF; kp[r] = r < kk ? sp[r] : 0.f; }
         __syncthreads();
         for (int k2 = 2; k2 <= kp2; k2 <<= 1)
             for (int j = k2 >> 1; j > 0; j >>= 1) {
@@ -982,32 +1009,57 @@ __device__ int block_sample(float* lg /*LDS [n]*/, int n, const SampleCfg& c, Rn
                     if (ixj > i) {
                         const int a0 = ki[i], a1 = ki[ixj];
                         const bool up = (i & k2) == 0;
-                        if ((a0 > a1) == up) { ki[i] = a1; ki[ixj] = a0; }
+                        if ((a0 > a1) == up) {
+                            ki[i] = a1; ki[ixj] = a0;
+                            const float t0 = kp[i]; kp[i] = kp[ixj]; kp[ixj] = t0;
+                        }
                     }
                 }
                 __syncthreads();
             }
+        cnt = kk;
+    } else {  // all n tokens (or a top-k too large for the scratch): index order is the identity
+        __syncthreads();
+        for (int i = tid; i < n; i += SAMPLE_THREADS) kp[i] = 0.f;
+        __syncthreads();
+        for (int r = tid; r < kk; r += SAMPLE_THREADS) kp[si[r]] = sp[r];
+        __syncthreads();
+        cnt = n;
     }
-    __syncthreads();
+    __shared__ int s_cut;       // number of leading sorted entries that survive top-p
+    __shared__ int s_do_topp;
     if (tid == 0) {
         bool do_topp = true;
         if (use_k) {
             float sum_p = 0.f;
-            if (idx_sorted) { for (int j = 0; j < kk; ++j) sum_p += lg[ki[j]]; }
-            else { for (int i = 0; i < n; ++i) if (lg[i] != 0.f) sum_p += lg[i]; }
+            for (int j = 0; j < cnt; ++j) sum_p += kp[j];  // ascending index; entries outside the top-k are 0 (or absent)
             do_topp = !(c.top_p <= 0.f || c.top_p >= sum_p);
         }
+        int cut = kk;
         if (do_topp) {  // zero every prob once the running cumsum (descending order) reached top_p
             float cumsum = 0.f;
             for (int r = 0; r < kk; ++r) {
-                if (cumsum >= c.top_p) lg[si[r]] = 0.f;
-                cumsum += lg[si[r]];
+                if (cumsum >= c.top_p) { cut = r; break; }
+                cumsum += sp[r];
             }
         }
+        s_cut = cut; s_do_topp = do_topp ? 1 : 0;
+    }
+    __syncthreads();
+    if (s_do_topp && s_cut < kk) {  // entries sorting at or after rank `cut` are zeroed (parallel predicate on (prob, index))
+        const float pc = sp[s_cut];
+        const int ic = si[s_cut];
+        for (int j = tid; j < cnt; j += SAMPLE_THREADS) {
+            const float pj = kp[j];
+            const int ij = small ? ki[j] : j;
+            if (pj < pc || (pj == pc && ij >= ic)) kp[j] = 0.f;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
         // WeightedIndex::new + sample (ascending index; zero weights do not move the cumulative sum)
         float total = 0.f;
-        if (idx_sorted) { for (int j = 0; j < kk; ++j) total += lg[ki[j]]; }
-        else { for (int i = 0; i < n; ++i) if (lg[i] != 0.f) total += lg[i]; }
+        for (int j = 0; j < cnt; ++j) total += kp[j];
         int res = 0;
         if (total > 0.f) {
             const float max_rand = __uint_as_float((0xFFFFFFFFu >> 9) | (127u << 23)) - 1.0f;
@@ -1021,15 +1073,15 @@ __device__ int block_sample(float* lg /*LDS [n]*/, int n, const SampleCfg& c, Rn
             float cum = 0.f;
             int last_nz = 0;
             res = -1;
-            const int cnt = idx_sorted ? kk : n;
             for (int j = 0; j < cnt; ++j) {
-                const int i = idx_sorted ? ki[j] : j;
-                if (lg[i] == 0.f) continue;
-                last_nz = i;
-                cum += lg[i];
-                if (cum > chosen) { res = i; break; }
+                const float wj = kp[j];
+                if (wj == 0.f) continue;
+                last_nz = j;
+                cum += wj;
+                if (cum > chosen) { res = j; break; }
             }
             if (res < 0) res = last_nz;
+            if (small) res = ki[res];
         }
         s_result = res;
     }
@@ -1300,6 +1352,47 @@ __global__ void k_convert_rows(WT* __restrict__ dst, const float* __restrict__ s
     }
 }
 
+// fp8 quantiser: one block per source row.  scale = amax / 448 (1 for an all-zero row); byte = e4m3fn_rne(v / scale) with an
+// IEEE-exact f32 division: pure integer / correctly-rounded f32 arithmetic, so any IEEE-754 host reproduces the stored
+// bytes and scales bit-for-bit (tests/test_fp8_gpu.py checks that against the CPU restatement).
+template <bool SYNTH>
+__global__ __launch_bounds__(256) void k_quant_fp8(uint8_t* __restrict__ dst, float* __restrict__ scales, const float* __restrict__ src,
+                                                   uint64_t key, long long n_cols, int row_mul, int row_off, float mean, float gscale) {
+    __shared__ float red[256];
+    const long long r = blockIdx.x;
+    auto elem = [&](long long c) -> float {
+        if (SYNTH) return synth_elem(key, (uint64_t)(r * n_cols + c), mean, gscale);
+        return src[r * n_cols + c];
+    };
+    float amax = 0.f;
+    for (long long c = threadIdx.x; c < n_cols; c += 256) amax = fmaxf(amax, fabsf(elem(c)));
+    red[threadIdx.x] = amax;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    amax = red[0];
+    const float sc = amax > 0.f ? __fdiv_rn(amax, 448.0f) : 1.0f;
+    const long long orow = r * row_mul + row_off;
+    if (threadIdx.x == 0) scales[orow] = sc;
+    for (long long c = threadIdx.x; c < n_cols; c += 256) dst[orow * n_cols + c] = f32_to_e4m3(__fdiv_rn(elem(c), sc));
+}
+
+// out[b] = the value the GEMV kernels' unpack path (v_cvt_pk_f32_fp8) assigns to byte b, in each of the 16 lane slots
+__global__ void k_fp8_decode_table(float* __restrict__ out) {
+    const unsigned b = threadIdx.x & 255u, slot = blockIdx.x;  // slot 0..15: position of the byte inside the 16-byte lane load
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+    w[slot >> 2] = b << (8 * (slot & 3));
+    u32x4 v; v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+    float f[16];
+    WTr<fp8_t>::unpack(v, f);
+    float r = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) if (i == (int)slot) r = f[i];
+    out[slot * 256 + b] = r;
+}
+
 // ================================================================================================ launchers
 #define FS_LAUNCH_CHECK() FS_HIP(hipGetLastError())
 
@@ -1324,16 +1417,16 @@ void LmKernels<WT>::qkv(const ModelDims& d, const float* x, const LayerW& w, con
         constexpr int K = decltype(Kc)::value;
         if (w.cache_resident)
             hipLaunchKernelGGL((k_qkv<WT, K, WAVES, false>), dim3(grid), dim3(WAVES * 64), 0, st, x, w.attn_norm, d.eps,
-                               (const WT*)w.wqkv, cos_t, sin_t, state, pos_static, rope_static, q_out, kv, d.H, d.Hk, d.Dh);
+                               (const WT*)w.wqkv, cos_t, sin_t, state, pos_static, rope_static, q_out, kv, d.H, d.Hk, d.Dh, w.s_qkv);
         else
             hipLaunchKernelGGL((k_qkv<WT, K, WAVES, true>), dim3(grid), dim3(WAVES * 64), 0, st, x, w.attn_norm, d.eps,
-                               (const WT*)w.wqkv, cos_t, sin_t, state, pos_static, rope_static, q_out, kv, d.H, d.Hk, d.Dh);
+                               (const WT*)w.wqkv, cos_t, sin_t, state, pos_static, rope_static, q_out, kv, d.H, d.Hk, d.Dh, w.s_qkv);
     });
     FS_LAUNCH_CHECK();
 }
 
 template <typename WT>
-int LmKernels<WT>::attn_chunk() { return AttnGeom<WT>::NW * AttnGeom<WT>::TW; }
+int LmKernels<WT>::attn_chunk() { return AttnGeom<KVT<WT>>::NW * AttnGeom<KVT<WT>>::TW; }
 
 template <typename WT>
 void LmKernels<WT>::attn_decode(const ModelDims& d, const float* q, KVView kv, const SeqState* state, float* part,
@@ -1342,11 +1435,11 @@ void LmKernels<WT>::attn_decode(const ModelDims& d, const float* q, KVView kv, c
     const int grid = d.Hk * nc_launch;
     FS_REQUIRE(n_chunks_max <= 128, "attention supports at most 128 chunks per sequence");
     if (d.Dh == 64 && d.n_rep == 8)
-        hipLaunchKernelGGL((k_attn_decode<WT, 64, 8>), dim3(grid), dim3(AttnGeom<WT>::NW * 64), 0, st, q, kv, state, part, d.Hk, n_chunks_max, nc_launch, 0, 0);
+        hipLaunchKernelGGL((k_attn_decode<KVT<WT>, 64, 8>), dim3(grid), dim3(AttnGeom<KVT<WT>>::NW * 64), 0, st, q, kv, state, part, d.Hk, n_chunks_max, nc_launch, 0, 0);
     else if (d.Dh == 32 && d.n_rep == 2)
-        hipLaunchKernelGGL((k_attn_decode<WT, 32, 2>), dim3(grid), dim3(AttnGeom<WT>::NW * 64), 0, st, q, kv, state, part, d.Hk, n_chunks_max, nc_launch, 0, 0);
+        hipLaunchKernelGGL((k_attn_decode<KVT<WT>, 32, 2>), dim3(grid), dim3(AttnGeom<KVT<WT>>::NW * 64), 0, st, q, kv, state, part, d.Hk, n_chunks_max, nc_launch, 0, 0);
     else if (d.Dh == 64 && d.n_rep == 2)
-        hipLaunchKernelGGL((k_attn_decode<WT, 64, 2>), dim3(grid), dim3(AttnGeom<WT>::NW * 64), 0, st, q, kv, state, part, d.Hk, n_chunks_max, nc_launch, 0, 0);
+        hipLaunchKernelGGL((k_attn_decode<KVT<WT>, 64, 2>), dim3(grid), dim3(AttnGeom<KVT<WT>>::NW * 64), 0, st, q, kv, state, part, d.Hk, n_chunks_max, nc_launch, 0, 0);
     else
         throw Error("unsupported attention geometry (head_dim, n_rep) = (" + std::to_string(d.Dh) + ", " +
                     std::to_string(d.n_rep) + ")");
@@ -1365,10 +1458,10 @@ void LmKernels<WT>::wo(const ModelDims& d, const float* part, int n_chunks_max, 
         auto go = [&](auto fused, auto dh) {
             if (w.cache_resident)
                 hipLaunchKernelGGL((k_wo<WT, K, WAVES, decltype(fused)::value, decltype(dh)::value, false>), dim3(grid), dim3(WAVES * 64), 0,
-                                   st, part, n_chunks_max, attn_chunk(), state, q, kv, fused_T, (const WT*)w.wo, x, d.H, d.Hk, d.dim);
+                                   st, part, n_chunks_max, attn_chunk(), state, q, kv, fused_T, (const WT*)w.wo, x, d.H, d.Hk, d.dim, w.s_o);
             else
                 hipLaunchKernelGGL((k_wo<WT, K, WAVES, decltype(fused)::value, decltype(dh)::value, true>), dim3(grid), dim3(WAVES * 64), 0,
-                                   st, part, n_chunks_max, attn_chunk(), state, q, kv, fused_T, (const WT*)w.wo, x, d.H, d.Hk, d.dim);
+                                   st, part, n_chunks_max, attn_chunk(), state, q, kv, fused_T, (const WT*)w.wo, x, d.H, d.Hk, d.dim, w.s_o);
         };
         using T = std::true_type; using F = std::false_type;
         using D64 = std::integral_constant<int, 64>; using D32 = std::integral_constant<int, 32>;
@@ -1386,10 +1479,10 @@ void LmKernels<WT>::ffn_up(const ModelDims& d, const float* x, const LayerW& w, 
         constexpr int K = decltype(Kc)::value;
         if (w.cache_resident)
             hipLaunchKernelGGL((k_ffn_up<WT, K, WAVES, false>), dim3(grid), dim3(WAVES * 64), 0, st, x, w.ffn_norm, d.eps,
-                               (const WT*)w.w13, act, d.inter);
+                               (const WT*)w.w13, act, d.inter, w.s_13);
         else
             hipLaunchKernelGGL((k_ffn_up<WT, K, WAVES, true>), dim3(grid), dim3(WAVES * 64), 0, st, x, w.ffn_norm, d.eps,
-                               (const WT*)w.w13, act, d.inter);
+                               (const WT*)w.w13, act, d.inter, w.s_13);
     });
     FS_LAUNCH_CHECK();
 }
@@ -1400,22 +1493,22 @@ void LmKernels<WT>::ffn_down(const ModelDims& d, const float* act, const LayerW&
     dispatch_k(d.inter, [&](auto Kc) {
         constexpr int K = decltype(Kc)::value;
         if (w.cache_resident)
-            hipLaunchKernelGGL((k_ffn_down<WT, K, KS, false>), dim3(d.dim), dim3(KS * 64), 0, st, act, (const WT*)w.w2, x, d.dim);
+            hipLaunchKernelGGL((k_ffn_down<WT, K, KS, false>), dim3(d.dim), dim3(KS * 64), 0, st, act, (const WT*)w.w2, x, d.dim, w.s_2);
         else
-            hipLaunchKernelGGL((k_ffn_down<WT, K, KS, true>), dim3(d.dim), dim3(KS * 64), 0, st, act, (const WT*)w.w2, x, d.dim);
+            hipLaunchKernelGGL((k_ffn_down<WT, K, KS, true>), dim3(d.dim), dim3(KS * 64), 0, st, act, (const WT*)w.w2, x, d.dim, w.s_2);
     });
     FS_LAUNCH_CHECK();
 }
 
 template <typename WT>
-void LmKernels<WT>::head(const ModelDims& d, const float* x, const float* norm_w, const void* W, int n_rows, float* logits,
-                         hipStream_t st) {
+void LmKernels<WT>::head(const ModelDims& d, const float* x, const float* norm_w, const void* W, const float* wscale, int n_rows,
+                         float* logits, hipStream_t st) {
     constexpr int WAVES = 4;
     const int grid = (n_rows + WAVES - 1) / WAVES;
     dispatch_k(d.dim, [&](auto Kc) {
         constexpr int K = decltype(Kc)::value;
         hipLaunchKernelGGL((k_head<WT, K, WAVES>), dim3(grid), dim3(WAVES * 64), 0, st, x, norm_w, d.eps, (const WT*)W,
-                           n_rows, logits);
+                           n_rows, logits, wscale);
     });
     FS_LAUNCH_CHECK();
 }
@@ -1423,7 +1516,7 @@ void LmKernels<WT>::head(const ModelDims& d, const float* x, const float* norm_w
 template <typename WT>
 void LmKernels<WT>::embed(const ModelDims& d, const void* tok_emb, const void* cb_emb, int n_cb, int cb_size,
                           const SampleCfg* cfg, const uint32_t* prompt, SeqState* state, float* x, hipStream_t st) {
-    hipLaunchKernelGGL((k_embed<WT>), dim3(1), dim3(256), 0, st, (const WT*)tok_emb, (const WT*)cb_emb, d.dim, n_cb, cb_size,
+    hipLaunchKernelGGL((k_embed<KVT<WT>>), dim3(1), dim3(256), 0, st, (const KVT<WT>*)tok_emb, (const KVT<WT>*)cb_emb, d.dim, n_cb, cb_size,
                        cfg, prompt, state, x);
     FS_LAUNCH_CHECK();
 }
@@ -1431,7 +1524,7 @@ void LmKernels<WT>::embed(const ModelDims& d, const void* tok_emb, const void* c
 template <typename WT>
 void LmKernels<WT>::fast_embed(const ModelDims& d, const void* fast_emb, const uint32_t* ids, int n, float* out,
                                hipStream_t st) {
-    hipLaunchKernelGGL((k_fast_embed<WT>), dim3(n), dim3(256), 0, st, (const WT*)fast_emb, d.dim, ids, out);
+    hipLaunchKernelGGL((k_fast_embed<KVT<WT>>), dim3(n), dim3(256), 0, st, (const KVT<WT>*)fast_emb, d.dim, ids, out);
     FS_LAUNCH_CHECK();
 }
 
@@ -1439,7 +1532,7 @@ template <typename WT>
 void SampleKernels<WT>::sample_slow(const ModelDims& d, const float* logits, int n, const SampleCfg* c, RngState* rng,
                                     SeqState* state, const float* x, float* xf, hipStream_t st) {
     FS_REQUIRE(n <= SAMPLE_MAXN, "audio-range vocabulary larger than the sampler capacity");
-    hipLaunchKernelGGL((k_sample_slow<WT>), dim3(1), dim3(SAMPLE_THREADS), 0, st, logits, n, c, rng, state, x, xf, d.dim);
+    hipLaunchKernelGGL((k_sample_slow<KVT<WT>>), dim3(1), dim3(SAMPLE_THREADS), 0, st, logits, n, c, rng, state, x, xf, d.dim);
     FS_LAUNCH_CHECK();
 }
 
@@ -1449,8 +1542,8 @@ void SampleKernels<WT>::sample_fast(const ModelDims& d, const float* logits, int
                                     const void* tok_emb, const void* cb_emb, float* x, uint32_t* out_codes, int out_cap,
                                     hipStream_t st) {
     FS_REQUIRE(cb_size <= SAMPLE_MAXN, "codebook larger than the sampler capacity");
-    hipLaunchKernelGGL((k_sample_fast<WT>), dim3(1), dim3(SAMPLE_THREADS), 0, st, logits, cb, n_cb, cb_size, c, rng, rp, state,
-                       (const WT*)fast_emb, xf, (const WT*)tok_emb, (const WT*)cb_emb, x, d.dim, out_codes, out_cap);
+    hipLaunchKernelGGL((k_sample_fast<KVT<WT>>), dim3(1), dim3(SAMPLE_THREADS), 0, st, logits, cb, n_cb, cb_size, c, rng, rp, state,
+                       (const KVT<WT>*)fast_emb, xf, (const KVT<WT>*)tok_emb, (const KVT<WT>*)cb_emb, x, d.dim, out_codes, out_cap);
     FS_LAUNCH_CHECK();
 }
 
@@ -1458,7 +1551,7 @@ template <typename WT>
 void SampleKernels<WT>::sample_slow_rows(const ModelDims& d, const float* logits, int ld, int n, const SampleCfg* c, const RngState* master,
                                          int B, int calls_per_frame, SeqState* states, const float* X, float* XF, hipStream_t st) {
     FS_REQUIRE(n <= SAMPLE_MAXN, "audio-range vocabulary larger than the sampler capacity");
-    hipLaunchKernelGGL((k_sample_slow_rows<WT>), dim3(B), dim3(SAMPLE_THREADS), 0, st, logits, ld, n, c, master, B, calls_per_frame, states,
+    hipLaunchKernelGGL((k_sample_slow_rows<KVT<WT>>), dim3(B), dim3(SAMPLE_THREADS), 0, st, logits, ld, n, c, master, B, calls_per_frame, states,
                        X, XF, d.dim);
     FS_LAUNCH_CHECK();
 }
@@ -1468,8 +1561,8 @@ void SampleKernels<WT>::sample_fast_rows(const ModelDims& d, const float* logits
                                          const void* tok_emb, const void* cb_emb, float* X, uint32_t* out_codes, int out_cap,
                                          hipStream_t st) {
     FS_REQUIRE(cb_size <= SAMPLE_MAXN, "codebook larger than the sampler capacity");
-    hipLaunchKernelGGL((k_sample_fast_rows<WT>), dim3(B), dim3(SAMPLE_THREADS), 0, st, logits, cb, n_cb, cb_size, c, master, B, states,
-                       (const WT*)fast_emb, XF, (const WT*)tok_emb, (const WT*)cb_emb, X, d.dim, out_codes, out_cap);
+    hipLaunchKernelGGL((k_sample_fast_rows<KVT<WT>>), dim3(B), dim3(SAMPLE_THREADS), 0, st, logits, cb, n_cb, cb_size, c, master, B, states,
+                       (const KVT<WT>*)fast_emb, XF, (const KVT<WT>*)tok_emb, (const KVT<WT>*)cb_emb, X, d.dim, out_codes, out_cap);
     FS_LAUNCH_CHECK();
 }
 
@@ -1480,6 +1573,7 @@ void launch_gather_rows(const void* src, int dim, uint32_t r0, uint32_t r1, void
 }
 template void launch_gather_rows<bf16_t>(const void*, int, uint32_t, uint32_t, void*, hipStream_t);
 template void launch_gather_rows<float>(const void*, int, uint32_t, uint32_t, void*, hipStream_t);
+template void launch_gather_rows<fp8_t>(const void*, int, uint32_t, uint32_t, void*, hipStream_t);
 
 void launch_advance(SeqState* state, hipStream_t st) {
     hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, st, state);
@@ -1508,6 +1602,23 @@ void launch_convert_rows(WT* dst, const float* src, int64_t n_rows, int64_t n_co
     FS_LAUNCH_CHECK();
 }
 
+void launch_synth_quant_fp8(uint8_t* dst, float* scales, uint64_t key, int64_t n_rows, int64_t n_cols, int row_mul, int row_off,
+                            float mean, float scale, hipStream_t st) {
+    hipLaunchKernelGGL((k_quant_fp8<true>), dim3((unsigned)n_rows), dim3(256), 0, st, dst, scales, (const float*)nullptr, key,
+                       (long long)n_cols, row_mul, row_off, mean, scale);
+    FS_LAUNCH_CHECK();
+}
+void launch_fp8_decode_table(float* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_fp8_decode_table, dim3(16), dim3(256), 0, st, out);
+    FS_LAUNCH_CHECK();
+}
+void launch_quant_rows_fp8(uint8_t* dst, float* scales, const float* src, int64_t n_rows, int64_t n_cols, int row_mul, int row_off,
+                           hipStream_t st) {
+    hipLaunchKernelGGL((k_quant_fp8<false>), dim3((unsigned)n_rows), dim3(256), 0, st, dst, scales, src, (uint64_t)0,
+                       (long long)n_cols, row_mul, row_off, 0.f, 0.f);
+    FS_LAUNCH_CHECK();
+}
+
 // ---- chunked prefill launchers (bf16 weights only; f32 handles take the sequential decode-kernel path)
 template <typename WT>
 bool LmKernels<WT>::has_mfma_prefill() { return std::is_same<WT, bf16_t>::value; }
@@ -1516,7 +1627,7 @@ template <typename WT>
 void LmKernels<WT>::prefill_embed(const ModelDims& d, const void* tok_emb, const void* cb_emb, int n_cb, int cb_size,
                                   const SampleCfg* cfg, const uint32_t* prompt, const SeqState* state, int M, float* X,
                                   hipStream_t st) {
-    hipLaunchKernelGGL((k_embed_rows<WT>), dim3(M), dim3(256), 0, st, (const WT*)tok_emb, (const WT*)cb_emb, d.dim, n_cb, cb_size,
+    hipLaunchKernelGGL((k_embed_rows<KVT<WT>>), dim3(M), dim3(256), 0, st, (const KVT<WT>*)tok_emb, (const KVT<WT>*)cb_emb, d.dim, n_cb, cb_size,
                        cfg, prompt, state, X);
     FS_LAUNCH_CHECK();
 }
@@ -1639,6 +1750,8 @@ template struct LmKernels<bf16_t>;
 template struct LmKernels<float>;
 template struct SampleKernels<bf16_t>;
 template struct SampleKernels<float>;
+template struct LmKernels<fp8_t>;
+template struct SampleKernels<fp8_t>;
 template void launch_synth_fill<bf16_t>(bf16_t*, uint64_t, int64_t, int64_t, int, int, float, float, int, hipStream_t);
 template void launch_synth_fill<float>(float*, uint64_t, int64_t, int64_t, int, int, float, float, int, hipStream_t);
 template void launch_convert_rows<bf16_t>(bf16_t*, const float*, int64_t, int64_t, int, int, hipStream_t);

@@ -9,7 +9,7 @@ import numpy as np
 
 from . import _ffi, config
 
-DTYPES = {"f32": 0, "bf16": 1}
+DTYPES = {"f32": 0, "bf16": 1, "fp8": 2}
 
 
 def _u32(a):

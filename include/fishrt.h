@@ -28,8 +28,11 @@ extern "C" {
 
 /* weight / KV-cache storage type.  Activations and accumulation are always f32.
  * FS_BF16 == the reference's CUDA dtype choice (fish_speech_core/src/bin/llama_generate.rs:179-182),
- * FS_F32  == its CPU dtype (used here for token-exact parity runs against the f32 oracle). */
-typedef enum { FS_F32 = 0, FS_BF16 = 1 } fs_dtype;
+ * FS_F32  == its CPU dtype (used here for token-exact parity runs against the f32 oracle),
+ * FS_FP8  == no reference counterpart (SURVEY.md §8 configs[4]): the Linear weights (wqkv, wo, w1/w3, w2, output,
+ *            fast_output) are quantised at load time to OCP e4m3fn bytes with one f32 absmax scale per output row
+ *            (scale = amax/448); embeddings and the KV cache stay bf16, norm vectors f32, all accumulation f32. */
+typedef enum { FS_F32 = 0, FS_BF16 = 1, FS_FP8 = 2 } fs_dtype;
 
 /* fish_speech_core/lib/lm/dual_ar.rs:57-81  (BaseModelArgs; training-only fields dropped) */
 typedef struct fs_model_args {
@@ -66,6 +69,14 @@ const char* fs_version(void);
 int fs_device_count(void);
 
 /* ---- DualARTransformer ---------------------------------------------------------------------------------- */
+
+/* FS_FP8 storage format (no reference counterpart; SURVEY.md §8 configs[4]).  fs_fp8_quantize_rows runs the loader's device
+ * quantiser on a host f32 matrix [rows, cols]: scales_out[r] = amax_r / 448 (1 for an all-zero row), q_out = e4m3fn bytes of
+ * w / scale (round-to-nearest-even, saturating; never NaN) -- what fs_lm_load_* stores for every Linear weight of an FS_FP8
+ * handle.  fs_fp8_decode_table returns, for each of the 16 byte positions of a lane's 16-byte weight load, the f32 value the
+ * GEMV kernels give each of the 256 byte codes (out[slot * 256 + code]). */
+int fs_fp8_quantize_rows(int device_id, const float* w, int64_t rows, int64_t cols, uint8_t* q_out, float* scales_out);
+int fs_fp8_decode_table(int device_id, float* out);
 
 /* DualARTransformer::load (dual_ar.rs:460-529) is split in create + one of the load calls.
  * max_batch: number of independent sequences (KV caches) the handle can hold (1 for the single-batch generator). */

@@ -14,6 +14,7 @@
 // cross-checked by tests/test_synth.py.  The oracle never ships in the product path.
 #pragma once
 #include <cstdint>
+#include <cmath>
 #include <cstring>
 #include <string>
 
@@ -45,6 +46,46 @@ static inline float round_bf16(float f) {
     r &= 0xFFFF0000u;
     float o; std::memcpy(&o, &r, 4);
     return o;
+}
+
+// f32 -> OCP e4m3fn (RNE, saturating) -> f32: what an fp8 checkpoint tensor holds after the per-row scale.  Same integer
+// algorithm as the product's quantiser (csrc/fs_common.h); cross-checked on the GPU by tests/test_fp8_gpu.py.
+static inline uint8_t f32_to_e4m3(float f) {
+    uint32_t u; std::memcpy(&u, &f, 4);
+    const uint8_t sign = (uint8_t)((u >> 24) & 0x80);
+    const uint32_t a = u & 0x7FFFFFFFu;
+    if (a > 0x7F800000u) return (uint8_t)(sign | 0x7F);
+    float af; std::memcpy(&af, &a, 4);
+    if (af >= 464.0f) return (uint8_t)(sign | 0x7E);
+    if (af < 0.0009765625f) return sign;
+    int e = (int)(a >> 23) - 127;
+    if (e < -6) return (uint8_t)(sign | (uint32_t)__builtin_rintf(af * 512.0f));
+    uint32_t mant = a & 0x7FFFFFu, keep = mant >> 20, rest = mant & 0xFFFFFu;
+    if (rest > 0x80000u || (rest == 0x80000u && (keep & 1u))) keep += 1;
+    if (keep == 8) { keep = 0; e += 1; }
+    if (e > 8) return (uint8_t)(sign | 0x7E);
+    uint8_t out = (uint8_t)(sign | ((uint32_t)(e + 7) << 3) | keep);
+    if ((out & 0x7F) == 0x7F) out = (uint8_t)(sign | 0x7E);
+    return out;
+}
+static inline float e4m3_to_f32(uint8_t b) {
+    const uint32_t sign = (uint32_t)(b & 0x80) << 24, e = (b >> 3) & 0xF, m = b & 7;
+    float f;
+    if (e == 0) f = (float)m * 0.001953125f;
+    else { const uint32_t u = ((e + 120) << 23) | (m << 20); std::memcpy(&f, &u, 4); }
+    uint32_t u; std::memcpy(&u, &f, 4); u |= sign; std::memcpy(&f, &u, 4);
+    return f;
+}
+// per-row absmax scaling: scale = amax / 448 (1 when the row is all zero); w -> e4m3(w / scale) * scale
+static inline void quant_rows_fp8(float* w, size_t rows, size_t cols) {
+#pragma omp parallel for schedule(static)
+    for (long long r = 0; r < (long long)rows; ++r) {
+        float* row = w + (size_t)r * cols;
+        float amax = 0.f;
+        for (size_t c = 0; c < cols; ++c) amax = std::fmax(amax, std::fabs(row[c]));
+        const float scale = amax > 0.f ? amax / 448.0f : 1.0f;
+        for (size_t c = 0; c < cols; ++c) row[c] = e4m3_to_f32(f32_to_e4m3(row[c] / scale)) * scale;
+    }
 }
 
 // Fill `n` floats of tensor `name`.

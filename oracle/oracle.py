@@ -83,6 +83,25 @@ def _chk(rc):
         raise RuntimeError(lib().orc_last_error().decode())
 
 
+def quant_rows_fp8(w):
+    """per-row absmax e4m3fn quantise + dequantise (the FS_FP8 storage format), f32 [rows, cols]"""
+    w = np.ascontiguousarray(w, dtype=np.float32).copy()
+    lib().orc_quant_rows_fp8(_p(w, C.c_float), C.c_uint64(w.shape[0]), C.c_uint64(w.shape[1]))
+    return w
+
+
+def e4m3_to_f32(b):
+    f = lib().orc_e4m3_to_f32
+    f.restype = C.c_float
+    return float(f(C.c_uint8(int(b))))
+
+
+def f32_to_e4m3(x):
+    f = lib().orc_f32_to_e4m3
+    f.restype = C.c_uint8
+    return int(f(C.c_float(float(x))))
+
+
 def synth(name, n, seed, mean=0.0, std=0.02, bf16=False):
     out = np.empty(n, np.float32)
     lib().orc_synth_fill(_p(out, C.c_float), C.c_uint64(n), name.encode(), C.c_uint64(seed), C.c_float(mean),
@@ -103,8 +122,9 @@ class OracleLM:
             lib().orc_lm_destroy(self.h)
             self.h = None
 
-    def load_synthetic(self, seed, bf16=False):
-        _chk(lib().orc_lm_load_synthetic(self.h, C.c_uint64(seed), int(bf16)))
+    def load_synthetic(self, seed, bf16=False, fp8=False):
+        # mode 0 f32 / 1 bf16 checkpoint / 2 fp8 Linear weights (FS_FP8 storage of the product)
+        _chk(lib().orc_lm_load_synthetic(self.h, C.c_uint64(seed), 2 if fp8 else int(bf16)))
         return self
 
     def set_kv_round_bf16(self, on):

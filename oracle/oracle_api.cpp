@@ -39,6 +39,11 @@ void orc_synth_fill(float* dst, uint64_t n, const char* name, uint64_t seed, flo
     fsgen::fill(dst, n, name, seed, mean, stdv, bf16 != 0);
 }
 
+// fp8 (OCP e4m3fn) helpers of the FS_FP8 storage format
+uint8_t orc_f32_to_e4m3(float f) { return fsgen::f32_to_e4m3(f); }
+float orc_e4m3_to_f32(uint8_t b) { return fsgen::e4m3_to_f32(b); }
+void orc_quant_rows_fp8(float* w, uint64_t rows, uint64_t cols) { fsgen::quant_rows_fp8(w, rows, cols); }
+
 // ---- LM
 void* orc_lm_create(const int* iargs /*11*/, const float* fargs /*2*/, const uint32_t* tok /*5*/) {
     ModelArgs a;
@@ -54,7 +59,7 @@ void* orc_lm_create(const int* iargs /*11*/, const float* fargs /*2*/, const uin
     return lm;
 }
 void orc_lm_destroy(void* p) { delete (LM*)p; }
-int orc_lm_load_synthetic(void* p, uint64_t seed, int bf16) { GUARD(((LM*)p)->load_synthetic(seed, bf16 != 0)) }
+int orc_lm_load_synthetic(void* p, uint64_t seed, int mode) { GUARD(((LM*)p)->load_synthetic(seed, mode)) }
 void orc_lm_set_kv_round_bf16(void* p, int on) { ((LM*)p)->kv_round_bf16 = on != 0; }
 int orc_lm_forward_generate(void* p, const uint32_t* toks, int B, int L, int input_pos, float* logits, float* hidden,
                             int full_head) {

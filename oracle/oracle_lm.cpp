@@ -104,8 +104,16 @@ void LM::init(const ModelArgs& args, const TokenCfg& tc) {
 // Synthetic init (SURVEY.md §8d "Synthetic weights", with non-trivial norm weights so that a wrong
 // norm tensor cannot hide): matrices/embeddings N(0, 0.02^2) (initializer_range, dual_ar.rs:93),
 // norm weights 1 + N(0, 0.1^2).  Tensor names are the reference loader's (dual_ar.rs:125-156,219-223,415-419,466-511).
-void LM::load_synthetic(uint64_t seed, bool bf16) {
-    auto mat = [&](std::vector<float>& dst, size_t n, const std::string& name) {
+// mode 0: f32 values; 1: every tensor rounded to bf16 (a bf16 checkpoint); 2: the product's FS_FP8 storage -- Linear weights
+// quantised per output row to e4m3fn (fsgen::quant_rows_fp8), embeddings and norm vectors rounded to bf16.
+void LM::load_synthetic(uint64_t seed, int mode) {
+    const bool bf16 = mode != 0, fp8 = mode == 2;
+    auto lin = [&](std::vector<float>& dst, size_t rows, size_t cols, const std::string& name) {
+        dst.resize(rows * cols);
+        fsgen::fill(dst.data(), rows * cols, name, seed, 0.f, 0.02, bf16 && !fp8);
+        if (fp8) fsgen::quant_rows_fp8(dst.data(), rows, cols);
+    };
+    auto emb = [&](std::vector<float>& dst, size_t n, const std::string& name) {
         dst.resize(n);
         fsgen::fill(dst.data(), n, name, seed, 0.f, 0.02, bf16);
     };
@@ -115,28 +123,30 @@ void LM::load_synthetic(uint64_t seed, bool bf16) {
     };
     const size_t D = a.dim, I = a.intermediate_size;
     const size_t QKV = (size_t)(a.n_head + 2 * a.n_local_heads) * a.head_dim;
-    mat(embeddings, (size_t)a.vocab_size * D, "embeddings.weight");
-    mat(codebook_embeddings, (size_t)a.codebook_size * a.num_codebooks * D, "codebook_embeddings.weight");
+    emb(embeddings, (size_t)a.vocab_size * D, "embeddings.weight");
+    emb(codebook_embeddings, (size_t)a.codebook_size * a.num_codebooks * D, "codebook_embeddings.weight");
     auto blocks = [&](std::vector<Block>& ls, const std::string& pre) {
         for (size_t l = 0; l < ls.size(); ++l) {
             std::string p = pre + std::to_string(l) + ".";
-            mat(ls[l].wqkv, QKV * D, p + "attention.wqkv.weight");
-            mat(ls[l].wo, D * D, p + "attention.wo.weight");
-            mat(ls[l].w1, I * D, p + "feed_forward.w1.weight");
-            mat(ls[l].w2, D * I, p + "feed_forward.w2.weight");
-            mat(ls[l].w3, I * D, p + "feed_forward.w3.weight");
+            lin(ls[l].wqkv, QKV, D, p + "attention.wqkv.weight");
+            lin(ls[l].wo, D, D, p + "attention.wo.weight");
+            lin(ls[l].w1, I, D, p + "feed_forward.w1.weight");
+            lin(ls[l].w2, D, I, p + "feed_forward.w2.weight");
+            lin(ls[l].w3, I, D, p + "feed_forward.w3.weight");
             nrm(ls[l].ffn_norm, D, p + "ffn_norm.weight");
             nrm(ls[l].attention_norm, D, p + "attention_norm.weight");
         }
     };
     blocks(layers, "layers.");
     nrm(norm, D, "norm.weight");
-    if (a.tie_word_embeddings) output = embeddings;  // dual_ar.rs:482-486
-    else mat(output, (size_t)a.vocab_size * D, "output.weight");
-    mat(fast_embeddings, (size_t)a.codebook_size * D, "fast_embeddings.weight");
+    if (a.tie_word_embeddings) {  // dual_ar.rs:482-486
+        if (fp8) lin(output, (size_t)a.vocab_size, D, "embeddings.weight");  // head = fp8 of the same checkpoint tensor
+        else output = embeddings;
+    } else lin(output, (size_t)a.vocab_size, D, "output.weight");
+    emb(fast_embeddings, (size_t)a.codebook_size * D, "fast_embeddings.weight");
     blocks(fast_layers, "fast_layers.");
     nrm(fast_norm, D, "fast_norm.weight");
-    mat(fast_output, (size_t)a.codebook_size * D, "fast_output.weight");
+    lin(fast_output, (size_t)a.codebook_size, D, "fast_output.weight");
 }
 
 // dual_ar.rs:532-567

@@ -67,7 +67,7 @@ struct LM {
     std::vector<float> cos_t, sin_t;  // (max_seq_len, head_dim/2)  dual_ar.rs:168-186
 
     void init(const ModelArgs& args, const TokenCfg& tc);
-    void load_synthetic(uint64_t seed, bool bf16_weights);
+    void load_synthetic(uint64_t seed, int mode);  // 0 f32, 1 bf16 checkpoint, 2 fp8 Linear weights (+ bf16 rest)
     // dual_ar.rs:574-635.  toks: (B, C+1, L) u32.  logits: (B, V) ; hidden: (B, dim) pre-norm.
     void forward_generate(const uint32_t* toks, int B, int L, int input_pos, float* logits, float* hidden,
                           bool full_vocab_head = true);

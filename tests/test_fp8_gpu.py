@@ -1,0 +1,187 @@
+"""GPU parity of the FS_FP8 weight path (SURVEY.md §8 configs[4]; no reference counterpart, so parity has two legs):
+
+ 1. EXACT restatement: the oracle dequantises the same per-row e4m3fn bytes/scales (oracle/fsgen.h quant_rows_fp8), keeps
+    embeddings / norm vectors bf16-rounded and rounds its KV to bf16 -> only accumulation order and bf16 K/V rounding
+    boundaries differ, i.e. the same tolerances as the bf16 mode (tests/test_lm_gpu.py, tests/test_lm_fullsize_gpu.py);
+ 2. "parity vs the bf16 build within logit tolerance" (SURVEY.md §8 configs[4]): FP8 logits vs the BF16 handle's on the same
+    checkpoint values, tolerance written in the test from the measured quantisation noise.
+
+The storage format itself (quantiser bytes + scales, hardware decode of all 256 codes) is checked bit-for-bit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import fishrt
+from fishrt import _ffi
+from fishrt import config as fcfg
+from oracle import oracle as orc
+
+SEED = 20240607
+TOL = dict(rtol=2e-3, atol=2e-3)   # same-rounding oracle comparison (as bf16 mode)
+FP8_TOL_15 = 1e-2                  # Fish-1.5 shapes, same-rounding oracle (as BF16_TOL in test_lm_fullsize_gpu.py)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def test_fp8_hardware_decode_matches_format_for_all_codes():
+    out = np.zeros((16, 256), np.float32)
+    _ffi.check(_ffi.lib().fs_fp8_decode_table(0, _p(out, C.c_float)))
+    exp = np.array([orc.e4m3_to_f32(b) for b in range(256)], np.float32)
+    finite = np.array([(b & 0x7F) != 0x7F for b in range(256)])
+    for slot in range(16):
+        assert np.array_equal(out[slot][finite].view(np.uint32), exp[finite].view(np.uint32)), slot
+        assert np.isnan(out[slot][~finite]).all()  # 0x7F / 0xFF are NaN in e4m3fn; the quantiser never emits them
+
+
+def test_fp8_quantiser_bit_identical_to_oracle():
+    rng = np.random.RandomState(3)
+    w = (rng.standard_normal((37, 256)) * 0.02).astype(np.float32)
+    w[3] = 0.0                                   # all-zero row -> scale 1
+    w[5, :8] = [448, -448, 464, 1e-9, -1e-9, 0.0, 17.0, -0.3]  # saturation / underflow inside one row
+    w[7] *= 1e-30                                # tiny row: scale subnormal-safe
+    w[9, 0] = 3e38                               # huge amax
+    q = np.zeros(w.shape, np.uint8)
+    sc = np.zeros(w.shape[0], np.float32)
+    _ffi.check(_ffi.lib().fs_fp8_quantize_rows(0, _p(w, C.c_float), C.c_int64(w.shape[0]), C.c_int64(w.shape[1]), _p(q, C.c_uint8),
+                                               _p(sc, C.c_float)))
+    amax = np.abs(w).max(1)
+    exp_sc = np.where(amax > 0, amax / np.float32(448.0), np.float32(1.0)).astype(np.float32)
+    assert np.array_equal(sc.view(np.uint32), exp_sc.view(np.uint32))
+    assert not ((q & 0x7F) == 0x7F).any()
+    deq = np.array([orc.e4m3_to_f32(b) for b in range(256)], np.float32)[q] * sc[:, None]
+    exp = orc.quant_rows_fp8(w)
+    assert np.array_equal(deq.view(np.uint32), exp.view(np.uint32))
+    # sanity of the format itself: relative error of a normal-range weight <= 2^-4 (3 mantissa bits, RNE)
+    big = np.abs(w[:3]) > amax[:3, None] * 2.0 ** -6
+    assert (np.abs(exp[:3] - w[:3])[big] <= np.abs(w[:3])[big] * 2.0 ** -4 * 1.0001).all()
+
+
+@pytest.fixture(scope="module")
+def tiny8():
+    return fishrt.DualARTransformer(fcfg.TINY, fcfg.TINY_TOKENS, 0, "fp8", 2).load_synthetic(SEED)
+
+
+@pytest.fixture(scope="module")
+def otiny8():
+    o = orc.OracleLM(orc.TINY).load_synthetic(SEED, fp8=True)
+    o.set_kv_round_bf16(True)
+    return o
+
+
+def _tiny_prompt(L=11, seed=4):
+    rng = np.random.RandomState(seed)
+    p = np.zeros((9, L), np.uint32)
+    p[0] = rng.randint(0, 400, L)
+    p[0, 3] = fcfg.TINY_TOKENS["semantic_start_id"] + 5  # a semantic column so the codebook embeddings take part
+    p[1:, 3] = rng.randint(0, 64, 8)
+    return p
+
+
+def test_tiny_fp8_teacher_forced_vs_oracle(tiny8, otiny8):
+    lm, o = tiny8, otiny8
+    p = _tiny_prompt()
+    lm.clear_slow_layer_caches(); o.clear_slow()
+    lg, hg = lm.forward_generate(p, 0)
+    lo, ho = o.forward_generate(p, 0)
+    np.testing.assert_allclose(hg, ho, **TOL)
+    np.testing.assert_allclose(lg, lo, **TOL)
+    # decode step + fast decoder
+    step = np.zeros((9, 1), np.uint32); step[0, 0] = 77
+    lg2, hg2 = lm.forward_generate(step, p.shape[1])
+    lo2, ho2 = o.forward_generate(step, p.shape[1])
+    np.testing.assert_allclose(lg2, lo2, **TOL)
+    lm.clear_fast_layer_caches(); o.clear_fast()
+    x = ho2
+    for ci in range(4):
+        fg, fo = lm.forward_generate_fast(x, ci)[0], o.forward_generate_fast(x, ci)[0]
+        np.testing.assert_allclose(fg, fo, **TOL)
+        x = lm.fast_embeddings([int(np.argmax(fo))])
+    # embeddings of an fp8 handle are the bf16 checkpoint values
+    ids = np.array([0, 11, 63], np.uint32)
+    assert np.array_equal(lm.fast_embeddings(ids), orc.synth("fast_embeddings.weight", 64 * 128, SEED, 0.0, 0.02, True).reshape(64, 128)[ids])
+
+
+@pytest.mark.parametrize("rp", [1.0, 1.2])
+def test_tiny_fp8_greedy_rollout_vs_oracle(tiny8, otiny8, rp):
+    lm, o = tiny8, otiny8
+    p = _tiny_prompt()
+    lm.clear_slow_layer_caches(); o.clear_slow()
+    M = 32 + p.shape[1] - 2
+    got = lm.generate_blocking(p, M, temp=0.0, top_p=1.0, top_k=0, repetition_penalty=rp, ignore_eos=True)
+    exp = o.generate(p, M, temp=0.0, repetition_penalty=rp, ignore_eos=True)
+    assert got.shape == exp.shape == (8, 32)
+    bad = np.nonzero((got != exp).any(0))[0]
+    if bad.size:  # only a near-tie may flip
+        f = int(bad[0])
+        assert o.last_margins[f] < TOL["atol"], f"fp8 free-run diverged at frame {f} on a margin of {o.last_margins[f]:.2e}"
+    # determinism
+    lm.clear_slow_layer_caches()
+    again = lm.generate_blocking(p, M, temp=0.0, top_p=1.0, top_k=0, repetition_penalty=rp, ignore_eos=True)
+    assert np.array_equal(got, again)
+
+
+def test_tiny_fp8_sampled_and_static_batch(tiny8, otiny8):
+    lm, o = tiny8, otiny8
+    p = _tiny_prompt(7, seed=8)
+    lm.clear_slow_layer_caches(); o.clear_slow()
+    kw = dict(temp=0.8, top_p=0.9, top_k=20, repetition_penalty=1.1)
+    got = lm.generate_blocking(p, 30, seed=99, ignore_eos=True, **kw)
+    exp = o.generate(p, 30, seed=99, ignore_eos=True, **kw)
+    n = min(got.shape[1], exp.shape[1])
+    same = (got[:, :n] == exp[:, :n]).all(0)
+    # sampling thresholds amplify 1e-3 logit differences only at CDF boundaries: most frames must agree, the first must
+    assert same[0] and same.mean() > 0.5, same
+    outs = lm.generate_static_batch([p, _tiny_prompt(5, seed=9)], 20, temp=0.0, top_p=1.0, top_k=0, repetition_penalty=1.0, ignore_eos=True)
+    assert len(outs) == 2 and all(x.shape[0] == 8 for x in outs)
+
+
+def _prompt15(L, seed=1234):
+    rng = np.random.RandomState(seed)
+    p = np.zeros((9, L), np.uint32)
+    p[0] = rng.randint(0, fcfg.FISH_1_5_TOKENS["im_end_id"], L)
+    return p
+
+
+def test_fish15_fp8_vs_oracle_and_vs_bf16_build():
+    p = _prompt15(16)
+    o = orc.OracleLM(orc.FISH15).load_synthetic(0xF15E5EED, fp8=True)
+    o.set_kv_round_bf16(True)
+    lo, ho = o.forward_generate(p, 0)
+    M = 16 + 22
+    o.clear_slow()
+    exp = o.generate(p, M, temp=0.0, repetition_penalty=1.2, ignore_eos=True)
+    margins = o.last_margins.copy()
+    del o
+    lm = fishrt.DualARTransformer(fcfg.FISH_1_5, fcfg.FISH_1_5_TOKENS, 0, "fp8").load_synthetic(0xF15E5EED)
+    lg, hg = lm.forward_generate(p, 0)
+    im_end = fcfg.FISH_1_5_TOKENS["im_end_id"]
+    d_l = float(np.abs(lg[0, im_end:] - lo[0, im_end:]).max())
+    d_h = float(np.abs(hg - ho).max() / np.sqrt(np.mean(ho ** 2)))
+    assert d_l < FP8_TOL_15 and d_h < 1e-2, (d_l, d_h)
+    lm.clear_slow_layer_caches()
+    got = lm.generate_blocking(p, M, temp=0.0, top_p=1.0, top_k=0, repetition_penalty=1.2, ignore_eos=True)
+    assert got.shape == exp.shape == (8, 24)
+    bad = np.nonzero((got != exp).any(0))[0]
+    n_same = int(bad[0]) if bad.size else 24
+    if bad.size:
+        assert margins[n_same] < FP8_TOL_15, f"fp8 free-run diverged at frame {n_same} on a margin of {margins[n_same]:.2e}"
+    st = lm.last_stats()
+    lm.close()
+    # leg 2: against the bf16 build of the same checkpoint values -- quantisation noise, not kernel error
+    lb = fishrt.DualARTransformer(fcfg.FISH_1_5, fcfg.FISH_1_5_TOKENS, 0, "bf16").load_synthetic(0xF15E5EED)
+    lbf, hbf = lb.forward_generate(p, 0)
+    lb.close()
+    a, b = lg[0, im_end:], lbf[0, im_end:]
+    rel = float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    corr = float(np.corrcoef(a, b)[0, 1])
+    print(f"fp8 vs oracle(fp8): max|dlogit| {d_l:.2e}, |dh|/rms {d_h:.2e}, greedy identical for {n_same}/24 frames; "
+          f"fp8 vs bf16 build: rel L2 logit error {rel:.3f}, corr {corr:.4f}; decode {st['decode_ms'] / max(1, st['frames'] - 1):.3f} ms/frame")
+    # per-row e4m3 (3 mantissa bits) has ~2.5% rms relative error per weight; with RANDOM synthetic weights (no trained
+    # structure, logit scale ~1) that noise compounds through 24 residual blocks to a measured rel-L2 logit error of 0.16
+    # (corr 0.987).  Tolerance = 1.5x the measurement: a kernel bug (wrong scale row, wrong byte order) gives rel ~ 1.
+    assert rel < 0.25 and corr > 0.97, (rel, corr)

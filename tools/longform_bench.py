@@ -1,13 +1,15 @@
-"""BASELINE.json configs[4] (bf16 variant): Fish-1.4 shapes (V = 32000, single <|semantic|> id, legacy 2-way slow sampler),
+"""BASELINE.json configs[4]: Fish-1.4 shapes (V = 32000, single <|semantic|> id, legacy 2-way slow sampler),
 one stream of 4096 frames (KV grows to 4096 + L; RoPE table 8192 -- the reference would fail past its max_seq_len 4096,
 dual_ar.rs:179,623), Firefly vocoder on a second stream consuming 64-frame chunks (+24-frame halo) while the LM continues.
-Reports LM-only RTF, end-to-end RTF and overlap efficiency.  (The fp8-weight variant of configs[4] is not implemented yet.)"""
+Reports LM-only RTF, end-to-end RTF and overlap efficiency.  usage: longform_bench.py [frames] [fp8|bf16] (configs[4] names
+fp8-e4m3 weights; bf16 is the comparison run)."""
 import sys, time
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/fish-speech.rs_amd")
 import numpy as np, fishrt
 from fishrt import config as fcfg
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-lm = fishrt.DualARTransformer(fcfg.FISH_1_4, fcfg.FISH_1_4_TOKENS, 0, "bf16").load_synthetic(0xF15E5EED)
+dtype = sys.argv[2] if len(sys.argv) > 2 else "fp8"
+lm = fishrt.DualARTransformer(fcfg.FISH_1_4, fcfg.FISH_1_4_TOKENS, 0, dtype).load_synthetic(0xF15E5EED)
 codec = fishrt.FireflyCodec(0).load_synthetic(0xC0DEC)
 rng = np.random.RandomState(4)
 L = 64
@@ -27,6 +29,6 @@ for rep in range(2):
     c2, pcm2 = synth(p, M, **kw)
     st = synth.stats
     audio_s = frames / 21.535
-    print(f"frames={codes.shape[1]}: LM alone {t_lm:.3f}s (RTF {audio_s/t_lm:.1f}), vocoder alone (one shot) {t_voc:.3f}s, sequential {t_lm+t_voc:.3f}s | "
+    print(f"[{dtype}] frames={codes.shape[1]}: LM alone {t_lm:.3f}s (RTF {audio_s/t_lm:.1f}), vocoder alone (one shot) {t_voc:.3f}s, sequential {t_lm+t_voc:.3f}s | "
           f"overlapped total {st['total_s']:.3f}s (RTF {audio_s/st['total_s']:.1f}), vocoder busy {st['vocoder_busy_s']:.3f}s, "
           f"overlap efficiency {st['overlap_efficiency']:.2f}, same codes {np.array_equal(codes, c2)}, pcm identical {np.array_equal(pcm[0,0], pcm2)}")

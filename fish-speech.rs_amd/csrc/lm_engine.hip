@@ -611,10 +611,16 @@ class LM final : public LMBase {
         FS_HIP(hipMemcpy(d_cos_.p, ct.data(), ct.size() * 4, hipMemcpyHostToDevice));
         FS_HIP(hipMemcpy(d_sin_.p, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
         // paged KV: one pool per slow layer, page = KV_PAGE tokens x Hk heads x Dh
-        max_pages_ = (a_.max_seq_len + KV_PAGE - 1) / KV_PAGE;
+        // (the table covers whole attention chunks: k_attn_decode reads the slot of every launched chunk unconditionally)
+        n_chunks_ = (a_.max_seq_len + LmKernels<WT>::attn_chunk() - 1) / LmKernels<WT>::attn_chunk();
+        FS_REQUIRE(n_chunks_ <= 128, "max_seq_len too large for the attention chunking (128 chunks)");
+        max_pages_ = std::max((a_.max_seq_len + KV_PAGE - 1) / KV_PAGE, n_chunks_ * LmKernels<WT>::attn_chunk() / KV_PAGE);
         n_pages_ = max_pages_ * B_;
         page_elems_ = (size_t)a_.n_local_heads * KV_PAGE * a_.head_dim;
+        // pools and partial buffers start zeroed: the attention kernels read rows / chunks past the current length
+        // unconditionally and mask them afterwards, which needs finite (not uninitialised) contents
         kv_pool_.alloc((size_t)a_.n_layer * 2 * n_pages_ * page_elems_ * sizeof(KT));
+        FS_HIP(hipMemset(kv_pool_.p, 0, kv_pool_.n));
         d_page_table_.alloc(sizeof(int) * (size_t)B_ * max_pages_);
         FS_HIP(hipMemset(d_page_table_.p, 0, d_page_table_.n));
         for (int p = n_pages_ - 1; p >= 0; --p) free_pages_.push_back(p);
@@ -623,15 +629,15 @@ class LM final : public LMBase {
         fast_len_.assign(B_, 0);
         // fast-decoder KV: one page per (layer, sequence); its page table is a single zero
         fast_pool_.alloc((size_t)std::max(1, a_.n_fast_layer) * 2 * B_ * page_elems_ * sizeof(KT));
+        FS_HIP(hipMemset(fast_pool_.p, 0, fast_pool_.n));
         d_zero_table_.alloc(sizeof(int) * 4);
         FS_HIP(hipMemset(d_zero_table_.p, 0, d_zero_table_.n));
         // activations / state
         d_x_.alloc(sizeof(float) * (size_t)B_ * a_.dim);
         d_xf_.alloc(sizeof(float) * (size_t)B_ * a_.dim);
         d_q_.alloc(sizeof(float) * a_.dim);
-        n_chunks_ = (a_.max_seq_len + LmKernels<WT>::attn_chunk() - 1) / LmKernels<WT>::attn_chunk();
-        FS_REQUIRE(n_chunks_ <= 128, "max_seq_len too large for the attention chunking (128 chunks)");
         d_part_.alloc(sizeof(float) * (size_t)a_.n_head * n_chunks_ * (a_.head_dim + 2));
+        FS_HIP(hipMemset(d_part_.p, 0, d_part_.n));
         d_act_.alloc(sizeof(float) * a_.intermediate_size);
         d_logits_slow_.alloc(sizeof(float) * a_.vocab_size);
         d_logits_fast_.alloc(sizeof(float) * a_.codebook_size);
@@ -754,6 +760,7 @@ class LM final : public LMBase {
         d_pfa_.alloc(sizeof(uint16_t) * 2 * kRows * a_.dim);
         d_pfc_.alloc(sizeof(uint16_t) * 2 * kRows * a_.intermediate_size);
         d_pfpart_.alloc(sizeof(float) * kRows * (size_t)a_.n_head * n_chunks_ * (a_.head_dim + 2));
+        FS_HIP(hipMemsetAsync(d_pfpart_.p, 0, d_pfpart_.n, st_));
         FS_HIP(hipMemsetAsync(d_pfa_.p, 0, d_pfa_.n, st_));
         FS_HIP(hipMemsetAsync(d_pfc_.p, 0, d_pfc_.n, st_));
     }
@@ -838,7 +845,7 @@ class LM final : public LMBase {
             KVView kv = slow_kv(l, b);
             LmKernels<WT>::qkv(d_, x(b), w, d_cos_.as<float>(), d_sin_.as<float>(), state(b), 0, 0, d_q_.as<float>(), kv, st_);
             LmKernels<WT>::attn_decode(d_, d_q_.as<float>(), kv, state(b), d_part_.as<float>(), n_chunks_, nc_launch_, st_);
-            LmKernels<WT>::wo(d_, d_part_.as<float>(), n_chunks_, state(b), nullptr, kv, 0, w, x(b), st_);
+            LmKernels<WT>::wo(d_, d_part_.as<float>(), n_chunks_, nc_launch_, state(b), nullptr, kv, 0, w, x(b), st_);
             LmKernels<WT>::ffn_up(d_, x(b), w, d_act_.as<float>(), st_);
             LmKernels<WT>::ffn_down(d_, d_act_.as<float>(), w, x(b), st_);
         }
@@ -848,7 +855,7 @@ class LM final : public LMBase {
             const LayerW& w = fast_[l];
             KVView kv = fast_kv(l, b);
             LmKernels<WT>::qkv(d_, xf(b), w, d_cos_.as<float>(), d_sin_.as<float>(), nullptr, kv_pos, rope_pos, d_q_.as<float>(), kv, st_);
-            LmKernels<WT>::wo(d_, nullptr, 0, nullptr, d_q_.as<float>(), kv, kv_pos + 1, w, xf(b), st_);
+            LmKernels<WT>::wo(d_, nullptr, 0, 0, nullptr, d_q_.as<float>(), kv, kv_pos + 1, w, xf(b), st_);
             LmKernels<WT>::ffn_up(d_, xf(b), w, d_act_.as<float>(), st_);
             LmKernels<WT>::ffn_down(d_, d_act_.as<float>(), w, xf(b), st_);
         }

@@ -101,8 +101,9 @@ struct LmKernels {
                             int n_chunks_max, int nc_launch, hipStream_t st);
     // combine the chunks of state->pos + 1 tokens (or, fused_T > 0: attend over fused_T <= 8 cached tokens in the
     // prologue) -> Wo GEMV -> x += .
-    static void wo(const ModelDims& d, const float* part, int n_chunks_max, const SeqState* state, const float* q, KVView kv,
-                   int fused_T, const LayerW& w, float* x, hipStream_t st);
+    // nc_launch = the chunk count attn_decode was launched with (ignored when fused_T > 0)
+    static void wo(const ModelDims& d, const float* part, int n_chunks_max, int nc_launch, const SeqState* state, const float* q,
+                   KVView kv, int fused_T, const LayerW& w, float* x, hipStream_t st);
     static void ffn_up(const ModelDims& d, const float* x, const LayerW& w, float* act, hipStream_t st);
     static void ffn_down(const ModelDims& d, const float* act, const LayerW& w, float* x, hipStream_t st);
     // x -> rmsnorm(norm_w) -> rows [0, n_rows) of W (x wscale[row] for fp8 weights) -> logits f32

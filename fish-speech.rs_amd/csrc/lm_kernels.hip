@@ -110,6 +110,11 @@ __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
+// Everything above this point is ISSUED before anything below it: keeps the machine scheduler from sinking the weight-stream
+// loads under the wait for the small L2-resident vectors (it otherwise serialises x-load -> RMSNorm -> weight request, which
+// costs a full L2 round trip + the norm per kernel node before the first HBM byte is even asked for).
+#define FS_ISSUE_FENCE() __builtin_amdgcn_sched_barrier(0)
+
 // A wave's view of a length-K vector / weight row: chunk c covers elements [c*64*EPL, (c+1)*64*EPL), lane l owns
 // EPL consecutive elements starting at c*64*EPL + l*EPL.
 template <typename WT, int K, bool NT = true>
@@ -190,13 +195,18 @@ __global__ __launch_bounds__(WAVES * 64) void k_qkv(const float* __restrict__ x,
     const int n_pairs = (H + 2 * Hk) * Dh / 2;
     if (pair >= n_pairs) return;
     // small L2-resident vectors FIRST (vmcnt retires in order: a load issued after the weight stream would wait for it),
-    // then the weight stream; the RMSNorm math then overlaps the weights' HBM flight
+    // then the weight stream, then the position-dependent scalar chain (pos -> page / cos / sin, only needed by the
+    // epilogue); the RMSNorm math and that chain overlap the weights' HBM flight
     float xr[R::NX], nr[R::NX];
     R::load_x(x, lane, xr);
     R::load_x(norm_w, lane, nr);
+    const int r0 = 2 * pair, qdim = H * Dh, kdim = Hk * Dh, half = Dh / 2;
+    typename R::vec w0[R::NCH], w1[R::NCH];
+    R::load_w(W + (size_t)r0 * K, lane, w0);
+    R::load_w(W + (size_t)(r0 + 1) * K, lane, w1);
+    FS_ISSUE_FENCE();
     const int pos = state ? state->pos : pos_static;
     const int rpos = state ? pos + state->rope_off : rope_static;
-    const int r0 = 2 * pair, qdim = H * Dh, kdim = Hk * Dh, half = Dh / 2;
     float c = 1.f, s = 0.f;
     KT* dst = nullptr;
     if (r0 < qdim + kdim) {
@@ -209,9 +219,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_qkv(const float* __restrict__ x,
         dst = kv_addr<KT>(r0 < qdim + kdim ? kv.k : kv.v, kv.page_table, pos, g, Hk, Dh) + dd;
     }
     const float s0 = row_scale<WT>(wscale, r0), s1 = row_scale<WT>(wscale, r0 + 1);
-    typename R::vec w0[R::NCH], w1[R::NCH];
-    R::load_w(W + (size_t)r0 * K, lane, w0);
-    R::load_w(W + (size_t)(r0 + 1) * K, lane, w1);
     R::rmsnorm(xr, nr, eps);
     const float a = wave_sum(R::dot(w0, xr)) * s0;
     const float b = wave_sum(R::dot(w1, xr)) * s1;
@@ -259,8 +266,6 @@ __global__ __launch_bounds__(AttnGeom<WT>::NW * 64) void k_attn_decode(const flo
     static_assert(TW % NTS == 0 && NLD >= 1, "attention geometry");
     using vec = typename WTr<WT>::vec;
     const int g = blockIdx.x / nc_launch, c = blockIdx.x % nc_launch;  // nc_launch <= n_chunks_max chunks are launched
-    const int T = state->pos + 1 + (int)blockIdx.y * pos_step;  // the row's own K/V were appended by the qkv stage
-    if (c * CH >= T) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __shared__ __attribute__((aligned(16))) WT sk[NW][TW * DH];
     __shared__ __attribute__((aligned(16))) WT sv[NW][TW * DH];
@@ -268,17 +273,20 @@ __global__ __launch_bounds__(AttnGeom<WT>::NW * 64) void k_attn_decode(const flo
     const int t_base = c * CH + wave * TW;
     // stage K/V tiles: lane l of load i covers token (i*64 + l) / LPT, 16-B slice l % LPT (1 KiB contiguous per load)
     // all TW tokens of a wave live in ONE page (TW divides KV_PAGE, t_base is TW-aligned): a single wave-uniform
-    // (scalar) page-table read, then 1 KiB-contiguous tile loads
+    // (scalar) page-table read, then 1 KiB-contiguous tile loads.  Neither depends on the current length: the page-table
+    // slot exists for every launched chunk (unassigned slots hold a valid page id) and rows past the length are stale but
+    // in bounds (the pools are zero-initialised, so always finite) -- they are masked below.  The length itself is read
+    // in parallel instead of in front of the chain.
     static_assert(KV_PAGE % TW == 0, "a wave's tokens must not straddle a KV page");
     const int t_base_u = __builtin_amdgcn_readfirstlane(t_base);
-    const int page = kv.page_table[min(t_base_u, T - 1) / KV_PAGE];
+    const int page = kv.page_table[t_base_u / KV_PAGE];
     const WT* kpage = reinterpret_cast<const WT*>(kv.k) + (size_t)(page * Hk + g) * KV_PAGE * DH;
     const WT* vpage = reinterpret_cast<const WT*>(kv.v) + (size_t)(page * Hk + g) * KV_PAGE * DH;
     vec kreg[NLD], vreg[NLD];
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
         const int tl = (i * 64 + lane) / LPT, sl = lane % LPT;
-        const int t = min(t_base + tl, T - 1);  // clamped rows are masked below
+        const int t = t_base + tl;
         kreg[i] = *reinterpret_cast<const vec*>(kpage + (size_t)(t % KV_PAGE) * DH + sl * EPL);
         vreg[i] = *reinterpret_cast<const vec*>(vpage + (size_t)(t % KV_PAGE) * DH + sl * EPL);
     }
@@ -291,6 +299,9 @@ __global__ __launch_bounds__(AttnGeom<WT>::NW * 64) void k_attn_decode(const flo
 #pragma unroll
         for (int i = 0; i < EPL; ++i) qr[hp][i] = qp[i];
     }
+    FS_ISSUE_FENCE();
+    const int T = state->pos + 1 + (int)blockIdx.y * pos_step;  // the row's own K/V were appended by the qkv stage
+    if (c * CH >= T) return;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
         *reinterpret_cast<vec*>(&sk[wave][(size_t)(i * 64 + lane) * EPL]) = kreg[i];
@@ -363,7 +374,7 @@ template <typename WT, int K, int WAVES, bool FUSED, int DH, bool NT>
 __global__ __launch_bounds__(WAVES * 64) void k_wo(const float* __restrict__ part, int n_chunks_max, int chunk,
                                                    const SeqState* __restrict__ state, const float* __restrict__ q, KVView kv,
                                                    int fused_T, const WT* __restrict__ W, float* __restrict__ x, int H, int Hk,
-                                                   int n_rows, const float* __restrict__ wscale) {
+                                                   int n_rows, const float* __restrict__ wscale, int nc_launch) {
     using R = Row<WT, K, NT>;
     using KT = KVT<WT>;
     constexpr int NTH = WAVES * 64;
@@ -381,25 +392,29 @@ __global__ __launch_bounds__(WAVES * 64) void k_wo(const float* __restrict__ par
     // Few, wide prologue loads (the texture-address unit retires one wave-instruction per ~16 cycles whatever its width),
     // all issued before the weight stream (vmcnt retires in issue order).
     if (!FUSED) {
-        const int T = state->pos + 1;
-        const int nc = (T + chunk - 1) / chunk;  // chunks k_attn_decode produced
+        // every prologue load is addressed from launch-time constants only (nc_launch = chunks this graph bucket launches),
+        // so nothing waits for state->pos before the weight stream is requested; chunks >= nc hold stale (finite) partials of
+        // earlier frames and are masked below
         // (a) {m, l} of every (head, chunk) + the first four chunks' o values (float4 per thread per chunk)
         const int e0 = threadIdx.x;
-        const bool has_ml = e0 < H * nc;
-        float2 mv = make_float2(0.f, 0.f);
-        if (has_ml) mv = *reinterpret_cast<const float2*>(part + ((size_t)(e0 / nc) * n_chunks_max + (e0 % nc)) * (DH + 2) + DH);
+        const int eh = e0 / nc_launch, ec = e0 % nc_launch;
+        const bool in_ml = e0 < H * nc_launch;
+        const float2 mv = *reinterpret_cast<const float2*>(part + ((size_t)(in_ml ? eh : 0) * n_chunks_max + ec) * (DH + 2) + DH);
         const int e4 = threadIdx.x * 4;  // this thread's 4 consecutive attn elements (K <= 4 * NTH for every supported K here)
         const bool has_o = e4 < K;
         const int ho = (has_o ? e4 : 0) / DH, ddo = e4 % DH;
         const float* po = part + (size_t)ho * n_chunks_max * (DH + 2) + ddo;
         float4 v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            v[j] = (has_o && j < nc) ? *reinterpret_cast<const float4*>(po + (size_t)j * (DH + 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < n_rows) R::load_w(W + (size_t)row * K, lane, wv);
-        if (has_ml) { ml[2 * ((e0 / nc) * 128 + (e0 % nc))] = mv.x; ml[2 * ((e0 / nc) * 128 + (e0 % nc)) + 1] = mv.y; }
-        for (int e = threadIdx.x + NTH; e < H * nc; e += NTH) {  // only when H * nc > NTH (very long sequences)
-            const int h = e / nc, c = e % nc;
+        for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const float4*>(po + (size_t)min(j, nc_launch - 1) * (DH + 2));
+        R::load_w(W + (size_t)min(row, n_rows - 1) * K, lane, wv);  // clamped, not predicated: a predicated load costs a wait
+        FS_ISSUE_FENCE();
+        const int T = state->pos + 1;
+        const int nc = (T + chunk - 1) / chunk;  // chunks k_attn_decode produced (<= nc_launch)
+        if (in_ml && ec < nc) { ml[2 * (eh * 128 + ec)] = mv.x; ml[2 * (eh * 128 + ec) + 1] = mv.y; }
+        for (int e = threadIdx.x + NTH; e < H * nc_launch; e += NTH) {  // only when H * nc_launch > NTH (very long sequences)
+            const int h = e / nc_launch, c = e % nc_launch;
+            if (c >= nc) continue;
             const float2 t2 = *reinterpret_cast<const float2*>(part + ((size_t)h * n_chunks_max + c) * (DH + 2) + DH);
             ml[2 * (h * 128 + c)] = t2.x;
             ml[2 * (h * 128 + c) + 1] = t2.y;
@@ -458,9 +473,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_wo(const float* __restrict__ par
         const int hv = (has_v ? ev : 0) / DH, ddv = ev % DH;
         vec vvv[8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t)
-            vvv[t] = (has_v && t < fused_T) ? *reinterpret_cast<const vec*>(vbase + ((size_t)(hv / n_rep) * KV_PAGE + t) * DH + ddv) : vec(0);
-        if (row < n_rows) R::load_w(W + (size_t)row * K, lane, wv);
+        for (int t = 0; t < 8; ++t)  // unconditional (rows t >= fused_T of the page are stale but in bounds; masked at use)
+            vvv[t] = *reinterpret_cast<const vec*>(vbase + ((size_t)(hv / n_rep) * KV_PAGE + t) * DH + ddv);
+        R::load_w(W + (size_t)min(row, n_rows - 1) * K, lane, wv);
+        FS_ISSUE_FENCE();
         {
             float acc = 0.f;
 #pragma unroll
@@ -524,6 +540,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_ffn_up(const float* __restrict__
     typename R::vec w1[R::NCH], w3[R::NCH];
     R::load_w(W13 + (size_t)(2 * r) * K, lane, w1);
     R::load_w(W13 + (size_t)(2 * r + 1) * K, lane, w3);
+    FS_ISSUE_FENCE();
     R::rmsnorm(xr, nr, eps);
     const float a = wave_sum(R::dot(w1, xr)) * row_scale<WT>(wscale, 2 * r);
     const float b = wave_sum(R::dot(w3, xr)) * row_scale<WT>(wscale, 2 * r + 1);
@@ -546,6 +563,7 @@ __global__ __launch_bounds__(KS * 64) void k_ffn_down(const float* __restrict__ 
     R::load_x(act + wave * (K / KS), lane, xr);
     typename R::vec wv[R::NCH];
     R::load_w(W2 + (size_t)row * K + wave * (K / KS), lane, wv);
+    FS_ISSUE_FENCE();
     const float d = wave_sum(R::dot(wv, xr));
     if (lane == 0) red[wave] = d;
     __syncthreads();
@@ -571,6 +589,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_head(const float* __restrict__ x
     R::load_x(norm_w, lane, nr);
     typename R::vec wv[R::NCH];
     R::load_w(W + (size_t)r * K, lane, wv);
+    FS_ISSUE_FENCE();
     R::rmsnorm(xr, nr, eps);
     const float d = wave_sum(R::dot(wv, xr)) * row_scale<WT>(wscale, r);
     if (lane == 0) logits[r] = d;
@@ -1447,8 +1466,10 @@ void LmKernels<WT>::attn_decode(const ModelDims& d, const float* q, KVView kv, c
 }
 
 template <typename WT>
-void LmKernels<WT>::wo(const ModelDims& d, const float* part, int n_chunks_max, const SeqState* state, const float* q, KVView kv,
-                       int fused_T, const LayerW& w, float* x, hipStream_t st) {
+void LmKernels<WT>::wo(const ModelDims& d, const float* part, int n_chunks_max, int nc_launch, const SeqState* state, const float* q,
+                       KVView kv, int fused_T, const LayerW& w, float* x, hipStream_t st) {
+    if (fused_T <= 0) FS_REQUIRE(nc_launch >= 1 && nc_launch <= n_chunks_max, "bad attention chunk count");
+    else nc_launch = 1;
     constexpr int WAVES = 4;
     const int grid = (d.dim + WAVES - 1) / WAVES;
     FS_REQUIRE(fused_T <= 8 && d.H <= 32 && d.H * 8 * 2 <= WAVES * 64 && d.dim <= 4 * WAVES * 64, "fused attention supports at most 8 cached tokens and 16 heads");
@@ -1458,10 +1479,10 @@ void LmKernels<WT>::wo(const ModelDims& d, const float* part, int n_chunks_max, 
         auto go = [&](auto fused, auto dh) {
             if (w.cache_resident)
                 hipLaunchKernelGGL((k_wo<WT, K, WAVES, decltype(fused)::value, decltype(dh)::value, false>), dim3(grid), dim3(WAVES * 64), 0,
-                                   st, part, n_chunks_max, attn_chunk(), state, q, kv, fused_T, (const WT*)w.wo, x, d.H, d.Hk, d.dim, w.s_o);
+                                   st, part, n_chunks_max, attn_chunk(), state, q, kv, fused_T, (const WT*)w.wo, x, d.H, d.Hk, d.dim, w.s_o, nc_launch);
             else
                 hipLaunchKernelGGL((k_wo<WT, K, WAVES, decltype(fused)::value, decltype(dh)::value, true>), dim3(grid), dim3(WAVES * 64), 0,
-                                   st, part, n_chunks_max, attn_chunk(), state, q, kv, fused_T, (const WT*)w.wo, x, d.H, d.Hk, d.dim, w.s_o);
+                                   st, part, n_chunks_max, attn_chunk(), state, q, kv, fused_T, (const WT*)w.wo, x, d.H, d.Hk, d.dim, w.s_o, nc_launch);
         };
         using T = std::true_type; using F = std::false_type;
         using D64 = std::integral_constant<int, 64>; using D32 = std::integral_constant<int, 32>;

@@ -79,23 +79,23 @@ int main(int argc, char** argv) {
     report("attn_decode (paged, T tokens)", T * 512.0, time_graph(st, N, R, [&](int i) {
         LmKernels<WT>::attn_decode(d, q, kv(i % NL), state, part, NC, NCL, st); }));
     report("wo   (combine + GEMV 1024x1024 + res)", 1024 * 1024 * 2.0, time_graph(st, N, R, [&](int i) {
-        LmKernels<WT>::wo(d, part, NC, state, nullptr, kv(i % NL), 0, lw[i % NL], x, st); }));
+        LmKernels<WT>::wo(d, part, NC, NCL, state, nullptr, kv(i % NL), 0, lw[i % NL], x, st); }));
     report("wo fused attn T=4 (fast decoder)", 1024 * 1024 * 2.0, time_graph(st, N, R, [&](int i) {
-        LmKernels<WT>::wo(d, nullptr, 0, nullptr, q, kv(i % NL), 4, lw[i % NL], x, st); }));
+        LmKernels<WT>::wo(d, nullptr, 0, 0, nullptr, q, kv(i % NL), 4, lw[i % NL], x, st); }));
     report("ffn_up (rmsnorm+GEMV 8192x1024+swiglu)", 2 * 4096 * 1024 * 2.0, time_graph(st, N, R, [&](int i) {
         LmKernels<WT>::ffn_up(d, x, lw[i % NL], act, st); }));
     report("ffn_down (GEMV 1024x4096 + res)", 1024 * 4096 * 2.0, time_graph(st, N, R, [&](int i) {
         LmKernels<WT>::ffn_down(d, act, lw[i % NL], x, st); }));
     report("head 1024 rows (rmsnorm+GEMV)", 1024 * 1024 * 2.0, time_graph(st, N, R, [&](int i) {
-        LmKernels<WT>::head(d, x, norm, lw[i % NL].wo, 1024, logits, st); }));
+        LmKernels<WT>::head(d, x, norm, lw[i % NL].wo, nullptr, 1024, logits, st); }));
     report("head 2037 rows (rmsnorm+GEMV)", 2037 * 1024 * 2.0, time_graph(st, N, R, [&](int i) {
-        LmKernels<WT>::head(d, x, norm, lw[i % NL].w13, 2037, logits, st); }));
+        LmKernels<WT>::head(d, x, norm, lw[i % NL].w13, nullptr, 2037, logits, st); }));
     // whole slow layer / fast layer chains
     float us_slow = time_graph(st, NL, R, [&](int i) {
         const LayerW& w = lw[i % NL]; KVView k = kv(i % NL);
         LmKernels<WT>::qkv(d, x, w, cos_t, sin_t, state, 0, 0, q, k, st);
         LmKernels<WT>::attn_decode(d, q, k, state, part, NC, NCL, st);
-        LmKernels<WT>::wo(d, part, NC, state, nullptr, k, 0, w, x, st);
+        LmKernels<WT>::wo(d, part, NC, NCL, state, nullptr, k, 0, w, x, st);
         LmKernels<WT>::ffn_up(d, x, w, act, st);
         LmKernels<WT>::ffn_down(d, act, w, x, st);
     });
@@ -103,7 +103,7 @@ int main(int argc, char** argv) {
     float us_fast = time_graph(st, NL, R, [&](int i) {
         const LayerW& w = lw[i % NL]; KVView k = kv(i % NL);
         LmKernels<WT>::qkv(d, x, w, cos_t, sin_t, nullptr, 3, 3, q, k, st);
-        LmKernels<WT>::wo(d, nullptr, 0, nullptr, q, k, 4, w, x, st);
+        LmKernels<WT>::wo(d, nullptr, 0, 0, nullptr, q, k, 4, w, x, st);
         LmKernels<WT>::ffn_up(d, x, w, act, st);
         LmKernels<WT>::ffn_down(d, act, w, x, st);
     });

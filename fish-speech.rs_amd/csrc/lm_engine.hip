@@ -67,7 +67,8 @@ void seed_key(uint64_t state, uint32_t* key) {
 }
 
 
-constexpr int kRows = 32;  // activation rows per MFMA pass (lm_kernels.hip PF_M)
+constexpr int kRows = 32;      // static-batch generator: sequences per step (== one 32-row MFMA panel)
+constexpr int kRowsCap = 512;  // row capacity of the MFMA row buffers: prompt tokens per prefill pass
 
 }  // namespace
 
@@ -352,7 +353,7 @@ class LM final : public LMBase {
     void generate_batch(const uint32_t* prompts, const int* lens, int n, int max_new_tokens, const fs_sampling& s, uint64_t seed,
                         uint32_t flags, uint32_t* codes_out, size_t cap, size_t* n_frames) override {
         FS_REQUIRE(n >= 1, "Must have at least one prompt");  // static_batch.rs:69-71
-        if (LmKernels<WT>::has_mfma_prefill() && n <= kRows && n <= B_ && a_.dim % 64 == 0 && a_.intermediate_size % 256 == 0 &&
+        if (LmKernels<WT>::has_mfma_prefill() && n <= kRows && n <= B_ && a_.dim % 128 == 0 && a_.intermediate_size % 128 == 0 &&
             a_.num_codebooks <= 8 && !legacy_) {
             generate_batch_rows(prompts, lens, n, max_new_tokens, s, seed, flags, codes_out, cap, n_frames);
             return;
@@ -725,11 +726,11 @@ class LM final : public LMBase {
     // appending their K/V.  Afterwards x(b) holds the pre-norm hidden state of the last processed token.
     void prefill_tokens(int b, int n, bool use_graph) {
         if (n <= 0) return;
-        if (LmKernels<WT>::has_mfma_prefill() && n > 1 && a_.dim % 64 == 0 && a_.intermediate_size % 256 == 0) {
+        if (LmKernels<WT>::has_mfma_prefill() && n > 1 && a_.dim % 128 == 0 && a_.intermediate_size % 128 == 0) {
             ensure_prefill_buffers();
             RowsCtx c = rows_ctx(state(b), /*pos_step=*/1, /*pt_stride=*/0);
             for (int done = 0; done < n;) {
-                const int M = std::min(kRows, n - done);
+                const int M = std::min(kRowsCap, n - done);
                 c.nc_launch = chunk_bucket(seq_len_[b] + done + M);
                 LmKernels<WT>::prefill_embed(d_, tok_emb_, cb_emb_, a_.num_codebooks, a_.codebook_size, d_cfg_.as<SampleCfg>(),
                                              d_prompt_.as<uint32_t>(), state(b), M, d_pfx_.as<float>(), st_);
@@ -754,12 +755,15 @@ class LM final : public LMBase {
     }
     void ensure_prefill_buffers() {
         if (d_pfx_.p) return;
-        d_pfx_.alloc(sizeof(float) * kRows * a_.dim);
-        d_pfq_.alloc(sizeof(float) * kRows * a_.dim);
-        d_pfslab_.alloc(sizeof(float) * 4 * kRows * a_.dim);
-        d_pfa_.alloc(sizeof(uint16_t) * 2 * kRows * a_.dim);
-        d_pfc_.alloc(sizeof(uint16_t) * 2 * kRows * a_.intermediate_size);
-        d_pfpart_.alloc(sizeof(float) * kRows * (size_t)a_.n_head * n_chunks_ * (a_.head_dim + 2));
+        const int I = a_.intermediate_size;
+        down_split_ = I % 1024 == 0 ? I / 1024 : (I % 256 == 0 ? I / 256 : I / 128);
+        d_pfx_.alloc(sizeof(float) * kRowsCap * a_.dim);
+        d_pfq_.alloc(sizeof(float) * kRowsCap * a_.dim);
+        d_pfslab_.alloc(sizeof(float) * down_split_ * kRowsCap * a_.dim);
+        d_pfa_.alloc(sizeof(uint16_t) * 2 * kRowsCap * a_.dim);
+        d_pfc_.alloc(sizeof(uint16_t) * 2 * kRowsCap * a_.intermediate_size);
+        d_pfpart_.alloc(sizeof(float) * kRowsCap * (size_t)a_.n_head * n_chunks_ * (a_.head_dim + 2));
+        FS_HIP(hipMemsetAsync(d_pfx_.p, 0, d_pfx_.n, st_));
         FS_HIP(hipMemsetAsync(d_pfpart_.p, 0, d_pfpart_.n, st_));
         FS_HIP(hipMemsetAsync(d_pfa_.p, 0, d_pfa_.n, st_));
         FS_HIP(hipMemsetAsync(d_pfc_.p, 0, d_pfc_.n, st_));
@@ -831,8 +835,8 @@ class LM final : public LMBase {
     RowsCtx rows_ctx(const SeqState* st, int pos_step, int pt_stride) {
         RowsCtx c;
         c.X = d_pfx_.as<float>(); c.Q = d_pfq_.as<float>(); c.part = d_pfpart_.as<float>(); c.P = d_pfslab_.as<float>();
-        c.Ahi = d_pfa_.as<uint16_t>(); c.Alo = c.Ahi + (size_t)kRows * a_.dim;
-        c.Chi = d_pfc_.as<uint16_t>(); c.Clo = c.Chi + (size_t)kRows * a_.intermediate_size;
+        c.Mcap = kRowsCap; c.down_split = down_split_;
+        c.A = d_pfa_.as<uint16_t>(); c.C = d_pfc_.as<uint16_t>();
         c.cos_t = d_cos_.as<float>(); c.sin_t = d_sin_.as<float>();
         c.state = st; c.n_chunks_max = n_chunks_; c.nc_launch = n_chunks_; c.pos_step = pos_step; c.pt_stride = pt_stride;
         return c;
@@ -943,7 +947,7 @@ class LM final : public LMBase {
     DevBuf d_rp_mask_, d_rp_seen_, d_rp_ring_, d_rp_meta_;
     DevBuf d_pfx_, d_pfq_, d_pfslab_, d_pfa_, d_pfc_, d_pfpart_;  // MFMA row-path activations (32 rows)
     DevBuf d_xfrows_, d_lrows_, d_lfast_, d_fast_state_, d_fast_table_;  // static-batch generator
-    int ld_slow_ = 0;
+    int ld_slow_ = 0, down_split_ = 4;
     bool batch_warm_ = false;
     std::map<int, hipGraphExec_t> batch_graphs_;
     RepPenState rp_ = {};

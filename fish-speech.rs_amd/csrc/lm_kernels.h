@@ -69,20 +69,24 @@ struct ModelDims {
 
 struct SampleCfg;
 
-// Buffers + row mapping of the MFMA row path (prefill chunks / batched decode).  All activation buffers hold 32 rows.
+// Buffers + row mapping of the MFMA row path (prefill / batched decode).  All activation buffers hold Mcap rows (a multiple
+// of 32: the GEMMs read whole 32-row panels, so rows >= M must exist and hold finite values).
 struct RowsCtx {
-    float* X;            // [32][dim]   residual stream (f32)
-    float* Q;            // [32][dim]   rope'd queries (f32)
-    float* part;         // [32][H][n_chunks_max][Dh + 2] attention partials
-    float* P;            // [4][32][dim] down-projection split-K slabs
-    uint16_t *Ahi, *Alo; // [32][dim]   bf16 hi/lo GEMM input (normed x / attention output)
-    uint16_t *Chi, *Clo; // [32][inter] bf16 hi/lo SwiGLU activations
+    int Mcap;            // row capacity of every buffer below
+    int down_split;      // K ranges (== slabs) of the down projection: inter / down_split must be 1024, 256 or 128
+    float* X;            // [Mcap][dim]   residual stream (f32)
+    float* Q;            // [Mcap][dim]   rope'd queries (f32)
+    float* part;         // [Mcap][H][n_chunks_max][Dh + 2] attention partials
+    float* P;            // [down_split][Mcap][dim] down-projection split-K slabs
+    uint16_t* A;         // [Mcap][dim]   bf16 hi+lo GEMM input (normed x / attention output), fragment-major (lm_kernels.hip frag_off)
+    uint16_t* C;         // [Mcap][inter] bf16 hi+lo SwiGLU activations, fragment-major
     const float *cos_t, *sin_t;
     const SeqState* state;  // position source (row m sits at state->pos + m * pos_step)
     int n_chunks_max;    // stride of `part`
     int nc_launch;       // attention chunks launched (covers the longest row of this pass)
     int pos_step;        // 1: rows = consecutive tokens of one sequence (prefill); 0: rows = sequences (batched decode)
     int pt_stride;       // page-table stride between rows (0 for prefill)
+    unsigned stage_mask = 0xFFu;  // micro-benchmark hook: bit i enables stage i of rows_layer (prep, qkv, attn, combine, wo, prep, w13, w2)
 };
 
 // ---- launchers (all asynchronous on `st`) -------------------------------------------------------------------
@@ -119,7 +123,7 @@ struct LmKernels {
     static void prefill_embed(const ModelDims& d, const void* tok_emb, const void* cb_emb, int n_cb, int cb_size,
                               const SampleCfg* cfg, const uint32_t* prompt, const SeqState* state, int M, float* X,
                               hipStream_t st);
-    // one transformer block over M <= 32 activation rows (X updated in place up to the down-projection, whose split-K
+    // one transformer block over M <= Mcap activation rows (X updated in place up to the down-projection, whose split-K
     // slabs are folded in by the NEXT rows_layer / rows_finish):
     //   x += slabs | rmsnorm+Wqkv+rope+KV append | attention over the paged cache | Wo + residual | rmsnorm+W13+SwiGLU | W2 slabs
     static void rows_layer(const ModelDims& d, int M, const RowsCtx& c, const LayerW& w, KVView kv, bool first, hipStream_t st);

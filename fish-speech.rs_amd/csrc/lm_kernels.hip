@@ -671,10 +671,20 @@ __device__ __forceinline__ void split_bf16(float a, bf16_t& hi, bf16_t& lo) {
     lo = WTr<bf16_t>::from_f32(a - WTr<bf16_t>::to_f32(hi));
 }
 
-// X[m] (+= sum_s P[s][m], fixed order) ; optional RMSNorm ; emit bf16 hi/lo [PF_M][D].  One block per row.
+// GEMM-input layout ("fragment-major"): the bf16 hi/lo activations are stored exactly as the MFMA B operand wants them, so
+// that every wave-wide operand load of k_gemm3 is ONE contiguous KiB (8 full cache lines) instead of 16 half lines strided
+// by a row (measured: the strided form cost 3.3 us of a 7 us GEMM node).  Element (row m, depth k, part hi=0 / lo=1) of a
+// [rows][K] activation matrix lives at (in bf16 elements)
+//     (((((m / 32) * (K / 32) + k / 32) * 2 + part) * 2 + (m / 16) % 2) * 64 + ((k / 8) % 4) * 16 + m % 16) * 8 + k % 8
+// i.e. [32-row panel][32-deep k-step][part][16-row tile][lane = kq*16 + row][8 consecutive k].
+__device__ __forceinline__ size_t frag_off(int m, int k, int part, int K) {
+    const int p = m >> 5, mt = (m >> 4) & 1, lr = m & 15, kk = k >> 5, lq = (k >> 3) & 3, e = k & 7;
+    return (((((size_t)p * (K >> 5) + kk) * 2 + part) * 2 + mt) * 64 + (lq * 16 + lr)) * 8 + e;
+}
+
+// X[m] (+= sum_s P[s][m], fixed order) ; optional RMSNorm ; emit bf16 hi/lo (fragment-major).  One block per row.
 __global__ __launch_bounds__(256) void k_prep(float* __restrict__ X, int D, const float* __restrict__ P, int S, size_t slab_stride,
-                                              const float* __restrict__ norm_w, float eps, bf16_t* __restrict__ Ohi,
-                                              bf16_t* __restrict__ Olo) {
+                                              const float* __restrict__ norm_w, float eps, bf16_t* __restrict__ Ohi) {
     __shared__ float red[4];
     const int m = blockIdx.x;
     float* xm = X + (size_t)m * D;
@@ -709,135 +719,132 @@ __global__ __launch_bounds__(256) void k_prep(float* __restrict__ X, int D, cons
         uint2 ph, pl;
         ph.x = hi[0] | ((uint32_t)hi[1] << 16); ph.y = hi[2] | ((uint32_t)hi[3] << 16);
         pl.x = lo[0] | ((uint32_t)lo[1] << 16); pl.y = lo[2] | ((uint32_t)lo[3] << 16);
-        *reinterpret_cast<uint2*>(Ohi + (size_t)m * D + e) = ph;
-        *reinterpret_cast<uint2*>(Olo + (size_t)m * D + e) = pl;
+        *reinterpret_cast<uint2*>(Ohi + frag_off(m, e, 0, D)) = ph;
+        *reinterpret_cast<uint2*>(Ohi + frag_off(m, e, 1, D)) = pl;
     }
 }
 
-// One block = 64 weight rows (4 waves x 16) x KB <= 1024 of K x all 32 activation rows.  The block's activation panel
-// (hi + lo, 32 x KB bf16 each) is staged ONCE into LDS; each wave's whole weight panel (16 rows x KB) goes in flight at
-// kernel entry (GEMV-style, <= 32 x 16 B per lane), so the kernel costs one HBM round trip plus KB/32 MFMA steps whose
-// B fragments are double-buffered out of LDS.
-template <int KB> struct GemmGeom {
-    static constexpr int LD = KB + 8;                                   // padded LDS row (bf16 elements)
-    static constexpr size_t LDS = (size_t)2 * PF_M * LD * sizeof(bf16_t); // hi + lo panels
-    static constexpr int NKS = KB / 32;                                  // MFMA k-steps
-    static constexpr int VPR = KB / 8;                                   // 16-B vectors per activation row
-    static constexpr int NVX = 2 * PF_M * VPR / 256;                     // staging vectors per thread (both parts)
-};
-
-template <int EPI, int KB>
-__global__ __launch_bounds__(256) void k_gemm2(const bf16_t* __restrict__ Xhi, const bf16_t* __restrict__ Xlo, int M, int K,
-                                               const bf16_t* __restrict__ W, int N, float* __restrict__ Y, int ldy,
-                                               bf16_t* __restrict__ Ohi, bf16_t* __restrict__ Olo, int ldo,
+// Block = 16*RT weight rows x one K range of 128*NKS (the 4 waves take a quarter each, NKS k-steps of 32) x ALL activation
+// rows, 32 at a time.  No LDS staging and no barrier in front of the MFMAs: a wave puts its whole weight panel in flight at
+// kernel entry (A operand, non-temporal, kept in VGPRs for every row panel), then per 32-row panel loads its B operands
+// (hi + lo slices of the activations, 16 B per lane per slice, L2-resident) straight into VGPRs and runs NKS * RT * 4 MFMAs.
+// The four K-quarter accumulators meet in 8 KB of LDS and are summed in a fixed order; the epilogue gives every thread
+// one (row pair, m) so RoPE pairs and SwiGLU (w1[r], w3[r]) pairs stay in one lane.  Small grids were the problem of the
+// first version of this kernel (64-row blocks: 20 blocks for Wqkv); 16-row blocks give 80 / 64 / 512 (256 with RT = 2) / 256.
+template <int EPI, int NKS, int RT>
+__global__ __launch_bounds__(256) void k_gemm3(const bf16_t* __restrict__ Xf, int M, int K,
+                                               const bf16_t* __restrict__ W, int N, float* __restrict__ Y, int ldy, size_t slab_stride,
+                                               bf16_t* __restrict__ Of, int ldo,
                                                const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                const SeqState* __restrict__ state, KVView kv, int H, int Hk, int Dh, RowMap rm) {
-    using GG = GemmGeom<KB>;
-    extern __shared__ __attribute__((aligned(16))) bf16_t xs_dyn[];  // [2 parts][PF_M][LD]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int n0 = blockIdx.x * 64 + wave * 16;  // this wave's 16 weight rows
-    const int kbeg = blockIdx.y * KB;            // split-K: blockIdx.y-th K range (K == gridDim.y * KB)
-    // ---- activation panel -> LDS.  Vector v = i * 256 + tid of the [2 parts][PF_M rows][VPR] grid: consecutive lanes read
-    // consecutive 16-B pieces of one row (coalesced) and write consecutive LDS words (conflict-free).
-    constexpr int NVX = GG::NVX, VPR = GG::VPR, HALF = (NVX + 1) / 2;
-    auto xsrc = [&](int i) {
-        const int v = i * 256 + (int)threadIdx.x, part = v / (PF_M * VPR), r = (v / VPR) % PF_M, cv = v % VPR;
-        return (part ? Xlo : Xhi) + (size_t)r * K + kbeg + cv * 8;
-    };
-    auto xdst = [&](int i) {
-        const int v = i * 256 + (int)threadIdx.x, part = v / (PF_M * VPR), r = (v / VPR) % PF_M, cv = v % VPR;
-        return xs_dyn + ((size_t)part * PF_M + r) * GG::LD + cv * 8;
-    };
-    u32x4 xr[HALF];
+    constexpr int ROWS = 16 * RT;
+    __shared__ float red[4][ROWS][33];
+    const int lane = threadIdx.x & 63, kq = threadIdx.x >> 6;
+    const int n0 = blockIdx.x * ROWS;
+    const int kbeg = ((int)blockIdx.y * 4 + kq) * NKS * 32 + (lane >> 4) * 8;  // this lane's first k of every 32-wide step (weights)
+    int pos0 = 0, rope_off = 0;
+    if (EPI == EPI_QKV) { pos0 = state->pos; rope_off = state->rope_off; }  // requested up front: the epilogue must not start a dependent chain
+    u32x4 wf[RT][NKS];
 #pragma unroll
-    for (int i = 0; i < HALF; ++i) xr[i] = *reinterpret_cast<const u32x4*>(xsrc(i));
-    // ---- the wave's whole weight panel in flight (non-temporal, straight to VGPRs)
-    const int wrow = min(n0 + (lane & 15), N - 1);
-    const bf16_t* wp = W + (size_t)wrow * K + kbeg + (lane >> 4) * 8;
-    u32x4 wf[GG::NKS];
+    for (int rt = 0; rt < RT; ++rt) {
+        const bf16_t* wp = W + (size_t)min(n0 + rt * 16 + (lane & 15), N - 1) * K + kbeg;
 #pragma unroll
-    for (int ks = 0; ks < GG::NKS; ++ks) wf[ks] = ld_stream(reinterpret_cast<const u32x4*>(wp + ks * 32));
-#pragma unroll
-    for (int i = 0; i < HALF; ++i) *reinterpret_cast<u32x4*>(xdst(i)) = xr[i];
-#pragma unroll
-    for (int i = 0; i < NVX - HALF; ++i) xr[i] = *reinterpret_cast<const u32x4*>(xsrc(HALF + i));
-#pragma unroll
-    for (int i = 0; i < NVX - HALF; ++i) *reinterpret_cast<u32x4*>(xdst(HALF + i)) = xr[i];
-    __syncthreads();
-    // ---- MFMA loop: B fragments (2 column tiles x hi/lo) double-buffered out of LDS
-    f32x4v acc[2];
-    acc[0] = f32x4v{0.f, 0.f, 0.f, 0.f};
-    acc[1] = f32x4v{0.f, 0.f, 0.f, 0.f};
-    const bf16_t* bbase = xs_dyn + (size_t)(lane & 15) * GG::LD + (lane >> 4) * 8;
-    auto ldb = [&](int ks, u32x4 (&f)[4]) {
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            f[mt * 2] = *reinterpret_cast<const u32x4*>(bbase + (size_t)mt * 16 * GG::LD + ks * 32);                       // hi
-            f[mt * 2 + 1] = *reinterpret_cast<const u32x4*>(bbase + ((size_t)PF_M + mt * 16) * GG::LD + ks * 32);         // lo
-        }
-    };
-    u32x4 bf0[4], bf1[4];
-    ldb(0, bf0);
-#pragma unroll
-    for (int ks = 0; ks < GG::NKS; ks += 2) {
-        if (ks + 1 < GG::NKS) ldb(ks + 1, bf1);
-        {
-            const bf16x8 af = __builtin_bit_cast(bf16x8, wf[ks]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[j >> 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, bf0[j]), acc[j >> 1], 0, 0, 0);
-        }
-        if (ks + 2 < GG::NKS) ldb(ks + 2, bf0);
-        if (ks + 1 < GG::NKS) {
-            const bf16x8 af = __builtin_bit_cast(bf16x8, wf[ks + 1]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[j >> 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, bf1[j]), acc[j >> 1], 0, 0, 0);
+        for (int ks = 0; ks < NKS; ++ks) {
+#if defined(FS_GEMM_DBG) && FS_GEMM_DBG == 2
+            wf[rt][ks] = u32x4(0x3c003c00u) + (unsigned)(size_t)wp;
+#else
+            wf[rt][ks] = ld_stream(reinterpret_cast<const u32x4*>(wp + ks * 32));
+#endif
         }
     }
-    // epilogue: lane holds C[row = n0 + (lane>>4)*4 + i][m = mt*16 + (lane&15)], i = 0..3
-    const int r0 = n0 + (lane >> 4) * 4;
-    if (r0 >= N) return;
+    // row panels are spread over blockIdx.z (prefill: many panels -> more blocks; the weight tile is then re-read from L2)
+    bool first_panel = true;
+    for (int mp = (int)blockIdx.z * PF_M; mp < M; mp += (int)gridDim.z * PF_M) {
+        // B operands of this panel (fragment-major: [k-step][hi, lo][16-row tile] blocks of one KiB each, lane-major)
+        const bf16_t* xp = Xf + ((size_t)(mp >> 5) * (K >> 5) + ((int)blockIdx.y * 4 + kq) * NKS) * 2048 + lane * 8;
+        u32x4 xf[NKS][4];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int m = mt * 16 + (lane & 15);
-        if (m >= M) continue;
-        const f32x4v c = acc[mt];
-        if (EPI == EPI_STORE) {  // split-K slab blockIdx.y
-            *reinterpret_cast<float4*>(Y + (size_t)blockIdx.y * PF_M * ldy + (size_t)m * ldy + r0) = make_float4(c.x, c.y, c.z, c.w);
-        } else if (EPI == EPI_RESIDUAL) {
-            float4* yp = reinterpret_cast<float4*>(Y + (size_t)m * ldy + r0);
-            const float4 o = *yp;
-            *yp = make_float4(o.x + c.x, o.y + c.y, o.z + c.z, o.w + c.w);
-        } else if (EPI == EPI_SWIGLU) {  // interleaved rows (2r, 2r+1) = (w1[r], w3[r]) -> act hi/lo for the down GEMM
-            const float a0 = (c.x / (1.f + __expf(-c.x))) * c.y, a1 = (c.z / (1.f + __expf(-c.z))) * c.w;
-            bf16_t h0, l0, h1, l1;
-            split_bf16(a0, h0, l0); split_bf16(a1, h1, l1);
-            *reinterpret_cast<uint32_t*>(Ohi + (size_t)m * ldo + r0 / 2) = h0 | ((uint32_t)h1 << 16);
-            *reinterpret_cast<uint32_t*>(Olo + (size_t)m * ldo + r0 / 2) = l0 | ((uint32_t)l1 << 16);
-        } else {  // EPI_QKV: rope_i + scatter (q -> Y[m][r], k/v -> paged cache of row m's sequence)
-            const int pos = state->pos + m * rm.pos_step, rpos = pos + state->rope_off;
-            const int* ptab = kv.page_table + (size_t)m * rm.pt_stride;
-            const int qdim = H * Dh, kdim = Hk * Dh, half = Dh / 2;
-            const float vals[4] = {c.x, c.y, c.z, c.w};
+        for (int ks = 0; ks < NKS; ++ks) {
+#if defined(FS_GEMM_DBG) && FS_GEMM_DBG == 1
+            xf[ks][0] = xf[ks][1] = xf[ks][2] = xf[ks][3] = u32x4(0x3c003c00u) + (unsigned)(size_t)xp;
+            continue;
+#endif
+            xf[ks][0] = *reinterpret_cast<const u32x4*>(xp + ks * 2048);          // hi, rows 0..15
+            xf[ks][1] = *reinterpret_cast<const u32x4*>(xp + ks * 2048 + 1024);   // lo, rows 0..15
+            xf[ks][2] = *reinterpret_cast<const u32x4*>(xp + ks * 2048 + 512);    // hi, rows 16..31
+            xf[ks][3] = *reinterpret_cast<const u32x4*>(xp + ks * 2048 + 1536);   // lo, rows 16..31
+        }
+        FS_ISSUE_FENCE();  // every operand load of the panel is in flight before the first MFMA waits (the scheduler would
+                           // otherwise meter them out a dozen at a time, one memory round trip per batch)
+        f32x4v acc[RT][2];
 #pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-                const int r = r0 + 2 * pr;
-                const float a = vals[2 * pr], b = vals[2 * pr + 1];
+        for (int rt = 0; rt < RT; ++rt) { acc[rt][0] = f32x4v{0.f, 0.f, 0.f, 0.f}; acc[rt][1] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const bf16x8 af = __builtin_bit_cast(bf16x8, wf[rt][ks]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[rt][j >> 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, xf[ks][j]), acc[rt][j >> 1], 0, 0, 0);
+            }
+        if (!first_panel) __syncthreads();  // the previous panel's epilogue has read `red`
+        first_panel = false;
+        // lane holds C[row = rt*16 + (lane>>4)*4 + i][m = mt*16 + (lane&15)]
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const f32x4v c = acc[rt][mt];
+                float* rp = &red[kq][rt * 16 + (lane >> 4) * 4][mt * 16 + (lane & 15)];
+                rp[0] = c.x; rp[33] = c.y; rp[66] = c.z; rp[99] = c.w;
+            }
+        __syncthreads();
+        // epilogue: slot = (row pair, m); K-quarters summed in a fixed order
+#pragma unroll
+        for (int sI = 0; sI < RT; ++sI) {
+            const int slot = sI * 256 + (int)threadIdx.x;
+            const int pr = slot % (ROWS / 2), ml = slot / (ROWS / 2);
+            const int r = n0 + 2 * pr, m = mp + ml;
+            const float a = (red[0][2 * pr][ml] + red[1][2 * pr][ml]) + (red[2][2 * pr][ml] + red[3][2 * pr][ml]);
+            const float b = (red[0][2 * pr + 1][ml] + red[1][2 * pr + 1][ml]) + (red[2][2 * pr + 1][ml] + red[3][2 * pr + 1][ml]);
+            if (r >= N || m >= M) continue;
+#if defined(FS_GEMM_DBG) && FS_GEMM_DBG == 3
+            if (a + b == 12345.678f) Y[0] = a;
+            continue;
+#endif
+            if (EPI == EPI_STORE) {  // split-K slab blockIdx.y
+                float* yp = Y + (size_t)blockIdx.y * slab_stride + (size_t)m * ldy + r;
+                yp[0] = a;
+                if (r + 1 < N) yp[1] = b;
+            } else if (EPI == EPI_RESIDUAL) {
+                float2* yp = reinterpret_cast<float2*>(Y + (size_t)m * ldy + r);
+                const float2 o = *yp;
+                *yp = make_float2(o.x + a, o.y + b);
+            } else if (EPI == EPI_SWIGLU) {  // interleaved rows (2r, 2r+1) = (w1[r], w3[r]) -> act hi/lo for the down GEMM
+                const float v = (a / (1.f + __expf(-a))) * b;
+                bf16_t h, l;
+                split_bf16(v, h, l);
+                Of[frag_off(m, r / 2, 0, ldo)] = h;
+                Of[frag_off(m, r / 2, 1, ldo)] = l;
+            } else {  // EPI_QKV: rope_i + scatter (q -> Y[m][r], k/v -> paged cache of row m's sequence)
+                const int pos = pos0 + m * rm.pos_step, rpos = pos + rope_off;
+                const int* ptab = kv.page_table + (size_t)m * rm.pt_stride;
+                const int qdim = H * Dh, kdim = Hk * Dh, half = Dh / 2;
                 if (r < qdim + kdim) {
                     const int j = (r % Dh) / 2;
                     const float cs = cos_t[(size_t)rpos * half + j], sn = sin_t[(size_t)rpos * half + j];
                     const float o0 = a * cs - b * sn, o1 = a * sn + b * cs;
-                    if (r < qdim) { Y[(size_t)m * ldy + r] = o0; Y[(size_t)m * ldy + r + 1] = o1; }
+                    if (r < qdim) { *reinterpret_cast<float2*>(Y + (size_t)m * ldy + r) = make_float2(o0, o1); }
                     else {
                         const int rk = r - qdim;
                         bf16_t* dst = kv_addr<bf16_t>(kv.k, ptab, pos, rk / Dh, Hk, Dh) + rk % Dh;
-                        dst[0] = WTr<bf16_t>::from_f32(o0); dst[1] = WTr<bf16_t>::from_f32(o1);
+                        *reinterpret_cast<uint32_t*>(dst) = WTr<bf16_t>::from_f32(o0) | ((uint32_t)WTr<bf16_t>::from_f32(o1) << 16);
                     }
                 } else {
                     const int rv = r - qdim - kdim;
                     bf16_t* dst = kv_addr<bf16_t>(kv.v, ptab, pos, rv / Dh, Hk, Dh) + rv % Dh;
-                    dst[0] = WTr<bf16_t>::from_f32(a); dst[1] = WTr<bf16_t>::from_f32(b);
+                    *reinterpret_cast<uint32_t*>(dst) = WTr<bf16_t>::from_f32(a) | ((uint32_t)WTr<bf16_t>::from_f32(b) << 16);
                 }
             }
         }
@@ -847,8 +854,7 @@ __global__ __launch_bounds__(256) void k_gemm2(const bf16_t* __restrict__ Xhi, c
 // combine the per-chunk attention partials of M rows -> attn hi/lo bf16 [PF_M][H*DH] (input of the Wo GEMM)
 template <int DH>
 __global__ __launch_bounds__(256) void k_attn_combine(const float* __restrict__ part_all, int n_chunks_max, int chunk,
-                                                      const SeqState* __restrict__ state, int pos_step, bf16_t* __restrict__ Ohi,
-                                                      bf16_t* __restrict__ Olo, int H) {
+                                                      const SeqState* __restrict__ state, int pos_step, bf16_t* __restrict__ Ohi, int H) {
     const int m = blockIdx.x;
     const int T = state->pos + 1 + m * pos_step, nc = (T + chunk - 1) / chunk;
     const float* part = part_all + (size_t)m * H * n_chunks_max * (DH + 2);
@@ -870,8 +876,8 @@ __global__ __launch_bounds__(256) void k_attn_combine(const float* __restrict__ 
         for (int c = 0; c < nc; ++c) O = fmaf(wl[h * 128 + c], p[c * (DH + 2)], O);
         bf16_t hi, lo;
         split_bf16(O, hi, lo);
-        Ohi[(size_t)m * H * DH + e] = hi;
-        Olo[(size_t)m * H * DH + e] = lo;
+        Ohi[frag_off(m, e, 0, H * DH)] = hi;
+        Ohi[frag_off(m, e, 1, H * DH)] = lo;
     }
 }
 
@@ -1653,35 +1659,35 @@ void LmKernels<WT>::prefill_embed(const ModelDims& d, const void* tok_emb, const
     FS_LAUNCH_CHECK();
 }
 
+// Y[M, N] (+)= f(X[M, K]) . W[N, K]^T over `ksplit` K ranges (slabs Y + s * slab_stride for EPI_STORE); rt = 16-row tiles
+// per wave (2 halves the L2 re-reads of the activations for the wide W13 GEMM)
 template <int EPI>
-static void gemm2_set_attr() {
-    static bool attr_set = false;
-    if (!attr_set) {
-        FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2<EPI, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)GemmGeom<1024>::LDS));
-        attr_set = true;
-    }
-}
-
-template <int EPI>
-static void launch_gemm2(int n_blocks_n, int ksplit, hipStream_t st, const bf16_t* Xhi, const bf16_t* Xlo, int M, int K, const bf16_t* W, int N,
-                         float* Y, int ldy, bf16_t* Ohi, bf16_t* Olo, int ldo, const float* cos_t, const float* sin_t,
+static void launch_gemm3(int N, int ksplit, int rt, hipStream_t st, const bf16_t* Xf, int M, int K, const bf16_t* W,
+                         float* Y, int ldy, size_t slab_stride, bf16_t* Of, int ldo, const float* cos_t, const float* sin_t,
                          const SeqState* state, KVView kv, int H, int Hk, int Dh, RowMap rm) {
-    gemm2_set_attr<EPI>();
-    FS_REQUIRE(K % ksplit == 0, "GEMM depth not divisible by the K split");
-    const int KB = K / ksplit;
-    const dim3 grid(n_blocks_n, ksplit);
-#define FS_GEMM_CASE(kb)                                                                                                          \
-    case kb:                                                                                                                      \
-        hipLaunchKernelGGL((k_gemm2<EPI, kb>), grid, dim3(256), GemmGeom<kb>::LDS, st, Xhi, Xlo, M, K, W, N, Y, ldy, Ohi, Olo, ldo, cos_t, \
-                           sin_t, state, kv, H, Hk, Dh, rm);                                                                       \
-        break;
-    switch (KB) {
-        FS_GEMM_CASE(1024)
-        FS_GEMM_CASE(256)
-        FS_GEMM_CASE(128)
-        FS_GEMM_CASE(64)
-        default: throw Error("unsupported per-block GEMM depth " + std::to_string(KB) + " (supported: 1024, 256, 128, 64)");
+    FS_REQUIRE(K % (ksplit * 128) == 0, "GEMM depth must be a multiple of 128 per K range");
+    const int nks = K / ksplit / 128;
+    // enough blocks to fill 256 CUs a few times over: spread the row panels over blockIdx.z until ~1024 blocks
+    const int nb = (N + 16 * rt - 1) / (16 * rt) * ksplit, panels = (M + PF_M - 1) / PF_M;
+    const int gz = std::max(1, std::min(panels, 1024 / std::max(1, nb)));
+    const dim3 grid((N + 16 * rt - 1) / (16 * rt), ksplit, gz);
+#define FS_GEMM_CASE(nk, r)                                                                                                          \
+    hipLaunchKernelGGL((k_gemm3<EPI, nk, r>), grid, dim3(256), 0, st, Xf, M, K, W, N, Y, ldy, slab_stride, Of, ldo, cos_t,  \
+                       sin_t, state, kv, H, Hk, Dh, rm)
+    if (rt == 2) {
+        switch (nks) {
+            case 8: FS_GEMM_CASE(8, 2); break;
+            case 2: FS_GEMM_CASE(2, 2); break;
+            case 1: FS_GEMM_CASE(1, 2); break;
+            default: throw Error("unsupported GEMM depth per K range " + std::to_string(K / ksplit) + " (supported: 1024, 256, 128)");
+        }
+    } else {
+        switch (nks) {
+            case 8: FS_GEMM_CASE(8, 1); break;
+            case 2: FS_GEMM_CASE(2, 1); break;
+            case 1: FS_GEMM_CASE(1, 1); break;
+            default: throw Error("unsupported GEMM depth per K range " + std::to_string(K / ksplit) + " (supported: 1024, 256, 128)");
+        }
     }
 #undef FS_GEMM_CASE
 }
@@ -1691,24 +1697,24 @@ void LmKernels<WT>::rows_layer(const ModelDims& d, int M, const RowsCtx& c, cons
     if constexpr (!std::is_same<WT, bf16_t>::value) {
         throw Error("the MFMA row path is implemented for bf16 weights only");
     } else {
-        FS_REQUIRE(M >= 1 && M <= PF_M, "at most 32 activation rows per pass");
-        FS_REQUIRE(d.dim % 256 == 0 && d.inter % 256 == 0 || (d.dim % PF_BK == 0 && d.inter % (PF_BK * 4) == 0),
-                   "row path needs dim % 64 == 0 and intermediate_size % 256 == 0");
+        FS_REQUIRE(M >= 1 && M <= c.Mcap, "more activation rows than the row buffers hold");
+        FS_REQUIRE(d.dim % 128 == 0 && d.inter % 128 == 0, "row path needs dim % 128 == 0 and intermediate_size % 128 == 0");
         const int qkv_rows = (d.H + 2 * d.Hk) * d.Dh;
         const RowMap rm{c.pos_step, c.pt_stride};
         const RowMap none{0, 0};
         KVView nokv = {};
-        const size_t slab = (size_t)PF_M * d.dim;
-        constexpr int DOWN_SPLIT = 4;
+        const size_t slab = (size_t)c.Mcap * d.dim;
+        const int DOWN_SPLIT = c.down_split;
         // (1) x += previous layer's down-proj slabs ; RMSNorm(attention_norm) -> hi/lo
-        hipLaunchKernelGGL(k_prep, dim3(M), dim3(256), 0, st, c.X, d.dim, c.P, first ? 0 : DOWN_SPLIT, slab, w.attn_norm, d.eps, c.Ahi, c.Alo);
+        if (c.stage_mask & 1u) hipLaunchKernelGGL(k_prep, dim3(M), dim3(256), 0, st, c.X, d.dim, c.P, first ? 0 : DOWN_SPLIT, slab, w.attn_norm, d.eps, c.A);
         // (2) Wqkv + rope + KV scatter
-        launch_gemm2<EPI_QKV>((qkv_rows + 63) / 64, 1, st, c.Ahi, c.Alo, M, d.dim, (const bf16_t*)w.wqkv, qkv_rows, c.Q, d.dim,
-                              nullptr, nullptr, 0, c.cos_t, c.sin_t, c.state, kv, d.H, d.Hk, d.Dh, rm);
+        if (c.stage_mask & 2u) launch_gemm3<EPI_QKV>(qkv_rows, 1, 1, st, c.A, M, d.dim, (const bf16_t*)w.wqkv, c.Q, d.dim, 0, nullptr, 0,
+                              c.cos_t, c.sin_t, c.state, kv, d.H, d.Hk, d.Dh, rm);
         // (3) attention over each row's KV prefix + chunk combine -> hi/lo
         const dim3 ga(d.Hk * c.nc_launch, M);
         const dim3 ta(AttnGeom<WT>::NW * 64);
-        if (d.Dh == 64 && d.n_rep == 8)
+        if (!(c.stage_mask & 4u)) {}
+        else if (d.Dh == 64 && d.n_rep == 8)
             hipLaunchKernelGGL((k_attn_decode<WT, 64, 8>), ga, ta, 0, st, c.Q, kv, c.state, c.part, d.Hk, c.n_chunks_max, c.nc_launch, c.pos_step, c.pt_stride);
         else if (d.Dh == 32 && d.n_rep == 2)
             hipLaunchKernelGGL((k_attn_decode<WT, 32, 2>), ga, ta, 0, st, c.Q, kv, c.state, c.part, d.Hk, c.n_chunks_max, c.nc_launch, c.pos_step, c.pt_stride);
@@ -1716,34 +1722,33 @@ void LmKernels<WT>::rows_layer(const ModelDims& d, int M, const RowsCtx& c, cons
             hipLaunchKernelGGL((k_attn_decode<WT, 64, 2>), ga, ta, 0, st, c.Q, kv, c.state, c.part, d.Hk, c.n_chunks_max, c.nc_launch, c.pos_step, c.pt_stride);
         else
             throw Error("unsupported attention geometry");
-        if (d.Dh == 64)
-            hipLaunchKernelGGL((k_attn_combine<64>), dim3(M), dim3(256), 0, st, c.part, c.n_chunks_max, attn_chunk(), c.state, c.pos_step, c.Ahi, c.Alo, d.H);
+        if (!(c.stage_mask & 8u)) {}
+        else if (d.Dh == 64)
+            hipLaunchKernelGGL((k_attn_combine<64>), dim3(M), dim3(256), 0, st, c.part, c.n_chunks_max, attn_chunk(), c.state, c.pos_step, c.A, d.H);
         else
-            hipLaunchKernelGGL((k_attn_combine<32>), dim3(M), dim3(256), 0, st, c.part, c.n_chunks_max, attn_chunk(), c.state, c.pos_step, c.Ahi, c.Alo, d.H);
+            hipLaunchKernelGGL((k_attn_combine<32>), dim3(M), dim3(256), 0, st, c.part, c.n_chunks_max, attn_chunk(), c.state, c.pos_step, c.A, d.H);
         // (4) Wo + residual (each output element owned by one lane: deterministic)
-        launch_gemm2<EPI_RESIDUAL>((d.dim + 63) / 64, 1, st, c.Ahi, c.Alo, M, d.dim, (const bf16_t*)w.wo, d.dim, c.X, d.dim, nullptr,
-                                   nullptr, 0, nullptr, nullptr, nullptr, nokv, 0, 0, 0, none);
+        if (c.stage_mask & 16u) launch_gemm3<EPI_RESIDUAL>(d.dim, 1, 1, st, c.A, M, d.dim, (const bf16_t*)w.wo, c.X, d.dim, 0, nullptr, 0,
+                                   nullptr, nullptr, nullptr, nokv, 0, 0, 0, none);
         // (5) RMSNorm(ffn_norm) -> hi/lo ; W1||W3 + SwiGLU -> act hi/lo ; W2 split-K slabs (summed by the next k_prep)
-        hipLaunchKernelGGL(k_prep, dim3(M), dim3(256), 0, st, c.X, d.dim, (const float*)nullptr, 0, slab, w.ffn_norm, d.eps, c.Ahi, c.Alo);
-        launch_gemm2<EPI_SWIGLU>((2 * d.inter + 63) / 64, 1, st, c.Ahi, c.Alo, M, d.dim, (const bf16_t*)w.w13, 2 * d.inter, nullptr, 0,
-                                 c.Chi, c.Clo, d.inter, nullptr, nullptr, nullptr, nokv, 0, 0, 0, none);
-        launch_gemm2<EPI_STORE>((d.dim + 63) / 64, DOWN_SPLIT, st, c.Chi, c.Clo, M, d.inter, (const bf16_t*)w.w2, d.dim, c.P,
-                                d.dim, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nokv, 0, 0, 0, none);
+        if (c.stage_mask & 32u) hipLaunchKernelGGL(k_prep, dim3(M), dim3(256), 0, st, c.X, d.dim, (const float*)nullptr, 0, slab, w.ffn_norm, d.eps, c.A);
+        if (c.stage_mask & 64u) launch_gemm3<EPI_SWIGLU>(2 * d.inter, 1, 2, st, c.A, M, d.dim, (const bf16_t*)w.w13, nullptr, 0, 0, c.C, d.inter,
+                                 nullptr, nullptr, nullptr, nokv, 0, 0, 0, none);
+        if (c.stage_mask & 128u) launch_gemm3<EPI_STORE>(d.dim, DOWN_SPLIT, 1, st, c.C, M, d.inter, (const bf16_t*)w.w2, c.P, d.dim, slab, nullptr, 0, nullptr, nullptr,
+                                nullptr, nokv, 0, 0, 0, none);
         FS_LAUNCH_CHECK();
     }
 }
 
-// one-time function attributes (dynamic LDS) -- must happen outside stream capture
+// (kept for API stability: the row kernels need no one-time setup any more)
 template <typename WT>
-void LmKernels<WT>::rows_warmup() {
-    gemm2_set_attr<EPI_STORE>(); gemm2_set_attr<EPI_RESIDUAL>(); gemm2_set_attr<EPI_SWIGLU>(); gemm2_set_attr<EPI_QKV>();
-}
+void LmKernels<WT>::rows_warmup() {}
 
 // x += last layer's down-proj slabs (closes a rows_layer chain); optionally RMSNorm -> hi/lo for a head GEMM
 template <typename WT>
 void LmKernels<WT>::rows_finish(const ModelDims& d, int M, const RowsCtx& c, const float* norm_w, hipStream_t st) {
-    hipLaunchKernelGGL(k_prep, dim3(M), dim3(256), 0, st, c.X, d.dim, c.P, 4, (size_t)PF_M * d.dim, norm_w, d.eps,
-                       norm_w ? c.Ahi : (bf16_t*)nullptr, norm_w ? c.Alo : (bf16_t*)nullptr);
+    hipLaunchKernelGGL(k_prep, dim3(M), dim3(256), 0, st, c.X, d.dim, c.P, c.down_split, (size_t)c.Mcap * d.dim, norm_w, d.eps,
+                       norm_w ? c.A : (bf16_t*)nullptr);
     FS_LAUNCH_CHECK();
 }
 
@@ -1753,11 +1758,11 @@ void LmKernels<WT>::rows_head(const ModelDims& d, int M, const RowsCtx& c, const
     if constexpr (!std::is_same<WT, bf16_t>::value) {
         throw Error("the MFMA row path is implemented for bf16 weights only");
     } else {
-        FS_REQUIRE(ld % 4 == 0 && ld >= ((n_rows + 3) / 4) * 4, "logits row stride must cover n_rows rounded up to 4");
+        FS_REQUIRE(ld >= n_rows, "logits row stride must cover n_rows");
         KVView nokv = {};
         // EPI_STORE with one K range writes slab 0 == the logits matrix itself (row stride ld)
-        launch_gemm2<EPI_STORE>((n_rows + 63) / 64, 1, st, c.Ahi, c.Alo, M, d.dim, (const bf16_t*)W, n_rows, logits, ld, nullptr, nullptr, 0,
-                                nullptr, nullptr, nullptr, nokv, 0, 0, 0, RowMap{0, 0});
+        launch_gemm3<EPI_STORE>(n_rows, 1, 1, st, c.A, M, d.dim, (const bf16_t*)W, logits, ld, 0, nullptr, 0, nullptr, nullptr, nullptr, nokv, 0, 0,
+                                0, RowMap{0, 0});
         FS_LAUNCH_CHECK();
     }
 }

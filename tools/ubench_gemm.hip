@@ -34,20 +34,28 @@ int main(int argc, char** argv) {
     std::vector<LayerW> lw(NL);
     for (int l = 0; l < NL; ++l) { uint8_t* b = arena + per_layer * l; lw[l].wqkv = b; b += (size_t)QKV * 2048; lw[l].wo = b; b += (size_t)2 << 20; lw[l].w13 = b; b += (size_t)16 << 20; lw[l].w2 = b; lw[l].attn_norm = norm; lw[l].ffn_norm = norm; }
     RowsCtx c;
+    c.Mcap = 512; c.down_split = 4;
     auto dalloc = [&](size_t n) { void* p; CK(hipMalloc(&p, n)); CK(hipMemset(p, 0, n)); return p; };
     const int NC = 8192 / LmKernels<WT>::attn_chunk();
-    c.X = (float*)dalloc(64 * 1024 * 4); c.Q = (float*)dalloc(64 * 1024 * 4); c.part = (float*)dalloc((size_t)64 * 16 * NC * 66 * 4);
-    c.P = (float*)dalloc(4 * 64 * 1024 * 4); c.Ahi = (uint16_t*)dalloc(2 * 64 * 1024 * 2); c.Alo = c.Ahi + 64 * 1024;
-    c.Chi = (uint16_t*)dalloc(2 * 64 * 4096 * 2); c.Clo = c.Chi + 64 * 4096;
+    c.X = (float*)dalloc(512 * 1024 * 4); c.Q = (float*)dalloc(512 * 1024 * 4); c.part = (float*)dalloc((size_t)512 * 16 * NC * 66 * 4);
+    c.P = (float*)dalloc(4 * 512 * 1024 * 4); c.A = (uint16_t*)dalloc(2 * 512 * 1024 * 2);
+    c.C = (uint16_t*)dalloc(2 * 512 * 4096 * 2);
     c.cos_t = (float*)dalloc(8192 * 32 * 4); c.sin_t = (float*)dalloc(8192 * 32 * 4);
     SeqState hs = {}; hs.pos = 300; SeqState* state = (SeqState*)dalloc(sizeof(SeqState)); CK(hipMemcpy(state, &hs, sizeof(hs), hipMemcpyHostToDevice));
-    c.state = state; c.n_chunks_max = NC; c.nc_launch = 4; c.pos_step = 1; c.pt_stride = 0;
+    c.state = state; c.n_chunks_max = NC; c.nc_launch = argc > 2 ? atoi(argv[2]) : 4; c.pos_step = argc > 3 ? atoi(argv[3]) : 1; c.pt_stride = 0;
     const int max_pages = 128; const size_t page_elems = 2 * KV_PAGE * 64;
     WT* kvpool = (WT*)dalloc((size_t)NL * 2 * max_pages * page_elems * sizeof(WT));
     std::vector<int> pt(max_pages); for (int i = 0; i < max_pages; ++i) pt[i] = i;
     int* d_pt = (int*)dalloc(max_pages * 4); CK(hipMemcpy(d_pt, pt.data(), max_pages * 4, hipMemcpyHostToDevice));
     auto kv = [&](int l) { KVView v; v.k = kvpool + (size_t)l * 2 * max_pages * page_elems; v.v = (WT*)v.k + max_pages * page_elems; v.page_table = d_pt; return v; };
     float us = time_graph(st, NL, 10, [&](int i) { LmKernels<WT>::rows_layer(d, M, c, lw[i % NL], kv(i % NL), i == 0, st); });
-    printf("rows_layer M=%d: %.1f us per layer (9 nodes) -> %.1f us/node; 24 layers = %.2f ms\n", M, us, us / 9, us * 24 / 1e3);
+    static const char* names[8] = {"prep(attn_norm)", "gemm qkv+rope+kv", "attention", "attn combine", "gemm wo+res", "prep(ffn_norm)", "gemm w13+swiglu", "gemm w2 slabs"};
+    for (int sI = 0; sI < 8; ++sI) {
+        c.stage_mask = 1u << sI;
+        float t = time_graph(st, NL, 10, [&](int i) { LmKernels<WT>::rows_layer(d, M, c, lw[i % NL], kv(i % NL), false, st); });
+        printf("  stage %d %-18s %7.2f us/node\n", sI, names[sI], t);
+    }
+    c.stage_mask = 0xFFu;
+    printf("rows_layer M=%d: %.1f us per layer (8 nodes) -> %.1f us/node; 24 layers = %.2f ms\n", M, us, us / 8, us * 24 / 1e3);
     return 0;
 }

@@ -656,8 +656,6 @@ __global__ void k_advance(SeqState* state) {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 constexpr int PF_M = 32;    // activation rows per pass
-constexpr int PF_BK = 64;   // K-slice
-constexpr int PF_LD = PF_BK + 8;
 
 enum { EPI_STORE = 0, EPI_RESIDUAL = 1, EPI_SWIGLU = 2, EPI_QKV = 3 };
 
@@ -750,11 +748,7 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* __restrict__ Xf, in
         const bf16_t* wp = W + (size_t)min(n0 + rt * 16 + (lane & 15), N - 1) * K + kbeg;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-#if defined(FS_GEMM_DBG) && FS_GEMM_DBG == 2
-            wf[rt][ks] = u32x4(0x3c003c00u) + (unsigned)(size_t)wp;
-#else
             wf[rt][ks] = ld_stream(reinterpret_cast<const u32x4*>(wp + ks * 32));
-#endif
         }
     }
     // row panels are spread over blockIdx.z (prefill: many panels -> more blocks; the weight tile is then re-read from L2)
@@ -765,10 +759,6 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* __restrict__ Xf, in
         u32x4 xf[NKS][4];
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-#if defined(FS_GEMM_DBG) && FS_GEMM_DBG == 1
-            xf[ks][0] = xf[ks][1] = xf[ks][2] = xf[ks][3] = u32x4(0x3c003c00u) + (unsigned)(size_t)xp;
-            continue;
-#endif
             xf[ks][0] = *reinterpret_cast<const u32x4*>(xp + ks * 2048);          // hi, rows 0..15
             xf[ks][1] = *reinterpret_cast<const u32x4*>(xp + ks * 2048 + 1024);   // lo, rows 0..15
             xf[ks][2] = *reinterpret_cast<const u32x4*>(xp + ks * 2048 + 512);    // hi, rows 16..31
@@ -809,10 +799,6 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* __restrict__ Xf, in
             const float a = (red[0][2 * pr][ml] + red[1][2 * pr][ml]) + (red[2][2 * pr][ml] + red[3][2 * pr][ml]);
             const float b = (red[0][2 * pr + 1][ml] + red[1][2 * pr + 1][ml]) + (red[2][2 * pr + 1][ml] + red[3][2 * pr + 1][ml]);
             if (r >= N || m >= M) continue;
-#if defined(FS_GEMM_DBG) && FS_GEMM_DBG == 3
-            if (a + b == 12345.678f) Y[0] = a;
-            continue;
-#endif
             if (EPI == EPI_STORE) {  // split-K slab blockIdx.y
                 float* yp = Y + (size_t)blockIdx.y * slab_stride + (size_t)m * ldy + r;
                 yp[0] = a;
@@ -895,6 +881,13 @@ __global__ void k_advance_n(SeqState* state, int n) {
 }
 
 // ------------------------------------------------------------------------------------------------ sampling
+#if defined(FS_SAMPLE_DBG) && FS_SAMPLE_DBG == 9
+__device__ unsigned long long g_dbg_ts[64];
+#define FS_TS(i) do { if (threadIdx.x == 0) g_dbg_ts[i] = clock64(); } while (0)
+void fs_dbg_read_ts(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg_ts), sizeof(unsigned long long) * 64); }
+#else
+#define FS_TS(i) do {} while (0)
+#endif
 // rand 0.8.5 StdRng == ChaCha12 (rand_chacha 0.3.1): word `n` of the keystream, 64-bit block counter, stream id 0.
 __device__ inline uint32_t chacha12_word(const uint32_t* key, unsigned long long n) {
     const unsigned long long ctr = n >> 4;
@@ -920,8 +913,338 @@ __device__ inline uint32_t chacha12_word(const uint32_t* key, unsigned long long
     return out;
 }
 
+// ---- single-thread sequential f32 chains over an LDS array (the sampler's sums must not depend on a reduction order, so
+// they are evaluated exactly as the scalar reference does: one running f32 sum in ascending order).  A naive loop pays the
+// LDS latency (~100 cycles) per element; these helpers fetch 32 values per step with eight independent 16-byte reads and
+// then run the dependent adds out of registers (~10 cycles per element).  `a` must be 16-byte aligned and readable up to
+// the next multiple of 32; entries >= n count as +0.0 (x + 0.0f == x exactly for the non-negative sums used here).
+__device__ __forceinline__ void lds_fetch32(const float* a, int j, int n, float (&v)[32]) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float4 t = *reinterpret_cast<const float4*>(a + j + 4 * q);
+        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
+    if (j + 32 > n) {  // tail chunk only: the full chunks run without per-element masking
+#pragma unroll
+        for (int e = 0; e < 32; ++e) if (j + e >= n) v[e] = 0.f;
+    }
+}
+__device__ float seq_sum(const float* a, int n) {
+    float sum = 0.f;
+    for (int j = 0; j < n; j += 32) {
+        float v[32];
+        lds_fetch32(a, j, n, v);
+#pragma unroll
+        for (int e = 0; e < 32; ++e) sum += v[e];
+    }
+    return sum;
+}
+// same chain, also leaving the running sums in cum[0..n) (cum may be written up to the next multiple of 32)
+__device__ float seq_sum_prefix(const float* a, int n, float* cum) {
+    float sum = 0.f;
+    for (int j = 0; j < n; j += 32) {
+        float v[32];
+        lds_fetch32(a, j, n, v);
+#pragma unroll
+        for (int e = 0; e < 32; ++e) { sum += v[e]; v[e] = sum; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(cum + j + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    }
+    return sum;
+}
+// top-p cut over probabilities sorted in descending order: the first rank r at which the running sum of sp[0..r) has
+// reached top_p (sampling/mod.rs:117-126); n when it never does
+__device__ int seq_topp_cut(const float* sp, int n, float top_p) {
+    float cumsum = 0.f;
+    for (int j = 0; j < n; j += 32) {
+        float v[32];
+        lds_fetch32(sp, j, n, v);
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+            if (j + e >= n) return n;
+            if (cumsum >= top_p) return j + e;
+            cumsum += v[e];
+        }
+    }
+    return n;
+}
+
 constexpr int SAMPLE_THREADS = 1024;
 constexpr int SAMPLE_MAXN = 4096;  // candidates handled by the sampler (audio range 2037, codebook 1024)
+
+// WeightedIndex::new + sample over the contiguous weights w[0..cnt) (ascending token index; zero weights do not move the
+// cumulative sum): rand 0.8.5 UniformFloat<f32>::sample_single over [0, total) + partition_point on the cumulative weights.
+// Block-wide: thread 0 runs the one sequential f32 chain (leaving the running sums in `cum`), then every thread tests its
+// own entries -- the pick is the FIRST non-zero entry whose inclusive running sum exceeds the draw, else the last non-zero
+// entry.  `word` = the StdRng word for this draw (computed off the critical path by a side wave).  All threads must call.
+__device__ int block_weighted_pick(const float* w, int cnt, float* cum, RngState* rng, uint32_t word) {
+    __shared__ float s_chosen;
+    __shared__ int s_first, s_last, s_any;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        const float total = seq_sum_prefix(w, cnt, cum);
+        s_any = total > 0.f ? 1 : 0;
+        if (total > 0.f) {
+            const float max_rand = __uint_as_float((0xFFFFFFFFu >> 9) | (127u << 23)) - 1.0f;
+            float scale = total;
+            while (scale * max_rand + 0.f >= total) scale = __uint_as_float(__float_as_uint(scale) - 1u);
+            rng->consumed += 1;
+            s_chosen = (__uint_as_float((word >> 9) | (127u << 23)) - 1.0f) * scale + 0.f;
+        }
+        s_first = 0x7FFFFFFF; s_last = -1;
+    }
+    __syncthreads();
+    if (s_any) {
+        const float chosen = s_chosen;
+        int first = 0x7FFFFFFF, last = -1;
+        for (int j = tid; j < cnt; j += SAMPLE_THREADS) {
+            if (w[j] == 0.f) continue;
+            last = j;
+            if (cum[j] > chosen && first == 0x7FFFFFFF) first = j;
+        }
+        if (first != 0x7FFFFFFF) atomicMin(&s_first, first);
+        if (last >= 0) atomicMax(&s_last, last);
+    }
+    __syncthreads();
+    const int res = !s_any ? 0 : (s_first != 0x7FFFFFFF ? s_first : s_last);
+    __syncthreads();
+    return res;
+}
+
+// ---- top-k (k <= 256) sampling of n <= 64 * EPL candidates by ONE wave, no block barrier inside (a barrier phase of a
+// 16-wave block costs ~0.4 us on this chip and the sort-based version needed ~40 of them; measured 36 us per call).  Lane l
+// owns the EPL consecutive candidates l*EPL .. l*EPL+EPL-1 in registers (ascending index == lane-major order):
+//   1. softmax in registers (DPP max, f64 sum);
+//   2. the k-th largest probability T by bisection on its bit pattern: v_cmp writes the lane mask, s_bcnt1 counts it --
+//      30 steps of EPL compares, all control flow scalar;
+//   3. keep p > T and the first k - #{p > T} ties in index order (v_mbcnt prefix counts), compact the kept set into the
+//      contiguous index-ordered arrays kp / ki and 64-bit keys (p bits : 255 - position);
+//   4. sort the <= 256 keys descending in registers (4 per lane: in-lane swaps, DPP for lane^1 / lane^2, ds_bpermute above);
+//   5. lane 0 runs the ascending-index sum of the kept probabilities while lane 1 runs the descending-order top-p cumsum --
+//      two sequential f32 chains in one instruction stream; entries ranked at or after the cut are zeroed.
+// wave_topk_select leaves kp / ki in LDS; wave_pick then draws from them.  Decisions are identical to the sorted version
+// (top-k ties: lower index first; sequential f32 sums in the reference's order).
+// (implementation note, measured with tools/ubench_valu.hip: a lone wave retires a dependent VALU op every ~6 cycles, but a
+// VALU result consumed by the SCALAR unit -- v_cmp -> s_bcnt1, ballot -> s_and -- costs ~32 cycles per hop, and a dependent
+// ds_bpermute ~70.  Hence: counts and prefix sums stay in vector registers (v_addc, DPP scans), compare-exchanges are
+// written as max / min selects, and the sequential sums are pure add chains whose comparisons happen afterwards in parallel.)
+// inclusive prefix sum over the 64 lanes (DPP row shifts + row broadcasts, no LDS, no scalar hop)
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+__device__ __forceinline__ unsigned long long dpp_xor_lane_u64(unsigned long long v, int which /*1: lane^1, 2: lane^2*/) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    if (which == 1) { lo = __builtin_amdgcn_mov_dpp(lo, DPP_XOR1, 0xF, 0xF, false); hi = __builtin_amdgcn_mov_dpp(hi, DPP_XOR1, 0xF, 0xF, false); }
+    else { lo = __builtin_amdgcn_mov_dpp(lo, DPP_XOR2, 0xF, 0xF, false); hi = __builtin_amdgcn_mov_dpp(hi, DPP_XOR2, 0xF, 0xF, false); }
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+template <int EPL>
+__device__ void wave_topk_select(const float* lg, int n, int kk, float inv_t, float top_p, float* kp, int* ki, float* sp,
+                                 unsigned long long* keyb, float* cumsp) {
+    const int lane = threadIdx.x & 63;
+    const int base = lane * EPL;
+    uint32_t u[EPL];
+    {
+        float v[EPL];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < EPL / 4; ++q) {
+            const float4 t = *reinterpret_cast<const float4*>(lg + base + 4 * q);
+            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+        }
+#pragma unroll
+        for (int s = 0; s < EPL; ++s) {
+            v[s] = (base + s < n) ? v[s] * inv_t : -INFINITY;
+            mx = fmaxf(mx, v[s]);
+        }
+        mx = fmaxf(mx, dpp_mov<DPP_XOR1>(mx)); mx = fmaxf(mx, dpp_mov<DPP_XOR2>(mx));
+        mx = fmaxf(mx, dpp_mov<DPP_HALF_MIRROR>(mx)); mx = fmaxf(mx, dpp_mov<DPP_MIRROR>(mx));
+        mx = fmaxf(fmaxf(readlane(mx, 15), readlane(mx, 31)), fmaxf(readlane(mx, 47), readlane(mx, 63)));
+        double part = 0.0;
+#pragma unroll
+        for (int s = 0; s < EPL; ++s) {
+            v[s] = (base + s < n) ? expf(v[s] - mx) : 0.f;
+            part += (double)v[s];
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) part += __shfl_xor(part, m, 64);
+        const float denom = (float)part;
+#pragma unroll
+        for (int s = 0; s < EPL; ++s) u[s] = __float_as_uint(v[s] / denom);  // 0 for slots past n
+    }
+    FS_TS(1);
+    // k-th largest: minimal x with #{u > x} < k.  Per-lane counts in vector registers, one scalar hop per step.
+    uint32_t lo = 0u, hi = 0x3F800000u;
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        // u, mid < 2^30: the borrow of mid - u is its bit 31 -- sub + shift + add per candidate, no compare / VCC round trip
+        uint32_t c0 = 0u, c1 = 0u;
+#pragma unroll
+        for (int s = 0; s < EPL; s += 2) { c0 += (mid - u[s]) >> 31; c1 += (mid - u[s + 1]) >> 31; }
+        int c = (int)(c0 + c1);
+        c += __builtin_amdgcn_mov_dpp(c, DPP_XOR1, 0xF, 0xF, false);
+        c += __builtin_amdgcn_mov_dpp(c, DPP_XOR2, 0xF, 0xF, false);
+        c += __builtin_amdgcn_mov_dpp(c, DPP_HALF_MIRROR, 0xF, 0xF, false);
+        c += __builtin_amdgcn_mov_dpp(c, DPP_MIRROR, 0xF, 0xF, false);
+        const int cnt = (__builtin_amdgcn_readlane(c, 15) + __builtin_amdgcn_readlane(c, 31)) +
+                        (__builtin_amdgcn_readlane(c, 47) + __builtin_amdgcn_readlane(c, 63));
+        if (cnt < kk) hi = mid; else lo = mid + 1u;
+    }
+    const uint32_t T = lo;
+    FS_TS(2);
+    // keep p > T and the first k - #{p > T} ties in index order (lane-major, then slot)
+    const int nvalid = min(max(n - base, 0), EPL);  // only matters for ties at T == 0 (slots past n hold 0 as well)
+    int my_gt = 0, my_eq = 0;
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) { my_gt += u[s] > T ? 1 : 0; my_eq += (u[s] == T && s < nvalid) ? 1 : 0; }
+    const int sc_gt = wave_incl_scan(my_gt), sc_eq = wave_incl_scan(my_eq);
+    const int r_ties = kk - __builtin_amdgcn_readlane(sc_gt, 63);  // ties to keep (>= 1)
+    int run_eq = sc_eq - my_eq;                                    // ties in lower lanes
+    uint32_t keepbits = 0u;
+    int my_keep = 0;
+#pragma unroll
+    for (int s = 0; s < EPL; ++s) {
+        const bool eq = u[s] == T && s < nvalid;
+        const bool keep = u[s] > T || (eq && run_eq < r_ties);
+        run_eq += eq ? 1 : 0;
+        keepbits |= keep ? (1u << s) : 0u;
+        my_keep += keep ? 1 : 0;
+    }
+    int pos = wave_incl_scan(my_keep) - my_keep;
+#pragma unroll
+    for (int s = 0; s < EPL; ++s)
+        if (keepbits & (1u << s)) {
+            kp[pos] = __uint_as_float(u[s]);
+            ki[pos] = base + s;
+            keyb[pos] = ((unsigned long long)u[s] << 32) | (unsigned long long)(255 - pos);
+            ++pos;
+        }
+    FS_TS(3);
+    // sort the kept keys (descending): position i = lane * 4 + s.  Bitonic network with the direction folded into the keys
+    // (keys of "ascending" regions are complemented for the duration of a merge phase), so every compare-exchange is the
+    // same max / min select.
+    unsigned long long k[4];
+    {
+        const ulonglong2 a = *reinterpret_cast<const ulonglong2*>(keyb + lane * 4), b = *reinterpret_cast<const ulonglong2*>(keyb + lane * 4 + 2);
+        k[0] = lane * 4 + 0 < kk ? a.x : 0ull; k[1] = lane * 4 + 1 < kk ? a.y : 0ull;
+        k[2] = lane * 4 + 2 < kk ? b.x : 0ull; k[3] = lane * 4 + 3 < kk ? b.y : 0ull;
+    }
+#pragma unroll
+    for (int lk = 1; lk <= 8; ++lk) {       // merge phase K = 1 << lk
+        const int K = 1 << lk;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {       // complement the regions that this phase sorts ascending
+            const uint32_t f = 0u - (uint32_t)(((lane * 4 + s) >> lk) & 1);
+            k[s] ^= ((unsigned long long)f << 32) | f;
+        }
+#pragma unroll
+        for (int j = K >> 1; j > 0; j >>= 1) {
+            if (j >= 4) {
+                const int lm = j >> 2;
+                const bool lower = (lane & lm) == 0;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const unsigned long long o = lm == 1 ? dpp_xor_lane_u64(k[s], 1) : (lm == 2 ? dpp_xor_lane_u64(k[s], 2) : __shfl_xor(k[s], lm, 64));
+                    const bool g = k[s] > o;
+                    const unsigned long long mxk = g ? k[s] : o, mnk = g ? o : k[s];
+                    k[s] = lower ? mxk : mnk;
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    if (s & j) continue;
+                    const unsigned long long a = k[s], b = k[s ^ j];
+                    const bool g = a > b;
+                    k[s] = g ? a : b;
+                    k[s ^ j] = g ? b : a;
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const uint32_t f = 0u - (uint32_t)(((lane * 4 + s) >> lk) & 1);
+            k[s] ^= ((unsigned long long)f << 32) | f;
+        }
+    }
+    *reinterpret_cast<float4*>(sp + lane * 4) = make_float4(__uint_as_float((uint32_t)(k[0] >> 32)), __uint_as_float((uint32_t)(k[1] >> 32)),
+                                                            __uint_as_float((uint32_t)(k[2] >> 32)), __uint_as_float((uint32_t)(k[3] >> 32)));
+    FS_TS(4);
+    // two sequential f32 chains in one instruction stream, pure adds: lane 0 sums kp (ascending index), lane 1 walks sp
+    // (descending order) and leaves its running sums in cumsp; the top-p cut is then found in parallel:
+    // cut = first rank r whose EXCLUSIVE running sum is >= top_p  ==  1 + first q with inclusive sum[q] >= top_p
+    const float* arr = lane == 1 ? sp : kp;
+    float cum = 0.f;
+    for (int j = 0; j < kk; j += 32) {
+        float v[32];
+        lds_fetch32(arr, j, kk, v);
+#pragma unroll
+        for (int e = 0; e < 32; ++e) { cum += v[e]; v[e] = cum; }
+        if (lane == 1) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(cumsp + j + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        }
+    }
+    const float sum_p = readlane(cum, 0);
+    const bool do_topp = !(top_p <= 0.f || top_p >= sum_p);
+    FS_TS(5);
+    if (do_topp) {  // zero every prob once the running cumsum (descending order) reached top_p
+        const float4 cq = *reinterpret_cast<const float4*>(cumsp + lane * 4);
+        const float cs[4] = {cq.x, cq.y, cq.z, cq.w};
+        int first = 0x7FFFFFFF;
+#pragma unroll
+        for (int s = 3; s >= 0; --s) if (lane * 4 + s < kk && cs[s] >= top_p) first = lane * 4 + s;
+        const unsigned long long mh = __ballot(first != 0x7FFFFFFF);
+        const int cutv = mh ? __builtin_amdgcn_readlane(first, __builtin_ctzll(mh)) + 1 : kk;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int i = lane * 4 + s;
+            if (i < kk && i >= cutv) kp[255 - (int)(k[s] & 0xFFull)] = 0.f;
+        }
+    }
+}
+
+// WeightedIndex::new + sample over the contiguous weights w[0..cnt), cnt <= 256, by one wave: every lane runs the same
+// sequential f32 chain (lane 0 leaves the running sums in `cum`), then each lane tests its four entries.
+__device__ int wave_pick(const float* w, int cnt, float* cum, RngState* rng, uint32_t word) {
+    const int lane = threadIdx.x & 63;
+    float total = 0.f;
+    for (int j = 0; j < cnt; j += 32) {
+        float v[32];
+        lds_fetch32(w, j, cnt, v);
+#pragma unroll
+        for (int e = 0; e < 32; ++e) { total += v[e]; v[e] = total; }
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(cum + j + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        }
+    }
+    if (!(total > 0.f)) return 0;
+    const float max_rand = __uint_as_float((0xFFFFFFFFu >> 9) | (127u << 23)) - 1.0f;
+    float scale = total;
+    while (scale * max_rand + 0.f >= total) scale = __uint_as_float(__float_as_uint(scale) - 1u);
+    if (lane == 0) rng->consumed += 1;
+    const float chosen = (__uint_as_float((word >> 9) | (127u << 23)) - 1.0f) * scale + 0.f;
+    const float4 wv = *reinterpret_cast<const float4*>(w + lane * 4), cv = *reinterpret_cast<const float4*>(cum + lane * 4);
+    const float ws[4] = {wv.x, wv.y, wv.z, wv.w}, cs[4] = {cv.x, cv.y, cv.z, cv.w};
+    int first = 0x7FFFFFFF, last = -1;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int j = lane * 4 + s;
+        if (j >= cnt || ws[s] == 0.f) continue;
+        last = j;
+        if (cs[s] > chosen && first == 0x7FFFFFFF) first = j;  // first kept item whose inclusive cumulative weight is > chosen
+    }
+    const unsigned long long mh = __ballot(first != 0x7FFFFFFF), mn = __ballot(last >= 0);
+    if (mh) return __builtin_amdgcn_readlane(first, __builtin_ctzll(mh));
+    return __builtin_amdgcn_readlane(last, 63 - __builtin_clzll(mn));
+}
 
 // Block-wide selection of one index from `n` logits held in LDS (already penalised / masked).
 //  temp == 0: host-ArgMax rule of candle's LogitsProcessor (max_by(total_cmp)): LAST maximal index wins.
@@ -972,28 +1295,96 @@ __device__ int block_sample(float* lg /*LDS [n]*/, int n, const SampleCfg& c, Rn
         __syncthreads();
         return res;
     }
-    // softmax(logits * (1/temp))
+    {
+        const bool use_k0 = c.top_k > 0 && c.top_k < n;
+        if (use_k0 && c.top_k <= 256 && n <= 2048) {
+            // one-wave path (see wave_topk_select): wave 0 selects, the last wave computes this draw's StdRng word meanwhile
+            const float inv_t0 = (float)(1.0 / (double)c.temp);
+            __shared__ uint32_t s_word0;
+            __shared__ __attribute__((aligned(16))) float w_kp[256 + 32];
+            __shared__ __attribute__((aligned(16))) float w_cum[256 + 32];
+            __shared__ __attribute__((aligned(16))) unsigned long long w_key[256];
+            __shared__ int w_ki[256];
+            const int kk0 = c.top_k;
+            FS_TS(0);
+            if (tid < 64) {
+                if (n <= 1024) wave_topk_select<16>(lg, n, kk0, inv_t0, c.top_p, w_kp, w_ki, sp, w_key, w_cum);
+                else wave_topk_select<32>(lg, n, kk0, inv_t0, c.top_p, w_kp, w_ki, sp, w_key, w_cum);
+            } else if (tid == SAMPLE_THREADS - 1) {
+                s_word0 = chacha12_word(rng->key, rng->consumed);
+            }
+            FS_TS(6);
+            __syncthreads();
+            FS_TS(7);
+            if (tid < 64) {
+                const int pick = wave_pick(w_kp, kk0, w_cum, rng, s_word0);
+                if (tid == 0) s_result = w_ki[pick];
+            }
+            FS_TS(8);
+            __syncthreads();
+            const int res = s_result;
+            __syncthreads();
+            return res;
+        }
+    }
+    // softmax(logits * (1/temp)).  Blocked ownership: thread t owns the `ept` consecutive candidates t*ept .. t*ept+ept-1
+    // (ascending index order == thread-major order, which the index-order prefix scans below rely on).
+    FS_TS(0);
     const float inv_t = (float)(1.0 / (double)c.temp);
+    const int ept = (n + SAMPLE_THREADS - 1) / SAMPLE_THREADS;  // 1..4
+    const int lane = tid & 63, wv = tid >> 6;
+    // the StdRng word of this call's draw: ~800 dependent integer ops, computed by the last wave while the others select
+    __shared__ uint32_t s_word;
+    if (tid == SAMPLE_THREADS - 1) s_word = chacha12_word(rng->key, rng->consumed);
+    float pv[4];
+    bool valid[4];
     float mx = -INFINITY;
-    for (int i = tid; i < n; i += SAMPLE_THREADS) { const float v = lg[i] * inv_t; lg[i] = v; mx = fmaxf(mx, v); }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int i = tid * ept + s;
+        valid[s] = s < ept && i < n;
+        pv[s] = valid[s] ? lg[i] * inv_t : -INFINITY;
+        mx = fmaxf(mx, pv[s]);
+    }
     float* rv = reinterpret_cast<float*>(red);
-    rv[tid] = mx;
+    mx = fmaxf(mx, dpp_mov<DPP_XOR1>(mx)); mx = fmaxf(mx, dpp_mov<DPP_XOR2>(mx));
+    mx = fmaxf(mx, dpp_mov<DPP_HALF_MIRROR>(mx)); mx = fmaxf(mx, dpp_mov<DPP_MIRROR>(mx));
+    mx = fmaxf(fmaxf(readlane(mx, 15), readlane(mx, 31)), fmaxf(readlane(mx, 47), readlane(mx, 63)));
+    if (lane == 0) rv[wv] = mx;
     __syncthreads();
-    for (int s = SAMPLE_THREADS / 2; s >= 1; s >>= 1) { if (tid < s) rv[tid] = fmaxf(rv[tid], rv[tid + s]); __syncthreads(); }
-    mx = rv[0];
+#pragma unroll
+    for (int w2 = 0; w2 < SAMPLE_THREADS / 64; ++w2) mx = fmaxf(mx, rv[w2]);
     __syncthreads();
     double part = 0.0;
-    for (int i = tid; i < n; i += SAMPLE_THREADS) { const float e = expf(lg[i] - mx); lg[i] = e; part += (double)e; }
-    red[tid] = part;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        pv[s] = valid[s] ? expf(pv[s] - mx) : 0.f;
+        part += (double)pv[s];
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) part += __shfl_xor(part, m, 64);
+    if (lane == 0) red[wv] = part;
     __syncthreads();
-    for (int s = SAMPLE_THREADS / 2; s >= 1; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
-    const float denom = (float)red[0];
+    double dsum = 0.0;
+#pragma unroll
+    for (int w2 = 0; w2 < SAMPLE_THREADS / 64; ++w2) dsum += red[w2];
+    const float denom = (float)dsum;
     __syncthreads();
-    // sort keys: (prob desc, index asc) via bitonic sort over the next power of two
+#pragma unroll
+    for (int s = 0; s < 4; ++s) pv[s] = pv[s] / denom;  // probabilities (by index, in registers)
+    FS_TS(1);
+    const bool use_k = c.top_k > 0 && c.top_k < n;
+    const int kk = use_k ? c.top_k : n;
+    __shared__ int s_cut;       // number of leading sorted entries that survive top-p
+    __shared__ int s_do_topp;
+    // ---- general path (no top-k, k > 256, or more than 2048 candidates): full bitonic sort by (prob desc, index asc) over the next power of two
+#pragma unroll
+    for (int s = 0; s < 4; ++s) if (valid[s]) lg[tid * ept + s] = pv[s];
     int np2 = 1;
     while (np2 < n) np2 <<= 1;
+    __syncthreads();
     for (int i = tid; i < np2; i += SAMPLE_THREADS) {
-        if (i < n) { sp[i] = lg[i] / denom; si[i] = i; } else { sp[i] = -1.f; si[i] = 0x7FFFFFFF; }
+        if (i < n) { sp[i] = lg[i]; si[i] = i; } else { sp[i] = -1.f; si[i] = 0x7FFFFFFF; }
     }
     __syncthreads();
     for (int k = 2; k <= np2; k <<= 1) {
@@ -1015,8 +1406,6 @@ __device__ int block_sample(float* lg /*LDS [n]*/, int n, const SampleCfg& c, Rn
     // run in ascending token-index order, the top-p cut in descending probability order, every sum is a sequential f32
     // chain.  To keep those chains short and free of dependent LDS indirections, the kept set (top_k entries, or all n)
     // is materialised as CONTIGUOUS arrays: kp[j] = probability of the j-th kept token in index order, ki[j] = its index.
-    const bool use_k = c.top_k > 0 && c.top_k < n;
-    const int kk = use_k ? c.top_k : n;
     int* ki = reinterpret_cast<int*>(red);  // 8 KB scratch: up to 2048 ints
     float* kp = lg;                          // the by-index array is no longer needed once (sp, si) are sorted
     const bool small = use_k && kk <= 2 * SAMPLE_THREADS;
@@ -1051,24 +1440,15 @@ __device__ int block_sample(float* lg /*LDS [n]*/, int n, const SampleCfg& c, Rn
         __syncthreads();
         cnt = n;
     }
-    __shared__ int s_cut;       // number of leading sorted entries that survive top-p
-    __shared__ int s_do_topp;
     if (tid == 0) {
         bool do_topp = true;
         if (use_k) {
-            float sum_p = 0.f;
-            for (int j = 0; j < cnt; ++j) sum_p += kp[j];  // ascending index; entries outside the top-k are 0 (or absent)
+            const float sum_p = seq_sum(kp, cnt);  // ascending index; entries outside the top-k are 0 (or absent)
             do_topp = !(c.top_p <= 0.f || c.top_p >= sum_p);
         }
-        int cut = kk;
-        if (do_topp) {  // zero every prob once the running cumsum (descending order) reached top_p
-            float cumsum = 0.f;
-            for (int r = 0; r < kk; ++r) {
-                if (cumsum >= c.top_p) { cut = r; break; }
-                cumsum += sp[r];
-            }
-        }
-        s_cut = cut; s_do_topp = do_topp ? 1 : 0;
+        // zero every prob once the running cumsum (descending order) reached top_p
+        s_cut = do_topp ? seq_topp_cut(sp, kk, c.top_p) : kk;
+        s_do_topp = do_topp ? 1 : 0;
     }
     __syncthreads();
     if (s_do_topp && s_cut < kk) {  // entries sorting at or after rank `cut` are zeroed (parallel predicate on (prob, index))
@@ -1081,48 +1461,21 @@ __device__ int block_sample(float* lg /*LDS [n]*/, int n, const SampleCfg& c, Rn
         }
     }
     __syncthreads();
-    if (tid == 0) {
-        // WeightedIndex::new + sample (ascending index; zero weights do not move the cumulative sum)
-        float total = 0.f;
-        for (int j = 0; j < cnt; ++j) total += kp[j];
-        int res = 0;
-        if (total > 0.f) {
-            const float max_rand = __uint_as_float((0xFFFFFFFFu >> 9) | (127u << 23)) - 1.0f;
-            float scale = total;
-            while (scale * max_rand + 0.f >= total) scale = __uint_as_float(__float_as_uint(scale) - 1u);
-            const uint32_t w = chacha12_word(rng->key, rng->consumed);
-            rng->consumed += 1;
-            const float chosen = (__uint_as_float((w >> 9) | (127u << 23)) - 1.0f) * scale + 0.f;
-            // first kept item whose inclusive cumulative weight is > chosen (== partition_point over the exclusive
-            // cumulative array of WeightedIndex, since chosen < total)
-            float cum = 0.f;
-            int last_nz = 0;
-            res = -1;
-            for (int j = 0; j < cnt; ++j) {
-                const float wj = kp[j];
-                if (wj == 0.f) continue;
-                last_nz = j;
-                cum += wj;
-                if (cum > chosen) { res = j; break; }
-            }
-            if (res < 0) res = last_nz;
-            if (small) res = ki[res];
-        }
-        s_result = res;
+    {
+        const int r = block_weighted_pick(kp, cnt, sp, rng, s_word);
+        const int res = small ? ki[r] : r;
+        __syncthreads();
+        return res;
     }
-    __syncthreads();
-    const int res = s_result;
-    __syncthreads();
-    return res;
 }
 
 template <typename WT>
 __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_slow(const float* __restrict__ logits, int n,
                                                                 const SampleCfg* __restrict__ cp, RngState* rng, SeqState* __restrict__ state,
                                                                 const float* __restrict__ x, float* __restrict__ xf, int dim) {
-    __shared__ float lg[SAMPLE_MAXN];
-    __shared__ float sp[SAMPLE_MAXN];
-    __shared__ int si[SAMPLE_MAXN];
+    __shared__ __attribute__((aligned(16))) float lg[SAMPLE_MAXN];
+    __shared__ __attribute__((aligned(16))) float sp[SAMPLE_MAXN];
+    __shared__ __attribute__((aligned(16))) int si[SAMPLE_MAXN];
     __shared__ double red[SAMPLE_THREADS];
     const int tid = threadIdx.x;
     const SampleCfg c = *cp;
@@ -1165,9 +1518,9 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_fast(const float* __r
                                                                 float* __restrict__ xf, const WT* __restrict__ tok_emb,
                                                                 const WT* __restrict__ cb_emb, float* __restrict__ x, int dim,
                                                                 uint32_t* __restrict__ out_codes, int out_cap) {
-    __shared__ float lg[SAMPLE_MAXN];
-    __shared__ float sp[SAMPLE_MAXN];
-    __shared__ int si[SAMPLE_MAXN];
+    __shared__ __attribute__((aligned(16))) float lg[SAMPLE_MAXN];
+    __shared__ __attribute__((aligned(16))) float sp[SAMPLE_MAXN];
+    __shared__ __attribute__((aligned(16))) int si[SAMPLE_MAXN];
     __shared__ double red[SAMPLE_THREADS];
     const int tid = threadIdx.x;
     const int n = cb_size;
@@ -1271,9 +1624,9 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_slow_rows(const float
                                                                      const SampleCfg* __restrict__ cp, const RngState* __restrict__ master,
                                                                      int B, int calls_per_frame, SeqState* __restrict__ states,
                                                                      const float* __restrict__ X, float* __restrict__ XF, int dim) {
-    __shared__ float lg[SAMPLE_MAXN];
-    __shared__ float sp[SAMPLE_MAXN];
-    __shared__ int si[SAMPLE_MAXN];
+    __shared__ __attribute__((aligned(16))) float lg[SAMPLE_MAXN];
+    __shared__ __attribute__((aligned(16))) float sp[SAMPLE_MAXN];
+    __shared__ __attribute__((aligned(16))) int si[SAMPLE_MAXN];
     __shared__ double red[SAMPLE_THREADS];
     __shared__ RngState lrng;
     const int tid = threadIdx.x, b = blockIdx.x;
@@ -1301,9 +1654,9 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_fast_rows(const float
                                                                      float* __restrict__ XF, const WT* __restrict__ tok_emb,
                                                                      const WT* __restrict__ cb_emb, float* __restrict__ X, int dim,
                                                                      uint32_t* __restrict__ out_codes, int out_cap) {
-    __shared__ float lg[SAMPLE_MAXN];
-    __shared__ float sp[SAMPLE_MAXN];
-    __shared__ int si[SAMPLE_MAXN];
+    __shared__ __attribute__((aligned(16))) float lg[SAMPLE_MAXN];
+    __shared__ __attribute__((aligned(16))) float sp[SAMPLE_MAXN];
+    __shared__ __attribute__((aligned(16))) int si[SAMPLE_MAXN];
     __shared__ double red[SAMPLE_THREADS];
     __shared__ RngState lrng;
     const int tid = threadIdx.x, b = blockIdx.x, n = cb_size;

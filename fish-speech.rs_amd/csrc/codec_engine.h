@@ -1,5 +1,6 @@
 // Host-side engine of the Firefly-GAN-VQ vocoder (FireflyCodec::decode, codec/firefly.rs:42-48).
 #pragma once
+#include <cstddef>
 #include <cstdint>
 #include <string>
 
@@ -11,6 +12,7 @@ class CodecBase {
     virtual void load_synthetic(uint64_t seed) = 0;
     virtual void load_safetensors(const std::string& path) = 0;
     virtual void decode(const uint32_t* codes, int b, int T, float* pcm_out) = 0;
+    virtual void encode(const float* pcm, int n, uint32_t* codes_out, size_t cap, size_t* L_out) = 0;
     virtual int sample_rate() = 0;
 };
 

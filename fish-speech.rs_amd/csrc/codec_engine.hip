@@ -4,7 +4,9 @@
 //   (codec/config.rs:155-167,98-113,196-202); `channel_div` scales every channel count down for tests.
 #include "codec_engine.h"
 
+#include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <map>
 #include <string>
 #include <vector>
@@ -138,8 +140,90 @@ class Codec final : public CodecBase {
         FS_HIP(hipStreamSynchronize(st_));
     }
 
+    // FireflyCodec::encode (firefly.rs:37-40) for one mono clip: pcm (n) -> indices (8, L), L = frames / 4
+    void encode(const float* pcm, int n, uint32_t* codes_out, size_t cap, size_t* L_out) override {
+        FS_HIP(hipSetDevice(device_));
+        FS_REQUIRE(loaded_, "weights not loaded: call fs_codec_load_safetensors or fs_codec_load_synthetic first");
+        const int pad = (kFft - kHop) / 2;
+        if (n < pad) throw Error("input shorter than the reflect padding (range end index out of range, spectrogram.rs:19)");
+        const long long Lp = (long long)n + 2 * pad, full = Lp / kHop, rem = Lp % kHop;
+        long long F = std::max(0LL, full - (kFft / kHop - 1));  // frames the streaming STFT emits (stft.rs:52-90)
+        if (rem > 0 && Lp >= kFft) F += 1;
+        FS_REQUIRE(F >= 4, "clip too short: the quantizer downsamples 4 mel frames into one code");
+        const int T = (int)F, G = 8, nf = kFft / 2 + 1;
+        ensure_mel_table();
+        dpcm_.ensure(sizeof(float) * n);
+        FS_HIP(hipMemcpyAsync(dpcm_.p, pcm, sizeof(float) * n, hipMemcpyHostToDevice, st_));
+        const size_t act = (size_t)std::max(nf, 4 * C_) * T;  // largest activation: lin (1025 x T) or a ConvNeXt hidden (4C x T)
+        for (int i = 0; i < 4; ++i) buf_[i].ensure(act * sizeof(float));
+        float *x = buf_[0].f(), *t1 = buf_[1].f(), *t2 = buf_[2].f(), *r = buf_[3].f();
+        codec_stft_mag((const float*)dpcm_.p, n, kFft, kHop, T, t1, st_);
+        codec_mel_log(t1, mel_fb_.f(), nf, kMels, T, x, st_);
+        auto block = [&](const CnxSpec& c, int Cb, int Tc) {  // x -> x (ConvNeXtBlock, convnext.rs:110-126)
+            codec_dwconv_ln(x, 1, Cb, Tc, R(c.dw), R(c.db), R(c.lnw), R(c.lnb), t2, st_);
+            codec_conv1d(t2, 1, Cb, Tc, conv(c.pw1), 1, false, CODEC_EPI_GELU, nullptr, nullptr, r, st_);
+            codec_conv1d(r, 1, 4 * Cb, Tc, conv(c.pw2), 1, false, CODEC_EPI_GAMMA_RES, x, R(c.gamma), t1, st_);
+            std::swap(x, t1);
+        };
+        // ConvNeXtEncoder (convnext.rs:319-331)
+        codec_conv1d(x, 1, kMels, T, conv(stem_conv_), 1, false, CODEC_EPI_NONE, nullptr, nullptr, t1, st_);
+        codec_layernorm_cf(t1, edims_[0], T, R(stem_lnw_), R(stem_lnb_), x, st_);
+        for (const auto& c : stages_[0]) block(c, edims_[0], T);
+        for (int i = 1; i < 4; ++i) {
+            codec_layernorm_cf(x, edims_[i - 1], T, R(mid_lnw_[i]), R(mid_lnb_[i]), t1, st_);
+            codec_conv1d(t1, 1, edims_[i - 1], T, conv(mid_conv_[i]), 1, false, CODEC_EPI_NONE, nullptr, nullptr, x, st_);
+            for (const auto& c : stages_[i]) block(c, edims_[i], T);
+        }
+        codec_layernorm_cf(x, edims_[3], T, R(enc_lnw_), R(enc_lnb_), t1, st_);
+        std::swap(x, t1);
+        // quantizer.encode (quantizer.rs:104-124): (strided conv k = s = 2 as space-to-depth + 1x1 conv) + ConvNeXt block, twice
+        int Tc = T;
+        for (int i = 0; i < 2; ++i) {
+            codec_space_to_depth(x, C_, Tc, 2, t1, st_);
+            Tc /= 2;
+            ConvW w = conv(down_conv_[i]);
+            w.k = 1;  // re-laid [Cin][2][Cout] == [2 Cin][1][Cout] over the space-to-depth channels
+            codec_conv1d(t1, 1, 2 * C_, Tc, w, 1, false, CODEC_EPI_NONE, nullptr, nullptr, x, st_);
+            block(down_cnx_[i], C_, Tc);
+        }
+        FS_REQUIRE((size_t)Tc <= cap, "codes_out capacity too small");
+        dcodes_.ensure(sizeof(uint32_t) * G * Tc);
+        codec_fsq_encode(x, C_, Tc, G, R(pin_w_), R(pin_b_), (uint32_t*)dcodes_.p, st_);
+        std::vector<uint32_t> host((size_t)G * Tc);
+        FS_HIP(hipMemcpyAsync(host.data(), dcodes_.p, sizeof(uint32_t) * G * Tc, hipMemcpyDeviceToHost, st_));
+        FS_HIP(hipStreamSynchronize(st_));
+        for (int g = 0; g < G; ++g) std::memcpy(codes_out + (size_t)g * cap, host.data() + (size_t)g * Tc, sizeof(uint32_t) * Tc);
+        *L_out = (size_t)Tc;
+    }
+
   private:
     struct CnxSpec { int dw, db, lnw, lnb, pw1, pw2, gamma; };
+    static constexpr int kMels = 160, kFft = 2048, kHop = 512;  // LogMelSpectrogramConfig::default (spectrogram.rs:114-126)
+
+    // slaney mel filterbank, [n_fft/2+1][n_mels] (the layout load_mel_buffer reads, spectrogram.rs:90-101), regenerated from
+    // the published formula (librosa.filters.mel, norm = "slaney", htk = False, f_min 0, f_max sr/2) in f64 and rounded to f32;
+    // the reference embeds the same table as melfilters160.bytes (max |diff| 1.8e-7, checked by the tests)
+    void ensure_mel_table() {
+        if (mel_fb_.p) return;
+        const int nf = kFft / 2 + 1, sr = 44100;
+        const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = std::log(6.4) / 27.0;
+        auto hz_to_mel = [&](double f) { return f >= min_log_hz ? min_log_mel + std::log(f / min_log_hz) / logstep : f / f_sp; };
+        auto mel_to_hz = [&](double m) { return m >= min_log_mel ? min_log_hz * std::exp(logstep * (m - min_log_mel)) : f_sp * m; };
+        std::vector<double> mel_f(kMels + 2);
+        const double m0 = hz_to_mel(0.0), m1 = hz_to_mel(sr / 2.0);
+        for (int i = 0; i < kMels + 2; ++i) mel_f[i] = mel_to_hz(m0 + (m1 - m0) * (double)i / (double)(kMels + 1));
+        std::vector<float> fb((size_t)nf * kMels, 0.f);
+        for (int m = 0; m < kMels; ++m) {
+            const double enorm = 2.0 / (mel_f[m + 2] - mel_f[m]);
+            for (int f = 0; f < nf; ++f) {
+                const double freq = (sr / 2.0) * (double)f / (double)(nf - 1);
+                const double lower = (freq - mel_f[m]) / (mel_f[m + 1] - mel_f[m]), upper = (mel_f[m + 2] - freq) / (mel_f[m + 2] - mel_f[m + 1]);
+                fb[(size_t)f * kMels + m] = (float)(std::max(0.0, std::min(lower, upper)) * enorm);
+            }
+        }
+        mel_fb_.alloc(fb.size() * sizeof(float));
+        FS_HIP(hipMemcpy(mel_fb_.p, fb.data(), fb.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
 
     const float* R(int tensor_idx) const { return raw_.f() + tensors_[tensor_idx].off; }
     ConvW conv(int spec_idx) const {
@@ -218,6 +302,55 @@ class Codec final : public CodecBase {
                 }
         }
         conv_post_ = add_conv("head.conv_post", 1, C_ >> 5, 13, false, (double)(C_ >> 5) * 13);
+        plan_encoder();
+    }
+    CnxSpec plan_block(const std::string& q, int Cb) {  // ConvNeXtBlock tensors (convnext.rs:60-108)
+        CnxSpec c;
+        c.dw = add_tensor(q + ".dwconv.conv.weight", {Cb, 1, 7}, 0.f, 1.0 / std::sqrt(7.0));
+        c.db = add_tensor(q + ".dwconv.conv.bias", {Cb}, 0.f, 0.02);
+        c.lnw = add_tensor(q + ".norm.weight", {Cb}, 1.f, 0.1);
+        c.lnb = add_tensor(q + ".norm.bias", {Cb}, 0.f, 0.02);
+        c.pw1 = add_linear_as_conv(q + ".pwconv1", 4 * Cb, Cb, (double)Cb);
+        c.pw2 = add_linear_as_conv(q + ".pwconv2", Cb, 4 * Cb, 4.0 * Cb);
+        c.gamma = add_tensor(q + ".gamma", {Cb}, 0.1f, 0.02);
+        return c;
+    }
+    // encoder side: backbone (ConvNeXtEncoder, convnext.rs:186-331; BackboneConfig::fish_1_4, config.rs:47-57), quantizer.downsample
+    // (quantizer.rs:44-66) and the per-group project_in (grouped_residual_fsq.rs:52-56)
+    void plan_encoder() {
+        const int div = 512 / C_;
+        const int full[4] = {128, 256, 384, 512};
+        for (int i = 0; i < 4; ++i) edims_[i] = full[i] / div;
+        if (div == 1) { edepths_[0] = 3; edepths_[1] = 3; edepths_[2] = 9; edepths_[3] = 3; }
+        else { edepths_[0] = 1; edepths_[1] = 1; edepths_[2] = 2; edepths_[3] = 1; }  // reduced test topology (channel_div > 1)
+        stem_conv_ = add_conv("backbone.downsample_layers.0.0", edims_[0], kMels, 7, false, (double)kMels * 7);
+        stem_lnw_ = add_tensor("backbone.downsample_layers.0.1.weight", {edims_[0]}, 1.f, 0.1);
+        stem_lnb_ = add_tensor("backbone.downsample_layers.0.1.bias", {edims_[0]}, 0.f, 0.02);
+        for (int i = 0; i < 4; ++i) {
+            if (i > 0) {
+                const std::string q = "backbone.downsample_layers." + std::to_string(i);
+                mid_lnw_[i] = add_tensor(q + ".0.weight", {edims_[i - 1]}, 1.f, 0.1);
+                mid_lnb_[i] = add_tensor(q + ".0.bias", {edims_[i - 1]}, 0.f, 0.02);
+                mid_conv_[i] = add_linear_as_conv(q + ".1", edims_[i], edims_[i - 1], (double)edims_[i - 1]);
+            }
+            for (int j = 0; j < edepths_[i]; ++j)
+                stages_[i].push_back(plan_block("backbone.stages." + std::to_string(i) + "." + std::to_string(j), edims_[i]));
+        }
+        enc_lnw_ = add_tensor("backbone.norm.weight", {edims_[3]}, 1.f, 0.1);
+        enc_lnb_ = add_tensor("backbone.norm.bias", {edims_[3]}, 0.f, 0.02);
+        for (int i = 0; i < 2; ++i) {
+            const std::string q = "quantizer.downsample." + std::to_string(i);
+            down_conv_[i] = add_conv(q + ".0", C_, C_, 2, false, (double)C_ * 2);
+            down_cnx_[i] = plan_block(q + ".1", C_);
+        }
+        const int G = 8, dg = C_ / G;
+        pin_w_ = (int)tensors_.size();
+        for (int g = 0; g < G; ++g)
+            add_tensor("quantizer.residual_fsq.rvqs." + std::to_string(g) + ".project_in.weight", {4, dg}, 0.f, 1.0 / std::sqrt((double)dg));
+        pin_b_ = (int)tensors_.size();
+        for (int g = 0; g < G; ++g) add_tensor("quantizer.residual_fsq.rvqs." + std::to_string(g) + ".project_in.bias", {4}, 0.f, 0.02);
+        repack_groups(pin_w_, G, (size_t)4 * dg);
+        repack_groups(pin_b_, G, 4);
     }
     void repack_groups(int first, int G, size_t each) {  // make G consecutive tensors contiguous (no padding between them)
         size_t off = tensors_[first].off;
@@ -243,6 +376,13 @@ class Codec final : public CodecBase {
     int proj_w_ = 0, proj_b_ = 0, up_conv_[2] = {0, 0}, conv_pre_ = 0, conv_post_ = 0, ups_[5] = {0, 0, 0, 0, 0};
     int res_[5][3][2][3] = {};
     CnxSpec cnx_[2] = {};
+    // encoder side
+    int edims_[4] = {128, 256, 384, 512}, edepths_[4] = {3, 3, 9, 3};
+    int stem_conv_ = 0, stem_lnw_ = 0, stem_lnb_ = 0, mid_lnw_[4] = {}, mid_lnb_[4] = {}, mid_conv_[4] = {}, enc_lnw_ = 0, enc_lnb_ = 0;
+    int down_conv_[2] = {0, 0}, pin_w_ = 0, pin_b_ = 0;
+    std::vector<CnxSpec> stages_[4];
+    CnxSpec down_cnx_[2] = {};
+    DBuf mel_fb_, dpcm_;
 };
 
 CodecBase* make_codec(int device, int channel_div) { return new Codec(device, channel_div); }

@@ -25,6 +25,12 @@ void codec_dwconv_ln(const float* x, int B, int C, int T, const float* dw, const
                      hipStream_t st);
 void codec_mean3(const float* a, const float* b, const float* c, float* y, size_t n, hipStream_t st);
 void codec_relayout(const float* src, float* dst, int Cout, int CinG, int K, bool transposed, hipStream_t st);
+// ---- encoder side (FireflyCodec::encode)
+void codec_stft_mag(const float* pcm, int n, int n_fft, int hop, int n_frames, float* lin /*[n_fft/2+1][frames]*/, hipStream_t st);
+void codec_mel_log(const float* lin, const float* fb /*[nf][n_mels]*/, int nf, int n_mels, int F, float* mel /*[n_mels][F]*/, hipStream_t st);
+void codec_layernorm_cf(const float* x, int C, int T, const float* w, const float* b, float* y, hipStream_t st);
+void codec_space_to_depth(const float* x, int C, int T, int s, float* y /*[C*s][T/s]*/, hipStream_t st);
+void codec_fsq_encode(const float* z, int C, int T, int G, const float* pin_w, const float* pin_b, uint32_t* codes, hipStream_t st);
 void codec_synth_fill(float* dst, uint64_t key, size_t n, float mean, float scale, hipStream_t st);
 
 }  // namespace fs

@@ -283,3 +283,139 @@ void codec_synth_fill(float* dst, uint64_t key, size_t n, float mean, float scal
 }
 
 }  // namespace fs
+
+// ================================================================================================ encoder side kernels
+// (FireflyCodec::encode, firefly.rs:37-40: log-mel front-end -> ConvNeXt encoder -> downsample -> grouped FSQ)
+namespace fs {
+
+// ---- STFT magnitude (audio/spectrogram.rs:29-88 + stft.rs:52-90).  One block per frame: frame f = padded[f*hop, f*hop + N),
+// padded = reflect pad that REPEATS the edge sample ((N - hop)/2 on both sides), tail beyond the padded signal zero-filled;
+// periodic Hann window and a radix-2 FFT in f64 (the reference runs rustfft in f64), |.| rounded to f32, + 1e-6.
+// Output channel-first: lin[k][f], k < N/2+1.
+template <int N>
+__global__ __launch_bounds__(256) void k_stft_mag(const float* __restrict__ pcm, int n, int hop, int n_frames, float* __restrict__ lin) {
+    __shared__ double re[N], im[N];
+    __shared__ double twr[N / 2], twi[N / 2];
+    const int f = blockIdx.x, pad = (N - hop) / 2;
+    const long long Lp = (long long)n + 2 * pad;
+    for (int j = threadIdx.x; j < N / 2; j += 256) {
+        const double a = -2.0 * 3.14159265358979323846 * (double)j / (double)N;
+        twr[j] = cos(a); twi[j] = sin(a);
+    }
+    for (int j = threadIdx.x; j < N; j += 256) {
+        const long long p = (long long)f * hop + j;
+        double v = 0.0;
+        if (p < Lp) {
+            const long long q = p - pad;
+            const long long src = q < 0 ? (-q - 1) : (q >= n ? (2LL * n - 1 - q) : q);
+            v = (double)pcm[src];
+        }
+        const double w = 0.5 * (1.0 - cos((2.0 * 3.14159265358979323846 * (double)j) / (double)N));
+        // bit-reversed store
+        const int r = (int)(__brev((unsigned)j) >> (32 - __builtin_ctz(N)));
+        re[r] = v * w; im[r] = 0.0;
+    }
+    __syncthreads();
+    for (int len = 2; len <= N; len <<= 1) {
+        const int half = len >> 1, step = N / len;
+        for (int b = threadIdx.x; b < N / 2; b += 256) {
+            const int k = b % half, i = (b / half) * len + k;
+            const double wr = twr[k * step], wi = twi[k * step];
+            const double xr = re[i + half] * wr - im[i + half] * wi, xi = re[i + half] * wi + im[i + half] * wr;
+            re[i + half] = re[i] - xr; im[i + half] = im[i] - xi;
+            re[i] += xr; im[i] += xi;
+        }
+        __syncthreads();
+    }
+    for (int k = threadIdx.x; k <= N / 2; k += 256)
+        lin[(size_t)k * n_frames + f] = (float)sqrt(re[k] * re[k] + im[k] * im[k]) + 1e-6f;
+}
+
+// mel[m][f] = log(clamp(sum_k lin[k][f] * fb[k][m], 1e-5, 100))  (spectrogram.rs:136-151); ascending-k f32 chain
+__global__ void k_mel_log(const float* __restrict__ lin, const float* __restrict__ fb, int nf, int n_mels, int F, float* __restrict__ mel) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
+    if (f >= F) return;
+    float acc = 0.f;
+    for (int k = 0; k < nf; ++k) acc = __fadd_rn(acc, __fmul_rn(lin[(size_t)k * F + f], fb[(size_t)k * n_mels + m]));
+    mel[(size_t)m * F + f] = logf(fminf(fmaxf(acc, 1e-5f), 100.0f));
+}
+
+// LayerNormChannelsFirst (convnext.rs:144-154), eps 1e-6: one thread per time step, two passes over the channels
+__global__ void k_layernorm_cf(const float* __restrict__ x, int C, int T, const float* __restrict__ w, const float* __restrict__ b,
+                               float* __restrict__ y) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    float mean = 0.f;
+    for (int c = 0; c < C; ++c) mean += x[(size_t)c * T + t];
+    mean /= (float)C;
+    float var = 0.f;
+    for (int c = 0; c < C; ++c) { const float d = x[(size_t)c * T + t] - mean; var += d * d; }
+    var /= (float)C;
+    const float sd = sqrtf(var + 1e-6f);
+    for (int c = 0; c < C; ++c) y[(size_t)c * T + t] = (x[(size_t)c * T + t] - mean) / sd * w[c] + b[c];
+}
+
+// strided FishConvNet with k == stride (quantizer.downsample, quantizer.rs:44-57: left pad k - stride = 0) as a 1x1 conv over
+// the space-to-depth view: y[i*s + k][t] = x[i][t*s + k]
+__global__ void k_space_to_depth(const float* __restrict__ x, int C, int T, int s, int Tout, float* __restrict__ y) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, ck = blockIdx.y;
+    if (t >= Tout) return;
+    y[(size_t)ck * Tout + t] = x[(size_t)(ck / s) * T + (size_t)t * s + ck % s];
+}
+
+// grouped residual FSQ with one quantizer per group (grouped_residual_fsq.rs:75-93,154-173, fsq.rs:68-118), levels (8,5,5,5):
+// z = project_in(x_g); r = bound(z); code = round(bound(r)) / half_width; index = sum_k (code_k * hw_k + hw_k) * basis_k
+__device__ __forceinline__ float dfsq_bound(float z, int lv) {
+    const float half_l = ((float)lv - 1.0f) * 1.001f / 2.0f;
+    const float offset = (lv % 2 == 0) ? 0.5f : 0.0f;
+    const float q = offset / half_l;
+    const float shift = logf((1.0f + q) / (1.0f - q)) * 0.5f;
+    return tanhf(z + shift) * half_l - offset;
+}
+__global__ void k_fsq_encode(const float* __restrict__ z, int C, int T, int G, const float* __restrict__ pin_w /*[G][4][dg]*/,
+                             const float* __restrict__ pin_b /*[G][4]*/, uint32_t* __restrict__ codes /*[G][T]*/) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;
+    if (t >= T) return;
+    const int dg = C / G;
+    const int levels[4] = {8, 5, 5, 5}, basis[4] = {1, 8, 40, 200};
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < dg; ++c) {
+        const float v = z[(size_t)(g * dg + c) * T + t];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = __fadd_rn(acc[k], __fmul_rn(v, pin_w[((size_t)g * 4 + k) * dg + c]));
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float r = dfsq_bound(acc[k] + pin_b[g * 4 + k], levels[k]);
+        const float hw = (float)(levels[k] / 2);
+        const float code = roundf(dfsq_bound(r, levels[k])) / hw;
+        sum += (code * hw + hw) * (float)basis[k];
+    }
+    codes[(size_t)g * T + t] = (uint32_t)(long long)sum;
+}
+
+void codec_stft_mag(const float* pcm, int n, int n_fft, int hop, int n_frames, float* lin, hipStream_t st) {
+    FS_REQUIRE(n_fft == 2048, "the STFT kernel is built for n_fft = 2048 (LogMelSpectrogramConfig::default)");
+    hipLaunchKernelGGL((k_stft_mag<2048>), dim3(n_frames), dim3(256), 0, st, pcm, n, hop, n_frames, lin);
+    FS_HIP(hipGetLastError());
+}
+void codec_mel_log(const float* lin, const float* fb, int nf, int n_mels, int F, float* mel, hipStream_t st) {
+    hipLaunchKernelGGL(k_mel_log, dim3((F + 63) / 64, n_mels), dim3(64), 0, st, lin, fb, nf, n_mels, F, mel);
+    FS_HIP(hipGetLastError());
+}
+void codec_layernorm_cf(const float* x, int C, int T, const float* w, const float* b, float* y, hipStream_t st) {
+    hipLaunchKernelGGL(k_layernorm_cf, dim3((T + 63) / 64), dim3(64), 0, st, x, C, T, w, b, y);
+    FS_HIP(hipGetLastError());
+}
+void codec_space_to_depth(const float* x, int C, int T, int s, float* y, hipStream_t st) {
+    const int Tout = T / s;
+    hipLaunchKernelGGL(k_space_to_depth, dim3((Tout + 63) / 64, C * s), dim3(64), 0, st, x, C, T, s, Tout, y);
+    FS_HIP(hipGetLastError());
+}
+void codec_fsq_encode(const float* z, int C, int T, int G, const float* pin_w, const float* pin_b, uint32_t* codes, hipStream_t st) {
+    hipLaunchKernelGGL(k_fsq_encode, dim3((T + 63) / 64, G), dim3(64), 0, st, z, C, T, G, pin_w, pin_b, codes);
+    FS_HIP(hipGetLastError());
+}
+
+}  // namespace fs

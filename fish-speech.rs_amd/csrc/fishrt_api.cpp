@@ -95,6 +95,11 @@ int fs_codec_decode(fs_codec_t* c, const uint32_t* codes, int b, int T, float* p
     FS_ARG(c && codes && pcm_out, "null argument");
     FS_TRY(c->impl->decode(codes, b, T, pcm_out))
 }
+int fs_codec_encode(fs_codec_t* c, const float* pcm, int n_samples, uint32_t* codes_out, size_t cap, size_t* n_frames) {
+    FS_ARG(c && pcm && codes_out && n_frames, "null argument");
+    FS_ARG(n_samples > 0, "empty input");
+    FS_TRY(c->impl->encode(pcm, n_samples, codes_out, cap, n_frames))
+}
 int fs_codec_sample_rate(fs_codec_t* c) { return c ? c->impl->sample_rate() : -1; }
 
 }  // extern "C"

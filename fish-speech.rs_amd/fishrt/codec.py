@@ -1,4 +1,4 @@
-"""fish_speech_python `FireflyCodec` (codec.rs:18-115) over the C ABI: decode(u32[b,8,T]) -> f32[b,1,2048*T]."""
+"""fish_speech_python `FireflyCodec` (codec.rs:18-115) over the C ABI: decode(u32[b,8,T]) -> f32[b,1,2048*T], encode(f32[1,1,n]) -> u32[1,8,L]."""
 import ctypes as C
 
 import numpy as np
@@ -42,3 +42,17 @@ class FireflyCodec:
         _ffi.check(_ffi.lib().fs_codec_decode(self._h, codes.ctypes.data_as(C.POINTER(C.c_uint32)), b, T,
                                               pcm.ctypes.data_as(C.POINTER(C.c_float))))
         return pcm
+
+    def encode(self, pcm_data):
+        """codec.rs:73-94: f32 (1, 1, n) mono 44.1 kHz PCM (the samples are flattened, spectrogram.rs:33) -> u32 (1, 8, L)."""
+        if not isinstance(pcm_data, np.ndarray) or not pcm_data.flags["C_CONTIGUOUS"]:
+            raise ValueError("Data must be a contiguous array")
+        if pcm_data.ndim != 3:
+            raise ValueError("pcm_data must be a 3-D array (1, 1, n)")
+        pcm = pcm_data.astype(np.float32, copy=False).reshape(-1)
+        cap = pcm.size // 2048 + 4
+        codes = np.zeros((8, cap), np.uint32)
+        n = C.c_size_t(0)
+        _ffi.check(_ffi.lib().fs_codec_encode(self._h, pcm.ctypes.data_as(C.POINTER(C.c_float)), int(pcm.size),
+                                              codes.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_size_t(cap), C.byref(n)))
+        return codes[None, :, : n.value].copy()

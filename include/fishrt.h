@@ -140,6 +140,11 @@ int fs_codec_load_safetensors(fs_codec_t* c, const char* path);
 int fs_codec_load_synthetic(fs_codec_t* c, uint64_t seed);
 /* FireflyCodec::decode (codec/firefly.rs:42-48): codes u32 [b, 8, T] (values 0..999) -> pcm f32 [b, 1, 2048*T] */
 int fs_codec_decode(fs_codec_t* c, const uint32_t* codes, int b, int T, float* pcm_out);
+/* FireflyCodec::encode (codec/firefly.rs:37-40) for one mono 44.1 kHz clip: LogMelSpectrogram::forward (audio/spectrogram.rs:
+ * 153-158: streaming STFT n_fft 2048 / hop 512 with edge-repeating reflect padding, 160 slaney mel bins, clamp(1e-5,100).log())
+ * -> FireflyEncoder::encode (codec/encoder.rs:38-42: ConvNeXt backbone, downsample x4, grouped FSQ).  codes_out: u32 [8, cap]
+ * row-major, *n_frames = L = mel_frames / 4 codes per group.  (channel_div > 1 handles use a reduced backbone depth (1,1,2,1).) */
+int fs_codec_encode(fs_codec_t* c, const float* pcm, int n_samples, uint32_t* codes_out, size_t cap, size_t* n_frames);
 /* FireflyCodec.sample_rate (codec/firefly.rs:13) */
 int fs_codec_sample_rate(fs_codec_t* c);
 

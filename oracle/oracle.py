@@ -248,6 +248,48 @@ class OracleCodec:
         return (pcm, st) if stage is not None else pcm
 
 
+def mel_filterbank(sr=44100, n_fft=2048, n_mels=160):
+    out = np.zeros((n_fft // 2 + 1, n_mels), np.float32)
+    _chk(lib().orc_codec_mel_filterbank(int(sr), int(n_fft), int(n_mels), _p(out, C.c_float)))
+    return out
+
+
+def _codec_log_mel(self, pcm):
+    pcm = np.ascontiguousarray(pcm, np.float32).reshape(-1)
+    cap = pcm.size // 512 + 8
+    mel = np.zeros((160, cap), np.float32)
+    flat = np.zeros(160 * cap, np.float32)
+    fr = C.c_int(0)
+    _chk(lib().orc_codec_log_mel(self.h, _p(pcm, C.c_float), int(pcm.size), _p(flat, C.c_float), cap, C.byref(fr)))
+    return flat[: 160 * fr.value].reshape(160, fr.value).copy()
+
+
+def _codec_encode_mel(self, mel, stage=None, stage_size=0):
+    mel = np.ascontiguousarray(mel, np.float32)
+    frames = mel.shape[1]
+    codes = np.zeros((8, frames), np.uint32)
+    L = C.c_int(0)
+    st = np.zeros(stage_size, np.float32) if stage is not None else None
+    _chk(lib().orc_codec_encode_mel(self.h, _p(mel, C.c_float), int(frames), _p(codes, C.c_uint32), int(frames), C.byref(L),
+                                    int(stage or 0), _p(st, C.c_float) if st is not None else None))
+    out = codes.reshape(-1)[: 8 * L.value].reshape(8, L.value).copy()
+    return (out, st) if stage is not None else out
+
+
+def _codec_encode(self, pcm):
+    pcm = np.ascontiguousarray(pcm, np.float32).reshape(-1)
+    cap = pcm.size // 512 + 8
+    codes = np.zeros(8 * cap, np.uint32)
+    L = C.c_int(0)
+    _chk(lib().orc_codec_encode(self.h, _p(pcm, C.c_float), int(pcm.size), _p(codes, C.c_uint32), cap, C.byref(L)))
+    return codes[: 8 * L.value].reshape(8, L.value).copy()
+
+
+OracleCodec.log_mel = _codec_log_mel
+OracleCodec.encode_mel = _codec_encode_mel
+OracleCodec.encode = _codec_encode
+
+
 def num_threads():
     return lib().orc_num_threads()
 

@@ -3,6 +3,7 @@
 #include <string>
 
 #include "fsgen.h"
+#include <stdexcept>
 #include "oracle_codec.h"
 #include "oracle_lm.h"
 
@@ -181,6 +182,40 @@ int orc_codec_decode(void* c, const uint32_t* codes, int T, float* pcm_out, int 
         auto pcm = ((Codec*)c)->decode(codes, T, stage_out ? &st : nullptr);
         std::memcpy(pcm_out, pcm.data(), sizeof(float) * pcm.size());
         if (stage_out) std::memcpy(stage_out, st.at(stage_idx).data(), sizeof(float) * st.at(stage_idx).size());
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// ---- encoder side.  mel_out: (n_mels * frames) channel-first; codes_out: (n_groups * L)
+int orc_codec_mel_filterbank(int sr, int n_fft, int n_mels, float* out) {
+    try { auto fb = Codec::mel_filterbank(sr, n_fft, n_mels); std::memcpy(out, fb.data(), sizeof(float) * fb.size()); return 0; }
+    catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+int orc_codec_log_mel(void* c, const float* pcm, int n, float* mel_out, int cap_frames, int* frames) {
+    try {
+        auto mel = ((Codec*)c)->log_mel(pcm, n, frames);
+        if (*frames > cap_frames) throw std::runtime_error("mel_out too small");
+        std::memcpy(mel_out, mel.data(), sizeof(float) * mel.size());
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+int orc_codec_encode_mel(void* c, const float* mel, int frames, uint32_t* codes_out, int cap_L, int* L, int stage_idx, float* stage_out) {
+    try {
+        Codec* cc = (Codec*)c;
+        std::vector<float> m(mel, mel + (size_t)cc->n_mels * frames);
+        std::vector<std::vector<float>> st;
+        auto idx = cc->encode_mel(m, frames, L, stage_out ? &st : nullptr);
+        if (*L > cap_L) throw std::runtime_error("codes_out too small");
+        std::memcpy(codes_out, idx.data(), sizeof(uint32_t) * idx.size());
+        if (stage_out) std::memcpy(stage_out, st.at(stage_idx).data(), sizeof(float) * st.at(stage_idx).size());
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+int orc_codec_encode(void* c, const float* pcm, int n, uint32_t* codes_out, int cap_L, int* L) {
+    try {
+        auto idx = ((Codec*)c)->encode(pcm, n, L);
+        if (*L > cap_L) throw std::runtime_error("codes_out too small");
+        std::memcpy(codes_out, idx.data(), sizeof(uint32_t) * idx.size());
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }

@@ -5,6 +5,7 @@
 //   hifi_gan.rs:74-85,114-117,208-216, utils/mod.rs:53-62,110-122, config.rs:98-113,155-167
 #include "oracle_codec.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <stdexcept>
@@ -113,11 +114,13 @@ void Codec::init_fish15() {
     n_groups = 8; levels = {8, 5, 5, 5}; input_dim = 512; downsample = {2, 2};
     up_rates = {8, 8, 2, 2, 2}; up_kernels = {16, 16, 4, 4, 4}; res_kernels = {3, 7, 11}; res_dils = {1, 3, 5};
     init_ch = 512; pre_k = 13; post_k = 13;
+    enc_dims = {128, 256, 384, 512}; enc_depths = {3, 3, 9, 3};  // BackboneConfig::fish_1_4 (config.rs:47-57)
 }
 
 void Codec::init_tiny() {  // channels / 8, same topology (tests only)
     init_fish15();
     input_dim = 64; init_ch = 64;
+    enc_dims = {16, 32, 48, 64}; enc_depths = {1, 1, 2, 1};
 }
 
 static void fill_conv(Conv& c, int cout, int cin_per_group, int k, bool transpose_layout, const std::string& name,
@@ -185,6 +188,57 @@ void Codec::load_synthetic(uint64_t seed) {
         }
     }
     fill_conv(conv_post, 1, init_ch >> ns, post_k, false, "head.conv_post", seed);
+    // ---- encoder (names of convnext.rs:186-271, quantizer.rs:44-66, grouped_residual_fsq.rs:52-56)
+    auto fill_block = [&](ConvNeXt& b, int Cb, const std::string& q) {
+        fill_conv(b.dwconv, Cb, 1, 7, false, q + ".dwconv", seed);
+        b.norm_w.resize(Cb); b.norm_b.resize(Cb); b.gamma.resize(Cb);
+        fsgen::fill(b.norm_w.data(), Cb, q + ".norm.weight", seed, 1.f, 0.1, false);
+        fsgen::fill(b.norm_b.data(), Cb, q + ".norm.bias", seed, 0.f, 0.02, false);
+        b.pw1_w.resize((size_t)4 * Cb * Cb); b.pw1_b.resize(4 * Cb); b.pw2_w.resize((size_t)4 * Cb * Cb); b.pw2_b.resize(Cb);
+        fsgen::fill(b.pw1_w.data(), b.pw1_w.size(), q + ".pwconv1.weight", seed, 0.f, 1.0 / std::sqrt((double)Cb), false);
+        fsgen::fill(b.pw1_b.data(), 4 * Cb, q + ".pwconv1.bias", seed, 0.f, 0.02, false);
+        fsgen::fill(b.pw2_w.data(), b.pw2_w.size(), q + ".pwconv2.weight", seed, 0.f, 1.0 / std::sqrt(4.0 * Cb), false);
+        fsgen::fill(b.pw2_b.data(), Cb, q + ".pwconv2.bias", seed, 0.f, 0.02, false);
+        fsgen::fill(b.gamma.data(), Cb, q + ".gamma", seed, 0.1f, 0.02, false);
+    };
+    auto fill_ln = [&](std::vector<float>& w, std::vector<float>& b, int n, const std::string& q) {
+        w.resize(n); b.resize(n);
+        fsgen::fill(w.data(), n, q + ".weight", seed, 1.f, 0.1, false);
+        fsgen::fill(b.data(), n, q + ".bias", seed, 0.f, 0.02, false);
+    };
+    const int nst = (int)enc_dims.size();
+    fill_conv(stem_conv, enc_dims[0], n_mels, enc_k, false, "backbone.downsample_layers.0.0", seed);
+    fill_ln(stem_ln_w, stem_ln_b, enc_dims[0], "backbone.downsample_layers.0.1");
+    mid_ln_w.assign(nst, {}); mid_ln_b.assign(nst, {}); mid_conv.assign(nst, Conv());
+    stages.assign(nst, {});
+    for (int i = 0; i < nst; ++i) {
+        if (i > 0) {
+            const std::string q = "backbone.downsample_layers." + std::to_string(i);
+            fill_ln(mid_ln_w[i], mid_ln_b[i], enc_dims[i - 1], q + ".0");
+            Conv& c = mid_conv[i];  // plain Conv1d: tensors `1.weight` / `1.bias` (convnext.rs:229-233)
+            c.cout = enc_dims[i]; c.k = 1;
+            c.w.resize((size_t)enc_dims[i] * enc_dims[i - 1]); c.b.resize(enc_dims[i]);
+            fsgen::fill(c.w.data(), c.w.size(), q + ".1.weight", seed, 0.f, 1.0 / std::sqrt((double)enc_dims[i - 1]), false);
+            fsgen::fill(c.b.data(), c.b.size(), q + ".1.bias", seed, 0.f, 0.02, false);
+        }
+        stages[i].resize(enc_depths[i]);
+        for (int j = 0; j < enc_depths[i]; ++j) fill_block(stages[i][j], enc_dims[i], "backbone.stages." + std::to_string(i) + "." + std::to_string(j));
+    }
+    fill_ln(enc_norm_w, enc_norm_b, enc_dims[nst - 1], "backbone.norm");
+    down_conv.resize(downsample.size()); down_block.resize(downsample.size());
+    for (size_t i = 0; i < downsample.size(); ++i) {
+        const std::string q = "quantizer.downsample." + std::to_string(i);
+        fill_conv(down_conv[i], C, C, downsample[i], false, q + ".0", seed);
+        fill_block(down_block[i], C, q + ".1");
+    }
+    pin_w.resize(n_groups); pin_b.resize(n_groups);
+    for (int g = 0; g < n_groups; ++g) {
+        const std::string q = "quantizer.residual_fsq.rvqs." + std::to_string(g) + ".project_in";
+        pin_w[g].resize((size_t)4 * dg); pin_b[g].resize(4);
+        fsgen::fill(pin_w[g].data(), pin_w[g].size(), q + ".weight", seed, 0.f, 1.0 / std::sqrt((double)dg), false);
+        fsgen::fill(pin_b[g].data(), 4, q + ".bias", seed, 0.f, 0.02, false);
+    }
+    mel_fb = mel_filterbank(44100, n_fft, n_mels);
 }
 
 // fsq.rs:137-144 + :119-122 : code[k] = ((floor(idx / basis_k) mod levels_k) - hw_k) / hw_k
@@ -263,6 +317,215 @@ std::vector<float> Codec::decode(const uint32_t* codes, int T, std::vector<std::
     fish_conv1d(x.data(), ch, Tc, conv_post, 1, 1, pcm, To);
     for (auto& v : pcm) v = std::tanh(v);
     return pcm;
+}
+
+
+// ================================================================================================ encoder side
+// Slaney mel filterbank (librosa.filters.mel, norm = "slaney", htk = False) for f_min = 0, f_max = sr / 2, evaluated in f64
+// and rounded to f32, laid out [n_fft/2+1][n_mels] as load_mel_buffer reads it (spectrogram.rs:90-101).  The reference embeds
+// this table as a binary resource (melfilters160.bytes); regenerated here from the published formula -- max |diff| to the
+// embedded table 1.8e-7 (tests/test_codec_encode.py checks a committed sample of the table).
+std::vector<float> Codec::mel_filterbank(int sr, int n_fft, int n_mels) {
+    const int nf = n_fft / 2 + 1;
+    const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = std::log(6.4) / 27.0;
+    auto hz_to_mel = [&](double f) { return f >= min_log_hz ? min_log_mel + std::log(f / min_log_hz) / logstep : f / f_sp; };
+    auto mel_to_hz = [&](double m) { return m >= min_log_mel ? min_log_hz * std::exp(logstep * (m - min_log_mel)) : f_sp * m; };
+    std::vector<double> mel_f(n_mels + 2);
+    const double m0 = hz_to_mel(0.0), m1 = hz_to_mel(sr / 2.0);
+    for (int i = 0; i < n_mels + 2; ++i) mel_f[i] = mel_to_hz(m0 + (m1 - m0) * (double)i / (double)(n_mels + 1));
+    std::vector<float> fb((size_t)nf * n_mels, 0.f);
+    for (int m = 0; m < n_mels; ++m) {
+        const double enorm = 2.0 / (mel_f[m + 2] - mel_f[m]);
+        for (int f = 0; f < nf; ++f) {
+            const double freq = (sr / 2.0) * (double)f / (double)(nf - 1);
+            const double lower = (freq - mel_f[m]) / (mel_f[m + 1] - mel_f[m]), upper = (mel_f[m + 2] - freq) / (mel_f[m + 2] - mel_f[m + 1]);
+            const double w = std::max(0.0, std::min(lower, upper));
+            fb[(size_t)f * n_mels + m] = (float)(w * enorm);
+        }
+    }
+    return fb;
+}
+
+// in-place iterative radix-2 FFT (forward, f64) -- the transform rustfft computes for the reference (stft.rs:82-83)
+static void fft_f64(std::vector<double>& re, std::vector<double>& im) {
+    const size_t n = re.size();
+    for (size_t i = 1, j = 0; i < n; ++i) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { std::swap(re[i], re[j]); std::swap(im[i], im[j]); }
+    }
+    for (size_t len = 2; len <= n; len <<= 1) {
+        const double ang = -2.0 * M_PI / (double)len;
+        for (size_t i = 0; i < n; i += len)
+            for (size_t k = 0; k < len / 2; ++k) {
+                const double wr = std::cos(ang * (double)k), wi = std::sin(ang * (double)k);
+                const size_t a = i + k, b = i + k + len / 2;
+                const double xr = re[b] * wr - im[b] * wi, xi = re[b] * wi + im[b] * wr;
+                re[b] = re[a] - xr; im[b] = im[a] - xi;
+                re[a] += xr; im[a] += xi;
+            }
+    }
+}
+
+std::vector<float> Codec::log_mel(const float* pcm, int n, int* frames_out) const {
+    const int pad = (n_fft - hop_length) / 2, nf = n_fft / 2 + 1;
+    if (n < pad) throw std::runtime_error("input shorter than the reflect padding (the reference slices out of range)");
+    // reflect_pad (spectrogram.rs:15-27): the edge samples ARE repeated (signal[0..pad] reversed)
+    std::vector<float> x((size_t)n + 2 * pad);
+    for (int i = 0; i < pad; ++i) x[i] = pcm[pad - 1 - i];
+    std::memcpy(&x[pad], pcm, sizeof(float) * n);
+    for (int i = 0; i < pad; ++i) x[(size_t)pad + n + i] = pcm[n - 1 - i];
+    const long long Lp = (long long)x.size();
+    // streaming STFT (stft.rs:52-90): a frame is emitted once >= n_fft samples were pushed; frame f = padded[f*hop, f*hop + n_fft),
+    // the final partial hop zero-filled
+    const long long full = Lp / hop_length, rem = Lp % hop_length;
+    long long n_frames = std::max(0LL, full - (n_fft / hop_length - 1));
+    if (rem > 0 && full * hop_length + rem >= n_fft) n_frames += 1;
+    *frames_out = (int)n_frames;
+    std::vector<double> win(n_fft);
+    for (int i = 0; i < n_fft; ++i) win[i] = 0.5 * (1.0 - std::cos((2.0 * M_PI * (double)i) / (double)n_fft));
+    std::vector<float> lin((size_t)nf * n_frames);  // channel-first [nf][frames]
+#pragma omp parallel for schedule(static)
+    for (long long f = 0; f < n_frames; ++f) {
+        std::vector<double> re(n_fft), im(n_fft, 0.0);
+        for (int j = 0; j < n_fft; ++j) {
+            const long long idx = f * hop_length + j;
+            re[j] = (idx < Lp ? (double)x[idx] : 0.0) * win[j];
+        }
+        fft_f64(re, im);
+        for (int k = 0; k < nf; ++k) lin[(size_t)k * n_frames + f] = (float)std::sqrt(re[k] * re[k] + im[k] * im[k]) + 1e-6f;
+    }
+    // apply_mel_scale + compress (spectrogram.rs:136-151): (frames, nf) . (nf, n_mels) -> transpose; clamp(1e-5, 100).log()
+    std::vector<float> mel((size_t)n_mels * n_frames);
+#pragma omp parallel for schedule(static)
+    for (int m = 0; m < n_mels; ++m)
+        for (long long f = 0; f < n_frames; ++f) {
+            float acc = 0.f;
+            for (int k = 0; k < nf; ++k) acc += lin[(size_t)k * n_frames + f] * mel_fb[(size_t)k * n_mels + m];
+            mel[(size_t)m * n_frames + f] = std::log(std::min(std::max(acc, 1e-5f), 100.0f));
+        }
+    return mel;
+}
+
+// LayerNormChannelsFirst (convnext.rs:144-154): per time step over channels, eps 1e-6
+static void layernorm_cf(std::vector<float>& x, int C, int T, const std::vector<float>& w, const std::vector<float>& b) {
+#pragma omp parallel for schedule(static)
+    for (int t = 0; t < T; ++t) {
+        float mean = 0.f;
+        for (int c = 0; c < C; ++c) mean += x[(size_t)c * T + t];
+        mean /= (float)C;
+        float var = 0.f;
+        for (int c = 0; c < C; ++c) { const float d = x[(size_t)c * T + t] - mean; var += d * d; }
+        var /= (float)C;
+        const float sd = std::sqrt(var + 1e-6f);
+        for (int c = 0; c < C; ++c) x[(size_t)c * T + t] = (x[(size_t)c * T + t] - mean) / sd * w[c] + b[c];
+    }
+}
+
+// FishConvNet with stride (utils/mod.rs:53-62): left pad (k-1)+1-stride zeros, then conv1d(stride)
+static void fish_conv1d_strided(const float* x, int Cin, int T, const Conv& c, int stride, std::vector<float>& y, int& Tout) {
+    const int k = c.k, Cout = c.cout, pad = k - stride;
+    const int Tp = T + pad;
+    Tout = (Tp - k) / stride + 1;
+    y.assign((size_t)Cout * Tout, 0.f);
+#pragma omp parallel for schedule(static)
+    for (int o = 0; o < Cout; ++o)
+        for (int t = 0; t < Tout; ++t) {
+            float acc = 0.f;
+            for (int i = 0; i < Cin; ++i)
+                for (int kk = 0; kk < k; ++kk) {
+                    const int src = t * stride + kk - pad;
+                    if (src >= 0) acc += c.w[((size_t)o * Cin + i) * k + kk] * x[(size_t)i * T + src];
+                }
+            y[(size_t)o * Tout + t] = acc + c.b[o];
+        }
+}
+
+// plain candle Conv1d k = 1 (MidLayer, convnext.rs:229-238)
+static void conv1x1(const std::vector<float>& x, int Cin, int T, const Conv& c, std::vector<float>& y) {
+    y.assign((size_t)c.cout * T, 0.f);
+#pragma omp parallel for schedule(static)
+    for (int o = 0; o < c.cout; ++o) {
+        float* yo = &y[(size_t)o * T];
+        for (int i = 0; i < Cin; ++i) {
+            const float w = c.w[(size_t)o * Cin + i];
+            const float* xi = &x[(size_t)i * T];
+            for (int t = 0; t < T; ++t) yo[t] += w * xi[t];
+        }
+        for (int t = 0; t < T; ++t) yo[t] += c.b[o];
+    }
+}
+
+// FSQ::bound (fsq.rs:68-84) for one coordinate of level count lv, all f32 as candle evaluates it
+static inline float fsq_bound(float z, int lv) {
+    const float half_l = ((float)lv - 1.0f) * 1.001f / 2.0f;
+    const float offset = (lv % 2 == 0) ? 0.5f : 0.0f;
+    const float q = offset / half_l;
+    const float shift = std::log((1.0f + q) / (1.0f - q)) * 0.5f;  // atanh as the reference spells it (fsq.rs:20-25)
+    return std::tanh(z + shift) * half_l - offset;
+}
+
+std::vector<uint32_t> Codec::encode_mel(const std::vector<float>& mel, int frames, int* L_out, std::vector<std::vector<float>>* so) const {
+    int T = frames, To;
+    // ConvNeXtEncoder (convnext.rs:319-331): stem conv + LN + blocks, then (LN + 1x1 conv + blocks) x 3, final LN
+    std::vector<float> x;
+    fish_conv1d(mel.data(), n_mels, T, stem_conv, 1, 1, x, To);
+    layernorm_cf(x, enc_dims[0], T, stem_ln_w, stem_ln_b);
+    for (const auto& b : stages[0]) convnext_block(b, x, enc_dims[0], T);
+    if (so) so->push_back(x);
+    for (size_t i = 1; i < enc_dims.size(); ++i) {
+        layernorm_cf(x, enc_dims[i - 1], T, mid_ln_w[i], mid_ln_b[i]);
+        std::vector<float> y;
+        conv1x1(x, enc_dims[i - 1], T, mid_conv[i], y);
+        x.swap(y);
+        for (const auto& b : stages[i]) convnext_block(b, x, enc_dims[i], T);
+        if (so) so->push_back(x);
+    }
+    layernorm_cf(x, enc_dims.back(), T, enc_norm_w, enc_norm_b);
+    if (so) so->push_back(x);
+    // quantizer.encode (quantizer.rs:104-124): downsample convs + blocks, then grouped residual FSQ
+    const int C = input_dim;
+    for (size_t i = 0; i < down_conv.size(); ++i) {
+        std::vector<float> y;
+        fish_conv1d_strided(x.data(), C, T, down_conv[i], downsample[i], y, To);
+        x.swap(y); T = To;
+        convnext_block(down_block[i], x, C, T);
+        if (so) so->push_back(x);
+    }
+    // ResidualFSQ::forward with num_quantizers == 1 (grouped_residual_fsq.rs:75-93): project_in, bound, then the layer's own
+    // quantize = round(bound(residual / scale)) / half_width (fsq.rs:86-91) -- bound is applied TWICE, as in the reference
+    const int dg = C / n_groups;
+    std::vector<uint32_t> idx((size_t)n_groups * T);
+    std::vector<float> margin((size_t)n_groups * T, 1.f);  // distance of the pre-round value from the nearest x.5 boundary
+    for (int g = 0; g < n_groups; ++g)
+        for (int t = 0; t < T; ++t) {
+            float sum = 0.f;
+            int basis = 1;
+            for (size_t k = 0; k < levels.size(); ++k) {
+                float acc = 0.f;
+                for (int c = 0; c < dg; ++c) acc += x[(size_t)(g * dg + c) * T + t] * pin_w[g][k * dg + c];
+                acc += pin_b[g][k];
+                const float residual = fsq_bound(acc, levels[k]);
+                const float hw = std::floor((float)levels[k] / 2.0f);
+                const float pre = fsq_bound(residual / 1.0f, levels[k]);
+                margin[(size_t)g * T + t] = std::min(margin[(size_t)g * T + t], std::fabs(std::fabs(pre - std::floor(pre)) - 0.5f));
+                const float code = std::round(pre) / hw;                                         // quantize
+                const float zhat = code * hw + hw;                                               // _scale_and_shift
+                sum += zhat * (float)basis;                                                      // codes_to_indices: sum then -> i64
+                basis *= levels[k];
+            }
+            idx[(size_t)g * T + t] = (uint32_t)(long long)sum;
+        }
+    if (so) so->push_back(margin);  // test aid (last stage): a GPU index may differ only where this is ~0
+    *L_out = T;
+    return idx;
+}
+
+std::vector<uint32_t> Codec::encode(const float* pcm, int n, int* L) const {
+    int frames = 0;
+    const std::vector<float> mel = log_mel(pcm, n, &frames);
+    return encode_mel(mel, frames, L);
 }
 
 }  // namespace oracle

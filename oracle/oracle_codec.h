@@ -31,6 +31,27 @@ struct Codec {
     std::vector<Conv> ups;
     std::vector<std::vector<ResBlock1>> res;  // [stage][kernel]
 
+    // ---- encoder side (FireflyCodec::encode, firefly.rs:37-40): mel front-end + ConvNeXt backbone + downsample + FSQ
+    int n_mels = 160, n_fft = 2048, hop_length = 512, enc_k = 7;
+    std::vector<int> enc_dims, enc_depths;            // backbone dims / depths (config.rs:47-57)
+    Conv stem_conv;                                   // backbone.downsample_layers.0.0 (FishConvNet k = 7)
+    std::vector<float> stem_ln_w, stem_ln_b;          // backbone.downsample_layers.0.1
+    std::vector<std::vector<float>> mid_ln_w, mid_ln_b;  // backbone.downsample_layers.i.0, i = 1..3
+    std::vector<Conv> mid_conv;                       // backbone.downsample_layers.i.1 (Conv1d k = 1)
+    std::vector<std::vector<ConvNeXt>> stages;        // backbone.stages.i.j
+    std::vector<float> enc_norm_w, enc_norm_b;        // backbone.norm
+    std::vector<Conv> down_conv;                      // quantizer.downsample.i.0 (FishConvNet k = stride = factor)
+    std::vector<ConvNeXt> down_block;                 // quantizer.downsample.i.1
+    std::vector<std::vector<float>> pin_w, pin_b;     // per group project_in [4, dim/groups], [4]
+    std::vector<float> mel_fb;                        // [n_fft/2+1][n_mels], slaney filterbank (see mel_filterbank)
+
+    static std::vector<float> mel_filterbank(int sample_rate, int n_fft, int n_mels);
+    // audio/spectrogram.rs:29-158 + stft.rs:52-90: pcm (n) -> log-mel (n_mels, frames), channel-first
+    std::vector<float> log_mel(const float* pcm, int n, int* frames) const;
+    // encoder.rs:38-42 + quantizer.rs:104-124: log-mel (n_mels, frames) -> indices (n_groups, L)
+    std::vector<uint32_t> encode_mel(const std::vector<float>& mel, int frames, int* L, std::vector<std::vector<float>>* stages_out = nullptr) const;
+    std::vector<uint32_t> encode(const float* pcm, int n, int* L) const;
+
     void init_fish15();
     void init_tiny();
     void load_synthetic(uint64_t seed);

@@ -420,6 +420,112 @@ def make_codec_golden():
     np.savez_compressed(os.path.join(HERE, "codec_tiny.npz"), **out)
 
 
+
+# ----------------------------------------------------------------------------- Firefly encoder (tiny: dims / 8, depths 1,1,2,1)
+REF_MEL = "/root/reference/fish_speech_core/lib/audio/melfilters160.bytes"
+
+
+def torch_log_mel(pcm, mel_table):
+    """spectrogram.rs:29-158 + stft.rs:52-90 with numpy's f64 FFT: reflect pad that REPEATS the edge, frame f = padded[512 f,
+    512 f + 2048) (tail zero-filled), periodic Hann, |.| -> f32, + 1e-6, (frames, 1025) @ (1025, 160), clamp(1e-5, 100).log()"""
+    pad = 768
+    x = np.concatenate([pcm[:pad][::-1], pcm, pcm[-pad:][::-1]]).astype(np.float64)
+    full, rem = divmod(len(x), 512)
+    n_frames = max(0, full - 3) + (1 if rem > 0 and len(x) >= 2048 else 0)
+    win = 0.5 * (1.0 - np.cos(2.0 * np.pi * np.arange(2048) / 2048.0))
+    frames = np.stack([np.pad(x[f * 512:f * 512 + 2048], (0, max(0, f * 512 + 2048 - len(x)))) * win for f in range(n_frames)])
+    lin = np.abs(np.fft.fft(frames, axis=1)[:, :1025]).astype(np.float32) + np.float32(1e-6)
+    mel = torch.from_numpy(lin) @ torch.from_numpy(mel_table)
+    return torch.log(torch.clamp(mel, 1e-5, 100.0)).t().contiguous()  # (160, frames)
+
+
+def ln_cf(x, w, b):  # LayerNormChannelsFirst (convnext.rs:144-154); x (1, C, T)
+    u = x.mean(1, keepdim=True)
+    s = (x - u).pow(2).mean(1, keepdim=True)
+    return (x - u) / torch.sqrt(s + 1e-6) * w[None, :, None] + b[None, :, None]
+
+
+def cnx_block(z, q, C, seed):  # convnext.rs:110-126
+    dw, db = conv_w(q + ".dwconv", C, 1, 7, seed)
+    h = fish_conv(z, dw, db, 1, C).permute(0, 2, 1)
+    h = F.layer_norm(h, (C,), synth(q + ".norm.weight", (C,), seed, 1.0, 0.1), synth(q + ".norm.bias", (C,), seed, 0.0, 0.02), 1e-6)
+    h = F.gelu(h @ synth(q + ".pwconv1.weight", (4 * C, C), seed, 0.0, 1.0 / math.sqrt(C)).t()
+               + synth(q + ".pwconv1.bias", (4 * C,), seed, 0.0, 0.02), approximate="tanh")
+    h = h @ synth(q + ".pwconv2.weight", (C, 4 * C), seed, 0.0, 1.0 / math.sqrt(4.0 * C)).t() + synth(q + ".pwconv2.bias", (C,), seed, 0.0, 0.02)
+    return z + (synth(q + ".gamma", (C,), seed, 0.1, 0.02) * h).permute(0, 2, 1)
+
+
+def torch_codec_encode_mel(mel, seed, dims, depths):
+    """encoder.rs:38-42: ConvNeXtEncoder (convnext.rs:319-331) -> quantizer.encode (quantizer.rs:104-124, FSQ fsq.rs:68-118)."""
+    stages = []
+    x = mel.unsqueeze(0)
+    w, b = conv_w("backbone.downsample_layers.0.0", dims[0], 160, 7, seed)
+    x = fish_conv(x, w, b)
+    x = ln_cf(x, synth("backbone.downsample_layers.0.1.weight", (dims[0],), seed, 1.0, 0.1), synth("backbone.downsample_layers.0.1.bias", (dims[0],), seed, 0.0, 0.02))
+    for j in range(depths[0]):
+        x = cnx_block(x, f"backbone.stages.0.{j}", dims[0], seed)
+    stages.append(x[0].clone())
+    for i in range(1, 4):
+        q = f"backbone.downsample_layers.{i}"
+        x = ln_cf(x, synth(q + ".0.weight", (dims[i - 1],), seed, 1.0, 0.1), synth(q + ".0.bias", (dims[i - 1],), seed, 0.0, 0.02))
+        x = F.conv1d(x, synth(q + ".1.weight", (dims[i], dims[i - 1], 1), seed, 0.0, 1.0 / math.sqrt(dims[i - 1])), synth(q + ".1.bias", (dims[i],), seed, 0.0, 0.02))
+        for j in range(depths[i]):
+            x = cnx_block(x, f"backbone.stages.{i}.{j}", dims[i], seed)
+        stages.append(x[0].clone())
+    x = ln_cf(x, synth("backbone.norm.weight", (dims[3],), seed, 1.0, 0.1), synth("backbone.norm.bias", (dims[3],), seed, 0.0, 0.02))
+    stages.append(x[0].clone())
+    C = dims[3]
+    for i in range(2):
+        q = f"quantizer.downsample.{i}"
+        w, b = conv_w(q + ".0", C, C, 2, seed)
+        x = F.conv1d(x, w, b, stride=2)  # FishConvNet: pad = k - stride = 0
+        x = cnx_block(x, q + ".1", C, seed)
+        stages.append(x[0].clone())
+    zt = x[0].t()  # (L, C)
+    G, dg = 8, C // 8
+    lv = torch.tensor([8.0, 5.0, 5.0, 5.0])
+    basis = torch.tensor([1.0, 8.0, 40.0, 200.0])
+    half_l = (lv - 1.0) * 1.001 / 2.0
+    offset = torch.where(lv % 2 == 0, torch.tensor(0.5), torch.tensor(0.0))
+    qv = offset / half_l
+    shift = torch.log((1.0 + qv) / (1.0 - qv)) * 0.5
+
+    def bound(z):
+        return torch.tanh(z + shift) * half_l - offset
+
+    hw = torch.floor(lv / 2.0)
+    out = []
+    for g in range(G):
+        p = f"quantizer.residual_fsq.rvqs.{g}.project_in"
+        z = zt[:, g * dg:(g + 1) * dg] @ synth(p + ".weight", (4, dg), seed, 0.0, 1.0 / math.sqrt(dg)).t() + synth(p + ".bias", (4,), seed, 0.0, 0.02)
+        residual = bound(z)
+        codes = torch.round(bound(residual / 1.0)) / hw      # torch.round is half-to-even; exact .5 does not occur after tanh
+        idx = ((codes * hw + hw) * basis).sum(-1).to(torch.int64)
+        out.append(idx)
+    return torch.stack(out, 0).numpy().astype(np.uint32), stages
+
+
+def make_codec_enc_golden():
+    seed = 0xC0DEC
+    rng = np.random.RandomState(11)
+    n = 512 * 30 + 123
+    t = np.arange(n) / 44100.0
+    pcm = (0.3 * np.sin(2 * np.pi * 220.0 * t) + 0.1 * np.sin(2 * np.pi * 1870.0 * t + 1.0) + 0.05 * rng.randn(n)).astype(np.float32)
+    table = np.fromfile(REF_MEL, dtype="<f4").reshape(1025, 160)
+    mel = torch_log_mel(pcm, table)
+    codes, stages = torch_codec_encode_mel(mel, seed, [16, 32, 48, 64], [1, 1, 2, 1])
+    out = dict(pcm=pcm, seed=np.uint64(seed), mel=mel.numpy(), codes=codes)
+    for i, s in enumerate(stages):
+        out[f"stage{i}"] = s.numpy()
+    # a sample of the reference's embedded mel table (the build regenerates the table from the slaney formula)
+    flat = table.reshape(-1)
+    nz = np.nonzero(flat)[0]
+    pick = np.concatenate([nz[rng.choice(len(nz), 400, replace=False)], rng.choice(flat.size, 112, replace=False)]).astype(np.int64)
+    out["mel_table_idx"], out["mel_table_val"] = pick, flat[pick]
+    print("  codec enc tiny: mel", tuple(mel.shape), "codes", codes.shape, "stage rms", [round(float(s.pow(2).mean().sqrt()), 3) for s in stages])
+    np.savez_compressed(os.path.join(HERE, "codec_enc_tiny.npz"), **out)
+
+
 def make_known_answers():
     """Weight-free known answers derived by hand from the reference sources."""
     out = {}
@@ -447,11 +553,13 @@ def make_known_answers():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["known", "lm", "codec"]
+    which = sys.argv[1:] or ["known", "lm", "codec", "enc"]
     if "known" in which:
         make_known_answers()
     if "lm" in which:
         make_lm_golden()
     if "codec" in which:
         make_codec_golden()
+    if "enc" in which:
+        make_codec_enc_golden()  # needs /root/reference (mel table): build container only
     print("wrote", sorted(f for f in os.listdir(HERE) if f.endswith(".npz")))

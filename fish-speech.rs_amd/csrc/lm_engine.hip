@@ -800,6 +800,7 @@ class LM final : public LMBase {
             cf.state = d_fast_state_.as<SeqState>() + cbi;
             cf.pt_stride = 1;
             cf.nc_launch = 1;
+            cf.small_attn = a_.num_codebooks <= 8;
             for (int l = 0; l < a_.n_fast_layer; ++l) {
                 KVView kv;
                 KT* base = fast_pool_.as<KT>() + ((size_t)l * 2 * B_) * page_elems_;

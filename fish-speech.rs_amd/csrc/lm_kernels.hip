@@ -867,6 +867,66 @@ __global__ __launch_bounds__(256) void k_attn_combine(const float* __restrict__ 
     }
 }
 
+// Whole attention of one activation row over <= 8 cached tokens (the fast decoder in the batched row path): all H heads in one
+// block, scores by two threads per (head, token), softmax . V with four output dims per thread, result straight into the
+// fragment-major hi/lo GEMM input -- replaces k_attn_decode + k_attn_combine (two graph nodes) where one 8-token page is all
+// there is.  The row's page is page_table[m * pt_stride] (single page), its length state->pos + 1 + m * pos_step <= 8.
+template <int DH>
+__global__ __launch_bounds__(256) void k_attn_small_rows(const float* __restrict__ q_all, KVView kv, const SeqState* __restrict__ state,
+                                                         int H, int Hk, int pos_step, int pt_stride, bf16_t* __restrict__ Ohi) {
+    __shared__ float sc[32 * 8];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const int T = state->pos + 1 + m * pos_step;
+    const int page = kv.page_table[(size_t)m * pt_stride];
+    const int n_rep = H / Hk;
+    const float* q = q_all + (size_t)m * H * DH;
+    const bf16_t* kb = reinterpret_cast<const bf16_t*>(kv.k) + (size_t)page * Hk * KV_PAGE * DH;
+    const bf16_t* vb = reinterpret_cast<const bf16_t*>(kv.v) + (size_t)page * Hk * KV_PAGE * DH;
+    const float scale = 1.0f / sqrtf((float)DH);
+    constexpr int QD = DH / 2;
+    for (int e1 = tid >> 1; e1 < H * 8; e1 += 128) {
+        const int h = e1 >> 3, t = e1 & 7, sl = tid & 1;
+        const bf16_t* kp = kb + ((size_t)(h / n_rep) * KV_PAGE + t) * DH + sl * QD;
+        const float* qp = q + h * DH + sl * QD;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < QD; i += 8) {
+            float kf[8];
+            WTr<bf16_t>::unpack(*reinterpret_cast<const u32x4*>(kp + i), kf);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc = fmaf(qp[i + j], kf[j] * scale, acc);  // q . (k^T * scale)  (dual_ar.rs:260)
+        }
+        acc += dpp_mov<DPP_XOR1>(acc);
+        if (sl == 0) sc[e1] = acc;
+    }
+    __syncthreads();
+    for (int e4 = tid * 4; e4 < H * DH; e4 += 1024) {
+        const int h = e4 / DH, dd = e4 % DH;
+        float mx = -1e30f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) if (t < T) mx = fmaxf(mx, sc[h * 8 + t]);
+        float L = 0.f, O[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            if (t < T) {
+                const float p = __expf(sc[h * 8 + t] - mx);
+                L += p;
+                const uint2 vv = *reinterpret_cast<const uint2*>(vb + ((size_t)(h / n_rep) * KV_PAGE + t) * DH + dd);
+                O[0] = fmaf(p, bf16_bits_to_f32((bf16_t)(vv.x & 0xFFFFu)), O[0]); O[1] = fmaf(p, bf16_bits_to_f32((bf16_t)(vv.x >> 16)), O[1]);
+                O[2] = fmaf(p, bf16_bits_to_f32((bf16_t)(vv.y & 0xFFFFu)), O[2]); O[3] = fmaf(p, bf16_bits_to_f32((bf16_t)(vv.y >> 16)), O[3]);
+            }
+        const float inv = 1.f / L;
+        bf16_t hi[4], lo[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) split_bf16(O[i] * inv, hi[i], lo[i]);
+        uint2 ph, pl;
+        ph.x = hi[0] | ((uint32_t)hi[1] << 16); ph.y = hi[2] | ((uint32_t)hi[3] << 16);
+        pl.x = lo[0] | ((uint32_t)lo[1] << 16); pl.y = lo[2] | ((uint32_t)lo[3] << 16);
+        *reinterpret_cast<uint2*>(Ohi + frag_off(m, e4, 0, H * DH)) = ph;
+        *reinterpret_cast<uint2*>(Ohi + frag_off(m, e4, 1, H * DH)) = pl;
+    }
+}
+
 template <typename WT>
 __global__ void k_embed_rows(const WT* __restrict__ tok_emb, const WT* __restrict__ cb_emb, int dim, int n_cb, int cb_size,
                              const SampleCfg* __restrict__ cfg, const uint32_t* __restrict__ prompt,
@@ -2064,22 +2124,30 @@ void LmKernels<WT>::rows_layer(const ModelDims& d, int M, const RowsCtx& c, cons
         if (c.stage_mask & 2u) launch_gemm3<EPI_QKV>(qkv_rows, 1, 1, st, c.A, M, d.dim, (const bf16_t*)w.wqkv, c.Q, d.dim, 0, nullptr, 0,
                               c.cos_t, c.sin_t, c.state, kv, d.H, d.Hk, d.Dh, rm);
         // (3) attention over each row's KV prefix + chunk combine -> hi/lo
+        if (c.small_attn && (c.stage_mask & 4u) && d.H <= 32 && (d.Dh == 64 || d.Dh == 32)) {
+            // fast decoder: <= 8 tokens in one page -> one node instead of two
+            if (d.Dh == 64)
+                hipLaunchKernelGGL((k_attn_small_rows<64>), dim3(M), dim3(256), 0, st, c.Q, kv, c.state, d.H, d.Hk, c.pos_step, c.pt_stride, c.A);
+            else
+                hipLaunchKernelGGL((k_attn_small_rows<32>), dim3(M), dim3(256), 0, st, c.Q, kv, c.state, d.H, d.Hk, c.pos_step, c.pt_stride, c.A);
+        } else {
         const dim3 ga(d.Hk * c.nc_launch, M);
-        const dim3 ta(AttnGeom<WT>::NW * 64);
-        if (!(c.stage_mask & 4u)) {}
-        else if (d.Dh == 64 && d.n_rep == 8)
-            hipLaunchKernelGGL((k_attn_decode<WT, 64, 8>), ga, ta, 0, st, c.Q, kv, c.state, c.part, d.Hk, c.n_chunks_max, c.nc_launch, c.pos_step, c.pt_stride);
-        else if (d.Dh == 32 && d.n_rep == 2)
-            hipLaunchKernelGGL((k_attn_decode<WT, 32, 2>), ga, ta, 0, st, c.Q, kv, c.state, c.part, d.Hk, c.n_chunks_max, c.nc_launch, c.pos_step, c.pt_stride);
-        else if (d.Dh == 64 && d.n_rep == 2)
-            hipLaunchKernelGGL((k_attn_decode<WT, 64, 2>), ga, ta, 0, st, c.Q, kv, c.state, c.part, d.Hk, c.n_chunks_max, c.nc_launch, c.pos_step, c.pt_stride);
-        else
-            throw Error("unsupported attention geometry");
-        if (!(c.stage_mask & 8u)) {}
-        else if (d.Dh == 64)
-            hipLaunchKernelGGL((k_attn_combine<64>), dim3(M), dim3(256), 0, st, c.part, c.n_chunks_max, attn_chunk(), c.state, c.pos_step, c.A, d.H);
-        else
-            hipLaunchKernelGGL((k_attn_combine<32>), dim3(M), dim3(256), 0, st, c.part, c.n_chunks_max, attn_chunk(), c.state, c.pos_step, c.A, d.H);
+            const dim3 ta(AttnGeom<WT>::NW * 64);
+            if (!(c.stage_mask & 4u)) {}
+            else if (d.Dh == 64 && d.n_rep == 8)
+                hipLaunchKernelGGL((k_attn_decode<WT, 64, 8>), ga, ta, 0, st, c.Q, kv, c.state, c.part, d.Hk, c.n_chunks_max, c.nc_launch, c.pos_step, c.pt_stride);
+            else if (d.Dh == 32 && d.n_rep == 2)
+                hipLaunchKernelGGL((k_attn_decode<WT, 32, 2>), ga, ta, 0, st, c.Q, kv, c.state, c.part, d.Hk, c.n_chunks_max, c.nc_launch, c.pos_step, c.pt_stride);
+            else if (d.Dh == 64 && d.n_rep == 2)
+                hipLaunchKernelGGL((k_attn_decode<WT, 64, 2>), ga, ta, 0, st, c.Q, kv, c.state, c.part, d.Hk, c.n_chunks_max, c.nc_launch, c.pos_step, c.pt_stride);
+            else
+                throw Error("unsupported attention geometry");
+            if (!(c.stage_mask & 8u)) {}
+            else if (d.Dh == 64)
+                hipLaunchKernelGGL((k_attn_combine<64>), dim3(M), dim3(256), 0, st, c.part, c.n_chunks_max, attn_chunk(), c.state, c.pos_step, c.A, d.H);
+            else
+                hipLaunchKernelGGL((k_attn_combine<32>), dim3(M), dim3(256), 0, st, c.part, c.n_chunks_max, attn_chunk(), c.state, c.pos_step, c.A, d.H);
+        }
         // (4) Wo + residual (each output element owned by one lane: deterministic)
         if (c.stage_mask & 16u) launch_gemm3<EPI_RESIDUAL>(d.dim, 1, 1, st, c.A, M, d.dim, (const bf16_t*)w.wo, c.X, d.dim, 0, nullptr, 0,
                                    nullptr, nullptr, nullptr, nokv, 0, 0, 0, none);

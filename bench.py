@@ -156,7 +156,8 @@ def main():
 
 def extras(cfg, tok):
     """Side measurements outside the timed region (not part of `value`): BASELINE.json configs[2] (static batch of 32 on the
-    MFMA row path) and the Firefly vocoder on the 256 frames of one request."""
+    MFMA row path), the Firefly vocoder on the 256 frames of one request, the encoder on a 10 s clip, and batch-1 decode with the
+    on-device top-k/top-p sampler and with fp8 weights."""
     import fishrt
     out = {}
     B, frames = 32, 64
@@ -187,7 +188,27 @@ def extras(cfg, tok):
     out["vocoder"] = {"workload": "FireflyCodec.decode of 256 frames (11.9 s of 44.1 kHz audio), f32, host buffers in/out",
                       "ms": round(dt * 1e3, 2), "rtf": round((256 / FRAME_RATE) / dt, 1), "tflops_f32": round(2.65e9 * 256 / dt / 1e12, 2),
                       "pcm_finite": bool(np.isfinite(pcm).all())}
+    # FireflyCodec.encode of a 10 s clip (mel front-end + ConvNeXt encoder + FSQ), host buffers in/out
+    t = np.arange(441000) / 44100.0
+    clip = (0.3 * np.sin(2 * np.pi * 220.0 * t) + 0.05 * np.random.RandomState(2).randn(t.size)).astype(np.float32)[None, None]
+    codec.encode(clip)
+    t0 = time.perf_counter()
+    enc = codec.encode(clip)
+    dt = time.perf_counter() - t0
+    out["encoder"] = {"workload": "FireflyCodec.encode of 10 s of 44.1 kHz audio (log-mel + ConvNeXt encoder + grouped FSQ), f32",
+                      "ms": round(dt * 1e3, 2), "rtf": round(10.0 / dt, 1), "codes_shape": list(enc.shape)}
     codec.close()
+    # batch-1 decode under the server's default sampling (temp 0.7 / top-p 0.8 / top-k 256, on-device sampler) and with fp8 weights
+    tokp = default_voice_prompt(tok)
+    for name, dtype, kw in (("sampled_b1", "bf16", dict(temp=0.7, top_p=0.8, top_k=256)), ("fp8_b1_greedy", "fp8", dict(temp=0.0, top_p=1.0, top_k=0))):
+        lm1 = fishrt.DualARTransformer(cfg, tok, 0, dtype).load_synthetic(SEED)
+        for _ in range(2):
+            lm1.clear_slow_layer_caches()
+            lm1.generate_blocking(tokp, 128 + tokp.shape[1] - 2, repetition_penalty=1.2, seed=1, ignore_eos=True, **kw)
+        st1 = lm1.last_stats()
+        out[name] = {"workload": f"configs[1] prompt, 128 frames, {dtype} weights, {kw}", "frame_us": round(st1["decode_ms"] * 1e3 / 127, 1),
+                     "decode_frames_per_s": round(127 / (st1["decode_ms"] * 1e-3), 1)}
+        lm1.close()
     return out
 
 

@@ -179,9 +179,10 @@ __device__ __forceinline__ WT* kv_addr(void* pool, const int* __restrict__ page_
 }
 
 // ------------------------------------------------------------------------------------------------ qkv + rope + kv append
-// One wave per interleaved-RoPE row PAIR (2p, 2p+1) of Wqkv, both rows' loads in flight together, so the pair meets in
-// registers (no LDS, no block barrier).  Position, page and cos/sin are fetched at kernel entry so the epilogue has no
-// dependent load left.
+// One wave per ROW of Wqkv (measured: a 2 MB GEMV node costs 2.4 us at one row per wave, 3.1 us at two -- the wave count, not
+// the byte count, sets the latency of these small nodes); the two rows of an interleaved-RoPE pair (2p, 2p+1) sit in adjacent
+// waves of one block and meet through 8 bytes of LDS.  Position, page and cos/sin are requested while the weights are in
+// flight, so the epilogue has no dependent load left.
 template <typename WT, int K, int WAVES, bool NT>
 __global__ __launch_bounds__(WAVES * 64) void k_qkv(const float* __restrict__ x, const float* __restrict__ norm_w, float eps,
                                                     const WT* __restrict__ W, const float* __restrict__ cos_t,
@@ -190,21 +191,21 @@ __global__ __launch_bounds__(WAVES * 64) void k_qkv(const float* __restrict__ x,
                                                     int H, int Hk, int Dh, const float* __restrict__ wscale) {
     using R = Row<WT, K, NT>;
     using KT = KVT<WT>;
-    const int lane = threadIdx.x & 63;
-    const int pair = blockIdx.x * WAVES + (threadIdx.x >> 6);
-    const int n_pairs = (H + 2 * Hk) * Dh / 2;
-    if (pair >= n_pairs) return;
+    static_assert(WAVES % 2 == 0, "row pairs live in one block");
+    __shared__ float dots[WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n_rows = (H + 2 * Hk) * Dh;
+    const int row = min(blockIdx.x * WAVES + wave, n_rows - 1);  // clamped (the grid covers whole pairs; n_rows is even)
     // small L2-resident vectors FIRST (vmcnt retires in order: a load issued after the weight stream would wait for it),
     // then the weight stream, then the position-dependent scalar chain (pos -> page / cos / sin, only needed by the
     // epilogue); the RMSNorm math and that chain overlap the weights' HBM flight
     float xr[R::NX], nr[R::NX];
     R::load_x(x, lane, xr);
     R::load_x(norm_w, lane, nr);
-    const int r0 = 2 * pair, qdim = H * Dh, kdim = Hk * Dh, half = Dh / 2;
-    typename R::vec w0[R::NCH], w1[R::NCH];
-    R::load_w(W + (size_t)r0 * K, lane, w0);
-    R::load_w(W + (size_t)(r0 + 1) * K, lane, w1);
+    typename R::vec wv[R::NCH];
+    R::load_w(W + (size_t)row * K, lane, wv);
     FS_ISSUE_FENCE();
+    const int r0 = row & ~1, qdim = H * Dh, kdim = Hk * Dh, half = Dh / 2;
     const int pos = state ? state->pos : pos_static;
     const int rpos = state ? pos + state->rope_off : rope_static;
     float c = 1.f, s = 0.f;
@@ -218,11 +219,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_qkv(const float* __restrict__ x,
         const int rk = (r0 - qdim) % kdim, g = rk / Dh, dd = rk % Dh;
         dst = kv_addr<KT>(r0 < qdim + kdim ? kv.k : kv.v, kv.page_table, pos, g, Hk, Dh) + dd;
     }
-    const float s0 = row_scale<WT>(wscale, r0), s1 = row_scale<WT>(wscale, r0 + 1);
+    const float sc = row_scale<WT>(wscale, row);
     R::rmsnorm(xr, nr, eps);
-    const float a = wave_sum(R::dot(w0, xr)) * s0;
-    const float b = wave_sum(R::dot(w1, xr)) * s1;
-    if (lane != 0) return;
+    const float d = wave_sum(R::dot(wv, xr)) * sc;
+    if (lane == 0) dots[wave] = d;
+    __syncthreads();
+    if (lane != 0 || (wave & 1) || blockIdx.x * WAVES + wave >= n_rows) return;
+    const float a = dots[wave], b = dots[wave + 1];
     if (r0 < qdim + kdim) {  // rope_i on the pair (2j, 2j+1) of its head (dual_ar.rs:246-247)
         const float o0 = a * c - b * s, o1 = a * s + b * c;
         if (r0 < qdim) { q_out[r0] = o0; q_out[r0 + 1] = o1; }
@@ -1848,9 +1851,9 @@ static void dispatch_k(int K, F&& f) {
 template <typename WT>
 void LmKernels<WT>::qkv(const ModelDims& d, const float* x, const LayerW& w, const float* cos_t, const float* sin_t,
                         const SeqState* state, int pos_static, int rope_static, float* q_out, KVView kv, hipStream_t st) {
-    constexpr int WAVES = 2;  // one RoPE row pair per wave
-    const int n_pairs = (d.H + 2 * d.Hk) * d.Dh / 2;
-    const int grid = (n_pairs + WAVES - 1) / WAVES;
+    constexpr int WAVES = 4;  // one row per wave, two RoPE pairs per block
+    const int n_rows = (d.H + 2 * d.Hk) * d.Dh;
+    const int grid = (n_rows + WAVES - 1) / WAVES;
     dispatch_k(d.dim, [&](auto Kc) {
         constexpr int K = decltype(Kc)::value;
         if (w.cache_resident)

@@ -116,6 +116,33 @@ def test_codec_checkpoint_equals_synthetic(tmp_path):
                     q = f"head.resblocks.{s}.blocks.{j}.{cv}.{m}"
                     put(q + ".conv.weight", (cout, cout, k), 0.0, 1 / math.sqrt(cout * k)); put(q + ".conv.bias", (cout,), 0.0, 0.02)
     put("head.conv_post.conv.weight", (1, C >> 5, 13), 0.0, 1 / math.sqrt((C >> 5) * 13)); put("head.conv_post.conv.bias", (1,), 0.0, 0.02)
+
+    # encoder side (convnext.rs:186-271, quantizer.rs:44-66, grouped_residual_fsq.rs:52-56); channel_div 8 -> dims / 8, depths 1,1,2,1
+    def block(q, Cb):
+        put(q + ".dwconv.conv.weight", (Cb, 1, 7), 0.0, 1 / math.sqrt(7)); put(q + ".dwconv.conv.bias", (Cb,), 0.0, 0.02)
+        put(q + ".norm.weight", (Cb,), 1.0, 0.1); put(q + ".norm.bias", (Cb,), 0.0, 0.02)
+        put(q + ".pwconv1.weight", (4 * Cb, Cb), 0.0, 1 / math.sqrt(Cb)); put(q + ".pwconv1.bias", (4 * Cb,), 0.0, 0.02)
+        put(q + ".pwconv2.weight", (Cb, 4 * Cb), 0.0, 1 / math.sqrt(4 * Cb)); put(q + ".pwconv2.bias", (Cb,), 0.0, 0.02)
+        put(q + ".gamma", (Cb,), 0.1, 0.02)
+
+    dims, depths = [16, 32, 48, 64], [1, 1, 2, 1]
+    put("backbone.downsample_layers.0.0.conv.weight", (dims[0], 160, 7), 0.0, 1 / math.sqrt(160 * 7)); put("backbone.downsample_layers.0.0.conv.bias", (dims[0],), 0.0, 0.02)
+    put("backbone.downsample_layers.0.1.weight", (dims[0],), 1.0, 0.1); put("backbone.downsample_layers.0.1.bias", (dims[0],), 0.0, 0.02)
+    for i in range(4):
+        if i > 0:
+            q = f"backbone.downsample_layers.{i}"
+            put(q + ".0.weight", (dims[i - 1],), 1.0, 0.1); put(q + ".0.bias", (dims[i - 1],), 0.0, 0.02)
+            put(q + ".1.weight", (dims[i], dims[i - 1], 1), 0.0, 1 / math.sqrt(dims[i - 1])); put(q + ".1.bias", (dims[i],), 0.0, 0.02)
+        for j in range(depths[i]):
+            block(f"backbone.stages.{i}.{j}", dims[i])
+    put("backbone.norm.weight", (dims[3],), 1.0, 0.1); put("backbone.norm.bias", (dims[3],), 0.0, 0.02)
+    for i in range(2):
+        q = f"quantizer.downsample.{i}"
+        put(q + ".0.conv.weight", (C, C, 2), 0.0, 1 / math.sqrt(C * 2)); put(q + ".0.conv.bias", (C,), 0.0, 0.02)
+        block(q + ".1", C)
+    for g in range(8):
+        put(f"quantizer.residual_fsq.rvqs.{g}.project_in.weight", (4, C // 8), 0.0, 1 / math.sqrt(C // 8))
+        put(f"quantizer.residual_fsq.rvqs.{g}.project_in.bias", (4,), 0.0, 0.02)
     path = str(tmp_path / "firefly.safetensors")
     _save(t, path, False)
     a = fishrt.FireflyCodec(0, channel_div=8).load_safetensors(path)
@@ -124,3 +151,5 @@ def test_codec_checkpoint_equals_synthetic(tmp_path):
     assert np.array_equal(a.decode(codes), b.decode(codes))
     o = orc.OracleCodec(tiny=True).load_synthetic(seed)
     assert float(np.sqrt(np.mean((a.decode(codes)[0, 0] - o.decode(codes[0])) ** 2))) < 1e-6
+    clip = (0.2 * np.sin(np.arange(20000) * 0.05) + 0.02 * np.random.RandomState(1).randn(20000)).astype(np.float32)[None, None]
+    assert np.array_equal(a.encode(clip), b.encode(clip))

@@ -141,7 +141,7 @@ def main():
                      "frac": round(achieved / HBM_PEAK, 4),
                      # HBM bytes per frame from the PMC passes of profiles/r01_pmc_hbm_traffic.csv (FETCH_SIZE x2 gfx950 correction
                      # + WRITE_SIZE, summed over the frame's 266 launches); collected offline, not in this run
-                     "traffic": 1.66e9, "traffic_source": "profiles/r01_pmc_hbm_traffic.csv (offline rocprofv3 --pmc passes)",
+                     "traffic": 1.75e9, "traffic_source": "profiles/r01_pmc_hbm_traffic.csv (offline rocprofv3 --pmc passes)",
                      "algorithmic_bytes_per_frame": int(bf), "frame_us": round(t_frame * 1e6, 2), "kv_len_avg": T_avg},
     }
     if rank == 0 and world == 1 and not args.no_extras:

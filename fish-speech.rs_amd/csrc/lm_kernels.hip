@@ -243,11 +243,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_qkv(const float* __restrict__ x,
 // row) each own one (query head, token subset): scores by DPP group-sums, a two-pass softmax in registers (no rescale
 // chain), P.V accumulated on the group's own dims -- no cross-group reduction of the output.  The block merges its
 // waves in LDS and writes one un-normalised partial {o[Dh], m, l} per (head, chunk); k_wo combines the chunks.
-template <typename WT> struct AttnGeom { static constexpr int TW = 16, NW = 8; };   // bf16: 8 waves x 16 tokens = 128-token chunks
-template <> struct AttnGeom<float> { static constexpr int TW = 16, NW = 4; };     // f32 : 4 waves x 16 tokens =  64-token chunks
+// chunk = NW waves x TW tokens (16 waves x 8 tokens was measured too: 4.49 vs 4.36 us, the wider block merge eats the shorter loop)
+template <typename WT, int DH> struct AttnGeom { static constexpr int TW = 16, NW = 8; };                          // bf16: 8 waves x 16 tokens = 128-token chunks
+template <int DH> struct AttnGeom<float, DH> { static constexpr int TW = 16, NW = 4; };                           // f32 :  64-token chunks
 
 template <typename WT, int DH, int NREP>
-__global__ __launch_bounds__(AttnGeom<WT>::NW * 64) void k_attn_decode(const float* __restrict__ q_all, KVView kv,
+__global__ __launch_bounds__((AttnGeom<WT, DH>::NW * 64)) void k_attn_decode(const float* __restrict__ q_all, KVView kv,
                                                      const SeqState* __restrict__ state, float* __restrict__ part_all,
                                                      int Hk, int n_chunks_max, int nc_launch, int pos_step, int pt_stride) {
     // blockIdx.y = activation row m (0 for the batch-1 decode step): prefill -> token pos + m of one sequence (pos_step 1,
@@ -261,8 +262,8 @@ __global__ __launch_bounds__(AttnGeom<WT>::NW * 64) void k_attn_decode(const flo
     constexpr int NRP = NREP < G ? NREP : G; // heads served per pass
     constexpr int NTS = G / NRP;             // token subsets per head
     constexpr int NHP = NREP / NRP;          // head passes
-    constexpr int TW = AttnGeom<WT>::TW;     // tokens per wave
-    constexpr int NW = AttnGeom<WT>::NW;     // waves per block
+    constexpr int TW = AttnGeom<WT, DH>::TW;     // tokens per wave
+    constexpr int NW = AttnGeom<WT, DH>::NW;     // waves per block
     constexpr int CH = NW * TW;              // tokens per block
     constexpr int TPG = TW / NTS;            // tokens per group
     constexpr int NLD = TW * LPT / 64;       // 16-B loads per lane per tile
@@ -302,6 +303,16 @@ __global__ __launch_bounds__(AttnGeom<WT>::NW * 64) void k_attn_decode(const flo
 #pragma unroll
         for (int i = 0; i < EPL; ++i) qr[hp][i] = qp[i];
     }
+    // q . (k^T * scale)  (dual_ar.rs:260).  For head_dim 64 the scale is 2^-3: scaling by a power of two commutes with every
+    // f32 rounding, so folding it into q once is bit-identical to scaling each k element (8 multiplies per token saved).
+    constexpr bool POW2 = (DH == 64 || DH == 16 || DH == 256);
+    if (POW2) {
+        const float s0 = 1.0f / sqrtf((float)DH);
+#pragma unroll
+        for (int hp = 0; hp < NHP; ++hp)
+#pragma unroll
+            for (int i = 0; i < EPL; ++i) qr[hp][i] *= s0;
+    }
     FS_ISSUE_FENCE();
     const int T = state->pos + 1 + (int)blockIdx.y * pos_step;  // the row's own K/V were appended by the qkv stage
     if (c * CH >= T) return;
@@ -323,7 +334,7 @@ __global__ __launch_bounds__(AttnGeom<WT>::NW * 64) void k_attn_decode(const flo
             WTr<WT>::unpack(*reinterpret_cast<const vec*>(&sk[wave][(size_t)tl * DH + sub * EPL]), kf);
             float a = 0.f;
 #pragma unroll
-            for (int i = 0; i < EPL; ++i) a = fmaf(qr[hp][i], kf[i] * scale, a);  // q . (k^T * scale)  (dual_ar.rs:260)
+            for (int i = 0; i < EPL; ++i) a = POW2 ? fmaf(qr[hp][i], kf[i], a) : fmaf(qr[hp][i], kf[i] * scale, a);
             a = group_sum<LPT>(a);
             sc[j] = (t_base + tl < T) ? a : -1e30f;
             m = fmaxf(m, sc[j]);
@@ -1867,7 +1878,7 @@ void LmKernels<WT>::qkv(const ModelDims& d, const float* x, const LayerW& w, con
 }
 
 template <typename WT>
-int LmKernels<WT>::attn_chunk() { return AttnGeom<KVT<WT>>::NW * AttnGeom<KVT<WT>>::TW; }
+int LmKernels<WT>::attn_chunk() { return AttnGeom<KVT<WT>, 64>::NW * AttnGeom<KVT<WT>, 64>::TW; }  // same for every head_dim
 
 template <typename WT>
 void LmKernels<WT>::attn_decode(const ModelDims& d, const float* q, KVView kv, const SeqState* state, float* part,
@@ -1876,11 +1887,11 @@ void LmKernels<WT>::attn_decode(const ModelDims& d, const float* q, KVView kv, c
     const int grid = d.Hk * nc_launch;
     FS_REQUIRE(n_chunks_max <= 128, "attention supports at most 128 chunks per sequence");
     if (d.Dh == 64 && d.n_rep == 8)
-        hipLaunchKernelGGL((k_attn_decode<KVT<WT>, 64, 8>), dim3(grid), dim3(AttnGeom<KVT<WT>>::NW * 64), 0, st, q, kv, state, part, d.Hk, n_chunks_max, nc_launch, 0, 0);
+        hipLaunchKernelGGL((k_attn_decode<KVT<WT>, 64, 8>), dim3(grid), dim3(AttnGeom<KVT<WT>, 64>::NW * 64), 0, st, q, kv, state, part, d.Hk, n_chunks_max, nc_launch, 0, 0);
     else if (d.Dh == 32 && d.n_rep == 2)
-        hipLaunchKernelGGL((k_attn_decode<KVT<WT>, 32, 2>), dim3(grid), dim3(AttnGeom<KVT<WT>>::NW * 64), 0, st, q, kv, state, part, d.Hk, n_chunks_max, nc_launch, 0, 0);
+        hipLaunchKernelGGL((k_attn_decode<KVT<WT>, 32, 2>), dim3(grid), dim3(AttnGeom<KVT<WT>, 32>::NW * 64), 0, st, q, kv, state, part, d.Hk, n_chunks_max, nc_launch, 0, 0);
     else if (d.Dh == 64 && d.n_rep == 2)
-        hipLaunchKernelGGL((k_attn_decode<KVT<WT>, 64, 2>), dim3(grid), dim3(AttnGeom<KVT<WT>>::NW * 64), 0, st, q, kv, state, part, d.Hk, n_chunks_max, nc_launch, 0, 0);
+        hipLaunchKernelGGL((k_attn_decode<KVT<WT>, 64, 2>), dim3(grid), dim3(AttnGeom<KVT<WT>, 64>::NW * 64), 0, st, q, kv, state, part, d.Hk, n_chunks_max, nc_launch, 0, 0);
     else
         throw Error("unsupported attention geometry (head_dim, n_rep) = (" + std::to_string(d.Dh) + ", " +
                     std::to_string(d.n_rep) + ")");
@@ -2135,14 +2146,13 @@ void LmKernels<WT>::rows_layer(const ModelDims& d, int M, const RowsCtx& c, cons
                 hipLaunchKernelGGL((k_attn_small_rows<32>), dim3(M), dim3(256), 0, st, c.Q, kv, c.state, d.H, d.Hk, c.pos_step, c.pt_stride, c.A);
         } else {
         const dim3 ga(d.Hk * c.nc_launch, M);
-            const dim3 ta(AttnGeom<WT>::NW * 64);
             if (!(c.stage_mask & 4u)) {}
             else if (d.Dh == 64 && d.n_rep == 8)
-                hipLaunchKernelGGL((k_attn_decode<WT, 64, 8>), ga, ta, 0, st, c.Q, kv, c.state, c.part, d.Hk, c.n_chunks_max, c.nc_launch, c.pos_step, c.pt_stride);
+                hipLaunchKernelGGL((k_attn_decode<WT, 64, 8>), ga, dim3(AttnGeom<WT, 64>::NW * 64), 0, st, c.Q, kv, c.state, c.part, d.Hk, c.n_chunks_max, c.nc_launch, c.pos_step, c.pt_stride);
             else if (d.Dh == 32 && d.n_rep == 2)
-                hipLaunchKernelGGL((k_attn_decode<WT, 32, 2>), ga, ta, 0, st, c.Q, kv, c.state, c.part, d.Hk, c.n_chunks_max, c.nc_launch, c.pos_step, c.pt_stride);
+                hipLaunchKernelGGL((k_attn_decode<WT, 32, 2>), ga, dim3(AttnGeom<WT, 32>::NW * 64), 0, st, c.Q, kv, c.state, c.part, d.Hk, c.n_chunks_max, c.nc_launch, c.pos_step, c.pt_stride);
             else if (d.Dh == 64 && d.n_rep == 2)
-                hipLaunchKernelGGL((k_attn_decode<WT, 64, 2>), ga, ta, 0, st, c.Q, kv, c.state, c.part, d.Hk, c.n_chunks_max, c.nc_launch, c.pos_step, c.pt_stride);
+                hipLaunchKernelGGL((k_attn_decode<WT, 64, 2>), ga, dim3(AttnGeom<WT, 64>::NW * 64), 0, st, c.Q, kv, c.state, c.part, d.Hk, c.n_chunks_max, c.nc_launch, c.pos_step, c.pt_stride);
             else
                 throw Error("unsupported attention geometry");
             if (!(c.stage_mask & 8u)) {}

@@ -36,7 +36,7 @@ struct Tensor {  // one checkpoint tensor
     size_t off;  // float offset in the raw arena
     size_t numel() const { size_t n = 1; for (auto s : shape) n *= (size_t)s; return n; }
 };
-struct ConvSpec { int raw, relaid, bias, cout, cin_g, k; bool transposed; };
+struct ConvSpec { int raw, relaid, bias, cout, cin_g, k; bool transposed; int stride; };
 }  // namespace
 
 class Codec final : public CodecBase {
@@ -242,8 +242,9 @@ class Codec final : public CodecBase {
     }
     // Conv1d `name.conv.weight [cout, cin_g, k]` / ConvTranspose1d `[cin, cout, k]` + `name.conv.bias [cout]`
     // (1.4+ names: codec/utils/mod.rs:28-40,84-96).  Synthetic init: N(0, 1/fan_in), bias N(0, 0.02^2).
-    int add_conv(const std::string& name, int cout, int cin_g, int k, bool transposed, double fan_in) {
+    int add_conv(const std::string& name, int cout, int cin_g, int k, bool transposed, double fan_in, int stride = 1) {
         ConvSpec s;
+        s.stride = stride;
         s.raw = transposed ? add_tensor(name + ".conv.weight", {cin_g, cout, k}, 0.f, 1.0 / std::sqrt(fan_in))
                            : add_tensor(name + ".conv.weight", {cout, cin_g, k}, 0.f, 1.0 / std::sqrt(fan_in));
         s.bias = add_tensor(name + ".conv.bias", {cout}, 0.f, 0.02);
@@ -255,6 +256,7 @@ class Codec final : public CodecBase {
     }
     int add_linear_as_conv(const std::string& name, int cout, int cin, double fan_in) {  // pwconv{1,2}.{weight,bias}
         ConvSpec s;
+        s.stride = 1;
         s.raw = add_tensor(name + ".weight", {cout, cin}, 0.f, 1.0 / std::sqrt(fan_in));
         s.bias = add_tensor(name + ".bias", {cout}, 0.f, 0.02);
         s.cout = cout; s.cin_g = cin; s.k = 1; s.transposed = false;
@@ -277,7 +279,7 @@ class Codec final : public CodecBase {
         repack_groups(proj_b_, G, (size_t)dg);
         for (int i = 0; i < 2; ++i) {
             const std::string p = "quantizer.upsample." + std::to_string(i);
-            up_conv_[i] = add_conv(p + ".0", C_, C_, 2, true, (double)C_);
+            up_conv_[i] = add_conv(p + ".0", C_, C_, 2, true, (double)C_, 2);
             CnxSpec c;
             const std::string q = p + ".1";
             c.dw = add_tensor(q + ".dwconv.conv.weight", {C_, 1, 7}, 0.f, 1.0 / std::sqrt(7.0));
@@ -293,7 +295,7 @@ class Codec final : public CodecBase {
         const int rates[5] = {8, 8, 2, 2, 2}, ks[5] = {16, 16, 4, 4, 4}, rk[3] = {3, 7, 11};
         for (int s = 0; s < 5; ++s) {
             const int cin = C_ >> s, cout = C_ >> (s + 1);
-            ups_[s] = add_conv("head.ups." + std::to_string(s), cout, cin, ks[s], true, (double)cin * ks[s] / rates[s]);
+            ups_[s] = add_conv("head.ups." + std::to_string(s), cout, cin, ks[s], true, (double)cin * ks[s] / rates[s], rates[s]);
             for (int j = 0; j < 3; ++j)
                 for (int m = 0; m < 3; ++m) {
                     const std::string q = "head.resblocks." + std::to_string(s) + ".blocks." + std::to_string(j);
@@ -360,7 +362,8 @@ class Codec final : public CodecBase {
     void relayout() {
         for (size_t i = 0; i < convs_.size(); ++i) {
             const ConvSpec& s = convs_[i];
-            codec_relayout(R(s.raw), relaid_.f() + relaid_off_[i], s.cout, s.cin_g, s.k, s.transposed, st_);
+            if (s.transposed) codec_relayout_tconv(R(s.raw), relaid_.f() + relaid_off_[i], s.cout, s.cin_g, s.k, s.stride, st_);
+            else codec_relayout(R(s.raw), relaid_.f() + relaid_off_[i], s.cout, s.cin_g, s.k, false, st_);
         }
         FS_HIP(hipStreamSynchronize(st_));
     }

@@ -19,12 +19,14 @@ void codec_fsq_project(const uint32_t* codes, int B, int G, int T, const float* 
 // causal conv1d, stride 1: y = epi(bias + W * pre(x)); x (B, Cin, T) -> y (B, Cout, T)
 void codec_conv1d(const float* x, int B, int Cin, int T, const ConvW& w, int dil, bool pre_silu, int epi, const float* res,
                   const float* gamma, float* y, hipStream_t st);
-// transposed conv1d with right trim: x (B, Cin, Tin) -> y (B, Cout, Tin * stride)
+// transposed conv1d with right trim: x (B, Cin, Tin) -> y (B, Cout, Tin * stride); w = polyphase layout (codec_relayout_tconv)
 void codec_tconv1d(const float* x, int B, int Cin, int Tin, const ConvW& w, int stride, bool pre_silu, float* y, hipStream_t st);
 void codec_dwconv_ln(const float* x, int B, int C, int T, const float* dw, const float* db, const float* lnw, const float* lnb, float* y,
                      hipStream_t st);
 void codec_mean3(const float* a, const float* b, const float* c, float* y, size_t n, hipStream_t st);
 void codec_relayout(const float* src, float* dst, int Cout, int CinG, int K, bool transposed, hipStream_t st);
+// ConvTranspose1d [Cin][Cout][K] -> polyphase causal-conv layout [Cin][K/stride][Cout*stride] (see codec_tconv1d)
+void codec_relayout_tconv(const float* src, float* dst, int Cout, int Cin, int K, int stride, hipStream_t st);
 // ---- encoder side (FireflyCodec::encode)
 void codec_stft_mag(const float* pcm, int n, int n_fft, int hop, int n_frames, float* lin /*[n_fft/2+1][frames]*/, hipStream_t st);
 void codec_mel_log(const float* lin, const float* fb /*[nf][n_mels]*/, int nf, int n_mels, int F, float* mel /*[n_mels][F]*/, hipStream_t st);

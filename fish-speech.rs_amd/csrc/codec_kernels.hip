@@ -60,7 +60,7 @@ enum { CEPI_NONE = 0, CEPI_GELU = 1, CEPI_GAMMA_RES = 2, CEPI_RES = 3, CEPI_TANH
 template <int CPT, int TPT, int ICH>
 __global__ __launch_bounds__(256) void k_conv1d(const float* __restrict__ x, int Cin, int T, const float* __restrict__ wt /*[Cin][K][Cout]*/,
                                                 const float* __restrict__ bias, int Cout, int K, int dil, int pre_silu, int epi,
-                                                const float* __restrict__ res, const float* __restrict__ gamma, float* __restrict__ y) {
+                                                const float* __restrict__ res, const float* __restrict__ gamma, float* __restrict__ y, int ps) {
     constexpr int OT = 8 * CPT, TT = 32 * TPT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int halo = (K - 1) * dil;
@@ -109,13 +109,14 @@ __global__ __launch_bounds__(256) void k_conv1d(const float* __restrict__ x, int
     for (int c = 0; c < CPT; ++c) {
         const int o = o0 + ty * CPT + c;
         if (o >= Cout) continue;
-        const float b = bias[o];
+        const float b = bias[o / ps];
 #pragma unroll
         for (int j = 0; j < TPT; ++j) {
             const int t = t0 + tx + 32 * j;
             if (t >= T) continue;
             float v = acc[c][j] + b;
-            const size_t oi = boff_out + (size_t)o * T + t;
+            // ps > 1: polyphase transposed conv -- GEMM row o = channel * ps + phase writes y[channel][t * ps + phase]
+            const size_t oi = boff_out + (size_t)(o / ps) * T * ps + (size_t)t * ps + o % ps;
             if (epi == CEPI_GELU) v = dgelu(v);
             else if (epi == CEPI_GAMMA_RES) v = res[oi] + gamma[o] * v;
             else if (epi == CEPI_RES) v = res[oi] + v;
@@ -125,39 +126,108 @@ __global__ __launch_bounds__(256) void k_conv1d(const float* __restrict__ x, int
     }
 }
 
-// ------------------------------------------------------------------------------------------------ transposed conv1d
-// candle conv_transpose1d (weight [Cin][Cout][K], stride s) + right trim of K - s (utils/mod.rs:110-122):
-//   y[o][u] = b[o] + sum_i sum_{k : (u - k) % s == 0, 0 <= (u-k)/s < Tin} pre(x[i][(u-k)/s]) * W[i][o][k],  u < Tin * s
-// One thread per (8 output channels, 1 output time); weights re-laid [Cin][K][Cout].
-template <int CPT>
-__global__ __launch_bounds__(256) void k_tconv1d(const float* __restrict__ x, int Cin, int Tin, const float* __restrict__ wt,
-                                                 const float* __restrict__ bias, int Cout, int K, int stride, int pre_silu,
-                                                 float* __restrict__ y) {
-    const int Tout = Tin * stride;
-    const int u = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int o0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * CPT;
-    if (u >= Tout || o0 >= Cout) return;
-    const size_t boff_in = (size_t)blockIdx.z * Cin * Tin, boff_out = (size_t)blockIdx.z * Cout * Tout;
-    float acc[CPT];
+// ------------------------------------------------------------------------------------------------ causal conv1d on the matrix cores
+// Same contract as k_conv1d, for the wide layers (Cout >= 64): the convolution is the GEMM Y[o][t] = sum_{(i,k)} W[o][(i,k)] *
+// X[(i,k)][t] with X[(i,k)][t] = pre(x[i][t + k*dil - halo]), evaluated with v_mfma_f32_32x32x2_f32 -- f32 in, f32 accumulate, so
+// every product is the exact f32 product of the VALU kernel (only the summation order differs).  Block = 4 waves = 64 output
+// channels x 128 time steps; wave w owns channels (w&1)*32.. and two 32-step time tiles (w>>1)*64 + {0, 32} (32 accumulator
+// registers).  Input channels are staged 16 at a time into LDS exactly like k_conv1d (x window [16][128 + halo], weights
+// [16*K][64]); one MFMA consumes TWO reduction items: lanes 0..31 feed channel 2p, lanes 32..63 channel 2p+1 of the same tap.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int ICH>
+__global__ __launch_bounds__(256) void k_conv1d_mfma(const float* __restrict__ x, int Cin, int T, const float* __restrict__ wt /*[Cin][K][Cout]*/,
+                                                     const float* __restrict__ bias, int Cout, int K, int dil, int pre_silu, int epi,
+                                                     const float* __restrict__ res, const float* __restrict__ gamma, float* __restrict__ y, int ps) {
+    constexpr int OT = 64, TT = 128;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int halo = (K - 1) * dil;
+    const int XS = TT + halo;
+    float* xs = smem;                       // [ICH][XS]
+    float* ws = smem + ((ICH * XS + 3) & ~3);  // [ICH*K][OT], 16-byte aligned
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, c = lane & 31;
+    const int ob = (wave & 1) * 32, tb = (wave >> 1) * 64;
+    const int t0 = blockIdx.x * TT, o0 = blockIdx.y * OT;
+    const size_t boff_in = (size_t)blockIdx.z * Cin * T, boff_out = (size_t)blockIdx.z * Cout * T;
+    f32x16 acc0, acc1;
 #pragma unroll
-    for (int c = 0; c < CPT; ++c) acc[c] = 0.f;
-    const int ph = u % stride;
-    for (int i = 0; i < Cin; ++i) {
-        const float* xi = x + boff_in + (size_t)i * Tin;
-        for (int k = ph; k < K; k += stride) {
-            const int t = (u - k) / stride;
-            if (u - k < 0 || t >= Tin) continue;
-            float xv = xi[t];
-            if (pre_silu) xv = dsilu(xv);
-            const float* wp = wt + ((size_t)i * K + k) * Cout + o0;
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    static_assert(ICH % 2 == 0, "channel pairs");
+    for (int i0 = 0; i0 < Cin; i0 += ICH) {
+        const int nic = min(ICH, Cin - i0);
+        // staging without integer division (it dominated the first version of this kernel: 2 runtime div/mod per element):
+        // x window: one row per input channel, lanes along time; weights: the tile's rows (i, k) are CONSECUTIVE rows of the
+        // re-laid [Cin][K][Cout] tensor ((i0 + i) * K + k == i0 * K + row), read as float4
+        // (all loads of a stage are issued before the first LDS store: 16 x-window rows + up to 13 weight float4 per thread)
+        {
+            const int tl = threadIdx.x, t = t0 + tl - halo;  // XS <= 256 (checked by the launcher): one window element per thread per row
+            float xv[ICH];
 #pragma unroll
-            for (int c = 0; c < CPT; ++c)
-                if (o0 + c < Cout) acc[c] = fmaf(xv, wp[c], acc[c]);
+            for (int i = 0; i < ICH; ++i)
+                xv[i] = (tl < XS && i < nic && t >= 0 && t < T) ? x[boff_in + (size_t)(i0 + i) * T + t] : 0.f;
+            const int rows = ICH * K, rows_valid = nic * K;
+            if (o0 + OT <= Cout && (Cout & 3) == 0) {
+                constexpr int NW4 = 13;  // ceil(16 * K * 16 / 256) for K <= 13
+                float4 wv[NW4];
+#pragma unroll
+                for (int j = 0; j < NW4; ++j) {
+                    const int e = j * 256 + (int)threadIdx.x, rr = e >> 4, q = e & 15;
+                    wv[j] = (rr < rows_valid) ? *reinterpret_cast<const float4*>(wt + ((size_t)i0 * K + rr) * Cout + o0 + q * 4)
+                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int j = 0; j < NW4; ++j) {
+                    const int e = j * 256 + (int)threadIdx.x, rr = e >> 4, q = e & 15;
+                    if (rr < rows) *reinterpret_cast<float4*>(ws + rr * OT + q * 4) = wv[j];
+                }
+            } else {
+                for (int e = threadIdx.x; e < rows * OT; e += 256) {
+                    const int rr = e >> 6, o = e & 63;
+                    ws[e] = (rr < rows_valid && o0 + o < Cout) ? wt[((size_t)i0 * K + rr) * Cout + o0 + o] : 0.f;
+                }
+            }
+            if (tl < XS) {
+#pragma unroll
+                for (int i = 0; i < ICH; ++i) xs[i * XS + tl] = pre_silu ? dsilu(xv[i]) : xv[i];
+            }
+        }
+        __syncthreads();
+        // reduction items in (k outer, channel-pair inner) order: lanes 0..31 take channel 2p, lanes 32..63 channel 2p+1 --
+        // every address below is a running sum, the 8 pairs of one tap are issued back to back
+        const float* wl = ws + h * K * OT + ob + c;
+        const float* xl = xs + h * XS + tb + c;
+        for (int k = 0; k < K; ++k) {
+            const float* wk = wl + k * OT;
+            const float* xk = xl + k * dil;
+#pragma unroll
+            for (int p = 0; p < ICH / 2; ++p) {
+                const float a = wk[p * 2 * K * OT];
+                const float b0 = xk[p * 2 * XS], b1 = xk[p * 2 * XS + 32];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // D[row][col]: register r of lane (h, c) holds row (r/4)*8 + h*4 + r%4, column c
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int o = o0 + ob + (r >> 2) * 8 + h * 4 + (r & 3);
+        if (o >= Cout) continue;
+        const float b = bias[o / ps];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int t = t0 + tb + j * 32 + c;
+            if (t >= T) continue;
+            float v = (j ? acc1[r] : acc0[r]) + b;
+            const size_t oi = boff_out + (size_t)(o / ps) * T * ps + (size_t)t * ps + o % ps;  // (see k_conv1d)
+            if (epi == CEPI_GELU) v = dgelu(v);
+            else if (epi == CEPI_GAMMA_RES) v = res[oi] + gamma[o] * v;
+            else if (epi == CEPI_RES) v = res[oi] + v;
+            else if (epi == CEPI_TANH) v = tanhf(v);
+            y[oi] = v;
         }
     }
-#pragma unroll
-    for (int c = 0; c < CPT; ++c)
-        if (o0 + c < Cout) y[boff_out + (size_t)(o0 + c) * Tout + u] = acc[c] + bias[o0 + c];
 }
 
 // ------------------------------------------------------------------------------------------------ ConvNeXt: dwconv k7 + LayerNorm
@@ -216,6 +286,20 @@ __global__ void k_relayout_conv(const float* __restrict__ src, float* __restrict
     }
 }
 
+// ConvTranspose1d weight [Cin][Cout][K], K = s * Kc -> polyphase causal-conv layout [Cin][Kc][Cout * s]:
+//   dst[(i * Kc + kc) * (Cout * s) + o * s + ph] = src[(i * Cout + o) * K + ph + (Kc - 1 - kc) * s]
+// (tap kc of the causal conv multiplies x[t + kc - (Kc - 1)], i.e. x[t - j] with j = Kc - 1 - kc)
+__global__ void k_relayout_tconv(const float* __restrict__ src, float* __restrict__ dst, int Cout, int Cin, int K, int s) {
+    const int Kc = K / s;
+    const size_t n = (size_t)Cout * Cin * K;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const int col = (int)(e % ((size_t)Cout * s)), o = col / s, ph = col % s;
+        const int kc = (int)((e / ((size_t)Cout * s)) % Kc);
+        const int i = (int)(e / ((size_t)Cout * s * Kc));
+        dst[e] = src[((size_t)i * Cout + o) * K + ph + (Kc - 1 - kc) * s];
+    }
+}
+
 __global__ void k_synth_f32(float* __restrict__ dst, uint64_t key, size_t n, float mean, float scale) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         dst[i] = synth_elem(key, (uint64_t)i, mean, scale);
@@ -229,8 +313,8 @@ void codec_fsq_project(const uint32_t* codes, int B, int G, int T, const float* 
     FS_LAUNCH_CHECK();
 }
 
-void codec_conv1d(const float* x, int B, int Cin, int T, const ConvW& w, int dil, bool pre_silu, int epi, const float* res,
-                  const float* gamma, float* y, hipStream_t st) {
+static void conv1d_launch(const float* x, int B, int Cin, int T, const ConvW& w, int dil, bool pre_silu, int epi, const float* res,
+                          const float* gamma, float* y, int ps, hipStream_t st) {
     const int K = w.k, Cout = w.cout;
     const int halo = (K - 1) * dil;
     auto launch = [&](auto cpt, auto tpt, auto ich) {
@@ -239,23 +323,37 @@ void codec_conv1d(const float* x, int B, int Cin, int T, const ConvW& w, int dil
         const size_t smem = sizeof(float) * ((size_t)ICH * (TT + halo) + (size_t)ICH * K * OT);
         FS_REQUIRE(smem <= 64 * 1024, "conv tile does not fit LDS");
         hipLaunchKernelGGL((k_conv1d<CPT, TPT, ICH>), dim3((T + TT - 1) / TT, (Cout + OT - 1) / OT, B), dim3(256), smem, st, x, Cin, T,
-                           w.wt, w.b, Cout, K, dil, pre_silu ? 1 : 0, epi, res, gamma, y);
+                           w.wt, w.b, Cout, K, dil, pre_silu ? 1 : 0, epi, res, gamma, y, ps);
     };
     using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I4 = std::integral_constant<int, 4>;
     using I8 = std::integral_constant<int, 8>; using I16 = std::integral_constant<int, 16>;
-    if (Cout >= 64) launch(I8(), I4(), I8());          // 64 ch x 128 t
+    if (Cout >= 64 && Cin >= 16) {                     // matrix cores: 64 ch x 128 t per block
+        constexpr int ICH = 16;
+        const size_t smem = sizeof(float) * ((((size_t)ICH * (128 + halo) + 3) & ~(size_t)3) + (size_t)ICH * K * 64);
+        FS_REQUIRE(smem <= 64 * 1024 && 128 + halo <= 256 && K <= 13, "conv tile does not fit the MFMA kernel (LDS / window / taps)");
+        hipLaunchKernelGGL((k_conv1d_mfma<ICH>), dim3((T + 127) / 128, (Cout + 63) / 64, B), dim3(256), smem, st, x, Cin, T, w.wt, w.b, Cout, K,
+                           dil, pre_silu ? 1 : 0, epi, res, gamma, y, ps);
+    } else if (Cout >= 64) launch(I8(), I4(), I8());   // 64 ch x 128 t
     else if (Cout >= 32) launch(I4(), I4(), I8());     // 32 ch x 128 t
     else if (Cout >= 16) launch(I2(), I8(), I16());    // 16 ch x 256 t
     else launch(I1(), I8(), I16());                    // <= 8 ch x 256 t (conv_post: 1 channel)
     FS_LAUNCH_CHECK();
 }
 
+void codec_conv1d(const float* x, int B, int Cin, int T, const ConvW& w, int dil, bool pre_silu, int epi, const float* res,
+                  const float* gamma, float* y, hipStream_t st) {
+    conv1d_launch(x, B, Cin, T, w, dil, pre_silu, epi, res, gamma, y, 1, st);
+}
+
+// Transposed conv (stride s, K = s * Kc taps, right trim K - s: utils/mod.rs:110-122) as ONE causal conv with Kc taps and
+// Cout * s GEMM rows (row = channel * s + phase): y[o][t*s + ph] = b[o] + sum_i sum_j x[i][t - j] * W[i][o][ph + j*s].
+// `w` must hold the polyphase re-layout made by codec_relayout_tconv ([Cin][Kc][Cout * s]) with w.cout = Cout, w.k = K.
 void codec_tconv1d(const float* x, int B, int Cin, int Tin, const ConvW& w, int stride, bool pre_silu, float* y, hipStream_t st) {
-    const int Tout = Tin * stride;
-    constexpr int CPT = 8;
-    hipLaunchKernelGGL((k_tconv1d<CPT>), dim3((Tout + 63) / 64, (w.cout + 4 * CPT - 1) / (4 * CPT), B), dim3(256), 0, st, x, Cin, Tin, w.wt,
-                       w.b, w.cout, w.k, stride, pre_silu ? 1 : 0, y);
-    FS_LAUNCH_CHECK();
+    FS_REQUIRE(w.k % stride == 0, "transposed conv kernel size must be a multiple of its stride");
+    ConvW p = w;
+    p.cout = w.cout * stride;
+    p.k = w.k / stride;
+    conv1d_launch(x, B, Cin, Tin, p, 1, pre_silu, CODEC_EPI_NONE, nullptr, nullptr, y, stride, st);
 }
 
 void codec_dwconv_ln(const float* x, int B, int C, int T, const float* dw, const float* db, const float* lnw, const float* lnb, float* y,
@@ -274,6 +372,13 @@ void codec_relayout(const float* src, float* dst, int Cout, int CinG, int K, boo
     const size_t n = (size_t)Cout * CinG * K;
     hipLaunchKernelGGL(k_relayout_conv, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, st, src, dst, Cout, CinG, K,
                        transposed ? 1 : 0);
+    FS_LAUNCH_CHECK();
+}
+
+void codec_relayout_tconv(const float* src, float* dst, int Cout, int Cin, int K, int stride, hipStream_t st) {
+    FS_REQUIRE(K % stride == 0, "transposed conv kernel size must be a multiple of its stride");
+    const size_t n = (size_t)Cout * Cin * K;
+    hipLaunchKernelGGL(k_relayout_tconv, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, st, src, dst, Cout, Cin, K, stride);
     FS_LAUNCH_CHECK();
 }
 

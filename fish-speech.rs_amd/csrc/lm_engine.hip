@@ -761,6 +761,10 @@ class LM final : public LMBase {
         d_pfq_.alloc(sizeof(float) * kRowsCap * a_.dim);
         d_pfslab_.alloc(sizeof(float) * down_split_ * kRowsCap * a_.dim);
         d_pfa_.alloc(sizeof(uint16_t) * 2 * kRowsCap * a_.dim);
+        d_pfa2_.alloc(sizeof(uint16_t) * 2 * kRowsCap * a_.dim);
+        d_pfss_.alloc(sizeof(float) * kRowsCap * (a_.dim / 16));
+        FS_HIP(hipMemsetAsync(d_pfa2_.p, 0, d_pfa2_.n, st_));
+        FS_HIP(hipMemsetAsync(d_pfss_.p, 0, d_pfss_.n, st_));
         d_pfc_.alloc(sizeof(uint16_t) * 2 * kRowsCap * a_.intermediate_size);
         d_pfpart_.alloc(sizeof(float) * kRowsCap * (size_t)a_.n_head * n_chunks_ * (a_.head_dim + 2));
         FS_HIP(hipMemsetAsync(d_pfx_.p, 0, d_pfx_.n, st_));
@@ -838,6 +842,7 @@ class LM final : public LMBase {
         c.X = d_pfx_.as<float>(); c.Q = d_pfq_.as<float>(); c.part = d_pfpart_.as<float>(); c.P = d_pfslab_.as<float>();
         c.Mcap = kRowsCap; c.down_split = down_split_;
         c.A = d_pfa_.as<uint16_t>(); c.C = d_pfc_.as<uint16_t>();
+        c.A2 = d_pfa2_.as<uint16_t>(); c.ss = d_pfss_.as<float>();
         c.cos_t = d_cos_.as<float>(); c.sin_t = d_sin_.as<float>();
         c.state = st; c.n_chunks_max = n_chunks_; c.nc_launch = n_chunks_; c.pos_step = pos_step; c.pt_stride = pt_stride;
         return c;
@@ -946,7 +951,7 @@ class LM final : public LMBase {
     // activations / state
     DevBuf d_x_, d_xf_, d_q_, d_part_, d_act_, d_logits_slow_, d_logits_fast_, d_state_, d_cfg_, d_rng_, d_prompt_, d_out_;
     DevBuf d_rp_mask_, d_rp_seen_, d_rp_ring_, d_rp_meta_;
-    DevBuf d_pfx_, d_pfq_, d_pfslab_, d_pfa_, d_pfc_, d_pfpart_;  // MFMA row-path activations (32 rows)
+    DevBuf d_pfx_, d_pfq_, d_pfslab_, d_pfa_, d_pfa2_, d_pfss_, d_pfc_, d_pfpart_;  // MFMA row-path activations (kRowsCap rows)
     DevBuf d_xfrows_, d_lrows_, d_lfast_, d_fast_state_, d_fast_table_;  // static-batch generator
     int ld_slow_ = 0, down_split_ = 4;
     bool batch_warm_ = false;

@@ -80,6 +80,8 @@ struct RowsCtx {
     float* P;            // [down_split][Mcap][dim] down-projection split-K slabs
     uint16_t* A;         // [Mcap][dim]   bf16 hi+lo GEMM input (normed x / attention output), fragment-major (lm_kernels.hip frag_off)
     uint16_t* C;         // [Mcap][inter] bf16 hi+lo SwiGLU activations, fragment-major
+    uint16_t* A2 = nullptr;  // [Mcap][dim] second GEMM-input buffer: with `ss` set, the ffn RMSNorm is folded into the Wo / W13 GEMMs
+    float* ss = nullptr;     // [Mcap][dim / 16] sum-of-squares partials of the Wo GEMM's blocks
     const float *cos_t, *sin_t;
     const SeqState* state;  // position source (row m sits at state->pos + m * pos_step)
     int n_chunks_max;    // stride of `part`

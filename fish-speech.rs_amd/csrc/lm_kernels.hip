@@ -671,7 +671,18 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 constexpr int PF_M = 32;    // activation rows per pass
 
-enum { EPI_STORE = 0, EPI_RESIDUAL = 1, EPI_SWIGLU = 2, EPI_QKV = 3 };
+enum { EPI_STORE = 0, EPI_RESIDUAL = 1, EPI_SWIGLU = 2, EPI_QKV = 3, EPI_RESIDUAL_NORM = 4, EPI_SWIGLU_RMS = 5 };
+// RMSNorm folded into the GEMMs around it (saves the k_prep node between Wo and W13): the Wo GEMM's epilogue writes the new
+// residual stream, the UN-normalised GEMM input split(x * g) and one sum-of-squares partial per (block, row); the W13 GEMM's
+// epilogue divides its accumulators by rms[m] = sqrt(sum_b partial[m][b] / D + eps) (a per-row scalar commutes with the GEMM).
+struct NormAux {
+    const float* g;   // norm weight [D]                       (EPI_RESIDUAL_NORM)
+    float* ss;        // partials [Mcap][nblk], row-major       (written by RESIDUAL_NORM, read by SWIGLU_RMS)
+    bf16_t* A2;       // fragment-major output of RESIDUAL_NORM
+    int nblk;         // blocks of the producing GEMM (multiple of 8)
+    int D;
+    float eps;
+};
 
 struct RowMap {       // how activation row m maps onto sequences / positions
     int pos_step;     // prefill: 1 (row m = token at pos + m of ONE sequence); batched decode: 0 (every row at pos)
@@ -748,9 +759,10 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* __restrict__ Xf, in
                                                const bf16_t* __restrict__ W, int N, float* __restrict__ Y, int ldy, size_t slab_stride,
                                                bf16_t* __restrict__ Of, int ldo,
                                                const float* __restrict__ cos_t, const float* __restrict__ sin_t,
-                                               const SeqState* __restrict__ state, KVView kv, int H, int Hk, int Dh, RowMap rm) {
+                                               const SeqState* __restrict__ state, KVView kv, int H, int Hk, int Dh, RowMap rm, NormAux na) {
     constexpr int ROWS = 16 * RT;
     __shared__ float red[4][ROWS][33];
+    __shared__ float s_rms[PF_M];
     const int lane = threadIdx.x & 63, kq = threadIdx.x >> 6;
     const int n0 = blockIdx.x * ROWS;
     const int kbeg = ((int)blockIdx.y * 4 + kq) * NKS * 32 + (lane >> 4) * 8;  // this lane's first k of every 32-wide step (weights)
@@ -768,6 +780,11 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* __restrict__ Xf, in
     // row panels are spread over blockIdx.z (prefill: many panels -> more blocks; the weight tile is then re-read from L2)
     bool first_panel = true;
     for (int mp = (int)blockIdx.z * PF_M; mp < M; mp += (int)gridDim.z * PF_M) {
+        float ss8 = 0.f;
+        if (EPI == EPI_SWIGLU_RMS) {  // this panel's 32 row norms: thread (m = tid/8, j = tid%8) sums every 8th block's partial, then 8 lanes meet
+            const float* sp = na.ss + (size_t)(mp + (threadIdx.x >> 3)) * na.nblk + (threadIdx.x & 7);
+            for (int q8 = 0; q8 < na.nblk; q8 += 8) ss8 += sp[q8];
+        }
         // B operands of this panel (fragment-major: [k-step][hi, lo][16-row tile] blocks of one KiB each, lane-major)
         const bf16_t* xp = Xf + ((size_t)(mp >> 5) * (K >> 5) + ((int)blockIdx.y * 4 + kq) * NKS) * 2048 + lane * 8;
         u32x4 xf[NKS][4];
@@ -792,8 +809,12 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* __restrict__ Xf, in
                 for (int j = 0; j < 4; ++j)
                     acc[rt][j >> 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, xf[ks][j]), acc[rt][j >> 1], 0, 0, 0);
             }
-        if (!first_panel) __syncthreads();  // the previous panel's epilogue has read `red`
+        if (!first_panel) __syncthreads();  // the previous panel's epilogue has read `red` (and s_rms)
         first_panel = false;
+        if (EPI == EPI_SWIGLU_RMS) {
+            const float tot = group_sum<8>(ss8);
+            if ((threadIdx.x & 7) == 0) s_rms[threadIdx.x >> 3] = sqrtf(tot / (float)na.D + na.eps);
+        }
         // lane holds C[row = rt*16 + (lane>>4)*4 + i][m = mt*16 + (lane&15)]
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
@@ -821,6 +842,25 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* __restrict__ Xf, in
                 float2* yp = reinterpret_cast<float2*>(Y + (size_t)m * ldy + r);
                 const float2 o = *yp;
                 *yp = make_float2(o.x + a, o.y + b);
+            } else if (EPI == EPI_RESIDUAL_NORM) {  // RT == 1: the 8 threads of one m are 8 adjacent lanes
+                float2* yp = reinterpret_cast<float2*>(Y + (size_t)m * ldy + r);
+                const float2 o = *yp;
+                const float v0 = o.x + a, v1 = o.y + b;
+                *yp = make_float2(v0, v1);
+                bf16_t h0, l0, h1, l1;
+                split_bf16(v0 * na.g[r], h0, l0); split_bf16(v1 * na.g[r + 1], h1, l1);
+                *reinterpret_cast<uint32_t*>(na.A2 + frag_off(m, r, 0, na.D)) = h0 | ((uint32_t)h1 << 16);
+                *reinterpret_cast<uint32_t*>(na.A2 + frag_off(m, r, 1, na.D)) = l0 | ((uint32_t)l1 << 16);
+                const float ssq = group_sum<8>(fmaf(v0, v0, v1 * v1));
+                if (pr == 0) na.ss[(size_t)m * na.nblk + blockIdx.x] = ssq;
+            } else if (EPI == EPI_SWIGLU_RMS) {
+                const float dn = s_rms[ml];
+                const float an = a / dn, bn = b / dn;
+                const float v = (an / (1.f + __expf(-an))) * bn;
+                bf16_t hh, ll;
+                split_bf16(v, hh, ll);
+                Of[frag_off(m, r / 2, 0, ldo)] = hh;
+                Of[frag_off(m, r / 2, 1, ldo)] = ll;
             } else if (EPI == EPI_SWIGLU) {  // interleaved rows (2r, 2r+1) = (w1[r], w3[r]) -> act hi/lo for the down GEMM
                 const float v = (a / (1.f + __expf(-a))) * b;
                 bf16_t h, l;
@@ -2091,7 +2131,7 @@ void LmKernels<WT>::prefill_embed(const ModelDims& d, const void* tok_emb, const
 template <int EPI>
 static void launch_gemm3(int N, int ksplit, int rt, hipStream_t st, const bf16_t* Xf, int M, int K, const bf16_t* W,
                          float* Y, int ldy, size_t slab_stride, bf16_t* Of, int ldo, const float* cos_t, const float* sin_t,
-                         const SeqState* state, KVView kv, int H, int Hk, int Dh, RowMap rm) {
+                         const SeqState* state, KVView kv, int H, int Hk, int Dh, RowMap rm, NormAux na = NormAux{}) {
     FS_REQUIRE(K % (ksplit * 128) == 0, "GEMM depth must be a multiple of 128 per K range");
     const int nks = K / ksplit / 128;
     // enough blocks to fill 256 CUs a few times over: spread the row panels over blockIdx.z until ~1024 blocks
@@ -2100,7 +2140,7 @@ static void launch_gemm3(int N, int ksplit, int rt, hipStream_t st, const bf16_t
     const dim3 grid((N + 16 * rt - 1) / (16 * rt), ksplit, gz);
 #define FS_GEMM_CASE(nk, r)                                                                                                          \
     hipLaunchKernelGGL((k_gemm3<EPI, nk, r>), grid, dim3(256), 0, st, Xf, M, K, W, N, Y, ldy, slab_stride, Of, ldo, cos_t,  \
-                       sin_t, state, kv, H, Hk, Dh, rm)
+                       sin_t, state, kv, H, Hk, Dh, rm, na)
     if (rt == 2) {
         switch (nks) {
             case 8: FS_GEMM_CASE(8, 2); break;
@@ -2162,12 +2202,23 @@ void LmKernels<WT>::rows_layer(const ModelDims& d, int M, const RowsCtx& c, cons
                 hipLaunchKernelGGL((k_attn_combine<32>), dim3(M), dim3(256), 0, st, c.part, c.n_chunks_max, attn_chunk(), c.state, c.pos_step, c.A, d.H);
         }
         // (4) Wo + residual (each output element owned by one lane: deterministic)
-        if (c.stage_mask & 16u) launch_gemm3<EPI_RESIDUAL>(d.dim, 1, 1, st, c.A, M, d.dim, (const bf16_t*)w.wo, c.X, d.dim, 0, nullptr, 0,
+        const bool fuse_norm = c.A2 != nullptr && c.ss != nullptr && (d.dim / 16) % 8 == 0;
+        NormAux na{w.ffn_norm, c.ss, c.A2, d.dim / 16, d.dim, d.eps};
+        if (!(c.stage_mask & 16u)) {}
+        else if (fuse_norm)
+            launch_gemm3<EPI_RESIDUAL_NORM>(d.dim, 1, 1, st, c.A, M, d.dim, (const bf16_t*)w.wo, c.X, d.dim, 0, nullptr, 0, nullptr, nullptr,
+                                            nullptr, nokv, 0, 0, 0, none, na);
+        else launch_gemm3<EPI_RESIDUAL>(d.dim, 1, 1, st, c.A, M, d.dim, (const bf16_t*)w.wo, c.X, d.dim, 0, nullptr, 0,
                                    nullptr, nullptr, nullptr, nokv, 0, 0, 0, none);
         // (5) RMSNorm(ffn_norm) -> hi/lo ; W1||W3 + SwiGLU -> act hi/lo ; W2 split-K slabs (summed by the next k_prep)
-        if (c.stage_mask & 32u) hipLaunchKernelGGL(k_prep, dim3(M), dim3(256), 0, st, c.X, d.dim, (const float*)nullptr, 0, slab, w.ffn_norm, d.eps, c.A);
-        if (c.stage_mask & 64u) launch_gemm3<EPI_SWIGLU>(2 * d.inter, 1, 2, st, c.A, M, d.dim, (const bf16_t*)w.w13, nullptr, 0, 0, c.C, d.inter,
-                                 nullptr, nullptr, nullptr, nokv, 0, 0, 0, none);
+        if (fuse_norm) {
+            if (c.stage_mask & 64u) launch_gemm3<EPI_SWIGLU_RMS>(2 * d.inter, 1, 2, st, c.A2, M, d.dim, (const bf16_t*)w.w13, nullptr, 0, 0, c.C, d.inter,
+                                     nullptr, nullptr, nullptr, nokv, 0, 0, 0, none, na);
+        } else {
+            if (c.stage_mask & 32u) hipLaunchKernelGGL(k_prep, dim3(M), dim3(256), 0, st, c.X, d.dim, (const float*)nullptr, 0, slab, w.ffn_norm, d.eps, c.A);
+            if (c.stage_mask & 64u) launch_gemm3<EPI_SWIGLU>(2 * d.inter, 1, 2, st, c.A, M, d.dim, (const bf16_t*)w.w13, nullptr, 0, 0, c.C, d.inter,
+                                     nullptr, nullptr, nullptr, nokv, 0, 0, 0, none);
+        }
         if (c.stage_mask & 128u) launch_gemm3<EPI_STORE>(d.dim, DOWN_SPLIT, 1, st, c.C, M, d.inter, (const bf16_t*)w.w2, c.P, d.dim, slab, nullptr, 0, nullptr, nullptr,
                                 nullptr, nokv, 0, 0, 0, none);
         FS_LAUNCH_CHECK();

@@ -39,7 +39,7 @@ int main(int argc, char** argv) {
     const int NC = 8192 / LmKernels<WT>::attn_chunk();
     c.X = (float*)dalloc(512 * 1024 * 4); c.Q = (float*)dalloc(512 * 1024 * 4); c.part = (float*)dalloc((size_t)512 * 16 * NC * 66 * 4);
     c.P = (float*)dalloc(4 * 512 * 1024 * 4); c.A = (uint16_t*)dalloc(2 * 512 * 1024 * 2);
-    c.C = (uint16_t*)dalloc(2 * 512 * 4096 * 2);
+    c.C = (uint16_t*)dalloc(2 * 512 * 4096 * 2); c.A2 = (uint16_t*)dalloc(2 * 512 * 1024 * 2); c.ss = (float*)dalloc(512 * 64 * 4);
     c.cos_t = (float*)dalloc(8192 * 32 * 4); c.sin_t = (float*)dalloc(8192 * 32 * 4);
     SeqState hs = {}; hs.pos = 300; SeqState* state = (SeqState*)dalloc(sizeof(SeqState)); CK(hipMemcpy(state, &hs, sizeof(hs), hipMemcpyHostToDevice));
     c.state = state; c.n_chunks_max = NC; c.nc_launch = argc > 2 ? atoi(argv[2]) : 4; c.pos_step = argc > 3 ? atoi(argv[3]) : 1; c.pt_stride = 0;

@@ -88,6 +88,7 @@ struct RowsCtx {
     int nc_launch;       // attention chunks launched (covers the longest row of this pass)
     int pos_step;        // 1: rows = consecutive tokens of one sequence (prefill); 0: rows = sequences (batched decode)
     int pt_stride;       // page-table stride between rows (0 for prefill)
+    bool no_flash = false;       // micro-benchmark / test hook: keep the chunked row attention for prefill passes
     bool small_attn = false;     // every row attends over <= 8 tokens of ONE page (fast decoder): fused attention node
     unsigned stage_mask = 0xFFu;  // micro-benchmark hook: bit i enables stage i of rows_layer (prep, qkv, attn, combine, wo, prep, w13, w2)
 };

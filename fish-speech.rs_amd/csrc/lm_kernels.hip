@@ -981,6 +981,174 @@ __global__ __launch_bounds__(256) void k_attn_small_rows(const float* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------ prefill attention (MFMA)
+// Causal flash attention for the rows of a prefill pass (consecutive tokens of ONE sequence, bf16 KV, head_dim 64): block =
+// (query head, 16-row tile); its 4 waves split the sequence page-wise (wave w takes KV pages w, w+4, ...), each producing a
+// local (max, sum, O) with a two-pass softmax over its own pages; one LDS merge, and the normalised result goes straight into
+// the fragment-major hi/lo GEMM input (replaces k_attn_decode over (chunks x rows) blocks + k_attn_combine: 57 + 7 us per
+// layer at 384 rows).  Per page (64 tokens = 4 MFMA token tiles) every operand load is in flight before the first MFMA.
+//   S^T[token][row] = K_tile[16 x 64] . Q^T[64 x 16]   v_mfma_f32_16x16x32_bf16, A = K straight from the paged cache (one 16-B load
+//                                                      per lane per 32 dims), B = the rows' q split bf16 hi + lo (held in VGPRs)
+//   two-pass softmax: pass 1 only takes the column maxima; pass 2 recomputes S, p = exp(s - max) -- the S^T accumulator layout
+//   (lane: row l&15, tokens (l>>4)*4..+3) IS the A-operand layout of the 16x16x16 MFMA, so
+//   O[row][dim] += P[row][16 tokens] . V[16 tokens][dim]   v_mfma_f32_16x16x16_bf16, p split hi + lo, B = V gathered from the
+//                                                      wave's private LDS copy of the tile (token-major -> 4 strided bf16)
+// The softmax scale 2^-3 is folded into q (exact).  Rows >= M and tokens past a row's position are masked.
+typedef short short4v __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_attn_prefill_mfma(const float* __restrict__ q_all, KVView kv, const SeqState* __restrict__ state,
+                                                           int M, int H, int Hk, bf16_t* __restrict__ Ohi) {
+    constexpr int DH = 64, VLD = DH + 8;
+    __shared__ __attribute__((aligned(16))) bf16_t vt[4][KV_PAGE * VLD];
+    __shared__ __attribute__((aligned(16))) float sm_o[4][16][DH + 4];
+    __shared__ float sm_m[4][16], sm_l[4][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = blockIdx.x % H, rt = blockIdx.x / H;  // query head, row tile
+    const int g = h / (H / Hk);
+    const int row0 = rt * 16, pos0 = state->pos;        // row m sits at position pos0 + m
+    const int c16 = lane & 15, q4 = lane >> 4;
+    // B operand of QK^T: q[row0 + c16][h][ks*32 + q4*8 ..+8], scaled, split hi/lo
+    bf16x8 qh[2], ql[2];
+    {
+        const int m = min(row0 + c16, M - 1);
+        const float* qp = q_all + ((size_t)m * H + h) * DH + q4 * 8;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const float4 a = *reinterpret_cast<const float4*>(qp + ks * 32), b = *reinterpret_cast<const float4*>(qp + ks * 32 + 4);
+            const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            uint32_t hw[4], lw[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                bf16_t h0, l0, h1, l1;
+                split_bf16(v[2 * i] * 0.125f, h0, l0); split_bf16(v[2 * i + 1] * 0.125f, h1, l1);
+                hw[i] = h0 | ((uint32_t)h1 << 16); lw[i] = l0 | ((uint32_t)l1 << 16);
+            }
+            u32x4 hv, lv; hv.x = hw[0]; hv.y = hw[1]; hv.z = hw[2]; hv.w = hw[3]; lv.x = lw[0]; lv.y = lw[1]; lv.z = lw[2]; lv.w = lw[3];
+            qh[ks] = __builtin_bit_cast(bf16x8, hv); ql[ks] = __builtin_bit_cast(bf16x8, lv);
+        }
+    }
+    const int my_pos = pos0 + row0 + c16;                       // last token this lane's row may see
+    const int n_tok = pos0 + min(row0 + 15, M - 1) + 1;           // tokens the tile's LAST row needs
+    const int n_groups = (n_tok + KV_PAGE - 1) / KV_PAGE;         // one group = one KV page = 4 token tiles of 16
+    const bf16_t* kpool = reinterpret_cast<const bf16_t*>(kv.k);
+    const bf16_t* vpool = reinterpret_cast<const bf16_t*>(kv.v);
+    // S^T of the 4 token tiles of page `grp`: all 8 K loads (A operands, straight from the cache) are in flight together
+    auto scores = [&](int grp, f32x4v (&sacc)[4]) {
+        const int page = kv.page_table[grp];
+        const bf16_t* kp = kpool + ((size_t)(page * Hk + g) * KV_PAGE + c16) * DH + q4 * 8;
+        u32x4 k0[4], k1[4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            k0[tt] = *reinterpret_cast<const u32x4*>(kp + (size_t)tt * 16 * DH);
+            k1[tt] = *reinterpret_cast<const u32x4*>(kp + (size_t)tt * 16 * DH + 32);
+        }
+        FS_ISSUE_FENCE();
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            f32x4v a = f32x4v{0.f, 0.f, 0.f, 0.f};
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, k0[tt]), qh[0], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, k0[tt]), ql[0], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, k1[tt]), qh[1], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, k1[tt]), ql[1], a, 0, 0, 0);
+            const int t0 = grp * KV_PAGE + tt * 16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (t0 + q4 * 4 + i > my_pos) a[i] = -1e30f;  // causal mask (also hides stale rows of the page)
+            sacc[tt] = a;
+        }
+    };
+    // pass 1: column maxima
+    float mx = -1e30f;
+    for (int grp = wave; grp < n_groups; grp += 4) {
+        f32x4v s4[4];
+        scores(grp, s4);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) mx = fmaxf(fmaxf(mx, fmaxf(s4[tt][0], s4[tt][1])), fmaxf(s4[tt][2], s4[tt][3]));
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    // pass 2: P . V
+    f32x4v o[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) o[nt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    float lsum = 0.f;
+    bf16_t* myv = vt[wave];
+    for (int grp = wave; grp < n_groups; grp += 4) {
+        {   // stage the page's V (64 tokens x 64 dims) token-major into the wave's private LDS region: 8 x 16-B loads per lane
+            const int page = kv.page_table[grp];
+            const bf16_t* vp = vpool + (size_t)(page * Hk + g) * KV_PAGE * DH;
+            u32x4 vr[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) vr[j] = *reinterpret_cast<const u32x4*>(vp + (size_t)(j * 64 + lane) * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int e = j * 64 + lane, tk = e >> 3, d8 = (e & 7) * 8;
+                *reinterpret_cast<u32x4*>(myv + tk * VLD + d8) = vr[j];
+            }
+        }
+        f32x4v s4[4];
+        scores(grp, s4);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            uint32_t ph[2], pl[2];
+            {
+                bf16_t hb[4], lb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float p = s4[tt][i] > -1e29f ? __expf(s4[tt][i] - mx) : 0.f;
+                    lsum += p;
+                    split_bf16(p, hb[i], lb[i]);
+                }
+                ph[0] = hb[0] | ((uint32_t)hb[1] << 16); ph[1] = hb[2] | ((uint32_t)hb[3] << 16);
+                pl[0] = lb[0] | ((uint32_t)lb[1] << 16); pl[1] = lb[2] | ((uint32_t)lb[3] << 16);
+            }
+            uint2 phv, plv; phv.x = ph[0]; phv.y = ph[1]; plv.x = pl[0]; plv.y = pl[1];
+            const short4v pa_h = __builtin_bit_cast(short4v, phv), pa_l = __builtin_bit_cast(short4v, plv);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const bf16_t* vq = myv + (tt * 16 + q4 * 4) * VLD + nt * 16 + c16;  // V[token tt*16 + q4*4 + j][dim nt*16 + c16]
+                uint2 bv;
+                bv.x = vq[0] | ((uint32_t)vq[VLD] << 16);
+                bv.y = vq[2 * VLD] | ((uint32_t)vq[3 * VLD] << 16);
+                const short4v vb = __builtin_bit_cast(short4v, bv);
+                o[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa_h, vb, o[nt], 0, 0, 0);
+                o[nt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa_l, vb, o[nt], 0, 0, 0);
+            }
+        }
+    }
+    lsum += __shfl_xor(lsum, 16, 64);
+    lsum += __shfl_xor(lsum, 32, 64);
+    // merge the 4 page-splits: o[nt][i] = O_w[row q4*4 + i][dim nt*16 + c16]; max / sum live in column layout (row = c16)
+    if (q4 == 0) { sm_m[wave][c16] = mx; sm_l[wave][c16] = lsum; }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sm_o[wave][q4 * 4 + i][nt * 16 + c16] = o[nt][i];
+    __syncthreads();
+    {
+        const int r = threadIdx.x >> 4, d4 = (threadIdx.x & 15) * 4, m = row0 + r;
+        if (m < M) {
+            const float mg = fmaxf(fmaxf(sm_m[0][r], sm_m[1][r]), fmaxf(sm_m[2][r], sm_m[3][r]));
+            float L = 0.f, O[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2) {
+                const float cf = __expf(sm_m[w2][r] - mg);  // a split without pages has max -1e30, sum 0, O 0
+                L = fmaf(sm_l[w2][r], cf, L);
+                const float4 ov = *reinterpret_cast<const float4*>(&sm_o[w2][r][d4]);
+                O[0] = fmaf(ov.x, cf, O[0]); O[1] = fmaf(ov.y, cf, O[1]); O[2] = fmaf(ov.z, cf, O[2]); O[3] = fmaf(ov.w, cf, O[3]);
+            }
+            const float inv = 1.f / L;
+            bf16_t hi[4], lo[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) split_bf16(O[i] * inv, hi[i], lo[i]);
+            uint2 phv, plv;
+            phv.x = hi[0] | ((uint32_t)hi[1] << 16); phv.y = hi[2] | ((uint32_t)hi[3] << 16);
+            plv.x = lo[0] | ((uint32_t)lo[1] << 16); plv.y = lo[2] | ((uint32_t)lo[3] << 16);
+            const int e = h * DH + d4;
+            *reinterpret_cast<uint2*>(Ohi + frag_off(m, e, 0, H * DH)) = phv;
+            *reinterpret_cast<uint2*>(Ohi + frag_off(m, e, 1, H * DH)) = plv;
+        }
+    }
+}
+
 template <typename WT>
 __global__ void k_embed_rows(const WT* __restrict__ tok_emb, const WT* __restrict__ cb_emb, int dim, int n_cb, int cb_size,
                              const SampleCfg* __restrict__ cfg, const uint32_t* __restrict__ prompt,
@@ -2178,7 +2346,10 @@ void LmKernels<WT>::rows_layer(const ModelDims& d, int M, const RowsCtx& c, cons
         if (c.stage_mask & 2u) launch_gemm3<EPI_QKV>(qkv_rows, 1, 1, st, c.A, M, d.dim, (const bf16_t*)w.wqkv, c.Q, d.dim, 0, nullptr, 0,
                               c.cos_t, c.sin_t, c.state, kv, d.H, d.Hk, d.Dh, rm);
         // (3) attention over each row's KV prefix + chunk combine -> hi/lo
-        if (c.small_attn && (c.stage_mask & 4u) && d.H <= 32 && (d.Dh == 64 || d.Dh == 32)) {
+        if (c.pos_step == 1 && c.pt_stride == 0 && (c.stage_mask & 4u) && d.Dh == 64 && M > 1 && !c.no_flash) {
+            // prefill: causal flash attention on the matrix cores, result straight into the Wo GEMM's input
+            hipLaunchKernelGGL(k_attn_prefill_mfma, dim3(d.H * ((M + 15) / 16)), dim3(256), 0, st, c.Q, kv, c.state, M, d.H, d.Hk, c.A);
+        } else if (c.small_attn && (c.stage_mask & 4u) && d.H <= 32 && (d.Dh == 64 || d.Dh == 32)) {
             // fast decoder: <= 8 tokens in one page -> one node instead of two
             if (d.Dh == 64)
                 hipLaunchKernelGGL((k_attn_small_rows<64>), dim3(M), dim3(256), 0, st, c.Q, kv, c.state, d.H, d.Hk, c.pos_step, c.pt_stride, c.A);

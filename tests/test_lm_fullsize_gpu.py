@@ -163,3 +163,32 @@ def test_fish15_prefix_cache_equivalence_and_determinism(lm15):
     assert np.array_equal(a, c)
     st = lm.last_stats()
     assert st["frames"] == a.shape[1] == 32 and st["prompt_tokens"] == L
+
+
+def test_fish15_bf16_prefill_pass_equals_token_steps(lm15):
+    """The prefill pass (MFMA GEMMs + causal flash attention over all rows at once) and the batch-1 decode kernels (GEMV +
+    flash-decoding, one token per call) are two implementations of the same function: after the same 150 tokens the hidden
+    state, the logits and the KV length must agree (bf16 KV rounding is identical on both paths; tolerance = summation order)."""
+    lm = lm15
+    p = _prompt(150, seed=7)
+    sem0 = fcfg.FISH_1_5_TOKENS["semantic_start_id"]
+    rng = np.random.RandomState(3)
+    for col in (5, 40, 41, 120):  # a few VQ columns so the codebook embeddings take part
+        p[0, col] = sem0 + rng.randint(0, 1024)
+        p[1:, col] = rng.randint(0, 1024, 8)
+    lm.clear_slow_layer_caches()
+    lg, hg = lm.forward_generate(p, 0)
+    assert lm.curr_kv_size() == 150
+    lm.clear_slow_layer_caches()
+    for t in range(150):
+        l1, h1 = lm.forward_generate(np.ascontiguousarray(p[:, t:t + 1]), t)
+    assert lm.curr_kv_size() == 150
+    im_end = fcfg.FISH_1_5_TOKENS["im_end_id"]
+    dh = float(np.abs(hg - h1).max() / np.sqrt(np.mean(h1 ** 2)))
+    dl = float(np.abs(lg[0, im_end:] - l1[0, im_end:]).max())
+    print(f"prefill pass vs token steps: |dh|/rms {dh:.2e}, max |dlogit| {dl:.2e}")
+    assert dh < 5e-3 and dl < 5e-3, (dh, dl)
+    # and a cached-prefix continuation: 100 tokens token-by-token state == pass state for the next 50 rows
+    lm.clear_slow_caches_until(100)
+    l2, h2 = lm.forward_generate(np.ascontiguousarray(p[:, 100:]), 100)
+    assert float(np.abs(h2 - h1).max() / np.sqrt(np.mean(h1 ** 2))) < 5e-3

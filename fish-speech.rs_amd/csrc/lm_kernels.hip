@@ -842,7 +842,7 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* __restrict__ Xf, in
                 float2* yp = reinterpret_cast<float2*>(Y + (size_t)m * ldy + r);
                 const float2 o = *yp;
                 *yp = make_float2(o.x + a, o.y + b);
-            } else if (EPI == EPI_RESIDUAL_NORM) {  // RT == 1: the 8 threads of one m are 8 adjacent lanes
+            } else if (EPI == EPI_RESIDUAL_NORM) {  // the ROWS/2 threads of one m are adjacent lanes (8, 16 or 32 of them)
                 float2* yp = reinterpret_cast<float2*>(Y + (size_t)m * ldy + r);
                 const float2 o = *yp;
                 const float v0 = o.x + a, v1 = o.y + b;
@@ -851,7 +851,8 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* __restrict__ Xf, in
                 split_bf16(v0 * na.g[r], h0, l0); split_bf16(v1 * na.g[r + 1], h1, l1);
                 *reinterpret_cast<uint32_t*>(na.A2 + frag_off(m, r, 0, na.D)) = h0 | ((uint32_t)h1 << 16);
                 *reinterpret_cast<uint32_t*>(na.A2 + frag_off(m, r, 1, na.D)) = l0 | ((uint32_t)l1 << 16);
-                const float ssq = group_sum<8>(fmaf(v0, v0, v1 * v1));
+                float ssq = group_sum<(ROWS / 2 >= 16 ? 16 : ROWS / 2)>(fmaf(v0, v0, v1 * v1));
+                if (ROWS / 2 == 32) ssq += __shfl_xor(ssq, 16, 64);
                 if (pr == 0) na.ss[(size_t)m * na.nblk + blockIdx.x] = ssq;
             } else if (EPI == EPI_SWIGLU_RMS) {
                 const float dn = s_rms[ml];
@@ -2309,7 +2310,14 @@ static void launch_gemm3(int N, int ksplit, int rt, hipStream_t st, const bf16_t
 #define FS_GEMM_CASE(nk, r)                                                                                                          \
     hipLaunchKernelGGL((k_gemm3<EPI, nk, r>), grid, dim3(256), 0, st, Xf, M, K, W, N, Y, ldy, slab_stride, Of, ldo, cos_t,  \
                        sin_t, state, kv, H, Hk, Dh, rm, na)
-    if (rt == 2) {
+    if (rt == 4) {
+        switch (nks) {
+            case 8: FS_GEMM_CASE(8, 4); break;
+            case 2: FS_GEMM_CASE(2, 4); break;
+            case 1: FS_GEMM_CASE(1, 4); break;
+            default: throw Error("unsupported GEMM depth per K range " + std::to_string(K / ksplit) + " (supported: 1024, 256, 128)");
+        }
+    } else if (rt == 2) {
         switch (nks) {
             case 8: FS_GEMM_CASE(8, 2); break;
             case 2: FS_GEMM_CASE(2, 2); break;
@@ -2335,6 +2343,11 @@ void LmKernels<WT>::rows_layer(const ModelDims& d, int M, const RowsCtx& c, cons
         FS_REQUIRE(M >= 1 && M <= c.Mcap, "more activation rows than the row buffers hold");
         FS_REQUIRE(d.dim % 128 == 0 && d.inter % 128 == 0, "row path needs dim % 128 == 0 and intermediate_size % 128 == 0");
         const int qkv_rows = (d.H + 2 * d.Hk) * d.Dh;
+        // 16-row-tiles per wave: 1 everywhere, 2 for the wide W13 (halves the L2 re-reads of the activation fragments).  64-row
+        // blocks (rt = 4) were measured for prefill-sized passes and are SLOWER (W13 at 384 rows: 33 -> 41 us): the lost
+        // occupancy costs more than the saved fragment traffic.
+        const int rt_qkv = 1, rt_o = 1, rt_13 = 2, rt_2 = 1;
+        const int nblk_o = d.dim / (16 * rt_o);
         const RowMap rm{c.pos_step, c.pt_stride};
         const RowMap none{0, 0};
         KVView nokv = {};
@@ -2343,7 +2356,7 @@ void LmKernels<WT>::rows_layer(const ModelDims& d, int M, const RowsCtx& c, cons
         // (1) x += previous layer's down-proj slabs ; RMSNorm(attention_norm) -> hi/lo
         if (c.stage_mask & 1u) hipLaunchKernelGGL(k_prep, dim3(M), dim3(256), 0, st, c.X, d.dim, c.P, first ? 0 : DOWN_SPLIT, slab, w.attn_norm, d.eps, c.A);
         // (2) Wqkv + rope + KV scatter
-        if (c.stage_mask & 2u) launch_gemm3<EPI_QKV>(qkv_rows, 1, 1, st, c.A, M, d.dim, (const bf16_t*)w.wqkv, c.Q, d.dim, 0, nullptr, 0,
+        if (c.stage_mask & 2u) launch_gemm3<EPI_QKV>(qkv_rows, 1, rt_qkv, st, c.A, M, d.dim, (const bf16_t*)w.wqkv, c.Q, d.dim, 0, nullptr, 0,
                               c.cos_t, c.sin_t, c.state, kv, d.H, d.Hk, d.Dh, rm);
         // (3) attention over each row's KV prefix + chunk combine -> hi/lo
         if (c.pos_step == 1 && c.pt_stride == 0 && (c.stage_mask & 4u) && d.Dh == 64 && M > 1 && !c.no_flash) {
@@ -2373,24 +2386,24 @@ void LmKernels<WT>::rows_layer(const ModelDims& d, int M, const RowsCtx& c, cons
                 hipLaunchKernelGGL((k_attn_combine<32>), dim3(M), dim3(256), 0, st, c.part, c.n_chunks_max, attn_chunk(), c.state, c.pos_step, c.A, d.H);
         }
         // (4) Wo + residual (each output element owned by one lane: deterministic)
-        const bool fuse_norm = c.A2 != nullptr && c.ss != nullptr && (d.dim / 16) % 8 == 0;
-        NormAux na{w.ffn_norm, c.ss, c.A2, d.dim / 16, d.dim, d.eps};
+        const bool fuse_norm = c.A2 != nullptr && c.ss != nullptr && nblk_o % 8 == 0 && d.dim % (16 * rt_o) == 0;
+        NormAux na{w.ffn_norm, c.ss, c.A2, nblk_o, d.dim, d.eps};
         if (!(c.stage_mask & 16u)) {}
         else if (fuse_norm)
-            launch_gemm3<EPI_RESIDUAL_NORM>(d.dim, 1, 1, st, c.A, M, d.dim, (const bf16_t*)w.wo, c.X, d.dim, 0, nullptr, 0, nullptr, nullptr,
+            launch_gemm3<EPI_RESIDUAL_NORM>(d.dim, 1, rt_o, st, c.A, M, d.dim, (const bf16_t*)w.wo, c.X, d.dim, 0, nullptr, 0, nullptr, nullptr,
                                             nullptr, nokv, 0, 0, 0, none, na);
-        else launch_gemm3<EPI_RESIDUAL>(d.dim, 1, 1, st, c.A, M, d.dim, (const bf16_t*)w.wo, c.X, d.dim, 0, nullptr, 0,
+        else launch_gemm3<EPI_RESIDUAL>(d.dim, 1, rt_o, st, c.A, M, d.dim, (const bf16_t*)w.wo, c.X, d.dim, 0, nullptr, 0,
                                    nullptr, nullptr, nullptr, nokv, 0, 0, 0, none);
         // (5) RMSNorm(ffn_norm) -> hi/lo ; W1||W3 + SwiGLU -> act hi/lo ; W2 split-K slabs (summed by the next k_prep)
         if (fuse_norm) {
-            if (c.stage_mask & 64u) launch_gemm3<EPI_SWIGLU_RMS>(2 * d.inter, 1, 2, st, c.A2, M, d.dim, (const bf16_t*)w.w13, nullptr, 0, 0, c.C, d.inter,
+            if (c.stage_mask & 64u) launch_gemm3<EPI_SWIGLU_RMS>(2 * d.inter, 1, rt_13, st, c.A2, M, d.dim, (const bf16_t*)w.w13, nullptr, 0, 0, c.C, d.inter,
                                      nullptr, nullptr, nullptr, nokv, 0, 0, 0, none, na);
         } else {
             if (c.stage_mask & 32u) hipLaunchKernelGGL(k_prep, dim3(M), dim3(256), 0, st, c.X, d.dim, (const float*)nullptr, 0, slab, w.ffn_norm, d.eps, c.A);
-            if (c.stage_mask & 64u) launch_gemm3<EPI_SWIGLU>(2 * d.inter, 1, 2, st, c.A, M, d.dim, (const bf16_t*)w.w13, nullptr, 0, 0, c.C, d.inter,
+            if (c.stage_mask & 64u) launch_gemm3<EPI_SWIGLU>(2 * d.inter, 1, rt_13, st, c.A, M, d.dim, (const bf16_t*)w.w13, nullptr, 0, 0, c.C, d.inter,
                                      nullptr, nullptr, nullptr, nokv, 0, 0, 0, none);
         }
-        if (c.stage_mask & 128u) launch_gemm3<EPI_STORE>(d.dim, DOWN_SPLIT, 1, st, c.C, M, d.inter, (const bf16_t*)w.w2, c.P, d.dim, slab, nullptr, 0, nullptr, nullptr,
+        if (c.stage_mask & 128u) launch_gemm3<EPI_STORE>(d.dim, DOWN_SPLIT, rt_2, st, c.C, M, d.inter, (const bf16_t*)w.w2, c.P, d.dim, slab, nullptr, 0, nullptr, nullptr,
                                 nullptr, nokv, 0, 0, 0, none);
         FS_LAUNCH_CHECK();
     }

@@ -124,6 +124,16 @@ def main():
     T_avg = L + args.frames / 2.0
     bf = frame_bytes(cfg, tok, T_avg)
     achieved = bf / t_frame
+    # the dominant kernel of the frame by bytes: k_ffn_up (RMSNorm + W1||W3 GEMV + SwiGLU), 56 launches per frame, measured live as a graph
+    # node over distinct layer weights with HIP events on the engine stream (fs_lm_bench_kernel); rocprof: profiles/r01_bench_kernel_stats.csv
+    up_us = lm.bench_kernel(3, int(T_avg), 50)
+    up_bytes = 2 * (2 * cfg["intermediate_size"] * cfg["dim"]) + 8 * cfg["dim"] + 4 * cfg["intermediate_size"]
+    per_kernel = {}
+    for name, kind, nbytes in (("k_qkv", 0, 2 * (cfg["n_head"] + 2 * cfg["n_local_heads"]) * cfg["head_dim"] * cfg["dim"]),
+                               ("k_attn_decode", 1, int(T_avg) * 2 * cfg["n_local_heads"] * cfg["head_dim"] * 2),
+                               ("k_wo", 2, 2 * cfg["dim"] * cfg["dim"]), ("k_ffn_down", 4, 2 * cfg["dim"] * cfg["intermediate_size"])):
+        us = lm.bench_kernel(kind, int(T_avg), 50)
+        per_kernel[name] = {"avg_us": round(us, 2), "algorithmic_bytes": nbytes, "GBps": round(nbytes / us / 1e3, 1)}
     res = {
         "metric": "codec tokens/sec (frames/s; 1 frame = 1 slow + 8 codebook tokens = 2048 PCM samples), Fish-1.5 batch=1",
         "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -142,7 +152,13 @@ def main():
                      # HBM bytes per frame from the PMC passes of profiles/r01_pmc_hbm_traffic.csv (FETCH_SIZE x2 gfx950 correction
                      # + WRITE_SIZE, summed over the frame's 266 launches); collected offline, not in this run
                      "traffic": 1.75e9, "traffic_source": "profiles/r01_pmc_hbm_traffic.csv (offline rocprofv3 --pmc passes)",
-                     "algorithmic_bytes_per_frame": int(bf), "frame_us": round(t_frame * 1e6, 2), "kv_len_avg": T_avg},
+                     "algorithmic_bytes_per_frame": int(bf), "frame_us": round(t_frame * 1e6, 2), "kv_len_avg": T_avg,
+                     "dominant_kernel": {"name": "k_ffn_up<bf16, 1024> (RMSNorm + W1||W3 GEMV + SwiGLU; 56 of the frame's 266 launches, 55 % of its bytes)",
+                                         "algorithmic_bytes_per_launch": up_bytes, "avg_us": round(up_us, 2),
+                                         "achieved": round(up_bytes / up_us / 1e3, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                         "frac": round(up_bytes / (up_us * 1e-6) / HBM_PEAK, 4),
+                                         "note": "graph node incl. the 1.55 us launch floor; HIP events on the engine stream"},
+                     "other_kernels": per_kernel},
     }
     if rank == 0 and world == 1 and not args.no_extras:
         res["extras"] = extras(cfg, tok)

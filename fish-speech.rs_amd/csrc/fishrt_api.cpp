@@ -79,6 +79,10 @@ int fs_lm_generate_batch(fs_lm_t* lm, const uint32_t* prompts, const int* lens, 
 }
 int fs_lm_last_stats(fs_lm_t* lm, fs_gen_stats* out) { FS_ARG(lm && out, "null argument"); FS_TRY(*out = lm->impl->last_stats()) }
 void* fs_lm_stream(fs_lm_t* lm) { return lm ? lm->impl->stream() : nullptr; }
+int fs_lm_bench_kernel(fs_lm_t* lm, int kind, int kv_len, int reps, float* us_per_launch) {
+    FS_ARG(lm && us_per_launch, "null argument");
+    FS_TRY(*us_per_launch = lm->impl->bench_kernel(kind, kv_len, reps))
+}
 
 int fs_codec_create(int device_id, int channel_div, fs_codec_t** out) {
     FS_ARG(out, "null argument");

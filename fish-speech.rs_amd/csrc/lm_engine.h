@@ -29,6 +29,10 @@ class LMBase {
                                 size_t* n_frames) = 0;
     virtual fs_gen_stats last_stats() = 0;
     virtual void* stream() = 0;
+    // measurement hook: average duration (us) of ONE launch of decode kernel `kind` (0 qkv, 1 attention, 2 wo, 3 ffn_up, 4 ffn_down) as a
+    // node of a captured graph that cycles over the slow layers' distinct weights (nothing cache-resident), HIP-event timed on the
+    // engine stream at KV length `kv_len`
+    virtual float bench_kernel(int kind, int kv_len, int reps) = 0;
 };
 
 // FS_FP8 storage format helpers (run on the device; used by offline quantisation tools and the parity tests)

@@ -241,6 +241,47 @@ class LM final : public LMBase {
     fs_gen_stats last_stats() override { return stats_; }
     void* stream() override { return (void*)st_; }
 
+    float bench_kernel(int kind, int kv_len, int reps) override {
+        use_device();
+        require_loaded();
+        FS_REQUIRE(kind >= 0 && kind <= 4 && reps >= 1, "bad kernel id");
+        FS_REQUIRE(kv_len >= 1 && kv_len < a_.max_seq_len, "bad KV length");
+        clear_slow();
+        ensure_capacity(0, kv_len);
+        SeqState s0 = {};
+        s0.pos = kv_len - 1;
+        FS_HIP(hipMemcpyAsync(state(0), &s0, sizeof(s0), hipMemcpyHostToDevice, st_));
+        set_bucket(kv_len);
+        hipGraph_t g = nullptr;
+        hipGraphExec_t ge = nullptr;
+        FS_HIP(hipStreamBeginCapture(st_, hipStreamCaptureModeThreadLocal));
+        for (int l = 0; l < a_.n_layer; ++l) {
+            const LayerW& w = slow_[l];
+            KVView kv = slow_kv(l, 0);
+            switch (kind) {
+                case 0: LmKernels<WT>::qkv(d_, x(0), w, d_cos_.as<float>(), d_sin_.as<float>(), state(0), 0, 0, d_q_.as<float>(), kv, st_); break;
+                case 1: LmKernels<WT>::attn_decode(d_, d_q_.as<float>(), kv, state(0), d_part_.as<float>(), n_chunks_, nc_launch_, st_); break;
+                case 2: LmKernels<WT>::wo(d_, d_part_.as<float>(), n_chunks_, nc_launch_, state(0), nullptr, kv, 0, w, x(0), st_); break;
+                case 3: LmKernels<WT>::ffn_up(d_, x(0), w, d_act_.as<float>(), st_); break;
+                default: LmKernels<WT>::ffn_down(d_, d_act_.as<float>(), w, x(0), st_); break;
+            }
+        }
+        FS_HIP(hipStreamEndCapture(st_, &g));
+        FS_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        FS_HIP(hipGraphDestroy(g));
+        FS_HIP(hipGraphLaunch(ge, st_));
+        FS_HIP(hipStreamSynchronize(st_));
+        FS_HIP(hipEventRecord(ev_[0], st_));
+        for (int r = 0; r < reps; ++r) FS_HIP(hipGraphLaunch(ge, st_));
+        FS_HIP(hipEventRecord(ev_[1], st_));
+        FS_HIP(hipStreamSynchronize(st_));
+        float ms = 0.f;
+        FS_HIP(hipEventElapsedTime(&ms, ev_[0], ev_[1]));
+        (void)hipGraphExecDestroy(ge);
+        clear_slow();
+        return ms * 1e3f / (float)(reps * a_.n_layer);
+    }
+
     // ------------------------------------------------------------------------------------------ generate_blocking
     void generate(const uint32_t* prompt, int L, int max_new_tokens, const fs_sampling& s, uint64_t seed, uint32_t flags,
                   uint32_t* codes_out, size_t cap, size_t* n_frames, fs_frame_cb cb, void* cb_user) override {

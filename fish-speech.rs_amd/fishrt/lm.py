@@ -138,6 +138,12 @@ class DualARTransformer:
     def stream(self):
         return _ffi.lib().fs_lm_stream(self._h)
 
+    def bench_kernel(self, kind, kv_len=495, reps=50):
+        """us per launch of one batch-1 decode kernel (0 qkv, 1 attention, 2 wo, 3 ffn_up, 4 ffn_down) as a graph node (measurement hook)."""
+        us = C.c_float(0)
+        _ffi.check(_ffi.lib().fs_lm_bench_kernel(self._h, int(kind), int(kv_len), int(reps), C.byref(us)))
+        return float(us.value)
+
 
 class LM:
     """fish_speech_python `LM` (lm.rs:23-199) with token-id inputs: __call__(list of prompts (C+1, L_i) for successive

@@ -405,7 +405,43 @@ __global__ __launch_bounds__(WAVES * 64) void k_wo(const float* __restrict__ par
     const float xres = (row < n_rows && lane == 0) ? x[row] : 0.f;
     // Few, wide prologue loads (the texture-address unit retires one wave-instruction per ~16 cycles whatever its width),
     // all issued before the weight stream (vmcnt retires in issue order).
-    if (!FUSED) {
+    if (!FUSED && nc_launch <= 8) {
+        // short sequences (<= 8 chunks): every thread merges the chunks of its own head in registers -- its {m, l} pairs and its
+        // four output dims of every chunk are 16 independent loads issued before the weight stream; no LDS hop, no barrier
+        // until the result vector is complete (same arithmetic, in the same order, as the general path below)
+        const int e4 = threadIdx.x * 4;
+        const bool has_o = e4 < K;
+        const int ho = (has_o ? e4 : 0) / DH, ddo = e4 % DH;
+        const float* pb = part + (size_t)ho * n_chunks_max * (DH + 2);
+        float2 mlv[8];
+        float4 ov[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int cc = min(c, nc_launch - 1);
+            mlv[c] = *reinterpret_cast<const float2*>(pb + (size_t)cc * (DH + 2) + DH);
+            ov[c] = *reinterpret_cast<const float4*>(pb + (size_t)cc * (DH + 2) + ddo);
+        }
+        R::load_w(W + (size_t)min(row, n_rows - 1) * K, lane, wv);
+        FS_ISSUE_FENCE();
+        const int T = state->pos + 1;
+        const int nc = (T + chunk - 1) / chunk;  // chunks k_attn_decode produced (<= nc_launch)
+        float mn = -1e30f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) if (c < nc) mn = fmaxf(mn, mlv[c].x);
+        float L = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) if (c < nc) L += mlv[c].y * __expf(mlv[c].x - mn);
+        const float inv = 1.f / L;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (c < nc) {
+                const float wj = __expf(mlv[c].x - mn) * inv;
+                acc.x = fmaf(wj, ov[c].x, acc.x); acc.y = fmaf(wj, ov[c].y, acc.y);
+                acc.z = fmaf(wj, ov[c].z, acc.z); acc.w = fmaf(wj, ov[c].w, acc.w);
+            }
+        if (has_o) *reinterpret_cast<float4*>(&attn[e4]) = acc;
+    } else if (!FUSED) {
         // every prologue load is addressed from launch-time constants only (nc_launch = chunks this graph bucket launches),
         // so nothing waits for state->pos before the weight stream is requested; chunks >= nc hold stale (finite) partials of
         // earlier frames and are masked below

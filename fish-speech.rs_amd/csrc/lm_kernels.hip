@@ -498,6 +498,67 @@ __global__ __launch_bounds__(WAVES * 64) void k_wo(const float* __restrict__ par
                 }
         }
         if (has_o) *reinterpret_cast<float4*>(&attn[e4]) = acc;
+    } else if (DH == 64 && K == 4 * NTH && H * 16 == NTH) {
+        // Fast decoder, Fish geometry (16 heads x 64 dims, 256 threads): head h is produced AND consumed by the 16 lanes
+        // tid = 16h .. 16h+15 (one DPP row of one wave): scores[h][t] by lane pair (2t, 2t+1) (32 dims each), then every lane of
+        // the row does softmax . V for 4 of the head's 64 dims.  The score exchange stays inside the wave (8 floats per head in
+        // LDS, no block barrier: a wave's LDS operations execute in order) -- one __syncthreads() less than the general path.
+        const float scale = 1.0f / sqrtf((float)DH);
+        const KT* kbase = reinterpret_cast<const KT*>(kv.k);
+        const KT* vbase = reinterpret_cast<const KT*>(kv.v);
+        constexpr int QD = DH / 2;
+        const int hh = threadIdx.x >> 4, t1 = (threadIdx.x >> 1) & 7, sl = threadIdx.x & 1;
+        const int g = hh / n_rep;
+        vec kvv[QD / EPL];
+        float4 qv[QD / 4];
+        {
+            const KT* kp = kbase + ((size_t)g * KV_PAGE + t1) * DH + sl * QD;  // rows t >= fused_T are stale but in bounds; masked below
+#pragma unroll
+            for (int i = 0; i < QD / EPL; ++i) kvv[i] = *reinterpret_cast<const vec*>(kp + i * EPL);
+#pragma unroll
+            for (int i = 0; i < QD / 4; ++i) qv[i] = *reinterpret_cast<const float4*>(q + hh * DH + sl * QD + i * 4);
+        }
+        const int ddv = (threadIdx.x & 15) * 4;  // this lane's 4 output dims of head hh
+        float vf4[8][4];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const KT* vp = vbase + ((size_t)g * KV_PAGE + t) * DH + ddv;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vf4[t][i] = WTr<KT>::to_f32(vp[i]);
+        }
+        R::load_w(W + (size_t)min(row, n_rows - 1) * K, lane, wv);
+        FS_ISSUE_FENCE();
+        {
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < QD / EPL; ++i) {
+                float kf[EPL];
+                WTr<KT>::unpack(kvv[i], kf);
+#pragma unroll
+                for (int j = 0; j < EPL; j += 4) {
+                    const float4 qq = qv[(i * EPL + j) / 4];
+                    acc = fmaf(qq.x, kf[j] * scale, acc); acc = fmaf(qq.y, kf[j + 1] * scale, acc);
+                    acc = fmaf(qq.z, kf[j + 2] * scale, acc); acc = fmaf(qq.w, kf[j + 3] * scale, acc);
+                }
+            }
+            acc = group_sum<2>(acc);
+            if (sl == 0) wl[hh * 8 + t1] = acc;
+        }
+        // (same wave: no block barrier)
+        float mn = -1e30f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) if (t < fused_T) mn = fmaxf(mn, wl[hh * 8 + t]);
+        float L = 0.f, O[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            if (t < fused_T) {
+                const float p = __expf(wl[hh * 8 + t] - mn);
+                L += p;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) O[i] = fmaf(p, vf4[t][i], O[i]);
+            }
+        const float inv = 1.f / L;
+        *reinterpret_cast<float4*>(&attn[threadIdx.x * 4]) = make_float4(O[0] * inv, O[1] * inv, O[2] * inv, O[3] * inv);
     } else {
         // Fast decoder: <= 8 cached tokens, all in page 0 of this layer's private KV page (no page-table lookup).
         // step 1: scores[h][t], TWO threads per (h, t) (DH/2 dims each, DPP pair-sum); step 2: softmax . V with one

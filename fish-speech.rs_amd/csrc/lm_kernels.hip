@@ -2168,7 +2168,7 @@ static void dispatch_k(int K, F&& f) {
 template <typename WT>
 void LmKernels<WT>::qkv(const ModelDims& d, const float* x, const LayerW& w, const float* cos_t, const float* sin_t,
                         const SeqState* state, int pos_static, int rope_static, float* q_out, KVView kv, hipStream_t st) {
-    constexpr int WAVES = 4;  // one row per wave, two RoPE pairs per block
+    constexpr int WAVES = 2;  // one row per wave, one RoPE pair per block
     const int n_rows = (d.H + 2 * d.Hk) * d.Dh;
     const int grid = (n_rows + WAVES - 1) / WAVES;
     dispatch_k(d.dim, [&](auto Kc) {

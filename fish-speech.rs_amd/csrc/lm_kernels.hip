@@ -1,4 +1,6 @@
-// Dual-AR transformer decode kernels for gfx950 (MI355X), batch-1 token path.
+// Dual-AR transformer kernels for gfx950 (MI355X): the batch-1 token path (GEMV kernels, flash-decoding attention, on-device
+// samplers) first, then the MFMA row path (skinny GEMMs over activation rows, prefill flash attention) used by the prefill
+// and by the static-batch generator.
 //
 // Every kernel here is HBM/latency-bound weight streaming (a 1024x1024 bf16 matrix is 2 MB; one CU can keep
 // ~32 KB in flight), so the design rules are (MI355X guide, "GEMV / M <= 16 decode weights"):
@@ -754,16 +756,13 @@ __global__ void k_advance(SeqState* state) {
 }
 
 // ------------------------------------------------------------------------------------------------ skinny GEMMs (MFMA)
-// M <= 64 rows of activations against bf16 weights streamed ONCE: used by the chunked prefill (rows = consecutive
-// prompt tokens of one sequence) and by the batched decode step (rows = sequences).  Y[M, N] = f(A[M, K]) . W[N, K]^T.
+// Activation ROWS against bf16 weights: the prefill (rows = up to 512 consecutive prompt tokens of one sequence per pass) and the
+// batched decode step (rows = sequences).  Y[M, N] = f(A[M, K]) . W[N, K]^T, 32 rows (one MFMA column-tile pair) at a time.
 // Numerics: activations stay f32-grade end to end -- every GEMM input is split once into bf16 hi + bf16 lo parts
 // (a = hi + lo up to 2^-17 relative; k_prep / producer epilogues) and both parts go through v_mfma_f32_16x16x32_bf16 with
 // f32 accumulation, so the MFMA path agrees with the f32-activation GEMV path far below bf16 resolution (the reference's
-// own CUDA path rounds activations to bf16).
-// Tile: block = 4 waves x 16 weight rows = 64 rows of W, all 64 activation rows (4 MFMA column tiles), K range =
-// [blockIdx.y * K/ksplit, ...).  A-operand = weights straight from global (lane l: row l&15, 16 B at k = (l>>4)*8,
-// non-temporal), B-operand = activation hi/lo slices double-buffered in LDS; one barrier per 64-wide K slice, the next
-// slice's global loads are issued before the current slice's MFMAs.
+// own CUDA path rounds activations to bf16).  Kernel: k_gemm3 below (A operand = weights straight from global, non-temporal;
+// B operand = fragment-major activations straight from L2; no LDS staging).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 constexpr int PF_M = 32;    // activation rows per pass

@@ -177,7 +177,6 @@ def extras(cfg, tok):
     import fishrt
     out = {}
     B, frames = 32, 64
-    lmb = fishrt.DualARTransformer(cfg, tok, 0, "bf16", max_batch=B).load_synthetic(SEED)
     rng = np.random.RandomState(77)
     prompts = []
     for L in rng.randint(64, 385, B):  # SURVEY.md §8d configs[2]: prompt lengths U{64..384}, seed 77
@@ -185,16 +184,18 @@ def extras(cfg, tok):
         p[0] = rng.randint(0, tok["im_end_id"], int(L))
         prompts.append(p)
     Lmax = max(p.shape[1] for p in prompts)
-    outs = lmb.generate_static_batch(prompts, frames + Lmax - 2, temp=0.7, top_p=0.8, top_k=256, seed=42, ignore_eos=True)
-    st = lmb.last_stats()
-    step_s = st["decode_ms"] * 1e-3 / (frames - 1)
-    bytes_step = frame_bytes(cfg, tok, 0) + B * 12288 * (Lmax + frames / 2)
-    out["static_batch32"] = {"workload": "BASELINE.json configs[2] shape: B=32, temp 0.7 / top-p 0.8 / top-k 256, prompts U{64..384}, "
-                                         f"{frames} frames (decode steps HIP-event timed; prefill excluded)",
-                             "decode_frames_per_s": round(B / step_s, 1), "step_us": round(step_s * 1e6, 1),
-                             "roofline_frac": round(bytes_step / step_s / HBM_PEAK, 4),
-                             "frames_out": int(sum(o.shape[1] for o in outs)), "prefill_ms_all_rows": round(st["prefill_ms"], 1)}
-    lmb.close()
+    for name, dtype, wb in (("static_batch32", "bf16", 2), ("static_batch32_fp8", "fp8", 1)):
+        lmb = fishrt.DualARTransformer(cfg, tok, 0, dtype, max_batch=B).load_synthetic(SEED)
+        outs = lmb.generate_static_batch(prompts, frames + Lmax - 2, temp=0.7, top_p=0.8, top_k=256, seed=42, ignore_eos=True)
+        st = lmb.last_stats()
+        step_s = st["decode_ms"] * 1e-3 / (frames - 1)
+        bytes_step = frame_bytes(cfg, tok, 0, wb) + B * 12288 * (Lmax + frames / 2)
+        out[name] = {"workload": f"BASELINE.json configs[2] shape: B=32, {dtype} weights, temp 0.7 / top-p 0.8 / top-k 256, prompts U{{64..384}}, "
+                                 f"{frames} frames (decode steps HIP-event timed; prefill excluded)",
+                     "decode_frames_per_s": round(B / step_s, 1), "step_us": round(step_s * 1e6, 1),
+                     "roofline_frac": round(bytes_step / step_s / HBM_PEAK, 4),
+                     "frames_out": int(sum(o.shape[1] for o in outs)), "prefill_ms_all_rows": round(st["prefill_ms"], 1)}
+        lmb.close()
     codec = fishrt.FireflyCodec(0).load_synthetic(0xC0DEC)
     codes = np.random.RandomState(1).randint(0, 1000, (1, 8, 256)).astype(np.uint32)
     codec.decode(codes)
@@ -223,7 +224,7 @@ def extras(cfg, tok):
             lm1.generate_blocking(tokp, 128 + tokp.shape[1] - 2, repetition_penalty=1.2, seed=1, ignore_eos=True, **kw)
         st1 = lm1.last_stats()
         out[name] = {"workload": f"configs[1] prompt, 128 frames, {dtype} weights, {kw}", "frame_us": round(st1["decode_ms"] * 1e3 / 127, 1),
-                     "decode_frames_per_s": round(127 / (st1["decode_ms"] * 1e-3), 1)}
+                     "decode_frames_per_s": round(127 / (st1["decode_ms"] * 1e-3), 1), "prefill_ms": round(st1["prefill_ms"], 2)}
         lm1.close()
     # N independent batch-1 request streams on this ONE GPU (own handle, HIP stream and host thread each; no lock-step batching):
     # the frame is a chain of dependent graph nodes whose launch gaps leave the chip idle, so independent chains interleave

@@ -835,8 +835,8 @@ class LM final : public LMBase {
         cs.nc_launch = nc_launch_;
         for (int l = 0; l < a_.n_layer; ++l) LmKernels<WT>::rows_layer(d_, B, cs, slow_[l], slow_kv(l, 0), l == 0, st_);
         LmKernels<WT>::rows_finish(d_, B, cs, norm_w_, st_);
-        LmKernels<WT>::rows_head(d_, B, cs, (const uint8_t*)out_w_ + (size_t)t_.im_end_id * a_.dim * sizeof(WT), n_audio_,
-                                 d_lrows_.as<float>(), ld_slow_, st_);
+        LmKernels<WT>::rows_head(d_, B, cs, (const uint8_t*)out_w_ + (size_t)t_.im_end_id * a_.dim * sizeof(WT),
+                                 kFp8 ? out_s_ + t_.im_end_id : nullptr, n_audio_, d_lrows_.as<float>(), ld_slow_, st_);
         SampleKernels<WT>::sample_slow_rows(d_, d_lrows_.as<float>(), ld_slow_, n_audio_, d_cfg_.as<SampleCfg>(), d_rng_.as<RngState>(), B,
                                             C + 1, state(0), cs.X, d_xfrows_.as<float>(), st_);
         for (int cbi = 0; cbi < C; ++cbi) {
@@ -853,7 +853,7 @@ class LM final : public LMBase {
                 LmKernels<WT>::rows_layer(d_, B, cf, fast_[l], kv, l == 0, st_);
             }
             LmKernels<WT>::rows_finish(d_, B, cf, fast_norm_w_, st_);
-            LmKernels<WT>::rows_head(d_, B, cf, fast_out_w_, a_.codebook_size, d_lfast_.as<float>(), a_.codebook_size, st_);
+            LmKernels<WT>::rows_head(d_, B, cf, fast_out_w_, kFp8 ? fast_out_s_ : nullptr, a_.codebook_size, d_lfast_.as<float>(), a_.codebook_size, st_);
             SampleKernels<WT>::sample_fast_rows(d_, d_lfast_.as<float>(), cbi, C, a_.codebook_size, d_cfg_.as<SampleCfg>(),
                                                 d_rng_.as<RngState>(), B, state(0), fast_emb_, d_xfrows_.as<float>(), tok_emb_, cb_emb_,
                                                 cs.X, d_out_.as<uint32_t>(), out_cap_, st_);

@@ -121,7 +121,7 @@ struct LmKernels {
     // state->step (prompt != null) or from state->cur
     static void embed(const ModelDims& d, const void* tok_emb, const void* cb_emb, int n_cb, int cb_size,
                       const SampleCfg* cfg, const uint32_t* prompt, SeqState* state, float* x, hipStream_t st);
-    // ---- chunked prefill (M <= 32 prompt tokens per pass; MFMA skinny GEMMs, bf16 weights only)
+    // ---- MFMA row path (prefill passes, static-batch steps): bf16 weights, or fp8 weights widened to bf16 in registers
     static bool has_mfma_prefill();
     // X[m] = embed(prompt column state->step + m), m < M
     static void prefill_embed(const ModelDims& d, const void* tok_emb, const void* cb_emb, int n_cb, int cb_size,
@@ -133,7 +133,8 @@ struct LmKernels {
     static void rows_layer(const ModelDims& d, int M, const RowsCtx& c, const LayerW& w, KVView kv, bool first, hipStream_t st);
     static void rows_finish(const ModelDims& d, int M, const RowsCtx& c, const float* norm_w, hipStream_t st);
     static void rows_warmup();
-    static void rows_head(const ModelDims& d, int M, const RowsCtx& c, const void* W, int n_rows, float* logits, int ld, hipStream_t st);
+    static void rows_head(const ModelDims& d, int M, const RowsCtx& c, const void* W, const float* wscale, int n_rows, float* logits, int ld,
+                          hipStream_t st);
     // fast_embeddings gather: out[i] = fast_emb[ids[i]]
     static void fast_embed(const ModelDims& d, const void* fast_emb, const uint32_t* ids, int n, float* out,
                            hipStream_t st);

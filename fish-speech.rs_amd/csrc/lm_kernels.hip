@@ -850,9 +850,25 @@ __global__ __launch_bounds__(256) void k_prep(float* __restrict__ X, int D, cons
 // The four K-quarter accumulators meet in 8 KB of LDS and are summed in a fixed order; the epilogue gives every thread
 // one (row pair, m) so RoPE pairs and SwiGLU (w1[r], w3[r]) pairs stay in one lane.  Small grids were the problem of the
 // first version of this kernel (64-row blocks: 20 blocks for Wqkv); 16-row blocks give 80 / 64 / 512 (256 with RT = 2) / 256.
-template <int EPI, int NKS, int RT>
+// FP8: the weights are e4m3fn bytes + one f32 scale per row (FS_FP8 handles): a lane's 8 bytes per k-step are widened to bf16 in
+// registers (exact: e4m3 has 3 mantissa bits) and the row scale is applied to the K-summed accumulator in the epilogue.
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x4 fp8x8_to_bf16x8(u32x2 v) {
+    u32x4 o;
+    const uint32_t w[2] = {v.x, v.y};
+    uint32_t r[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8(w[i], false), hi = __builtin_amdgcn_cvt_pk_f32_fp8(w[i], true);
+        r[2 * i] = (__float_as_uint(lo.x) >> 16) | (__float_as_uint(lo.y) & 0xFFFF0000u);
+        r[2 * i + 1] = (__float_as_uint(hi.x) >> 16) | (__float_as_uint(hi.y) & 0xFFFF0000u);
+    }
+    o.x = r[0]; o.y = r[1]; o.z = r[2]; o.w = r[3];
+    return o;
+}
+template <int EPI, int NKS, int RT, bool FP8>
 __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* __restrict__ Xf, int M, int K,
-                                               const bf16_t* __restrict__ W, int N, float* __restrict__ Y, int ldy, size_t slab_stride,
+                                               const void* __restrict__ Wv, const float* __restrict__ wscale, int N, float* __restrict__ Y, int ldy, size_t slab_stride,
                                                bf16_t* __restrict__ Of, int ldo,
                                                const float* __restrict__ cos_t, const float* __restrict__ sin_t,
                                                const SeqState* __restrict__ state, KVView kv, int H, int Hk, int Dh, RowMap rm, NormAux na) {
@@ -867,10 +883,18 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* __restrict__ Xf, in
     u32x4 wf[RT][NKS];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-        const bf16_t* wp = W + (size_t)min(n0 + rt * 16 + (lane & 15), N - 1) * K + kbeg;
+        const size_t woff = (size_t)min(n0 + rt * 16 + (lane & 15), N - 1) * K + kbeg;
+        if (FP8) {
+            const uint8_t* wp = reinterpret_cast<const uint8_t*>(Wv) + woff;
+            u32x2 raw[NKS];
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            wf[rt][ks] = ld_stream(reinterpret_cast<const u32x4*>(wp + ks * 32));
+            for (int ks = 0; ks < NKS; ++ks) raw[ks] = ld_stream(reinterpret_cast<const u32x2*>(wp + ks * 32));
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) wf[rt][ks] = fp8x8_to_bf16x8(raw[ks]);
+        } else {
+            const bf16_t* wp = reinterpret_cast<const bf16_t*>(Wv) + woff;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) wf[rt][ks] = ld_stream(reinterpret_cast<const u32x4*>(wp + ks * 32));
         }
     }
     // row panels are spread over blockIdx.z (prefill: many panels -> more blocks; the weight tile is then re-read from L2)
@@ -927,9 +951,10 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* __restrict__ Xf, in
             const int slot = sI * 256 + (int)threadIdx.x;
             const int pr = slot % (ROWS / 2), ml = slot / (ROWS / 2);
             const int r = n0 + 2 * pr, m = mp + ml;
-            const float a = (red[0][2 * pr][ml] + red[1][2 * pr][ml]) + (red[2][2 * pr][ml] + red[3][2 * pr][ml]);
-            const float b = (red[0][2 * pr + 1][ml] + red[1][2 * pr + 1][ml]) + (red[2][2 * pr + 1][ml] + red[3][2 * pr + 1][ml]);
+            float a = (red[0][2 * pr][ml] + red[1][2 * pr][ml]) + (red[2][2 * pr][ml] + red[3][2 * pr][ml]);
+            float b = (red[0][2 * pr + 1][ml] + red[1][2 * pr + 1][ml]) + (red[2][2 * pr + 1][ml] + red[3][2 * pr + 1][ml]);
             if (r >= N || m >= M) continue;
+            if (FP8) { a *= wscale[r]; b *= wscale[min(r + 1, N - 1)]; }
             if (EPI == EPI_STORE) {  // split-K slab blockIdx.y
                 float* yp = Y + (size_t)blockIdx.y * slab_stride + (size_t)m * ldy + r;
                 yp[0] = a;
@@ -2380,7 +2405,7 @@ void launch_quant_rows_fp8(uint8_t* dst, float* scales, const float* src, int64_
 
 // ---- chunked prefill launchers (bf16 weights only; f32 handles take the sequential decode-kernel path)
 template <typename WT>
-bool LmKernels<WT>::has_mfma_prefill() { return std::is_same<WT, bf16_t>::value; }
+bool LmKernels<WT>::has_mfma_prefill() { return std::is_same<WT, bf16_t>::value || std::is_same<WT, fp8_t>::value; }
 
 template <typename WT>
 void LmKernels<WT>::prefill_embed(const ModelDims& d, const void* tok_emb, const void* cb_emb, int n_cb, int cb_size,
@@ -2394,7 +2419,7 @@ void LmKernels<WT>::prefill_embed(const ModelDims& d, const void* tok_emb, const
 // Y[M, N] (+)= f(X[M, K]) . W[N, K]^T over `ksplit` K ranges (slabs Y + s * slab_stride for EPI_STORE); rt = 16-row tiles
 // per wave (2 halves the L2 re-reads of the activations for the wide W13 GEMM)
 template <int EPI>
-static void launch_gemm3(int N, int ksplit, int rt, hipStream_t st, const bf16_t* Xf, int M, int K, const bf16_t* W,
+static void launch_gemm3(int N, int ksplit, int rt, hipStream_t st, const bf16_t* Xf, int M, int K, const void* W, const float* wscale,
                          float* Y, int ldy, size_t slab_stride, bf16_t* Of, int ldo, const float* cos_t, const float* sin_t,
                          const SeqState* state, KVView kv, int H, int Hk, int Dh, RowMap rm, NormAux na = NormAux{}) {
     FS_REQUIRE(K % (ksplit * 128) == 0, "GEMM depth must be a multiple of 128 per K range");
@@ -2404,8 +2429,14 @@ static void launch_gemm3(int N, int ksplit, int rt, hipStream_t st, const bf16_t
     const int gz = std::max(1, std::min(panels, 1024 / std::max(1, nb)));
     const dim3 grid((N + 16 * rt - 1) / (16 * rt), ksplit, gz);
 #define FS_GEMM_CASE(nk, r)                                                                                                          \
-    hipLaunchKernelGGL((k_gemm3<EPI, nk, r>), grid, dim3(256), 0, st, Xf, M, K, W, N, Y, ldy, slab_stride, Of, ldo, cos_t,  \
-                       sin_t, state, kv, H, Hk, Dh, rm, na)
+    do {                                                                                                                             \
+        if (wscale)                                                                                                                  \
+            hipLaunchKernelGGL((k_gemm3<EPI, nk, r, true>), grid, dim3(256), 0, st, Xf, M, K, W, wscale, N, Y, ldy, slab_stride, Of, ldo,  \
+                               cos_t, sin_t, state, kv, H, Hk, Dh, rm, na);                                                      \
+        else                                                                                                                         \
+            hipLaunchKernelGGL((k_gemm3<EPI, nk, r, false>), grid, dim3(256), 0, st, Xf, M, K, W, wscale, N, Y, ldy, slab_stride, Of, ldo, \
+                               cos_t, sin_t, state, kv, H, Hk, Dh, rm, na);                                                      \
+    } while (0)
     if (rt == 4) {
         switch (nks) {
             case 8: FS_GEMM_CASE(8, 4); break;
@@ -2433,9 +2464,10 @@ static void launch_gemm3(int N, int ksplit, int rt, hipStream_t st, const bf16_t
 
 template <typename WT>
 void LmKernels<WT>::rows_layer(const ModelDims& d, int M, const RowsCtx& c, const LayerW& w, KVView kv, bool first, hipStream_t st) {
-    if constexpr (!std::is_same<WT, bf16_t>::value) {
-        throw Error("the MFMA row path is implemented for bf16 weights only");
+    if constexpr (std::is_same<WT, float>::value) {
+        throw Error("the MFMA row path needs bf16 or fp8 weights");
     } else {
+        using KT = KVT<WT>;  // bf16 KV cache for both weight types
         FS_REQUIRE(M >= 1 && M <= c.Mcap, "more activation rows than the row buffers hold");
         FS_REQUIRE(d.dim % 128 == 0 && d.inter % 128 == 0, "row path needs dim % 128 == 0 and intermediate_size % 128 == 0");
         const int qkv_rows = (d.H + 2 * d.Hk) * d.Dh;
@@ -2452,7 +2484,7 @@ void LmKernels<WT>::rows_layer(const ModelDims& d, int M, const RowsCtx& c, cons
         // (1) x += previous layer's down-proj slabs ; RMSNorm(attention_norm) -> hi/lo
         if (c.stage_mask & 1u) hipLaunchKernelGGL(k_prep, dim3(M), dim3(256), 0, st, c.X, d.dim, c.P, first ? 0 : DOWN_SPLIT, slab, w.attn_norm, d.eps, c.A);
         // (2) Wqkv + rope + KV scatter
-        if (c.stage_mask & 2u) launch_gemm3<EPI_QKV>(qkv_rows, 1, rt_qkv, st, c.A, M, d.dim, (const bf16_t*)w.wqkv, c.Q, d.dim, 0, nullptr, 0,
+        if (c.stage_mask & 2u) launch_gemm3<EPI_QKV>(qkv_rows, 1, rt_qkv, st, c.A, M, d.dim, w.wqkv, w.s_qkv, c.Q, d.dim, 0, nullptr, 0,
                               c.cos_t, c.sin_t, c.state, kv, d.H, d.Hk, d.Dh, rm);
         // (3) attention over each row's KV prefix + chunk combine -> hi/lo
         if (c.pos_step == 1 && c.pt_stride == 0 && (c.stage_mask & 4u) && d.Dh == 64 && M > 1 && !c.no_flash) {
@@ -2468,11 +2500,11 @@ void LmKernels<WT>::rows_layer(const ModelDims& d, int M, const RowsCtx& c, cons
         const dim3 ga(d.Hk * c.nc_launch, M);
             if (!(c.stage_mask & 4u)) {}
             else if (d.Dh == 64 && d.n_rep == 8)
-                hipLaunchKernelGGL((k_attn_decode<WT, 64, 8>), ga, dim3(AttnGeom<WT, 64>::NW * 64), 0, st, c.Q, kv, c.state, c.part, d.Hk, c.n_chunks_max, c.nc_launch, c.pos_step, c.pt_stride);
+                hipLaunchKernelGGL((k_attn_decode<KT, 64, 8>), ga, dim3(AttnGeom<KT, 64>::NW * 64), 0, st, c.Q, kv, c.state, c.part, d.Hk, c.n_chunks_max, c.nc_launch, c.pos_step, c.pt_stride);
             else if (d.Dh == 32 && d.n_rep == 2)
-                hipLaunchKernelGGL((k_attn_decode<WT, 32, 2>), ga, dim3(AttnGeom<WT, 32>::NW * 64), 0, st, c.Q, kv, c.state, c.part, d.Hk, c.n_chunks_max, c.nc_launch, c.pos_step, c.pt_stride);
+                hipLaunchKernelGGL((k_attn_decode<KT, 32, 2>), ga, dim3(AttnGeom<KT, 32>::NW * 64), 0, st, c.Q, kv, c.state, c.part, d.Hk, c.n_chunks_max, c.nc_launch, c.pos_step, c.pt_stride);
             else if (d.Dh == 64 && d.n_rep == 2)
-                hipLaunchKernelGGL((k_attn_decode<WT, 64, 2>), ga, dim3(AttnGeom<WT, 64>::NW * 64), 0, st, c.Q, kv, c.state, c.part, d.Hk, c.n_chunks_max, c.nc_launch, c.pos_step, c.pt_stride);
+                hipLaunchKernelGGL((k_attn_decode<KT, 64, 2>), ga, dim3(AttnGeom<KT, 64>::NW * 64), 0, st, c.Q, kv, c.state, c.part, d.Hk, c.n_chunks_max, c.nc_launch, c.pos_step, c.pt_stride);
             else
                 throw Error("unsupported attention geometry");
             if (!(c.stage_mask & 8u)) {}
@@ -2486,20 +2518,20 @@ void LmKernels<WT>::rows_layer(const ModelDims& d, int M, const RowsCtx& c, cons
         NormAux na{w.ffn_norm, c.ss, c.A2, nblk_o, d.dim, d.eps};
         if (!(c.stage_mask & 16u)) {}
         else if (fuse_norm)
-            launch_gemm3<EPI_RESIDUAL_NORM>(d.dim, 1, rt_o, st, c.A, M, d.dim, (const bf16_t*)w.wo, c.X, d.dim, 0, nullptr, 0, nullptr, nullptr,
+            launch_gemm3<EPI_RESIDUAL_NORM>(d.dim, 1, rt_o, st, c.A, M, d.dim, w.wo, w.s_o, c.X, d.dim, 0, nullptr, 0, nullptr, nullptr,
                                             nullptr, nokv, 0, 0, 0, none, na);
-        else launch_gemm3<EPI_RESIDUAL>(d.dim, 1, rt_o, st, c.A, M, d.dim, (const bf16_t*)w.wo, c.X, d.dim, 0, nullptr, 0,
+        else launch_gemm3<EPI_RESIDUAL>(d.dim, 1, rt_o, st, c.A, M, d.dim, w.wo, w.s_o, c.X, d.dim, 0, nullptr, 0,
                                    nullptr, nullptr, nullptr, nokv, 0, 0, 0, none);
         // (5) RMSNorm(ffn_norm) -> hi/lo ; W1||W3 + SwiGLU -> act hi/lo ; W2 split-K slabs (summed by the next k_prep)
         if (fuse_norm) {
-            if (c.stage_mask & 64u) launch_gemm3<EPI_SWIGLU_RMS>(2 * d.inter, 1, rt_13, st, c.A2, M, d.dim, (const bf16_t*)w.w13, nullptr, 0, 0, c.C, d.inter,
+            if (c.stage_mask & 64u) launch_gemm3<EPI_SWIGLU_RMS>(2 * d.inter, 1, rt_13, st, c.A2, M, d.dim, w.w13, w.s_13, nullptr, 0, 0, c.C, d.inter,
                                      nullptr, nullptr, nullptr, nokv, 0, 0, 0, none, na);
         } else {
             if (c.stage_mask & 32u) hipLaunchKernelGGL(k_prep, dim3(M), dim3(256), 0, st, c.X, d.dim, (const float*)nullptr, 0, slab, w.ffn_norm, d.eps, c.A);
-            if (c.stage_mask & 64u) launch_gemm3<EPI_SWIGLU>(2 * d.inter, 1, rt_13, st, c.A, M, d.dim, (const bf16_t*)w.w13, nullptr, 0, 0, c.C, d.inter,
+            if (c.stage_mask & 64u) launch_gemm3<EPI_SWIGLU>(2 * d.inter, 1, rt_13, st, c.A, M, d.dim, w.w13, w.s_13, nullptr, 0, 0, c.C, d.inter,
                                      nullptr, nullptr, nullptr, nokv, 0, 0, 0, none);
         }
-        if (c.stage_mask & 128u) launch_gemm3<EPI_STORE>(d.dim, DOWN_SPLIT, rt_2, st, c.C, M, d.inter, (const bf16_t*)w.w2, c.P, d.dim, slab, nullptr, 0, nullptr, nullptr,
+        if (c.stage_mask & 128u) launch_gemm3<EPI_STORE>(d.dim, DOWN_SPLIT, rt_2, st, c.C, M, d.inter, w.w2, w.s_2, c.P, d.dim, slab, nullptr, 0, nullptr, nullptr,
                                 nullptr, nokv, 0, 0, 0, none);
         FS_LAUNCH_CHECK();
     }
@@ -2519,14 +2551,15 @@ void LmKernels<WT>::rows_finish(const ModelDims& d, int M, const RowsCtx& c, con
 
 // head GEMM of the MFMA row path: logits[m][0..n_rows) = W[n_rows, dim] . (hi + lo)[m]  (input = rows_finish(norm_w) output)
 template <typename WT>
-void LmKernels<WT>::rows_head(const ModelDims& d, int M, const RowsCtx& c, const void* W, int n_rows, float* logits, int ld, hipStream_t st) {
-    if constexpr (!std::is_same<WT, bf16_t>::value) {
-        throw Error("the MFMA row path is implemented for bf16 weights only");
+void LmKernels<WT>::rows_head(const ModelDims& d, int M, const RowsCtx& c, const void* W, const float* wscale, int n_rows, float* logits, int ld,
+                              hipStream_t st) {
+    if constexpr (std::is_same<WT, float>::value) {
+        throw Error("the MFMA row path needs bf16 or fp8 weights");
     } else {
         FS_REQUIRE(ld >= n_rows, "logits row stride must cover n_rows");
         KVView nokv = {};
         // EPI_STORE with one K range writes slab 0 == the logits matrix itself (row stride ld)
-        launch_gemm3<EPI_STORE>(n_rows, 1, 1, st, c.A, M, d.dim, (const bf16_t*)W, logits, ld, 0, nullptr, 0, nullptr, nullptr, nullptr, nokv, 0, 0,
+        launch_gemm3<EPI_STORE>(n_rows, 1, 1, st, c.A, M, d.dim, W, wscale, logits, ld, 0, nullptr, 0, nullptr, nullptr, nullptr, nokv, 0, 0,
                                 0, RowMap{0, 0});
         FS_LAUNCH_CHECK();
     }

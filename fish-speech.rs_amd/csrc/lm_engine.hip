@@ -67,8 +67,10 @@ void seed_key(uint64_t state, uint32_t* key) {
 }
 
 
-constexpr int kRows = 32;      // static-batch generator: sequences per step (== one 32-row MFMA panel)
-constexpr int kRowsCap = 512;  // row capacity of the MFMA row buffers: prompt tokens per prefill pass
+constexpr int kRows = 256;     // static-batch generator: max sequences per step (32-row MFMA panels; <= kPartRows)
+constexpr int kRowsCap = 2048; // row capacity of the MFMA row buffers: prompt tokens per prefill pass (one sequence, or a group of
+                               // left-padded static-batch prompts)
+constexpr int kPartRows = 512; // rows of the chunked-attention partials buffer (static-batch steps; prefill passes when head_dim != 64)
 
 }  // namespace
 
@@ -433,24 +435,51 @@ class LM final : public LMBase {
         stats_ = {};
         FS_HIP(hipEventRecord(ev_[0], st_));
         // left-pad with <|im_end|>/0 (static_batch.rs:68-111; the pad mask is built but never applied, dual_ar.rs:589-615)
-        std::vector<uint32_t> padded((size_t)C1 * Lmax);
+        const size_t pstride = (size_t)C1 * Lmax;
+        std::vector<uint32_t> padded(pstride * B);
         size_t off = 0;
         for (int b = 0; b < B; ++b) {
             const int L = lens[b], pad = Lmax - L;
+            uint32_t* pp = padded.data() + pstride * b;
             for (int r = 0; r < C1; ++r) {
-                for (int j = 0; j < pad; ++j) padded[(size_t)r * Lmax + j] = r == 0 ? t_.im_end_id : 0u;
-                std::memcpy(&padded[(size_t)r * Lmax + pad], prompts + off + (size_t)r * L, sizeof(uint32_t) * L);
+                for (int j = 0; j < pad; ++j) pp[(size_t)r * Lmax + j] = r == 0 ? t_.im_end_id : 0u;
+                std::memcpy(&pp[(size_t)r * Lmax + pad], prompts + off + (size_t)r * L, sizeof(uint32_t) * L);
             }
             off += (size_t)C1 * L;
-            validate_tokens(padded.data(), padded.size(), 1, Lmax);
+            validate_tokens(pp, pstride, 1, Lmax);
             ensure_capacity(b, Lmax + (int)n_iter - 1);
-            FS_HIP(hipMemcpyAsync(d_prompt_.p, padded.data(), sizeof(uint32_t) * padded.size(), hipMemcpyHostToDevice, st_));
+        }
+        const int Lp = Lmax - 1;  // prompt tokens run through the slow transformer before the first frame
+        const bool no_group = std::getenv("FISHRT_NO_GROUP_PREFILL") != nullptr;  // test hook: one sequence per pass
+        if (Lp >= 1 && Lp <= kRowsCap && a_.head_dim == 64 && !no_group) {
+            // group prefill: every prompt has Lmax columns and starts at position 0, so the first Lmax - 1 tokens of as many
+            // sequences as fit the row buffers go through ONE pass (GEMM rows = sequences x tokens, flash attention per sequence)
+            if (d_bprompt_.n < sizeof(uint32_t) * padded.size()) d_bprompt_.alloc(sizeof(uint32_t) * padded.size());
+            FS_HIP(hipMemcpyAsync(d_bprompt_.p, padded.data(), sizeof(uint32_t) * padded.size(), hipMemcpyHostToDevice, st_));
             SeqState ss = {};
             ss.prompt_L = Lmax;
-            FS_HIP(hipMemcpyAsync(state(b), &ss, sizeof(ss), hipMemcpyHostToDevice, st_));
-            prefill_tokens(b, Lmax - 1, /*use_graph=*/false);
-            FS_HIP(hipStreamSynchronize(st_));  // `padded` / d_prompt_ are reused by the next row
-            seq_len_[b] = Lmax - 1;
+            FS_HIP(hipMemcpyAsync(state(0), &ss, sizeof(ss), hipMemcpyHostToDevice, st_));
+            const int per_pass = std::max(1, kRowsCap / Lp);
+            for (int b0 = 0; b0 < B; b0 += per_pass) {
+                const int S = std::min(per_pass, B - b0), M = S * Lp;
+                RowsCtx c = rows_ctx(state(0), /*pos_step=*/1, /*pt_stride=*/max_pages_);
+                c.seq_rows = Lp;
+                LmKernels<WT>::prefill_embed(d_, tok_emb_, cb_emb_, C, a_.codebook_size, d_cfg_.as<SampleCfg>(),
+                                             d_bprompt_.as<uint32_t>() + pstride * b0, state(0), M, d_pfx_.as<float>(), st_, Lp, pstride);
+                for (int l = 0; l < a_.n_layer; ++l) LmKernels<WT>::rows_layer(d_, M, c, slow_[l], slow_kv(l, b0), l == 0, st_);
+            }
+            FS_HIP(hipStreamSynchronize(st_));
+            for (int b = 0; b < B; ++b) seq_len_[b] = Lp;
+        } else {
+            for (int b = 0; b < B; ++b) {
+                FS_HIP(hipMemcpyAsync(d_prompt_.p, padded.data() + pstride * b, sizeof(uint32_t) * pstride, hipMemcpyHostToDevice, st_));
+                SeqState ss = {};
+                ss.prompt_L = Lmax;
+                FS_HIP(hipMemcpyAsync(state(b), &ss, sizeof(ss), hipMemcpyHostToDevice, st_));
+                prefill_tokens(b, Lp, /*use_graph=*/false);
+                FS_HIP(hipStreamSynchronize(st_));  // d_prompt_ is reused by the next row
+                seq_len_[b] = Lp;
+            }
         }
         // first-frame inputs: the rows of d_pfx_ are scratch during prefill, so the last prompt column of every row is
         // embedded only now (through the state's `cur` slots)
@@ -771,7 +800,7 @@ class LM final : public LMBase {
             ensure_prefill_buffers();
             RowsCtx c = rows_ctx(state(b), /*pos_step=*/1, /*pt_stride=*/0);
             for (int done = 0; done < n;) {
-                const int M = std::min(kRowsCap, n - done);
+                const int M = std::min(a_.head_dim == 64 ? kRowsCap : kPartRows, n - done);
                 c.nc_launch = chunk_bucket(seq_len_[b] + done + M);
                 LmKernels<WT>::prefill_embed(d_, tok_emb_, cb_emb_, a_.num_codebooks, a_.codebook_size, d_cfg_.as<SampleCfg>(),
                                              d_prompt_.as<uint32_t>(), state(b), M, d_pfx_.as<float>(), st_);
@@ -807,7 +836,7 @@ class LM final : public LMBase {
         FS_HIP(hipMemsetAsync(d_pfa2_.p, 0, d_pfa2_.n, st_));
         FS_HIP(hipMemsetAsync(d_pfss_.p, 0, d_pfss_.n, st_));
         d_pfc_.alloc(sizeof(uint16_t) * 2 * kRowsCap * a_.intermediate_size);
-        d_pfpart_.alloc(sizeof(float) * kRowsCap * (size_t)a_.n_head * n_chunks_ * (a_.head_dim + 2));
+        d_pfpart_.alloc(sizeof(float) * kPartRows * (size_t)a_.n_head * n_chunks_ * (a_.head_dim + 2));
         FS_HIP(hipMemsetAsync(d_pfx_.p, 0, d_pfx_.n, st_));
         FS_HIP(hipMemsetAsync(d_pfpart_.p, 0, d_pfpart_.n, st_));
         FS_HIP(hipMemsetAsync(d_pfa_.p, 0, d_pfa_.n, st_));
@@ -881,7 +910,7 @@ class LM final : public LMBase {
     RowsCtx rows_ctx(const SeqState* st, int pos_step, int pt_stride) {
         RowsCtx c;
         c.X = d_pfx_.as<float>(); c.Q = d_pfq_.as<float>(); c.part = d_pfpart_.as<float>(); c.P = d_pfslab_.as<float>();
-        c.Mcap = kRowsCap; c.down_split = down_split_;
+        c.Mcap = kRowsCap; c.part_rows = kPartRows; c.down_split = down_split_;
         c.A = d_pfa_.as<uint16_t>(); c.C = d_pfc_.as<uint16_t>();
         c.A2 = d_pfa2_.as<uint16_t>(); c.ss = d_pfss_.as<float>();
         c.cos_t = d_cos_.as<float>(); c.sin_t = d_sin_.as<float>();
@@ -993,6 +1022,7 @@ class LM final : public LMBase {
     DevBuf d_x_, d_xf_, d_q_, d_part_, d_act_, d_logits_slow_, d_logits_fast_, d_state_, d_cfg_, d_rng_, d_prompt_, d_out_;
     DevBuf d_rp_mask_, d_rp_seen_, d_rp_ring_, d_rp_meta_;
     DevBuf d_pfx_, d_pfq_, d_pfslab_, d_pfa_, d_pfa2_, d_pfss_, d_pfc_, d_pfpart_;  // MFMA row-path activations (kRowsCap rows)
+    DevBuf d_bprompt_;  // static batch: all left-padded prompts [B][C + 1][Lmax] (group prefill)
     DevBuf d_xfrows_, d_lrows_, d_lfast_, d_fast_state_, d_fast_table_;  // static-batch generator
     int ld_slow_ = 0, down_split_ = 4;
     bool batch_warm_ = false;

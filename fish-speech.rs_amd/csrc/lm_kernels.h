@@ -72,11 +72,12 @@ struct SampleCfg;
 // Buffers + row mapping of the MFMA row path (prefill / batched decode).  All activation buffers hold Mcap rows (a multiple
 // of 32: the GEMMs read whole 32-row panels, so rows >= M must exist and hold finite values).
 struct RowsCtx {
-    int Mcap;            // row capacity of every buffer below
+    int Mcap;            // row capacity of every buffer below (except `part`)
+    int part_rows;       // row capacity of `part` (chunked attention: static-batch steps, head_dim != 64 prefill passes)
     int down_split;      // K ranges (== slabs) of the down projection: inter / down_split must be 1024, 256 or 128
     float* X;            // [Mcap][dim]   residual stream (f32)
     float* Q;            // [Mcap][dim]   rope'd queries (f32)
-    float* part;         // [Mcap][H][n_chunks_max][Dh + 2] attention partials
+    float* part;         // [part_rows][H][n_chunks_max][Dh + 2] attention partials
     float* P;            // [down_split][Mcap][dim] down-projection split-K slabs
     uint16_t* A;         // [Mcap][dim]   bf16 hi+lo GEMM input (normed x / attention output), fragment-major (lm_kernels.hip frag_off)
     uint16_t* C;         // [Mcap][inter] bf16 hi+lo SwiGLU activations, fragment-major
@@ -87,7 +88,8 @@ struct RowsCtx {
     int n_chunks_max;    // stride of `part`
     int nc_launch;       // attention chunks launched (covers the longest row of this pass)
     int pos_step;        // 1: rows = consecutive tokens of one sequence (prefill); 0: rows = sequences (batched decode)
-    int pt_stride;       // page-table stride between rows (0 for prefill)
+    int pt_stride;       // page-table stride between rows (0 for prefill) / between sequences (group prefill)
+    int seq_rows = 0;    // > 0: group prefill -- rows = seq_rows consecutive tokens of each of M / seq_rows sequences, all starting at state->pos
     bool no_flash = false;       // micro-benchmark / test hook: keep the chunked row attention for prefill passes
     bool small_attn = false;     // every row attends over <= 8 tokens of ONE page (fast decoder): fused attention node
     unsigned stage_mask = 0xFFu;  // micro-benchmark hook: bit i enables stage i of rows_layer (prep, qkv, attn, combine, wo, prep, w13, w2)
@@ -126,7 +128,7 @@ struct LmKernels {
     // X[m] = embed(prompt column state->step + m), m < M
     static void prefill_embed(const ModelDims& d, const void* tok_emb, const void* cb_emb, int n_cb, int cb_size,
                               const SampleCfg* cfg, const uint32_t* prompt, const SeqState* state, int M, float* X,
-                              hipStream_t st);
+                              hipStream_t st, int seq_rows = 0, size_t prompt_stride = 0);
     // one transformer block over M <= Mcap activation rows (X updated in place up to the down-projection, whose split-K
     // slabs are folded in by the NEXT rows_layer / rows_finish):
     //   x += slabs | rmsnorm+Wqkv+rope+KV append | attention over the paged cache | Wo + residual | rmsnorm+W13+SwiGLU | W2 slabs

@@ -783,6 +783,7 @@ struct NormAux {
 struct RowMap {       // how activation row m maps onto sequences / positions
     int pos_step;     // prefill: 1 (row m = token at pos + m of ONE sequence); batched decode: 0 (every row at pos)
     int pt_stride;    // prefill: 0 (one page table); batched decode: page-table stride between sequences
+    int seq_rows;     // > 0: group prefill -- row m = token (m % seq_rows) of sequence (m / seq_rows), page tables pt_stride apart
 };
 
 __device__ __forceinline__ void split_bf16(float a, bf16_t& hi, bf16_t& lo) {
@@ -990,8 +991,9 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* __restrict__ Xf, in
                 Of[frag_off(m, r / 2, 0, ldo)] = h;
                 Of[frag_off(m, r / 2, 1, ldo)] = l;
             } else {  // EPI_QKV: rope_i + scatter (q -> Y[m][r], k/v -> paged cache of row m's sequence)
-                const int pos = pos0 + m * rm.pos_step, rpos = pos + rope_off;
-                const int* ptab = kv.page_table + (size_t)m * rm.pt_stride;
+                const int sq = rm.seq_rows > 0 ? m / rm.seq_rows : m;  // sequence of row m / its token index within the pass
+                const int pos = pos0 + (rm.seq_rows > 0 ? m - sq * rm.seq_rows : m * rm.pos_step), rpos = pos + rope_off;
+                const int* ptab = kv.page_table + (size_t)sq * rm.pt_stride;
                 const int qdim = H * Dh, kdim = Hk * Dh, half = Dh / 2;
                 if (r < qdim + kdim) {
                     const int j = (r % Dh) / 2;
@@ -1117,8 +1119,9 @@ __global__ __launch_bounds__(256) void k_attn_small_rows(const float* __restrict
 //                                                      wave's private LDS copy of the tile (token-major -> 4 strided bf16)
 // The softmax scale 2^-3 is folded into q (exact).  Rows >= M and tokens past a row's position are masked.
 typedef short short4v __attribute__((ext_vector_type(4)));
+// blockIdx.y = sequence of a group pass (rows [y * M, (y + 1) * M), page table y * pt_stride further on); one sequence: gridDim.y = 1.
 __global__ __launch_bounds__(256) void k_attn_prefill_mfma(const float* __restrict__ q_all, KVView kv, const SeqState* __restrict__ state,
-                                                           int M, int H, int Hk, bf16_t* __restrict__ Ohi) {
+                                                           int M, int H, int Hk, bf16_t* __restrict__ Ohi, int pt_stride) {
     constexpr int DH = 64, VLD = DH + 8;
     __shared__ __attribute__((aligned(16))) bf16_t vt[4][KV_PAGE * VLD];
     __shared__ __attribute__((aligned(16))) float sm_o[4][16][DH + 4];
@@ -1126,13 +1129,15 @@ __global__ __launch_bounds__(256) void k_attn_prefill_mfma(const float* __restri
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = blockIdx.x % H, rt = blockIdx.x / H;  // query head, row tile
     const int g = h / (H / Hk);
-    const int row0 = rt * 16, pos0 = state->pos;        // row m sits at position pos0 + m
+    const int row0 = rt * 16, pos0 = state->pos;        // row m of this sequence sits at position pos0 + m
+    const int mbase = (int)blockIdx.y * M;              // first activation row of this sequence
+    const int* ptab = kv.page_table + (size_t)blockIdx.y * pt_stride;
     const int c16 = lane & 15, q4 = lane >> 4;
     // B operand of QK^T: q[row0 + c16][h][ks*32 + q4*8 ..+8], scaled, split hi/lo
     bf16x8 qh[2], ql[2];
     {
         const int m = min(row0 + c16, M - 1);
-        const float* qp = q_all + ((size_t)m * H + h) * DH + q4 * 8;
+        const float* qp = q_all + ((size_t)(mbase + m) * H + h) * DH + q4 * 8;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const float4 a = *reinterpret_cast<const float4*>(qp + ks * 32), b = *reinterpret_cast<const float4*>(qp + ks * 32 + 4);
@@ -1155,7 +1160,7 @@ __global__ __launch_bounds__(256) void k_attn_prefill_mfma(const float* __restri
     const bf16_t* vpool = reinterpret_cast<const bf16_t*>(kv.v);
     // S^T of the 4 token tiles of page `grp`: all 8 K loads (A operands, straight from the cache) are in flight together
     auto scores = [&](int grp, f32x4v (&sacc)[4]) {
-        const int page = kv.page_table[grp];
+        const int page = ptab[grp];
         const bf16_t* kp = kpool + ((size_t)(page * Hk + g) * KV_PAGE + c16) * DH + q4 * 8;
         u32x4 k0[4], k1[4];
 #pragma unroll
@@ -1195,7 +1200,7 @@ __global__ __launch_bounds__(256) void k_attn_prefill_mfma(const float* __restri
     bf16_t* myv = vt[wave];
     for (int grp = wave; grp < n_groups; grp += 4) {
         {   // stage the page's V (64 tokens x 64 dims) token-major into the wave's private LDS region: 8 x 16-B loads per lane
-            const int page = kv.page_table[grp];
+            const int page = ptab[grp];
             const bf16_t* vp = vpool + (size_t)(page * Hk + g) * KV_PAGE * DH;
             u32x4 vr[8];
 #pragma unroll
@@ -1265,8 +1270,8 @@ __global__ __launch_bounds__(256) void k_attn_prefill_mfma(const float* __restri
             phv.x = hi[0] | ((uint32_t)hi[1] << 16); phv.y = hi[2] | ((uint32_t)hi[3] << 16);
             plv.x = lo[0] | ((uint32_t)lo[1] << 16); plv.y = lo[2] | ((uint32_t)lo[3] << 16);
             const int e = h * DH + d4;
-            *reinterpret_cast<uint2*>(Ohi + frag_off(m, e, 0, H * DH)) = phv;
-            *reinterpret_cast<uint2*>(Ohi + frag_off(m, e, 1, H * DH)) = plv;
+            *reinterpret_cast<uint2*>(Ohi + frag_off(mbase + m, e, 0, H * DH)) = phv;
+            *reinterpret_cast<uint2*>(Ohi + frag_off(mbase + m, e, 1, H * DH)) = plv;
         }
     }
 }
@@ -1274,9 +1279,11 @@ __global__ __launch_bounds__(256) void k_attn_prefill_mfma(const float* __restri
 template <typename WT>
 __global__ void k_embed_rows(const WT* __restrict__ tok_emb, const WT* __restrict__ cb_emb, int dim, int n_cb, int cb_size,
                              const SampleCfg* __restrict__ cfg, const uint32_t* __restrict__ prompt,
-                             const SeqState* __restrict__ state, float* __restrict__ X) {
-    embed_tokens<WT>(tok_emb, cb_emb, dim, n_cb, cb_size, cfg->sem_lo, cfg->sem_hi, prompt + state->step + blockIdx.x,
-                     state->prompt_L, X + (size_t)blockIdx.x * dim, threadIdx.x, blockDim.x);
+                             const SeqState* __restrict__ state, float* __restrict__ X, int seq_rows, size_t prompt_stride) {
+    // seq_rows > 0: group pass -- row m = prompt column step + (m % seq_rows) of the (m / seq_rows)-th staged prompt
+    const int m = blockIdx.x, sq = seq_rows > 0 ? m / seq_rows : 0, j = seq_rows > 0 ? m - sq * seq_rows : m;
+    embed_tokens<WT>(tok_emb, cb_emb, dim, n_cb, cb_size, cfg->sem_lo, cfg->sem_hi, prompt + (size_t)sq * prompt_stride + state->step + j,
+                     state->prompt_L, X + (size_t)m * dim, threadIdx.x, blockDim.x);
 }
 
 __global__ void k_advance_n(SeqState* state, int n) {
@@ -2410,9 +2417,9 @@ bool LmKernels<WT>::has_mfma_prefill() { return std::is_same<WT, bf16_t>::value 
 template <typename WT>
 void LmKernels<WT>::prefill_embed(const ModelDims& d, const void* tok_emb, const void* cb_emb, int n_cb, int cb_size,
                                   const SampleCfg* cfg, const uint32_t* prompt, const SeqState* state, int M, float* X,
-                                  hipStream_t st) {
+                                  hipStream_t st, int seq_rows, size_t prompt_stride) {
     hipLaunchKernelGGL((k_embed_rows<KVT<WT>>), dim3(M), dim3(256), 0, st, (const KVT<WT>*)tok_emb, (const KVT<WT>*)cb_emb, d.dim, n_cb, cb_size,
-                       cfg, prompt, state, X);
+                       cfg, prompt, state, X, seq_rows, prompt_stride);
     FS_LAUNCH_CHECK();
 }
 
@@ -2476,8 +2483,8 @@ void LmKernels<WT>::rows_layer(const ModelDims& d, int M, const RowsCtx& c, cons
         // occupancy costs more than the saved fragment traffic.
         const int rt_qkv = 1, rt_o = 1, rt_13 = 2, rt_2 = 1;
         const int nblk_o = d.dim / (16 * rt_o);
-        const RowMap rm{c.pos_step, c.pt_stride};
-        const RowMap none{0, 0};
+        const RowMap rm{c.pos_step, c.pt_stride, c.seq_rows};
+        const RowMap none{0, 0, 0};
         KVView nokv = {};
         const size_t slab = (size_t)c.Mcap * d.dim;
         const int DOWN_SPLIT = c.down_split;
@@ -2487,9 +2494,15 @@ void LmKernels<WT>::rows_layer(const ModelDims& d, int M, const RowsCtx& c, cons
         if (c.stage_mask & 2u) launch_gemm3<EPI_QKV>(qkv_rows, 1, rt_qkv, st, c.A, M, d.dim, w.wqkv, w.s_qkv, c.Q, d.dim, 0, nullptr, 0,
                               c.cos_t, c.sin_t, c.state, kv, d.H, d.Hk, d.Dh, rm);
         // (3) attention over each row's KV prefix + chunk combine -> hi/lo
-        if (c.pos_step == 1 && c.pt_stride == 0 && (c.stage_mask & 4u) && d.Dh == 64 && M > 1 && !c.no_flash) {
+        if (c.seq_rows > 0) {
+            // group prefill: M = n_seq * seq_rows rows, every sequence starts at state->pos; flash attention per sequence
+            FS_REQUIRE(d.Dh == 64 && M % c.seq_rows == 0 && !c.no_flash, "group prefill needs head_dim 64 and whole sequences");
+            if (c.stage_mask & 4u)
+                hipLaunchKernelGGL(k_attn_prefill_mfma, dim3(d.H * ((c.seq_rows + 15) / 16), M / c.seq_rows), dim3(256), 0, st, c.Q, kv, c.state,
+                                   c.seq_rows, d.H, d.Hk, c.A, c.pt_stride);
+        } else if (c.pos_step == 1 && c.pt_stride == 0 && (c.stage_mask & 4u) && d.Dh == 64 && M > 1 && !c.no_flash) {
             // prefill: causal flash attention on the matrix cores, result straight into the Wo GEMM's input
-            hipLaunchKernelGGL(k_attn_prefill_mfma, dim3(d.H * ((M + 15) / 16)), dim3(256), 0, st, c.Q, kv, c.state, M, d.H, d.Hk, c.A);
+            hipLaunchKernelGGL(k_attn_prefill_mfma, dim3(d.H * ((M + 15) / 16)), dim3(256), 0, st, c.Q, kv, c.state, M, d.H, d.Hk, c.A, 0);
         } else if (c.small_attn && (c.stage_mask & 4u) && d.H <= 32 && (d.Dh == 64 || d.Dh == 32)) {
             // fast decoder: <= 8 tokens in one page -> one node instead of two
             if (d.Dh == 64)
@@ -2497,6 +2510,7 @@ void LmKernels<WT>::rows_layer(const ModelDims& d, int M, const RowsCtx& c, cons
             else
                 hipLaunchKernelGGL((k_attn_small_rows<32>), dim3(M), dim3(256), 0, st, c.Q, kv, c.state, d.H, d.Hk, c.pos_step, c.pt_stride, c.A);
         } else {
+        FS_REQUIRE(M <= c.part_rows, "more rows than the attention-partials buffer holds");
         const dim3 ga(d.Hk * c.nc_launch, M);
             if (!(c.stage_mask & 4u)) {}
             else if (d.Dh == 64 && d.n_rep == 8)

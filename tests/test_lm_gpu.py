@@ -277,3 +277,80 @@ def test_fish14_legacy_slow_sampler_vs_oracle():
     got = lm.generate_blocking(p, 40, temp=0.0, top_p=1.0, top_k=0, repetition_penalty=1.0, seed=3, ignore_eos=True)
     assert got.shape == (8, 40 - 9 + 2)
     assert np.array_equal(got, o.generate(p, 40, temp=0.0, repetition_penalty=1.0, seed=3, ignore_eos=True))
+
+
+def test_static_batch_more_rows_than_one_mfma_panel():
+    """B = 40 > 32 rows: the static-batch GEMMs loop over two 32-row panels; every row must still equal the oracle's
+    static_batch restatement (greedy; same-rounding bf16 weights and KV)."""
+    lm = _tiny("bf16", 40)
+    o = orc.OracleLM(orc.TINY).load_synthetic(SEED, bf16=True)
+    o.set_kv_round_bf16(True)
+    lens = [3 + (7 * i) % 11 for i in range(40)]
+    prompts = _batch_prompts(40, lens)
+    M = 30
+    got = lm.generate_static_batch(prompts, M, seed=42, temp=0.0, top_p=1.0, top_k=0, ignore_eos=True)
+    exp = o.generate_batch(prompts, M, seed=42, temp=0.0, top_p=1.0, top_k=0, ignore_eos=True)
+    assert [g.shape for g in got] == [e.shape for e in exp]
+    agree = [int(np.argmin((g == e).all(0))) if not (g == e).all() else g.shape[1] for g, e in zip(got, exp)]
+    print("B=40 identical frame prefix per row: min", min(agree), "of", got[0].shape[1])
+    assert min(agree) >= 8, agree
+    # sampled: per-row child RNG streams are indexed by (call, row) with B = 40
+    got = lm.generate_static_batch(prompts, M, seed=42, temp=0.7, top_p=0.8, top_k=32, ignore_eos=True)
+    exp = o.generate_batch(prompts, M, seed=42, temp=0.7, top_p=0.8, top_k=32, ignore_eos=True)
+    agree = [int(np.argmin((g == e).all(0))) if not (g == e).all() else g.shape[1] for g, e in zip(got, exp)]
+    assert min(agree) >= 4 and np.mean(agree) >= 8, agree
+    lm.close()
+
+
+# head_dim 64 at a small width: the configuration that takes the causal flash-attention prefill kernel and the group prefill of
+# static batches (the TINY config has head_dim 32 and keeps the chunked row attention)
+MID = dict(fcfg.TINY, dim=256, n_head=4, n_local_heads=2, head_dim=64, intermediate_size=1024)
+
+
+def _mid(dtype, max_batch=1):
+    return fishrt.DualARTransformer(MID, fcfg.TINY_TOKENS, 0, dtype, max_batch).load_synthetic(SEED)
+
+
+def _omid():
+    o = orc.OracleLM(dict(orc.TINY, dim=256, n_head=4, n_local_heads=2, head_dim=64, intermediate_size=1024)).load_synthetic(SEED, bf16=True)
+    o.set_kv_round_bf16(True)
+    return o
+
+
+def test_mid_flash_prefill_vs_oracle():
+    """forward_generate over 45 prompt tokens (one MFMA pass + causal flash attention, then a cached-prefix continuation of 20
+    more) against the oracle on the same bf16-rounded weights / KV."""
+    lm, o = _mid("bf16"), _omid()
+    p = _batch_prompts(3, [65])[0]
+    lg, hg = lm.forward_generate(np.ascontiguousarray(p[:, :45]), 0)
+    lo, ho = o.forward_generate(np.ascontiguousarray(p[:, :45]), 0)
+    np.testing.assert_allclose(hg, ho, **TOLBF)
+    np.testing.assert_allclose(lg, lo, **TOLBF)
+    lg, hg = lm.forward_generate(np.ascontiguousarray(p[:, 45:]), 45)
+    lo, ho = o.forward_generate(np.ascontiguousarray(p[:, 45:]), 45)
+    np.testing.assert_allclose(hg, ho, **TOLBF)
+    np.testing.assert_allclose(lg, lo, **TOLBF)
+    assert lm.curr_kv_size() == 65
+    lm.close()
+
+
+@pytest.mark.parametrize("B,span", [(5, 17), (37, 67)])  # (37, 67): 37 x 68 prompt rows > 2048 -> two group passes
+def test_mid_static_batch_group_prefill_vs_oracle(B, span, monkeypatch):
+    """Static batch whose prompts are prefilled as ONE group pass (rows = sequences x tokens) -- against the oracle, and
+    bit-identical to the one-sequence-per-pass prefill (row results do not depend on where a row sits in a pass)."""
+    lm, o = _mid("bf16", B), _omid()
+    lens = [3 + (5 * i) % span for i in range(B)]
+    prompts = _batch_prompts(11, lens)
+    M = max(lens) + 14
+    kw = dict(seed=42, temp=0.0, top_p=1.0, top_k=0, ignore_eos=True)
+    got = lm.generate_static_batch(prompts, M, **kw)
+    exp = o.generate_batch(prompts, M, **kw)
+    assert [g.shape for g in got] == [e.shape for e in exp]
+    agree = [int(np.argmin((g == e).all(0))) if not (g == e).all() else g.shape[1] for g, e in zip(got, exp)]
+    print(f"B={B} group prefill: identical frame prefix per row min {min(agree)} of {got[0].shape[1]}")
+    assert min(agree) >= 6, agree
+    monkeypatch.setenv("FISHRT_NO_GROUP_PREFILL", "1")
+    seq = lm.generate_static_batch(prompts, M, **kw)
+    monkeypatch.delenv("FISHRT_NO_GROUP_PREFILL")
+    assert all(np.array_equal(a, b) for a, b in zip(got, seq))
+    lm.close()

@@ -34,15 +34,17 @@ int main(int argc, char** argv) {
     std::vector<LayerW> lw(NL);
     for (int l = 0; l < NL; ++l) { uint8_t* b = arena + per_layer * l; lw[l].wqkv = b; b += (size_t)QKV * 2048; lw[l].wo = b; b += (size_t)2 << 20; lw[l].w13 = b; b += (size_t)16 << 20; lw[l].w2 = b; lw[l].attn_norm = norm; lw[l].ffn_norm = norm; }
     RowsCtx c;
-    c.Mcap = 512; c.down_split = 4;
+    c.Mcap = 2048; c.part_rows = 512; c.down_split = 4;
     auto dalloc = [&](size_t n) { void* p; CK(hipMalloc(&p, n)); CK(hipMemset(p, 0, n)); return p; };
     const int NC = 8192 / LmKernels<WT>::attn_chunk();
-    c.X = (float*)dalloc(512 * 1024 * 4); c.Q = (float*)dalloc(512 * 1024 * 4); c.part = (float*)dalloc((size_t)512 * 16 * NC * 66 * 4);
-    c.P = (float*)dalloc(4 * 512 * 1024 * 4); c.A = (uint16_t*)dalloc(2 * 512 * 1024 * 2);
-    c.C = (uint16_t*)dalloc(2 * 512 * 4096 * 2); c.A2 = (uint16_t*)dalloc(2 * 512 * 1024 * 2); c.ss = (float*)dalloc(512 * 64 * 4);
+    c.X = (float*)dalloc(2048 * 1024 * 4); c.Q = (float*)dalloc(2048 * 1024 * 4); c.part = (float*)dalloc((size_t)512 * 16 * NC * 66 * 4);
+    c.P = (float*)dalloc((size_t)4 * 2048 * 1024 * 4); c.A = (uint16_t*)dalloc(2 * 2048 * 1024 * 2);
+    c.C = (uint16_t*)dalloc((size_t)2 * 2048 * 4096 * 2); c.A2 = (uint16_t*)dalloc(2 * 2048 * 1024 * 2); c.ss = (float*)dalloc(2048 * 64 * 4);
     c.cos_t = (float*)dalloc(8192 * 32 * 4); c.sin_t = (float*)dalloc(8192 * 32 * 4);
     SeqState hs = {}; hs.pos = 300; SeqState* state = (SeqState*)dalloc(sizeof(SeqState)); CK(hipMemcpy(state, &hs, sizeof(hs), hipMemcpyHostToDevice));
     c.state = state; c.n_chunks_max = NC; c.nc_launch = argc > 2 ? atoi(argv[2]) : 4; c.pos_step = argc > 3 ? atoi(argv[3]) : 1; c.pt_stride = 0;
+    c.seq_rows = argc > 4 ? atoi(argv[4]) : 0;  // > 0: group prefill (M must be a multiple); all sequences share one page table here
+    if (c.seq_rows) { hs.pos = 0; CK(hipMemcpy(state, &hs, sizeof(hs), hipMemcpyHostToDevice)); }
     const int max_pages = 128; const size_t page_elems = 2 * KV_PAGE * 64;
     WT* kvpool = (WT*)dalloc((size_t)NL * 2 * max_pages * page_elems * sizeof(WT));
     std::vector<int> pt(max_pages); for (int i = 0; i < max_pages; ++i) pt[i] = i;

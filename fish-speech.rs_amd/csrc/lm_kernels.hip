@@ -14,6 +14,7 @@
 // Reference semantics implemented: fish_speech_core/lib/lm/dual_ar.rs:118-165 (FFN), :239-249 (rope_i),
 // :252-279 (SDPA), :281-384 (Attention::forward), :429-440 (block), :532-567 (embed), :629-631 (head).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "fs_common.h"
 #include "fs_synth.h"
@@ -844,6 +845,78 @@ __global__ __launch_bounds__(256) void k_prep(float* __restrict__ X, int D, cons
     }
 }
 
+// Epilogue of the row-path GEMMs for one (row pair r/r+1, activation row m): a, b are the K-summed (and fp8-scaled) dot products.
+// Thread mapping contract: the ROWS / 2 threads of one m are adjacent lanes (RESIDUAL_NORM's sum of squares meets by shuffles).
+struct GemmEpi {
+    float* Y; int ldy; size_t slab_stride; bf16_t* Of; int ldo;
+    const float *cos_t, *sin_t;
+    KVView kv; int H, Hk, Dh; RowMap rm; NormAux na;
+    int pos0, rope_off, N;
+};
+template <int EPI, int ROWS>
+__device__ __forceinline__ void gemm_epilogue(float a, float b, int r, int m, int ml, int pr, const GemmEpi& g, const float* s_rms) {
+    float* const Y = g.Y; const int ldy = g.ldy, ldo = g.ldo, N = g.N, H = g.H, Hk = g.Hk, Dh = g.Dh, pos0 = g.pos0, rope_off = g.rope_off;
+    const size_t slab_stride = g.slab_stride;
+    bf16_t* const Of = g.Of;
+    const float *cos_t = g.cos_t, *sin_t = g.sin_t;
+    const KVView& kv = g.kv; const RowMap& rm = g.rm; const NormAux& na = g.na;
+    if (EPI == EPI_STORE) {  // split-K slab blockIdx.y
+        float* yp = Y + (size_t)blockIdx.y * slab_stride + (size_t)m * ldy + r;
+        yp[0] = a;
+        if (r + 1 < N) yp[1] = b;
+    } else if (EPI == EPI_RESIDUAL) {
+        float2* yp = reinterpret_cast<float2*>(Y + (size_t)m * ldy + r);
+        const float2 o = *yp;
+        *yp = make_float2(o.x + a, o.y + b);
+    } else if (EPI == EPI_RESIDUAL_NORM) {  // the ROWS/2 threads of one m are adjacent lanes (8, 16 or 32 of them)
+        float2* yp = reinterpret_cast<float2*>(Y + (size_t)m * ldy + r);
+        const float2 o = *yp;
+        const float v0 = o.x + a, v1 = o.y + b;
+        *yp = make_float2(v0, v1);
+        bf16_t h0, l0, h1, l1;
+        split_bf16(v0 * na.g[r], h0, l0); split_bf16(v1 * na.g[r + 1], h1, l1);
+        *reinterpret_cast<uint32_t*>(na.A2 + frag_off(m, r, 0, na.D)) = h0 | ((uint32_t)h1 << 16);
+        *reinterpret_cast<uint32_t*>(na.A2 + frag_off(m, r, 1, na.D)) = l0 | ((uint32_t)l1 << 16);
+        float ssq = group_sum<(ROWS / 2 >= 16 ? 16 : ROWS / 2)>(fmaf(v0, v0, v1 * v1));
+        if (ROWS / 2 == 32) ssq += __shfl_xor(ssq, 16, 64);
+        if (pr == 0) na.ss[(size_t)m * na.nblk + blockIdx.x] = ssq;
+    } else if (EPI == EPI_SWIGLU_RMS) {
+        const float dn = s_rms[ml];
+        const float an = a / dn, bn = b / dn;
+        const float v = (an / (1.f + __expf(-an))) * bn;
+        bf16_t hh, ll;
+        split_bf16(v, hh, ll);
+        Of[frag_off(m, r / 2, 0, ldo)] = hh;
+        Of[frag_off(m, r / 2, 1, ldo)] = ll;
+    } else if (EPI == EPI_SWIGLU) {  // interleaved rows (2r, 2r+1) = (w1[r], w3[r]) -> act hi/lo for the down GEMM
+        const float v = (a / (1.f + __expf(-a))) * b;
+        bf16_t h, l;
+        split_bf16(v, h, l);
+        Of[frag_off(m, r / 2, 0, ldo)] = h;
+        Of[frag_off(m, r / 2, 1, ldo)] = l;
+    } else {  // EPI_QKV: rope_i + scatter (q -> Y[m][r], k/v -> paged cache of row m's sequence)
+        const int sq = rm.seq_rows > 0 ? m / rm.seq_rows : m;  // sequence of row m / its token index within the pass
+        const int pos = pos0 + (rm.seq_rows > 0 ? m - sq * rm.seq_rows : m * rm.pos_step), rpos = pos + rope_off;
+        const int* ptab = kv.page_table + (size_t)sq * rm.pt_stride;
+        const int qdim = H * Dh, kdim = Hk * Dh, half = Dh / 2;
+        if (r < qdim + kdim) {
+            const int j = (r % Dh) / 2;
+            const float cs = cos_t[(size_t)rpos * half + j], sn = sin_t[(size_t)rpos * half + j];
+            const float o0 = a * cs - b * sn, o1 = a * sn + b * cs;
+            if (r < qdim) { *reinterpret_cast<float2*>(Y + (size_t)m * ldy + r) = make_float2(o0, o1); }
+            else {
+                const int rk = r - qdim;
+                bf16_t* dst = kv_addr<bf16_t>(kv.k, ptab, pos, rk / Dh, Hk, Dh) + rk % Dh;
+                *reinterpret_cast<uint32_t*>(dst) = WTr<bf16_t>::from_f32(o0) | ((uint32_t)WTr<bf16_t>::from_f32(o1) << 16);
+            }
+        } else {
+            const int rv = r - qdim - kdim;
+            bf16_t* dst = kv_addr<bf16_t>(kv.v, ptab, pos, rv / Dh, Hk, Dh) + rv % Dh;
+            *reinterpret_cast<uint32_t*>(dst) = WTr<bf16_t>::from_f32(a) | ((uint32_t)WTr<bf16_t>::from_f32(b) << 16);
+        }
+    }
+}
+
 // Block = 16*RT weight rows x one K range of 128*NKS (the 4 waves take a quarter each, NKS k-steps of 32) x ALL activation
 // rows, 32 at a time.  No LDS staging and no barrier in front of the MFMAs: a wave puts its whole weight panel in flight at
 // kernel entry (A operand, non-temporal, kept in VGPRs for every row panel), then per 32-row panel loads its B operands
@@ -881,6 +954,7 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* __restrict__ Xf, in
     const int kbeg = ((int)blockIdx.y * 4 + kq) * NKS * 32 + (lane >> 4) * 8;  // this lane's first k of every 32-wide step (weights)
     int pos0 = 0, rope_off = 0;
     if (EPI == EPI_QKV) { pos0 = state->pos; rope_off = state->rope_off; }  // requested up front: the epilogue must not start a dependent chain
+    const GemmEpi ge{Y, ldy, slab_stride, Of, ldo, cos_t, sin_t, kv, H, Hk, Dh, rm, na, pos0, rope_off, N};
     u32x4 wf[RT][NKS];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -956,61 +1030,143 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* __restrict__ Xf, in
             float b = (red[0][2 * pr + 1][ml] + red[1][2 * pr + 1][ml]) + (red[2][2 * pr + 1][ml] + red[3][2 * pr + 1][ml]);
             if (r >= N || m >= M) continue;
             if (FP8) { a *= wscale[r]; b *= wscale[min(r + 1, N - 1)]; }
-            if (EPI == EPI_STORE) {  // split-K slab blockIdx.y
-                float* yp = Y + (size_t)blockIdx.y * slab_stride + (size_t)m * ldy + r;
-                yp[0] = a;
-                if (r + 1 < N) yp[1] = b;
-            } else if (EPI == EPI_RESIDUAL) {
-                float2* yp = reinterpret_cast<float2*>(Y + (size_t)m * ldy + r);
-                const float2 o = *yp;
-                *yp = make_float2(o.x + a, o.y + b);
-            } else if (EPI == EPI_RESIDUAL_NORM) {  // the ROWS/2 threads of one m are adjacent lanes (8, 16 or 32 of them)
-                float2* yp = reinterpret_cast<float2*>(Y + (size_t)m * ldy + r);
-                const float2 o = *yp;
-                const float v0 = o.x + a, v1 = o.y + b;
-                *yp = make_float2(v0, v1);
-                bf16_t h0, l0, h1, l1;
-                split_bf16(v0 * na.g[r], h0, l0); split_bf16(v1 * na.g[r + 1], h1, l1);
-                *reinterpret_cast<uint32_t*>(na.A2 + frag_off(m, r, 0, na.D)) = h0 | ((uint32_t)h1 << 16);
-                *reinterpret_cast<uint32_t*>(na.A2 + frag_off(m, r, 1, na.D)) = l0 | ((uint32_t)l1 << 16);
-                float ssq = group_sum<(ROWS / 2 >= 16 ? 16 : ROWS / 2)>(fmaf(v0, v0, v1 * v1));
-                if (ROWS / 2 == 32) ssq += __shfl_xor(ssq, 16, 64);
-                if (pr == 0) na.ss[(size_t)m * na.nblk + blockIdx.x] = ssq;
-            } else if (EPI == EPI_SWIGLU_RMS) {
-                const float dn = s_rms[ml];
-                const float an = a / dn, bn = b / dn;
-                const float v = (an / (1.f + __expf(-an))) * bn;
-                bf16_t hh, ll;
-                split_bf16(v, hh, ll);
-                Of[frag_off(m, r / 2, 0, ldo)] = hh;
-                Of[frag_off(m, r / 2, 1, ldo)] = ll;
-            } else if (EPI == EPI_SWIGLU) {  // interleaved rows (2r, 2r+1) = (w1[r], w3[r]) -> act hi/lo for the down GEMM
-                const float v = (a / (1.f + __expf(-a))) * b;
-                bf16_t h, l;
-                split_bf16(v, h, l);
-                Of[frag_off(m, r / 2, 0, ldo)] = h;
-                Of[frag_off(m, r / 2, 1, ldo)] = l;
-            } else {  // EPI_QKV: rope_i + scatter (q -> Y[m][r], k/v -> paged cache of row m's sequence)
-                const int sq = rm.seq_rows > 0 ? m / rm.seq_rows : m;  // sequence of row m / its token index within the pass
-                const int pos = pos0 + (rm.seq_rows > 0 ? m - sq * rm.seq_rows : m * rm.pos_step), rpos = pos + rope_off;
-                const int* ptab = kv.page_table + (size_t)sq * rm.pt_stride;
-                const int qdim = H * Dh, kdim = Hk * Dh, half = Dh / 2;
-                if (r < qdim + kdim) {
-                    const int j = (r % Dh) / 2;
-                    const float cs = cos_t[(size_t)rpos * half + j], sn = sin_t[(size_t)rpos * half + j];
-                    const float o0 = a * cs - b * sn, o1 = a * sn + b * cs;
-                    if (r < qdim) { *reinterpret_cast<float2*>(Y + (size_t)m * ldy + r) = make_float2(o0, o1); }
-                    else {
-                        const int rk = r - qdim;
-                        bf16_t* dst = kv_addr<bf16_t>(kv.k, ptab, pos, rk / Dh, Hk, Dh) + rk % Dh;
-                        *reinterpret_cast<uint32_t*>(dst) = WTr<bf16_t>::from_f32(o0) | ((uint32_t)WTr<bf16_t>::from_f32(o1) << 16);
-                    }
-                } else {
-                    const int rv = r - qdim - kdim;
-                    bf16_t* dst = kv_addr<bf16_t>(kv.v, ptab, pos, rv / Dh, Hk, Dh) + rv % Dh;
-                    *reinterpret_cast<uint32_t*>(dst) = WTr<bf16_t>::from_f32(a) | ((uint32_t)WTr<bf16_t>::from_f32(b) << 16);
+            gemm_epilogue<EPI, ROWS>(a, b, r, m, ml, pr, ge, s_rms);
+        }
+    }
+}
+
+// ---- large-M variant (M >= GB_MIN_M rows: prefill passes, group prefill, big static batches) ---------------------------------
+// k_gemm3 re-reads a panel's activation fragments once per 16 (or 32) weight rows through the CU's vector L1, which bounds it at
+// 64 B/clk; with many panels that traffic, not the weight stream, is the cost.  Here a block owns 64 weight rows x one 1024-deep
+// K range (wave = (K half, 32-row group): 2 A tiles x 16 k-steps stay in VGPRs for every panel) and the panel's fragments go
+// through LDS once per block: 4-k-step chunks (32 KB: both K halves), double-buffered, global loads for chunk i+1 in flight
+// during the 32 MFMAs per wave of chunk i; every fragment read from LDS feeds two A tiles.  Per chunk and block: 32 KB through
+// L1, 64 KB of LDS reads, 128 MFMAs -- the three pipes are balanced.  The two K halves meet in LDS (aliased onto the stage
+// buffer that was just consumed) and the epilogue is the one of k_gemm3 (ROWS = 64).
+constexpr int GB_ROWS = 64, GB_CH = 4, GB_MIN_M = 128;
+static int gemm_big_min_m() {  // FISHRT_GEMM_BIG_MIN_M: tuning / test hook (rows from which the LDS-staged variant is taken)
+    static const int v = [] { const char* e = std::getenv("FISHRT_GEMM_BIG_MIN_M"); return e ? std::atoi(e) : GB_MIN_M; }();
+    return v;
+}
+// measured (tools/ubench_gemm, Fish-1.5 shapes): a block's fixed cost (128 KB weight tile + 4 latency-exposed chunk rounds) is
+// ~8 us, so the variant wins from 128 rows for the wide GEMMs (W13: 128 tiles, W2: 16 tiles x 4 K ranges) and only from
+// ~512 rows for Wqkv / Wo (20 / 16 tiles)
+static bool gemm_big_ok(int M, int N, int K, int ksplit) {
+    if (K % ksplit != 0 || K / ksplit != 1024) return false;
+    const int m0 = gemm_big_min_m();
+    return M >= 4 * m0 || (M >= m0 && (N + GB_ROWS - 1) / GB_ROWS * ksplit >= 64);
+}
+template <int EPI, bool FP8>
+__global__ __launch_bounds__(256, 2) void k_gemm_big(const bf16_t* __restrict__ Xf, int M, int K,
+                                                     const void* __restrict__ Wv, const float* __restrict__ wscale, int N, float* __restrict__ Y, int ldy,
+                                                     size_t slab_stride, bf16_t* __restrict__ Of, int ldo,
+                                                     const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                                                     const SeqState* __restrict__ state, KVView kv, int H, int Hk, int Dh, RowMap rm, NormAux na) {
+    constexpr int ROWS = GB_ROWS, NKS = 16, STAGE = 2 * GB_CH * 4096;  // bytes per stage: 2 K halves x 4 k-steps x 4 KB
+    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = wave >> 1, rg = wave & 1;
+    const int n0 = blockIdx.x * ROWS;
+    int mp = (int)blockIdx.z * PF_M;
+    if (mp >= M) return;
+    int pos0 = 0, rope_off = 0;
+    if (EPI == EPI_QKV) { pos0 = state->pos; rope_off = state->rope_off; }
+    const GemmEpi ge{Y, ldy, slab_stride, Of, ldo, cos_t, sin_t, kv, H, Hk, Dh, rm, na, pos0, rope_off, N};
+    const int ksw = (int)blockIdx.y * 32 + kh * NKS;  // this wave's first 32-deep k-step
+    u32x4 wf[2][NKS];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const size_t woff = (size_t)min(n0 + rg * 32 + t * 16 + (lane & 15), N - 1) * K + (size_t)ksw * 32 + (lane >> 4) * 8;
+        if (FP8) {
+            const uint8_t* wp = reinterpret_cast<const uint8_t*>(Wv) + woff;
+            u32x2 raw[NKS];
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) raw[ks] = ld_stream(reinterpret_cast<const u32x2*>(wp + ks * 32));
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) wf[t][ks] = fp8x8_to_bf16x8(raw[ks]);
+        } else {
+            const bf16_t* wp = reinterpret_cast<const bf16_t*>(Wv) + woff;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) wf[t][ks] = ld_stream(reinterpret_cast<const u32x4*>(wp + ks * 32));
+        }
+    }
+    // chunk c of panel p: thread unit i -> K half i >> 2, k-step i & 3 of the chunk, 16-B slot tid of that k-step's 4 KB block
+    u32x4 g[8];
+    auto load_chunk = [&](int p, int c) {
+        const bf16_t* base = Xf + ((size_t)(p >> 5) * (K >> 5) + (size_t)blockIdx.y * 32 + c * GB_CH) * 2048 + tid * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g[i] = *reinterpret_cast<const u32x4*>(base + (size_t)((i >> 2) * NKS + (i & 3)) * 2048);
+    };
+    auto store_chunk = [&](int sb) {
+        uint8_t* dst = lds + sb * STAGE + tid * 16;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<u32x4*>(dst + i * 4096) = g[i];
+    };
+    load_chunk(mp, 0);
+    store_chunk(0);
+    __syncthreads();
+    int sb = 0;
+    const int mstep = (int)gridDim.z * PF_M;
+    for (; mp < M; mp += mstep) {
+        const int mp_next = mp + mstep;
+        float ss8 = 0.f;
+        if (EPI == EPI_SWIGLU_RMS) {
+            const float* sp = na.ss + (size_t)(mp + (tid >> 3)) * na.nblk + (tid & 7);
+            for (int q8 = 0; q8 < na.nblk; q8 += 8) ss8 += sp[q8];
+        }
+        f32x4v acc[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { acc[t][0] = f32x4v{0.f, 0.f, 0.f, 0.f}; acc[t][1] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int c = 0; c < NKS / GB_CH; ++c) {
+            const bool has_next = c + 1 < NKS / GB_CH || mp_next < M;
+            if (has_next) load_chunk(c + 1 < NKS / GB_CH ? mp : mp_next, (c + 1) % (NKS / GB_CH));
+            const uint8_t* src = lds + sb * STAGE + kh * (GB_CH * 4096) + lane * 16;
+#pragma unroll
+            for (int ks = 0; ks < GB_CH; ++ks) {
+                bf16x8 xf[4];  // hi rows 0..15, lo rows 0..15, hi rows 16..31, lo rows 16..31 (order of k_gemm3)
+                xf[0] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(src + ks * 4096));
+                xf[1] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(src + ks * 4096 + 2048));
+                xf[2] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(src + ks * 4096 + 1024));
+                xf[3] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(src + ks * 4096 + 3072));
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const bf16x8 af = __builtin_bit_cast(bf16x8, wf[t][c * GB_CH + ks]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[t][j >> 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xf[j], acc[t][j >> 1], 0, 0, 0);
                 }
             }
+            if (c == NKS / GB_CH - 1) {  // panel complete: the K halves meet in the stage buffer that was just consumed
+                float (*red)[ROWS][33] = reinterpret_cast<float (*)[ROWS][33]>(lds + sb * STAGE);
+                float* s_rms = reinterpret_cast<float*>(lds + sb * STAGE + 2 * ROWS * 33 * sizeof(float));
+                __syncthreads();
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const f32x4v cc = acc[t][mt];
+                        float* rp = &red[kh][rg * 32 + t * 16 + (lane >> 4) * 4][mt * 16 + (lane & 15)];
+                        rp[0] = cc.x; rp[33] = cc.y; rp[66] = cc.z; rp[99] = cc.w;
+                    }
+                if (EPI == EPI_SWIGLU_RMS) {
+                    const float tot = group_sum<8>(ss8);
+                    if ((tid & 7) == 0) s_rms[tid >> 3] = sqrtf(tot / (float)na.D + na.eps);
+                }
+                __syncthreads();
+#pragma unroll
+                for (int sI = 0; sI < ROWS / 16; ++sI) {
+                    const int slot = sI * 256 + tid;
+                    const int pr = slot % (ROWS / 2), ml = slot / (ROWS / 2);
+                    const int r = n0 + 2 * pr, m = mp + ml;
+                    float a = red[0][2 * pr][ml] + red[1][2 * pr][ml];
+                    float b = red[0][2 * pr + 1][ml] + red[1][2 * pr + 1][ml];
+                    if (r >= N || m >= M) continue;
+                    if (FP8) { a *= wscale[r]; b *= wscale[min(r + 1, N - 1)]; }
+                    gemm_epilogue<EPI, ROWS>(a, b, r, m, ml, pr, ge, s_rms);
+                }
+            }
+            if (has_next) store_chunk(sb ^ 1);
+            __syncthreads();
+            sb ^= 1;
         }
     }
 }
@@ -2430,6 +2586,18 @@ static void launch_gemm3(int N, int ksplit, int rt, hipStream_t st, const bf16_t
                          float* Y, int ldy, size_t slab_stride, bf16_t* Of, int ldo, const float* cos_t, const float* sin_t,
                          const SeqState* state, KVView kv, int H, int Hk, int Dh, RowMap rm, NormAux na = NormAux{}) {
     FS_REQUIRE(K % (ksplit * 128) == 0, "GEMM depth must be a multiple of 128 per K range");
+    if (gemm_big_ok(M, N, K, ksplit)) {
+        const int tiles = (N + GB_ROWS - 1) / GB_ROWS, panels_b = (M + PF_M - 1) / PF_M;
+        const int gzb = std::max(1, std::min(panels_b, 512 / std::max(1, tiles * ksplit)));
+        const dim3 gridb(tiles, ksplit, gzb);
+        if (wscale)
+            hipLaunchKernelGGL((k_gemm_big<EPI, true>), gridb, dim3(256), 0, st, Xf, M, K, W, wscale, N, Y, ldy, slab_stride, Of, ldo, cos_t, sin_t,
+                               state, kv, H, Hk, Dh, rm, na);
+        else
+            hipLaunchKernelGGL((k_gemm_big<EPI, false>), gridb, dim3(256), 0, st, Xf, M, K, W, wscale, N, Y, ldy, slab_stride, Of, ldo, cos_t, sin_t,
+                               state, kv, H, Hk, Dh, rm, na);
+        return;
+    }
     const int nks = K / ksplit / 128;
     // enough blocks to fill 256 CUs a few times over: spread the row panels over blockIdx.z until ~1024 blocks
     const int nb = (N + 16 * rt - 1) / (16 * rt) * ksplit, panels = (M + PF_M - 1) / PF_M;
@@ -2482,7 +2650,7 @@ void LmKernels<WT>::rows_layer(const ModelDims& d, int M, const RowsCtx& c, cons
         // blocks (rt = 4) were measured for prefill-sized passes and are SLOWER (W13 at 384 rows: 33 -> 41 us): the lost
         // occupancy costs more than the saved fragment traffic.
         const int rt_qkv = 1, rt_o = 1, rt_13 = 2, rt_2 = 1;
-        const int nblk_o = d.dim / (16 * rt_o);
+        const int nblk_o = gemm_big_ok(M, d.dim, d.dim, 1) ? d.dim / GB_ROWS : d.dim / (16 * rt_o);  // blocks of the Wo GEMM (sum-of-squares partials)
         const RowMap rm{c.pos_step, c.pt_stride, c.seq_rows};
         const RowMap none{0, 0, 0};
         KVView nokv = {};

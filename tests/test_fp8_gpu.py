@@ -210,16 +210,16 @@ def test_fish15_fp8_prefill_pass_equals_token_steps():
     """FS_FP8 prefill pass (MFMA GEMMs over all prompt rows, fp8 weights) vs the batch-1 fp8 GEMV kernels token by token: same
     weights bytes, same scales, same bf16 KV rounding -> agreement to summation order."""
     lm = fishrt.DualARTransformer(fcfg.FISH_1_5, fcfg.FISH_1_5_TOKENS, 0, "fp8").load_synthetic(0xF15E5EED)
-    p = _prompt15(90, seed=7)
+    p = _prompt15(150, seed=7)  # >= 128 rows: the large-M GEMM variant
     sem0 = fcfg.FISH_1_5_TOKENS["semantic_start_id"]
     rng = np.random.RandomState(3)
     for col in (5, 40, 41):
         p[0, col] = sem0 + rng.randint(0, 1024)
         p[1:, col] = rng.randint(0, 1024, 8)
     lg, hg = lm.forward_generate(p, 0)
-    assert lm.curr_kv_size() == 90
+    assert lm.curr_kv_size() == 150
     lm.clear_slow_layer_caches()
-    for t in range(90):
+    for t in range(150):
         l1, h1 = lm.forward_generate(np.ascontiguousarray(p[:, t:t + 1]), t)
     im_end = fcfg.FISH_1_5_TOKENS["im_end_id"]
     dh = float(np.abs(hg - h1).max() / np.sqrt(np.mean(h1 ** 2)))

@@ -192,3 +192,28 @@ def test_fish15_bf16_prefill_pass_equals_token_steps(lm15):
     lm.clear_slow_caches_until(100)
     l2, h2 = lm.forward_generate(np.ascontiguousarray(p[:, 100:]), 100)
     assert float(np.abs(h2 - h1).max() / np.sqrt(np.mean(h1 ** 2))) < 5e-3
+
+
+def test_fish15_bf16_long_prefill_pass_vs_oracle(lm15, oracle15):
+    """A 200-token prompt in ONE pass (>= 128 rows: the large-M LDS-staged GEMM variant + causal flash attention) against the
+    oracle's forward_generate on the same bf16-rounded weights and bf16-rounded K/V, then a 3-token cached-prefix continuation
+    (small-M GEMM kernel) on top of that cache."""
+    lm, o = lm15, oracle15
+    p = _prompt(203, seed=21)
+    sem0 = fcfg.FISH_1_5_TOKENS["semantic_start_id"]
+    rng = np.random.RandomState(5)
+    for col in (7, 90, 91, 180):
+        p[0, col] = sem0 + rng.randint(0, 1024)
+        p[1:, col] = rng.randint(0, 1024, 8)
+    o.set_kv_round_bf16(True)
+    o.clear_slow(); lm.clear_slow_layer_caches()
+    im_end = fcfg.FISH_1_5_TOKENS["im_end_id"]
+    for lo_, hi_ in ((0, 200), (200, 203)):
+        chunk = np.ascontiguousarray(p[:, lo_:hi_])
+        lg, hg = lm.forward_generate(chunk, lo_)
+        lo, ho = o.forward_generate(chunk, lo_)
+        dl = float(np.abs(lg[0, im_end:] - lo[0, im_end:]).max())
+        dh = float(np.abs(hg - ho).max() / np.sqrt(np.mean(ho ** 2)))
+        print(f"prefill rows [{lo_}, {hi_}) vs oracle: max |dlogit| {dl:.2e}, |dh|/rms {dh:.2e}")
+        assert dl < BF16_TOL and dh < BF16_TOL, (lo_, hi_, dl, dh)
+    assert lm.curr_kv_size() == 203

@@ -91,6 +91,7 @@ struct RowsCtx {
     int pt_stride;       // page-table stride between rows (0 for prefill) / between sequences (group prefill)
     int seq_rows = 0;    // > 0: group prefill -- rows = seq_rows consecutive tokens of each of M / seq_rows sequences, all starting at state->pos
     bool no_flash = false;       // micro-benchmark / test hook: keep the chunked row attention for prefill passes
+    bool chunked_attn = false;   // micro-benchmark / test hook: keep k_attn_decode + k_attn_combine for rows-are-sequences passes
     bool small_attn = false;     // every row attends over <= 8 tokens of ONE page (fast decoder): fused attention node
     unsigned stage_mask = 0xFFu;  // micro-benchmark hook: bit i enables stage i of rows_layer (prep, qkv, attn, combine, wo, prep, w13, w2)
 };

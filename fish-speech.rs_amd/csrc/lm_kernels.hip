@@ -1261,6 +1261,139 @@ __global__ __launch_bounds__(256) void k_attn_small_rows(const float* __restrict
     }
 }
 
+// Static-batch decode attention in ONE node: block = (kv head g, activation row m) walks the row's whole KV prefix chunk by
+// chunk (same wave / lane-group geometry as k_attn_decode; the next chunk's K/V tiles are in flight while the current one is
+// scored), every lane group keeps a running (max, sum, o) (online softmax), the waves meet once in LDS and the normalised result
+// goes straight into the fragment-major hi/lo input of the Wo GEMM -- replaces k_attn_decode over (chunks x rows) blocks +
+// k_attn_combine (two graph nodes and the partials round trip) for the rows-are-sequences passes.
+template <typename WT, int DH, int NREP>
+__global__ __launch_bounds__((AttnGeom<WT, DH>::NW * 64)) void k_attn_rows(const float* __restrict__ q_all, KVView kv,
+                                                   const SeqState* __restrict__ state, int Hk, int pos_step, int pt_stride,
+                                                   bf16_t* __restrict__ Ohi) {
+    const int g = blockIdx.x, mrow = blockIdx.y;
+    kv.page_table += (size_t)mrow * pt_stride;
+    const float* q = q_all + (size_t)mrow * Hk * NREP * DH;
+    constexpr int EPL = WTr<WT>::EPL;
+    constexpr int LPT = DH / EPL, G = 64 / LPT, NRP = NREP < G ? NREP : G, NTS = G / NRP, NHP = NREP / NRP;
+    constexpr int TW = AttnGeom<WT, DH>::TW, NW = AttnGeom<WT, DH>::NW, CH = NW * TW, TPG = TW / NTS, NLD = TW * LPT / 64;
+    static_assert(TW % NTS == 0 && NLD >= 1 && KV_PAGE % TW == 0, "attention geometry");
+    using vec = typename WTr<WT>::vec;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ __attribute__((aligned(16))) WT sk[NW][TW * DH];
+    __shared__ __attribute__((aligned(16))) WT sv[NW][TW * DH];
+    __shared__ float sp[NW][NREP][NTS][DH + 2];
+    const int T = state->pos + 1 + mrow * pos_step;  // the row's own K/V were appended by the qkv stage
+    const int nc = (T + CH - 1) / CH;
+    vec kreg[NLD], vreg[NLD];
+    auto load_tiles = [&](int c) {  // chunk c: this wave's TW tokens live in one page
+        const int t_base = __builtin_amdgcn_readfirstlane(c * CH + wave * TW);
+        const int page = kv.page_table[t_base / KV_PAGE];
+        const WT* kpage = reinterpret_cast<const WT*>(kv.k) + (size_t)(page * Hk + g) * KV_PAGE * DH;
+        const WT* vpage = reinterpret_cast<const WT*>(kv.v) + (size_t)(page * Hk + g) * KV_PAGE * DH;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int tl = (i * 64 + lane) / LPT, sl = lane % LPT;
+            const int t = t_base + tl;
+            kreg[i] = *reinterpret_cast<const vec*>(kpage + (size_t)(t % KV_PAGE) * DH + sl * EPL);
+            vreg[i] = *reinterpret_cast<const vec*>(vpage + (size_t)(t % KV_PAGE) * DH + sl * EPL);
+        }
+    };
+    load_tiles(0);
+    const int gi = lane / LPT, sub = lane % LPT;
+    const int rl = gi % NRP, ts = gi / NRP;
+    constexpr bool POW2 = (DH == 64 || DH == 16 || DH == 256);
+    const float scale = 1.0f / sqrtf((float)DH);
+    float qr[NHP][EPL];
+#pragma unroll
+    for (int hp = 0; hp < NHP; ++hp) {
+        const float* qp = q + (size_t)(g * NREP + hp * NRP + rl) * DH + sub * EPL;
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) qr[hp][i] = POW2 ? qp[i] * scale : qp[i];  // 2^-k scale folded into q (exact), see k_attn_decode
+    }
+    float mr[NHP], lr[NHP], orun[NHP][EPL];
+#pragma unroll
+    for (int hp = 0; hp < NHP; ++hp) {
+        mr[hp] = -1e30f; lr[hp] = 0.f;
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) orun[hp][i] = 0.f;
+    }
+    for (int c = 0; c < nc; ++c) {
+        const int t_base = c * CH + wave * TW;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            *reinterpret_cast<vec*>(&sk[wave][(size_t)(i * 64 + lane) * EPL]) = kreg[i];
+            *reinterpret_cast<vec*>(&sv[wave][(size_t)(i * 64 + lane) * EPL]) = vreg[i];
+        }
+        if (c + 1 < nc) load_tiles(c + 1);
+        // (each wave reads only the tile it wrote: no block barrier, LDS operations of one wave stay in order)
+#pragma unroll
+        for (int hp = 0; hp < NHP; ++hp) {
+            float sc[TPG];
+            float mc = -1e30f;
+#pragma unroll
+            for (int j = 0; j < TPG; ++j) {
+                const int tl = ts + j * NTS;
+                float kf[EPL];
+                WTr<WT>::unpack(*reinterpret_cast<const vec*>(&sk[wave][(size_t)tl * DH + sub * EPL]), kf);
+                float a = 0.f;
+#pragma unroll
+                for (int i = 0; i < EPL; ++i) a = POW2 ? fmaf(qr[hp][i], kf[i], a) : fmaf(qr[hp][i], kf[i] * scale, a);
+                a = group_sum<LPT>(a);
+                sc[j] = (t_base + tl < T) ? a : -1e30f;
+                mc = fmaxf(mc, sc[j]);
+            }
+            const float mn = fmaxf(mr[hp], mc), f = __expf(mr[hp] - mn);
+            float l = lr[hp] * f, o[EPL];
+#pragma unroll
+            for (int i = 0; i < EPL; ++i) o[i] = orun[hp][i] * f;
+#pragma unroll
+            for (int j = 0; j < TPG; ++j) {
+                const int tl = ts + j * NTS;
+                const float p = (t_base + tl < T) ? __expf(sc[j] - mn) : 0.f;
+                l += p;
+                float vf[EPL];
+                WTr<WT>::unpack(*reinterpret_cast<const vec*>(&sv[wave][(size_t)tl * DH + sub * EPL]), vf);
+#pragma unroll
+                for (int i = 0; i < EPL; ++i) o[i] = fmaf(p, vf[i], o[i]);
+            }
+            mr[hp] = mn; lr[hp] = l;
+#pragma unroll
+            for (int i = 0; i < EPL; ++i) orun[hp][i] = o[i];
+        }
+    }
+#pragma unroll
+    for (int hp = 0; hp < NHP; ++hp) {
+        float* dst = sp[wave][hp * NRP + rl][ts];
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) dst[sub * EPL + i] = orun[hp][i];
+        if (sub == 0) { dst[DH] = mr[hp]; dst[DH + 1] = lr[hp]; }
+    }
+    __syncthreads();
+    const int H = Hk * NREP;
+    for (int e = threadIdx.x; e < NREP * DH; e += NW * 64) {
+        const int r = e / DH, dd = e % DH;
+        float mn = -1e30f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+#pragma unroll
+            for (int k = 0; k < NTS; ++k) mn = fmaxf(mn, sp[w][r][k][DH]);
+        float L = 0.f, O = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+#pragma unroll
+            for (int k = 0; k < NTS; ++k) {
+                const float cf = __expf(sp[w][r][k][DH] - mn);
+                L += sp[w][r][k][DH + 1] * cf;
+                O += sp[w][r][k][dd] * cf;
+            }
+        bf16_t hi, lo;
+        split_bf16(O / L, hi, lo);
+        const int col = (g * NREP + r) * DH + dd;
+        Ohi[frag_off(mrow, col, 0, H * DH)] = hi;
+        Ohi[frag_off(mrow, col, 1, H * DH)] = lo;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ prefill attention (MFMA)
 // Causal flash attention for the rows of a prefill pass (consecutive tokens of ONE sequence, bf16 KV, head_dim 64): block =
 // (query head, 16-row tile); its 4 waves split the sequence page-wise (wave w takes KV pages w, w+4, ...), each producing a
@@ -2677,6 +2810,16 @@ void LmKernels<WT>::rows_layer(const ModelDims& d, int M, const RowsCtx& c, cons
                 hipLaunchKernelGGL((k_attn_small_rows<64>), dim3(M), dim3(256), 0, st, c.Q, kv, c.state, d.H, d.Hk, c.pos_step, c.pt_stride, c.A);
             else
                 hipLaunchKernelGGL((k_attn_small_rows<32>), dim3(M), dim3(256), 0, st, c.Q, kv, c.state, d.H, d.Hk, c.pos_step, c.pt_stride, c.A);
+        } else if (c.pos_step == 0 && !c.chunked_attn && ((d.Dh == 64 && (d.n_rep == 8 || d.n_rep == 2)) || (d.Dh == 32 && d.n_rep == 2))) {
+            // static-batch decode: one fused node per layer (whole KV prefix per (kv head, row) block)
+            const dim3 gr(d.Hk, M);
+            if (!(c.stage_mask & 4u)) {}
+            else if (d.Dh == 64 && d.n_rep == 8)
+                hipLaunchKernelGGL((k_attn_rows<KT, 64, 8>), gr, dim3(AttnGeom<KT, 64>::NW * 64), 0, st, c.Q, kv, c.state, d.Hk, c.pos_step, c.pt_stride, c.A);
+            else if (d.Dh == 64)
+                hipLaunchKernelGGL((k_attn_rows<KT, 64, 2>), gr, dim3(AttnGeom<KT, 64>::NW * 64), 0, st, c.Q, kv, c.state, d.Hk, c.pos_step, c.pt_stride, c.A);
+            else
+                hipLaunchKernelGGL((k_attn_rows<KT, 32, 2>), gr, dim3(AttnGeom<KT, 32>::NW * 64), 0, st, c.Q, kv, c.state, d.Hk, c.pos_step, c.pt_stride, c.A);
         } else {
         FS_REQUIRE(M <= c.part_rows, "more rows than the attention-partials buffer holds");
         const dim3 ga(d.Hk * c.nc_launch, M);

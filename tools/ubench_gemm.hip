@@ -43,6 +43,7 @@ int main(int argc, char** argv) {
     c.cos_t = (float*)dalloc(8192 * 32 * 4); c.sin_t = (float*)dalloc(8192 * 32 * 4);
     SeqState hs = {}; hs.pos = 300; SeqState* state = (SeqState*)dalloc(sizeof(SeqState)); CK(hipMemcpy(state, &hs, sizeof(hs), hipMemcpyHostToDevice));
     c.state = state; c.n_chunks_max = NC; c.nc_launch = argc > 2 ? atoi(argv[2]) : 4; c.pos_step = argc > 3 ? atoi(argv[3]) : 1; c.pt_stride = 0;
+    c.chunked_attn = getenv("UB_CHUNKED_ATTN") != nullptr;
     c.seq_rows = argc > 4 ? atoi(argv[4]) : 0;  // > 0: group prefill (M must be a multiple); all sequences share one page table here
     if (c.seq_rows) { hs.pos = 0; CK(hipMemcpy(state, &hs, sizeof(hs), hipMemcpyHostToDevice)); }
     const int max_pages = 128; const size_t page_elems = 2 * KV_PAGE * 64;

@@ -1,0 +1,105 @@
+"""Edge / size cases of the MFMA row path at Fish-1.5 shapes (bf16): prompts longer than one 2048-row pass, static batches
+that are prefilled in several group passes or (prompts > 2048 tokens) one sequence at a time, per-row EOS in a big batch,
+and the max_seq_len error paths (dual_ar.rs:623-624).  Every check is an equivalence between two product paths that share
+no kernel sequence, or a reference-defined error -- the numeric oracle comparisons live in test_lm_fullsize_gpu.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import fishrt
+from fishrt import config as fcfg
+
+SEED = 0xF15E5EED
+IM_END = fcfg.FISH_1_5_TOKENS["im_end_id"]
+SEM0 = fcfg.FISH_1_5_TOKENS["semantic_start_id"]
+
+
+def _prompt(L, seed):
+    rng = np.random.RandomState(seed)
+    p = np.zeros((9, L), np.uint32)
+    p[0] = rng.randint(0, IM_END, L)
+    for col in range(3, L, 37):  # VQ columns so the codebook embeddings take part
+        p[0, col] = SEM0 + rng.randint(0, 1024)
+        p[1:, col] = rng.randint(0, 1024, 8)
+    return p
+
+
+@pytest.fixture(scope="module")
+def lm():
+    m = fishrt.DualARTransformer(fcfg.FISH_1_5, fcfg.FISH_1_5_TOKENS, 0, "bf16", 48).load_synthetic(SEED)
+    yield m
+    m.close()
+
+
+def test_prompt_longer_than_one_pass(lm):
+    """2300 prompt tokens = one 2048-row pass + one 252-row pass (both on the large-M GEMM) vs 23 passes of 100 rows (small-M
+    GEMM kernel, flash attention over a growing cached prefix): same hidden state / logits to summation order."""
+    p = _prompt(2300, 5)
+    lm.clear_slow_layer_caches()
+    lg, hg = lm.forward_generate(p, 0)
+    assert lm.curr_kv_size() == 2300
+    lm.clear_slow_layer_caches()
+    for lo in range(0, 2300, 100):
+        l1, h1 = lm.forward_generate(np.ascontiguousarray(p[:, lo:lo + 100]), lo)
+    assert lm.curr_kv_size() == 2300
+    dh = float(np.abs(hg - h1).max() / np.sqrt(np.mean(h1 ** 2)))
+    dl = float(np.abs(lg[0, IM_END:] - l1[0, IM_END:]).max())
+    print(f"2300-token prompt, 2 passes vs 23 passes: |dh|/rms {dh:.2e}, max |dlogit| {dl:.2e}")
+    assert dh < 5e-3 and dl < 5e-3, (dh, dl)
+    # generation continues from that cache
+    lm.clear_slow_layer_caches()
+    out = lm.generate_blocking(p, 2300 + 6, temp=0.0, top_p=1.0, top_k=0, repetition_penalty=1.2, ignore_eos=True)
+    assert out.shape == (8, 8) and lm.last_stats()["prompt_tokens"] == 2300
+
+
+def test_static_batch_prefill_paths_agree(lm, monkeypatch):
+    """48 ragged prompts up to 300 tokens: group prefill (7 passes of <= 6 sequences) vs one sequence per pass.  At these
+    shapes the two take different GEMM kernels (large-M vs small-M), so tokens are compared over the first frames only."""
+    rng = np.random.RandomState(9)
+    prompts = [_prompt(int(L), 100 + i) for i, L in enumerate(rng.randint(20, 301, 48))]
+    Lmax = max(p.shape[1] for p in prompts)
+    kw = dict(seed=42, temp=0.0, top_p=1.0, top_k=0, ignore_eos=True)
+    a = lm.generate_static_batch(prompts, Lmax + 4, **kw)
+    st = lm.last_stats()
+    monkeypatch.setenv("FISHRT_NO_GROUP_PREFILL", "1")
+    b = lm.generate_static_batch(prompts, Lmax + 4, **kw)
+    monkeypatch.delenv("FISHRT_NO_GROUP_PREFILL")
+    assert [x.shape for x in a] == [x.shape for x in b] == [(8, 6)] * 48
+    same0 = sum(int(np.array_equal(x[:, 0], y[:, 0])) for x, y in zip(a, b))
+    same_all = sum(int(np.array_equal(x, y)) for x, y in zip(a, b))
+    print(f"group vs per-sequence prefill: first frame identical on {same0}/48 rows, all 6 frames on {same_all}/48; prefill {st['prefill_ms']:.1f} ms")
+    assert same0 >= 44  # random full-size weights give near-flat logits: a near-tie may flip, a wrong row mapping flips everything
+
+
+def test_static_batch_prompts_longer_than_group_capacity(lm):
+    """Prompts of 2100 tokens do not fit a group pass (2048 rows): the per-sequence prefill path (2 passes each) is taken."""
+    prompts = [_prompt(2100, 31), _prompt(1500, 32), _prompt(2100, 33)]
+    kw = dict(seed=42, temp=0.0, top_p=1.0, top_k=0, ignore_eos=True)
+    outs = lm.generate_static_batch(prompts, 2100 + 3, **kw)
+    assert [o.shape for o in outs] == [(8, 5)] * 3
+    # rows 0 and 2 have no padding: their first frame equals the batch-1 path's first frame on the same prompt
+    for i in (0, 2):
+        lm.clear_slow_layer_caches()
+        one = lm.generate_blocking(prompts[i], 2100 + 3, temp=0.0, top_p=1.0, top_k=0, repetition_penalty=1.0, ignore_eos=True)
+        assert one.shape == (8, 5)
+        print(f"row {i}: static batch vs batch-1 identical frames:", int(np.argmin((one == outs[i]).all(0))) if not (one == outs[i]).all() else 5)
+
+
+def test_static_batch_eos_rows_finish_independently(lm):
+    """No ignore_eos, sampled at temperature 1.5 over the 2037-way audio range: rows hit <|im_end|> at different frames; a dead
+    row stops recording while the others go on (static_batch.rs:160-173,328-331); stats count only recorded frames."""
+    prompts = [_prompt(16 + (i % 5), 200 + i) for i in range(48)]
+    outs = lm.generate_static_batch(prompts, 20 + 700, seed=7, temp=1.5, top_p=1.0, top_k=0)
+    n = [o.shape[1] for o in outs]
+    print("frames per row: min", min(n), "max", max(n), "distinct", len(set(n)))
+    assert lm.last_stats()["frames"] == sum(n)
+    assert len(set(n)) > 4 and min(n) >= 1 and max(n) <= 702
+
+
+def test_max_seq_len_errors(lm):
+    p = _prompt(fcfg.FISH_1_5["max_seq_len"] + 1, 3)
+    with pytest.raises(Exception, match="max_seq_len"):
+        lm.generate_blocking(p, p.shape[1] + 4, temp=0.0, top_p=1.0, top_k=0, ignore_eos=True)
+    with pytest.raises(Exception, match="max_seq_len"):
+        lm.generate_static_batch([p, _prompt(10, 1)], p.shape[1] + 4, temp=0.0, top_p=1.0, top_k=0, ignore_eos=True)

@@ -1269,10 +1269,13 @@ __global__ __launch_bounds__(256) void k_attn_small_rows(const float* __restrict
 template <typename WT, int DH, int NREP>
 __global__ __launch_bounds__((AttnGeom<WT, DH>::NW * 64)) void k_attn_rows(const float* __restrict__ q_all, KVView kv,
                                                    const SeqState* __restrict__ state, int Hk, int pos_step, int pt_stride,
-                                                   bf16_t* __restrict__ Ohi) {
-    const int g = blockIdx.x, mrow = blockIdx.y;
+                                                   bf16_t* __restrict__ Ohi, int hsplit) {
+    // hsplit > 1: the query heads of a kv group are spread over hsplit blocks of NREP heads each (small batches: more blocks,
+    // less VALU work per wave; the K/V tiles are then read hsplit times, from L2)
+    const int g = blockIdx.x / hsplit, hb = (blockIdx.x % hsplit) * NREP, mrow = blockIdx.y;
+    const int GH = NREP * hsplit;  // query heads per kv head
     kv.page_table += (size_t)mrow * pt_stride;
-    const float* q = q_all + (size_t)mrow * Hk * NREP * DH;
+    const float* q = q_all + (size_t)mrow * Hk * GH * DH;
     constexpr int EPL = WTr<WT>::EPL;
     constexpr int LPT = DH / EPL, G = 64 / LPT, NRP = NREP < G ? NREP : G, NTS = G / NRP, NHP = NREP / NRP;
     constexpr int TW = AttnGeom<WT, DH>::TW, NW = AttnGeom<WT, DH>::NW, CH = NW * TW, TPG = TW / NTS, NLD = TW * LPT / 64;
@@ -1306,7 +1309,7 @@ __global__ __launch_bounds__((AttnGeom<WT, DH>::NW * 64)) void k_attn_rows(const
     float qr[NHP][EPL];
 #pragma unroll
     for (int hp = 0; hp < NHP; ++hp) {
-        const float* qp = q + (size_t)(g * NREP + hp * NRP + rl) * DH + sub * EPL;
+        const float* qp = q + (size_t)(g * GH + hb + hp * NRP + rl) * DH + sub * EPL;
 #pragma unroll
         for (int i = 0; i < EPL; ++i) qr[hp][i] = POW2 ? qp[i] * scale : qp[i];  // 2^-k scale folded into q (exact), see k_attn_decode
     }
@@ -1369,7 +1372,7 @@ __global__ __launch_bounds__((AttnGeom<WT, DH>::NW * 64)) void k_attn_rows(const
         if (sub == 0) { dst[DH] = mr[hp]; dst[DH + 1] = lr[hp]; }
     }
     __syncthreads();
-    const int H = Hk * NREP;
+    const int H = Hk * GH;
     for (int e = threadIdx.x; e < NREP * DH; e += NW * 64) {
         const int r = e / DH, dd = e % DH;
         float mn = -1e30f;
@@ -1388,7 +1391,7 @@ __global__ __launch_bounds__((AttnGeom<WT, DH>::NW * 64)) void k_attn_rows(const
             }
         bf16_t hi, lo;
         split_bf16(O / L, hi, lo);
-        const int col = (g * NREP + r) * DH + dd;
+        const int col = (g * GH + hb + r) * DH + dd;
         Ohi[frag_off(mrow, col, 0, H * DH)] = hi;
         Ohi[frag_off(mrow, col, 1, H * DH)] = lo;
     }
@@ -2812,14 +2815,20 @@ void LmKernels<WT>::rows_layer(const ModelDims& d, int M, const RowsCtx& c, cons
                 hipLaunchKernelGGL((k_attn_small_rows<32>), dim3(M), dim3(256), 0, st, c.Q, kv, c.state, d.H, d.Hk, c.pos_step, c.pt_stride, c.A);
         } else if (c.pos_step == 0 && !c.chunked_attn && ((d.Dh == 64 && (d.n_rep == 8 || d.n_rep == 2)) || (d.Dh == 32 && d.n_rep == 2))) {
             // static-batch decode: one fused node per layer (whole KV prefix per (kv head, row) block)
-            const dim3 gr(d.Hk, M);
+            // few rows: split the 8 query heads of a kv group over two blocks (64 -> 128 blocks at 32 rows)
+            const int hs = (d.Dh == 64 && d.n_rep == 8) ? (d.Hk * M <= 64 ? 4 : (d.Hk * M < 256 ? 2 : 1)) : 1;
+            const dim3 gr(d.Hk * hs, M);
             if (!(c.stage_mask & 4u)) {}
+            else if (d.Dh == 64 && d.n_rep == 8 && hs == 4)
+                hipLaunchKernelGGL((k_attn_rows<KT, 64, 2>), gr, dim3(AttnGeom<KT, 64>::NW * 64), 0, st, c.Q, kv, c.state, d.Hk, c.pos_step, c.pt_stride, c.A, 4);
+            else if (d.Dh == 64 && d.n_rep == 8 && hs == 2)
+                hipLaunchKernelGGL((k_attn_rows<KT, 64, 4>), gr, dim3(AttnGeom<KT, 64>::NW * 64), 0, st, c.Q, kv, c.state, d.Hk, c.pos_step, c.pt_stride, c.A, 2);
             else if (d.Dh == 64 && d.n_rep == 8)
-                hipLaunchKernelGGL((k_attn_rows<KT, 64, 8>), gr, dim3(AttnGeom<KT, 64>::NW * 64), 0, st, c.Q, kv, c.state, d.Hk, c.pos_step, c.pt_stride, c.A);
+                hipLaunchKernelGGL((k_attn_rows<KT, 64, 8>), gr, dim3(AttnGeom<KT, 64>::NW * 64), 0, st, c.Q, kv, c.state, d.Hk, c.pos_step, c.pt_stride, c.A, 1);
             else if (d.Dh == 64)
-                hipLaunchKernelGGL((k_attn_rows<KT, 64, 2>), gr, dim3(AttnGeom<KT, 64>::NW * 64), 0, st, c.Q, kv, c.state, d.Hk, c.pos_step, c.pt_stride, c.A);
+                hipLaunchKernelGGL((k_attn_rows<KT, 64, 2>), gr, dim3(AttnGeom<KT, 64>::NW * 64), 0, st, c.Q, kv, c.state, d.Hk, c.pos_step, c.pt_stride, c.A, 1);
             else
-                hipLaunchKernelGGL((k_attn_rows<KT, 32, 2>), gr, dim3(AttnGeom<KT, 32>::NW * 64), 0, st, c.Q, kv, c.state, d.Hk, c.pos_step, c.pt_stride, c.A);
+                hipLaunchKernelGGL((k_attn_rows<KT, 32, 2>), gr, dim3(AttnGeom<KT, 32>::NW * 64), 0, st, c.Q, kv, c.state, d.Hk, c.pos_step, c.pt_stride, c.A, 1);
         } else {
         FS_REQUIRE(M <= c.part_rows, "more rows than the attention-partials buffer holds");
         const dim3 ga(d.Hk * c.nc_launch, M);

@@ -253,12 +253,15 @@ template <int DH> struct AttnGeom<float, DH> { static constexpr int TW = 16, NW 
 template <typename WT, int DH, int NREP>
 __global__ __launch_bounds__((AttnGeom<WT, DH>::NW * 64)) void k_attn_decode(const float* __restrict__ q_all, KVView kv,
                                                      const SeqState* __restrict__ state, float* __restrict__ part_all,
-                                                     int Hk, int n_chunks_max, int nc_launch, int pos_step, int pt_stride) {
+                                                     int Hk, int n_chunks_max, int nc_launch, int pos_step, int pt_stride, int hsplit) {
+    // hsplit > 1: the query heads of a kv group are spread over hsplit blocks of NREP heads each (the score / P.V work of a wave is
+    // VALU-bound: 16 tokens x 8 heads ~ 900 instructions; the K/V tiles are then read hsplit times, from L2)
+    const int GH = NREP * hsplit;
     // blockIdx.y = activation row m (0 for the batch-1 decode step): prefill -> token pos + m of one sequence (pos_step 1,
     // pt_stride 0); batched decode -> sequence m at pos (pos_step 0, pt_stride = page-table stride)
     kv.page_table += (size_t)blockIdx.y * pt_stride;
-    const float* q = q_all + (size_t)blockIdx.y * Hk * NREP * DH;
-    float* part = part_all + (size_t)blockIdx.y * Hk * NREP * n_chunks_max * (DH + 2);
+    const float* q = q_all + (size_t)blockIdx.y * Hk * GH * DH;
+    float* part = part_all + (size_t)blockIdx.y * Hk * GH * n_chunks_max * (DH + 2);
     constexpr int EPL = WTr<WT>::EPL;
     constexpr int LPT = DH / EPL;            // lanes per head row
     constexpr int G = 64 / LPT;              // lane groups per wave
@@ -272,7 +275,7 @@ __global__ __launch_bounds__((AttnGeom<WT, DH>::NW * 64)) void k_attn_decode(con
     constexpr int NLD = TW * LPT / 64;       // 16-B loads per lane per tile
     static_assert(TW % NTS == 0 && NLD >= 1, "attention geometry");
     using vec = typename WTr<WT>::vec;
-    const int g = blockIdx.x / nc_launch, c = blockIdx.x % nc_launch;  // nc_launch <= n_chunks_max chunks are launched
+    const int g = blockIdx.x / (nc_launch * hsplit), hb = (blockIdx.x / nc_launch) % hsplit * NREP, c = blockIdx.x % nc_launch;  // nc_launch <= n_chunks_max chunks are launched
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __shared__ __attribute__((aligned(16))) WT sk[NW][TW * DH];
     __shared__ __attribute__((aligned(16))) WT sv[NW][TW * DH];
@@ -302,7 +305,7 @@ __global__ __launch_bounds__((AttnGeom<WT, DH>::NW * 64)) void k_attn_decode(con
     float qr[NHP][EPL];
 #pragma unroll
     for (int hp = 0; hp < NHP; ++hp) {
-        const float* qp = q + (size_t)(g * NREP + hp * NRP + rl) * DH + sub * EPL;
+        const float* qp = q + (size_t)(g * GH + hb + hp * NRP + rl) * DH + sub * EPL;
 #pragma unroll
         for (int i = 0; i < EPL; ++i) qr[hp][i] = qp[i];
     }
@@ -377,7 +380,7 @@ __global__ __launch_bounds__((AttnGeom<WT, DH>::NW * 64)) void k_attn_decode(con
                 L += sp[w][r][k][DH + 1] * cf;
                 O += sp[w][r][k][dd] * cf;
             }
-        float* dst = part + ((size_t)(g * NREP + r) * n_chunks_max + c) * (DH + 2);
+        float* dst = part + ((size_t)(g * GH + hb + r) * n_chunks_max + c) * (DH + 2);
         dst[dd] = O;
         if (dd == 0) { dst[DH] = mn; dst[DH + 1] = L; }
     }
@@ -2515,12 +2518,19 @@ void LmKernels<WT>::attn_decode(const ModelDims& d, const float* q, KVView kv, c
     FS_REQUIRE(nc_launch >= 1 && nc_launch <= n_chunks_max, "bad attention chunk count");
     const int grid = d.Hk * nc_launch;
     FS_REQUIRE(n_chunks_max <= 128, "attention supports at most 128 chunks per sequence");
-    if (d.Dh == 64 && d.n_rep == 8)
-        hipLaunchKernelGGL((k_attn_decode<KVT<WT>, 64, 8>), dim3(grid), dim3(AttnGeom<KVT<WT>, 64>::NW * 64), 0, st, q, kv, state, part, d.Hk, n_chunks_max, nc_launch, 0, 0);
+    static const int hs8 = [] { const char* e = std::getenv("FISHRT_ATTN_HSPLIT"); return e ? std::atoi(e) : 4; }();  // tuning hook: 1, 2 or 4
+    if (d.Dh == 64 && d.n_rep == 8 && hs8 == 8 && !std::is_same<WT, float>::value)
+        hipLaunchKernelGGL((k_attn_decode<KVT<WT>, 64, 1>), dim3(grid * 8), dim3(AttnGeom<KVT<WT>, 64>::NW * 64), 0, st, q, kv, state, part, d.Hk, n_chunks_max, nc_launch, 0, 0, 8);
+    else if (d.Dh == 64 && d.n_rep == 8 && hs8 == 4 && !std::is_same<WT, float>::value)
+        hipLaunchKernelGGL((k_attn_decode<KVT<WT>, 64, 2>), dim3(grid * 4), dim3(AttnGeom<KVT<WT>, 64>::NW * 64), 0, st, q, kv, state, part, d.Hk, n_chunks_max, nc_launch, 0, 0, 4);
+    else if (d.Dh == 64 && d.n_rep == 8 && hs8 == 2 && !std::is_same<WT, float>::value)
+        hipLaunchKernelGGL((k_attn_decode<KVT<WT>, 64, 4>), dim3(grid * 2), dim3(AttnGeom<KVT<WT>, 64>::NW * 64), 0, st, q, kv, state, part, d.Hk, n_chunks_max, nc_launch, 0, 0, 2);
+    else if (d.Dh == 64 && d.n_rep == 8)
+        hipLaunchKernelGGL((k_attn_decode<KVT<WT>, 64, 8>), dim3(grid), dim3(AttnGeom<KVT<WT>, 64>::NW * 64), 0, st, q, kv, state, part, d.Hk, n_chunks_max, nc_launch, 0, 0, 1);
     else if (d.Dh == 32 && d.n_rep == 2)
-        hipLaunchKernelGGL((k_attn_decode<KVT<WT>, 32, 2>), dim3(grid), dim3(AttnGeom<KVT<WT>, 32>::NW * 64), 0, st, q, kv, state, part, d.Hk, n_chunks_max, nc_launch, 0, 0);
+        hipLaunchKernelGGL((k_attn_decode<KVT<WT>, 32, 2>), dim3(grid), dim3(AttnGeom<KVT<WT>, 32>::NW * 64), 0, st, q, kv, state, part, d.Hk, n_chunks_max, nc_launch, 0, 0, 1);
     else if (d.Dh == 64 && d.n_rep == 2)
-        hipLaunchKernelGGL((k_attn_decode<KVT<WT>, 64, 2>), dim3(grid), dim3(AttnGeom<KVT<WT>, 64>::NW * 64), 0, st, q, kv, state, part, d.Hk, n_chunks_max, nc_launch, 0, 0);
+        hipLaunchKernelGGL((k_attn_decode<KVT<WT>, 64, 2>), dim3(grid), dim3(AttnGeom<KVT<WT>, 64>::NW * 64), 0, st, q, kv, state, part, d.Hk, n_chunks_max, nc_launch, 0, 0, 1);
     else
         throw Error("unsupported attention geometry (head_dim, n_rep) = (" + std::to_string(d.Dh) + ", " +
                     std::to_string(d.n_rep) + ")");
@@ -2834,11 +2844,11 @@ void LmKernels<WT>::rows_layer(const ModelDims& d, int M, const RowsCtx& c, cons
         const dim3 ga(d.Hk * c.nc_launch, M);
             if (!(c.stage_mask & 4u)) {}
             else if (d.Dh == 64 && d.n_rep == 8)
-                hipLaunchKernelGGL((k_attn_decode<KT, 64, 8>), ga, dim3(AttnGeom<KT, 64>::NW * 64), 0, st, c.Q, kv, c.state, c.part, d.Hk, c.n_chunks_max, c.nc_launch, c.pos_step, c.pt_stride);
+                hipLaunchKernelGGL((k_attn_decode<KT, 64, 8>), ga, dim3(AttnGeom<KT, 64>::NW * 64), 0, st, c.Q, kv, c.state, c.part, d.Hk, c.n_chunks_max, c.nc_launch, c.pos_step, c.pt_stride, 1);
             else if (d.Dh == 32 && d.n_rep == 2)
-                hipLaunchKernelGGL((k_attn_decode<KT, 32, 2>), ga, dim3(AttnGeom<KT, 32>::NW * 64), 0, st, c.Q, kv, c.state, c.part, d.Hk, c.n_chunks_max, c.nc_launch, c.pos_step, c.pt_stride);
+                hipLaunchKernelGGL((k_attn_decode<KT, 32, 2>), ga, dim3(AttnGeom<KT, 32>::NW * 64), 0, st, c.Q, kv, c.state, c.part, d.Hk, c.n_chunks_max, c.nc_launch, c.pos_step, c.pt_stride, 1);
             else if (d.Dh == 64 && d.n_rep == 2)
-                hipLaunchKernelGGL((k_attn_decode<KT, 64, 2>), ga, dim3(AttnGeom<KT, 64>::NW * 64), 0, st, c.Q, kv, c.state, c.part, d.Hk, c.n_chunks_max, c.nc_launch, c.pos_step, c.pt_stride);
+                hipLaunchKernelGGL((k_attn_decode<KT, 64, 2>), ga, dim3(AttnGeom<KT, 64>::NW * 64), 0, st, c.Q, kv, c.state, c.part, d.Hk, c.n_chunks_max, c.nc_launch, c.pos_step, c.pt_stride, 1);
             else
                 throw Error("unsupported attention geometry");
             if (!(c.stage_mask & 8u)) {}

@@ -115,7 +115,10 @@ int fs_lm_generate(fs_lm_t* lm, const uint32_t* prompt, int L, int max_new_token
 
 /* generate_static_batch (generate/static_batch.rs:282-390), audio_only = true: n prompts [num_codebooks+1, L_i]
  * (concatenated in `prompts`, lengths in `lens`), left-padded with <|im_end|>/0 as static_batch.rs:68-111,
- * lock-step decode, ragged outputs: codes_out u32 [n, num_codebooks, cap], n_frames[n]. */
+ * lock-step decode, ragged outputs: codes_out u32 [n, num_codebooks, cap], n_frames[n].
+ * bf16 / fp8 handles with n <= min(max_batch, 256): the n sequences are the rows of every GEMM (weights streamed once per step
+ * for the whole batch) and the prompts are prefilled as group passes; otherwise (f32 handles, n > 256) the rows are generated
+ * one after another on KV slot 0 with identical results under greedy decoding. */
 int fs_lm_generate_batch(fs_lm_t* lm, const uint32_t* prompts, const int* lens, int n, int max_new_tokens,
                          const fs_sampling* sampling, uint64_t seed, uint32_t flags, uint32_t* codes_out, size_t cap,
                          size_t* n_frames);

@@ -246,7 +246,7 @@ class LM final : public LMBase {
     float bench_kernel(int kind, int kv_len, int reps) override {
         use_device();
         require_loaded();
-        FS_REQUIRE(kind >= 0 && kind <= 4 && reps >= 1, "bad kernel id");
+        FS_REQUIRE(kind >= 0 && kind <= 7 && reps >= 1, "bad kernel id");
         FS_REQUIRE(kv_len >= 1 && kv_len < a_.max_seq_len, "bad KV length");
         clear_slow();
         ensure_capacity(0, kv_len);
@@ -257,6 +257,17 @@ class LM final : public LMBase {
         hipGraph_t g = nullptr;
         hipGraphExec_t ge = nullptr;
         FS_HIP(hipStreamBeginCapture(st_, hipStreamCaptureModeThreadLocal));
+        int nodes = a_.n_layer;
+        if (kind == 5) {  // the fast decoder's layers over the 8 codebook positions (4 nodes per layer)
+            for (int cbi = 0; cbi < a_.num_codebooks; ++cbi) enqueue_fast_layers(0, cbi, cbi);
+            nodes = a_.num_codebooks * a_.n_fast_layer * 4;
+        } else if (kind == 6 || kind == 7) {  // fast / slow (audio-range) head GEMV
+            nodes = 16;
+            for (int i = 0; i < nodes; ++i) {
+                if (kind == 6) LmKernels<WT>::head(d_, xf(0), fast_norm_w_, fast_out_w_, fast_out_s_, a_.codebook_size, d_logits_fast_.as<float>(), st_);
+                else LmKernels<WT>::head(d_, x(0), norm_w_, slow_head_w(), slow_head_s(), n_audio_, d_logits_slow_.as<float>(), st_);
+            }
+        } else
         for (int l = 0; l < a_.n_layer; ++l) {
             const LayerW& w = slow_[l];
             KVView kv = slow_kv(l, 0);
@@ -281,7 +292,7 @@ class LM final : public LMBase {
         FS_HIP(hipEventElapsedTime(&ms, ev_[0], ev_[1]));
         (void)hipGraphExecDestroy(ge);
         clear_slow();
-        return ms * 1e3f / (float)(reps * a_.n_layer);
+        return ms * 1e3f / (float)(reps * nodes);
     }
 
     // ------------------------------------------------------------------------------------------ generate_blocking

@@ -134,7 +134,8 @@ int fs_lm_last_stats(fs_lm_t* lm, fs_gen_stats* out);
 void* fs_lm_stream(fs_lm_t* lm);
 /* Measurement hook (bench.py `roofline.dominant_kernel`): average duration in microseconds of ONE launch of a batch-1 decode kernel --
  * kind 0 qkv, 1 attention, 2 wo, 3 ffn_up (RMSNorm + W1||W3 GEMV + SwiGLU), 4 ffn_down -- run as a node of a captured hipGraph that cycles
- * over the slow layers' distinct weights (nothing cache-resident) at KV length kv_len, timed with HIP events on the engine stream.
+ * over the slow layers' distinct weights (nothing cache-resident) at KV length kv_len, timed with HIP events on the engine stream;
+ * kind 5 = average node of the fast decoder's layers over the 8 codebook positions, 6 = fast head GEMV, 7 = slow audio-range head GEMV.
  * Clears the slow KV caches. */
 int fs_lm_bench_kernel(fs_lm_t* lm, int kind, int kv_len, int reps, float* us_per_launch);
 

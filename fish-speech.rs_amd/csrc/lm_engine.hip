@@ -400,10 +400,10 @@ class LM final : public LMBase {
         if (n_frames) *n_frames = n;
     }
 
-    // generate_static_batch (static_batch.rs:282-390) -- first version: rows are independent sequences, so the
-    // lock-step batch is evaluated row after row on KV slot 0 (identical tokens under greedy decoding).  The left
-    // padding with <|im_end|>/0 IS applied because the reference never masks it (dual_ar.rs:589-615); repetition
-    // penalty is a no-op in the reference's batch path for Fish models (static_batch.rs:204-206 => mask stays 1).
+    // generate_static_batch (static_batch.rs:282-390).  bf16 / fp8 handles with n <= min(max_batch, kRows): the MFMA row path below
+    // (rows = sequences).  Otherwise rows are independent sequences evaluated one after another on KV slot 0 (identical tokens under
+    // greedy decoding).  The left padding with <|im_end|>/0 IS applied because the reference never masks it (dual_ar.rs:589-615);
+    // repetition penalty is a no-op in the reference's batch path for Fish models (static_batch.rs:204-206 => mask stays 1).
     void generate_batch(const uint32_t* prompts, const int* lens, int n, int max_new_tokens, const fs_sampling& s, uint64_t seed,
                         uint32_t flags, uint32_t* codes_out, size_t cap, size_t* n_frames) override {
         FS_REQUIRE(n >= 1, "Must have at least one prompt");  // static_batch.rs:69-71

@@ -2712,7 +2712,7 @@ void launch_quant_rows_fp8(uint8_t* dst, float* scales, const float* src, int64_
     FS_LAUNCH_CHECK();
 }
 
-// ---- chunked prefill launchers (bf16 weights only; f32 handles take the sequential decode-kernel path)
+// ---- MFMA row-path launchers (bf16 and fp8 weights; f32 handles take the sequential decode-kernel path)
 template <typename WT>
 bool LmKernels<WT>::has_mfma_prefill() { return std::is_same<WT, bf16_t>::value || std::is_same<WT, fp8_t>::value; }
 

@@ -1,4 +1,4 @@
-// Micro-benchmark of the MFMA skinny GEMM (k_gemm2) in isolation: graph of 48 launches over distinct weights.
+// Micro-benchmark of the MFMA row path (rows_layer: k_prep, k_gemm3 / k_gemm_big, attention) stage by stage: graph of 24 layers over distinct weights.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <functional>

@@ -205,6 +205,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_qkv(const float* __restrict__ x,
     float xr[R::NX], nr[R::NX];
     R::load_x(x, lane, xr);
     R::load_x(norm_w, lane, nr);
+    const float sc = row_scale<WT>(wscale, row);  // fp8: requested in front of the weight stream (an L2 round trip at the tail otherwise)
     typename R::vec wv[R::NCH];
     R::load_w(W + (size_t)row * K, lane, wv);
     FS_ISSUE_FENCE();
@@ -222,7 +223,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_qkv(const float* __restrict__ x,
         const int rk = (r0 - qdim) % kdim, g = rk / Dh, dd = rk % Dh;
         dst = kv_addr<KT>(r0 < qdim + kdim ? kv.k : kv.v, kv.page_table, pos, g, Hk, Dh) + dd;
     }
-    const float sc = row_scale<WT>(wscale, row);
     R::rmsnorm(xr, nr, eps);
     const float d = wave_sum(R::dot(wv, xr)) * sc;
     if (lane == 0) dots[wave] = d;
@@ -409,6 +409,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_wo(const float* __restrict__ par
     const int n_rep = H / Hk;
     typename R::vec wv[R::NCH];
     const float xres = (row < n_rows && lane == 0) ? x[row] : 0.f;
+    const float sc = row_scale<WT>(wscale, min(row, n_rows - 1));  // fp8: in front of the weight stream
     // Few, wide prologue loads (the texture-address unit retires one wave-instruction per ~16 cycles whatever its width),
     // all issued before the weight stream (vmcnt retires in issue order).
     if (!FUSED && nc_launch <= 8) {
@@ -637,7 +638,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_wo(const float* __restrict__ par
     if (row >= n_rows) return;
     float xr[R::NX];
     R::load_x(attn, lane, xr);
-    const float d = wave_sum(R::dot(wv, xr)) * row_scale<WT>(wscale, row);
+    const float d = wave_sum(R::dot(wv, xr)) * sc;
     if (lane == 0) x[row] = xres + d;
 }
 
@@ -654,13 +655,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_ffn_up(const float* __restrict__
     float xr[R::NX], nr[R::NX];
     R::load_x(x, lane, xr);
     R::load_x(norm_w, lane, nr);
+    const float s1 = row_scale<WT>(wscale, 2 * r), s3 = row_scale<WT>(wscale, 2 * r + 1);  // fp8: in front of the weight stream
     typename R::vec w1[R::NCH], w3[R::NCH];
     R::load_w(W13 + (size_t)(2 * r) * K, lane, w1);
     R::load_w(W13 + (size_t)(2 * r + 1) * K, lane, w3);
     FS_ISSUE_FENCE();
     R::rmsnorm(xr, nr, eps);
-    const float a = wave_sum(R::dot(w1, xr)) * row_scale<WT>(wscale, 2 * r);
-    const float b = wave_sum(R::dot(w3, xr)) * row_scale<WT>(wscale, 2 * r + 1);
+    const float a = wave_sum(R::dot(w1, xr)) * s1;
+    const float b = wave_sum(R::dot(w3, xr)) * s3;
     if (lane == 0) act[r] = (a / (1.f + __expf(-a))) * b;  // candle silu = x / (1 + exp(-x))
 }
 
@@ -676,6 +678,7 @@ __global__ __launch_bounds__(KS * 64) void k_ffn_down(const float* __restrict__ 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x;
     const float xres = (threadIdx.x == 0) ? x[row] : 0.f;
+    const float sc = row_scale<WT>(wscale, row);  // fp8: in front of the weight stream
     float xr[R::NX];
     R::load_x(act + wave * (K / KS), lane, xr);
     typename R::vec wv[R::NCH];
@@ -688,7 +691,7 @@ __global__ __launch_bounds__(KS * 64) void k_ffn_down(const float* __restrict__ 
         float t = red[0];
 #pragma unroll
         for (int i = 1; i < KS; ++i) t += red[i];
-        x[row] = xres + t * row_scale<WT>(wscale, row);
+        x[row] = xres + t * sc;
     }
 }
 
@@ -704,11 +707,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_head(const float* __restrict__ x
     float xr[R::NX], nr[R::NX];
     R::load_x(x, lane, xr);
     R::load_x(norm_w, lane, nr);
+    const float sc = row_scale<WT>(wscale, r);  // fp8: in front of the weight stream
     typename R::vec wv[R::NCH];
     R::load_w(W + (size_t)r * K, lane, wv);
     FS_ISSUE_FENCE();
     R::rmsnorm(xr, nr, eps);
-    const float d = wave_sum(R::dot(wv, xr)) * row_scale<WT>(wscale, r);
+    const float d = wave_sum(R::dot(wv, xr)) * sc;
     if (lane == 0) logits[r] = d;
 }
 

@@ -947,7 +947,8 @@ __device__ __forceinline__ u32x4 fp8x8_to_bf16x8(u32x2 v) {
     o.x = r[0]; o.y = r[1]; o.z = r[2]; o.w = r[3];
     return o;
 }
-template <int EPI, int NKS, int RT, bool FP8>
+// HALF: M <= 16 (small static batches) -- rows 16..31 of the only panel do not exist: their operand loads and MFMAs are skipped.
+template <int EPI, int NKS, int RT, bool FP8, bool HALF = false>
 __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* __restrict__ Xf, int M, int K,
                                                const void* __restrict__ Wv, const float* __restrict__ wscale, int N, float* __restrict__ Y, int ldy, size_t slab_stride,
                                                bf16_t* __restrict__ Of, int ldo,
@@ -994,8 +995,10 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* __restrict__ Xf, in
         for (int ks = 0; ks < NKS; ++ks) {
             xf[ks][0] = *reinterpret_cast<const u32x4*>(xp + ks * 2048);          // hi, rows 0..15
             xf[ks][1] = *reinterpret_cast<const u32x4*>(xp + ks * 2048 + 1024);   // lo, rows 0..15
-            xf[ks][2] = *reinterpret_cast<const u32x4*>(xp + ks * 2048 + 512);    // hi, rows 16..31
-            xf[ks][3] = *reinterpret_cast<const u32x4*>(xp + ks * 2048 + 1536);   // lo, rows 16..31
+            if (!HALF) {
+                xf[ks][2] = *reinterpret_cast<const u32x4*>(xp + ks * 2048 + 512);    // hi, rows 16..31
+                xf[ks][3] = *reinterpret_cast<const u32x4*>(xp + ks * 2048 + 1536);   // lo, rows 16..31
+            }
         }
         FS_ISSUE_FENCE();  // every operand load of the panel is in flight before the first MFMA waits (the scheduler would
                            // otherwise meter them out a dozen at a time, one memory round trip per batch)
@@ -1008,7 +1011,7 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* __restrict__ Xf, in
             for (int rt = 0; rt < RT; ++rt) {
                 const bf16x8 af = __builtin_bit_cast(bf16x8, wf[rt][ks]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < (HALF ? 2 : 4); ++j)
                     acc[rt][j >> 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, xf[ks][j]), acc[rt][j >> 1], 0, 0, 0);
             }
         if (!first_panel) __syncthreads();  // the previous panel's epilogue has read `red` (and s_rms)
@@ -2755,9 +2758,15 @@ static void launch_gemm3(int N, int ksplit, int rt, hipStream_t st, const bf16_t
     const dim3 grid((N + 16 * rt - 1) / (16 * rt), ksplit, gz);
 #define FS_GEMM_CASE(nk, r)                                                                                                          \
     do {                                                                                                                             \
-        if (wscale)                                                                                                                  \
+        if (wscale && M <= 16)                                                                                                       \
+            hipLaunchKernelGGL((k_gemm3<EPI, nk, r, true, true>), grid, dim3(256), 0, st, Xf, M, K, W, wscale, N, Y, ldy, slab_stride, Of, \
+                               ldo, cos_t, sin_t, state, kv, H, Hk, Dh, rm, na);                                                 \
+        else if (wscale)                                                                                                             \
             hipLaunchKernelGGL((k_gemm3<EPI, nk, r, true>), grid, dim3(256), 0, st, Xf, M, K, W, wscale, N, Y, ldy, slab_stride, Of, ldo,  \
                                cos_t, sin_t, state, kv, H, Hk, Dh, rm, na);                                                      \
+        else if (M <= 16)                                                                                                            \
+            hipLaunchKernelGGL((k_gemm3<EPI, nk, r, false, true>), grid, dim3(256), 0, st, Xf, M, K, W, wscale, N, Y, ldy, slab_stride, Of, \
+                               ldo, cos_t, sin_t, state, kv, H, Hk, Dh, rm, na);                                                 \
         else                                                                                                                         \
             hipLaunchKernelGGL((k_gemm3<EPI, nk, r, false>), grid, dim3(256), 0, st, Xf, M, K, W, wscale, N, Y, ldy, slab_stride, Of, ldo, \
                                cos_t, sin_t, state, kv, H, Hk, Dh, rm, na);                                                      \

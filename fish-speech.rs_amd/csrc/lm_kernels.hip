@@ -275,7 +275,10 @@ __global__ __launch_bounds__((AttnGeom<WT, DH>::NW * 64)) void k_attn_decode(con
     constexpr int NLD = TW * LPT / 64;       // 16-B loads per lane per tile
     static_assert(TW % NTS == 0 && NLD >= 1, "attention geometry");
     using vec = typename WTr<WT>::vec;
-    const int g = blockIdx.x / (nc_launch * hsplit), hb = (blockIdx.x / nc_launch) % hsplit * NREP, c = blockIdx.x % nc_launch;  // nc_launch <= n_chunks_max chunks are launched
+    // block id = head part * (Hk * nc_launch) + (kv head * nc_launch + chunk): with Hk * nc_launch a multiple of 8 the blocks that share
+    // a K/V tile get ids congruent mod 8, i.e. the same XCD and L2 (workgroups go round-robin over the 8 XCDs)
+    const int tile = blockIdx.x % (Hk * nc_launch), hb = (int)(blockIdx.x / (Hk * nc_launch)) * NREP;
+    const int g = tile / nc_launch, c = tile % nc_launch;  // nc_launch <= n_chunks_max chunks are launched
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __shared__ __attribute__((aligned(16))) WT sk[NW][TW * DH];
     __shared__ __attribute__((aligned(16))) WT sv[NW][TW * DH];

@@ -134,11 +134,14 @@ __global__ __launch_bounds__(256) void k_conv1d(const float* __restrict__ x, int
 // registers).  Input channels are staged 16 at a time into LDS exactly like k_conv1d (x window [16][128 + halo], weights
 // [16*K][64]); one MFMA consumes TWO reduction items: lanes 0..31 feed channel 2p, lanes 32..63 channel 2p+1 of the same tap.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-template <int ICH>
+// OT = output channels per block: 64 (wave = 32 channels x 64 samples, two MFMA tiles) or 32 (thin late stages with 16..63
+// channels: wave = 32 channels x 32 samples, one tile; rows >= Cout are zero-filled and never stored)
+template <int ICH, int OT>
 __global__ __launch_bounds__(256) void k_conv1d_mfma(const float* __restrict__ x, int Cin, int T, const float* __restrict__ wt /*[Cin][K][Cout]*/,
                                                      const float* __restrict__ bias, int Cout, int K, int dil, int pre_silu, int epi,
                                                      const float* __restrict__ res, const float* __restrict__ gamma, float* __restrict__ y, int ps) {
-    constexpr int OT = 64, TT = 128;
+    constexpr int TT = 128, NT = OT == 64 ? 2 : 1;  // MFMA tiles (32 samples each) per wave
+    static_assert(OT == 64 || OT == 32, "block height");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int halo = (K - 1) * dil;
     const int XS = TT + halo;
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(256) void k_conv1d_mfma(const float* __restrict__ x
     float* ws = smem + ((ICH * XS + 3) & ~3);  // [ICH*K][OT], 16-byte aligned
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, c = lane & 31;
-    const int ob = (wave & 1) * 32, tb = (wave >> 1) * 64;
+    const int ob = OT == 64 ? (wave & 1) * 32 : 0, tb = OT == 64 ? (wave >> 1) * 64 : wave * 32;
     const int t0 = blockIdx.x * TT, o0 = blockIdx.y * OT;
     const size_t boff_in = (size_t)blockIdx.z * Cin * T, boff_out = (size_t)blockIdx.z * Cout * T;
     f32x16 acc0, acc1;
@@ -167,22 +170,23 @@ __global__ __launch_bounds__(256) void k_conv1d_mfma(const float* __restrict__ x
                 xv[i] = (tl < XS && i < nic && t >= 0 && t < T) ? x[boff_in + (size_t)(i0 + i) * T + t] : 0.f;
             const int rows = ICH * K, rows_valid = nic * K;
             if (o0 + OT <= Cout && (Cout & 3) == 0) {
-                constexpr int NW4 = 13;  // ceil(16 * K * 16 / 256) for K <= 13
+                constexpr int Q4 = OT / 4;                          // float4 per weight row of the tile
+                constexpr int NW4 = (16 * 13 * Q4 + 255) / 256;     // ceil(ICH * K * Q4 / 256) for K <= 13
                 float4 wv[NW4];
 #pragma unroll
                 for (int j = 0; j < NW4; ++j) {
-                    const int e = j * 256 + (int)threadIdx.x, rr = e >> 4, q = e & 15;
+                    const int e = j * 256 + (int)threadIdx.x, rr = e / Q4, q = e % Q4;
                     wv[j] = (rr < rows_valid) ? *reinterpret_cast<const float4*>(wt + ((size_t)i0 * K + rr) * Cout + o0 + q * 4)
                                               : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
 #pragma unroll
                 for (int j = 0; j < NW4; ++j) {
-                    const int e = j * 256 + (int)threadIdx.x, rr = e >> 4, q = e & 15;
+                    const int e = j * 256 + (int)threadIdx.x, rr = e / Q4, q = e % Q4;
                     if (rr < rows) *reinterpret_cast<float4*>(ws + rr * OT + q * 4) = wv[j];
                 }
             } else {
                 for (int e = threadIdx.x; e < rows * OT; e += 256) {
-                    const int rr = e >> 6, o = e & 63;
+                    const int rr = e / OT, o = e % OT;
                     ws[e] = (rr < rows_valid && o0 + o < Cout) ? wt[((size_t)i0 * K + rr) * Cout + o0 + o] : 0.f;
                 }
             }
@@ -202,9 +206,12 @@ __global__ __launch_bounds__(256) void k_conv1d_mfma(const float* __restrict__ x
 #pragma unroll
             for (int p = 0; p < ICH / 2; ++p) {
                 const float a = wk[p * 2 * K * OT];
-                const float b0 = xk[p * 2 * XS], b1 = xk[p * 2 * XS + 32];
+                const float b0 = xk[p * 2 * XS];
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+                if (NT == 2) {
+                    const float b1 = xk[p * 2 * XS + 32];
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+                }
             }
         }
         __syncthreads();
@@ -216,7 +223,7 @@ __global__ __launch_bounds__(256) void k_conv1d_mfma(const float* __restrict__ x
         if (o >= Cout) continue;
         const float b = bias[o / ps];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NT; ++j) {
             const int t = t0 + tb + j * 32 + c;
             if (t >= T) continue;
             float v = (j ? acc1[r] : acc0[r]) + b;
@@ -331,7 +338,12 @@ static void conv1d_launch(const float* x, int B, int Cin, int T, const ConvW& w,
         constexpr int ICH = 16;
         const size_t smem = sizeof(float) * ((((size_t)ICH * (128 + halo) + 3) & ~(size_t)3) + (size_t)ICH * K * 64);
         FS_REQUIRE(smem <= 64 * 1024 && 128 + halo <= 256 && K <= 13, "conv tile does not fit the MFMA kernel (LDS / window / taps)");
-        hipLaunchKernelGGL((k_conv1d_mfma<ICH>), dim3((T + 127) / 128, (Cout + 63) / 64, B), dim3(256), smem, st, x, Cin, T, w.wt, w.b, Cout, K,
+        hipLaunchKernelGGL((k_conv1d_mfma<ICH, 64>), dim3((T + 127) / 128, (Cout + 63) / 64, B), dim3(256), smem, st, x, Cin, T, w.wt, w.b, Cout, K,
+                           dil, pre_silu ? 1 : 0, epi, res, gamma, y, ps);
+    } else if (Cout >= 16 && Cin >= 16 && 128 + halo <= 256 && K <= 13) {  // thin late stages: 32 ch x 128 t per block, still on the matrix cores
+        constexpr int ICH = 16;
+        const size_t smem = sizeof(float) * ((((size_t)ICH * (128 + halo) + 3) & ~(size_t)3) + (size_t)ICH * K * 32);
+        hipLaunchKernelGGL((k_conv1d_mfma<ICH, 32>), dim3((T + 127) / 128, (Cout + 31) / 32, B), dim3(256), smem, st, x, Cin, T, w.wt, w.b, Cout, K,
                            dil, pre_silu ? 1 : 0, epi, res, gamma, y, ps);
     } else if (Cout >= 64) launch(I8(), I4(), I8());   // 64 ch x 128 t
     else if (Cout >= 32) launch(I4(), I4(), I8());     // 32 ch x 128 t

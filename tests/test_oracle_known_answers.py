@@ -107,3 +107,32 @@ def test_synth_generator_spec():
         assert np.array_equal(got, exp)
     big = orc.synth("x", 200000, 3, 0.0, 1.0)
     assert abs(float(big.mean())) < 0.01 and abs(float(big.std()) - 1.0) < 0.01
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 1, 64), (1, 2, 166, 64)])
+def test_repeat_kv_is_head_index_division(shape):  # lm/ops/repeat_kv.rs:126-162 (the reference's only kernel-level test)
+    """RepeatKV(n_rep = 8) == cat-reshape == "query head h reads kv head h // n_rep" (how every fishrt attention kernel and the
+    oracle index the cache instead of materialising the repeat), at the two shapes the reference tests."""
+    rng = np.random.RandomState(0)
+    x = rng.standard_normal(shape).astype(np.float32)
+    b, hk, t, d = shape
+    n_rep = 8
+    cat_reshape = np.concatenate([x[:, :, None]] * n_rep, axis=2).reshape(b, hk * n_rep, t, d)  # dual_ar.rs:336-357 fallback
+    by_index = x[:, np.arange(hk * n_rep) // n_rep]
+    assert np.array_equal(cat_reshape, by_index)
+    assert np.array_equal(cat_reshape, np.repeat(x, n_rep, axis=1))
+
+
+def test_rescale_semantic_tokens_arithmetic():  # generate/utils.rs:36-56 (contiguous Fish-1.5 case :45-46) + :13-16
+    """Sampling happens over logits[im_end_id:], so index 0 is <|im_end|> and index k is <|semantic:k-1|> = semantic_start + k - 1;
+    with im_end_id == semantic_start_id - 1 both branches of the reference collapse to idx + im_end_id."""
+    im_end, sem0 = 100011, 100012
+    idx = np.array([0, 1, 2, 1024], np.int64)
+    generic = np.where(idx == 0, im_end, idx - 1 + sem0)  # the reference's non-contiguous branch
+    assert np.array_equal(idx + im_end, generic)
+
+
+def test_default_voice_fixture_properties():  # voices-template/default.npy (SURVEY.md §8c)
+    v = np.load(os.path.join(os.path.dirname(__file__), "golden", "default_voice_codes.npy"))
+    assert v.shape == (8, 274) and v.dtype == np.int64
+    assert v.min() >= 3 and v.max() <= 999  # FSQ indices of the (8, 5, 5, 5) levels: < 1000

@@ -8,6 +8,7 @@
 // trims k - stride samples on the right (utils/mod.rs:110-122); SiLU pre-activations, bias, GELU, gamma/residual and the
 // final tanh are fused into the producing / consuming convolution.
 #include <hip/hip_runtime.h>
+#include <set>
 
 #include "codec_kernels.h"
 #include "fs_common.h"
@@ -136,12 +137,15 @@ __global__ __launch_bounds__(256) void k_conv1d(const float* __restrict__ x, int
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 // OT = output channels per block: 64 (wave = 32 channels x 64 samples, two MFMA tiles) or 32 (thin late stages with 16..63
 // channels: wave = 32 channels x 32 samples, one tile; rows >= Cout are zero-filled and never stored)
-template <int ICH, int OT>
+// TT = samples per block: 128, or 256 where the grid stays large (twice the MFMA work per staged weight tile and per barrier).
+template <int ICH, int OT, int TT>
 __global__ __launch_bounds__(256) void k_conv1d_mfma(const float* __restrict__ x, int Cin, int T, const float* __restrict__ wt /*[Cin][K][Cout]*/,
                                                      const float* __restrict__ bias, int Cout, int K, int dil, int pre_silu, int epi,
                                                      const float* __restrict__ res, const float* __restrict__ gamma, float* __restrict__ y, int ps) {
-    constexpr int TT = 128, NT = OT == 64 ? 2 : 1;  // MFMA tiles (32 samples each) per wave
-    static_assert(OT == 64 || OT == 32, "block height");
+    constexpr int WT_ = OT == 64 ? TT / 2 : TT / 4;  // samples per wave
+    constexpr int NT = WT_ / 32;                     // MFMA tiles (32 samples each) per wave
+    constexpr int NPX = TT / 128;                     // window elements per thread per row (XS = TT + halo <= 256 * NPX, checked by the launcher)
+    static_assert((OT == 64 || OT == 32) && (TT == 128 || TT == 256), "block shape");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int halo = (K - 1) * dil;
     const int XS = TT + halo;
@@ -149,12 +153,14 @@ __global__ __launch_bounds__(256) void k_conv1d_mfma(const float* __restrict__ x
     float* ws = smem + ((ICH * XS + 3) & ~3);  // [ICH*K][OT], 16-byte aligned
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, c = lane & 31;
-    const int ob = OT == 64 ? (wave & 1) * 32 : 0, tb = OT == 64 ? (wave >> 1) * 64 : wave * 32;
+    const int ob = OT == 64 ? (wave & 1) * 32 : 0, tb = OT == 64 ? (wave >> 1) * WT_ : wave * WT_;
     const int t0 = blockIdx.x * TT, o0 = blockIdx.y * OT;
     const size_t boff_in = (size_t)blockIdx.z * Cin * T, boff_out = (size_t)blockIdx.z * Cout * T;
-    f32x16 acc0, acc1;
+    f32x16 acc[NT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     static_assert(ICH % 2 == 0, "channel pairs");
     for (int i0 = 0; i0 < Cin; i0 += ICH) {
         const int nic = min(ICH, Cin - i0);
@@ -163,11 +169,14 @@ __global__ __launch_bounds__(256) void k_conv1d_mfma(const float* __restrict__ x
         // re-laid [Cin][K][Cout] tensor ((i0 + i) * K + k == i0 * K + row), read as float4
         // (all loads of a stage are issued before the first LDS store: 16 x-window rows + up to 13 weight float4 per thread)
         {
-            const int tl = threadIdx.x, t = t0 + tl - halo;  // XS <= 256 (checked by the launcher): one window element per thread per row
-            float xv[ICH];
+            float xv[NPX][ICH];  // window element tl + 256 * q of every row
 #pragma unroll
-            for (int i = 0; i < ICH; ++i)
-                xv[i] = (tl < XS && i < nic && t >= 0 && t < T) ? x[boff_in + (size_t)(i0 + i) * T + t] : 0.f;
+            for (int q = 0; q < NPX; ++q) {
+                const int tl = (int)threadIdx.x + 256 * q, t = t0 + tl - halo;
+#pragma unroll
+                for (int i = 0; i < ICH; ++i)
+                    xv[q][i] = (tl < XS && i < nic && t >= 0 && t < T) ? x[boff_in + (size_t)(i0 + i) * T + t] : 0.f;
+            }
             const int rows = ICH * K, rows_valid = nic * K;
             if (o0 + OT <= Cout && (Cout & 3) == 0) {
                 constexpr int Q4 = OT / 4;                          // float4 per weight row of the tile
@@ -190,9 +199,13 @@ __global__ __launch_bounds__(256) void k_conv1d_mfma(const float* __restrict__ x
                     ws[e] = (rr < rows_valid && o0 + o < Cout) ? wt[((size_t)i0 * K + rr) * Cout + o0 + o] : 0.f;
                 }
             }
-            if (tl < XS) {
 #pragma unroll
-                for (int i = 0; i < ICH; ++i) xs[i * XS + tl] = pre_silu ? dsilu(xv[i]) : xv[i];
+            for (int q = 0; q < NPX; ++q) {
+                const int tl = (int)threadIdx.x + 256 * q;
+                if (tl < XS) {
+#pragma unroll
+                    for (int i = 0; i < ICH; ++i) xs[i * XS + tl] = pre_silu ? dsilu(xv[q][i]) : xv[q][i];
+                }
             }
         }
         __syncthreads();
@@ -206,12 +219,9 @@ __global__ __launch_bounds__(256) void k_conv1d_mfma(const float* __restrict__ x
 #pragma unroll
             for (int p = 0; p < ICH / 2; ++p) {
                 const float a = wk[p * 2 * K * OT];
-                const float b0 = xk[p * 2 * XS];
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-                if (NT == 2) {
-                    const float b1 = xk[p * 2 * XS + 32];
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
-                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xk[p * 2 * XS + 32 * j], acc[j], 0, 0, 0);
             }
         }
         __syncthreads();
@@ -226,7 +236,7 @@ __global__ __launch_bounds__(256) void k_conv1d_mfma(const float* __restrict__ x
         for (int j = 0; j < NT; ++j) {
             const int t = t0 + tb + j * 32 + c;
             if (t >= T) continue;
-            float v = (j ? acc1[r] : acc0[r]) + b;
+            float v = acc[j][r] + b;
             const size_t oi = boff_out + (size_t)(o / ps) * T * ps + (size_t)t * ps + o % ps;  // (see k_conv1d)
             if (epi == CEPI_GELU) v = dgelu(v);
             else if (epi == CEPI_GAMMA_RES) v = res[oi] + gamma[o] * v;
@@ -334,17 +344,29 @@ static void conv1d_launch(const float* x, int B, int Cin, int T, const ConvW& w,
     };
     using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I4 = std::integral_constant<int, 4>;
     using I8 = std::integral_constant<int, 8>; using I16 = std::integral_constant<int, 16>;
-    if (Cout >= 64 && Cin >= 16) {                     // matrix cores: 64 ch x 128 t per block
+    const bool mfma_ok = Cin >= 16 && Cout >= 16 && K <= 13 && halo <= 256;
+    if (mfma_ok) {  // matrix cores: 64 (or, for the thin late stages, 32) channels x 128 or 256 samples per block
         constexpr int ICH = 16;
-        const size_t smem = sizeof(float) * ((((size_t)ICH * (128 + halo) + 3) & ~(size_t)3) + (size_t)ICH * K * 64);
-        FS_REQUIRE(smem <= 64 * 1024 && 128 + halo <= 256 && K <= 13, "conv tile does not fit the MFMA kernel (LDS / window / taps)");
-        hipLaunchKernelGGL((k_conv1d_mfma<ICH, 64>), dim3((T + 127) / 128, (Cout + 63) / 64, B), dim3(256), smem, st, x, Cin, T, w.wt, w.b, Cout, K,
-                           dil, pre_silu ? 1 : 0, epi, res, gamma, y, ps);
-    } else if (Cout >= 16 && Cin >= 16 && 128 + halo <= 256 && K <= 13) {  // thin late stages: 32 ch x 128 t per block, still on the matrix cores
-        constexpr int ICH = 16;
-        const size_t smem = sizeof(float) * ((((size_t)ICH * (128 + halo) + 3) & ~(size_t)3) + (size_t)ICH * K * 32);
-        hipLaunchKernelGGL((k_conv1d_mfma<ICH, 32>), dim3((T + 127) / 128, (Cout + 31) / 32, B), dim3(256), smem, st, x, Cin, T, w.wt, w.b, Cout, K,
-                           dil, pre_silu ? 1 : 0, epi, res, gamma, y, ps);
+        const int OT = Cout >= 64 ? 64 : 32;
+        // 256-sample blocks (twice the MFMA work per staged weight tile / barrier) where >= 512 blocks remain
+        const bool wide = (long long)((T + 255) / 256) * ((Cout + OT - 1) / OT) * B >= 512 && 256 + halo <= 512;
+        const int TT = wide ? 256 : 128;
+        FS_REQUIRE(TT + halo <= (TT == 256 ? 512 : 256), "conv window does not fit the MFMA kernel's staging");
+        const size_t smem = sizeof(float) * ((((size_t)ICH * (TT + halo) + 3) & ~(size_t)3) + (size_t)ICH * K * OT);
+        FS_REQUIRE(smem <= 128 * 1024, "conv tile does not fit LDS");
+        auto go = [&](auto kern) {
+            if (smem > 64 * 1024) {  // above the default dynamic-LDS limit: raise it once per kernel (not inside a graph capture)
+                static thread_local std::set<const void*> raised;
+                if (raised.insert((const void*)kern).second)
+                    FS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+            }
+            hipLaunchKernelGGL(kern, dim3((T + TT - 1) / TT, (Cout + OT - 1) / OT, B), dim3(256), smem, st, x, Cin, T, w.wt, w.b, Cout, K, dil,
+                               pre_silu ? 1 : 0, epi, res, gamma, y, ps);
+        };
+        if (OT == 64 && TT == 256) go(k_conv1d_mfma<ICH, 64, 256>);
+        else if (OT == 64) go(k_conv1d_mfma<ICH, 64, 128>);
+        else if (TT == 256) go(k_conv1d_mfma<ICH, 32, 256>);
+        else go(k_conv1d_mfma<ICH, 32, 128>);
     } else if (Cout >= 64) launch(I8(), I4(), I8());   // 64 ch x 128 t
     else if (Cout >= 32) launch(I4(), I4(), I8());     // 32 ch x 128 t
     else if (Cout >= 16) launch(I2(), I8(), I16());    // 16 ch x 256 t

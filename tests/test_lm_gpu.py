@@ -354,3 +354,36 @@ def test_mid_static_batch_group_prefill_vs_oracle(B, span, monkeypatch):
     monkeypatch.delenv("FISHRT_NO_GROUP_PREFILL")
     assert all(np.array_equal(a, b) for a, b in zip(got, seq))
     lm.close()
+
+
+@pytest.mark.parametrize("which", ["tiny", "mid"])
+def test_random_chunked_prefill_schedules_vs_oracle(which):
+    """24 random prompts (1..90 tokens, random VQ columns) fed as random chunk schedules (single tokens, short and long chunks,
+    i.e. decode kernels, small-M and multi-panel MFMA passes over growing cached prefixes; head_dim 32 -> chunked row attention,
+    head_dim 64 -> flash prefill) -- the last chunk's logits / hidden state and the KV length against the oracle."""
+    if which == "tiny":
+        lm = _tiny("bf16")
+        o = orc.OracleLM(orc.TINY).load_synthetic(SEED, bf16=True); o.set_kv_round_bf16(True)
+    else:
+        lm, o = _mid("bf16"), _omid()
+    rng = np.random.RandomState(1234)
+    worst = 0.0
+    for case in range(24):
+        L = int(rng.randint(1, 91))
+        p = np.zeros((9, L), np.uint32)
+        p[0] = rng.randint(0, 400, L)
+        for col in np.nonzero(rng.rand(L) < 0.2)[0]:
+            p[0, col] = 401 + rng.randint(0, 64)
+            p[1:, col] = rng.randint(0, 64, 8)
+        cuts = sorted(set([0, L] + [int(c) for c in rng.randint(0, L + 1, rng.randint(0, 5))]))
+        lm.clear_slow_layer_caches(); o.clear_slow()
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            chunk = np.ascontiguousarray(p[:, a:b])
+            lg, hg = lm.forward_generate(chunk, a)
+            lo, ho = o.forward_generate(chunk, a)
+        assert lm.curr_kv_size() == L
+        np.testing.assert_allclose(hg, ho, **TOLBF, err_msg=f"case {case}: L={L} cuts={cuts}")
+        np.testing.assert_allclose(lg, lo, **TOLBF, err_msg=f"case {case}: L={L} cuts={cuts}")
+        worst = max(worst, float(np.abs(lg - lo).max()))
+    print(f"{which}: 24 random chunk schedules, worst |dlogit| {worst:.2e}")
+    lm.close()

@@ -387,3 +387,29 @@ def test_random_chunked_prefill_schedules_vs_oracle(which):
         worst = max(worst, float(np.abs(lg - lo).max()))
     print(f"{which}: 24 random chunk schedules, worst |dlogit| {worst:.2e}")
     lm.close()
+
+
+@pytest.mark.parametrize("which", ["tiny", "mid"])
+def test_static_batch_sizes_around_panel_boundaries_vs_oracle(which):
+    """Static batches of 1, 2, 15, 16, 17, 33 and 64 rows (half-panel GEMM variant up to 16 rows, one / two / several 32-row panels,
+    fused row attention with and without the head split) with ragged prompts -- every row against the oracle's static_batch."""
+    if which == "tiny":
+        lm = _tiny("bf16", 64)
+        o = orc.OracleLM(orc.TINY).load_synthetic(SEED, bf16=True); o.set_kv_round_bf16(True)
+    else:
+        lm, o = _mid("bf16", 64), _omid()
+    rng = np.random.RandomState(77)
+    kw = dict(seed=42, temp=0.0, top_p=1.0, top_k=0, ignore_eos=True)
+    for B in (1, 2, 15, 16, 17, 33, 64):
+        lens = [int(x) for x in rng.randint(2, 40, B)]
+        prompts = _batch_prompts(1000 + B, lens)
+        M = max(lens) + 12
+        got = lm.generate_static_batch(prompts, M, **kw)
+        exp = o.generate_batch(prompts, M, **kw)
+        assert [g.shape for g in got] == [e.shape for e in exp]
+        agree = [int(np.argmin((g == e).all(0))) if not (g == e).all() else g.shape[1] for g, e in zip(got, exp)]
+        # bf16 near-ties (flat logits of random weights) flip a few rows somewhere in a 14-frame free run (measured 5 of 64 rows, at
+        # frames 2..13, i.e. ~0.06 % of the greedy decisions); a wrong row / position / panel mapping breaks every row at frame 0
+        nf = got[0].shape[1]
+        assert sum(a == nf for a in agree) >= 0.85 * B and min(agree) >= 1 and np.mean(agree) >= 0.9 * nf, (B, agree)
+    lm.close()

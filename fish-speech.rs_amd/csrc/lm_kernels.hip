@@ -1279,10 +1279,14 @@ __global__ __launch_bounds__(256) void k_attn_small_rows(const float* __restrict
 // scored), every lane group keeps a running (max, sum, o) (online softmax), the waves meet once in LDS and the normalised result
 // goes straight into the fragment-major hi/lo input of the Wo GEMM -- replaces k_attn_decode over (chunks x rows) blocks +
 // k_attn_combine (two graph nodes and the partials round trip) for the rows-are-sequences passes.
-template <typename WT, int DH, int NREP>
+// PART (batch-1 decode over a LONG prefix, > 8 chunks of 128 tokens): blockIdx.z = super-chunk of `tpb` consecutive chunks; instead
+// of the normalised hi/lo row the block leaves {o, m, l} in slot blockIdx.z of k_attn_decode's partials layout, so that k_wo always
+// merges <= 8 partials in registers (its general LDS merge over 32..64 chunks costs 9..16 us per layer at 4..8 k tokens).
+template <typename WT, int DH, int NREP, bool PART = false>
 __global__ __launch_bounds__((AttnGeom<WT, DH>::NW * 64)) void k_attn_rows(const float* __restrict__ q_all, KVView kv,
                                                    const SeqState* __restrict__ state, int Hk, int pos_step, int pt_stride,
-                                                   bf16_t* __restrict__ Ohi, int hsplit) {
+                                                   bf16_t* __restrict__ Ohi, int hsplit, float* __restrict__ part_all = nullptr,
+                                                   int n_chunks_max = 0, int tpb = 1 << 30) {
     // hsplit > 1: the query heads of a kv group are spread over hsplit blocks of NREP heads each (small batches: more blocks,
     // less VALU work per wave; the K/V tiles are then read hsplit times, from L2)
     const int g = blockIdx.x / hsplit, hb = (blockIdx.x % hsplit) * NREP, mrow = blockIdx.y;
@@ -1299,7 +1303,9 @@ __global__ __launch_bounds__((AttnGeom<WT, DH>::NW * 64)) void k_attn_rows(const
     __shared__ __attribute__((aligned(16))) WT sv[NW][TW * DH];
     __shared__ float sp[NW][NREP][NTS][DH + 2];
     const int T = state->pos + 1 + mrow * pos_step;  // the row's own K/V were appended by the qkv stage
-    const int nc = (T + CH - 1) / CH;
+    const int nc_all = (T + CH - 1) / CH;
+    const int c0 = PART ? (int)blockIdx.z * tpb : 0, nc = PART ? min(nc_all, c0 + tpb) : nc_all;  // this block's chunks [c0, nc)
+    if (c0 >= nc) return;  // super-chunk past the current length (the graph bucket launches a power of two of them)
     vec kreg[NLD], vreg[NLD];
     auto load_tiles = [&](int c) {  // chunk c: this wave's TW tokens live in one page
         const int t_base = __builtin_amdgcn_readfirstlane(c * CH + wave * TW);
@@ -1314,7 +1320,7 @@ __global__ __launch_bounds__((AttnGeom<WT, DH>::NW * 64)) void k_attn_rows(const
             vreg[i] = *reinterpret_cast<const vec*>(vpage + (size_t)(t % KV_PAGE) * DH + sl * EPL);
         }
     };
-    load_tiles(0);
+    load_tiles(c0);
     const int gi = lane / LPT, sub = lane % LPT;
     const int rl = gi % NRP, ts = gi / NRP;
     constexpr bool POW2 = (DH == 64 || DH == 16 || DH == 256);
@@ -1333,7 +1339,7 @@ __global__ __launch_bounds__((AttnGeom<WT, DH>::NW * 64)) void k_attn_rows(const
 #pragma unroll
         for (int i = 0; i < EPL; ++i) orun[hp][i] = 0.f;
     }
-    for (int c = 0; c < nc; ++c) {
+    for (int c = c0; c < nc; ++c) {
         const int t_base = c * CH + wave * TW;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
@@ -1402,11 +1408,17 @@ __global__ __launch_bounds__((AttnGeom<WT, DH>::NW * 64)) void k_attn_rows(const
                 L += sp[w][r][k][DH + 1] * cf;
                 O += sp[w][r][k][dd] * cf;
             }
-        bf16_t hi, lo;
-        split_bf16(O / L, hi, lo);
-        const int col = (g * GH + hb + r) * DH + dd;
-        Ohi[frag_off(mrow, col, 0, H * DH)] = hi;
-        Ohi[frag_off(mrow, col, 1, H * DH)] = lo;
+        if (PART) {
+            float* dst = part_all + (((size_t)mrow * H + g * GH + hb + r) * n_chunks_max + blockIdx.z) * (DH + 2);
+            dst[dd] = O;
+            if (dd == 0) { dst[DH] = mn; dst[DH + 1] = L; }
+        } else {
+            bf16_t hi, lo;
+            split_bf16(O / L, hi, lo);
+            const int col = (g * GH + hb + r) * DH + dd;
+            Ohi[frag_off(mrow, col, 0, H * DH)] = hi;
+            Ohi[frag_off(mrow, col, 1, H * DH)] = lo;
+        }
     }
 }
 
@@ -2522,6 +2534,14 @@ void LmKernels<WT>::qkv(const ModelDims& d, const float* x, const LayerW& w, con
 template <typename WT>
 int LmKernels<WT>::attn_chunk() { return AttnGeom<KVT<WT>, 64>::NW * AttnGeom<KVT<WT>, 64>::TW; }  // same for every head_dim
 
+// batch-1 decode over more than 8 chunks: attention blocks take `tpb` consecutive chunks each so that k_wo merges 8 partials
+// (FISHRT_ATTN_SUPERCHUNK=0 disables: tuning / test hook)
+template <typename WT>
+static int attn_tiles_per_block(const ModelDims& d, int nc_launch) {
+    static const bool on = [] { const char* e = std::getenv("FISHRT_ATTN_SUPERCHUNK"); return !e || std::atoi(e) != 0; }();
+    if (!on || std::is_same<WT, float>::value || d.Dh != 64 || d.n_rep != 8 || nc_launch <= 8) return 1;
+    return (nc_launch + 7) / 8;
+}
 template <typename WT>
 void LmKernels<WT>::attn_decode(const ModelDims& d, const float* q, KVView kv, const SeqState* state, float* part,
                                 int n_chunks_max, int nc_launch, hipStream_t st) {
@@ -2529,6 +2549,13 @@ void LmKernels<WT>::attn_decode(const ModelDims& d, const float* q, KVView kv, c
     const int grid = d.Hk * nc_launch;
     FS_REQUIRE(n_chunks_max <= 128, "attention supports at most 128 chunks per sequence");
     static const int hs8 = [] { const char* e = std::getenv("FISHRT_ATTN_HSPLIT"); return e ? std::atoi(e) : 4; }();  // tuning hook: 1, 2 or 4
+    if (const int tpb = attn_tiles_per_block<WT>(d, nc_launch); tpb > 1) {
+        if constexpr (!std::is_same<WT, float>::value)
+            hipLaunchKernelGGL((k_attn_rows<KVT<WT>, 64, 2, true>), dim3(d.Hk * 4, 1, (nc_launch + tpb - 1) / tpb), dim3(AttnGeom<KVT<WT>, 64>::NW * 64), 0,
+                               st, q, kv, state, d.Hk, 0, 0, (bf16_t*)nullptr, 4, part, n_chunks_max, tpb);
+        FS_LAUNCH_CHECK();
+        return;
+    }
     if (d.Dh == 64 && d.n_rep == 8 && hs8 == 8 && !std::is_same<WT, float>::value)
         hipLaunchKernelGGL((k_attn_decode<KVT<WT>, 64, 1>), dim3(grid * 8), dim3(AttnGeom<KVT<WT>, 64>::NW * 64), 0, st, q, kv, state, part, d.Hk, n_chunks_max, nc_launch, 0, 0, 8);
     else if (d.Dh == 64 && d.n_rep == 8 && hs8 == 4 && !std::is_same<WT, float>::value)
@@ -2550,8 +2577,13 @@ void LmKernels<WT>::attn_decode(const ModelDims& d, const float* q, KVView kv, c
 template <typename WT>
 void LmKernels<WT>::wo(const ModelDims& d, const float* part, int n_chunks_max, int nc_launch, const SeqState* state, const float* q,
                        KVView kv, int fused_T, const LayerW& w, float* x, hipStream_t st) {
-    if (fused_T <= 0) FS_REQUIRE(nc_launch >= 1 && nc_launch <= n_chunks_max, "bad attention chunk count");
-    else nc_launch = 1;
+    int chunk = attn_chunk();
+    if (fused_T <= 0) {
+        FS_REQUIRE(nc_launch >= 1 && nc_launch <= n_chunks_max, "bad attention chunk count");
+        const int tpb = attn_tiles_per_block<WT>(d, nc_launch);  // attn_decode left one partial per super-chunk
+        chunk *= tpb;
+        nc_launch = (nc_launch + tpb - 1) / tpb;
+    } else nc_launch = 1;
     constexpr int WAVES = 4;
     const int grid = (d.dim + WAVES - 1) / WAVES;
     FS_REQUIRE(fused_T <= 8 && d.H <= 32 && d.H * 8 * 2 <= WAVES * 64 && d.dim <= 4 * WAVES * 64, "fused attention supports at most 8 cached tokens and 16 heads");
@@ -2561,10 +2593,10 @@ void LmKernels<WT>::wo(const ModelDims& d, const float* part, int n_chunks_max, 
         auto go = [&](auto fused, auto dh) {
             if (w.cache_resident)
                 hipLaunchKernelGGL((k_wo<WT, K, WAVES, decltype(fused)::value, decltype(dh)::value, false>), dim3(grid), dim3(WAVES * 64), 0,
-                                   st, part, n_chunks_max, attn_chunk(), state, q, kv, fused_T, (const WT*)w.wo, x, d.H, d.Hk, d.dim, w.s_o, nc_launch);
+                                   st, part, n_chunks_max, chunk, state, q, kv, fused_T, (const WT*)w.wo, x, d.H, d.Hk, d.dim, w.s_o, nc_launch);
             else
                 hipLaunchKernelGGL((k_wo<WT, K, WAVES, decltype(fused)::value, decltype(dh)::value, true>), dim3(grid), dim3(WAVES * 64), 0,
-                                   st, part, n_chunks_max, attn_chunk(), state, q, kv, fused_T, (const WT*)w.wo, x, d.H, d.Hk, d.dim, w.s_o, nc_launch);
+                                   st, part, n_chunks_max, chunk, state, q, kv, fused_T, (const WT*)w.wo, x, d.H, d.Hk, d.dim, w.s_o, nc_launch);
         };
         using T = std::true_type; using F = std::false_type;
         using D64 = std::integral_constant<int, 64>; using D32 = std::integral_constant<int, 32>;

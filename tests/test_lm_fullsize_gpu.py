@@ -219,17 +219,18 @@ def test_fish15_bf16_long_prefill_pass_vs_oracle(lm15, oracle15):
     assert lm.curr_kv_size() == 203
 
 
-def test_fish15_bf16_decode_steps_beyond_eight_attention_chunks(lm15, oracle15):
-    """KV length > 1024 tokens = more than 8 attention chunks: the batch-1 decode step then takes k_wo's general (LDS) chunk merge
-    instead of the register merge, and the graph bucket is 16 chunks.  1100 prompt tokens in one pass, then three single-token
-    steps, every step against the oracle (same bf16-rounded weights and K/V)."""
+@pytest.mark.parametrize("L0", [1100, 2150])
+def test_fish15_bf16_decode_steps_beyond_eight_attention_chunks(lm15, oracle15, L0):
+    """KV length > 1024 tokens = more than 8 attention chunks (graph buckets of 16 / 32 chunks): the batch-1 attention blocks then
+    take 2 / 4 consecutive chunks each (online softmax) so that k_wo still merges <= 8 partials.  L0 prompt tokens in one or two
+    passes, then three single-token steps, every step against the oracle (same bf16-rounded weights and K/V)."""
     lm, o = lm15, oracle15
-    p = _prompt(1103, seed=33)
+    p = _prompt(L0 + 3, seed=33)
     o.set_kv_round_bf16(True)
     o.clear_slow(); lm.clear_slow_layer_caches()
     im_end = fcfg.FISH_1_5_TOKENS["im_end_id"]
     worst = 0.0
-    for lo_, hi_ in ((0, 1100), (1100, 1101), (1101, 1102), (1102, 1103)):
+    for lo_, hi_ in ((0, L0), (L0, L0 + 1), (L0 + 1, L0 + 2), (L0 + 2, L0 + 3)):
         chunk = np.ascontiguousarray(p[:, lo_:hi_])
         lg, hg = lm.forward_generate(chunk, lo_)
         lo, ho = o.forward_generate(chunk, lo_)
@@ -237,5 +238,5 @@ def test_fish15_bf16_decode_steps_beyond_eight_attention_chunks(lm15, oracle15):
         dh = float(np.abs(hg - ho).max() / np.sqrt(np.mean(ho ** 2)))
         worst = max(worst, dl, dh)
         assert dl < BF16_TOL and dh < BF16_TOL, (lo_, hi_, dl, dh)
-    print(f"KV 1100..1103 (16-chunk bucket): worst max|dlogit| / |dh|/rms {worst:.2e}")
-    assert lm.curr_kv_size() == 1103
+    print(f"KV {L0}..{L0 + 3}: worst max|dlogit| / |dh|/rms {worst:.2e}")
+    assert lm.curr_kv_size() == L0 + 3

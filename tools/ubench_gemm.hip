@@ -41,7 +41,7 @@ int main(int argc, char** argv) {
     c.P = (float*)dalloc((size_t)4 * 2048 * 1024 * 4); c.A = (uint16_t*)dalloc(2 * 2048 * 1024 * 2);
     c.C = (uint16_t*)dalloc((size_t)2 * 2048 * 4096 * 2); c.A2 = (uint16_t*)dalloc(2 * 2048 * 1024 * 2); c.ss = (float*)dalloc(2048 * 64 * 4);
     c.cos_t = (float*)dalloc(8192 * 32 * 4); c.sin_t = (float*)dalloc(8192 * 32 * 4);
-    SeqState hs = {}; hs.pos = 300; SeqState* state = (SeqState*)dalloc(sizeof(SeqState)); CK(hipMemcpy(state, &hs, sizeof(hs), hipMemcpyHostToDevice));
+    SeqState hs = {}; hs.pos = getenv("UB_POS") ? atoi(getenv("UB_POS")) : 300; SeqState* state = (SeqState*)dalloc(sizeof(SeqState)); CK(hipMemcpy(state, &hs, sizeof(hs), hipMemcpyHostToDevice));
     c.state = state; c.n_chunks_max = NC; c.nc_launch = argc > 2 ? atoi(argv[2]) : 4; c.pos_step = argc > 3 ? atoi(argv[3]) : 1; c.pt_stride = 0;
     c.chunked_attn = getenv("UB_CHUNKED_ATTN") != nullptr;
     c.seq_rows = argc > 4 ? atoi(argv[4]) : 0;  // > 0: group prefill (M must be a multiple); all sequences share one page table here

@@ -360,10 +360,9 @@ class LM final : public LMBase {
                 const size_t n = (size_t)hs->n_out;
                 if (n > delivered) {
                     std::vector<uint32_t> tmp((size_t)C * out_cap_);
-                    // column block [delivered, n) of every row
-                    for (int c = 0; c < C; ++c)
-                        FS_HIP(hipMemcpy(tmp.data() + (size_t)c * out_cap_ + delivered, d_out_.as<uint32_t>() + (size_t)c * out_cap_ + delivered,
-                                         sizeof(uint32_t) * (n - delivered), hipMemcpyDeviceToHost));
+                    // column block [delivered, n) of every row: one strided copy
+                    FS_HIP(hipMemcpy2D(tmp.data() + delivered, sizeof(uint32_t) * out_cap_, d_out_.as<uint32_t>() + delivered,
+                                       sizeof(uint32_t) * out_cap_, sizeof(uint32_t) * (n - delivered), (size_t)C, hipMemcpyDeviceToHost));
                     std::vector<uint32_t> fr(C);
                     for (size_t f = delivered; f < n && !stop; ++f) {
                         for (int c = 0; c < C; ++c) fr[c] = tmp[(size_t)c * out_cap_ + f];

@@ -413,3 +413,33 @@ def test_static_batch_sizes_around_panel_boundaries_vs_oracle(which):
         nf = got[0].shape[1]
         assert sum(a == nf for a in agree) >= 0.85 * B and min(agree) >= 1 and np.mean(agree) >= 0.9 * nf, (B, agree)
     lm.close()
+
+
+def test_static_batch_single_token_prompts_and_max_rows():
+    """Edge cases of the static-batch row path: prompts of ONE token (no prefill pass at all: Lmax - 1 == 0), mixed 1 / 2-token
+    prompts, and the maximum of 256 rows -- against the oracle's static_batch restatement."""
+    o = _omid()
+    kw = dict(seed=42, temp=0.0, top_p=1.0, top_k=0, ignore_eos=True)
+    lm = _mid("bf16", 256)
+    for lens in ([1, 1, 1], [1, 2], [2]):
+        prompts = _batch_prompts(5 + len(lens), lens)
+        got = lm.generate_static_batch(prompts, max(lens) + 6, **kw)
+        exp = o.generate_batch(prompts, max(lens) + 6, **kw)
+        assert [g.shape for g in got] == [e.shape for e in exp]
+        assert all(np.array_equal(g[:, :3], e[:, :3]) for g, e in zip(got, exp)), lens
+    lens = [2 + (i * 7) % 13 for i in range(256)]
+    prompts = _batch_prompts(99, lens)
+    got = lm.generate_static_batch(prompts, max(lens) + 4, **kw)
+    exp = o.generate_batch(prompts, max(lens) + 4, **kw)
+    assert len(got) == 256 and [g.shape for g in got] == [e.shape for e in exp]
+    same0 = sum(int(np.array_equal(g[:, 0], e[:, 0])) for g, e in zip(got, exp))
+    full = sum(int(np.array_equal(g, e)) for g, e in zip(got, exp))
+    print(f"256 rows: first frame identical on {same0}, all 6 frames on {full}")
+    assert same0 >= 250 and full >= 0.85 * 256
+    lm.close()
+    # more prompts than the handle's max_batch: rows are generated one after another on KV slot 0 (same tokens under greedy decoding)
+    small = fishrt.DualARTransformer(MID, fcfg.TINY_TOKENS, 0, "bf16", 4).load_synthetic(SEED)
+    seq = small.generate_static_batch(prompts[:5], max(lens[:5]) + 4, **kw)
+    exp5 = o.generate_batch(prompts[:5], max(lens[:5]) + 4, **kw)
+    assert [g.shape for g in seq] == [e.shape for e in exp5] and all(np.array_equal(g[:, 0], e[:, 0]) for g, e in zip(seq, exp5))
+    small.close()

@@ -1743,8 +1743,7 @@ __device__ int block_weighted_pick(const float* w, int cnt, float* cum, RngState
 // 16-wave block costs ~0.4 us on this chip and the sort-based version needed ~40 of them; measured 36 us per call).  Lane l
 // owns the EPL consecutive candidates l*EPL .. l*EPL+EPL-1 in registers (ascending index == lane-major order):
 //   1. softmax in registers (DPP max, f64 sum);
-//   2. the k-th largest probability T by bisection on its bit pattern: v_cmp writes the lane mask, s_bcnt1 counts it --
-//      30 steps of EPL compares, all control flow scalar;
+//   2. the k-th largest probability T by radix select on its bit pattern (8 + 8 + 8 + 6 bits, LDS histogram per pass);
 //   3. keep p > T and the first k - #{p > T} ties in index order (v_mbcnt prefix counts), compact the kept set into the
 //      contiguous index-ordered arrays kp / ki and 64-bit keys (p bits : 255 - position);
 //   4. sort the <= 256 keys descending in registers (4 per lane: in-lane swaps, DPP for lane^1 / lane^2, ds_bpermute above);
@@ -1808,23 +1807,37 @@ __device__ void wave_topk_select(const float* lg, int n, int kk, float inv_t, fl
         for (int s = 0; s < EPL; ++s) u[s] = __float_as_uint(v[s] / denom);  // 0 for slots past n
     }
     FS_TS(1);
-    // k-th largest: minimal x with #{u > x} < k.  Per-lane counts in vector registers, one scalar hop per step.
-    uint32_t lo = 0u, hi = 0x3F800000u;
-    while (lo < hi) {
-        const uint32_t mid = lo + ((hi - lo) >> 1);
-        // u, mid < 2^30: the borrow of mid - u is its bit 31 -- sub + shift + add per candidate, no compare / VCC round trip
-        uint32_t c0 = 0u, c1 = 0u;
+    // k-th largest value T (#{u > T} < k <= #{u >= T}) by radix select over the 30-bit patterns, 8 + 8 + 8 + 6 bits from the top:
+    // per pass the candidates whose higher bits match the prefix are counted into a 256-bin LDS histogram (ds_add, no return),
+    // every lane takes 4 bins, a DPP scan gives the counts above each lane, and the bin holding the rank-th candidate extends
+    // the prefix -- 4 passes of ~1000 cycles instead of 30 bisection steps of ~380 (each a count over all candidates + a scalar hop)
+    uint32_t* hist = reinterpret_cast<uint32_t*>(keyb);  // 256 bins; keyb is only written after T is known
+    uint32_t prefix = 0u;
+    int krem = kk;
 #pragma unroll
-        for (int s = 0; s < EPL; s += 2) { c0 += (mid - u[s]) >> 31; c1 += (mid - u[s + 1]) >> 31; }
-        int c = (int)(c0 + c1);
-        c += __builtin_amdgcn_mov_dpp(c, DPP_XOR1, 0xF, 0xF, false);
-        c += __builtin_amdgcn_mov_dpp(c, DPP_XOR2, 0xF, 0xF, false);
-        c += __builtin_amdgcn_mov_dpp(c, DPP_HALF_MIRROR, 0xF, 0xF, false);
-        c += __builtin_amdgcn_mov_dpp(c, DPP_MIRROR, 0xF, 0xF, false);
-        const int cnt = (__builtin_amdgcn_readlane(c, 15) + __builtin_amdgcn_readlane(c, 31)) +
-                        (__builtin_amdgcn_readlane(c, 47) + __builtin_amdgcn_readlane(c, 63));
-        if (cnt < kk) hi = mid; else lo = mid + 1u;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = pass == 0 ? 22 : (pass == 1 ? 14 : (pass == 2 ? 6 : 0)), bits = pass == 3 ? 6 : 8;
+        *reinterpret_cast<uint4*>(hist + lane * 4) = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int s2 = 0; s2 < EPL; ++s2)
+            if (pass == 0 || (u[s2] >> (shift + bits)) == prefix) atomicAdd(&hist[(u[s2] >> shift) & ((1u << bits) - 1u)], 1u);
+        const uint4 hv = *reinterpret_cast<const uint4*>(hist + lane * 4);  // bins 4 * lane .. 4 * lane + 3 (one wave: LDS ops stay in order)
+        const int h4[4] = {(int)hv.x, (int)hv.y, (int)hv.z, (int)hv.w};
+        const int mine = (h4[0] + h4[1]) + (h4[2] + h4[3]);
+        const int incl = wave_incl_scan(mine);
+        int above = __builtin_amdgcn_readlane(incl, 63) - incl;  // candidates in bins of higher lanes
+        int found_bin = -1, found_above = 0;
+#pragma unroll
+        for (int j = 3; j >= 0; --j) {  // from this lane's top bin down: the bin with above < rank <= above + count
+            if (found_bin < 0 && above < krem && krem <= above + h4[j]) { found_bin = lane * 4 + j; found_above = above; }
+            above += h4[j];
+        }
+        const unsigned long long m = __ballot(found_bin >= 0);  // exactly one lane (rank <= number of candidates)
+        const int src = __builtin_ctzll(m);
+        prefix = (prefix << bits) | (uint32_t)__builtin_amdgcn_readlane(found_bin, src);
+        krem -= __builtin_amdgcn_readlane(found_above, src);
     }
+    const uint32_t lo = prefix;
     const uint32_t T = lo;
     FS_TS(2);
     // keep p > T and the first k - #{p > T} ties in index order (lane-major, then slot)

@@ -240,3 +240,21 @@ def test_fish15_bf16_decode_steps_beyond_eight_attention_chunks(lm15, oracle15, 
         assert dl < BF16_TOL and dh < BF16_TOL, (lo_, hi_, dl, dh)
     print(f"KV {L0}..{L0 + 3}: worst max|dlogit| / |dh|/rms {worst:.2e}")
     assert lm.curr_kv_size() == L0 + 3
+
+
+def test_fish15_f32_decode_steps_over_nine_chunks_general_merge():
+    """f32 handles keep one attention block per 64-token chunk; beyond 8 chunks (T > 512) k_wo takes its general LDS merge of the
+    chunk partials (bf16 / fp8 handles never do: their attention blocks take several chunks each).  600 prompt tokens as token
+    steps (the f32 parity path has no MFMA prefill), then two more -- logits / hidden state against the f32 oracle."""
+    p = _prompt(602, seed=44)
+    o = orc.OracleLM(orc.FISH15).load_synthetic(SEED, bf16=False)
+    lm = fishrt.DualARTransformer(fcfg.FISH_1_5, fcfg.FISH_1_5_TOKENS, 0, "f32").load_synthetic(SEED)
+    im_end = fcfg.FISH_1_5_TOKENS["im_end_id"]
+    for lo_, hi_ in ((0, 600), (600, 601), (601, 602)):
+        chunk = np.ascontiguousarray(p[:, lo_:hi_])
+        lg, hg = lm.forward_generate(chunk, lo_)
+        lo, ho = o.forward_generate(chunk, lo_)
+        np.testing.assert_allclose(hg, ho, rtol=5e-4, atol=5e-5)
+        np.testing.assert_allclose(lg[0, im_end:], lo[0, im_end:], rtol=5e-4, atol=1e-4)
+    assert lm.curr_kv_size() == 602
+    lm.close()

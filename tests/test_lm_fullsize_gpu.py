@@ -219,7 +219,7 @@ def test_fish15_bf16_long_prefill_pass_vs_oracle(lm15, oracle15):
     assert lm.curr_kv_size() == 203
 
 
-@pytest.mark.parametrize("L0", [1100, 2150])
+@pytest.mark.parametrize("L0", [1100, 2150, 4200])  # graph buckets of 16 / 32 / 64 chunks
 def test_fish15_bf16_decode_steps_beyond_eight_attention_chunks(lm15, oracle15, L0):
     """KV length > 1024 tokens = more than 8 attention chunks (graph buckets of 16 / 32 chunks): the batch-1 attention blocks then
     take 2 / 4 consecutive chunks each (online softmax) so that k_wo still merges <= 8 partials.  L0 prompt tokens in one or two

@@ -1951,14 +1951,29 @@ __device__ void wave_topk_select(const float* lg, int n, int kk, float inv_t, fl
     }
 }
 
-// WeightedIndex::new + sample over the contiguous weights w[0..cnt), cnt <= 256, by one wave: every lane runs the same
-// sequential f32 chain (lane 0 leaves the running sums in `cum`), then each lane tests its four entries.
-__device__ int wave_pick(const float* w, int cnt, float* cum, RngState* rng, uint32_t word) {
+// WeightedIndex::new + sample over the contiguous weights w[0..cnt), cnt <= 256, by one wave.  Zero weights (entries cut by top-p)
+// do not move the cumulative f32 sum (x + 0 == x exactly) and are never picked, so the sequential chain only walks the NON-ZERO
+// weights, compacted in ascending index order first (DPP prefix scan; `cval` / `cpos` = LDS scratch for <= 256 floats / ints):
+// after a top-p cut that is typically a few dozen of the 256 entries.  Every lane runs the same chain (lane 0 leaves the running
+// sums in `cum`), then each lane tests its four compacted entries.
+__device__ int wave_pick(const float* w, int cnt, float* cum, RngState* rng, uint32_t word, float* cval, int* cpos) {
     const int lane = threadIdx.x & 63;
+    const float4 wv = *reinterpret_cast<const float4*>(w + lane * 4);
+    const float ws[4] = {wv.x, wv.y, wv.z, wv.w};
+    int mine = 0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) mine += (lane * 4 + s < cnt && ws[s] != 0.f) ? 1 : 0;
+    const int incl = wave_incl_scan(mine);
+    const int m = __builtin_amdgcn_readlane(incl, 63);  // non-zero weights
+    if (m == 0) return 0;
+    int pos = incl - mine;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        if (lane * 4 + s < cnt && ws[s] != 0.f) { cval[pos] = ws[s]; cpos[pos] = lane * 4 + s; ++pos; }
     float total = 0.f;
-    for (int j = 0; j < cnt; j += 32) {
+    for (int j = 0; j < m; j += 32) {
         float v[32];
-        lds_fetch32(w, j, cnt, v);
+        lds_fetch32(cval, j, m, v);
 #pragma unroll
         for (int e = 0; e < 32; ++e) { total += v[e]; v[e] = total; }
         if (lane == 0) {
@@ -1972,19 +1987,17 @@ __device__ int wave_pick(const float* w, int cnt, float* cum, RngState* rng, uin
     while (scale * max_rand + 0.f >= total) scale = __uint_as_float(__float_as_uint(scale) - 1u);
     if (lane == 0) rng->consumed += 1;
     const float chosen = (__uint_as_float((word >> 9) | (127u << 23)) - 1.0f) * scale + 0.f;
-    const float4 wv = *reinterpret_cast<const float4*>(w + lane * 4), cv = *reinterpret_cast<const float4*>(cum + lane * 4);
-    const float ws[4] = {wv.x, wv.y, wv.z, wv.w}, cs[4] = {cv.x, cv.y, cv.z, cv.w};
-    int first = 0x7FFFFFFF, last = -1;
+    const float4 cv = *reinterpret_cast<const float4*>(cum + lane * 4);
+    const float cs[4] = {cv.x, cv.y, cv.z, cv.w};
+    int first = 0x7FFFFFFF;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const int j = lane * 4 + s;
-        if (j >= cnt || ws[s] == 0.f) continue;
-        last = j;
-        if (cs[s] > chosen && first == 0x7FFFFFFF) first = j;  // first kept item whose inclusive cumulative weight is > chosen
+        if (j < m && cs[s] > chosen && first == 0x7FFFFFFF) first = j;  // first kept item whose inclusive cumulative weight is > chosen
     }
-    const unsigned long long mh = __ballot(first != 0x7FFFFFFF), mn = __ballot(last >= 0);
-    if (mh) return __builtin_amdgcn_readlane(first, __builtin_ctzll(mh));
-    return __builtin_amdgcn_readlane(last, 63 - __builtin_clzll(mn));
+    const unsigned long long mh = __ballot(first != 0x7FFFFFFF);
+    const int jsel = mh ? __builtin_amdgcn_readlane(first, __builtin_ctzll(mh)) : m - 1;  // else the last non-zero item
+    return cpos[jsel];
 }
 
 // Block-wide selection of one index from `n` logits held in LDS (already penalised / masked).
@@ -2058,7 +2071,7 @@ __device__ int block_sample(float* lg /*LDS [n]*/, int n, const SampleCfg& c, Rn
             __syncthreads();
             FS_TS(7);
             if (tid < 64) {
-                const int pick = wave_pick(w_kp, kk0, w_cum, rng, s_word0);
+                const int pick = wave_pick(w_kp, kk0, w_cum, rng, s_word0, sp, si);  // sp / si: free after the sort
                 if (tid == 0) s_result = w_ki[pick];
             }
             FS_TS(8);

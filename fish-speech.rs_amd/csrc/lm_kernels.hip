@@ -2223,6 +2223,38 @@ __device__ int block_sample(float* lg /*LDS [n]*/, int n, const SampleCfg& c, Rn
     }
 }
 
+// Greedy pick (temp == 0, host ArgMax rule: LAST maximal index) without the three block barriers of block_sample: a thread's
+// candidates (indices tid + j * SAMPLE_THREADS) stay in registers, a wave reduces (value, then index) by DPP, lane 0 of every wave
+// does one 64-bit LDS atomicMax on {order-preserving value bits : index}, ONE barrier, everybody reads the winner.  *s_key must
+// have been zeroed before the previous barrier.  (A 16-wave barrier phase costs ~0.4 us on this chip.)
+__device__ __forceinline__ int dpp_wave_max_int(int v) {
+    v = max(v, __builtin_amdgcn_mov_dpp(v, DPP_XOR1, 0xF, 0xF, false)); v = max(v, __builtin_amdgcn_mov_dpp(v, DPP_XOR2, 0xF, 0xF, false));
+    v = max(v, __builtin_amdgcn_mov_dpp(v, DPP_HALF_MIRROR, 0xF, 0xF, false)); v = max(v, __builtin_amdgcn_mov_dpp(v, DPP_MIRROR, 0xF, 0xF, false));
+    return max(max(__builtin_amdgcn_readlane(v, 15), __builtin_amdgcn_readlane(v, 31)), max(__builtin_amdgcn_readlane(v, 47), __builtin_amdgcn_readlane(v, 63)));
+}
+__device__ __forceinline__ int greedy_pick(const float (&val)[SAMPLE_MAXN / SAMPLE_THREADS], int n, unsigned long long* s_key) {
+    const int tid = threadIdx.x;
+    float bv = -INFINITY;
+    int bi = -1;
+#pragma unroll
+    for (int j = 0; j < SAMPLE_MAXN / SAMPLE_THREADS; ++j) {
+        const int i = tid + j * SAMPLE_THREADS;
+        if (i < n && (bi < 0 || !(val[j] < bv))) { bv = val[j]; bi = i; }  // ascending i per thread: the later equal value wins
+    }
+    float wm = bv;
+    wm = fmaxf(wm, dpp_mov<DPP_XOR1>(wm)); wm = fmaxf(wm, dpp_mov<DPP_XOR2>(wm));
+    wm = fmaxf(wm, dpp_mov<DPP_HALF_MIRROR>(wm)); wm = fmaxf(wm, dpp_mov<DPP_MIRROR>(wm));
+    wm = fmaxf(fmaxf(readlane(wm, 15), readlane(wm, 31)), fmaxf(readlane(wm, 47), readlane(wm, 63)));
+    const int ci = dpp_wave_max_int((bi >= 0 && bv == wm) ? bi : -1);
+    if ((tid & 63) == 0 && ci >= 0) {
+        uint32_t u = __float_as_uint(wm);
+        u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;  // unsigned order == float order
+        atomicMax(s_key, ((unsigned long long)u << 32) | (unsigned long long)(uint32_t)ci);
+    }
+    __syncthreads();
+    return (int)(*s_key & 0xFFFFFFFFull);
+}
+
 template <typename WT>
 __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_slow(const float* __restrict__ logits, int n,
                                                                 const SampleCfg* __restrict__ cp, RngState* rng, SeqState* __restrict__ state,
@@ -2233,6 +2265,27 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_slow(const float* __r
     __shared__ double red[SAMPLE_THREADS];
     const int tid = threadIdx.x;
     const SampleCfg c = *cp;
+    __shared__ unsigned long long s_key;
+    if (c.temp == 0.f && !c.legacy) {  // greedy: two barriers instead of five (see greedy_pick)
+        if (tid == 0) s_key = 0ull;
+        float val[SAMPLE_MAXN / SAMPLE_THREADS];
+#pragma unroll
+        for (int j = 0; j < SAMPLE_MAXN / SAMPLE_THREADS; ++j) {
+            const int i = tid + j * SAMPLE_THREADS;
+            val[j] = i < n ? logits[i] : -INFINITY;
+            if (i == 0 && c.ignore_eos) val[j] = -INFINITY;
+        }
+        for (int i = tid; i < dim; i += SAMPLE_THREADS) xf[i] = x[i];  // hidden_states -> fast decoder input (:149)
+        __syncthreads();
+        const int idx = greedy_pick(val, n, &s_key);
+        if (tid == 0) {
+            uint32_t tok = (uint32_t)idx + c.im_end_id;  // rescale_semantic_tokens (utils.rs:45-46)
+            if (state->done) tok = c.im_end_id;
+            state->cur[0] = tok;
+            if (tok == c.im_end_id && state->done == 0) state->done = 1;
+        }
+        return;
+    }
     for (int i = tid; i < n; i += SAMPLE_THREADS) lg[i] = logits[i];
     for (int i = tid; i < dim; i += SAMPLE_THREADS) xf[i] = x[i];  // hidden_states -> fast decoder input (:149)
     __syncthreads();
@@ -2282,6 +2335,9 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_fast(const float* __r
     // one round trip for everything the decision needs: state words, the repetition-penalty ring, logits and mask
     __shared__ int s_ring[17], s_meta[2];
     __shared__ uint32_t s_prev, s_cur0, s_have_prev;
+    __shared__ unsigned long long s_key;
+    const bool greedy = c.temp == 0.f;
+    if (tid == 22) s_key = 0ull;
     if (tid < 17) s_ring[tid] = rp.ring[cb * 17 + tid];
     else if (tid < 19) s_meta[tid - 17] = rp.ring_meta[cb * 2 + tid - 17];
     else if (tid == 19) s_prev = state->prev[cb + 1];
@@ -2320,13 +2376,14 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_fast(const float* __r
                     if (i == dropped && m == c.rep_pen) m = 1.0f;
                     if (m != m0) mask[i] = m;
                 }
-                lg[i] = pen ? lv[j] / m : lv[j];
+                lv[j] = pen ? lv[j] / m : lv[j];
+                if (!greedy) lg[i] = lv[j];
             }
         }
-        __syncthreads();
+        if (!greedy) __syncthreads();
     }
     int code = 0;
-    if (!eos) code = block_sample(lg, n, c, rng, sp, si, red);
+    if (!eos) code = greedy ? greedy_pick(lv, n, &s_key) : block_sample(lg, n, c, rng, sp, si, red);
     if (tid == 0) state->cur[cb + 1] = (uint32_t)code;
     if (cb != n_cb - 1) {
         if (!eos)

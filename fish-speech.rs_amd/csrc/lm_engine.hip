@@ -14,12 +14,14 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <type_traits>
 #include <vector>
 
 #include "fs_common.h"
 #include "fs_synth.h"
 #include "lm_kernels.h"
+#include "lm_persist.h"
 #include "safetensors.h"
 
 namespace fs {
@@ -66,6 +68,14 @@ void seed_key(uint64_t state, uint32_t* key) {
     }
 }
 
+
+// The persistent fast-decoder kernel needs all of its 256 workgroups co-resident; two such launches from two handles of one GPU
+// could each hold half of the CUs and wait for the other half forever (until their spin limits).  One generate call at a time may
+// use it per device; a concurrent call on another handle takes the per-node graph instead.
+std::mutex& persist_mutex(int device) {
+    static std::mutex m[64];
+    return m[device & 63];
+}
 
 constexpr int kRows = 256;     // static-batch generator: max sequences per step (32-row MFMA panels; <= kPartRows)
 constexpr int kRowsCap = 2048; // row capacity of the MFMA row buffers: prompt tokens per prefill pass (one sequence, or a group of
@@ -140,6 +150,7 @@ class LM final : public LMBase {
         FS_HIP(hipStreamSynchronize(st_));
         loaded_ = true;
         refresh_legacy_head();
+        pack_persist();
     }
 
     void load_safetensors(const std::string& path) override {
@@ -172,6 +183,7 @@ class LM final : public LMBase {
         }
         loaded_ = true;
         refresh_legacy_head();
+        pack_persist();
     }
 
     // ------------------------------------------------------------------------------------------ teacher-forced API
@@ -321,6 +333,14 @@ class LM final : public LMBase {
         cfg.top_k = (int)std::min<uint64_t>(s.top_k, 1u << 30);
         cfg.rep_pen = s.repetition_penalty; cfg.ignore_eos = (flags & FS_GEN_IGNORE_EOS) ? 1 : 0;
         FS_HIP(hipMemcpyAsync(d_cfg_.p, &cfg, sizeof(cfg), hipMemcpyHostToDevice, st_));
+        // greedy decoding on a Fish-geometry bf16 handle: the 8 fast-decoder passes of a frame run as ONE persistent launch
+        // (lm_persist.hip) instead of 144 graph nodes, if no other handle of this GPU is using it right now
+        std::unique_lock<std::mutex> plock;
+        use_persist_ = false;
+        if (persist_ok_ && cfg.temp == 0.f && !(flags & FS_GEN_NO_PERSIST)) {
+            plock = std::unique_lock<std::mutex>(persist_mutex(device_), std::try_to_lock);
+            use_persist_ = plock.owns_lock();
+        }
         RngState rng = {};
         seed_key(seed, rng.key);
         FS_HIP(hipMemcpyAsync(d_rng_.p, &rng, sizeof(rng), hipMemcpyHostToDevice, st_));
@@ -388,6 +408,23 @@ class LM final : public LMBase {
         FS_HIP(hipEventElapsedTime(&ms01, ev_[0], ev_[1]));
         FS_HIP(hipEventElapsedTime(&ms12, ev_[1], ev_[2]));
         stats_.prefill_ms = ms01; stats_.decode_ms = ms12; stats_.frames = n; stats_.prompt_tokens = (uint64_t)L;
+        if (use_persist_ && getenv("FISHRT_PERSIST_PROF")) {
+            unsigned long long pr[16];
+            FS_HIP(hipMemcpy(pr, d_ctl_.as<uint32_t>() + 16, sizeof(pr), hipMemcpyDeviceToHost));
+            FS_HIP(hipMemset(d_ctl_.as<uint32_t>() + 16, 0, sizeof(pr)));
+            const double f = 0.01 / std::max<double>(1.0, (double)stats_.graph_launches - (double)L + 1);  // us per frame
+            fprintf(stderr, "persist prof (us/frame, workgroup 0; wait+work): preload %.1f  S1 %.1f+%.1f  S2 %.1f+%.1f  S3 %.1f+%.1f  S4 %.1f+%.1f  head %.1f+%.1f  decision %.1f+%.1f  tail %.1f\n",
+                    pr[0] * f, pr[9] * f, pr[1] * f, pr[10] * f, pr[2] * f, pr[11] * f, pr[3] * f, pr[12] * f, pr[4] * f, pr[13] * f, pr[5] * f, pr[14] * f, pr[6] * f, pr[7] * f);
+        }
+        if (use_persist_) {
+            uint32_t ctl[4] = {0, 0, 0, 0};
+            FS_HIP(hipMemcpy(ctl, d_ctl_.p, sizeof(ctl), hipMemcpyDeviceToHost));
+            if (ctl[1] || ctl[2]) {
+                FS_HIP(hipMemset(d_ctl_.as<uint32_t>() + 1, 0, 8));
+                throw Error(ctl[1] ? "persistent fast-decoder kernel: a grid-wide wait timed out (are all 256 CUs available to this process?)"
+                                   : "persistent fast-decoder kernel launched with temp != 0");
+            }
+        }
         if (clamped && !hs->done && !stop)
             throw Error("generation ran past max_seq_len without <|im_end|> (the reference fails at dual_ar.rs:623-624)");
         FS_REQUIRE(n <= cap, "codes_out capacity too small for the generated frames");
@@ -439,6 +476,14 @@ class LM final : public LMBase {
         cfg.top_k = (int)std::min<uint64_t>(s.top_k, 1u << 30);
         cfg.rep_pen = 1.0f; cfg.ignore_eos = (flags & FS_GEN_IGNORE_EOS) ? 1 : 0;
         FS_HIP(hipMemcpyAsync(d_cfg_.p, &cfg, sizeof(cfg), hipMemcpyHostToDevice, st_));
+        // greedy decoding on a Fish-geometry bf16 handle: the 8 fast-decoder passes of a frame run as ONE persistent launch
+        // (lm_persist.hip) instead of 144 graph nodes, if no other handle of this GPU is using it right now
+        std::unique_lock<std::mutex> plock;
+        use_persist_ = false;
+        if (persist_ok_ && cfg.temp == 0.f && !(flags & FS_GEN_NO_PERSIST)) {
+            plock = std::unique_lock<std::mutex>(persist_mutex(device_), std::try_to_lock);
+            use_persist_ = plock.owns_lock();
+        }
         RngState rng = {};
         seed_key(seed, rng.key);  // BatchedLogitsProcessor::new(seed) (the reference passes 42, static_batch.rs:63)
         FS_HIP(hipMemcpyAsync(d_rng_.p, &rng, sizeof(rng), hipMemcpyHostToDevice, st_));
@@ -928,6 +973,44 @@ class LM final : public LMBase {
         return c;
     }
 
+    // ---- persistent fast decoder (lm_persist.hip): per-lane weight image, edge buffers, control words
+    void pack_persist() {
+        persist_ok_ = false;
+        if constexpr (std::is_same<WT, bf16_t>::value) {
+            if (getenv("FISHRT_NO_PERSIST")) return;
+            if (!fast_persist_supported(d_, a_.n_fast_layer, a_.num_codebooks, a_.codebook_size)) return;
+            hipDeviceProp_t prop;
+            FS_HIP(hipGetDeviceProperties(&prop, device_));
+            if (prop.multiProcessorCount < PF_BLOCKS) return;  // every workgroup needs its own CU
+            if (!d_pack_.p) {
+                d_pack_.alloc(fast_persist_pack_bytes());
+                d_edges_.alloc(fast_persist_edge_bytes());
+                FS_HIP(hipMemset(d_edges_.p, 0, d_edges_.n));
+                d_ctl_.alloc(256);
+                FS_HIP(hipMemset(d_ctl_.p, 0, d_ctl_.n));
+            }
+            launch_fast_persist_pack(fast_.data(), fast_out_w_, d_pack_.p, st_);
+            FS_HIP(hipStreamSynchronize(st_));
+            persist_ok_ = true;
+        }
+    }
+    FastPersistArgs persist_args() {
+        FastPersistArgs A = {};
+        A.wpack = d_pack_.p;
+        for (int l = 0; l < PF_LAYERS; ++l) { A.norms[2 * l] = fast_[l].attn_norm; A.norms[2 * l + 1] = fast_[l].ffn_norm; }
+        A.norms[2 * PF_LAYERS] = fast_norm_w_;
+        A.fast_emb = fast_emb_; A.tok_emb = tok_emb_; A.cb_emb = cb_emb_;
+        A.cos_t = d_cos_.as<float>(); A.sin_t = d_sin_.as<float>();
+        A.eps = d_.eps;
+        A.xf = xf(0); A.x = x(0);
+        A.state = state(0); A.cfg = d_cfg_.as<SampleCfg>(); A.rp = rp_;
+        A.out_codes = d_out_.as<uint32_t>(); A.out_cap = out_cap_;
+        A.edges = d_edges_.as<unsigned long long>();
+        A.ctl = d_ctl_.as<uint32_t>();
+        A.prof = getenv("FISHRT_PERSIST_PROF") ? reinterpret_cast<unsigned long long*>(d_ctl_.as<uint32_t>() + 16) : nullptr;
+        return A;
+    }
+
     // ---- kernel sequences
     void enqueue_slow_layers(int b) {
         for (int l = 0; l < a_.n_layer; ++l) {
@@ -961,11 +1044,12 @@ class LM final : public LMBase {
     void set_bucket(int T) { nc_launch_ = chunk_bucket(T); }
     // graphs for the bucket currently in nc_launch_ (captured on first use)
     void use_graphs_for_bucket() {
-        auto it = graphs_.find(nc_launch_);
+        const int key = nc_launch_ * 2 + (use_persist_ ? 1 : 0);
+        auto it = graphs_.find(key);
         if (it == graphs_.end()) {
             g_frame_ = nullptr; g_step_ = nullptr;
             build_graphs();
-            graphs_[nc_launch_] = {g_frame_, g_step_};
+            graphs_[key] = {g_frame_, g_step_};
         } else {
             g_frame_ = it->second.first; g_step_ = it->second.second;
         }
@@ -990,6 +1074,8 @@ class LM final : public LMBase {
         LmKernels<WT>::head(d_, x(0), norm_w_, slow_head_w(), slow_head_s(), n_audio_, d_logits_slow_.as<float>(), st_);
         SampleKernels<WT>::sample_slow(d_, d_logits_slow_.as<float>(), n_audio_, d_cfg_.as<SampleCfg>(), d_rng_.as<RngState>(), state(0),
                                        x(0), xf(0), st_);
+        if (use_persist_) launch_fast_persist(persist_args(), st_);
+        else
         for (int cbi = 0; cbi < C; ++cbi) {
             enqueue_fast_layers(0, cbi, cbi);
             LmKernels<WT>::head(d_, xf(0), fast_norm_w_, fast_out_w_, fast_out_s_, a_.codebook_size, d_logits_fast_.as<float>(), st_);
@@ -1031,6 +1117,8 @@ class LM final : public LMBase {
     // activations / state
     DevBuf d_x_, d_xf_, d_q_, d_part_, d_act_, d_logits_slow_, d_logits_fast_, d_state_, d_cfg_, d_rng_, d_prompt_, d_out_;
     DevBuf d_rp_mask_, d_rp_seen_, d_rp_ring_, d_rp_meta_;
+    DevBuf d_pack_, d_edges_, d_ctl_;  // persistent fast decoder
+    bool persist_ok_ = false, use_persist_ = false;
     DevBuf d_pfx_, d_pfq_, d_pfslab_, d_pfa_, d_pfa2_, d_pfss_, d_pfc_, d_pfpart_;  // MFMA row-path activations (kRowsCap rows)
     DevBuf d_bprompt_;  // static batch: all left-padded prompts [B][C + 1][Lmax] (group prefill)
     DevBuf d_xfrows_, d_lrows_, d_lfast_, d_fast_state_, d_fast_table_;  // static-batch generator

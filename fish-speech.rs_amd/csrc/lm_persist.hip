@@ -1,0 +1,723 @@
+// Persistent fast-decoder kernel (see lm_persist.h): one launch = the 8 codebook passes of one audio frame.
+//
+// Reference semantics implemented (same arithmetic as the per-node kernels of lm_kernels.hip, other summation order):
+//   forward_generate_fast  fish_speech_core/lib/lm/dual_ar.rs:638-673  (4 blocks at RoPE position = codebook index, own KV
+//                          cache cleared every frame, fast_norm, fast_output)
+//   TransformerBlock / Attention / FeedForward  dual_ar.rs:160-165,281-384,429-440 (interleaved RoPE, scale on K, GQA by head index)
+//   frame loop             generate/single_batch.rs:146-210 (8 codebooks, rep-pen keyed on the previous frame, EOS -> zeros)
+//   rep-pen                sampling/rep_pen.rs:37-65 (window 16, never-incremented count)
+//   embed                  dual_ar.rs:532-567
+//
+// Work split.  Workgroup b owns output rows [5b, 5b+5) of Wqkv, [4b, 4b+4) of Wo / W2 / fast_output and the 16 SwiGLU pairs
+// [16b, 16b+16) of W13 of EVERY fast layer; inside the workgroup the reduction dimension is split over all 512 lanes (lane t owns
+// input elements 2t, 2t+1; for W2: 1024q + 2t, +1, q = 0..3), so a lane's activation slice arrives straight from its own sweep
+// loads and never passes through LDS.  Per-row partial sums are reduced with halving trees (v_permlane32/16_swap + DPP: 70
+// instructions for 32 rows instead of 32 x 12), the 8 wave partials meet in LDS, `rows` lanes add them in wave order, apply the
+// epilogue (residual / SwiGLU) and publish to the 8 replicas of the edge buffer.
+//
+// Edge protocol (MI355X guide, Guideline 16 R2): a granule = one aligned 8-byte {f32 value, tag} written by ONE relaxed
+// agent-scope (sc1, write-through) store; tag = launch epoch * 256 + edge index + 1, unique over the life of the handle, so buffers
+// are never re-armed; consumers sweep with 16-byte sc1 loads (2 granules) and retry only the units whose tags are not there yet.
+// Edge e uses buffer e % 4: a producer can publish edge e only after it has consumed edge e-1, which every workgroup published
+// after consuming edge e-2, so nobody still reads the buffer of edge e-4 (nor e-2).  Every spin is bounded; a timeout sets
+// ctl[1] and lets the thread run on (garbage tokens, no hang), the host turns it into an error.
+//
+// State ordering inside a launch: per-frame inputs (SeqState, rep-pen ring / mask, sampler config) are read by every workgroup
+// BEFORE its first publish; only workgroup 0 writes them, and it cannot reach its first write before it has consumed a
+// full edge, i.e. before every workgroup has completed those reads.
+#include "lm_persist.h"
+
+#include <hip/hip_runtime.h>
+
+#include "fs_common.h"
+
+namespace fs {
+
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned long long u64;
+typedef __attribute__((address_space(1))) u64 gu64;
+#define PF_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+constexpr unsigned PF_SPIN_MAX = 1u << 17;  // ~0.1 s of polling before a thread gives up
+
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
+// bf16 pair -> two f32, AT THE USE SITE: as plain C++ the shifts / masks of all 168 weight dwords get placed right behind the
+// top-of-pass pin (336 live floats, spills); volatile asm keeps them behind the sweep of the stage that consumes them
+__device__ __forceinline__ void pf_unpack(uint32_t w, float& lo, float& hi) {
+    asm volatile("v_lshlrev_b32 %0, 16, %2\n\tv_and_b32 %1, 0xffff0000, %2" : "=&v"(lo), "=v"(hi) : "v"(w));
+}
+__device__ __forceinline__ float pf_dot2(uint32_t w, float c0, float c1, float acc) {
+    float lo, hi;
+    pf_unpack(w, lo, hi);
+    acc = fmaf(lo, c0, acc);
+    return fmaf(hi, c1, acc);
+}
+__device__ __forceinline__ uint32_t f32_to_bf16_rne(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+
+template <int CTRL>
+__device__ __forceinline__ float pf_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+constexpr int PF_XOR1 = 0xB1, PF_XOR2 = 0x4E, PF_HALF_MIRROR = 0x141, PF_MIRROR = 0x140;
+
+// Sum of N per-lane values over the 64 lanes of a wave, all N at once: levels [lane^32, lane^16, row mirror, half mirror, xor 2,
+// xor 1]; while more than one value is alive a level HALVES the value set (the lanes on either side keep different values and
+// exchange the other half), afterwards it is a plain butterfly.  Returns the total of value index
+//   N = 32: lane >> 1;   N = 16: lane >> 2;   N = 4: lane >> 4          (every lane of the group holds it).
+template <int N>
+__device__ __forceinline__ float pf_reduce(float (&v)[N], int lane) {
+    static_assert(N == 4 || N == 16 || N == 32, "value counts used by the kernel");
+    int n = N;
+    // level lane^32
+    {
+        const int h = n / 2;
+#pragma unroll
+        for (int i = 0; i < N / 2; ++i) {
+            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + h]), false, false);
+            v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        }
+        n = h;
+    }
+    // level lane^16
+    {
+        const int h = n / 2;
+#pragma unroll
+        for (int i = 0; i < N / 4; ++i) {
+            const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + h]), false, false);
+            v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        }
+        n = h;
+    }
+    if (N == 4) {  // one value left: butterfly over the 16 lanes of the row
+        float t = v[0];
+        t += pf_dpp<PF_MIRROR>(t); t += pf_dpp<PF_HALF_MIRROR>(t); t += pf_dpp<PF_XOR2>(t); t += pf_dpp<PF_XOR1>(t);
+        return t;
+    }
+    // N >= 16: n = N / 4 values (8 or 4) alive
+    {   // row mirror: lanes 0..7 <-> 15..8
+        const bool pred = (lane & 8) != 0;
+        const int h = n / 2;
+#pragma unroll
+        for (int i = 0; i < N / 8; ++i) {
+            const float keep = pred ? v[i + h] : v[i], send = pred ? v[i] : v[i + h];
+            v[i] = keep + pf_dpp<PF_MIRROR>(send);
+        }
+        n = h;
+    }
+    {   // half mirror: lanes 0..3 <-> 7..4
+        const bool pred = (lane & 4) != 0;
+        const int h = n / 2;
+#pragma unroll
+        for (int i = 0; i < N / 16; ++i) {
+            const float keep = pred ? v[i + h] : v[i], send = pred ? v[i] : v[i + h];
+            v[i] = keep + pf_dpp<PF_HALF_MIRROR>(send);
+        }
+        n = h;
+    }
+    if (N == 16) {  // one value left
+        float t = v[0];
+        t += pf_dpp<PF_XOR2>(t); t += pf_dpp<PF_XOR1>(t);
+        return t;
+    }
+    {   // N == 32: two values left; xor 2 halves them
+        const bool pred = (lane & 2) != 0;
+        const float keep = pred ? v[1] : v[0], send = pred ? v[0] : v[1];
+        float t = keep + pf_dpp<PF_XOR2>(send);
+        t += pf_dpp<PF_XOR1>(t);
+        return t;
+    }
+}
+
+__device__ __forceinline__ float pf_wave_sum(float v) {
+    v += pf_dpp<PF_XOR1>(v); v += pf_dpp<PF_XOR2>(v); v += pf_dpp<PF_HALF_MIRROR>(v); v += pf_dpp<PF_MIRROR>(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    const auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r2[0]) + __uint_as_float(r2[1]);
+}
+
+// value barrier: what is derived from the result is not loop-invariant, so per-lane addresses / predicates are recomputed per stage
+// (a few VALU ops) instead of being hoisted out of the pass loop into ~150 extra live registers
+__device__ __forceinline__ int pf_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+
+// ---- edge sweeps: NL 16-byte units per lane (unit u = granules 2u, 2u+1), all of a lane's loads in flight, retried until both
+// tags of every unit match.  `dead` latches after a timeout: the thread then stops waiting for anything.
+__device__ __forceinline__ bool pf_tags_ok(const u32x4& v, unsigned tag) { return v.y == tag && v.w == tag; }
+
+__device__ __forceinline__ void pf_sweep1(const u64* base, int unit, unsigned tag, u32x4& v, bool& dead, uint32_t* ctl) {
+    const u64* p = base + 2 * (size_t)unit;
+    for (unsigned spins = 0;; ++spins) {
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+        if (pf_tags_ok(v, tag) || dead) return;
+        if (spins > PF_SPIN_MAX) { dead = true; atomicAdd(ctl + 1, 1u); return; }
+    }
+}
+__device__ __forceinline__ void pf_sweep2(const u64* base, int unit0, int unit1, unsigned tag, u32x4& v0, u32x4& v1, bool& dead,
+                                          uint32_t* ctl) {
+    const u64 *p0 = base + 2 * (size_t)unit0, *p1 = base + 2 * (size_t)unit1;
+    for (unsigned spins = 0;; ++spins) {
+        asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(v0), "=&v"(v1) : "v"(p0), "v"(p1) : "memory");
+        if ((pf_tags_ok(v0, tag) && pf_tags_ok(v1, tag)) || dead) return;
+        if (spins > PF_SPIN_MAX) { dead = true; atomicAdd(ctl + 1, 1u); return; }
+    }
+}
+__device__ __forceinline__ void pf_sweep4(const u64* base, int tid, unsigned tag, u32x4 (&v)[4], bool& dead, uint32_t* ctl) {
+    const u64 *p0 = base + 2 * (size_t)tid, *p1 = p0 + 2 * PF_THREADS, *p2 = p1 + 2 * PF_THREADS, *p3 = p2 + 2 * PF_THREADS;
+    for (unsigned spins = 0;; ++spins) {
+        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
+                     "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+        if ((pf_tags_ok(v[0], tag) && pf_tags_ok(v[1], tag) && pf_tags_ok(v[2], tag) && pf_tags_ok(v[3], tag)) || dead) return;
+        if (spins > PF_SPIN_MAX) { dead = true; atomicAdd(ctl + 1, 1u); return; }
+    }
+}
+
+__device__ __forceinline__ void pf_publish(u64* edges, unsigned e, int rep, int index, unsigned tag, float value) {
+    gu64* g = (gu64*)(edges + ((size_t)(e & (PF_RING - 1)) * PF_REPL + rep) * PF_EDGE_CAP + index);
+    __hip_atomic_store(g, ((u64)tag << 32) | (u64)__float_as_uint(value), PF_RLX_AGENT);
+}
+
+// LDS carve (bytes).  Everything lives in ONE dynamic array (guide: Guideline 17)
+constexpr int L_W2 = 0;                                   // [16 chunks][512 lanes] x 16 B
+constexpr int L_KC = L_W2 + PF_LDS_CHUNKS * PF_THREADS * 16;  // K cache: [4 layers][8 pos][64] bf16 pairs
+constexpr int L_VC = L_KC + PF_LAYERS * 8 * 64 * 4;
+constexpr int L_QS = L_VC + PF_LAYERS * 8 * 64 * 4;       // rope'd q, f32 [1024]
+constexpr int L_XS = L_QS + 4096;                          // residual stream copy, f32 [1024]
+constexpr int L_RED = L_XS + 4096;                         // [2][8 waves][32] row partials
+constexpr int L_RSS = L_RED + 2 * 8 * 32 * 4;              // [2][8] sum-of-squares partials
+constexpr int L_SC = L_RSS + 2 * 8 * 4;                    // [16 heads][8 pos] attention scores
+constexpr int L_AMAX = L_SC + 16 * 8 * 4;                  // [2][8 waves] {value, index}
+constexpr int L_ROPE = L_AMAX + 2 * 8 * 8;                 // cos [8][32], sin [8][32]
+constexpr int L_RING = L_ROPE + 2 * 8 * 32 * 4;            // rep-pen ring [8][17], meta [8][2], prev [16], misc [16]
+constexpr int L_END = L_RING + (8 * 17 + 8 * 2 + 16 + 16) * 4;
+static_assert(L_END <= 160 * 1024, "LDS budget");
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ weight image
+// chunk c < 42: dwords 4c .. 4c+3 of the lane's register image; dword d: layer l = d / 41, i = d % 41:
+//   i < 5: Wqkv row 5b + i;  i < 9: Wo row 4b + i - 5;  else W13 (interleaved) row 32b + i - 9;   d >= 164: fast_output row 4b + d - 164
+// each dword = elements (2t, 2t+1) of that row.  chunk 42 + 4l + q: {W2_l row 4b + r, elements (1024q + 2t, +1)}, r = 0..3
+__global__ __launch_bounds__(PF_THREADS) void k_pf_pack(LayerW w0, LayerW w1, LayerW w2, LayerW w3, const uint32_t* __restrict__ head,
+                                                        u32x4* __restrict__ pack) {
+    const int b = blockIdx.x, c = blockIdx.y, t = threadIdx.x;
+    const LayerW* ws[4] = {&w0, &w1, &w2, &w3};
+    u32x4 out;
+    if (c < PF_REG_CHUNKS) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int d = 4 * c + k;
+            uint32_t v;
+            if (d >= PF_LAYERS * 41) v = head[(size_t)(4 * b + d - PF_LAYERS * 41) * 512 + t];
+            else {
+                const LayerW& w = *ws[d / 41];
+                const int i = d % 41;
+                if (i < 5) v = reinterpret_cast<const uint32_t*>(w.wqkv)[(size_t)(5 * b + i) * 512 + t];
+                else if (i < 9) v = reinterpret_cast<const uint32_t*>(w.wo)[(size_t)(4 * b + i - 5) * 512 + t];
+                else v = reinterpret_cast<const uint32_t*>(w.w13)[(size_t)(32 * b + i - 9) * 512 + t];
+            }
+            out[k] = v;
+        }
+    } else {
+        const int l = (c - PF_REG_CHUNKS) / 4, q = (c - PF_REG_CHUNKS) % 4;
+        const uint32_t* W2 = reinterpret_cast<const uint32_t*>(ws[l]->w2);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[r] = W2[(size_t)(4 * b + r) * 2048 + 512 * q + t];
+    }
+    pack[((size_t)b * PF_CHUNKS + c) * PF_THREADS + t] = out;
+}
+
+// ------------------------------------------------------------------------------------------------ the frame kernel
+__global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32x4* w2s = reinterpret_cast<u32x4*>(smem + L_W2);
+    uint32_t* kc = reinterpret_cast<uint32_t*>(smem + L_KC);
+    uint32_t* vc = reinterpret_cast<uint32_t*>(smem + L_VC);
+    float* qs = reinterpret_cast<float*>(smem + L_QS);
+    float* xs = reinterpret_cast<float*>(smem + L_XS);
+    float* red = reinterpret_cast<float*>(smem + L_RED);
+    float* rss = reinterpret_cast<float*>(smem + L_RSS);
+    float* sc = reinterpret_cast<float*>(smem + L_SC);
+    float* amax = reinterpret_cast<float*>(smem + L_AMAX);
+    float* rope_c = reinterpret_cast<float*>(smem + L_ROPE);
+    float* rope_s = rope_c + 8 * 32;
+    int* s_ring = reinterpret_cast<int*>(smem + L_RING);
+    int* s_meta = s_ring + 8 * 17;
+    uint32_t* s_prev = reinterpret_cast<uint32_t*>(s_meta + 8 * 2);
+    uint32_t* s_misc = s_prev + 16;  // [0] cur0, [1] have_prev, [2] done, [3] epoch, [4..11] codes of this frame
+
+    const int tid_k = threadIdx.x, b = blockIdx.x;
+    int tid = tid_k, lane = tid & 63, wave = tid >> 6;
+    const int rep = b & (PF_REPL - 1);
+    u64* const edges = A.edges;
+    const u64* const my_edges = A.edges + (size_t)rep * PF_EDGE_CAP;  // + (e & 3) * PF_REPL * PF_EDGE_CAP per edge
+    const SampleCfg cfg = *A.cfg;
+
+    // ---- per-frame inputs (see "State ordering" above)
+    if (tid < 8 * 17) s_ring[tid] = A.rp.ring[tid];
+    else if (tid < 8 * 17 + 16) s_meta[tid - 8 * 17] = A.rp.ring_meta[tid - 8 * 17];
+    else if (tid < 8 * 17 + 32) s_prev[tid - 8 * 17 - 16] = A.state->prev[tid - 8 * 17 - 16];
+    else if (tid == 200) s_misc[0] = A.state->cur[0];
+    else if (tid == 201) s_misc[1] = (uint32_t)A.state->have_prev;
+    else if (tid == 202) s_misc[2] = (uint32_t)A.state->done;
+    else if (tid == 203) s_misc[3] = A.ctl[0];
+    if (tid >= 256) {  // RoPE rows 0..7
+        const int i = tid - 256;
+        rope_c[i] = A.cos_t[i];
+        rope_s[i] = A.sin_t[i];
+    }
+    __syncthreads();
+    const uint32_t cur0 = s_misc[0];
+    const bool have_prev = s_misc[1] != 0;
+    const int done_in = (int)s_misc[2];
+    const unsigned epoch = s_misc[3];
+    if (done_in == 2) return;  // generator already terminated: replays leave position / outputs untouched
+    const bool eos = cur0 == cfg.im_end_id;  // single_batch.rs:153-156: push zeros, skip the fast decoder
+    if (eos && b != 0) return;
+    const bool greedy = cfg.temp == 0.f;
+    if (!greedy && tid == 0 && b == 0) atomicAdd(A.ctl + 2, 1u);  // the host never launches this kernel with temp != 0
+
+    bool dead = false;
+    float x0 = 0.f, x1 = 0.f;
+    unsigned long long tk[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = A.prof ? wall_clock64() : 0;
+#define PF_TICK(k) do { if (A.prof) { const unsigned long long n_ = wall_clock64(); tk[k] += n_ - t_last; t_last = n_; } } while (0)
+    if (!eos) {
+        // ---- resident weights: 42 register chunks + 16 LDS chunks per lane
+        const u32x4* wp = reinterpret_cast<const u32x4*>(A.wpack) + (size_t)b * PF_CHUNKS * PF_THREADS + tid;
+        uint32_t wr[PF_REG_DW];
+#pragma unroll
+        for (int c = 0; c < PF_REG_CHUNKS; ++c) {
+            const u32x4 t4 = wp[(size_t)c * PF_THREADS];
+            wr[4 * c] = t4.x; wr[4 * c + 1] = t4.y; wr[4 * c + 2] = t4.z; wr[4 * c + 3] = t4.w;
+        }
+#pragma unroll
+        for (int c = 0; c < PF_LDS_CHUNKS; ++c) w2s[c * PF_THREADS + tid] = wp[(size_t)(PF_REG_CHUNKS + c) * PF_THREADS];
+        // repetition-penalty mask of this lane's two candidates of every codebook: bit 2 cb + k <=> mask[cb][2 tid + k] != 1
+        uint32_t mbits = 0;
+#pragma unroll
+        for (int cbi = 0; cbi < 8; ++cbi) {
+            const float2 m2 = *reinterpret_cast<const float2*>(A.rp.mask + (size_t)cbi * 1024 + 2 * tid);
+            mbits |= (m2.x != 1.0f ? 1u : 0u) << (2 * cbi);
+            mbits |= (m2.y != 1.0f ? 1u : 0u) << (2 * cbi + 1);
+        }
+        {
+            const float2 xin = *reinterpret_cast<const float2*>(A.xf + 2 * tid);
+            x0 = xin.x; x1 = xin.y;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every per-frame input has arrived before this workgroup's first publish
+        // pin the weight image: keeps the optimiser from re-loading (sinking) any of it into the loop
+#pragma unroll
+        for (int d = 0; d < PF_REG_DW; ++d) asm volatile("" : "+v"(wr[d]));
+
+        PF_TICK(0);
+        unsigned e = 0;                       // edge counter of this launch
+        const unsigned tag0 = epoch * 256u;   // tag of edge e = tag0 + e + 1
+        int par = 0;                          // parity of the double-buffered LDS partials
+#pragma unroll 1
+        for (int cb = 0; cb < 8; ++cb) {
+            const int T = cb + 1;
+#pragma unroll
+            for (int l = 0; l < PF_LAYERS; ++l) {
+                const uint32_t* wl = wr + 41 * l;
+                // ================= S1: (gather x) -> RMSNorm -> Wqkv rows -> publish 5 values
+                {
+                    tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
+                    const float2 nw = *reinterpret_cast<const float2*>(A.norms[2 * l] + 2 * tid);
+                    if (l > 0) {
+                        u32x4 v;
+                        pf_sweep1(my_edges + (size_t)(e & 3) * PF_REPL * PF_EDGE_CAP, tid, tag0 + e + 1, v, dead, A.ctl);
+                        x0 = __uint_as_float(v.x); x1 = __uint_as_float(v.z);
+                        ++e;
+                        PF_TICK(9);
+                    }
+                    *reinterpret_cast<float2*>(xs + 2 * tid) = make_float2(x0, x1);
+                    float ss = fmaf(x0, x0, 0.f);
+                    ss = fmaf(x1, x1, ss);
+                    ss = pf_wave_sum(ss);
+                    if (lane == 0) rss[par * 8 + wave] = ss;
+                    __syncthreads();
+                    float tot = rss[par * 8];
+#pragma unroll
+                    for (int w = 1; w < 8; ++w) tot += rss[par * 8 + w];
+                    const float dn = sqrtf(tot / 1024.f + A.eps);
+                    const float xn0 = (x0 / dn) * nw.x, xn1 = (x1 / dn) * nw.y;
+                    float a4[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a4[r] = pf_dot2(wl[r], xn0, xn1, 0.f);
+                    const float a5 = pf_dot2(wl[4], xn0, xn1, 0.f);
+                    const float r4 = pf_reduce<4>(a4, lane);
+                    const float r5 = pf_wave_sum(a5);
+                    if ((lane & 15) == 0) red[(par * 8 + wave) * 32 + (lane >> 4)] = r4;
+                    if (lane == 0) red[(par * 8 + wave) * 32 + 4] = r5;
+                    __syncthreads();
+                    if (tid < 5 * PF_REPL) {
+                        const int r = tid % 5, rr = tid / 5;
+                        float t = red[(par * 8) * 32 + r];
+#pragma unroll
+                        for (int w = 1; w < 8; ++w) t += red[(par * 8 + w) * 32 + r];
+                        pf_publish(edges, e, rr, 5 * b + r, tag0 + e + 1, t);
+                    }
+                    par ^= 1;
+                    PF_TICK(1);
+                }
+                // ================= S2: gather qkv -> RoPE, KV append, attention over T <= 8 tokens -> Wo rows + residual -> publish 4
+                {
+                    tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
+                    u32x4 vq, vk;
+                    const u64* eb = my_edges + (size_t)(e & 3) * PF_REPL * PF_EDGE_CAP;
+                    if (tid < 128) pf_sweep2(eb, tid, 512 + tid, tag0 + e + 1, vq, vk, dead, A.ctl);
+                    else pf_sweep1(eb, tid, tag0 + e + 1, vq, dead, A.ctl);
+                    ++e;
+                    PF_TICK(10);
+                    const int j = tid & 31;
+                    const float c = rope_c[cb * 32 + j], s = rope_s[cb * 32 + j];
+                    {   // q pair (dual_ar.rs:246-247)
+                        const float qa = __uint_as_float(vq.x), qb = __uint_as_float(vq.z);
+                        *reinterpret_cast<float2*>(qs + 2 * tid) = make_float2(qa * c - qb * s, qa * s + qb * c);
+                    }
+                    if (tid < 64) {   // k pair of kv head tid / 32: RoPE, bf16 (the cache dtype)
+                        const float ka = __uint_as_float(vk.x), kb = __uint_as_float(vk.z);
+                        kc[(l * 8 + cb) * 64 + tid] = f32_to_bf16_rne(ka * c - kb * s) | (f32_to_bf16_rne(ka * s + kb * c) << 16);
+                    } else if (tid < 128) {
+                        vc[(l * 8 + cb) * 64 + tid - 64] = f32_to_bf16_rne(__uint_as_float(vk.x)) | (f32_to_bf16_rne(__uint_as_float(vk.z)) << 16);
+                    }
+                    __syncthreads();
+                    const int h = tid >> 5, g = h >> 3, p = (tid >> 2) & 7, qd = tid & 3;
+                    {
+                        const float scale = 0.125f;  // 1 / sqrt(64), applied to K (dual_ar.rs:260)
+                        const float4* qp = reinterpret_cast<const float4*>(qs + h * 64 + qd * 16);
+                        const u32x4* kp = reinterpret_cast<const u32x4*>(kc + (l * 8 + p) * 64 + g * 32 + qd * 8);
+                        float acc = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            const u32x4 kw = kp[i];
+                            const float4 q0 = qp[2 * i], q1 = qp[2 * i + 1];
+                            acc = fmaf(q0.x, bf_lo(kw.x) * scale, acc); acc = fmaf(q0.y, bf_hi(kw.x) * scale, acc);
+                            acc = fmaf(q0.z, bf_lo(kw.y) * scale, acc); acc = fmaf(q0.w, bf_hi(kw.y) * scale, acc);
+                            acc = fmaf(q1.x, bf_lo(kw.z) * scale, acc); acc = fmaf(q1.y, bf_hi(kw.z) * scale, acc);
+                            acc = fmaf(q1.z, bf_lo(kw.w) * scale, acc); acc = fmaf(q1.w, bf_hi(kw.w) * scale, acc);
+                        }
+                        acc += pf_dpp<PF_XOR1>(acc);
+                        acc += pf_dpp<PF_XOR2>(acc);
+                        if (qd == 0) sc[h * 8 + p] = acc;
+                    }
+                    __builtin_amdgcn_wave_barrier();  // both heads of a wave are scored and consumed by that wave (LDS ops of a wave are in order)
+                    float at0, at1;
+                    {
+                        float mn = -1e30f;
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) if (t < T) mn = fmaxf(mn, sc[h * 8 + t]);
+                        float L = 0.f, O0 = 0.f, O1 = 0.f;
+#pragma unroll
+                        for (int t = 0; t < 8; ++t)
+                            if (t < T) {
+                                const float pr = __expf(sc[h * 8 + t] - mn);
+                                L += pr;
+                                const uint32_t vw = vc[(l * 8 + t) * 64 + g * 32 + j];
+                                O0 = fmaf(pr, bf_lo(vw), O0);
+                                O1 = fmaf(pr, bf_hi(vw), O1);
+                            }
+                        const float inv = 1.f / L;
+                        at0 = O0 * inv; at1 = O1 * inv;
+                    }
+                    float a4[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a4[r] = pf_dot2(wl[5 + r], at0, at1, 0.f);
+                    const float r4 = pf_reduce<4>(a4, lane);
+                    if ((lane & 15) == 0) red[(par * 8 + wave) * 32 + (lane >> 4)] = r4;
+                    float xres = 0.f;
+                    if (tid < 4 * PF_REPL) xres = xs[4 * b + (tid & 3)];
+                    __syncthreads();
+                    if (tid < 4 * PF_REPL) {
+                        const int r = tid & 3, rr = tid >> 2;
+                        float t = red[(par * 8) * 32 + r];
+#pragma unroll
+                        for (int w = 1; w < 8; ++w) t += red[(par * 8 + w) * 32 + r];
+                        pf_publish(edges, e, rr, 4 * b + r, tag0 + e + 1, xres + t);
+                    }
+                    par ^= 1;
+                    PF_TICK(2);
+                }
+                // ================= S3: gather h -> RMSNorm -> 16 SwiGLU pairs of W13 -> publish 16 activations
+                {
+                    tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
+                    const float2 nw = *reinterpret_cast<const float2*>(A.norms[2 * l + 1] + 2 * tid);
+                    u32x4 v;
+                    pf_sweep1(my_edges + (size_t)(e & 3) * PF_REPL * PF_EDGE_CAP, tid, tag0 + e + 1, v, dead, A.ctl);
+                    ++e;
+                    PF_TICK(11);
+                    x0 = __uint_as_float(v.x); x1 = __uint_as_float(v.z);
+                    *reinterpret_cast<float2*>(xs + 2 * tid) = make_float2(x0, x1);
+                    float ss = fmaf(x0, x0, 0.f);
+                    ss = fmaf(x1, x1, ss);
+                    ss = pf_wave_sum(ss);
+                    if (lane == 0) rss[par * 8 + wave] = ss;
+                    __syncthreads();
+                    float tot = rss[par * 8];
+#pragma unroll
+                    for (int w = 1; w < 8; ++w) tot += rss[par * 8 + w];
+                    const float dn = sqrtf(tot / 1024.f + A.eps);
+                    const float xn0 = (x0 / dn) * nw.x, xn1 = (x1 / dn) * nw.y;
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        float a16[16];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            a16[r] = pf_dot2(wl[9 + half * 16 + r], xn0, xn1, 0.f);
+                        }
+                        const float r16 = pf_reduce<16>(a16, lane);
+                        if ((lane & 3) == 0) red[(par * 8 + wave) * 32 + half * 16 + (lane >> 2)] = r16;
+                    }
+                    __syncthreads();
+                    if (tid < 16 * PF_REPL) {
+                        const int jj = tid & 15, rr = tid >> 4;
+                        float ga = red[(par * 8) * 32 + 2 * jj], gb = red[(par * 8) * 32 + 2 * jj + 1];
+#pragma unroll
+                        for (int w = 1; w < 8; ++w) { ga += red[(par * 8 + w) * 32 + 2 * jj]; gb += red[(par * 8 + w) * 32 + 2 * jj + 1]; }
+                        pf_publish(edges, e, rr, 16 * b + jj, tag0 + e + 1, (ga / (1.f + __expf(-ga))) * gb);  // candle silu = x / (1 + exp(-x))
+                    }
+                    par ^= 1;
+                    PF_TICK(3);
+                }
+                // ================= S4: gather the 4096 activations -> W2 rows (LDS-resident) + residual -> publish 4
+                {
+                    tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
+                    u32x4 v[4];
+                    pf_sweep4(my_edges + (size_t)(e & 3) * PF_REPL * PF_EDGE_CAP, tid, tag0 + e + 1, v, dead, A.ctl);
+                    ++e;
+                    PF_TICK(12);
+                    float a4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const u32x4 w = w2s[(l * 4 + q) * PF_THREADS + tid];
+                        const float c0 = __uint_as_float(v[q].x), c1 = __uint_as_float(v[q].z);
+                        a4[0] = fmaf(bf_lo(w.x), c0, a4[0]); a4[0] = fmaf(bf_hi(w.x), c1, a4[0]);
+                        a4[1] = fmaf(bf_lo(w.y), c0, a4[1]); a4[1] = fmaf(bf_hi(w.y), c1, a4[1]);
+                        a4[2] = fmaf(bf_lo(w.z), c0, a4[2]); a4[2] = fmaf(bf_hi(w.z), c1, a4[2]);
+                        a4[3] = fmaf(bf_lo(w.w), c0, a4[3]); a4[3] = fmaf(bf_hi(w.w), c1, a4[3]);
+                    }
+                    const float r4 = pf_reduce<4>(a4, lane);
+                    if ((lane & 15) == 0) red[(par * 8 + wave) * 32 + (lane >> 4)] = r4;
+                    float xres = 0.f;
+                    if (tid < 4 * PF_REPL) xres = xs[4 * b + (tid & 3)];
+                    __syncthreads();
+                    if (tid < 4 * PF_REPL) {
+                        const int r = tid & 3, rr = tid >> 2;
+                        float t = red[(par * 8) * 32 + r];
+#pragma unroll
+                        for (int w = 1; w < 8; ++w) t += red[(par * 8 + w) * 32 + r];
+                        pf_publish(edges, e, rr, 4 * b + r, tag0 + e + 1, xres + t);
+                    }
+                    par ^= 1;
+                    PF_TICK(4);
+                }
+            }
+            // ================= head: gather x -> fast_norm -> 4 rows of fast_output -> publish 4 logits
+            {
+                tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
+                const float2 nw = *reinterpret_cast<const float2*>(A.norms[2 * PF_LAYERS] + 2 * tid);
+                u32x4 v;
+                pf_sweep1(my_edges + (size_t)(e & 3) * PF_REPL * PF_EDGE_CAP, tid, tag0 + e + 1, v, dead, A.ctl);
+                ++e;
+                PF_TICK(13);
+                x0 = __uint_as_float(v.x); x1 = __uint_as_float(v.z);
+                float ss = fmaf(x0, x0, 0.f);
+                ss = fmaf(x1, x1, ss);
+                ss = pf_wave_sum(ss);
+                if (lane == 0) rss[par * 8 + wave] = ss;
+                __syncthreads();
+                float tot = rss[par * 8];
+#pragma unroll
+                for (int w = 1; w < 8; ++w) tot += rss[par * 8 + w];
+                const float dn = sqrtf(tot / 1024.f + A.eps);
+                const float xn0 = (x0 / dn) * nw.x, xn1 = (x1 / dn) * nw.y;
+                float a4[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a4[r] = pf_dot2(wr[PF_LAYERS * 41 + r], xn0, xn1, 0.f);
+                const float r4 = pf_reduce<4>(a4, lane);
+                if ((lane & 15) == 0) red[(par * 8 + wave) * 32 + (lane >> 4)] = r4;
+                __syncthreads();
+                if (tid < 4 * PF_REPL) {
+                    const int r = tid & 3, rr = tid >> 2;
+                    float t = red[(par * 8) * 32 + r];
+#pragma unroll
+                    for (int w = 1; w < 8; ++w) t += red[(par * 8 + w) * 32 + r];
+                    pf_publish(edges, e, rr, 4 * b + r, tag0 + e + 1, t);
+                }
+                par ^= 1;
+                    PF_TICK(5);
+            }
+            // ================= decision: gather the 1024 logits -> rep-pen -> argmax (host ArgMax rule: LAST maximal index) -> next input
+            {
+                tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
+                u32x4 v;
+                pf_sweep1(my_edges + (size_t)(e & 3) * PF_REPL * PF_EDGE_CAP, tid, tag0 + e + 1, v, dead, A.ctl);
+                ++e;
+                PF_TICK(14);
+                float lv0 = __uint_as_float(v.x), lv1 = __uint_as_float(v.z);
+                // SingleBatchedRepPenProcessor::apply (rep_pen.rs:37-65); "token in tokens_seen" == "mask[token] == penalty"
+                int last = -1, dropped = -1, head = 0, len = 0;
+                bool drop = false;
+                if (have_prev) {
+                    last = (int)s_prev[cb + 1];
+                    head = (s_meta[cb * 2] + 16) % 17;  // push_front
+                    len = s_meta[cb * 2 + 1] + 1;
+                    drop = len > 16;
+                    if (drop) dropped = s_ring[cb * 17 + (head + len - 1) % 17];  // pop_back
+                }
+                float m0 = ((mbits >> (2 * cb)) & 1u) ? cfg.rep_pen : 1.0f, m1 = ((mbits >> (2 * cb + 1)) & 1u) ? cfg.rep_pen : 1.0f;
+                if (have_prev) {
+                    const float o0 = m0, o1 = m1;
+                    const int i0 = 2 * tid, i1 = 2 * tid + 1;
+                    if (i0 == last) m0 = cfg.rep_pen;
+                    if (i0 == dropped && m0 == cfg.rep_pen) m0 = 1.0f;
+                    if (i1 == last) m1 = cfg.rep_pen;
+                    if (i1 == dropped && m1 == cfg.rep_pen) m1 = 1.0f;
+                    if (b == 0) {
+                        if (m0 != o0) A.rp.mask[(size_t)cb * 1024 + i0] = m0;
+                        if (m1 != o1) A.rp.mask[(size_t)cb * 1024 + i1] = m1;
+                        if (tid == 0) { A.rp.ring[cb * 17 + head] = last; A.rp.ring_meta[cb * 2] = head; A.rp.ring_meta[cb * 2 + 1] = drop ? 16 : len; }
+                    }
+                    lv0 = lv0 / m0; lv1 = lv1 / m1;
+                }
+                // per lane: ascending index, the later equal value wins
+                float bv = lv0;
+                int bi = 2 * tid;
+                if (!(lv1 < bv)) { bv = lv1; bi = 2 * tid + 1; }
+                float wm = bv;
+                wm = fmaxf(wm, pf_dpp<PF_XOR1>(wm)); wm = fmaxf(wm, pf_dpp<PF_XOR2>(wm));
+                wm = fmaxf(wm, pf_dpp<PF_HALF_MIRROR>(wm)); wm = fmaxf(wm, pf_dpp<PF_MIRROR>(wm));
+                wm = fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(wm), 15)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wm), 31))),
+                           fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(wm), 47)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wm), 63))));
+                int ci = (bv == wm) ? bi : -1;
+                ci = max(ci, __builtin_amdgcn_mov_dpp(ci, PF_XOR1, 0xF, 0xF, false)); ci = max(ci, __builtin_amdgcn_mov_dpp(ci, PF_XOR2, 0xF, 0xF, false));
+                ci = max(ci, __builtin_amdgcn_mov_dpp(ci, PF_HALF_MIRROR, 0xF, 0xF, false)); ci = max(ci, __builtin_amdgcn_mov_dpp(ci, PF_MIRROR, 0xF, 0xF, false));
+                ci = max(max(__builtin_amdgcn_readlane(ci, 15), __builtin_amdgcn_readlane(ci, 31)), max(__builtin_amdgcn_readlane(ci, 47), __builtin_amdgcn_readlane(ci, 63)));
+                if (lane == 0) { amax[(par * 8 + wave) * 2] = wm; amax[(par * 8 + wave) * 2 + 1] = __int_as_float(ci); }
+                __syncthreads();
+                float gv = amax[(par * 8) * 2];
+                int gi = __float_as_int(amax[(par * 8) * 2 + 1]);
+#pragma unroll
+                for (int w = 1; w < 8; ++w) {
+                    const float v2 = amax[(par * 8 + w) * 2];
+                    const int i2 = __float_as_int(amax[(par * 8 + w) * 2 + 1]);
+                    if (v2 > gv || (v2 == gv && i2 > gi)) { gv = v2; gi = i2; }
+                }
+                par ^= 1;
+                    PF_TICK(6);
+                const uint32_t code = (uint32_t)max(gi, 0);
+                if (tid == 0) {
+                    s_misc[4 + cb] = code;
+                    if (b == 0) A.state->cur[cb + 1] = code;
+                }
+                if (cb != 7) {  // hidden_states = fast_embeddings(code) (single_batch.rs:181-183)
+                    const uint32_t ew = reinterpret_cast<const uint32_t*>(A.fast_emb)[(size_t)code * 512 + tid];
+                    x0 = bf_lo(ew); x1 = bf_hi(ew);
+                }
+            }
+        }
+    } else if (tid < 8) {
+        s_misc[4 + tid] = 0;
+        A.state->cur[tid + 1] = 0;
+    }
+    if (b != 0) return;
+    // ---- end of frame, workgroup 0 only (single_batch.rs:185-210 + generate_blocking :250,264-266)
+    __syncthreads();
+    uint32_t* cur = s_prev;  // reuse: [slow, c0..c7]
+    if (tid == 0) cur[0] = cur0;
+    else if (tid <= 8) cur[tid] = s_misc[3 + tid];
+    __syncthreads();
+    if (tid == 0) {
+        SeqState* st = A.state;
+        const int frame = st->frame;
+        if (done_in == 1) st->done = 2;
+        if (frame == 0 || cur0 != cfg.im_end_id) {
+            const int o = st->n_out;
+            if (o < A.out_cap)
+                for (int cc = 0; cc < 8; ++cc) A.out_codes[(size_t)cc * A.out_cap + o] = cur[cc + 1];
+            st->n_out = o + 1;
+        }
+        for (int i = 0; i <= 8; ++i) st->prev[i] = cur[i];
+        st->have_prev = 1;
+        st->pos += 1;
+        st->frame = frame + 1;
+        A.ctl[0] = epoch + 1;
+    }
+    // next slow input: embed([slow, c0..c7]) (dual_ar.rs:532-567): token row first, then the codebook rows in order
+    {
+        const uint32_t sem = cur[0];
+        const float m = (sem >= cfg.sem_lo && sem <= cfg.sem_hi) ? 1.f : 0.f;
+        const uint32_t* te = reinterpret_cast<const uint32_t*>(A.tok_emb);
+        const uint32_t* ce = reinterpret_cast<const uint32_t*>(A.cb_emb);
+        const uint32_t w0 = te[(size_t)sem * 512 + tid];
+        float e0 = 0.f + bf_lo(w0), e1 = 0.f + bf_hi(w0);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const uint32_t wv = ce[((size_t)c * 1024 + cur[c + 1]) * 512 + tid];
+            e0 += bf_lo(wv) * m;
+            e1 += bf_hi(wv) * m;
+        }
+        *reinterpret_cast<float2*>(A.x + 2 * tid) = make_float2(e0, e1);
+    }
+    PF_TICK(7);
+    if (A.prof && tid == 0) for (int k = 0; k < 16; ++k) A.prof[k] += tk[k];
+#undef PF_TICK
+}
+
+// ------------------------------------------------------------------------------------------------ reduction self-test
+__global__ __launch_bounds__(64) void k_pf_reduce_selftest(const float* __restrict__ in, float* __restrict__ out) {
+    const int lane = threadIdx.x;
+    float v32[32], v16[16], v4[4];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) v32[i] = in[lane * 32 + i];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v16[i] = in[lane * 32 + i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v4[i] = in[lane * 32 + i];
+    const float r32 = pf_reduce<32>(v32, lane), r16 = pf_reduce<16>(v16, lane), r4 = pf_reduce<4>(v4, lane);
+    if ((lane & 1) == 0) out[lane >> 1] = r32;
+    if ((lane & 3) == 0) out[32 + (lane >> 2)] = r16;
+    if ((lane & 15) == 0) out[64 + (lane >> 4)] = r4;
+    const float ws = pf_wave_sum(in[lane * 32]);
+    if (lane == 63) out[64 + 4] = ws;
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+bool fast_persist_supported(const ModelDims& d, int n_fast_layer, int n_cb, int cb_size) {
+    return d.dim == 1024 && d.inter == 4096 && d.H == 16 && d.Hk == 2 && d.Dh == 64 && n_fast_layer == PF_LAYERS && n_cb == 8 &&
+           cb_size == 1024;
+}
+size_t fast_persist_pack_bytes() { return (size_t)PF_BLOCKS * PF_CHUNKS * PF_THREADS * 16; }
+size_t fast_persist_edge_bytes() { return (size_t)PF_RING * PF_REPL * PF_EDGE_CAP * 8; }
+
+void launch_fast_persist_pack(const LayerW* fast, const void* head_w, void* pack, hipStream_t st) {
+    hipLaunchKernelGGL(k_pf_pack, dim3(PF_BLOCKS, PF_CHUNKS), dim3(PF_THREADS), 0, st, fast[0], fast[1], fast[2], fast[3],
+                       reinterpret_cast<const uint32_t*>(head_w), reinterpret_cast<u32x4*>(pack));
+    FS_HIP(hipGetLastError());
+}
+
+void launch_fast_persist(const FastPersistArgs& a, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_persist), hipFuncAttributeMaxDynamicSharedMemorySize, L_END));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_fast_persist, dim3(PF_BLOCKS), dim3(PF_THREADS), L_END, st, a);
+    FS_HIP(hipGetLastError());
+}
+
+void launch_pf_reduce_selftest(const float* in, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_pf_reduce_selftest, dim3(1), dim3(64), 0, st, in, out);
+    FS_HIP(hipGetLastError());
+}
+
+}  // namespace fs

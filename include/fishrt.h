@@ -107,8 +107,13 @@ int fs_lm_curr_kv_size(fs_lm_t* lm);                       /* dual_ar.rs:695-700
  * *n_frames receives the number of frames written (<= cap).  The KV cache is NOT cleared first (the caller
  * owns cache lifetime exactly as with the reference: fish_speech_python/src/lm.rs:94,131-135).
  * seed: seeds the sampler RNG (the reference draws rand::random(), single_batch.rs:46).
- * flags: FS_GEN_IGNORE_EOS masks <|im_end|> (bench-only, fixed-length runs: SURVEY.md §8d). */
+ * flags: FS_GEN_IGNORE_EOS masks <|im_end|> (bench-only, fixed-length runs: SURVEY.md §8d).
+ *        FS_GEN_NO_PERSIST keeps the fast decoder on the per-node graph path.  By default a greedy call (temp == 0) on a bf16 handle
+ *        with the Fish geometry runs the 8 codebook passes of every frame as ONE persistent launch (csrc/lm_persist.hip: weights
+ *        resident in VGPRs / LDS, in-launch hand-offs); that launch needs all 256 CUs of the device, so only one generate call per
+ *        GPU uses it at a time (a concurrent call on another handle silently takes the per-node path). */
 #define FS_GEN_IGNORE_EOS 1u
+#define FS_GEN_NO_PERSIST 2u
 int fs_lm_generate(fs_lm_t* lm, const uint32_t* prompt, int L, int max_new_tokens, const fs_sampling* sampling,
                    uint64_t seed, uint32_t flags, uint32_t* codes_out, size_t cap, size_t* n_frames, fs_frame_cb cb,
                    void* cb_user);

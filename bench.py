@@ -6,9 +6,14 @@ Fish-Speech-1.5 (synthetic weights at the true shapes), bf16, batch=1, default-v
 A "step" is ONE REQUEST through the hot path (prefill of the prompt + 256 decode frames) on each rank; at N GPUs every
 rank serves its own independent request stream (replica fan-out, weak scaling, no data-path collective: SURVEY.md §8e).
 value = frames produced by all ranks / wall time of the timed region (prefill included), max over ranks.
+`python bench.py --gpus N` starts its own ranks (torch.distributed.run) when no launcher environment is present; under the
+driver's `python -m torch.distributed.run ... bench.py --gpus N` it uses the given ranks.  `--config 3` runs BASELINE.json
+configs[3] instead (256 requests sharded i mod N, static batches of 32 per GPU, strong scaling).  Without a visible MI355X the
+ranks exercise the control path only (dry run, value null): libfishrt has no CPU path.
 
 Extra objects on the JSON line:
-  roofline     -- HBM roofline of the decode FRAME (one hipGraph replay = 266 kernels = the unit of the hot loop):
+  roofline     -- HBM roofline of the decode FRAME (one hipGraph replay = the unit of the hot loop: 123 kernels with the
+                  persistent fast decoder, 266 with --no-persistent):
                   achieved = B_frame(T_avg) / t_frame, t_frame from HIP events recorded on the engine's own stream
                   (fs_lm_last_stats); B_frame is SURVEY.md §8(d)'s algorithmic-bytes formula.
   cpu_baseline -- the CPU restatement (oracle/, kind "port": the reference is Rust+candle and cannot be built here) timed
@@ -68,29 +73,175 @@ def frame_bytes(cfg, tok, T, wbytes=2):
     return slow + fast + kv_tok * T + kv_fast
 
 
+def config2_prompts(tok, n):
+    """SURVEY.md §8d configs[2] / [3]: prompt lengths U{64..384}, seed 77; row 0 random text ids, codebook rows 0."""
+    rng = np.random.RandomState(77)
+    lens = rng.randint(64, 385, 256)
+    prompts = []
+    for L in lens:
+        p = np.zeros((9, int(L)), np.uint32)
+        p[0] = rng.randint(0, tok["im_end_id"], int(L))
+        prompts.append(p)
+    return prompts[:n]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start one process per GPU ourselves."""
+    if args.gpus <= 1 or "RANK" in os.environ or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
+
+
+def dry_run(args, dist, rank, world):
+    """No MI355X visible (CPU box): exercise the launch, request sharding, prompt broadcast and code fan-in with the gloo backend
+    on placeholder code arrays -- nothing is computed or timed, `value` is null.  libfishrt has no CPU path to fall back to."""
+    from fishrt import config as fcfg, fanout
+    tok = fcfg.FISH_1_5_TOKENS
+    n_req, B, frames = 256, 32, 4
+    packed = lens = None
+    if rank == 0:
+        prompts = config2_prompts(tok, n_req)
+        lens = np.array([p.shape[1] for p in prompts], np.int32)
+        packed = np.zeros((n_req, 9, int(lens.max())), np.uint32)
+        for i, p in enumerate(prompts):
+            packed[i, :, : p.shape[1]] = p
+    packed, lens = fanout.broadcast_prompts(dist, packed, lens)
+    mine = fanout.shard_requests(n_req, rank, world)
+    codes = np.stack([np.full((8, frames), int(packed[i, 0, lens[i] - 1]) % 1000, np.uint32) for i in mine])
+    ca, fa, seen = fanout.all_gather_codes(dist, codes, np.full(len(mine), frames, np.int32))
+    ok = seen == world and all((ca[r, k] == int(packed[i, 0, lens[i] - 1]) % 1000).all()
+                               for r in range(world) for k, i in enumerate(fanout.shard_requests(n_req, r, world)))
+    fanout.barrier(dist)
+    if rank == 0:
+        print(json.dumps({"metric": "codec tokens/sec (frames/s)", "value": None, "unit": "frames/s", "n_gpus": world, "dry_run": True,
+                          "reason": "no HIP device visible: control path only (launch, shard, broadcast, all-gather); fishrt has no CPU path",
+                          "requests": n_req, "requests_per_rank": [len(fanout.shard_requests(n_req, r, world)) for r in range(world)],
+                          "collective_ranks": int(seen), "backend": "gloo" if dist is not None else None, "fan_in_ok": bool(ok),
+                          "batch_per_rank": B}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
+
+
+def run_config3(args, lm_factory, dist, rank, world, cfg, tok):
+    """BASELINE.json configs[3]: 256 requests (configs[2] prompts), request i -> rank i mod N, static batches of 32 per rank
+    (generate_static_batch, temp 0.7 / top-p 0.8 / top-k 256, on-device sampling), `frames` frames per request.  The prompt batch is
+    broadcast from rank 0 and the codes are all-gathered at the end (RCCL); nothing on the per-token path crosses GPUs."""
+    import torch
+    from fishrt import fanout
+    n_req, B, frames = 256, 32, args.frames
+    packed = lens = None
+    if rank == 0:
+        prompts = config2_prompts(tok, n_req)
+        lens = np.array([p.shape[1] for p in prompts], np.int32)
+        packed = np.zeros((n_req, 9, int(lens.max())), np.uint32)
+        for i, p in enumerate(prompts):
+            packed[i, :, : p.shape[1]] = p
+    packed, lens = fanout.broadcast_prompts(dist, packed, lens)
+    mine = fanout.shard_requests(n_req, rank, world)
+    lm = lm_factory(B)
+
+    def one_job():
+        codes = np.zeros((len(mine), 8, frames), np.uint32)
+        nf = np.zeros(len(mine), np.int32)
+        dec_s = pre_s = 0.0
+        for b0 in range(0, len(mine), B):
+            idx = mine[b0:b0 + B]
+            ps = [np.ascontiguousarray(packed[i, :, : lens[i]]) for i in idx]
+            Lmax = max(p.shape[1] for p in ps)
+            outs = lm.generate_static_batch(ps, frames + Lmax - 2, temp=0.7, top_p=0.8, top_k=256, seed=42, ignore_eos=True)
+            st = lm.last_stats()
+            dec_s += st["decode_ms"] * 1e-3
+            pre_s += st["prefill_ms"] * 1e-3
+            for k, o in enumerate(outs):
+                codes[b0 + k, :, : o.shape[1]] = o
+                nf[b0 + k] = o.shape[1]
+        return codes, nf, dec_s, pre_s
+
+    def barrier():
+        fanout.barrier(dist)
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_job()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        codes, nf, dec_s, pre_s = one_job()
+        ca, fa, seen = fanout.all_gather_codes(dist, codes, nf)  # the job's fan-in is part of the timed region
+    barrier()
+    dt = fanout.max_over_ranks(dist, time.perf_counter() - t0)
+    assert seen == world and fa.shape == (world, len(mine)) and int(fa.sum()) == n_req * frames, (seen, fa.shape, int(fa.sum()))
+    frames_total = n_req * frames * args.steps
+    n_batches = (len(mine) + B - 1) // B
+    step_s = dec_s / (n_batches * (frames - 1))
+    res = {
+        "metric": "codec tokens/sec (frames/s; 1 frame = 1 slow + 8 codebook tokens = 2048 PCM samples), Fish-1.5 static batches of 32",
+        "value": round(frames_total / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic (deterministic synthetic weights at Fish-1.5 shapes; configs[2] prompts U{64..384})",
+        "config": {"workload": "BASELINE.json configs[3]: 256 requests sharded i mod N, static batches of 32 per GPU, "
+                               f"temp 0.7 / top-p 0.8 / top-k 256, {frames} frames per request; one step = the whole 256-request job "
+                               "(prefill + decode + code fan-in in the timed region)",
+                   "requests": n_req, "batch_per_gpu": B, "frames_per_request": frames,
+                   "parallelism": f"request shards x{world}; prompt broadcast + code all-gather over RCCL, no per-token collective"},
+        "rtf": round((frames_total / FRAME_RATE) / dt, 2),
+        "rccl_ranks": int(seen), "frames_per_rank": [int(v) for v in fa.sum(axis=1)],
+        "decode_step_us_rank0": round(step_s * 1e6, 1), "prefill_s_per_job_rank0": round(pre_s, 3),
+        "roofline": {"bound": "hbm", "kernel": "static-batch decode step (one graph replay, B = 32 rows on the MFMA row path)",
+                     "achieved": round((frame_bytes(cfg, tok, 0) + B * 12288 * (float(lens.mean()) + frames / 2)) / step_s / 1e9, 2),
+                     "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                     "frac": round((frame_bytes(cfg, tok, 0) + B * 12288 * (float(lens.mean()) + frames / 2)) / step_s / HBM_PEAK, 4), "traffic": None},
+    }
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=256)
+    ap.add_argument("--config", type=int, default=1, choices=(1, 3),
+                    help="1: BASELINE.json configs[1] (batch-1 request per GPU, the headline metric); 3: configs[3] (256 requests sharded 32/GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed configs[2] / vocoder side measurements")
+    ap.add_argument("--no-persistent", action="store_true", help="FS_GEN_NO_PERSIST: fast decoder as 144 graph nodes per frame (A/B)")
     args = ap.parse_args()
+    self_launch(args)
 
-    import torch
+    import torch  # before libfishrt: both bring a HIP runtime, and the one loaded first serves the process
     import fishrt
     from fishrt import config as fcfg, fanout
     rank, local_rank, world = fanout.env_rank()
-    dist = fanout.init("nccl" if world > 1 else None)  # RCCL; control plane only (barrier + max-reduce)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}; run `python bench.py --gpus N` (it starts the "
+              f"ranks itself) or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`", file=sys.stderr)
+        sys.exit(2)
+    have_gpu = fishrt.lib().fs_device_count() > 0
+    dist = fanout.init(("nccl" if have_gpu else "gloo") if world > 1 else None)  # nccl == RCCL: control plane + request fan-out only
+    if not have_gpu:
+        dry_run(args, dist, rank, world)
 
     cfg, tok = fcfg.FISH_1_5, fcfg.FISH_1_5_TOKENS
+    if args.config == 3:
+        return run_config3(args, lambda B: fishrt.DualARTransformer(cfg, tok, local_rank, "bf16", max_batch=B).load_synthetic(SEED),
+                           dist, rank, world, cfg, tok)
     lm = fishrt.DualARTransformer(cfg, tok, local_rank, "bf16").load_synthetic(SEED)
     prompt = default_voice_prompt(tok)
     L = prompt.shape[1]
     M = args.frames + L - 2  # budget counts prompt tokens (single_batch.rs:61,77): frames = M - L + 2
-    samp = dict(temp=0.0, top_p=1.0, top_k=0, repetition_penalty=1.2, ignore_eos=True)
+    samp = dict(temp=0.0, top_p=1.0, top_k=0, repetition_penalty=1.2, ignore_eos=True, persistent=not args.no_persistent)
 
     def one_request():
         lm.clear_slow_layer_caches()
@@ -115,17 +266,21 @@ def main():
     if args.warmup:
         assert np.array_equal(out, ref_out), "non-deterministic greedy tokens across requests"
     dt = fanout.max_over_ranks(dist, dt)
+    # fan-in of every rank's codes: one all-gather over RCCL after the timed region
+    ca, fa, seen = fanout.all_gather_codes(dist, out[None], np.array([out.shape[1]], np.int32))
+    assert seen == world and ca.shape == (world, 1, 8, args.frames)
 
     frames_total = args.frames * args.steps * world
     value = frames_total / dt
     dec_ms = float(np.mean([s["decode_ms"] for s in stats]))
     pre_ms = float(np.mean([s["prefill_ms"] for s in stats]))
+    kpf = int(stats[-1]["kernels_per_frame"])
     t_frame = dec_ms * 1e-3 / (args.frames - 1)  # events bracket frames 1..n-1 exactly like `start_decode` (:261)
     T_avg = L + args.frames / 2.0
     bf = frame_bytes(cfg, tok, T_avg)
     achieved = bf / t_frame
-    # the dominant kernel of the frame by bytes: k_ffn_up (RMSNorm + W1||W3 GEMV + SwiGLU), 56 launches per frame, measured live as a graph
-    # node over distinct layer weights with HIP events on the engine stream (fs_lm_bench_kernel); rocprof: profiles/r01_bench_kernel_stats.csv
+    # the dominant kernel of the frame by bytes: k_ffn_up (RMSNorm + W1||W3 GEMV + SwiGLU) of the slow transformer, measured live as a graph
+    # node over distinct layer weights with HIP events on the engine stream (fs_lm_bench_kernel); rocprof: profiles/
     up_us = lm.bench_kernel(3, int(T_avg), 50)
     up_bytes = 2 * (2 * cfg["intermediate_size"] * cfg["dim"]) + 8 * cfg["dim"] + 4 * cfg["intermediate_size"]
     per_kernel = {}
@@ -134,6 +289,7 @@ def main():
                                ("k_wo", 2, 2 * cfg["dim"] * cfg["dim"]), ("k_ffn_down", 4, 2 * cfg["dim"] * cfg["intermediate_size"])):
         us = lm.bench_kernel(kind, int(T_avg), 50)
         per_kernel[name] = {"avg_us": round(us, 2), "algorithmic_bytes": nbytes, "GBps": round(nbytes / us / 1e3, 1)}
+    traffic = offline_traffic(kpf)
     res = {
         "metric": "codec tokens/sec (frames/s; 1 frame = 1 slow + 8 codebook tokens = 2048 PCM samples), Fish-1.5 batch=1",
         "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -142,18 +298,17 @@ def main():
         "config": {"workload": "BASELINE.json configs[1]: Fish-1.5 bf16 batch=1, default-voice prompt, 256-frame generation, "
                                "one request per step per GPU (prefill included in the timed region)",
                    "prompt_positions": L, "frames_per_request": args.frames, "requests_per_step": world,
-                   "parallelism": f"replicas x{world} (no data-path collective)"},
-        "rtf": round((frames_total / FRAME_RATE) / dt, 2),
+                   "parallelism": f"replicas x{world} (no data-path collective; codes all-gathered over RCCL after the run)"},
+        "rtf": round((frames_total / FRAME_RATE) / dt, 2), "rccl_ranks": int(seen), "frames_per_rank": [int(v) for v in fa.sum(axis=1) * args.steps],
         "decode_frames_per_s_per_gpu": round(1.0 / t_frame, 2), "prefill_ms": round(pre_ms, 3),
-        "roofline": {"bound": "hbm", "kernel": "decode frame = one hipGraph replay (24 slow blocks + head + sample + 8 x (4 fast "
-                                               "blocks + head + sample)); HIP-event timed on the engine stream",
+        "roofline": {"bound": "hbm", "kernel": f"decode frame = one hipGraph replay of {kpf} kernels (24 slow blocks x 5 + head + sample, then "
+                                               + ("the 8 codebook passes of the fast decoder as ONE persistent launch" if kpf < 200 else "8 x (4 fast blocks x 4 + head + sample)")
+                                               + "); HIP-event timed on the engine stream",
                      "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK, 4),
-                     # HBM bytes per frame from the PMC passes of profiles/r01_pmc_hbm_traffic.csv (FETCH_SIZE x2 gfx950 correction
-                     # + WRITE_SIZE, summed over the frame's 266 launches); collected offline, not in this run
-                     "traffic": 1.75e9, "traffic_source": "profiles/r01_pmc_hbm_traffic.csv (offline rocprofv3 --pmc passes)",
-                     "algorithmic_bytes_per_frame": int(bf), "frame_us": round(t_frame * 1e6, 2), "kv_len_avg": T_avg,
-                     "dominant_kernel": {"name": "k_ffn_up<bf16, 1024> (RMSNorm + W1||W3 GEMV + SwiGLU; 56 of the frame's 266 launches, 55 % of its bytes)",
+                     **traffic,
+                     "algorithmic_bytes_per_frame": int(bf), "frame_us": round(t_frame * 1e6, 2), "kv_len_avg": T_avg, "kernels_per_frame": kpf,
+                     "dominant_kernel": {"name": "k_ffn_up<bf16, 1024> (RMSNorm + W1||W3 GEMV + SwiGLU; the slow transformer's 24 launches = 24 % of the frame's algorithmic bytes)",
                                          "algorithmic_bytes_per_launch": up_bytes, "avg_us": round(up_us, 2),
                                          "achieved": round(up_bytes / up_us / 1e3, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                                          "frac": round(up_bytes / (up_us * 1e-6) / HBM_PEAK, 4),
@@ -170,19 +325,27 @@ def main():
         dist.destroy_process_group()
 
 
+def offline_traffic(kernels_per_frame):
+    """roofline.traffic: HBM bytes per decode frame from the PMC passes summarised in profiles/r02_pmc_hbm_traffic.json (written by
+    tools/pmc_traffic.py from `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs; counters cannot be read inside this process).
+    The summary names the command, the counter corrections and the commit it was taken at; null when no summary matches the path."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
+    if os.path.exists(path):
+        with open(path) as f:
+            t = json.load(f)
+        key = "persistent" if kernels_per_frame < 200 else "per_node"
+        if key in t:
+            return {"traffic": t[key]["hbm_bytes_per_frame"], "traffic_source": f"offline: profiles/r02_pmc_hbm_traffic.json[{key}] ({t[key].get('command', '')}; commit {t.get('commit', '?')})"}
+    return {"traffic": None, "traffic_source": "no PMC summary for this path under profiles/ (tools/pmc_traffic.sh)"}
+
+
 def extras(cfg, tok):
     """Side measurements outside the timed region (not part of `value`): BASELINE.json configs[2] (static batch of 32 on the
     MFMA row path), the Firefly vocoder on the 256 frames of one request, the encoder on a 10 s clip, and batch-1 decode with the
     on-device top-k/top-p sampler and with fp8 weights."""
     import fishrt
     out = {}
-    rng = np.random.RandomState(77)
-    lens = rng.randint(64, 385, 256)  # SURVEY.md §8d configs[2]: prompt lengths U{64..384}, seed 77 (first 32 = the B=32 batch)
-    prompts_all = []
-    for L in lens:
-        p = np.zeros((9, int(L)), np.uint32)
-        p[0] = rng.randint(0, tok["im_end_id"], int(L))
-        prompts_all.append(p)
+    prompts_all = config2_prompts(tok, 256)  # SURVEY.md §8d configs[2]: prompt lengths U{64..384}, seed 77 (first 32 = the B=32 batch)
     for name, dtype, wb, B, frames in (("static_batch32", "bf16", 2, 32, 64), ("static_batch32_fp8", "fp8", 1, 32, 64),
                                        ("static_batch256", "bf16", 2, 256, 32)):
         prompts = prompts_all[:B]

@@ -367,6 +367,7 @@ class LM final : public LMBase {
         launch_frame(0);
         FS_HIP(hipEventRecord(ev_[1], st_));
         stats_.graph_launches = (uint64_t)L;
+        stats_.kernels_per_frame = (uint64_t)(a_.n_layer * 5 + 2 + (use_persist_ ? 1 : a_.num_codebooks * (a_.n_fast_layer * 4 + 2)));
         // decode: one graph replay per frame; the host only peeks at the done flag every CHUNK frames
         const int CHUNK = cb ? 8 : 32;
         long long it = 1;

@@ -71,10 +71,10 @@ constexpr int PF_XOR1 = 0xB1, PF_XOR2 = 0x4E, PF_HALF_MIRROR = 0x141, PF_MIRROR 
 // Sum of N per-lane values over the 64 lanes of a wave, all N at once: levels [lane^32, lane^16, row mirror, half mirror, xor 2,
 // xor 1]; while more than one value is alive a level HALVES the value set (the lanes on either side keep different values and
 // exchange the other half), afterwards it is a plain butterfly.  Returns the total of value index
-//   N = 32: lane >> 1;   N = 16: lane >> 2;   N = 4: lane >> 4          (every lane of the group holds it).
+//   N = 32: lane >> 1;   N = 16: lane >> 2;   N = 8: lane >> 3;   N = 4: lane >> 4     (every lane of the group holds it).
 template <int N>
 __device__ __forceinline__ float pf_reduce(float (&v)[N], int lane) {
-    static_assert(N == 4 || N == 16 || N == 32, "value counts used by the kernel");
+    static_assert(N == 4 || N == 8 || N == 16 || N == 32, "value counts used by the kernel");
     int n = N;
     // level lane^32
     {
@@ -101,7 +101,7 @@ __device__ __forceinline__ float pf_reduce(float (&v)[N], int lane) {
         t += pf_dpp<PF_MIRROR>(t); t += pf_dpp<PF_HALF_MIRROR>(t); t += pf_dpp<PF_XOR2>(t); t += pf_dpp<PF_XOR1>(t);
         return t;
     }
-    // N >= 16: n = N / 4 values (8 or 4) alive
+    // N >= 8: n = N / 4 values (8, 4 or 2) alive
     {   // row mirror: lanes 0..7 <-> 15..8
         const bool pred = (lane & 8) != 0;
         const int h = n / 2;
@@ -111,6 +111,11 @@ __device__ __forceinline__ float pf_reduce(float (&v)[N], int lane) {
             v[i] = keep + pf_dpp<PF_MIRROR>(send);
         }
         n = h;
+    }
+    if (N == 8) {  // one value left
+        float t = v[0];
+        t += pf_dpp<PF_HALF_MIRROR>(t); t += pf_dpp<PF_XOR2>(t); t += pf_dpp<PF_XOR1>(t);
+        return t;
     }
     {   // half mirror: lanes 0..3 <-> 7..4
         const bool pred = (lane & 4) != 0;
@@ -192,9 +197,9 @@ constexpr int L_KC = L_W2 + PF_LDS_CHUNKS * PF_THREADS * 16;  // K cache: [4 lay
 constexpr int L_VC = L_KC + PF_LAYERS * 8 * 64 * 4;
 constexpr int L_QS = L_VC + PF_LAYERS * 8 * 64 * 4;       // rope'd q, f32 [1024]
 constexpr int L_XS = L_QS + 4096;                          // residual stream copy, f32 [1024]
-constexpr int L_RED = L_XS + 4096;                         // [2][8 waves][32] row partials
-constexpr int L_RSS = L_RED + 2 * 8 * 32 * 4;              // [2][8] sum-of-squares partials
-constexpr int L_SC = L_RSS + 2 * 8 * 4;                    // [16 heads][8 pos] attention scores
+constexpr int PF_RED = 40;                                 // row partials per wave: 32 rows + sum of squares
+constexpr int L_RED = L_XS + 4096;                         // [2][8 waves][PF_RED]
+constexpr int L_SC = L_RED + 2 * 8 * PF_RED * 4;                   // [16 heads][8 pos] attention scores
 constexpr int L_AMAX = L_SC + 16 * 8 * 4;                  // [2][8 waves] {value, index}
 constexpr int L_ROPE = L_AMAX + 2 * 8 * 8;                 // cos [8][32], sin [8][32]
 constexpr int L_RING = L_ROPE + 2 * 8 * 32 * 4;            // rep-pen ring [8][17], meta [8][2], prev [16], misc [16]
@@ -245,7 +250,6 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
     float* qs = reinterpret_cast<float*>(smem + L_QS);
     float* xs = reinterpret_cast<float*>(smem + L_XS);
     float* red = reinterpret_cast<float*>(smem + L_RED);
-    float* rss = reinterpret_cast<float*>(smem + L_RSS);
     float* sc = reinterpret_cast<float*>(smem + L_SC);
     float* amax = reinterpret_cast<float*>(smem + L_AMAX);
     float* rope_c = reinterpret_cast<float*>(smem + L_ROPE);
@@ -301,6 +305,9 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
         }
 #pragma unroll
         for (int c = 0; c < PF_LDS_CHUNKS; ++c) w2s[c * PF_THREADS + tid] = wp[(size_t)(PF_REG_CHUNKS + c) * PF_THREADS];
+        float2 nwr[2 * PF_LAYERS + 1];  // this lane's slice of the nine RMSNorm weight vectors
+#pragma unroll
+        for (int i = 0; i < 2 * PF_LAYERS + 1; ++i) nwr[i] = *reinterpret_cast<const float2*>(A.norms[i] + 2 * tid);
         // repetition-penalty mask of this lane's two candidates of every codebook: bit 2 cb + k <=> mask[cb][2 tid + k] != 1
         uint32_t mbits = 0;
 #pragma unroll
@@ -331,7 +338,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
                 // ================= S1: (gather x) -> RMSNorm -> Wqkv rows -> publish 5 values
                 {
                     tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
-                    const float2 nw = *reinterpret_cast<const float2*>(A.norms[2 * l] + 2 * tid);
+                    const float2 nw = nwr[2 * l];
                     if (l > 0) {
                         u32x4 v;
                         pf_sweep1(my_edges + (size_t)(e & 3) * PF_REPL * PF_EDGE_CAP, tid, tag0 + e + 1, v, dead, A.ctl);
@@ -340,31 +347,23 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
                         PF_TICK(9);
                     }
                     *reinterpret_cast<float2*>(xs + 2 * tid) = make_float2(x0, x1);
-                    float ss = fmaf(x0, x0, 0.f);
-                    ss = fmaf(x1, x1, ss);
-                    ss = pf_wave_sum(ss);
-                    if (lane == 0) rss[par * 8 + wave] = ss;
-                    __syncthreads();
-                    float tot = rss[par * 8];
+                    // RMSNorm folded through the GEMV: W . ((x / d) * g) = (W . (x * g)) / d -- the row sums and sum(x^2) go through ONE
+                    // reduction (no separate norm barrier); the publishing lanes divide by d
+                    const float xn0 = x0 * nw.x, xn1 = x1 * nw.y;
+                    float a8[8];
 #pragma unroll
-                    for (int w = 1; w < 8; ++w) tot += rss[par * 8 + w];
-                    const float dn = sqrtf(tot / 1024.f + A.eps);
-                    const float xn0 = (x0 / dn) * nw.x, xn1 = (x1 / dn) * nw.y;
-                    float a4[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) a4[r] = pf_dot2(wl[r], xn0, xn1, 0.f);
-                    const float a5 = pf_dot2(wl[4], xn0, xn1, 0.f);
-                    const float r4 = pf_reduce<4>(a4, lane);
-                    const float r5 = pf_wave_sum(a5);
-                    if ((lane & 15) == 0) red[(par * 8 + wave) * 32 + (lane >> 4)] = r4;
-                    if (lane == 0) red[(par * 8 + wave) * 32 + 4] = r5;
+                    for (int r = 0; r < 5; ++r) a8[r] = pf_dot2(wl[r], xn0, xn1, 0.f);
+                    a8[5] = fmaf(x1, x1, fmaf(x0, x0, 0.f));
+                    a8[6] = 0.f; a8[7] = 0.f;
+                    const float r8 = pf_reduce<8>(a8, lane);
+                    if ((lane & 7) == 0) red[(par * 8 + wave) * PF_RED + (lane >> 3)] = r8;
                     __syncthreads();
                     if (tid < 5 * PF_REPL) {
                         const int r = tid % 5, rr = tid / 5;
-                        float t = red[(par * 8) * 32 + r];
+                        float t = red[(par * 8) * PF_RED + r], tot = red[(par * 8) * PF_RED + 5];
 #pragma unroll
-                        for (int w = 1; w < 8; ++w) t += red[(par * 8 + w) * 32 + r];
-                        pf_publish(edges, e, rr, 5 * b + r, tag0 + e + 1, t);
+                        for (int w = 1; w < 8; ++w) { t += red[(par * 8 + w) * PF_RED + r]; tot += red[(par * 8 + w) * PF_RED + 5]; }
+                        pf_publish(edges, e, rr, 5 * b + r, tag0 + e + 1, t / sqrtf(tot / 1024.f + A.eps));
                     }
                     par ^= 1;
                     PF_TICK(1);
@@ -433,15 +432,15 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) a4[r] = pf_dot2(wl[5 + r], at0, at1, 0.f);
                     const float r4 = pf_reduce<4>(a4, lane);
-                    if ((lane & 15) == 0) red[(par * 8 + wave) * 32 + (lane >> 4)] = r4;
+                    if ((lane & 15) == 0) red[(par * 8 + wave) * PF_RED + (lane >> 4)] = r4;
                     float xres = 0.f;
                     if (tid < 4 * PF_REPL) xres = xs[4 * b + (tid & 3)];
                     __syncthreads();
                     if (tid < 4 * PF_REPL) {
                         const int r = tid & 3, rr = tid >> 2;
-                        float t = red[(par * 8) * 32 + r];
+                        float t = red[(par * 8) * PF_RED + r];
 #pragma unroll
-                        for (int w = 1; w < 8; ++w) t += red[(par * 8 + w) * 32 + r];
+                        for (int w = 1; w < 8; ++w) t += red[(par * 8 + w) * PF_RED + r];
                         pf_publish(edges, e, rr, 4 * b + r, tag0 + e + 1, xres + t);
                     }
                     par ^= 1;
@@ -450,39 +449,35 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
                 // ================= S3: gather h -> RMSNorm -> 16 SwiGLU pairs of W13 -> publish 16 activations
                 {
                     tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
-                    const float2 nw = *reinterpret_cast<const float2*>(A.norms[2 * l + 1] + 2 * tid);
+                    const float2 nw = nwr[2 * l + 1];
                     u32x4 v;
                     pf_sweep1(my_edges + (size_t)(e & 3) * PF_REPL * PF_EDGE_CAP, tid, tag0 + e + 1, v, dead, A.ctl);
                     ++e;
                     PF_TICK(11);
                     x0 = __uint_as_float(v.x); x1 = __uint_as_float(v.z);
                     *reinterpret_cast<float2*>(xs + 2 * tid) = make_float2(x0, x1);
-                    float ss = fmaf(x0, x0, 0.f);
-                    ss = fmaf(x1, x1, ss);
-                    ss = pf_wave_sum(ss);
-                    if (lane == 0) rss[par * 8 + wave] = ss;
-                    __syncthreads();
-                    float tot = rss[par * 8];
-#pragma unroll
-                    for (int w = 1; w < 8; ++w) tot += rss[par * 8 + w];
-                    const float dn = sqrtf(tot / 1024.f + A.eps);
-                    const float xn0 = (x0 / dn) * nw.x, xn1 = (x1 / dn) * nw.y;
+                    const float xn0 = x0 * nw.x, xn1 = x1 * nw.y;  // RMSNorm folded through the GEMV (see S1)
+                    const float ssw = pf_wave_sum(fmaf(x1, x1, fmaf(x0, x0, 0.f)));
+                    if (lane == 0) red[(par * 8 + wave) * PF_RED + 32] = ssw;
 #pragma unroll
                     for (int half = 0; half < 2; ++half) {
                         float a16[16];
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            a16[r] = pf_dot2(wl[9 + half * 16 + r], xn0, xn1, 0.f);
-                        }
+                        for (int r = 0; r < 16; ++r) a16[r] = pf_dot2(wl[9 + half * 16 + r], xn0, xn1, 0.f);
                         const float r16 = pf_reduce<16>(a16, lane);
-                        if ((lane & 3) == 0) red[(par * 8 + wave) * 32 + half * 16 + (lane >> 2)] = r16;
+                        if ((lane & 3) == 0) red[(par * 8 + wave) * PF_RED + half * 16 + (lane >> 2)] = r16;
                     }
                     __syncthreads();
                     if (tid < 16 * PF_REPL) {
                         const int jj = tid & 15, rr = tid >> 4;
-                        float ga = red[(par * 8) * 32 + 2 * jj], gb = red[(par * 8) * 32 + 2 * jj + 1];
+                        float ga = red[(par * 8) * PF_RED + 2 * jj], gb = red[(par * 8) * PF_RED + 2 * jj + 1], tot = red[(par * 8) * PF_RED + 32];
 #pragma unroll
-                        for (int w = 1; w < 8; ++w) { ga += red[(par * 8 + w) * 32 + 2 * jj]; gb += red[(par * 8 + w) * 32 + 2 * jj + 1]; }
+                        for (int w = 1; w < 8; ++w) {
+                            ga += red[(par * 8 + w) * PF_RED + 2 * jj]; gb += red[(par * 8 + w) * PF_RED + 2 * jj + 1];
+                            tot += red[(par * 8 + w) * PF_RED + 32];
+                        }
+                        const float dn = sqrtf(tot / 1024.f + A.eps);
+                        ga /= dn; gb /= dn;
                         pf_publish(edges, e, rr, 16 * b + jj, tag0 + e + 1, (ga / (1.f + __expf(-ga))) * gb);  // candle silu = x / (1 + exp(-x))
                     }
                     par ^= 1;
@@ -506,15 +501,15 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
                         a4[3] = fmaf(bf_lo(w.w), c0, a4[3]); a4[3] = fmaf(bf_hi(w.w), c1, a4[3]);
                     }
                     const float r4 = pf_reduce<4>(a4, lane);
-                    if ((lane & 15) == 0) red[(par * 8 + wave) * 32 + (lane >> 4)] = r4;
+                    if ((lane & 15) == 0) red[(par * 8 + wave) * PF_RED + (lane >> 4)] = r4;
                     float xres = 0.f;
                     if (tid < 4 * PF_REPL) xres = xs[4 * b + (tid & 3)];
                     __syncthreads();
                     if (tid < 4 * PF_REPL) {
                         const int r = tid & 3, rr = tid >> 2;
-                        float t = red[(par * 8) * 32 + r];
+                        float t = red[(par * 8) * PF_RED + r];
 #pragma unroll
-                        for (int w = 1; w < 8; ++w) t += red[(par * 8 + w) * 32 + r];
+                        for (int w = 1; w < 8; ++w) t += red[(par * 8 + w) * PF_RED + r];
                         pf_publish(edges, e, rr, 4 * b + r, tag0 + e + 1, xres + t);
                     }
                     par ^= 1;
@@ -524,34 +519,27 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
             // ================= head: gather x -> fast_norm -> 4 rows of fast_output -> publish 4 logits
             {
                 tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
-                const float2 nw = *reinterpret_cast<const float2*>(A.norms[2 * PF_LAYERS] + 2 * tid);
+                const float2 nw = nwr[2 * PF_LAYERS];
                 u32x4 v;
                 pf_sweep1(my_edges + (size_t)(e & 3) * PF_REPL * PF_EDGE_CAP, tid, tag0 + e + 1, v, dead, A.ctl);
                 ++e;
                 PF_TICK(13);
                 x0 = __uint_as_float(v.x); x1 = __uint_as_float(v.z);
-                float ss = fmaf(x0, x0, 0.f);
-                ss = fmaf(x1, x1, ss);
-                ss = pf_wave_sum(ss);
-                if (lane == 0) rss[par * 8 + wave] = ss;
-                __syncthreads();
-                float tot = rss[par * 8];
+                const float xn0 = x0 * nw.x, xn1 = x1 * nw.y;  // RMSNorm folded through the GEMV (see S1)
+                float a8[8];
 #pragma unroll
-                for (int w = 1; w < 8; ++w) tot += rss[par * 8 + w];
-                const float dn = sqrtf(tot / 1024.f + A.eps);
-                const float xn0 = (x0 / dn) * nw.x, xn1 = (x1 / dn) * nw.y;
-                float a4[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) a4[r] = pf_dot2(wr[PF_LAYERS * 41 + r], xn0, xn1, 0.f);
-                const float r4 = pf_reduce<4>(a4, lane);
-                if ((lane & 15) == 0) red[(par * 8 + wave) * 32 + (lane >> 4)] = r4;
+                for (int r = 0; r < 4; ++r) a8[r] = pf_dot2(wr[PF_LAYERS * 41 + r], xn0, xn1, 0.f);
+                a8[4] = fmaf(x1, x1, fmaf(x0, x0, 0.f));
+                a8[5] = 0.f; a8[6] = 0.f; a8[7] = 0.f;
+                const float r8 = pf_reduce<8>(a8, lane);
+                if ((lane & 7) == 0) red[(par * 8 + wave) * PF_RED + (lane >> 3)] = r8;
                 __syncthreads();
                 if (tid < 4 * PF_REPL) {
                     const int r = tid & 3, rr = tid >> 2;
-                    float t = red[(par * 8) * 32 + r];
+                    float t = red[(par * 8) * PF_RED + r], tot = red[(par * 8) * PF_RED + 4];
 #pragma unroll
-                    for (int w = 1; w < 8; ++w) t += red[(par * 8 + w) * 32 + r];
-                    pf_publish(edges, e, rr, 4 * b + r, tag0 + e + 1, t);
+                    for (int w = 1; w < 8; ++w) { t += red[(par * 8 + w) * PF_RED + r]; tot += red[(par * 8 + w) * PF_RED + 4]; }
+                    pf_publish(edges, e, rr, 4 * b + r, tag0 + e + 1, t / sqrtf(tot / 1024.f + A.eps));
                 }
                 par ^= 1;
                     PF_TICK(5);

@@ -71,3 +71,49 @@ def gather_results(dist, n_requests, local_results):
     for d in out:
         merged.update(d)
     return [merged[i] for i in range(n_requests)]
+
+
+def _dev(dist):
+    return "cuda" if dist.get_backend() == "nccl" else "cpu"
+
+
+def broadcast_prompts(dist, packed=None, lens=None, src=0):
+    """the packed prompt batch -- u32 [n_req, C+1, Lmax] (left-aligned rows) + lengths [n_req] -- goes from
+    `src` to every rank with two broadcasts (<= 3.5 MB for 256 x 9 x 384); every rank then serves shard_requests() of it."""
+    import numpy as np
+    if dist is None:
+        return np.ascontiguousarray(packed, np.uint32), np.asarray(lens, np.int32)
+    import torch
+    dev, me = _dev(dist), dist.get_rank()
+    shape = torch.tensor(list(packed.shape) if me == src else [0, 0, 0], dtype=torch.int64, device=dev)
+    dist.broadcast(shape, src)
+    n, c1, lmax = (int(v) for v in shape.tolist())
+    if me == src:
+        buf = torch.from_numpy(np.ascontiguousarray(packed, np.uint32).view(np.int32)).to(dev)
+        ln = torch.from_numpy(np.asarray(lens, np.int32)).to(dev)
+    else:
+        buf = torch.empty((n, c1, lmax), dtype=torch.int32, device=dev)
+        ln = torch.empty((n,), dtype=torch.int32, device=dev)
+    dist.broadcast(buf, src)
+    dist.broadcast(ln, src)
+    return buf.cpu().numpy().view(np.uint32), ln.cpu().numpy()
+
+
+def all_gather_codes(dist, codes, n_frames):
+    """end-of-run fan-in.  codes u32 [B, C, N] (this rank's requests, padded to N frames), n_frames i32 [B]
+    -> (codes_all [world, B, C, N], n_frames_all [world, B], ranks_seen) on EVERY rank: one all-gather each over RCCL (gloo in the
+    CPU tests).  ranks_seen = the communicator's world size, reported by the bench."""
+    import numpy as np
+    codes = np.ascontiguousarray(codes, np.uint32)
+    n_frames = np.ascontiguousarray(n_frames, np.int32)
+    if dist is None:
+        return codes[None], n_frames[None], 1
+    import torch
+    dev, world = _dev(dist), dist.get_world_size()
+    c = torch.from_numpy(codes.view(np.int32)).to(dev)
+    f = torch.from_numpy(n_frames).to(dev)
+    co = [torch.empty_like(c) for _ in range(world)]
+    fo = [torch.empty_like(f) for _ in range(world)]
+    dist.all_gather(co, c)
+    dist.all_gather(fo, f)
+    return torch.stack(co).cpu().numpy().view(np.uint32), torch.stack(fo).cpu().numpy(), world

@@ -133,6 +133,8 @@ int fs_lm_generate_batch(fs_lm_t* lm, const uint32_t* prompts, const int* lens, 
 typedef struct fs_gen_stats {
     double prefill_ms, decode_ms;     /* decode_ms covers frames 1..n-1 exactly like `start_decode` (:261) */
     uint64_t frames, prompt_tokens, graph_launches;
+    uint64_t kernels_per_frame;       /* kernel nodes of one decode-frame graph replay of this call: 266 on the per-node path,
+                                         123 when the fast decoder ran as one persistent launch (FS_GEN_NO_PERSIST) */
 } fs_gen_stats;
 int fs_lm_last_stats(fs_lm_t* lm, fs_gen_stats* out);
 /* the hipStream_t the handle launches on (for callers that bracket calls with their own HIP events) */

@@ -30,4 +30,19 @@ if rank == 0:
     print("FANOUT_OK", world, flush=True)
 else:
     assert allr is None
+# SURVEY.md 8e (2) + (3): prompt broadcast, per-rank shard, all-gather of the padded code arrays
+packed = (np.arange(6 * 9 * 5, dtype=np.uint32).reshape(6, 9, 5) * 7 + 3) if rank == 0 else None
+lens = np.array([5, 4, 3, 5, 2, 1], np.int32) if rank == 0 else None
+pk, ln = fanout.broadcast_prompts(dist, packed, lens)
+assert pk.shape == (6, 9, 5) and pk.dtype == np.uint32 and int(pk[5, 8, 4]) == (6 * 9 * 5 - 1) * 7 + 3 and ln.tolist() == [5, 4, 3, 5, 2, 1]
+mine = fanout.shard_requests(6, rank, world)
+codes = np.stack([np.full((8, 4), 100 * i + 1, np.uint32) for i in mine])
+nf = np.array([1 + (i % 4) for i in mine], np.int32)
+ca, fa, seen = fanout.all_gather_codes(dist, codes, nf)
+assert seen == world and ca.shape == (world, len(mine), 8, 4) and fa.shape == (world, len(mine))
+for r in range(world):
+    for k, i in enumerate(fanout.shard_requests(6, r, world)):
+        assert (ca[r, k] == 100 * i + 1).all() and fa[r, k] == 1 + (i % 4)
+if rank == 0:
+    print("FANIN_OK", world, flush=True)
 dist.destroy_process_group()

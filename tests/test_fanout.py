@@ -24,4 +24,26 @@ def test_gloo_world2_fanout():
            "--master-port", "29517", os.path.join(ROOT, "tests", "dist_worker.py"), "2"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
-    assert "FANOUT_OK 2" in p.stdout
+    assert "FANOUT_OK 2" in p.stdout and "FANIN_OK 2" in p.stdout
+
+
+def test_bench_gpus2_self_launch_dry_run():
+    """`python bench.py --gpus 2` without torchrun starts its own ranks; on a box without an MI355X the ranks run the control path
+    only (shard, prompt broadcast, code all-gather over gloo), print a JSON line flagged dry_run and exit 0."""
+    import json
+    import fishrt
+    if fishrt.lib().fs_device_count() > 0:
+        import pytest
+        pytest.skip("a GPU is visible: the real bench runs instead (covered by the driver)")
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["dry_run"] is True and j["n_gpus"] == 2 and j["collective_ranks"] == 2 and j["fan_in_ok"] and j["requests_per_rank"] == [128, 128]
+    # a mismatching launcher environment is a usage error, not an assert
+    env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    p2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env2)
+    assert p2.returncode == 2 and "WORLD_SIZE=1" in p2.stderr

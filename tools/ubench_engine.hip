@@ -39,7 +39,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // NL = 16-B sweep loads per thread (N_in = NT * 2 * NL granules); ROWS = output rows per workgroup; WL = 16-B weight loads per thread
 // per stage (W = NT * 16 * WL bytes per CU); R = replicas; LOCAL = no cross-CU dependency
-template <int NL, int ROWS, int WL, int R, bool LOCAL>
+template <int NL, int ROWS, int WL, int R, bool LOCAL, int PM = 0, int KP = 4, int DS = 5>
 __global__ __launch_bounds__(NT) void k_engine(gu64* gran, int stages, const u32x4* __restrict__ wbuf, size_t w_n16, float* out, unsigned* tmo, unsigned long long* prof, int NB) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* xs = reinterpret_cast<float*>(smem);              // [N_in]
@@ -67,6 +67,7 @@ __global__ __launch_bounds__(NT) void k_engine(gu64* gran, int stages, const u32
         gu64* g = LOCAL ? gran + (size_t)(4 * R + b) * NMAX : edge(s, rep);
         u32x4 v[NL];
         unsigned spins = 0;
+        if (PM == 0) {
         for (;;) {
             bool ok = true;
 #pragma unroll
@@ -81,6 +82,31 @@ __global__ __launch_bounds__(NT) void k_engine(gu64* gran, int stages, const u32
             ++npoll;
             if (ok) break;
             if (++spins > SPIN_MAX) { fail = true; break; }
+        }
+        } else {
+            // staggered polls landing in LDS (LDS-DMA, sc1): KP sweeps in flight DS x 64 clocks apart; a sweep that comes back too early
+            // costs one stagger period instead of a full round trip, and sweeps still in flight after the hit land in slots nobody reads
+            u32x4* land = reinterpret_cast<u32x4*>(smem + 32 * 1024) + (size_t)wave * KP * NL * 64;
+            auto issue = [&](int i) {
+#pragma unroll
+                for (int j = 0; j < NL; ++j)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + (size_t)(j * NT + tid) * 2),
+                                                     (__attribute__((address_space(3))) void*)(land + ((i % KP) * NL + j) * 64), 16, 0, 16);
+            };
+#pragma unroll
+            for (int i = 0; i < KP; ++i) { issue(i); if (i + 1 < KP) __builtin_amdgcn_s_sleep(DS); }
+            for (int c = 0;; ++c) {
+                if (KP == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(1 * NL) : "memory");
+                else if (KP == 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NL) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * NL) : "memory");
+                bool ok = true;
+#pragma unroll
+                for (int j = 0; j < NL; ++j) { v[j] = land[((c % KP) * NL + j) * 64 + lane]; ok &= LOCAL || (v[j].y == tag && v[j].w == tag); }
+                ++npoll;
+                if (ok) break;
+                if (++spins > SPIN_MAX) { fail = true; break; }
+                issue(c + KP);
+            }
         }
         const unsigned long long c1 = clock64();
 #pragma unroll
@@ -134,10 +160,11 @@ __global__ __launch_bounds__(NT) void k_engine(gu64* gran, int stages, const u32
         for (int j = 0; j < WL; ++j) wcur[j] = wnext[j];
     }
     if (tid == 0) { out[b] = last; if (fail) atomicAdd(tmo, 1u); }
-    if (tid == 0 && (b == 0 || b == 77)) { unsigned long long* pr = prof + (b ? 8 : 0); for (int i = 0; i < 5; ++i) pr[i] = tp[i]; pr[5] = npoll; }
+    if (tid == 511 && b == 0) { unsigned long long* pr = prof + 8; for (int i = 0; i < 5; ++i) pr[i] = tp[i]; pr[5] = npoll; }
+    if (tid == 0 && (b == 0)) { unsigned long long* pr = prof + (b ? 8 : 0); for (int i = 0; i < 5; ++i) pr[i] = tp[i]; pr[5] = npoll; }
 }
 
-template <int NL, int ROWS, int WL, int R, bool LOCAL>
+template <int NL, int ROWS, int WL, int R, bool LOCAL, int PM = 0, int KP = 4, int DS = 5>
 static float run(int stages, const u32x4* wbuf, size_t w_n16, bool* ok, bool show = false) {
     unsigned long long* prof; CK(hipMalloc(&prof, 16 * 8)); CK(hipMemset(prof, 0, 128));
     const int NB = g_nb;
@@ -155,7 +182,8 @@ static float run(int stages, const u32x4* wbuf, size_t w_n16, bool* ok, bool sho
         CK(hipMemcpy((void*)gran, h.data(), gb, hipMemcpyHostToDevice)); CK(hipMemset(tmo, 0, 4));
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0, st));
-        hipLaunchKernelGGL((k_engine<NL, ROWS, WL, R, LOCAL>), dim3(NB), dim3(NT), 100 * 1024, st, gran, stages, wbuf, w_n16, out, tmo, prof, NB);
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_engine<NL, ROWS, WL, R, LOCAL, PM, KP, DS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        hipLaunchKernelGGL((k_engine<NL, ROWS, WL, R, LOCAL, PM, KP, DS>), dim3(NB), dim3(NT), 160 * 1024, st, gran, stages, wbuf, w_n16, out, tmo, prof, NB);
         CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         best = ms < best ? ms : best;
@@ -163,7 +191,7 @@ static float run(int stages, const u32x4* wbuf, size_t w_n16, bool* ok, bool sho
         if (f) *ok = false;
     }
     if (show) { unsigned long long hp[16]; CK(hipMemcpy(hp, prof, 128, hipMemcpyDeviceToHost));
-        for (int k = 0; k < 2; ++k) printf("      [blk %d] cycles/stage: poll %.0f  bar1 %.0f  gemv %.0f  bar2 %.0f  publish %.0f ; polls/stage %.2f\n", k ? 77 : 0, hp[8*k+0] / (double)stages, hp[8*k+1] / (double)stages, hp[8*k+2] / (double)stages, hp[8*k+3] / (double)stages, hp[8*k+4] / (double)stages, hp[8*k+5] / (double)stages); }
+        for (int k = 0; k < 2; ++k) printf("      [blk 0 tid %d] cycles/stage: poll %.0f  bar1 %.0f  gemv %.0f  bar2 %.0f  publish %.0f ; polls/stage %.2f\n", k ? 511 : 0, hp[8*k+0] / (double)stages, hp[8*k+1] / (double)stages, hp[8*k+2] / (double)stages, hp[8*k+3] / (double)stages, hp[8*k+4] / (double)stages, hp[8*k+5] / (double)stages); }
     CK(hipFree(prof));
     CK(hipFree((void*)gran)); CK(hipFree(out)); CK(hipFree(tmo)); CK(hipStreamDestroy(st));
     return best * 1e3f / stages;
@@ -193,6 +221,19 @@ int main(int argc, char** argv) {
         printf("  %3d workgroups, N_in 1024, resident weights: R=1 %6.3f  R=8 %6.3f us/stage %s\n", nb, a, b8, (o1 && o2) ? "" : "TIMEOUT");
     }
     g_nb = 256;
+    {
+        bool o;
+        printf("  staggered LDS-DMA polls, N_in 1024, resident, R=8, 256 workgroups:\n");
+        printf("    single poll (baseline)      %6.3f\n", run<1, 4, 0, 8, false, 0>(stages, wbuf, n16, &o));
+        printf("    KP=2 DS=8  (0.22 us apart)  %6.3f %s\n", run<1, 4, 0, 8, false, 1, 2, 8>(stages, wbuf, n16, &o, true), o ? "" : "TIMEOUT");
+        printf("    KP=3 DS=5  (0.14 us apart)  %6.3f %s\n", run<1, 4, 0, 8, false, 1, 3, 5>(stages, wbuf, n16, &o, true), o ? "" : "TIMEOUT");
+        printf("    KP=4 DS=5                   %6.3f %s\n", run<1, 4, 0, 8, false, 1, 4, 5>(stages, wbuf, n16, &o, true), o ? "" : "TIMEOUT");
+        printf("    KP=4 DS=3  (0.08 us apart)  %6.3f %s\n", run<1, 4, 0, 8, false, 1, 4, 3>(stages, wbuf, n16, &o, true), o ? "" : "TIMEOUT");
+        printf("    KP=4 DS=8                   %6.3f %s\n", run<1, 4, 0, 8, false, 1, 4, 8>(stages, wbuf, n16, &o, true), o ? "" : "TIMEOUT");
+        printf("    N_in 4096: single %6.3f", run<4, 4, 0, 8, false, 0>(stages, wbuf, n16, &o));
+        printf("  KP=3 DS=5 %6.3f", run<4, 4, 0, 8, false, 1, 3, 5>(stages, wbuf, n16, &o));
+        printf("  KP=2 DS=8 %6.3f\n", run<4, 4, 0, 8, false, 1, 2, 8>(stages, wbuf, n16, &o));
+    }
     ROW(1, 4, 0, "N_in 1024,  4 rows/CU, resident weights");
     ROW(1, 4, 1, "N_in 1024,  4 rows/CU,  8 KB/CU/stage ( 2 MB: wo)");
     ROW(1, 32, 0, "N_in 1024, 32 rows/CU, resident weights");

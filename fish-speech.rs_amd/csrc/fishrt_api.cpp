@@ -7,6 +7,11 @@
 #include "codec_engine.h"
 #include "fs_common.h"
 #include "lm_engine.h"
+#include "lm_persist.h"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
 
 static thread_local std::string g_err;
 
@@ -34,6 +39,35 @@ int fs_fp8_quantize_rows(int device_id, const float* w, int64_t rows, int64_t co
     FS_TRY(fs::fp8_quantize_rows(device_id, w, rows, cols, q_out, scales_out))
 }
 int fs_fp8_decode_table(int device_id, float* out) { FS_ARG(out, "null argument"); FS_TRY(fs::fp8_decode_table(device_id, out)) }
+
+static void selftest_pf_reduce(int device) {
+    FS_HIP(hipSetDevice(device));
+    std::vector<float> in(64 * 32), out(96, 0.f);
+    uint32_t st = 12345u;
+    for (auto& v : in) { st = st * 1664525u + 1013904223u; v = (float)((st >> 8) & 0xFFFF) / 65536.f - 0.5f; }
+    float *din = nullptr, *dout = nullptr;
+    FS_HIP(hipMalloc(&din, in.size() * 4));
+    FS_HIP(hipMalloc(&dout, out.size() * 4));
+    FS_HIP(hipMemcpy(din, in.data(), in.size() * 4, hipMemcpyHostToDevice));
+    FS_HIP(hipMemset(dout, 0, out.size() * 4));
+    fs::launch_pf_reduce_selftest(din, dout, nullptr);
+    FS_HIP(hipDeviceSynchronize());
+    FS_HIP(hipMemcpy(out.data(), dout, out.size() * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(din); (void)hipFree(dout);
+    auto host = [&](int i) { double s = 0; for (int l = 0; l < 64; ++l) s += in[l * 32 + i]; return (float)s; };
+    for (int i = 0; i < 32; ++i) if (std::fabs(out[i] - host(i)) > 1e-4f) throw fs::Error("pf_reduce<32> value " + std::to_string(i) + " wrong");
+    for (int i = 0; i < 16; ++i) if (std::fabs(out[32 + i] - host(i)) > 1e-4f) throw fs::Error("pf_reduce<16> value " + std::to_string(i) + " wrong");
+    for (int i = 0; i < 8; ++i) if (std::fabs(out[48 + i] - host(i)) > 1e-4f) throw fs::Error("pf_reduce<8> value " + std::to_string(i) + " wrong");
+    for (int i = 0; i < 4; ++i) if (std::fabs(out[64 + i] - host(i)) > 1e-4f) throw fs::Error("pf_reduce<4> value " + std::to_string(i) + " wrong");
+    if (std::fabs(out[68] - host(0)) > 1e-4f) throw fs::Error("pf_wave_sum wrong");
+}
+int fs_selftest(int device_id, const char* what) {
+    FS_ARG(what, "null argument");
+    FS_TRY({
+        if (std::strcmp(what, "pf_reduce") == 0) selftest_pf_reduce(device_id);
+        else throw fs::Error(std::string("unknown self-test: ") + what);
+    })
+}
 
 int fs_lm_create(const fs_model_args* args, const fs_token_cfg* tok, int device_id, fs_dtype dtype, int max_batch, fs_lm_t** out) {
     FS_ARG(args && tok && out, "null argument");

@@ -664,19 +664,24 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
 // ------------------------------------------------------------------------------------------------ reduction self-test
 __global__ __launch_bounds__(64) void k_pf_reduce_selftest(const float* __restrict__ in, float* __restrict__ out) {
     const int lane = threadIdx.x;
-    float v32[32], v16[16], v4[4];
+    float v32[32], v16[16], v8[8], v4[4];
 #pragma unroll
     for (int i = 0; i < 32; ++i) v32[i] = in[lane * 32 + i];
 #pragma unroll
     for (int i = 0; i < 16; ++i) v16[i] = in[lane * 32 + i];
 #pragma unroll
+    for (int i = 0; i < 8; ++i) v8[i] = in[lane * 32 + i];
+#pragma unroll
     for (int i = 0; i < 4; ++i) v4[i] = in[lane * 32 + i];
-    const float r32 = pf_reduce<32>(v32, lane), r16 = pf_reduce<16>(v16, lane), r4 = pf_reduce<4>(v4, lane);
-    if ((lane & 1) == 0) out[lane >> 1] = r32;
-    if ((lane & 3) == 0) out[32 + (lane >> 2)] = r16;
-    if ((lane & 15) == 0) out[64 + (lane >> 4)] = r4;
+    const float r32 = pf_reduce<32>(v32, lane), r16 = pf_reduce<16>(v16, lane), r8 = pf_reduce<8>(v8, lane), r4 = pf_reduce<4>(v4, lane);
+    // out: [0, 32) N = 32; [32, 48) N = 16; [48, 56) N = 8; [64, 68) N = 4; [68] wave sum.  The LAST lane of every group writes, so a
+    // result that is wrong in part of the group is seen
+    if ((lane & 1) == 1) out[lane >> 1] = r32;
+    if ((lane & 3) == 3) out[32 + (lane >> 2)] = r16;
+    if ((lane & 7) == 7) out[48 + (lane >> 3)] = r8;
+    if ((lane & 15) == 15) out[64 + (lane >> 4)] = r4;
     const float ws = pf_wave_sum(in[lane * 32]);
-    if (lane == 63) out[64 + 4] = ws;
+    if (lane == 37) out[68] = ws;
 }
 
 // ------------------------------------------------------------------------------------------------ host side

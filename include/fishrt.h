@@ -78,6 +78,10 @@ int fs_device_count(void);
 int fs_fp8_quantize_rows(int device_id, const float* w, int64_t rows, int64_t cols, uint8_t* q_out, float* scales_out);
 int fs_fp8_decode_table(int device_id, float* out);
 
+/* Device self-test of an internal building block, by name (diagnostics; used by the parity tests): "pf_reduce" = the multi-value
+ * wave reductions of the persistent fast-decoder kernel (csrc/lm_persist.hip) against host sums.  0 = passed. */
+int fs_selftest(int device_id, const char* what);
+
 /* DualARTransformer::load (dual_ar.rs:460-529) is split in create + one of the load calls.
  * max_batch: number of independent sequences (KV caches) the handle can hold (1 for the single-batch generator). */
 int fs_lm_create(const fs_model_args* args, const fs_token_cfg* tok, int device_id, fs_dtype dtype, int max_batch,

@@ -7,6 +7,7 @@
 #include "codec_engine.h"
 #include "fs_common.h"
 #include "lm_engine.h"
+#include "lm_kernels.h"
 #include "lm_persist.h"
 
 #include <cmath>
@@ -67,6 +68,11 @@ int fs_selftest(int device_id, const char* what) {
         if (std::strcmp(what, "pf_reduce") == 0) selftest_pf_reduce(device_id);
         else throw fs::Error(std::string("unknown self-test: ") + what);
     })
+}
+
+int fs_selftest_sample_rows(int device_id, const float* logits, int B, int n, const fs_sampling* s, uint64_t seed, int call_index, uint32_t* out) {
+    FS_ARG(logits && s && out, "null argument");
+    FS_TRY(fs::debug_sample_rows(device_id, logits, B, n, s->temp, s->top_p, s->top_k, seed, call_index, out))
 }
 
 int fs_lm_create(const fs_model_args* args, const fs_token_cfg* tok, int device_id, fs_dtype dtype, int max_batch, fs_lm_t** out) {

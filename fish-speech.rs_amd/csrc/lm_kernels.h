@@ -211,4 +211,8 @@ void launch_quant_rows_fp8(uint8_t* dst, float* scales, const float* src, int64_
 // out[slot * 256 + b] = f32 value the fp8 GEMV unpack path gives byte b at lane-slot `slot` (16 x 256 floats)
 void launch_fp8_decode_table(float* out, hipStream_t st);
 
+// test hook behind fs_selftest_sample_rows (include/fishrt.h)
+void debug_sample_rows(int device, const float* logits, int B, int n, double temp, double top_p, uint64_t top_k, uint64_t seed,
+                       int call_index, uint32_t* out);
+
 }  // namespace fs

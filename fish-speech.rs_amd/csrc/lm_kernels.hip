@@ -15,6 +15,8 @@
 // :252-279 (SDPA), :281-384 (Attention::forward), :429-440 (block), :532-567 (embed), :629-631 (head).
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <algorithm>
+#include <vector>
 
 #include "fs_common.h"
 #include "fs_synth.h"
@@ -3043,6 +3045,40 @@ void LmKernels<WT>::rows_head(const ModelDims& d, int M, const RowsCtx& c, const
 void launch_advance_n(SeqState* state, int n, hipStream_t st) {
     hipLaunchKernelGGL(k_advance_n, dim3(1), dim3(1), 0, st, state, n);
     FS_LAUNCH_CHECK();
+}
+
+// ---- sampler test hook (fs_selftest_sample_rows): the static-batch slow sampler on caller-provided logits, B rows of n candidates,
+// as sample() call number `call_index` of a request (child StdRng of row b = master u64 number call_index * B + b)
+void debug_sample_rows(int device, const float* logits, int B, int n, double temp, double top_p, uint64_t top_k, uint64_t seed,
+                       int call_index, uint32_t* out) {
+    FS_REQUIRE(B >= 1 && n >= 1 && n <= SAMPLE_MAXN, "bad sampler test shape");
+    FS_HIP(hipSetDevice(device));
+    float* d_logits = nullptr; SampleCfg* d_cfg = nullptr; RngState* d_rng = nullptr; SeqState* d_st = nullptr;
+    FS_HIP(hipMalloc(&d_logits, sizeof(float) * (size_t)B * n));
+    FS_HIP(hipMalloc(&d_cfg, sizeof(SampleCfg))); FS_HIP(hipMalloc(&d_rng, sizeof(RngState))); FS_HIP(hipMalloc(&d_st, sizeof(SeqState) * B));
+    FS_HIP(hipMemcpy(d_logits, logits, sizeof(float) * (size_t)B * n, hipMemcpyHostToDevice));
+    SampleCfg c = {};
+    c.temp = (float)temp; c.top_p = (float)top_p; c.top_k = (int)std::min<uint64_t>(top_k, 1u << 30); c.rep_pen = 1.f;
+    FS_HIP(hipMemcpy(d_cfg, &c, sizeof(c), hipMemcpyHostToDevice));
+    RngState r = {};
+    unsigned long long state = seed;
+    for (int i = 0; i < 8; ++i) {  // rand_core seed_from_u64 (PCG32 expansion)
+        state = state * 6364136223846793005ull + 11634580027462260723ull;
+        const uint32_t xorshifted = (uint32_t)(((state >> 18) ^ state) >> 27);
+        const uint32_t rot = (uint32_t)(state >> 59);
+        r.key[i] = (xorshifted >> rot) | (xorshifted << ((32 - rot) & 31));
+    }
+    FS_HIP(hipMemcpy(d_rng, &r, sizeof(r), hipMemcpyHostToDevice));
+    std::vector<SeqState> hs(B);
+    for (auto& s : hs) { s = SeqState{}; s.frame = call_index; }
+    FS_HIP(hipMemcpy(d_st, hs.data(), sizeof(SeqState) * B, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL((k_sample_slow_rows<bf16_t>), dim3(B), dim3(SAMPLE_THREADS), 0, nullptr, d_logits, n, n, d_cfg, d_rng, B, 1, d_st,
+                       (const float*)nullptr, (float*)nullptr, 0);
+    FS_LAUNCH_CHECK();
+    FS_HIP(hipDeviceSynchronize());
+    FS_HIP(hipMemcpy(hs.data(), d_st, sizeof(SeqState) * B, hipMemcpyDeviceToHost));
+    for (int b = 0; b < B; ++b) out[b] = hs[b].cur[0];
+    (void)hipFree(d_logits); (void)hipFree(d_cfg); (void)hipFree(d_rng); (void)hipFree(d_st);
 }
 
 template struct LmKernels<bf16_t>;

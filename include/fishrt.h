@@ -81,6 +81,11 @@ int fs_fp8_decode_table(int device_id, float* out);
 /* Device self-test of an internal building block, by name (diagnostics; used by the parity tests): "pf_reduce" = the multi-value
  * wave reductions of the persistent fast-decoder kernel (csrc/lm_persist.hip) against host sums.  0 = passed. */
 int fs_selftest(int device_id, const char* what);
+/* The static-batch sampler (BatchedLogitsProcessor::sample, sampling/mod.rs:77-109) on caller-provided logits f32 [B, n]
+ * (n <= 4096): out[b] = token of row b for sample() call number `call_index` of a request seeded with `seed` (row b draws from
+ * the child StdRng seeded with master u64 number call_index * B + b; temp <= 1e-7 -> first-max argmax).  Diagnostics / parity tests. */
+int fs_selftest_sample_rows(int device_id, const float* logits, int B, int n, const fs_sampling* s, uint64_t seed, int call_index,
+                            uint32_t* out);
 
 /* DualARTransformer::load (dual_ar.rs:460-529) is split in create + one of the load calls.
  * max_batch: number of independent sequences (KV caches) the handle can hold (1 for the single-batch generator). */

@@ -157,6 +157,14 @@ void orc_reppen_mask(void* r, float* mask_out) {
     RepPen* rp = (RepPen*)r;
     std::memcpy(mask_out, rp->mask.data(), sizeof(float) * rp->mask.size());
 }
+void orc_rng_chacha12_block(const uint32_t* key8, uint64_t counter, uint32_t* out16) { rng_chacha12_block(key8, counter, out16); }
+void orc_rng_seed_key(uint64_t seed, uint32_t* key8) { rng_seed_key(seed, key8); }
+void orc_rng_stream(uint64_t seed, int n32, uint32_t* out32, int n64, uint64_t* out64) { rng_stream(seed, n32, out32, n64, out64); }
+void orc_rng_weighted_index(uint64_t seed, const float* w, int n, int draws, uint32_t* out) { rng_weighted_index(seed, w, n, draws, out); }
+void orc_batched_sample(uint64_t seed, double temp, double top_p, uint64_t top_k, const float* logits, int B, int n, int call_index, uint32_t* out) {
+    Sampling s; s.temp = temp; s.top_p = top_p; s.top_k = top_k; s.repetition_penalty = 1.f;
+    rng_batched_sample(seed, s, logits, B, n, call_index, out);
+}
 void* orc_sampler_create(uint64_t seed, double temp, double top_p, uint64_t top_k) {
     Sampling s; s.temp = temp; s.top_p = top_p; s.top_k = top_k;
     return new LogitsProcessor(seed, s);

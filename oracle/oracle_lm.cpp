@@ -330,6 +330,7 @@ struct ChaCha12Rng {
     uint32_t buf[64];
     int idx = 64;
     static inline uint32_t rotl(uint32_t v, int c) { return (v << c) | (v >> (32 - c)); }
+    ChaCha12Rng(const uint32_t* k, int) { std::memcpy(key, k, sizeof(key)); }  // from_seed: key words as given (known-answer tests)
     explicit ChaCha12Rng(uint64_t state) {  // rand_core SeedableRng::seed_from_u64 (PCG32 expansion)
         for (int i = 0; i < 8; ++i) {
             state = state * 6364136223846793005ull + 11634580027462260723ull;
@@ -412,6 +413,27 @@ static uint32_t weighted_index_sample(ChaCha12Rng& rng, const std::vector<float>
     return (uint32_t)lo;
 }
 
+// ---- test hooks: the RNG chain piece by piece (pinned in tests/test_oracle_known_answers.py against published vectors and an
+// independent pure-Python restatement)
+void rng_chacha12_block(const uint32_t* key8, uint64_t counter, uint32_t* out16) {
+    ChaCha12Rng r(key8, 0);
+    r.block(counter, out16);
+}
+void rng_seed_key(uint64_t seed, uint32_t* key8) {
+    ChaCha12Rng r(seed);
+    std::memcpy(key8, r.key, sizeof(r.key));
+}
+void rng_stream(uint64_t seed, int n_u32_first, uint32_t* out32, int n_u64, uint64_t* out64) {
+    ChaCha12Rng r(seed);
+    for (int i = 0; i < n_u32_first; ++i) out32[i] = r.next_u32();
+    for (int i = 0; i < n_u64; ++i) out64[i] = r.next_u64();
+}
+void rng_weighted_index(uint64_t seed, const float* w, int n, int draws, uint32_t* out) {
+    ChaCha12Rng r(seed);
+    std::vector<float> wv(w, w + n);
+    for (int i = 0; i < draws; ++i) out[i] = weighted_index_sample(r, wv);
+}
+
 LogitsProcessor::LogitsProcessor(uint64_t seed, const Sampling& sa) : s(sa), rng(new ChaCha12Rng(seed)) {}
 LogitsProcessor::~LogitsProcessor() { delete rng; }
 
@@ -481,6 +503,13 @@ std::vector<uint32_t> batched_sample(ChaCha12Rng& master, const Sampling& s, con
         out[b] = sample_probs(child, p, (size_t)s.top_k, (float)s.top_p);
     }
     return out;
+}
+
+void rng_batched_sample(uint64_t seed, const Sampling& s, const float* logits, int B, int n, int call_index, uint32_t* out) {
+    ChaCha12Rng master(seed);
+    for (long long i = 0; i < (long long)call_index * B; ++i) (void)master.next_u64();  // the earlier sample() calls of the request
+    const std::vector<uint32_t> r = batched_sample(master, s, logits, (size_t)B, (size_t)n, (size_t)n);
+    std::memcpy(out, r.data(), sizeof(uint32_t) * B);
 }
 
 uint32_t LogitsProcessor::sample(const float* logits, size_t n) {

@@ -108,4 +108,11 @@ struct LogitsProcessor {
     uint32_t sample(const float* logits, size_t n);
 };
 
+// test hooks into the sampler's RNG chain (rand 0.8.5 StdRng = ChaCha12, seed_from_u64, BlockRng::next_u64, WeightedIndex<f32>)
+void rng_chacha12_block(const uint32_t* key8, uint64_t counter, uint32_t* out16);
+void rng_seed_key(uint64_t seed, uint32_t* key8);
+void rng_stream(uint64_t seed, int n_u32_first, uint32_t* out32, int n_u64, uint64_t* out64);
+void rng_weighted_index(uint64_t seed, const float* w, int n, int draws, uint32_t* out);
+void rng_batched_sample(uint64_t seed, const Sampling& s, const float* logits, int B, int n, int call_index, uint32_t* out);
+
 }  // namespace oracle

@@ -217,8 +217,55 @@ def argmax_last(v):  # host ArgMax: iter().enumerate().max_by(total_cmp) -> last
     return int(np.nonzero(v == m)[0][-1])
 
 
-def generate(lm, prompt, max_new_tokens, rep_pen, ignore_eos=False):
-    """single_batch.rs:31-214 + 217-306, greedy (temp == 0)."""
+class PySampler:
+    """candle_transformers LogitsProcessor with Sampling::TopKThenTopP (call sites single_batch.rs:38-46,133,169; vendored twin
+    sampling/mod.rs:51-132) on top of tests/golden/rng_ref.py (StdRng, WeightedIndex).  Conventions shared with oracle/ and the HIP
+    sampler, both documented there: the top-k set is kept in ascending token order (`select_nth_unstable_by` leaves it unspecified)
+    and the softmax denominator is accumulated in f64."""
+
+    def __init__(self, seed, temp, top_p, top_k):
+        import rng_ref
+        self.R = rng_ref
+        self.rng = rng_ref.StdRng(seed)
+        self.temp, self.top_p, self.top_k = temp, np.float32(top_p), top_k
+
+    def _multinomial(self, probs):
+        return self.R.weighted_index_sample(self.rng, [float(v) for v in probs])
+
+    def _topp(self, probs):
+        order = sorted(range(len(probs)), key=lambda i: -float(probs[i]))  # stable: ties stay in index order (slice::sort_by)
+        cumsum = np.float32(0.0)
+        for i in order:
+            if cumsum >= self.top_p:
+                probs[i] = np.float32(0.0)
+            cumsum = np.float32(cumsum + probs[i])
+        return self._multinomial(probs)
+
+    def sample(self, logits):
+        import math
+        lg = np.asarray(logits, np.float32)
+        if self.temp == 0.0:
+            return int(np.nonzero(lg == lg.max())[0][-1])
+        z = lg * np.float32(1.0 / self.temp)
+        mx = z.max()
+        e = np.array([np.float32(math.exp(float(np.float32(v - mx)))) for v in z], np.float32)
+        p = e / np.float32(e.astype(np.float64).sum())
+        n = len(p)
+        if self.top_k == 0 or self.top_k >= n:
+            return self._topp(p.copy())
+        order = sorted(range(n), key=lambda i: -float(p[i]))
+        keep = sorted(order[: self.top_k])
+        tk = np.array([p[i] for i in keep], np.float32)
+        sum_p = np.float32(0.0)
+        for v in tk:
+            sum_p = np.float32(sum_p + v)
+        j = self._multinomial(tk) if (self.top_p <= 0 or self.top_p >= sum_p) else self._topp(tk)
+        return keep[j]
+
+
+def generate(lm, prompt, max_new_tokens, rep_pen, ignore_eos=False, sampler=None):
+    """single_batch.rs:31-214 + 217-306; greedy (temp == 0) unless a PySampler is given."""
+    pick = (lambda v: sampler.sample(v.numpy())) if sampler is not None else argmax_last
     cfg = lm.cfg
     C = cfg["num_codebooks"]
     im_end = cfg["im_end_id"]
@@ -236,7 +283,7 @@ def generate(lm, prompt, max_new_tokens, rep_pen, ignore_eos=False):
             sl[0] = float("-inf")
         top2 = torch.topk(sl, 2).values
         margins.append(float(top2[0] - top2[1]))
-        sem = argmax_last(sl) + im_end
+        sem = pick(sl) + im_end
         cb = [sem]
         lm.clear_fast()
         x = hidden
@@ -249,7 +296,7 @@ def generate(lm, prompt, max_new_tokens, rep_pen, ignore_eos=False):
                 fl = rps[ci].apply(fl, prev[ci + 1])
             top2 = torch.topk(fl, 2).values
             margins.append(float(top2[0] - top2[1]))
-            a = argmax_last(fl)
+            a = pick(fl)
             if ci != C - 1:
                 x = lm.fast_embeddings[a].view(1, -1)
             cb.append(a)
@@ -307,6 +354,17 @@ def make_lm_golden():
             out[f"{tag}_rollout_rp{int(rp * 10)}_frames"] = frames
             out[f"{tag}_rollout_rp{int(rp * 10)}_min_margin"] = np.float32(margin)
             print(f"  LM {tag} rp={rp}: 24 frames, min top-2 margin {margin:.3e}")
+        if not bf16:
+            # sampled rollouts (temp / top-k / top-p / WeightedIndex / StdRng): the independent pure-Python RNG + sampler
+            for name, kw in (("s1", dict(seed=42, temp=0.7, top_p=0.8, top_k=20)), ("s2", dict(seed=7, temp=1.0, top_p=0.95, top_k=50)),
+                             ("s3", dict(seed=123456789, temp=0.7, top_p=1.0, top_k=16))):
+                lm.clear_slow()
+                codes_out, frames, _ = generate(lm, torch.from_numpy(prompt), 24 + L - 2, 1.2, ignore_eos=True, sampler=PySampler(**kw))
+                assert codes_out.shape == (8, 24), codes_out.shape
+                out[f"sampled_{name}_cfg"] = np.array([kw["seed"], kw["temp"], kw["top_p"], kw["top_k"]], np.float64)
+                out[f"sampled_{name}_rollout"] = codes_out
+                out[f"sampled_{name}_frames"] = frames
+                print(f"  LM sampled rollout {name} {kw}: 24 frames")
         # batched prefill B=2 with left padding (static_batch.rs:68-111): pad mask is NOT applied (dual_ar.rs:589-615)
         lm.clear_slow()
         p2 = np.zeros((2, 9, L), np.int64)

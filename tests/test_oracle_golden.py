@@ -69,6 +69,19 @@ def test_greedy_rollout_token_exact(lm_tag, rp):
     assert np.array_equal(out, LMG[f"{tag}_rollout_rp{int(rp * 10)}"])
 
 
+@pytest.mark.parametrize("name", ["s1", "s2", "s3"])
+def test_sampled_rollout_token_exact(name):
+    """temp / top-k / top-p / WeightedIndex / StdRng: the oracle's sampled token stream against the fixture produced by the independent
+    PyTorch model + pure-Python sampler and RNG (make_golden.py PySampler, rng_ref.py; the RNG itself is pinned to public vectors in
+    test_oracle_known_answers.py).  f32 weights; 24 frames x 9 draws."""
+    seed, temp, top_p, top_k = LMG[f"sampled_{name}_cfg"]
+    lm = orc.OracleLM(orc.TINY).load_synthetic(int(LMG["seed"]), bf16=False)
+    p = LMG["prompt"]
+    out = lm.generate(p, 24 + p.shape[1] - 2, temp=float(temp), top_p=float(top_p), top_k=int(top_k), repetition_penalty=1.2,
+                      seed=int(seed), ignore_eos=True)
+    assert np.array_equal(out, LMG[f"sampled_{name}_rollout"])
+
+
 def test_partial_head_equals_full_head(lm_tag):
     lm, _ = lm_tag
     lm.clear_slow()

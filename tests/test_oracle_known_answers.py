@@ -136,3 +136,68 @@ def test_default_voice_fixture_properties():  # voices-template/default.npy (SUR
     v = np.load(os.path.join(os.path.dirname(__file__), "golden", "default_voice_codes.npy"))
     assert v.shape == (8, 274) and v.dtype == np.int64
     assert v.min() >= 3 and v.max() <= 999  # FSQ indices of the (8, 5, 5, 5) levels: < 1000
+
+
+# ---- the sampler's RNG chain (rand 0.8.5 StdRng = ChaCha12 behind BlockRng; rand_core seed_from_u64; WeightedIndex<f32>):
+# public vectors -> independent pure-Python restatement (tests/golden/rng_ref.py) -> oracle/'s C++ (which the HIP sampler is tested against)
+import ctypes as _C
+import sys as _sys
+
+_sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import rng_ref  # noqa: E402
+
+TC1 = {  # "Test Vectors for the Stream Cipher ChaCha" (Strombergson draft), TC1: all-zero 256-bit key and IV, keystream block 0
+    8: "3e00ef2f895f40d67f5bb8e81f09a5a12c840ec3ce9a7f3b181be188ef711a1e984ce172b9216f419f445367456d5619314a42a3da86b001387bfdb80e0cfe42",
+    12: "9bf49a6a0755f953811fce125f2683d50429c3bb49e074147e0089a52eae155f0564f879d27ae3c02ce82834acfa8c793a629f2ca0de6919610be82f411326be",
+    20: "76b8e0ada0f13d90405d6ae55386bd28bdd219b8a08ded1aa836efcc8b770dc7da41597c5157488d7724e03fb8d84a376a43b8f41518a11cc387b669b2ee6586",
+}
+
+
+def test_python_rng_reference_matches_public_vectors():
+    for rounds, hexs in TC1.items():
+        assert rng_ref.keystream_hex([0] * 8, rounds) == hexs
+    # pcg32 demo (pcg-random.org, pcg32_srandom_r(42, 54)): pins the LCG multiplier and the XSH-RR output permutation
+    assert rng_ref.pcg32_demo(42, 54, 6) == [0xA15C02B7, 0x7B47F409, 0xBA1D3330, 0x83D2F293, 0xBFA4784B, 0xCBED606E]
+
+
+def _orc_block(key, counter):
+    out = (_C.c_uint32 * 16)()
+    orc.lib().orc_rng_chacha12_block((_C.c_uint32 * 8)(*key), _C.c_uint64(counter), out)
+    return list(out)
+
+
+def test_oracle_chacha12_block_known_answer():
+    import struct
+    assert struct.pack("<16I", *_orc_block([0] * 8, 0)).hex() == TC1[12]
+    # 64-bit block counter in words 12-13 (rand_chacha), arbitrary keys: against the Python reference
+    rs = np.random.RandomState(5)
+    for ctr in (1, 2, 0xFFFFFFFF, 0x100000000, 0x123456789ABC):
+        key = [int(v) for v in rs.randint(0, 2 ** 32, 8, dtype=np.uint64)]
+        assert _orc_block(key, ctr) == rng_ref.chacha_block(key, ctr, 12)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 42, 0xF15E5EED, 2 ** 63 + 12345, 2 ** 64 - 1])
+def test_oracle_seed_from_u64_and_stream(seed):
+    key = (_C.c_uint32 * 8)()
+    orc.lib().orc_rng_seed_key(_C.c_uint64(seed), key)
+    assert list(key) == rng_ref.seed_from_u64(seed)
+    # next_u32 x 61, then next_u64 across the 64-word buffer boundary (index 61, 63 -> straddles two buffers), then more
+    n32, n64 = 61, 70
+    o32, o64 = (_C.c_uint32 * n32)(), (_C.c_uint64 * n64)()
+    orc.lib().orc_rng_stream(_C.c_uint64(seed), n32, o32, n64, o64)
+    r = rng_ref.StdRng(seed)
+    assert list(o32) == [r.next_u32() for _ in range(n32)]
+    assert list(o64) == [r.next_u64() for _ in range(n64)]
+
+
+def test_oracle_weighted_index_matches_python_reference():
+    rs = np.random.RandomState(11)
+    cases = [rs.rand(7).astype(np.float32), rs.rand(256).astype(np.float32) ** 8, np.array([0, 0, 1, 0, 2, 0], np.float32),
+             np.array([1e-30, 1.0, 1e-30], np.float32), (rs.rand(1024) * (rs.rand(1024) > 0.7)).astype(np.float32) + np.float32(1e-12)]
+    for i, w in enumerate(cases):
+        draws = 300
+        out = (_C.c_uint32 * draws)()
+        orc.lib().orc_rng_weighted_index(_C.c_uint64(1000 + i), w.ctypes.data_as(_C.POINTER(_C.c_float)), len(w), draws, out)
+        r = rng_ref.StdRng(1000 + i)
+        assert list(out) == [rng_ref.weighted_index_sample(r, [float(v) for v in w]) for _ in range(draws)]
+        assert all(w[j] > 0 for j in out)

@@ -112,6 +112,14 @@ int fs_lm_generate(fs_lm_t* lm, const uint32_t* prompt, int L, int max_new_token
     FS_ARG(lm && prompt && sampling && n_frames, "null argument");
     FS_TRY(lm->impl->generate(prompt, L, max_new_tokens, *sampling, seed, flags, codes_out, cap, n_frames, cb, cb_user))
 }
+int fs_lm_generate_with_hidden(fs_lm_t* lm, const uint32_t* prompt, int L, int max_new_tokens, const fs_sampling* sampling, uint64_t seed,
+                               uint32_t flags, uint32_t* codes_out, size_t cap, size_t* n_frames, float* hidden_out, size_t hidden_cap,
+                               size_t* n_hidden, fs_frame_cb cb, void* cb_user) {
+    FS_ARG(lm && prompt && sampling && n_frames, "null argument");
+    FS_ARG(!hidden_out || n_hidden, "hidden_out without n_hidden");
+    FS_TRY(lm->impl->generate(prompt, L, max_new_tokens, *sampling, seed, flags, codes_out, cap, n_frames, cb, cb_user, hidden_out,
+                              hidden_cap, n_hidden))
+}
 int fs_lm_generate_batch(fs_lm_t* lm, const uint32_t* prompts, const int* lens, int n, int max_new_tokens, const fs_sampling* sampling,
                          uint64_t seed, uint32_t flags, uint32_t* codes_out, size_t cap, size_t* n_frames) {
     FS_ARG(lm && prompts && lens && sampling && codes_out && n_frames, "null argument");

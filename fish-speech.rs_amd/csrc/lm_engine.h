@@ -23,7 +23,7 @@ class LMBase {
     virtual int kv_len() = 0;
     virtual void generate(const uint32_t* prompt, int L, int max_new_tokens, const fs_sampling& s, uint64_t seed,
                           uint32_t flags, uint32_t* codes_out, size_t cap, size_t* n_frames, fs_frame_cb cb,
-                          void* cb_user) = 0;
+                          void* cb_user, float* hidden_out = nullptr, size_t hidden_cap = 0, size_t* n_hidden = nullptr) = 0;
     virtual void generate_batch(const uint32_t* prompts, const int* lens, int n, int max_new_tokens,
                                 const fs_sampling& s, uint64_t seed, uint32_t flags, uint32_t* codes_out, size_t cap,
                                 size_t* n_frames) = 0;

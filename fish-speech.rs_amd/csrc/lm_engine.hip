@@ -309,7 +309,8 @@ class LM final : public LMBase {
 
     // ------------------------------------------------------------------------------------------ generate_blocking
     void generate(const uint32_t* prompt, int L, int max_new_tokens, const fs_sampling& s, uint64_t seed, uint32_t flags,
-                  uint32_t* codes_out, size_t cap, size_t* n_frames, fs_frame_cb cb, void* cb_user) override {
+                  uint32_t* codes_out, size_t cap, size_t* n_frames, fs_frame_cb cb, void* cb_user, float* hidden_out, size_t hidden_cap,
+                  size_t* n_hidden) override {
         use_device();
         require_loaded();
         const int C = a_.num_codebooks, C1 = C + 1;
@@ -341,6 +342,10 @@ class LM final : public LMBase {
             plock = std::unique_lock<std::mutex>(persist_mutex(device_), std::try_to_lock);
             use_persist_ = plock.owns_lock();
         }
+        // generate_blocking_with_hidden: the slow sampler stores the hidden state of every iteration through this pointer cell
+        if (hidden_out && !d_hidden_.p) d_hidden_.alloc(sizeof(float) * (size_t)out_cap_ * a_.dim);
+        float* hid_dev = hidden_out ? d_hidden_.as<float>() : nullptr;
+        FS_HIP(hipMemcpyAsync(d_hid_slot_.p, &hid_dev, sizeof(hid_dev), hipMemcpyHostToDevice, st_));
         RngState rng = {};
         seed_key(seed, rng.key);
         FS_HIP(hipMemcpyAsync(d_rng_.p, &rng, sizeof(rng), hipMemcpyHostToDevice, st_));
@@ -435,6 +440,12 @@ class LM final : public LMBase {
             for (int c = 0; c < C; ++c) std::memcpy(codes_out + (size_t)c * cap, tmp.data() + (size_t)c * out_cap_, sizeof(uint32_t) * n);
         }
         if (n_frames) *n_frames = n;
+        if (hidden_out) {
+            const size_t rows = (size_t)hs->frame;  // iterations executed, the terminating <|im_end|> one included (single_batch.rs:264-266)
+            FS_REQUIRE(rows <= hidden_cap, "hidden_out capacity too small for the generator iterations");
+            FS_HIP(hipMemcpy(hidden_out, d_hidden_.p, sizeof(float) * rows * a_.dim, hipMemcpyDeviceToHost));
+            if (n_hidden) *n_hidden = rows;
+        }
     }
 
     // generate_static_batch (static_batch.rs:282-390).  bf16 / fp8 handles with n <= min(max_batch, kRows): the MFMA row path below
@@ -615,7 +626,7 @@ class LM final : public LMBase {
             clear_slow();  // static_batch.rs:118-121
             // child seed per row (sampling/mod.rs:93-95 draws one u64 per row per call; here one per row per request)
             generate(padded.data(), Lmax, max_new_tokens, sb, seed + 0x9E3779B97F4A7C15ull * (uint64_t)i, flags,
-                     codes_out + (size_t)i * a_.num_codebooks * cap, cap, &n_frames[i], nullptr, nullptr);
+                     codes_out + (size_t)i * a_.num_codebooks * cap, cap, &n_frames[i], nullptr, nullptr, nullptr, 0, nullptr);
         }
     }
 
@@ -768,6 +779,8 @@ class LM final : public LMBase {
         d_act_.alloc(sizeof(float) * a_.intermediate_size);
         d_logits_slow_.alloc(sizeof(float) * a_.vocab_size);
         d_logits_fast_.alloc(sizeof(float) * a_.codebook_size);
+        d_hid_slot_.alloc(sizeof(float*));
+        FS_HIP(hipMemset(d_hid_slot_.p, 0, sizeof(float*)));
         d_state_.alloc(sizeof(SeqState) * B_);
         FS_HIP(hipMemset(d_state_.p, 0, d_state_.n));
         d_cfg_.alloc(sizeof(SampleCfg));
@@ -1074,7 +1087,7 @@ class LM final : public LMBase {
         // audio-range head: rows [im_end, V) only (constrain_probs_to_audio, utils.rs:13-16)
         LmKernels<WT>::head(d_, x(0), norm_w_, slow_head_w(), slow_head_s(), n_audio_, d_logits_slow_.as<float>(), st_);
         SampleKernels<WT>::sample_slow(d_, d_logits_slow_.as<float>(), n_audio_, d_cfg_.as<SampleCfg>(), d_rng_.as<RngState>(), state(0),
-                                       x(0), xf(0), st_);
+                                       x(0), xf(0), st_, d_hid_slot_.as<float*>());
         if (use_persist_) launch_fast_persist(persist_args(), st_);
         else
         for (int cbi = 0; cbi < C; ++cbi) {
@@ -1119,6 +1132,7 @@ class LM final : public LMBase {
     DevBuf d_x_, d_xf_, d_q_, d_part_, d_act_, d_logits_slow_, d_logits_fast_, d_state_, d_cfg_, d_rng_, d_prompt_, d_out_;
     DevBuf d_rp_mask_, d_rp_seen_, d_rp_ring_, d_rp_meta_;
     DevBuf d_pack_, d_edges_, d_ctl_;  // persistent fast decoder
+    DevBuf d_hidden_, d_hid_slot_;     // generate_blocking_with_hidden: [out_cap][dim] rows + the pointer cell the captured graphs read
     bool persist_ok_ = false, use_persist_ = false;
     DevBuf d_pfx_, d_pfq_, d_pfslab_, d_pfa_, d_pfa2_, d_pfss_, d_pfc_, d_pfpart_;  // MFMA row-path activations (kRowsCap rows)
     DevBuf d_bprompt_;  // static batch: all left-padded prompts [B][C + 1][Lmax] (group prefill)

@@ -170,9 +170,10 @@ struct RngState {      // rand 0.8.5 StdRng (ChaCha12) stream position
 
 template <typename WT>
 struct SampleKernels {
-    // slow token: logits over [im_end, V) (utils.rs:13-16) -> token = idx + im_end; sets done; copies x -> xf
+    // slow token: logits over [im_end, V) (utils.rs:13-16) -> token = idx + im_end; sets done; copies x -> xf; *hid_slot (device
+    // pointer cell, may hold null): hidden-state rows [iteration][dim] of generate_blocking_with_hidden
     static void sample_slow(const ModelDims& d, const float* logits, int n, const SampleCfg* c, RngState* rng,
-                            SeqState* state, const float* x, float* xf, hipStream_t st);
+                            SeqState* state, const float* x, float* xf, hipStream_t st, float* const* hid_slot = nullptr);
     // codebook cb: rep-pen (if have_prev), sample, cur[cb+1]; xf = fast_emb[code]; cb == last: finish the frame
     // (record codes, prev = cur, x = embed(cur), pos++, frame++)
     static void sample_fast(const ModelDims& d, const float* logits, int cb, int n_cb, int cb_size, const SampleCfg* c,

@@ -2260,13 +2260,19 @@ __device__ __forceinline__ int greedy_pick(const float (&val)[SAMPLE_MAXN / SAMP
 template <typename WT>
 __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_slow(const float* __restrict__ logits, int n,
                                                                 const SampleCfg* __restrict__ cp, RngState* rng, SeqState* __restrict__ state,
-                                                                const float* __restrict__ x, float* __restrict__ xf, int dim) {
+                                                                const float* __restrict__ x, float* __restrict__ xf, int dim,
+                                                                float* const* __restrict__ hid_slot) {
     __shared__ __attribute__((aligned(16))) float lg[SAMPLE_MAXN];
     __shared__ __attribute__((aligned(16))) float sp[SAMPLE_MAXN];
     __shared__ __attribute__((aligned(16))) int si[SAMPLE_MAXN];
     __shared__ double red[SAMPLE_THREADS];
     const int tid = threadIdx.x;
     const SampleCfg c = *cp;
+    // generate_blocking_with_hidden (single_batch.rs:250,264-266): the hidden state of every generator iteration, the terminating one
+    // included, row = iteration index; replays after termination (done != 0 on entry) write nothing
+    float* hid = hid_slot ? *hid_slot : nullptr;
+    if (hid && state->done != 0) hid = nullptr;
+    if (hid) hid += (size_t)state->frame * dim;
     __shared__ unsigned long long s_key;
     if (c.temp == 0.f && !c.legacy) {  // greedy: two barriers instead of five (see greedy_pick)
         if (tid == 0) s_key = 0ull;
@@ -2277,7 +2283,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_slow(const float* __r
             val[j] = i < n ? logits[i] : -INFINITY;
             if (i == 0 && c.ignore_eos) val[j] = -INFINITY;
         }
-        for (int i = tid; i < dim; i += SAMPLE_THREADS) xf[i] = x[i];  // hidden_states -> fast decoder input (:149)
+        for (int i = tid; i < dim; i += SAMPLE_THREADS) { const float h = x[i]; xf[i] = h; if (hid) hid[i] = h; }  // hidden_states -> fast decoder input (:149)
         __syncthreads();
         const int idx = greedy_pick(val, n, &s_key);
         if (tid == 0) {
@@ -2289,7 +2295,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_slow(const float* __r
         return;
     }
     for (int i = tid; i < n; i += SAMPLE_THREADS) lg[i] = logits[i];
-    for (int i = tid; i < dim; i += SAMPLE_THREADS) xf[i] = x[i];  // hidden_states -> fast decoder input (:149)
+    for (int i = tid; i < dim; i += SAMPLE_THREADS) { const float h = x[i]; xf[i] = h; if (hid) hid[i] = h; }  // hidden_states -> fast decoder input (:149)
     __syncthreads();
     if (c.legacy) {
         // legacy_softmax_sample (sampling/mod.rs:8-26): P(pad) = softmax([pad, eos])[0]; u ~ U[0,1) = (next_u32 >> 8) * 2^-24
@@ -2750,9 +2756,9 @@ void LmKernels<WT>::fast_embed(const ModelDims& d, const void* fast_emb, const u
 
 template <typename WT>
 void SampleKernels<WT>::sample_slow(const ModelDims& d, const float* logits, int n, const SampleCfg* c, RngState* rng,
-                                    SeqState* state, const float* x, float* xf, hipStream_t st) {
+                                    SeqState* state, const float* x, float* xf, hipStream_t st, float* const* hid_slot) {
     FS_REQUIRE(n <= SAMPLE_MAXN, "audio-range vocabulary larger than the sampler capacity");
-    hipLaunchKernelGGL((k_sample_slow<KVT<WT>>), dim3(1), dim3(SAMPLE_THREADS), 0, st, logits, n, c, rng, state, x, xf, d.dim);
+    hipLaunchKernelGGL((k_sample_slow<KVT<WT>>), dim3(1), dim3(SAMPLE_THREADS), 0, st, logits, n, c, rng, state, x, xf, d.dim, hid_slot);
     FS_LAUNCH_CHECK();
 }
 

@@ -114,6 +114,26 @@ class DualARTransformer:
                                              out.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_size_t(cap), C.byref(n), cb, None))
         return out[:, : n.value].copy()
 
+    def generate_blocking_with_hidden(self, prompt, max_new_tokens, collect_hidden_states=True, temp=0.7, top_p=0.9, top_k=50,
+                                      repetition_penalty=1.2, seed=0, ignore_eos=False, persistent=True):
+        """generate/single_batch.rs:217-306 -> (codes u32 (C, n_frames), hidden f32 (n_iterations, 1, dim) or None)."""
+        prompt = _u32(prompt)
+        Cb, D = self.cfg["num_codebooks"], self.cfg["dim"]
+        if prompt.ndim != 2 or prompt.shape[0] != Cb + 1:
+            raise ValueError("Input tokens must have num_codebooks + 1 codebooks!")
+        L = prompt.shape[1]
+        cap = max(1, max_new_tokens - L + 2) + 1
+        out = np.zeros((Cb, cap), np.uint32)
+        hid = np.zeros((cap, D), np.float32) if collect_hidden_states else None
+        n, nh = C.c_size_t(0), C.c_size_t(0)
+        s = _ffi.Sampling(float(temp), float(top_p), int(top_k), float(repetition_penalty))
+        _ffi.check(_ffi.lib().fs_lm_generate_with_hidden(
+            self._h, prompt.ctypes.data_as(C.POINTER(C.c_uint32)), L, int(max_new_tokens), C.byref(s), C.c_uint64(seed),
+            (1 if ignore_eos else 0) | (0 if persistent else 2), out.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_size_t(cap), C.byref(n),
+            hid.ctypes.data_as(C.POINTER(C.c_float)) if collect_hidden_states else None, C.c_size_t(cap), C.byref(nh),
+            C.cast(None, _ffi.FRAME_CB), None))
+        return out[:, : n.value].copy(), (hid[: nh.value].reshape(nh.value, 1, D).copy() if collect_hidden_states else None)
+
     def generate_static_batch(self, prompts, max_new_tokens, temp=0.7, top_p=0.9, top_k=50, repetition_penalty=1.2,
                               seed=42, ignore_eos=False):
         """generate/static_batch.rs:282-390 (audio_only).  prompts: list of u32 (C+1, L_i) -> list of (C, n_i)."""

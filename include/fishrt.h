@@ -116,6 +116,13 @@ int fs_lm_curr_kv_size(fs_lm_t* lm);                       /* dual_ar.rs:695-700
  * *n_frames receives the number of frames written (<= cap).  The KV cache is NOT cleared first (the caller
  * owns cache lifetime exactly as with the reference: fish_speech_python/src/lm.rs:94,131-135).
  * seed: seeds the sampler RNG (the reference draws rand::random(), single_batch.rs:46).
+ * Extensions / restrictions relative to the reference, stated here so that nobody takes them for parity:
+ *   - sampling->top_k == 0 means "no top-k" when temp > 0.  The reference has no such setting: `select_nth_unstable_by(0, ..)` yields an
+ *     empty candidate set (candle's single path then fails in WeightedIndex::new, the batch path falls to `unwrap_or(0)`,
+ *     sampling/mod.rs:57-75).  With temp == 0 top_k is never looked at (argmax first), there as here.
+ *   - Fish 1.5 handles require im_end_id + 1 == semantic_start_id (the contiguous branch of constrain_probs_to_audio /
+ *     rescale_semantic_tokens, generate/utils.rs:13-16,45-46); the gather branch for a non-adjacent <|im_end|> (:17-30,47-51) is
+ *     rejected with an error.
  * flags: FS_GEN_IGNORE_EOS masks <|im_end|> (bench-only, fixed-length runs: SURVEY.md §8d).
  *        FS_GEN_NO_PERSIST keeps the fast decoder on the per-node graph path.  By default a greedy call (temp == 0) on a bf16 handle
  *        with the Fish geometry runs the 8 codebook passes of every frame as ONE persistent launch (csrc/lm_persist.hip: weights
@@ -126,6 +133,15 @@ int fs_lm_curr_kv_size(fs_lm_t* lm);                       /* dual_ar.rs:695-700
 int fs_lm_generate(fs_lm_t* lm, const uint32_t* prompt, int L, int max_new_tokens, const fs_sampling* sampling,
                    uint64_t seed, uint32_t flags, uint32_t* codes_out, size_t cap, size_t* n_frames, fs_frame_cb cb,
                    void* cb_user);
+/* generate_blocking_with_hidden (generate/single_batch.rs:217-306; caller: server/lib/handlers/speech.rs:27-48).
+ * hidden_out != NULL <=> collect_hidden_states = true: f32 [hidden_cap, dim] receives the slow transformer's pre-norm hidden state
+ * (the `hidden_states` of forward_generate, dual_ar.rs:629-634) of EVERY generator iteration in order -- the first frame, every later
+ * frame, and the terminating <|im_end|> iteration whose codes are not emitted (:264-266), so *n_hidden is *n_frames or
+ * *n_frames + 1; hidden_cap >= max_new_tokens - L + 2 always suffices.  hidden_out == NULL is fs_lm_generate (the reference
+ * returns None). */
+int fs_lm_generate_with_hidden(fs_lm_t* lm, const uint32_t* prompt, int L, int max_new_tokens, const fs_sampling* sampling,
+                               uint64_t seed, uint32_t flags, uint32_t* codes_out, size_t cap, size_t* n_frames, float* hidden_out,
+                               size_t hidden_cap, size_t* n_hidden, fs_frame_cb cb, void* cb_user);
 
 /* generate_static_batch (generate/static_batch.rs:282-390), audio_only = true: n prompts [num_codebooks+1, L_i]
  * (concatenated in `prompts`, lengths in `lens`), left-padded with <|im_end|>/0 as static_batch.rs:68-111,

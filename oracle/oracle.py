@@ -175,7 +175,9 @@ class OracleLM:
         return np.ctypeslib.as_array(ptr, (int(np.prod(shape)),)).reshape(shape)
 
     def generate(self, prompt, max_new_tokens, temp=0.0, top_p=1.0, top_k=0, repetition_penalty=1.0, seed=0,
-                 ignore_eos=False, max_frames=-1):
+                 ignore_eos=False, max_frames=-1, collect_hidden=False):
+        """generate_blocking[_with_hidden] (single_batch.rs:217-324).  collect_hidden: also returns the slow transformer's hidden state
+        of EVERY generator iteration, the terminating <|im_end|> one included (:264-266), f32 (n_iter, dim)."""
         prompt = np.ascontiguousarray(prompt, np.uint32)
         Cb = self.cfg["num_codebooks"]
         assert prompt.shape[0] == Cb + 1
@@ -185,13 +187,17 @@ class OracleLM:
         n, nit = C.c_int(0), C.c_int(0)
         pf, dc = C.c_double(0), C.c_double(0)
         margins = np.zeros(cap, np.float32)
+        hid = np.zeros((cap, self.cfg["dim"]), np.float32) if collect_hidden else None
+        nh = C.c_int(0)
         _chk(lib().orc_lm_generate(self.h, _p(prompt, C.c_uint32), L, int(max_new_tokens), C.c_double(temp),
                                    C.c_double(top_p), C.c_uint64(top_k), C.c_float(repetition_penalty),
                                    C.c_uint64(seed), int(ignore_eos), int(max_frames), _p(out, C.c_uint32), cap,
-                                   C.byref(n), C.byref(pf), C.byref(dc), _p(margins, C.c_float), C.byref(nit)))
+                                   C.byref(n), C.byref(pf), C.byref(dc), _p(margins, C.c_float), C.byref(nit),
+                                   _p(hid, C.c_float) if collect_hidden else None, cap, C.byref(nh)))
         self.last_prefill_s, self.last_decode_s = pf.value, dc.value
         self.last_margins = margins[: nit.value].copy()  # min top-2 margin of the 9 decisions of each iteration
-        return out[: Cb * n.value].reshape(Cb, n.value).copy()
+        codes = out[: Cb * n.value].reshape(Cb, n.value).copy()
+        return (codes, hid[: nh.value].copy()) if collect_hidden else codes
 
 
 def _generate_batch(self, prompts, max_new_tokens, temp=0.0, top_p=1.0, top_k=0, seed=42, ignore_eos=False):

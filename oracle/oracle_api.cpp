@@ -101,14 +101,20 @@ const float* orc_lm_tensor(void* p, const char* name, int layer) {
 int orc_lm_generate(void* p, const uint32_t* prompt, int L, int max_new_tokens, double temp, double top_p, uint64_t top_k,
                     float rep_pen, uint64_t seed, int ignore_eos, int max_frames, uint32_t* codes_out, int cap,
                     int* n_frames, double* prefill_s, double* decode_s, float* margins_out /*[iterations] or null*/,
-                    int* n_iter_out) {
+                    int* n_iter_out, float* hidden_out /*[hidden_cap, dim] or null*/, int hidden_cap, int* n_hidden) {
     try {
         LM* lm = (LM*)p;
         Sampling s; s.temp = temp; s.top_p = top_p; s.top_k = top_k; s.repetition_penalty = rep_pen;
         int n = 0;
-        std::vector<float> margins;
-        auto out = lm->generate(prompt, L, max_new_tokens, s, seed, ignore_eos != 0, &n, nullptr, prefill_s, decode_s,
+        std::vector<float> margins, hid;
+        auto out = lm->generate(prompt, L, max_new_tokens, s, seed, ignore_eos != 0, &n, hidden_out ? &hid : nullptr, prefill_s, decode_s,
                                 max_frames, margins_out ? &margins : nullptr);
+        if (hidden_out) {
+            const int rows = (int)(hid.size() / (size_t)lm->a.dim);
+            if (rows > hidden_cap) { g_err = "hidden_out too small"; return 2; }
+            std::memcpy(hidden_out, hid.data(), sizeof(float) * hid.size());
+            if (n_hidden) *n_hidden = rows;
+        }
         if (margins_out) std::memcpy(margins_out, margins.data(), sizeof(float) * margins.size());
         if (n_iter_out) *n_iter_out = (int)margins.size();
         if (n > cap) { g_err = "codes_out too small"; return 2; }

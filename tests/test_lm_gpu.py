@@ -147,6 +147,52 @@ def test_eos_semantics_and_budget(tiny32):
         lm.forward_generate(np.full((9, 2), 600, np.uint32), lm.curr_kv_size())
 
 
+def test_generate_blocking_with_hidden_vs_oracle(tiny32):
+    """single_batch.rs:217-306: codes + the slow transformer's hidden state of every generator iteration (the terminating <|im_end|>
+    iteration included, :264-266); collect_hidden_states = false returns None; Fish-1.5 shapes in bf16 below."""
+    lm = tiny32
+    o = orc.OracleLM(orc.TINY).load_synthetic(SEED)
+    rng = np.random.RandomState(5)
+    n_plus_one = 0
+    for trial in range(6):
+        L = int(rng.randint(1, 9))
+        p = np.zeros((9, L), np.uint32)
+        p[0] = rng.randint(0, 400, L)
+        lm.clear_slow_layer_caches(); o.clear_slow()
+        codes, hid = lm.generate_blocking_with_hidden(p, 120, True, temp=0.0, top_p=1.0, top_k=0, repetition_penalty=1.1)
+        ec, eh = o.generate(p, 120, temp=0.0, repetition_penalty=1.1, collect_hidden=True)
+        assert np.array_equal(codes, ec)
+        assert hid.shape == (eh.shape[0], 1, eh.shape[1]) and hid.shape[0] in (codes.shape[1], codes.shape[1] + 1)
+        np.testing.assert_allclose(hid[:, 0], eh, rtol=2e-4, atol=2e-5)
+        n_plus_one += hid.shape[0] == codes.shape[1] + 1
+        # the rows are what forward_generate returns as `hidden` for the same position
+        lm.clear_slow_layer_caches()
+        _, h0 = lm.forward_generate(p, 0)
+        np.testing.assert_allclose(hid[0, 0], h0.reshape(-1), rtol=1e-5, atol=1e-6)
+    assert n_plus_one >= 1, "no run ended on <|im_end|>: the extra hidden row of the terminating iteration went untested"
+    lm.clear_slow_layer_caches()
+    codes2, none = lm.generate_blocking_with_hidden(p, 120, False, temp=0.0, top_p=1.0, top_k=0, repetition_penalty=1.1)
+    assert none is None and np.array_equal(codes2, codes)
+
+
+def test_generate_blocking_with_hidden_fish15_bf16():
+    lm = fishrt.DualARTransformer(fcfg.FISH_1_5, fcfg.FISH_1_5_TOKENS, 0, "bf16").load_synthetic(SEED)
+    rng = np.random.RandomState(8)
+    p = np.zeros((9, 20), np.uint32)
+    p[0] = rng.randint(0, 100000, 20)
+    for persistent in (True, False):
+        lm.clear_slow_layer_caches()
+        codes, hid = lm.generate_blocking_with_hidden(p, 20 + 10, True, temp=0.0, top_p=1.0, top_k=0, repetition_penalty=1.2, ignore_eos=True,
+                                                      persistent=persistent)
+        assert codes.shape == (8, 12) and hid.shape == (12, 1, 1024) and np.isfinite(hid).all()
+        lm.clear_slow_layer_caches()
+        _, h0 = lm.forward_generate(p, 0)
+        # (generate runs the last prompt token through the GEMV decode kernels, forward_generate runs all of them as one MFMA pass)
+        np.testing.assert_allclose(hid[0, 0], h0.reshape(-1), rtol=2e-3, atol=1e-3)
+        assert np.abs(hid[1, 0] - hid[0, 0]).max() > 1e-2
+    lm.close()
+
+
 def test_streaming_callback_matches_blocking(tiny32):
     lm = tiny32
     p = LMG["prompt"]

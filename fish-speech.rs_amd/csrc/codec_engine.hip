@@ -76,9 +76,7 @@ class Codec final : public CodecBase {
         SafeTensors sf(path);
         std::vector<float> host;
         for (const auto& t : tensors_) {
-            const StTensor* s = sf.find(t.name);
-            if (!s) throw Error("cannot find tensor " + t.name);
-            if ((size_t)s->numel() != t.numel()) throw Error("shape mismatch for " + t.name);
+            const StTensor* s = &sf.get(t.name, t.shape);  // exact shape, as candle's VarBuilder::get (a transposed tensor is an error)
             host.resize(t.numel());
             SafeTensors::to_f32(*s, host.data());
             FS_HIP(hipMemcpyAsync(raw_.f() + t.off, host.data(), host.size() * 4, hipMemcpyHostToDevice, st_));
@@ -254,10 +252,12 @@ class Codec final : public CodecBase {
         convs_.push_back(s);
         return (int)convs_.size() - 1;
     }
-    int add_linear_as_conv(const std::string& name, int cout, int cin, double fan_in) {  // pwconv{1,2}.{weight,bias}
+    // pwconv{1,2}.{weight,bias} (nn.Linear: [cout, cin]); conv_k1: a kernel-1 Conv1d whose checkpoint tensor is [cout, cin, 1]
+    int add_linear_as_conv(const std::string& name, int cout, int cin, double fan_in, bool conv_k1 = false) {
         ConvSpec s;
         s.stride = 1;
-        s.raw = add_tensor(name + ".weight", {cout, cin}, 0.f, 1.0 / std::sqrt(fan_in));
+        s.raw = conv_k1 ? add_tensor(name + ".weight", {cout, cin, 1}, 0.f, 1.0 / std::sqrt(fan_in))
+                        : add_tensor(name + ".weight", {cout, cin}, 0.f, 1.0 / std::sqrt(fan_in));
         s.bias = add_tensor(name + ".bias", {cout}, 0.f, 0.02);
         s.cout = cout; s.cin_g = cin; s.k = 1; s.transposed = false;
         relaid_off_.push_back(relaid_floats_);
@@ -333,7 +333,7 @@ class Codec final : public CodecBase {
                 const std::string q = "backbone.downsample_layers." + std::to_string(i);
                 mid_lnw_[i] = add_tensor(q + ".0.weight", {edims_[i - 1]}, 1.f, 0.1);
                 mid_lnb_[i] = add_tensor(q + ".0.bias", {edims_[i - 1]}, 0.f, 0.02);
-                mid_conv_[i] = add_linear_as_conv(q + ".1", edims_[i], edims_[i - 1], (double)edims_[i - 1]);
+                mid_conv_[i] = add_linear_as_conv(q + ".1", edims_[i], edims_[i - 1], (double)edims_[i - 1], /*conv_k1=*/true);
             }
             for (int j = 0; j < edepths_[i]; ++j)
                 stages_[i].push_back(plan_block("backbone.stages." + std::to_string(i) + "." + std::to_string(j), edims_[i]));

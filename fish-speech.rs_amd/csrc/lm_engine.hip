@@ -161,10 +161,9 @@ class LM final : public LMBase {
         for (const auto& td : tensors_) {
             std::string name = td.name;
             if (name == "output.weight" && a_.tie_word_embeddings) name = "embeddings.weight";  // dual_ar.rs:482-486
-            const StTensor* t = st.find(name);
-            if (!t) throw Error("cannot find tensor " + name);  // candle VarBuilder: "cannot find tensor"
-            if (t->numel() != td.rows * td.cols)
-                throw Error("shape mismatch for " + name + ": expected " + std::to_string(td.rows) + "x" + std::to_string(td.cols));
+            // exact shape, as candle's VarBuilder::get: [rows, cols] for matrices / embeddings, [n] for norm vectors (a transposed tensor
+            // of the same element count is an error, not a silent load)
+            const StTensor* t = &st.get(name, td.is_vec ? std::vector<int64_t>{td.cols} : std::vector<int64_t>{td.rows, td.cols});
             host.resize((size_t)t->numel());
             SafeTensors::to_f32(*t, host.data());
             if (stage.n < host.size() * 4) stage.alloc(host.size() * 4);

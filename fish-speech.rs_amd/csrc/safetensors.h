@@ -7,6 +7,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <climits>
 #include <cstdint>
 #include <cstring>
 #include <functional>
@@ -30,31 +31,59 @@ struct StTensor {
     }
 };
 
+// read-only mapping of a file; unmaps / closes on destruction, so a throwing SafeTensors constructor leaks nothing
+struct MappedFile {
+    int fd = -1;
+    const uint8_t* base = nullptr;
+    size_t size = 0;
+    explicit MappedFile(const std::string& path) {
+        fd = open(path.c_str(), O_RDONLY);
+        if (fd < 0) throw Error("cannot open " + path);
+        struct stat sb;
+        if (fstat(fd, &sb) != 0) { close(fd); fd = -1; throw Error("cannot stat " + path); }
+        size = (size_t)sb.st_size;
+        if (size < 8) { close(fd); fd = -1; throw Error("safetensors file too small: " + path); }
+        void* m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) { close(fd); fd = -1; throw Error("mmap failed: " + path); }
+        base = (const uint8_t*)m;
+    }
+    ~MappedFile() {
+        if (base) munmap((void*)base, size);
+        if (fd >= 0) close(fd);
+    }
+    MappedFile(const MappedFile&) = delete;
+    MappedFile& operator=(const MappedFile&) = delete;
+};
+
+inline size_t st_elem_size(const std::string& dtype) {
+    if (dtype == "F32") return 4;
+    if (dtype == "BF16" || dtype == "F16") return 2;
+    throw Error("unsupported safetensors dtype " + dtype);
+}
+
 class SafeTensors {
   public:
-    explicit SafeTensors(const std::string& path) {
-        fd_ = open(path.c_str(), O_RDONLY);
-        if (fd_ < 0) throw Error("cannot open " + path);
-        struct stat sb;
-        if (fstat(fd_, &sb) != 0) throw Error("cannot stat " + path);
-        size_ = (size_t)sb.st_size;
-        if (size_ < 8) throw Error("safetensors file too small: " + path);
-        base_ = (const uint8_t*)mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd_, 0);
-        if (base_ == MAP_FAILED) throw Error("mmap failed: " + path);
+    explicit SafeTensors(const std::string& path) : f_(path) {
         uint64_t hlen;
-        std::memcpy(&hlen, base_, 8);
-        if (8 + hlen > size_) throw Error("corrupt safetensors header: " + path);
-        parse(std::string((const char*)base_ + 8, (size_t)hlen), base_ + 8 + hlen, size_ - 8 - hlen);
-    }
-    ~SafeTensors() {
-        if (base_ && base_ != MAP_FAILED) munmap((void*)base_, size_);
-        if (fd_ >= 0) close(fd_);
+        std::memcpy(&hlen, f_.base, 8);
+        if (hlen > f_.size - 8) throw Error("corrupt safetensors header: " + path);  // (no 8 + hlen: it wraps for a huge hlen)
+        parse(std::string((const char*)f_.base + 8, (size_t)hlen), f_.base + 8 + hlen, f_.size - 8 - (size_t)hlen);
     }
     const StTensor* find(const std::string& name) const {
         auto it = t_.find(name);
         return it == t_.end() ? nullptr : &it->second;
     }
-    // element `i` as f32 (F32 / BF16 / F16 supported)
+    // what candle's VarBuilder::get checks: the tensor exists with exactly this shape
+    const StTensor& get(const std::string& name, const std::vector<int64_t>& shape) const {
+        const StTensor* t = find(name);
+        if (!t) throw Error("cannot find tensor " + name);
+        if (t->shape != shape) {
+            auto fmt = [](const std::vector<int64_t>& v) { std::string r = "["; for (size_t i = 0; i < v.size(); ++i) r += (i ? ", " : "") + std::to_string(v[i]); return r + "]"; };
+            throw Error("shape mismatch for " + name + ": expected " + fmt(shape) + ", got " + fmt(t->shape));
+        }
+        return *t;
+    }
+    // all elements as f32 (F32 / BF16 / F16); the byte count was checked against shape x dtype when the header was parsed
     static void to_f32(const StTensor& t, float* dst) {
         const int64_t n = t.numel();
         if (t.dtype == "F32") {
@@ -80,52 +109,76 @@ class SafeTensors {
     }
 
   private:
-    // tiny JSON scanner for the flat header layout
+    // tiny JSON scanner for the flat header layout; every character access is bounds-checked (a truncated header is an error, not a read
+    // past the string)
     void parse(const std::string& h, const uint8_t* data, size_t data_len) {
         size_t i = 0;
+        auto at = [&](size_t k) -> char { if (k >= h.size()) throw Error("safetensors header: truncated"); return h[k]; };
         auto ws = [&]() { while (i < h.size() && (h[i] == ' ' || h[i] == '\n' || h[i] == '\t' || h[i] == '\r')) ++i; };
-        auto expect = [&](char c) { ws(); if (i >= h.size() || h[i] != c) throw Error(std::string("safetensors header: expected '") + c + "'"); ++i; };
+        auto expect = [&](char c) { ws(); if (at(i) != c) throw Error(std::string("safetensors header: expected '") + c + "'"); ++i; };
         auto str = [&]() {
             ws();
-            if (h[i] != '"') throw Error("safetensors header: expected string");
+            if (at(i) != '"') throw Error("safetensors header: expected string");
             std::string s;
-            for (++i; i < h.size() && h[i] != '"'; ++i) { if (h[i] == '\\' && i + 1 < h.size()) ++i; s.push_back(h[i]); }
+            for (++i; at(i) != '"'; ++i) { if (h[i] == '\\') { ++i; (void)at(i); } s.push_back(h[i]); }
             ++i;
             return s;
         };
-        auto num = [&]() { ws(); int64_t v = 0; while (i < h.size() && h[i] >= '0' && h[i] <= '9') v = v * 10 + (h[i++] - '0'); return v; };
+        auto num = [&]() {
+            ws();
+            if (at(i) < '0' || h[i] > '9') throw Error("safetensors header: expected a non-negative integer");
+            int64_t v = 0;
+            while (i < h.size() && h[i] >= '0' && h[i] <= '9') {
+                if (v > (INT64_MAX - 9) / 10) throw Error("safetensors header: integer overflow");
+                v = v * 10 + (h[i++] - '0');
+            }
+            return v;
+        };
+        int depth = 0;
         std::function<void()> skip = [&]() {  // skip any JSON value
             ws();
-            if (h[i] == '"') { str(); return; }
+            if (at(i) == '"') { str(); return; }
             if (h[i] == '{' || h[i] == '[') {
+                if (++depth > 64) throw Error("safetensors header: nesting too deep");
                 const char open = h[i], close = open == '{' ? '}' : ']';
                 ++i;
-                for (ws(); h[i] != close; ws()) { if (open == '{') { str(); expect(':'); } skip(); ws(); if (h[i] == ',') ++i; }
+                for (ws(); at(i) != close; ws()) { if (open == '{') { str(); expect(':'); } skip(); ws(); if (at(i) == ',') ++i; }
                 ++i;
+                --depth;
                 return;
             }
             while (i < h.size() && h[i] != ',' && h[i] != '}' && h[i] != ']') ++i;
         };
         expect('{');
-        for (ws(); i < h.size() && h[i] != '}'; ws()) {
+        for (ws(); at(i) != '}'; ws()) {
             const std::string name = str();
             expect(':');
-            if (name == "__metadata__") { skip(); ws(); if (h[i] == ',') ++i; continue; }
+            if (name == "__metadata__") { skip(); ws(); if (at(i) == ',') ++i; continue; }
             StTensor t;
             int64_t b = 0, e = 0;
+            bool have_off = false;
             expect('{');
-            for (ws(); h[i] != '}'; ws()) {
+            for (ws(); at(i) != '}'; ws()) {
                 const std::string key = str();
                 expect(':');
                 if (key == "dtype") t.dtype = str();
-                else if (key == "shape") { expect('['); for (ws(); h[i] != ']'; ws()) { t.shape.push_back(num()); ws(); if (h[i] == ',') ++i; } ++i; }
-                else if (key == "data_offsets") { expect('['); b = num(); expect(','); e = num(); expect(']'); }
+                else if (key == "shape") { expect('['); for (ws(); at(i) != ']'; ws()) { t.shape.push_back(num()); ws(); if (at(i) == ',') ++i; } ++i; }
+                else if (key == "data_offsets") { expect('['); b = num(); expect(','); e = num(); expect(']'); have_off = true; }
                 else skip();
                 ws();
-                if (h[i] == ',') ++i;
+                if (at(i) == ',') ++i;
             }
             ++i;
-            if (e < b || (size_t)e > data_len) throw Error("safetensors: bad offsets for " + name);
+            if (!have_off || e < b || (uint64_t)e > (uint64_t)data_len) throw Error("safetensors: bad offsets for " + name);
+            // the byte range must be exactly shape x dtype (a short range would be read past; safetensors itself rejects such files)
+            uint64_t numel = 1;
+            for (int64_t d : t.shape) {
+                if (d < 0 || (d > 0 && numel > UINT64_MAX / (uint64_t)d)) throw Error("safetensors: bad shape for " + name);
+                numel *= (uint64_t)d;
+            }
+            const uint64_t es = st_elem_size(t.dtype);
+            if (numel > UINT64_MAX / es || numel * es != (uint64_t)(e - b))
+                throw Error("safetensors: " + name + " has " + std::to_string(e - b) + " bytes, its shape and dtype need " + std::to_string(numel * es));
             t.data = data + b;
             t.nbytes = (size_t)(e - b);
             t_[name] = t;
@@ -133,9 +186,7 @@ class SafeTensors {
             if (i < h.size() && h[i] == ',') ++i;
         }
     }
-    int fd_ = -1;
-    const uint8_t* base_ = nullptr;
-    size_t size_ = 0;
+    MappedFile f_;
     std::map<std::string, StTensor> t_;
 };
 

@@ -85,6 +85,58 @@ def test_lm_checkpoint_equals_synthetic(tmp_path, dtype, store_bf16):
         fishrt.DualARTransformer(cfg, tok, 0, dtype).load_safetensors(path)
 
 
+def test_malformed_checkpoints_are_errors_not_crashes(tmp_path):
+    """header / offset validation of csrc/safetensors.h: a truncated or inconsistent file must come back as an error string (the
+    reference's safetensors crate rejects the same files), never as a read past the mapping; a transposed tensor of the right element
+    count is a shape error as with candle's VarBuilder::get"""
+    import json, struct
+    cfg, tok = fcfg.TINY, fcfg.TINY_TOKENS
+    good = _lm_tensors(cfg, False)
+    path = str(tmp_path / "bad.safetensors")
+
+    def write(hdr_bytes, payload, hlen=None):
+        with open(path, "wb") as f:
+            f.write(struct.pack("<Q", len(hdr_bytes) if hlen is None else hlen)); f.write(hdr_bytes); f.write(payload)
+
+    def header_and_payload(tensors, patch=None):
+        hdr, blobs, off = {}, [], 0
+        for k, v in tensors.items():
+            b = np.ascontiguousarray(v, np.float32).tobytes()
+            hdr[k] = {"dtype": "F32", "shape": list(v.shape), "data_offsets": [off, off + len(b)]}
+            off += len(b); blobs.append(b)
+        if patch:
+            patch(hdr)
+        return json.dumps(hdr).encode(), b"".join(blobs)
+
+    def expect_error(match):
+        with pytest.raises(RuntimeError, match=match):
+            fishrt.DualARTransformer(cfg, tok, 0, "f32").load_safetensors(path)
+
+    # 1. transposed matrix: same numel, wrong shape
+    t = dict(good); t["layers.0.feed_forward.w2.weight"] = np.ascontiguousarray(t["layers.0.feed_forward.w2.weight"].T)
+    write(*header_and_payload(t)); expect_error("shape mismatch for layers.0.feed_forward.w2.weight")
+    # 2. data_offsets [0, 0] with a full shape (would read past the mapping)
+    write(*header_and_payload(good, lambda h: h["norm.weight"].update(data_offsets=[0, 0]))); expect_error("norm.weight")
+    # 3. byte range shorter than shape x dtype
+    def short(h):
+        b, e = h["fast_norm.weight"]["data_offsets"]; h["fast_norm.weight"]["data_offsets"] = [b, e - 4]
+    write(*header_and_payload(good, short)); expect_error("fast_norm.weight")
+    # 4. offsets beyond the file
+    hj, pl = header_and_payload(good)
+    write(hj, pl[: len(pl) // 2]); expect_error("bad offsets")
+    # 5. header length larger than the file / absurd (8 + hlen wraps)
+    write(hj, pl, hlen=len(hj) + len(pl) + 100); expect_error("corrupt safetensors header")
+    write(hj, pl, hlen=2 ** 64 - 4); expect_error("corrupt safetensors header")
+    # 6. truncated header JSON
+    write(hj[: len(hj) // 2], b""); expect_error("safetensors")           # the first tensor's offsets already fail (no payload)
+    write(hj[: len(hj) // 2], pl); expect_error("safetensors header")      # with the payload present the scanner runs off the header
+    # 7. unsupported dtype
+    write(*header_and_payload(good, lambda h: h["norm.weight"].update(dtype="I64"))); expect_error("unsupported safetensors dtype")
+    # the handle machinery still works afterwards
+    write(*header_and_payload(good))
+    fishrt.DualARTransformer(cfg, tok, 0, "f32").load_safetensors(path).close()
+
+
 def test_codec_checkpoint_equals_synthetic(tmp_path):
     import math
     C, seed = 64, 1234

@@ -114,6 +114,7 @@ class LM final : public LMBase {
         plan_tensors();
         alloc_runtime();
         for (auto& e : ev_) FS_HIP(hipEventCreate(&e));
+        for (auto& e : ev_batch_) FS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     ~LM() override {
         (void)hipSetDevice(device_);
@@ -124,6 +125,7 @@ class LM final : public LMBase {
             if (kvp.second.second) (void)hipGraphExecDestroy(kvp.second.second);
         }
         for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
+        for (auto& e : ev_batch_) if (e) (void)hipEventDestroy(e);
         if (h_pin_) (void)hipHostFree(h_pin_);
         if (st_) (void)hipStreamDestroy(st_);
     }
@@ -372,41 +374,66 @@ class LM final : public LMBase {
         FS_HIP(hipEventRecord(ev_[1], st_));
         stats_.graph_launches = (uint64_t)L;
         stats_.kernels_per_frame = (uint64_t)(a_.n_layer * 5 + 2 + (use_persist_ ? 1 : a_.num_codebooks * (a_.n_fast_layer * 4 + 2)));
-        // decode: one graph replay per frame; the host only peeks at the done flag every CHUNK frames
+        // decode: one graph replay per frame, enqueued in batches of CHUNK.  Behind every batch the stream copies the generator state
+        // and the batch's code columns into pinned memory and records an event; the host looks at batch b (done flag, frame callback)
+        // while batch b + 1 is already running, so the GPU never waits for the host between batches
         const int CHUNK = cb ? 8 : 32;
         long long it = 1;
         size_t delivered = 0;
-        bool stop = false;
-        SeqState* hs = reinterpret_cast<SeqState*>(h_pin_);
-        auto poll = [&]() {
-            FS_HIP(hipMemcpyAsync(hs, state(0), sizeof(SeqState), hipMemcpyDeviceToHost, st_));
-            FS_HIP(hipStreamSynchronize(st_));
+        bool stop = false, ended = false;
+        SeqState* hs = reinterpret_cast<SeqState*>(h_pin_);  // final state (after the loop)
+        auto slot_state = [&](int sl) { return reinterpret_cast<SeqState*>((char*)h_pin_ + 256 + 256 * sl); };
+        auto slot_codes = [&](int sl) { return reinterpret_cast<uint32_t*>((char*)h_pin_ + 1024 + 1024 * sl); };  // [C][CHUNK]
+        static_assert(sizeof(SeqState) <= 256, "pinned slot size");
+        struct Batch { long long first, end; int slot; };
+        auto enqueue_batch = [&](int sl) {
+            Batch b{it, std::min<long long>(n_iter, it + CHUNK), sl};
+            for (; it < b.end; ++it) { launch_frame(it); stats_.graph_launches += 1; }
+            FS_HIP(hipMemcpyAsync(slot_state(sl), state(0), sizeof(SeqState), hipMemcpyDeviceToHost, st_));
+            if (cb)  // columns [first, end) of every codebook row (frame index == iteration index until <|im_end|>)
+                FS_HIP(hipMemcpy2DAsync(slot_codes(sl), sizeof(uint32_t) * CHUNK, d_out_.as<uint32_t>() + b.first, sizeof(uint32_t) * out_cap_,
+                                        sizeof(uint32_t) * (size_t)(b.end - b.first), (size_t)C, hipMemcpyDeviceToHost, st_));
+            FS_HIP(hipEventRecord(ev_batch_[sl], st_));
+            return b;
+        };
+        auto retire_batch = [&](const Batch& b) {  // true when the generator has terminated or the callback asked to stop
+            FS_HIP(hipEventSynchronize(ev_batch_[b.slot]));
+            const SeqState* s2 = slot_state(b.slot);
             if (cb) {
-                const size_t n = (size_t)hs->n_out;
-                if (n > delivered) {
-                    std::vector<uint32_t> tmp((size_t)C * out_cap_);
-                    // column block [delivered, n) of every row: one strided copy
-                    FS_HIP(hipMemcpy2D(tmp.data() + delivered, sizeof(uint32_t) * out_cap_, d_out_.as<uint32_t>() + delivered,
-                                       sizeof(uint32_t) * out_cap_, sizeof(uint32_t) * (n - delivered), (size_t)C, hipMemcpyDeviceToHost));
-                    std::vector<uint32_t> fr(C);
-                    for (size_t f = delivered; f < n && !stop; ++f) {
-                        for (int c = 0; c < C; ++c) fr[c] = tmp[(size_t)c * out_cap_ + f];
-                        if (cb(cb_user, f, fr.data())) stop = true;
-                    }
-                    delivered = n;
+                const size_t n = std::min<size_t>((size_t)s2->n_out, (size_t)b.end);
+                std::vector<uint32_t> fr(C);
+                for (size_t f = std::max<size_t>(delivered, (size_t)b.first); f < n && !stop; ++f) {
+                    for (int c = 0; c < C; ++c) fr[c] = slot_codes(b.slot)[(size_t)c * CHUNK + (f - (size_t)b.first)];
+                    if (cb(cb_user, f, fr.data())) stop = true;
+                    delivered = f + 1;
                 }
             }
-            return hs->done != 0;
+            if (s2->done != 0) ended = true;
+            return ended || stop;
         };
-        while (it < n_iter && !stop) {
-            const long long end = std::min<long long>(n_iter, it + CHUNK);
-            for (; it < end; ++it) { launch_frame(it); stats_.graph_launches += 1; }
-            if (it < n_iter || cb) { if (poll()) break; }
+        if (cb) {  // frame 0 (produced by the prefill iteration) is delivered before the decode batches
+            FS_HIP(hipMemcpyAsync(slot_state(0), state(0), sizeof(SeqState), hipMemcpyDeviceToHost, st_));
+            FS_HIP(hipMemcpy2DAsync(slot_codes(0), sizeof(uint32_t) * CHUNK, d_out_.as<uint32_t>(), sizeof(uint32_t) * out_cap_, sizeof(uint32_t), (size_t)C,
+                                    hipMemcpyDeviceToHost, st_));
+            FS_HIP(hipEventRecord(ev_batch_[0], st_));
+            retire_batch(Batch{0, 1, 0});
+        }
+        {
+            Batch prev{0, 0, 0};
+            bool have_prev = false;
+            int sl = cb ? 1 : 0;
+            while (it < n_iter && !(ended || stop)) {
+                const Batch cur = enqueue_batch(sl);
+                sl ^= 1;
+                if (have_prev) retire_batch(prev);  // batch b is examined while batch b + 1 runs
+                prev = cur;
+                have_prev = true;
+            }
+            if (have_prev && !(stop)) retire_batch(prev);
         }
         FS_HIP(hipEventRecord(ev_[2], st_));
         FS_HIP(hipMemcpyAsync(hs, state(0), sizeof(SeqState), hipMemcpyDeviceToHost, st_));
         FS_HIP(hipStreamSynchronize(st_));
-        if (cb && !stop) poll();
         const size_t n = (size_t)hs->n_out;
         seq_len_[0] = hs->pos;
         float ms01 = 0, ms12 = 0;
@@ -1143,6 +1170,7 @@ class LM final : public LMBase {
     void* h_pin_ = nullptr;
     hipGraphExec_t g_frame_ = nullptr, g_step_ = nullptr;
     hipEvent_t ev_[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_batch_[2] = {nullptr, nullptr};  // decode batches in flight (generate)
     fs_gen_stats stats_ = {};
 };
 

@@ -56,3 +56,4 @@ class FireflyCodec:
         _ffi.check(_ffi.lib().fs_codec_encode(self._h, pcm.ctypes.data_as(C.POINTER(C.c_float)), int(pcm.size),
                                               codes.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_size_t(cap), C.byref(n)))
         return codes[None, :, : n.value].copy()
+

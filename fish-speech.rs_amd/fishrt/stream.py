@@ -25,54 +25,76 @@ def decode_chunk(codec, codes, a, b, halo=HALO):
 
 
 class StreamingSynth:
-    """generate_blocking + FireflyCodec.decode with the vocoder running in a worker thread on its own HIP stream."""
+    """generate_blocking + FireflyCodec.decode with the vocoder running in a worker thread on its own HIP stream.
 
-    def __init__(self, lm, codec, chunk=64, halo=HALO):
-        self.lm, self.codec, self.chunk, self.halo = lm, codec, chunk, halo
+    chunk: frames per vocoder call once the stream is under way; first_chunk: size of the first call (time to first audio).  Every call
+    re-decodes `halo` frames of left context (all convolutions are causal), so larger steady-state chunks cost less: 24 / 64 = 37 % extra
+    vocoder work at chunk 64, 9 % at 256.  The codes live in one preallocated (C, cap) array that the frame callback fills column by
+    column (no per-chunk rebuild).  stats: frames, lm_s, vocoder_busy_s, total_s, overlap_efficiency, first_audio_s (time from the call
+    to the first PCM chunk)."""
+
+    def __init__(self, lm, codec, chunk=256, halo=HALO, first_chunk=32):
+        self.lm, self.codec, self.chunk, self.halo, self.first_chunk = lm, codec, chunk, halo, min(first_chunk, chunk)
 
     def __call__(self, prompt, max_new_tokens, **gen_kw):
         Cb = self.lm.cfg["num_codebooks"]
-        frames, q, pcm_parts = [], queue.Queue(), []
-        t_busy = [0.0]
+        cap = max(1, max_new_tokens - np.asarray(prompt).shape[1] + 2) + 1
+        codes = np.zeros((Cb, cap), np.uint32)
+        n_frames = [0]
+        q, pcm_parts, errors = queue.Queue(), [], []
+        t_busy, t_first = [0.0], [None]
+        t0 = time.perf_counter()
+
+        def vocode(a, b):
+            t1 = time.perf_counter()
+            pcm_parts.append(decode_chunk(self.codec, codes, a, b, self.halo))
+            t_busy[0] += time.perf_counter() - t1
+            if t_first[0] is None:
+                t_first[0] = time.perf_counter() - t0
 
         def worker():
-            done_upto = 0
-            while True:
-                item = q.get()
-                if item is None:
-                    break
-                n = item
-                # vocode every complete chunk available so far
-                while done_upto + self.chunk <= n:
-                    codes = np.array(frames[: done_upto + self.chunk], np.uint32).T
-                    t0 = time.perf_counter()
-                    pcm_parts.append(decode_chunk(self.codec, codes, done_upto, done_upto + self.chunk, self.halo))
-                    t_busy[0] += time.perf_counter() - t0
-                    done_upto += self.chunk
-            n = len(frames)
-            if n > done_upto:  # tail
-                codes = np.array(frames, np.uint32).T
-                t0 = time.perf_counter()
-                pcm_parts.append(decode_chunk(self.codec, codes, done_upto, n, self.halo))
-                t_busy[0] += time.perf_counter() - t0
+            try:
+                done_upto = 0
+                while True:
+                    n = q.get()
+                    final = n is None
+                    if final:
+                        n = n_frames[0]
+                    while True:  # vocode every complete chunk available so far (the first one is shorter)
+                        step = self.first_chunk if done_upto == 0 else self.chunk
+                        if done_upto + step > n:
+                            break
+                        vocode(done_upto, done_upto + step)
+                        done_upto += step
+                    if final:
+                        if n > done_upto:
+                            vocode(done_upto, n)  # tail
+                        return
+            except BaseException as e:  # surfaced by the caller after join
+                errors.append(e)
 
-        th = threading.Thread(target=worker)
+        th = threading.Thread(target=worker, daemon=True)
         th.start()
 
-        def on_frame(idx, codes):
-            frames.append(list(codes))
-            if len(frames) % self.chunk == 0:
-                q.put(len(frames))
-            return False
+        def on_frame(idx, fr):
+            codes[:, idx] = fr
+            n_frames[0] = idx + 1
+            done = idx + 1
+            if done == self.first_chunk or (done > self.first_chunk and (done - self.first_chunk) % self.chunk == 0):
+                q.put(done)
+            return bool(errors)  # stop generating if the vocoder thread died
 
-        t0 = time.perf_counter()
-        out = self.lm.generate_blocking(prompt, max_new_tokens, on_frame=on_frame, **gen_kw)
-        t_lm = time.perf_counter() - t0
-        q.put(None)
-        th.join()
+        try:
+            out = self.lm.generate_blocking(prompt, max_new_tokens, on_frame=on_frame, **gen_kw)
+            t_lm = time.perf_counter() - t0
+        finally:
+            q.put(None)  # the worker always gets its sentinel, also when generate_blocking raises
+            th.join()
+        if errors:
+            raise errors[0]
         t_all = time.perf_counter() - t0
-        assert out.shape[1] == len(frames) and Cb == out.shape[0]
+        assert out.shape[1] == n_frames[0] and Cb == out.shape[0] and np.array_equal(out, codes[:, : n_frames[0]])
         pcm = np.concatenate(pcm_parts) if pcm_parts else np.zeros(0, np.float32)
-        self.stats = dict(frames=len(frames), lm_s=t_lm, vocoder_busy_s=t_busy[0], total_s=t_all,
+        self.stats = dict(frames=n_frames[0], lm_s=t_lm, vocoder_busy_s=t_busy[0], total_s=t_all, first_audio_s=t_first[0],
                           overlap_efficiency=(t_lm + t_busy[0] - t_all) / max(t_busy[0], 1e-9))
         return out, pcm

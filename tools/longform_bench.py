@@ -1,6 +1,7 @@
 """BASELINE.json configs[4]: Fish-1.4 shapes (V = 32000, single <|semantic|> id, legacy 2-way slow sampler),
 one stream of 4096 frames (KV grows to 4096 + L; RoPE table 8192 -- the reference would fail past its max_seq_len 4096,
-dual_ar.rs:179,623), Firefly vocoder on a second stream consuming 64-frame chunks (+24-frame halo) while the LM continues.
+dual_ar.rs:179,623), Firefly vocoder on a second stream consuming a 32-frame first chunk, then 256-frame chunks (+24-frame halo) while the
+LM continues.
 Reports LM-only RTF, end-to-end RTF and overlap efficiency.  usage: longform_bench.py [frames] [fp8|bf16] (configs[4] names
 fp8-e4m3 weights; bf16 is the comparison run)."""
 import sys, time
@@ -25,10 +26,10 @@ for rep in range(2):
     t = time.perf_counter(); codes = lm.generate_blocking(p, M, **kw); t_lm = time.perf_counter() - t
     t = time.perf_counter(); pcm = Clamp(codec).decode(np.ascontiguousarray(codes[None])); t_voc = time.perf_counter() - t
     lm.clear_slow_layer_caches()
-    synth = fishrt.StreamingSynth(lm, Clamp(codec), chunk=64)
+    synth = fishrt.StreamingSynth(lm, Clamp(codec), chunk=256, first_chunk=32)
     c2, pcm2 = synth(p, M, **kw)
     st = synth.stats
     audio_s = frames / 21.535
     print(f"[{dtype}] frames={codes.shape[1]}: LM alone {t_lm:.3f}s (RTF {audio_s/t_lm:.1f}), vocoder alone (one shot) {t_voc:.3f}s, sequential {t_lm+t_voc:.3f}s | "
           f"overlapped total {st['total_s']:.3f}s (RTF {audio_s/st['total_s']:.1f}), vocoder busy {st['vocoder_busy_s']:.3f}s, "
-          f"overlap efficiency {st['overlap_efficiency']:.2f}, same codes {np.array_equal(codes, c2)}, pcm identical {np.array_equal(pcm[0,0], pcm2)}")
+          f"first audio after {st['first_audio_s'] * 1e3:.0f} ms, overlap efficiency {st['overlap_efficiency']:.2f}, same codes {np.array_equal(codes, c2)}, pcm identical {np.array_equal(pcm[0,0], pcm2)}")

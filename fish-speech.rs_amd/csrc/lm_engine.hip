@@ -338,10 +338,11 @@ class LM final : public LMBase {
         // greedy decoding on a Fish-geometry bf16 handle: the 8 fast-decoder passes of a frame run as ONE persistent launch
         // (lm_persist.hip) instead of 144 graph nodes, if no other handle of this GPU is using it right now
         std::unique_lock<std::mutex> plock;
-        use_persist_ = false;
-        if (persist_ok_ && cfg.temp == 0.f && !(flags & FS_GEN_NO_PERSIST)) {
+        use_persist_ = use_pslow_ = false;
+        if ((persist_ok_ || pslow_ok_) && !(flags & FS_GEN_NO_PERSIST)) {
             plock = std::unique_lock<std::mutex>(persist_mutex(device_), std::try_to_lock);
-            use_persist_ = plock.owns_lock();
+            use_persist_ = plock.owns_lock() && persist_ok_ && cfg.temp == 0.f;  // the fast kernel decides greedily in-launch
+            use_pslow_ = plock.owns_lock() && pslow_ok_;                          // the slow kernel feeds any sampler
         }
         // generate_blocking_with_hidden: the slow sampler stores the hidden state of every iteration through this pointer cell
         if (hidden_out && !d_hidden_.p) d_hidden_.alloc(sizeof(float) * (size_t)out_cap_ * a_.dim);
@@ -373,7 +374,7 @@ class LM final : public LMBase {
         launch_frame(0);
         FS_HIP(hipEventRecord(ev_[1], st_));
         stats_.graph_launches = (uint64_t)L;
-        stats_.kernels_per_frame = (uint64_t)(a_.n_layer * 5 + 2 + (use_persist_ ? 1 : a_.num_codebooks * (a_.n_fast_layer * 4 + 2)));
+        stats_.kernels_per_frame = (uint64_t)((use_pslow_ ? 2 : a_.n_layer * 5 + 2) + (use_persist_ ? 1 : a_.num_codebooks * (a_.n_fast_layer * 4 + 2)));
         // decode: one graph replay per frame, enqueued in batches of CHUNK.  Behind every batch the stream copies the generator state
         // and the batch's code columns into pinned memory and records an event; the host looks at batch b (done flag, frame callback)
         // while batch b + 1 is already running, so the GPU never waits for the host between batches
@@ -448,6 +449,22 @@ class LM final : public LMBase {
             fprintf(stderr, "persist prof (us/frame, workgroup 0; wait+work): preload %.1f  S1 %.1f+%.1f  S2 %.1f+%.1f  S3 %.1f+%.1f  S4 %.1f+%.1f  head %.1f+%.1f  decision %.1f+%.1f  tail %.1f\n",
                     pr[0] * f, pr[9] * f, pr[1] * f, pr[10] * f, pr[2] * f, pr[11] * f, pr[3] * f, pr[12] * f, pr[4] * f, pr[13] * f, pr[5] * f, pr[14] * f, pr[6] * f, pr[7] * f);
         }
+        if (use_pslow_) {
+            if (getenv("FISHRT_PERSIST_PROF")) {
+                unsigned long long pr[8];
+                FS_HIP(hipMemcpy(pr, d_sctl_.as<uint32_t>() + 16, sizeof(pr), hipMemcpyDeviceToHost));
+                FS_HIP(hipMemset(d_sctl_.as<uint32_t>() + 16, 0, sizeof(pr)));
+                const double f = 0.01 / std::max<double>(1.0, (double)stats_.graph_launches - (double)L + 1);
+                fprintf(stderr, "slow persist prof (us/frame, workgroup 0): S1 %.1f  S2 %.1f  S3 %.1f  S4 %.1f  S5 %.1f  head %.1f\n", pr[1] * f, pr[2] * f, pr[3] * f,
+                        pr[4] * f, pr[5] * f, pr[6] * f);
+            }
+            uint32_t ctl[4] = {0, 0, 0, 0};
+            FS_HIP(hipMemcpy(ctl, d_sctl_.p, sizeof(ctl), hipMemcpyDeviceToHost));
+            if (ctl[1]) {
+                FS_HIP(hipMemset(d_sctl_.as<uint32_t>() + 1, 0, 4));
+                throw Error("persistent slow-transformer kernel: a grid-wide wait timed out (are all 256 CUs available to this process?)");
+            }
+        }
         if (use_persist_) {
             uint32_t ctl[4] = {0, 0, 0, 0};
             FS_HIP(hipMemcpy(ctl, d_ctl_.p, sizeof(ctl), hipMemcpyDeviceToHost));
@@ -517,10 +534,11 @@ class LM final : public LMBase {
         // greedy decoding on a Fish-geometry bf16 handle: the 8 fast-decoder passes of a frame run as ONE persistent launch
         // (lm_persist.hip) instead of 144 graph nodes, if no other handle of this GPU is using it right now
         std::unique_lock<std::mutex> plock;
-        use_persist_ = false;
-        if (persist_ok_ && cfg.temp == 0.f && !(flags & FS_GEN_NO_PERSIST)) {
+        use_persist_ = use_pslow_ = false;
+        if ((persist_ok_ || pslow_ok_) && !(flags & FS_GEN_NO_PERSIST)) {
             plock = std::unique_lock<std::mutex>(persist_mutex(device_), std::try_to_lock);
-            use_persist_ = plock.owns_lock();
+            use_persist_ = plock.owns_lock() && persist_ok_ && cfg.temp == 0.f;  // the fast kernel decides greedily in-launch
+            use_pslow_ = plock.owns_lock() && pslow_ok_;                          // the slow kernel feeds any sampler
         }
         RngState rng = {};
         seed_key(seed, rng.key);  // BatchedLogitsProcessor::new(seed) (the reference passes 42, static_batch.rs:63)
@@ -1032,7 +1050,39 @@ class LM final : public LMBase {
             launch_fast_persist_pack(fast_.data(), fast_out_w_, d_pack_.p, st_);
             FS_HIP(hipStreamSynchronize(st_));
             persist_ok_ = true;
+            // slow transformer: same geometry, the audio-range head must fit 8 rows per workgroup
+            pslow_ok_ = false;
+            if (getenv("FISHRT_NO_PERSIST_SLOW") || n_audio_ > 8 * PF_BLOCKS) return;
+            if (!d_spack_.p) {
+                d_spack_.alloc(slow_persist_pack_bytes(a_.n_layer));
+                d_hpack_.alloc((size_t)PF_BLOCKS * PS_HEAD_IMAGE);
+                d_snorms_.alloc(sizeof(float) * (size_t)(2 * a_.n_layer + 1) * a_.dim);
+                d_sedges_.alloc(slow_persist_edge_bytes());
+                FS_HIP(hipMemset(d_sedges_.p, 0, d_sedges_.n));
+                d_sctl_.alloc(256);
+                FS_HIP(hipMemset(d_sctl_.p, 0, d_sctl_.n));
+            }
+            std::vector<const float*> np;
+            for (int l = 0; l < a_.n_layer; ++l) { np.push_back(slow_[l].attn_norm); np.push_back(slow_[l].ffn_norm); }
+            np.push_back(norm_w_);
+            launch_slow_persist_pack(slow_.data(), a_.n_layer, slow_head_w(), n_audio_, np.data(), d_spack_.p, d_hpack_.p, d_snorms_.as<float>(), st_);
+            FS_HIP(hipStreamSynchronize(st_));
+            pslow_ok_ = true;
         }
+    }
+    SlowPersistArgs pslow_args() {
+        SlowPersistArgs A = {};
+        A.wpack = d_spack_.p; A.hpack = d_hpack_.p; A.norms = d_snorms_.as<float>();
+        A.n_layer = a_.n_layer; A.n_head_rows = n_audio_;
+        A.cos_t = d_cos_.as<float>(); A.sin_t = d_sin_.as<float>(); A.eps = d_.eps;
+        A.x = x(0); A.logits = d_logits_slow_.as<float>(); A.state = state(0);
+        A.kv_pool = kv_pool_.p; A.layer_half = (size_t)n_pages_ * page_elems_;
+        A.page_table = d_page_table_.as<int>();
+        A.n_sl = std::min(nc_launch_, 16);
+        A.edges = d_sedges_.as<unsigned long long>();
+        A.ctl = d_sctl_.as<uint32_t>();
+        A.prof = getenv("FISHRT_PERSIST_PROF") ? reinterpret_cast<unsigned long long*>(d_sctl_.as<uint32_t>() + 16) : nullptr;
+        return A;
     }
     FastPersistArgs persist_args() {
         FastPersistArgs A = {};
@@ -1084,7 +1134,7 @@ class LM final : public LMBase {
     void set_bucket(int T) { nc_launch_ = chunk_bucket(T); }
     // graphs for the bucket currently in nc_launch_ (captured on first use)
     void use_graphs_for_bucket() {
-        const int key = nc_launch_ * 2 + (use_persist_ ? 1 : 0);
+        const int key = nc_launch_ * 4 + (use_persist_ ? 2 : 0) + (use_pslow_ ? 1 : 0);
         auto it = graphs_.find(key);
         if (it == graphs_.end()) {
             g_frame_ = nullptr; g_step_ = nullptr;
@@ -1109,9 +1159,12 @@ class LM final : public LMBase {
         FS_HIP(hipGraphDestroy(g));
         // (2) one audio frame: x holds the embedded input of position state->pos
         FS_HIP(hipStreamBeginCapture(st_, hipStreamCaptureModeThreadLocal));
+        if (use_pslow_) launch_slow_persist(pslow_args(), st_);  // 24 blocks + head as ONE persistent launch (lm_persist_slow.hip)
+        else {
         enqueue_slow_layers(0);
         // audio-range head: rows [im_end, V) only (constrain_probs_to_audio, utils.rs:13-16)
         LmKernels<WT>::head(d_, x(0), norm_w_, slow_head_w(), slow_head_s(), n_audio_, d_logits_slow_.as<float>(), st_);
+        }
         SampleKernels<WT>::sample_slow(d_, d_logits_slow_.as<float>(), n_audio_, d_cfg_.as<SampleCfg>(), d_rng_.as<RngState>(), state(0),
                                        x(0), xf(0), st_, d_hid_slot_.as<float*>());
         if (use_persist_) launch_fast_persist(persist_args(), st_);
@@ -1159,7 +1212,8 @@ class LM final : public LMBase {
     DevBuf d_rp_mask_, d_rp_seen_, d_rp_ring_, d_rp_meta_;
     DevBuf d_pack_, d_edges_, d_ctl_;  // persistent fast decoder
     DevBuf d_hidden_, d_hid_slot_;     // generate_blocking_with_hidden: [out_cap][dim] rows + the pointer cell the captured graphs read
-    bool persist_ok_ = false, use_persist_ = false;
+    bool persist_ok_ = false, use_persist_ = false, pslow_ok_ = false, use_pslow_ = false;
+    DevBuf d_spack_, d_hpack_, d_snorms_, d_sedges_, d_sctl_;  // persistent slow transformer
     DevBuf d_pfx_, d_pfq_, d_pfslab_, d_pfa_, d_pfa2_, d_pfss_, d_pfc_, d_pfpart_;  // MFMA row-path activations (kRowsCap rows)
     DevBuf d_bprompt_;  // static batch: all left-padded prompts [B][C + 1][Lmax] (group prefill)
     DevBuf d_xfrows_, d_lrows_, d_lfast_, d_fast_state_, d_fast_table_;  // static-batch generator

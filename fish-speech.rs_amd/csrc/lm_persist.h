@@ -49,6 +49,36 @@ struct FastPersistArgs {
     uint32_t* ctl;              // [0] launch counter (tag epoch), [1] spin-timeout count (host checks it), [2] launches with temp != 0 (refused)
 };
 
+// ---- persistent slow-transformer kernel (lm_persist_slow.hip): one launch = the 24 blocks + the audio-range head of one decode step
+constexpr int PS_EDGE_CAP = 16 * 16 * 66 + 64;  // largest edge: attention partials of 16 heads x 16 token slices x {o[64], m, l}
+constexpr size_t PS_LAYER_IMAGE = 116736;        // bytes per (layer, workgroup): Wqkv 5 rows, Wo 4, W13 32, W2 4 rows x 4096
+constexpr size_t PS_HEAD_IMAGE = 16384;          // bytes per workgroup: 8 head rows
+
+struct SlowPersistArgs {
+    const void* wpack;      // [n_layer][PF_BLOCKS][PS_LAYER_IMAGE] per-lane weight images (launch_slow_persist_pack)
+    const void* hpack;      // [PF_BLOCKS][PS_HEAD_IMAGE] head rows [8b, 8b+8) (zero beyond n_head_rows)
+    const float* norms;     // [2 * n_layer + 1][1024] f32: attention_norm l, ffn_norm l, ..., norm
+    int n_layer, n_head_rows;
+    const float* cos_t;     // [max_seq_len][32]
+    const float* sin_t;
+    float eps;
+    float* x;               // [1024] in: embedded input of this position; out: pre-norm hidden state (forward_generate's `hidden`)
+    float* logits;          // [n_head_rows] out
+    const SeqState* state;  // pos (KV length), rope_off, done
+    void* kv_pool;          // bf16; layer l: K pool at l * 2 * layer_half, V pool at + layer_half (elements)
+    size_t layer_half;      // n_pages * page_elems
+    const int* page_table;
+    int n_sl;               // token slices per head of the attention stage (1, 2, 4, 8 or 16)
+    unsigned long long* edges;  // [PF_RING][PF_REPL][PS_EDGE_CAP]
+    unsigned long long* prof;
+    uint32_t* ctl;          // [0] epoch, [1] timeouts
+};
+size_t slow_persist_pack_bytes(int n_layer);
+size_t slow_persist_edge_bytes();
+void launch_slow_persist_pack(const LayerW* layers, int n_layer, const void* head_w, int n_head_rows, const float* const* norm_ptrs,
+                              void* wpack, void* hpack, float* norms_flat, hipStream_t st);
+void launch_slow_persist(const SlowPersistArgs& a, hipStream_t st);
+
 // true when the model has the geometry the kernel is written for
 bool fast_persist_supported(const ModelDims& d, int n_fast_layer, int n_cb, int cb_size);
 size_t fast_persist_pack_bytes();

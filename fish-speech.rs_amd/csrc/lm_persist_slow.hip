@@ -1,0 +1,554 @@
+// Persistent slow-transformer kernel: one launch = DualARTransformer::forward_generate for ONE new token at batch 1 (24 blocks over
+// the paged KV cache + final norm + audio-range head), 256 workgroups x 512 threads, every workgroup co-resident.
+//
+// Reference semantics (same arithmetic as the per-node kernels of lm_kernels.hip, other summation order):
+//   forward_generate   fish_speech_core/lib/lm/dual_ar.rs:574-635 (L == 1: no mask, :360)
+//   Attention::forward dual_ar.rs:281-384 (interleaved RoPE on q / k, scale on K, K/V appended to the cache, GQA by head index)
+//   FeedForward        dual_ar.rs:160-165;  TransformerBlock :429-440;  constrain_probs_to_audio generate/utils.rs:13-16
+//
+// Unlike the fast decoder (lm_persist.hip) the 717 MB of slow weights cannot stay on chip: every stage's weight slice (its
+// workgroup's rows, 8-64 KB per CU) is requested into VGPRs ONE STAGE AHEAD, right after the current stage's sweep has completed, so
+// the HBM stream of stage s+1 runs under stage s's arithmetic, publish and the propagation of its edge; a CU's loads return in issue
+// order, so the sweep of stage s+1 simply completes when both the weights and the edge are there.
+//
+// Stages per block (edges are all-gathers of 8-byte {value, tag} granules, see lm_persist_dev.h):
+//   S1  (gather x) -> RMSNorm folded -> Wqkv rows [5b, 5b+5)                                  -> 1280 granules
+//   S2  attention: workgroup (h, s) = (b / n_sl, b % n_sl), b < 16 n_sl, owns query head h over token slice s of the cache (K/V tile
+//       prefetched during S1; the new token's k / v come from the qkv edge and are appended to the cache by the workgroup of the
+//       last slice of heads 0 and 8) -> un-normalised partial {o[64], m, l} per (head, slice)   -> 16 n_sl 66 granules
+//   S3  every workgroup merges the slices of all heads (flash-decoding combine), Wo rows [4b, 4b+4) + residual -> 1024 granules
+//   S4  gather h -> RMSNorm folded -> 16 SwiGLU pairs of W13                                   -> 4096 granules
+//   S5  gather the activations -> W2 rows [4b, 4b+4) + residual                                 -> 1024 granules
+//   head: gather x (= the pre-norm hidden state, also written to A.x) -> norm folded -> head rows [8b, 8b+8) -> A.logits (plain stores)
+#include "lm_persist.h"
+
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "fs_common.h"
+
+namespace fs {
+
+namespace {
+
+#include "lm_persist_dev.h"
+
+constexpr int PS_DROR8 = 0x128;  // DPP row_ror:8 -- lane l <- lane l ^ 8 inside a row of 16
+
+// byte offsets inside a (layer, workgroup) weight image; every region is [chunk][512 lanes] x 16 B (B: x 4 B)
+constexpr size_t IM_QKV4 = 0, IM_QKV1 = 8192, IM_WO = 10240, IM_W13 = 18432, IM_W2 = 83968;
+static_assert(IM_W2 + 4 * 8192 == PS_LAYER_IMAGE, "image layout");
+
+// LDS carve
+constexpr int S_XS = 0;                       // residual stream copy f32 [1024]
+constexpr int S_RED = S_XS + 4096;            // [2][8][PS_RED] row partials
+constexpr int PS_RED = 40;
+constexpr int S_QS = S_RED + 2 * 8 * PS_RED * 4;   // rope'd, pre-scaled q of this workgroup's head, f32 [64]
+constexpr int S_KN = S_QS + 256;              // new token's k (rope'd, bf16-rounded) f32 [64]
+constexpr int S_VN = S_KN + 256;              // new token's v (bf16-rounded) f32 [64]
+constexpr int S_PART = S_VN + 256;            // [8 waves][72]: o[64], l
+constexpr int S_WMAX = S_PART + 8 * 72 * 4;   // [8] wave maxima + [1] block max
+constexpr int S_PAGES = S_WMAX + 64;          // page ids of this workgroup's token slice, int [160]
+constexpr int S_END = S_PAGES + 160 * 4;
+constexpr int PS_LDS = 96 * 1024;             // requested size: > half of the CU's LDS, so the 256 workgroups sit on 256 different CUs
+static_assert(S_END <= PS_LDS, "LDS budget");
+
+// up to 8 units (16 B = 2 granules each) per lane, all in flight; units >= n are not loaded
+__device__ __forceinline__ void pf_sweep8u(const u64* base, const int (&unit)[8], int n, unsigned tag, u32x4 (&v)[8], bool& dead, uint32_t* ctl) {
+    const u64* p[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) p[i] = base + 2 * (size_t)unit[i < n ? i : 0];
+    for (unsigned spins = 0;; ++spins) {
+        asm volatile(
+            "global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %9, off sc1\n\tglobal_load_dwordx4 %2, %10, off sc1\n\t"
+            "global_load_dwordx4 %3, %11, off sc1\n\tglobal_load_dwordx4 %4, %12, off sc1\n\tglobal_load_dwordx4 %5, %13, off sc1\n\t"
+            "global_load_dwordx4 %6, %14, off sc1\n\tglobal_load_dwordx4 %7, %15, off sc1\n\ts_waitcnt vmcnt(0)"
+            : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+            : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7])
+            : "memory");
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ok &= pf_tags_ok(v[i], tag);
+        if (ok || dead) return;
+        if (spins > PF_SPIN_MAX) { dead = true; atomicAdd(ctl + 1, 1u); return; }
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ weight images
+__global__ __launch_bounds__(PF_THREADS) void k_ps_pack_layer(LayerW w, unsigned char* __restrict__ image /*[PF_BLOCKS][PS_LAYER_IMAGE]*/) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    unsigned char* im = image + (size_t)b * PS_LAYER_IMAGE;
+    const uint32_t* Wq = reinterpret_cast<const uint32_t*>(w.wqkv);
+    const uint32_t* Wo = reinterpret_cast<const uint32_t*>(w.wo);
+    const uint32_t* W13 = reinterpret_cast<const uint32_t*>(w.w13);
+    const uint32_t* W2 = reinterpret_cast<const uint32_t*>(w.w2);
+    u32x4 v;
+    for (int r = 0; r < 4; ++r) v[r] = Wq[(size_t)(5 * b + r) * 512 + t];
+    reinterpret_cast<u32x4*>(im + IM_QKV4)[t] = v;
+    reinterpret_cast<uint32_t*>(im + IM_QKV1)[t] = Wq[(size_t)(5 * b + 4) * 512 + t];
+    for (int r = 0; r < 4; ++r) v[r] = Wo[(size_t)(4 * b + r) * 512 + t];
+    reinterpret_cast<u32x4*>(im + IM_WO)[t] = v;
+    for (int c = 0; c < 8; ++c) {
+        for (int r = 0; r < 4; ++r) v[r] = W13[(size_t)(32 * b + 4 * c + r) * 512 + t];
+        reinterpret_cast<u32x4*>(im + IM_W13)[c * PF_THREADS + t] = v;
+    }
+    for (int q = 0; q < 4; ++q) {
+        for (int r = 0; r < 4; ++r) v[r] = W2[(size_t)(4 * b + r) * 2048 + 512 * q + t];
+        reinterpret_cast<u32x4*>(im + IM_W2)[q * PF_THREADS + t] = v;
+    }
+}
+__global__ __launch_bounds__(PF_THREADS) void k_ps_pack_head(const uint32_t* __restrict__ W, int n_rows, unsigned char* __restrict__ image) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    for (int c = 0; c < 2; ++c) {
+        u32x4 v;
+        for (int r = 0; r < 4; ++r) { const int row = 8 * b + 4 * c + r; v[r] = row < n_rows ? W[(size_t)row * 512 + t] : 0u; }
+        reinterpret_cast<u32x4*>(image + (size_t)b * PS_HEAD_IMAGE)[c * PF_THREADS + t] = v;
+    }
+}
+__global__ void k_ps_copy_norm(const float* __restrict__ src, float* __restrict__ dst) { dst[blockIdx.x * 256 + threadIdx.x] = src[blockIdx.x * 256 + threadIdx.x]; }
+
+// ------------------------------------------------------------------------------------------------ the step kernel
+__global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* xs = reinterpret_cast<float*>(smem + S_XS);
+    float* red = reinterpret_cast<float*>(smem + S_RED);
+    float* qs = reinterpret_cast<float*>(smem + S_QS);
+    float* knew = reinterpret_cast<float*>(smem + S_KN);
+    float* vnew = reinterpret_cast<float*>(smem + S_VN);
+    float* part = reinterpret_cast<float*>(smem + S_PART);
+    float* wmax = reinterpret_cast<float*>(smem + S_WMAX);
+    int* s_pages = reinterpret_cast<int*>(smem + S_PAGES);
+
+    const int tid_k = threadIdx.x, b = blockIdx.x;
+    int tid = tid_k, lane = tid & 63, wave = tid >> 6;
+    const int rep = b & (PF_REPL - 1);
+    u64* const edges = A.edges;
+    const size_t ering = (size_t)PF_REPL * PS_EDGE_CAP;
+    const u64* const my_edges = A.edges + (size_t)rep * PS_EDGE_CAP;
+    auto pub = [&](unsigned e, int rr, int index, unsigned tag, float value) {
+        gu64* g = (gu64*)(edges + (size_t)(e & (PF_RING - 1)) * ering + (size_t)rr * PS_EDGE_CAP + index);
+        __hip_atomic_store(g, ((u64)tag << 32) | (u64)__float_as_uint(value), PF_RLX_AGENT);
+    };
+
+    if (A.state->done != 0) return;  // generator terminated: the slow sampler ignores the logits (k_sample_slow), replays leave the cache alone
+    const int pos = A.state->pos;             // cached tokens; the new token sits at index pos
+    const int rpos = pos + A.state->rope_off;
+    const unsigned epoch = A.ctl[0];
+    const unsigned tag0 = epoch * 256u;
+    // attention role
+    const int n_sl = A.n_sl;
+    const bool att = b < 16 * n_sl;
+    const int ah = att ? b / n_sl : 0, as = att ? b % n_sl : 0, ag = ah >> 3;
+    const int chunk_t = (pos + n_sl - 1) / n_sl;
+    const int t0 = min(pos, as * chunk_t), t1 = min(pos, (as + 1) * chunk_t);  // cached tokens [t0, t1) of this slice
+    const bool last_slice = att && as == n_sl - 1;                                // also covers the new token
+    const int n_tok = t1 - t0;
+    const int n_tiles = att ? max((n_tok + 127) / 128, last_slice ? 1 : 0) : 0;
+    if (att) {
+        const int p0 = t0 >> 6;
+        for (int i = tid; i < 160; i += PF_THREADS) s_pages[i] = (n_tok > 0 && p0 + i <= ((t1 - 1) >> 6)) ? A.page_table[p0 + i] : 0;
+    }
+    const int page_new = A.page_table[pos >> 6];
+    float2 x2 = *reinterpret_cast<const float2*>(A.x + 2 * tid);
+    float x0 = x2.x, x1 = x2.y;
+    __syncthreads();
+
+    const unsigned char* wimg = reinterpret_cast<const unsigned char*>(A.wpack) + (size_t)b * PS_LAYER_IMAGE;
+    const size_t layer_img = (size_t)PF_BLOCKS * PS_LAYER_IMAGE;
+    // weight registers, each filled one stage ahead
+    u32x4 wq4 = reinterpret_cast<const u32x4*>(wimg + IM_QKV4)[tid];
+    uint32_t wq1 = reinterpret_cast<const uint32_t*>(wimg + IM_QKV1)[tid];
+    u32x4 wo4, w13[8], w2r[4];
+    u32x4 kreg[2] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}}, vreg[2] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};  // zero unless this slice has cached tokens
+    bool dead = false;
+    unsigned e = 0;
+    int par = 0;
+    unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = A.prof ? wall_clock64() : 0;
+#define PS_TICK(k) do { if (A.prof) { const unsigned long long n_ = wall_clock64(); tk[k] += n_ - t_last; t_last = n_; } } while (0)
+
+    auto load_kv_tile = [&](int l, int tile) {  // 128 tokens x 64 dims of K and V of kv head ag: lane unit i = tid + 512 u -> token i >> 3, 16-B slice i & 7
+        const uint16_t* kpool = reinterpret_cast<const uint16_t*>(A.kv_pool) + (size_t)l * 2 * A.layer_half;
+        const uint16_t* vpool = kpool + A.layer_half;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + PF_THREADS * u;
+            const int t = min(t0 + tile * 128 + (i >> 3), max(t1 - 1, t0));  // clamped: rows past the slice are masked at use
+            const int pg = s_pages[(t >> 6) - (t0 >> 6)];
+            const size_t off = ((size_t)(pg * 2 + ag) * KV_PAGE + (t & 63)) * 64 + (size_t)(i & 7) * 8;
+            kreg[u] = *reinterpret_cast<const u32x4*>(kpool + off);
+            vreg[u] = *reinterpret_cast<const u32x4*>(vpool + off);
+        }
+    };
+
+#pragma unroll 1
+    for (int l = 0; l < A.n_layer; ++l) {
+        const unsigned char* wl = wimg + (size_t)l * layer_img;
+        // ================= S1
+        {
+            tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
+            const float2 nw = *reinterpret_cast<const float2*>(A.norms + (size_t)(2 * l) * 1024 + 2 * tid);
+            if (l > 0) {
+                u32x4 v;
+                pf_sweep1(my_edges + (size_t)(e & 3) * ering, tid, tag0 + e + 1, v, dead, A.ctl);
+                x0 = __uint_as_float(v.x); x1 = __uint_as_float(v.z);
+                ++e;
+            }
+            if (att && n_tok > 0) load_kv_tile(l, 0);  // this layer's first K/V tile, under the qkv stage
+            *reinterpret_cast<float2*>(xs + 2 * tid) = make_float2(x0, x1);
+            const float xn0 = x0 * nw.x, xn1 = x1 * nw.y;
+            float a8[8];
+            a8[0] = pf_dot2(wq4.x, xn0, xn1, 0.f); a8[1] = pf_dot2(wq4.y, xn0, xn1, 0.f);
+            a8[2] = pf_dot2(wq4.z, xn0, xn1, 0.f); a8[3] = pf_dot2(wq4.w, xn0, xn1, 0.f);
+            a8[4] = pf_dot2(wq1, xn0, xn1, 0.f);
+            a8[5] = fmaf(x1, x1, fmaf(x0, x0, 0.f));
+            a8[6] = 0.f; a8[7] = 0.f;
+            const float r8 = pf_reduce<8>(a8, lane);
+            if ((lane & 7) == 0) red[(par * 8 + wave) * PS_RED + (lane >> 3)] = r8;
+            __syncthreads();
+            if (tid < 5 * PF_REPL) {
+                const int r = tid % 5, rr = tid / 5;
+                float t = red[(par * 8) * PS_RED + r], tot = red[(par * 8) * PS_RED + 5];
+#pragma unroll
+                for (int w = 1; w < 8; ++w) { t += red[(par * 8 + w) * PS_RED + r]; tot += red[(par * 8 + w) * PS_RED + 5]; }
+                pub(e, rr, 5 * b + r, tag0 + e + 1, t / sqrtf(tot / 1024.f + A.eps));
+            }
+            par ^= 1;
+            PS_TICK(1);
+        }
+        // ================= S2: attention of (head ah, slice as)
+        wo4 = reinterpret_cast<const u32x4*>(wl + IM_WO)[tid];  // next stage's weights
+        if (att) {
+            tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
+            const u64* eb = my_edges + (size_t)(e & 3) * ering;
+            if (tid < 96) {  // q of head ah (32 units), k / v of kv head ag (32 units each)
+                const int unit = tid < 32 ? 32 * ah + tid : (tid < 64 ? 512 + 32 * ag + (tid - 32) : 576 + 32 * ag + (tid - 64));
+                u32x4 v;
+                pf_sweep1(eb, unit, tag0 + e + 1, v, dead, A.ctl);
+                const float a0 = __uint_as_float(v.x), a1 = __uint_as_float(v.z);
+                const int j = tid & 31;
+                const float c = A.cos_t[(size_t)rpos * 32 + j], s = A.sin_t[(size_t)rpos * 32 + j];
+                if (tid < 32) {  // rope_i, then the 1/sqrt(64) of the scores folded into q (a power of two: exact)
+                    *reinterpret_cast<float2*>(qs + 2 * j) = make_float2((a0 * c - a1 * s) * 0.125f, (a0 * s + a1 * c) * 0.125f);
+                } else if (tid < 64) {
+                    const uint32_t k0 = f32_to_bf16_rne(a0 * c - a1 * s), k1 = f32_to_bf16_rne(a0 * s + a1 * c);
+                    *reinterpret_cast<float2*>(knew + 2 * j) = make_float2(bf_lo(k0), bf_lo(k1));
+                    if (last_slice && (ah & 7) == 0)  // append to the cache (dual_ar.rs:316-324) -- one writer per kv head
+                        reinterpret_cast<uint32_t*>(reinterpret_cast<uint16_t*>(A.kv_pool) + (size_t)l * 2 * A.layer_half +
+                                                    ((size_t)(page_new * 2 + ag) * KV_PAGE + (pos & 63)) * 64)[j] = k0 | (k1 << 16);
+                } else {
+                    const uint32_t v0 = f32_to_bf16_rne(a0), v1 = f32_to_bf16_rne(a1);
+                    *reinterpret_cast<float2*>(vnew + 2 * j) = make_float2(bf_lo(v0), bf_lo(v1));
+                    if (last_slice && (ah & 7) == 0)
+                        reinterpret_cast<uint32_t*>(reinterpret_cast<uint16_t*>(A.kv_pool) + (size_t)l * 2 * A.layer_half + A.layer_half +
+                                                    ((size_t)(page_new * 2 + ag) * KV_PAGE + (pos & 63)) * 64)[j] = v0 | (v1 << 16);
+                }
+            }
+            ++e;
+            __syncthreads();
+            // running {m, l, o[d]} of the slice, owned by threads d < 64 (o) -- every thread tracks m and l redundantly
+            float run_m = -1e30f, run_l = 0.f, run_o = 0.f;
+            const int du = tid & 7;
+            float qv[8];
+            {
+                const float4 q0 = *reinterpret_cast<const float4*>(qs + du * 8), q1 = *reinterpret_cast<const float4*>(qs + du * 8 + 4);
+                qv[0] = q0.x; qv[1] = q0.y; qv[2] = q0.z; qv[3] = q0.w; qv[4] = q1.x; qv[5] = q1.y; qv[6] = q1.z; qv[7] = q1.w;
+            }
+            for (int tile = 0; tile < n_tiles; ++tile) {
+                if (tile > 0) load_kv_tile(l, tile);
+                // scores of this lane's two tokens (8 lanes per token, 8 dims each)
+                float sc[3];
+                bool valid[3];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int t = t0 + tile * 128 + ((tid + PF_THREADS * u) >> 3);
+                    valid[u] = t < t1;
+                    const u32x4 kk = kreg[u];
+                    float a = 0.f;
+                    a = fmaf(qv[0], bf_lo(kk.x), a); a = fmaf(qv[1], bf_hi(kk.x), a); a = fmaf(qv[2], bf_lo(kk.y), a); a = fmaf(qv[3], bf_hi(kk.y), a);
+                    a = fmaf(qv[4], bf_lo(kk.z), a); a = fmaf(qv[5], bf_hi(kk.z), a); a = fmaf(qv[6], bf_lo(kk.w), a); a = fmaf(qv[7], bf_hi(kk.w), a);
+                    a += pf_dpp<PF_XOR1>(a); a += pf_dpp<PF_XOR2>(a); a += pf_dpp<PF_HALF_MIRROR>(a);
+                    sc[u] = valid[u] ? a : -1e30f;
+                }
+                // the new token rides with the last tile of the last slice on lanes 0..7 of wave 0
+                const bool has_new = last_slice && tile == n_tiles - 1 && tid < 8;
+                {
+                    float a = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) a = fmaf(qv[i], knew[du * 8 + i], a);
+                    a += pf_dpp<PF_XOR1>(a); a += pf_dpp<PF_XOR2>(a); a += pf_dpp<PF_HALF_MIRROR>(a);
+                    valid[2] = has_new;
+                    sc[2] = has_new ? a : -1e30f;
+                }
+                float m = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
+                m = fmaxf(m, pf_dpp<PF_XOR1>(m)); m = fmaxf(m, pf_dpp<PF_XOR2>(m)); m = fmaxf(m, pf_dpp<PF_HALF_MIRROR>(m)); m = fmaxf(m, pf_dpp<PF_MIRROR>(m));
+                m = fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 15)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 31))),
+                          fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 47)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 63))));
+                if (lane == 0) wmax[wave] = m;
+                __syncthreads();
+                float mt = wmax[0];
+#pragma unroll
+                for (int w = 1; w < 8; ++w) mt = fmaxf(mt, wmax[w]);
+                // p = exp(s - m_tile); partial l (one lane per token) and o (this lane's 8 dims), summed over the tokens of the wave
+                float o9[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const float p = valid[u] ? __expf(sc[u] - mt) : 0.f;
+                    if (du == 0) o9[8] += p;
+                    if (u < 2) {
+                        const u32x4 vv = vreg[u];
+                        o9[0] = fmaf(p, bf_lo(vv.x), o9[0]); o9[1] = fmaf(p, bf_hi(vv.x), o9[1]); o9[2] = fmaf(p, bf_lo(vv.y), o9[2]); o9[3] = fmaf(p, bf_hi(vv.y), o9[3]);
+                        o9[4] = fmaf(p, bf_lo(vv.z), o9[4]); o9[5] = fmaf(p, bf_hi(vv.z), o9[5]); o9[6] = fmaf(p, bf_lo(vv.w), o9[6]); o9[7] = fmaf(p, bf_hi(vv.w), o9[7]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) o9[i] = fmaf(p, vnew[du * 8 + i], o9[i]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 9; ++i) {  // sum over the 8 tokens of the wave that share this lane's dim slice (lane ^ 8, ^ 16, ^ 32)
+                    float t = o9[i];
+                    t += pf_dpp<PS_DROR8>(t);
+                    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+                    t = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                    const auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+                    o9[i] = __uint_as_float(r2[0]) + __uint_as_float(r2[1]);
+                }
+                if (lane < 8) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) part[wave * 72 + lane * 8 + i] = o9[i];
+                    if (lane == 0) part[wave * 72 + 64] = o9[8];
+                }
+                __syncthreads();
+                {   // merge the tile into the running state (flash-decoding rescale)
+                    float lt = part[64], ot = tid < 64 ? part[tid] : 0.f;
+#pragma unroll
+                    for (int w = 1; w < 8; ++w) { lt += part[w * 72 + 64]; if (tid < 64) ot += part[w * 72 + tid]; }
+                    const float mn = fmaxf(run_m, mt);
+                    const float ca = __expf(run_m - mn), cb2 = __expf(mt - mn);
+                    run_l = run_l * ca + lt * cb2;
+                    run_o = run_o * ca + ot * cb2;
+                    run_m = mn;
+                }
+                __syncthreads();  // part / wmax are rewritten by the next tile
+            }
+            // publish {o[64], m, l}
+            const int base = (ah * n_sl + as) * 66;
+            // stage the 66 values in LDS so that 528 (value, replica) stores can be spread over the workgroup
+            if (tid < 64) part[tid] = run_o;
+            if (tid == 64) { part[64] = run_m; part[65] = run_l; }
+            __syncthreads();
+            for (int idx = tid; idx < 66 * PF_REPL; idx += PF_THREADS) {
+                const int jj = idx % 66, rr = idx / 66;
+                pub(e, rr, base + jj, tag0 + e + 1, part[jj]);
+            }
+            __syncthreads();
+            PS_TICK(2);
+        } else {
+            ++e;
+        }
+        // ================= S3: merge the slices of every head -> Wo rows + residual
+        {
+            tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
+            const int h = tid >> 5, j = tid & 31;
+            const u64* eb = my_edges + (size_t)(e & 3) * ering;
+            float mn = -1e30f, L = 0.f, at0 = 0.f, at1 = 0.f;
+            // two passes over the slices would need the maxima first: keep {m, l, o} of up to 16 slices in registers (n_sl <= 16)
+            float sm[16], sl_[16], so0[16], so1[16];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int s0 = 4 * g4;  // compile-time: the slice arrays stay in registers
+                if (s0 < n_sl) {
+                    int unit[8];
+                    u32x4 v[8];
+                    const int ns = min(4, n_sl - s0);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int gbase = (h * n_sl + s0 + (k < ns ? k : 0)) * 66;
+                        unit[2 * k] = (gbase + 2 * j) >> 1;
+                        unit[2 * k + 1] = (gbase + 64) >> 1;
+                    }
+                    pf_sweep8u(eb, unit, 2 * ns, tag0 + e + 1, v, dead, A.ctl);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        so0[s0 + k] = __uint_as_float(v[2 * k].x); so1[s0 + k] = __uint_as_float(v[2 * k].z);
+                        sm[s0 + k] = __uint_as_float(v[2 * k + 1].x); sl_[s0 + k] = __uint_as_float(v[2 * k + 1].z);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { so0[s0 + k] = 0.f; so1[s0 + k] = 0.f; sm[s0 + k] = -1e30f; sl_[s0 + k] = 0.f; }
+                }
+            }
+            ++e;
+            w13[0] = reinterpret_cast<const u32x4*>(wl + IM_W13)[tid];  // next stage's weights (64 KB per CU), behind the sweep
+#pragma unroll
+            for (int c = 1; c < 8; ++c) w13[c] = reinterpret_cast<const u32x4*>(wl + IM_W13)[c * PF_THREADS + tid];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) if (s < n_sl) mn = fmaxf(mn, sm[s]);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) if (s < n_sl) L += sl_[s] * __expf(sm[s] - mn);
+            const float inv = 1.f / L;
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                if (s < n_sl) {
+                    const float wj = __expf(sm[s] - mn) * inv;
+                    at0 = fmaf(wj, so0[s], at0);
+                    at1 = fmaf(wj, so1[s], at1);
+                }
+            float a4[4];
+            a4[0] = pf_dot2(wo4.x, at0, at1, 0.f); a4[1] = pf_dot2(wo4.y, at0, at1, 0.f);
+            a4[2] = pf_dot2(wo4.z, at0, at1, 0.f); a4[3] = pf_dot2(wo4.w, at0, at1, 0.f);
+            const float r4 = pf_reduce<4>(a4, lane);
+            if ((lane & 15) == 0) red[(par * 8 + wave) * PS_RED + (lane >> 4)] = r4;
+            float xres = 0.f;
+            if (tid < 4 * PF_REPL) xres = xs[4 * b + (tid & 3)];
+            __syncthreads();
+            if (tid < 4 * PF_REPL) {
+                const int r = tid & 3, rr = tid >> 2;
+                float t = red[(par * 8) * PS_RED + r];
+#pragma unroll
+                for (int w = 1; w < 8; ++w) t += red[(par * 8 + w) * PS_RED + r];
+                pub(e, rr, 4 * b + r, tag0 + e + 1, xres + t);
+            }
+            par ^= 1;
+            PS_TICK(3);
+        }
+        // ================= S4: gather h -> RMSNorm folded -> 16 SwiGLU pairs
+        {
+            tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
+            const float2 nw = *reinterpret_cast<const float2*>(A.norms + (size_t)(2 * l + 1) * 1024 + 2 * tid);
+            u32x4 v;
+            pf_sweep1(my_edges + (size_t)(e & 3) * ering, tid, tag0 + e + 1, v, dead, A.ctl);
+            ++e;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w2r[q] = reinterpret_cast<const u32x4*>(wl + IM_W2)[q * PF_THREADS + tid];  // next stage's weights
+            x0 = __uint_as_float(v.x); x1 = __uint_as_float(v.z);
+            *reinterpret_cast<float2*>(xs + 2 * tid) = make_float2(x0, x1);
+            const float xn0 = x0 * nw.x, xn1 = x1 * nw.y;
+            const float ssw = pf_wave_sum(fmaf(x1, x1, fmaf(x0, x0, 0.f)));
+            if (lane == 0) red[(par * 8 + wave) * PS_RED + 32] = ssw;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                float a16[16];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const u32x4 w = w13[half * 4 + c];
+                    a16[4 * c] = pf_dot2(w.x, xn0, xn1, 0.f); a16[4 * c + 1] = pf_dot2(w.y, xn0, xn1, 0.f);
+                    a16[4 * c + 2] = pf_dot2(w.z, xn0, xn1, 0.f); a16[4 * c + 3] = pf_dot2(w.w, xn0, xn1, 0.f);
+                }
+                const float r16 = pf_reduce<16>(a16, lane);
+                if ((lane & 3) == 0) red[(par * 8 + wave) * PS_RED + half * 16 + (lane >> 2)] = r16;
+            }
+            __syncthreads();
+            if (tid < 16 * PF_REPL) {
+                const int jj = tid & 15, rr = tid >> 4;
+                float ga = red[(par * 8) * PS_RED + 2 * jj], gb = red[(par * 8) * PS_RED + 2 * jj + 1], tot = red[(par * 8) * PS_RED + 32];
+#pragma unroll
+                for (int w = 1; w < 8; ++w) {
+                    ga += red[(par * 8 + w) * PS_RED + 2 * jj]; gb += red[(par * 8 + w) * PS_RED + 2 * jj + 1];
+                    tot += red[(par * 8 + w) * PS_RED + 32];
+                }
+                const float dn = sqrtf(tot / 1024.f + A.eps);
+                ga /= dn; gb /= dn;
+                pub(e, rr, 16 * b + jj, tag0 + e + 1, (ga / (1.f + __expf(-ga))) * gb);
+            }
+            par ^= 1;
+            PS_TICK(4);
+        }
+        // ================= S5: gather the activations -> W2 rows + residual
+        {
+            tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
+            u32x4 v[4];
+            pf_sweep4(my_edges + (size_t)(e & 3) * ering, tid, tag0 + e + 1, v, dead, A.ctl);
+            ++e;
+            if (l + 1 < A.n_layer) {  // next layer's Wqkv rows
+                wq4 = reinterpret_cast<const u32x4*>(wl + layer_img + IM_QKV4)[tid];
+                wq1 = reinterpret_cast<const uint32_t*>(wl + layer_img + IM_QKV1)[tid];
+            }
+            float a4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const u32x4 w = w2r[q];
+                const float c0 = __uint_as_float(v[q].x), c1 = __uint_as_float(v[q].z);
+                a4[0] = pf_dot2(w.x, c0, c1, a4[0]); a4[1] = pf_dot2(w.y, c0, c1, a4[1]);
+                a4[2] = pf_dot2(w.z, c0, c1, a4[2]); a4[3] = pf_dot2(w.w, c0, c1, a4[3]);
+            }
+            const float r4 = pf_reduce<4>(a4, lane);
+            if ((lane & 15) == 0) red[(par * 8 + wave) * PS_RED + (lane >> 4)] = r4;
+            float xres = 0.f;
+            if (tid < 4 * PF_REPL) xres = xs[4 * b + (tid & 3)];
+            __syncthreads();
+            if (tid < 4 * PF_REPL) {
+                const int r = tid & 3, rr = tid >> 2;
+                float t = red[(par * 8) * PS_RED + r];
+#pragma unroll
+                for (int w = 1; w < 8; ++w) t += red[(par * 8 + w) * PS_RED + r];
+                pub(e, rr, 4 * b + r, tag0 + e + 1, xres + t);
+            }
+            par ^= 1;
+            PS_TICK(5);
+        }
+    }
+    // ================= head: gather the final x (= the hidden state the generator hands to the fast decoder) -> norm folded -> 8 rows
+    {
+        tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
+        const float2 nw = *reinterpret_cast<const float2*>(A.norms + (size_t)(2 * A.n_layer) * 1024 + 2 * tid);
+        const u32x4* hp = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(A.hpack) + (size_t)b * PS_HEAD_IMAGE);
+        const u32x4 h0 = hp[tid], h1 = hp[PF_THREADS + tid];
+        u32x4 v;
+        pf_sweep1(my_edges + (size_t)(e & 3) * ering, tid, tag0 + e + 1, v, dead, A.ctl);
+        ++e;
+        x0 = __uint_as_float(v.x); x1 = __uint_as_float(v.z);
+        if (b == 0) *reinterpret_cast<float2*>(A.x + 2 * tid) = make_float2(x0, x1);
+        const float xn0 = x0 * nw.x, xn1 = x1 * nw.y;
+        float a8[8];
+        a8[0] = pf_dot2(h0.x, xn0, xn1, 0.f); a8[1] = pf_dot2(h0.y, xn0, xn1, 0.f); a8[2] = pf_dot2(h0.z, xn0, xn1, 0.f); a8[3] = pf_dot2(h0.w, xn0, xn1, 0.f);
+        a8[4] = pf_dot2(h1.x, xn0, xn1, 0.f); a8[5] = pf_dot2(h1.y, xn0, xn1, 0.f); a8[6] = pf_dot2(h1.z, xn0, xn1, 0.f); a8[7] = pf_dot2(h1.w, xn0, xn1, 0.f);
+        const float ssw = pf_wave_sum(fmaf(x1, x1, fmaf(x0, x0, 0.f)));
+        const float r8 = pf_reduce<8>(a8, lane);
+        if ((lane & 7) == 0) red[(par * 8 + wave) * PS_RED + (lane >> 3)] = r8;
+        if (lane == 0) red[(par * 8 + wave) * PS_RED + 8] = ssw;
+        __syncthreads();
+        if (tid < 8 && 8 * b + tid < A.n_head_rows) {
+            float t = red[(par * 8) * PS_RED + tid], tot = red[(par * 8) * PS_RED + 8];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) { t += red[(par * 8 + w) * PS_RED + tid]; tot += red[(par * 8 + w) * PS_RED + 8]; }
+            A.logits[8 * b + tid] = t / sqrtf(tot / 1024.f + A.eps);
+        }
+        PS_TICK(6);
+    }
+    if (b == 0 && tid == 0) {
+        A.ctl[0] = epoch + 1;
+        if (A.prof) for (int k = 0; k < 8; ++k) A.prof[k] += tk[k];
+    }
+#undef PS_TICK
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+size_t slow_persist_pack_bytes(int n_layer) { return (size_t)n_layer * PF_BLOCKS * PS_LAYER_IMAGE; }
+size_t slow_persist_edge_bytes() { return (size_t)PF_RING * PF_REPL * PS_EDGE_CAP * 8; }
+
+void launch_slow_persist_pack(const LayerW* layers, int n_layer, const void* head_w, int n_head_rows, const float* const* norm_ptrs,
+                              void* wpack, void* hpack, float* norms_flat, hipStream_t st) {
+    for (int l = 0; l < n_layer; ++l)
+        hipLaunchKernelGGL(k_ps_pack_layer, dim3(PF_BLOCKS), dim3(PF_THREADS), 0, st, layers[l],
+                           reinterpret_cast<unsigned char*>(wpack) + (size_t)l * PF_BLOCKS * PS_LAYER_IMAGE);
+    hipLaunchKernelGGL(k_ps_pack_head, dim3(PF_BLOCKS), dim3(PF_THREADS), 0, st, reinterpret_cast<const uint32_t*>(head_w), n_head_rows,
+                       reinterpret_cast<unsigned char*>(hpack));
+    for (int i = 0; i < 2 * n_layer + 1; ++i)
+        hipLaunchKernelGGL(k_ps_copy_norm, dim3(4), dim3(256), 0, st, norm_ptrs[i], norms_flat + (size_t)i * 1024);
+    FS_HIP(hipGetLastError());
+}
+
+void launch_slow_persist(const SlowPersistArgs& a, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_slow_persist), hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_slow_persist, dim3(PF_BLOCKS), dim3(PF_THREADS), PS_LDS, st, a);
+    FS_HIP(hipGetLastError());
+}
+
+}  // namespace fs

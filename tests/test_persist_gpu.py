@@ -1,4 +1,5 @@
-"""GPU: the persistent fast-decoder kernel (csrc/lm_persist.hip; default for greedy decoding on bf16 Fish-geometry handles) against
+"""GPU: the persistent decode kernels (csrc/lm_persist_slow.hip: the 24 slow blocks + head of a step as one launch, any sampler;
+csrc/lm_persist.hip: the 8 codebook passes of the fast decoder as one launch, greedy decoding; both default on bf16 Fish-geometry handles) against
 (1) the per-node graph path of the same handle (FS_GEN_NO_PERSIST), token for token, and (2) the CPU oracle under the bf16 protocol
 of DESIGN.md (divergence only at a near-tie the oracle reports).  Plus its building blocks and its exclusivity rule."""
 import ctypes as C
@@ -101,22 +102,24 @@ def test_reduction_trees_selftest():
 
 @pytest.mark.parametrize("rep_pen", [1.0, 1.2])
 def test_persistent_equals_per_node_path(lm15, rep_pen):
-    for p in (_text_prompt(16, 1234), _vq_prompt(96, 7), _text_prompt(200, 99)):
+    # KV lengths 16..4300: attention stage with 1, 2, 4, 16 token slices per head, one to three 128-token tiles per workgroup
+    for p in (_text_prompt(16, 1234), _vq_prompt(96, 7), _text_prompt(200, 99), _text_prompt(1100, 5), _vq_prompt(4200, 6)):
         L = p.shape[1]
         lm15.clear_slow_layer_caches()
         a = lm15.generate_blocking(p, L + 62, repetition_penalty=rep_pen, persistent=False, **GREEDY)
         assert lm15.last_stats()["kernels_per_frame"] == 266
         lm15.clear_slow_layer_caches()
         b = lm15.generate_blocking(p, L + 62, repetition_penalty=rep_pen, persistent=True, **GREEDY)
-        assert lm15.last_stats()["kernels_per_frame"] == 123, "the persistent launch was not taken"
+        assert lm15.last_stats()["kernels_per_frame"] == 3, "the persistent launches were not taken"
         assert a.shape == b.shape == (8, 64)
         if not np.array_equal(a, b):
             # the two paths sum in different orders; an f32 rounding difference in a new K / V element can flip its bf16 rounding in the
-            # cache (2^-9 relative), so the logits of the two paths differ by up to ~1e-4 (measured 1.3e-4 at logit scale 3; the
-            # oracle protocol allows BF16_TOL = 1e-2): they may part ways only where their two choices are that close
+            # cache (2^-9 relative) and feed back through up to 24 blocks, so the logits of the two paths differ by up to ~1e-3 (measured
+            # 1.3e-3 at logit scale 3 with both kernels persistent, 1.3e-4 with the fast decoder alone; each path is within BF16_TOL = 1e-2
+            # of the oracle): they may part ways only where their two choices are that close
             f, cbd, gap, top2 = _replay_gap(lm15, p, a, b, rep_pen)
             print(f"L={L} rep_pen={rep_pen}: paths part at frame {f} codebook {cbd}: gap between the two choices {gap:.2e} (top-2 margin {top2:.2e})")
-            assert gap < 1e-3, (f, cbd, gap)
+            assert gap < 5e-3, (f, cbd, gap)
             assert f >= 16
         else:
             print(f"L={L} rep_pen={rep_pen}: 64/64 frames identical")
@@ -142,6 +145,31 @@ def test_free_running_greedy_vs_oracle(lm15, persistent):
         print(f"persistent={persistent}: all 48 frames identical to the oracle")
 
 
+def test_slow_kernel_hidden_states_vs_per_node_path_and_oracle(lm15):
+    """the persistent slow kernel's output itself: the hidden state of every frame (generate_blocking_with_hidden) against the per-node
+    path (same handle) and against the bf16-mode oracle, at KV lengths that exercise 1, 4 and 16 token slices per head"""
+    o = orc.OracleLM(orc.FISH15).load_synthetic(SEED, bf16=True)
+    o.set_kv_round_bf16(True)
+    for L, seed in ((16, 1234), (300, 8), (1300, 9)):
+        p = _text_prompt(L, seed)
+        kw = dict(temp=0.0, top_p=1.0, top_k=0, repetition_penalty=1.2, ignore_eos=True)
+        lm15.clear_slow_layer_caches()
+        ca, ha = lm15.generate_blocking_with_hidden(p, L + 10, True, persistent=False, **kw)
+        lm15.clear_slow_layer_caches()
+        cb, hb = lm15.generate_blocking_with_hidden(p, L + 10, True, persistent=True, **kw)
+        o.clear_slow()
+        ce, he = o.generate(p, L + 10, temp=0.0, repetition_penalty=1.2, ignore_eos=True, collect_hidden=True)
+        n = 12
+        same_ab = n if np.array_equal(ca, cb) else int(np.argmax((ca != cb).any(0)))
+        same_be = n if np.array_equal(cb, ce) else int(np.argmax((cb != ce).any(0)))
+        rms = float(np.sqrt(np.mean(he ** 2)))
+        d_ab = max(float(np.abs(ha[f, 0] - hb[f, 0]).max()) / rms for f in range(same_ab + 1 if same_ab < n else n))
+        d_be = max(float(np.abs(hb[f, 0] - he[f]).max()) / rms for f in range(same_be + 1 if same_be < n else n))
+        print(f"L={L}: hidden |d|/rms persistent vs per-node {d_ab:.2e} over {same_ab} identical frames; persistent vs oracle {d_be:.2e} over {same_be}")
+        assert d_ab < 5e-3 and d_be < BF16_TOL, (L, d_ab, d_be)
+        assert same_ab >= 1 and same_be >= 1
+
+
 def test_eos_and_budget_semantics_match_per_node_path(lm15):
     """no ignore_eos: runs that sample <|im_end|> stop at the same frame with the same codes on both paths (first frame recorded
     unconditionally, zeros pushed for the terminating frame: single_batch.rs:153-156,250,264-266); runs that do not, fill the
@@ -163,7 +191,7 @@ def test_eos_and_budget_semantics_match_per_node_path(lm15):
             parted += 1
     print(f"identical runs: {same_eos} ended on <|im_end|> before the budget, {same_full} filled it; {parted} parted at a near-tie")
     assert same_eos >= 1, "no run sampled <|im_end|>: the EOS branch of the persistent kernel went unexercised"
-    assert parted <= 10
+    assert parted <= 36  # with random weights (flat logits) two decisions an f32-noise distance apart are common within 72 frames x 9 decisions
 
 
 def test_only_one_handle_per_gpu_takes_the_persistent_launch(lm15):
@@ -189,11 +217,22 @@ def test_only_one_handle_per_gpu_takes_the_persistent_launch(lm15):
     assert not any(t.is_alive() for t in ths), "a generate call hung"
     assert np.array_equal(res["a"], ref) and np.array_equal(res["b"], ref)
     print("kernels per frame seen:", kpf)
+    assert kpf["a"] | kpf["b"] <= {3, 266} and 3 in (kpf["a"] | kpf["b"])
     lm2.close()
 
 
-def test_sampled_calls_stay_on_the_per_node_path(lm15):
+def test_sampled_calls_use_the_slow_kernel_and_the_per_node_fast_decoder(lm15):
+    """temp > 0: the slow transformer still runs as one persistent launch (it only produces logits), the fast decoder with its
+    on-device top-k / top-p sampler stays on the per-node path; the sampled stream equals the all-per-node one (same logits up to
+    summation order, so equal except where a draw lands on a CDF boundary)"""
     p = _text_prompt(16, 11)
+    kw = dict(temp=0.7, top_p=0.8, top_k=256, repetition_penalty=1.2, seed=3, ignore_eos=True)
     lm15.clear_slow_layer_caches()
-    lm15.generate_blocking(p, 16 + 6, temp=0.7, top_p=0.8, top_k=256, repetition_penalty=1.2, seed=3, ignore_eos=True)
+    a = lm15.generate_blocking(p, 16 + 30, **kw)
+    assert lm15.last_stats()["kernels_per_frame"] == 2 + 8 * 18
+    lm15.clear_slow_layer_caches()
+    b = lm15.generate_blocking(p, 16 + 30, persistent=False, **kw)
     assert lm15.last_stats()["kernels_per_frame"] == 266
+    same = int(np.argmax((a != b).any(0))) if (a != b).any() else a.shape[1]
+    print(f"sampled: {same}/{a.shape[1]} frames identical between the paths")
+    assert same >= 2  # ~1e-3 logit noise between the paths moves the CDF boundaries: a 1-2 % chance per draw to part, 9 draws per frame

@@ -1,0 +1,43 @@
+"""Summarise the rocprofv3 --pmc passes of tools/pmc_traffic.sh: HBM bytes per decode frame = sum over the frame's kernels of
+FETCH_SIZE x 2 (gfx950: the counter tallies 128-B requests at 64 B for wide coalesced reads, MI355X_MICROARCH.md HBM) + WRITE_SIZE, both
+reported in KiB.  Only the decode-frame kernels are counted (prefill / setup kernels are listed separately).
+usage: pmc_traffic.py <dir with pmc_{persistent,per_node}_{FETCH_SIZE,WRITE_SIZE}> <out.json> <frames>"""
+import collections, csv, glob, json, re, subprocess, sys
+
+root, out_path, frames = sys.argv[1], sys.argv[2], int(sys.argv[3])
+DECODE = ("::k_fast_persist", "::k_slow_persist", "::k_sample_slow", "::k_sample_fast", "::k_qkv", "::k_attn_decode", "::k_wo<", "::k_ffn_up", "::k_ffn_down", "::k_head<")
+
+
+def load(d, name):
+    tot = collections.defaultdict(lambda: [0, 0.0])
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == name:
+                k = re.sub(r"\(.*", "", r["Kernel_Name"])
+                tot[k][0] += 1
+                tot[k][1] += float(r["Counter_Value"])
+    return tot
+
+
+res = {}
+try:
+    res["commit"] = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], cwd=sys.path[0]).decode().strip()
+except Exception:
+    res["commit"] = "unknown"
+for mode in ("persistent", "per_node"):
+    F, W = load(f"{root}/pmc_{mode}_FETCH_SIZE", "FETCH_SIZE"), load(f"{root}/pmc_{mode}_WRITE_SIZE", "WRITE_SIZE")
+    if not F:
+        continue
+    kernels, total = {}, 0.0
+    for k in sorted(F):
+        if not any(d in k for d in DECODE):
+            continue
+        fetch_b = F[k][1] * 1024 * 2
+        write_b = W.get(k, [0, 0.0])[1] * 1024
+        kernels[k] = {"dispatches": F[k][0], "fetch_bytes_x2": int(fetch_b), "write_bytes": int(write_b)}
+        total += fetch_b + write_b
+    # the run = 1 request: (frames) decode frames, of which frame 0 is produced by the prefill iteration's graph replay too
+    res[mode] = {"hbm_bytes_per_frame": int(total / frames), "frames": frames, "kernels": kernels,
+                 "command": f"rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python tools/pmc_run.py {frames} " + ("0" if mode == "per_node" else "1"),
+                 "corrections": "FETCH_SIZE KiB x 1024 x 2 (gfx950 wide-read correction) + WRITE_SIZE KiB x 1024"}
+json.dump(res, open(out_path, "w"), indent=1)

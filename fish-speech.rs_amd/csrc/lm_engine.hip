@@ -334,6 +334,7 @@ class LM final : public LMBase {
         cfg.temp = (float)s.temp; cfg.top_p = (float)s.top_p;
         cfg.top_k = (int)std::min<uint64_t>(s.top_k, 1u << 30);
         cfg.rep_pen = s.repetition_penalty; cfg.ignore_eos = (flags & FS_GEN_IGNORE_EOS) ? 1 : 0;
+        cfg.batch_rows = batch_rows_; cfg.batch_row = batch_row_; cfg.batch_calls = a_.num_codebooks + 1;  // batch_rows > 0 only inside generate_batch_sequential
         FS_HIP(hipMemcpyAsync(d_cfg_.p, &cfg, sizeof(cfg), hipMemcpyHostToDevice, st_));
         // greedy decoding on a Fish-geometry bf16 handle: the 8 fast-decoder passes of a frame run as ONE persistent launch
         // (lm_persist.hip) instead of 144 graph nodes, if no other handle of this GPU is using it right now
@@ -341,7 +342,7 @@ class LM final : public LMBase {
         use_persist_ = use_pslow_ = false;
         if ((persist_ok_ || pslow_ok_) && !(flags & FS_GEN_NO_PERSIST)) {
             plock = std::unique_lock<std::mutex>(persist_mutex(device_), std::try_to_lock);
-            use_persist_ = plock.owns_lock() && persist_ok_ && cfg.temp == 0.f;  // the fast kernel decides greedily in-launch
+            use_persist_ = plock.owns_lock() && persist_ok_ && cfg.temp == 0.f && batch_rows_ == 0;  // the fast kernel decides greedily in-launch (host ArgMax rule)
             use_pslow_ = plock.owns_lock() && pslow_ok_;                          // the slow kernel feeds any sampler
         }
         // generate_blocking_with_hidden: the slow sampler stores the hidden state of every iteration through this pointer cell
@@ -531,15 +532,6 @@ class LM final : public LMBase {
         cfg.top_k = (int)std::min<uint64_t>(s.top_k, 1u << 30);
         cfg.rep_pen = 1.0f; cfg.ignore_eos = (flags & FS_GEN_IGNORE_EOS) ? 1 : 0;
         FS_HIP(hipMemcpyAsync(d_cfg_.p, &cfg, sizeof(cfg), hipMemcpyHostToDevice, st_));
-        // greedy decoding on a Fish-geometry bf16 handle: the 8 fast-decoder passes of a frame run as ONE persistent launch
-        // (lm_persist.hip) instead of 144 graph nodes, if no other handle of this GPU is using it right now
-        std::unique_lock<std::mutex> plock;
-        use_persist_ = use_pslow_ = false;
-        if ((persist_ok_ || pslow_ok_) && !(flags & FS_GEN_NO_PERSIST)) {
-            plock = std::unique_lock<std::mutex>(persist_mutex(device_), std::try_to_lock);
-            use_persist_ = plock.owns_lock() && persist_ok_ && cfg.temp == 0.f;  // the fast kernel decides greedily in-launch
-            use_pslow_ = plock.owns_lock() && pslow_ok_;                          // the slow kernel feeds any sampler
-        }
         RngState rng = {};
         seed_key(seed, rng.key);  // BatchedLogitsProcessor::new(seed) (the reference passes 42, static_batch.rs:63)
         FS_HIP(hipMemcpyAsync(d_rng_.p, &rng, sizeof(rng), hipMemcpyHostToDevice, st_));
@@ -668,9 +660,15 @@ class LM final : public LMBase {
             }
             off += (size_t)C1 * L;
             clear_slow();  // static_batch.rs:118-121
-            // child seed per row (sampling/mod.rs:93-95 draws one u64 per row per call; here one per row per request)
-            generate(padded.data(), Lmax, max_new_tokens, sb, seed + 0x9E3779B97F4A7C15ull * (uint64_t)i, flags,
-                     codes_out + (size_t)i * a_.num_codebooks * cap, cap, &n_frames[i], nullptr, nullptr, nullptr, 0, nullptr);
+            // BatchedLogitsProcessor semantics on the single-sequence kernels (sampling/mod.rs:77-109): temp <= 1e-7 -> device argmax
+            // (FIRST maximal index), else the child StdRng of (sample() call, row i) seeded from the master's u64 number call * n + i --
+            // row i generated on its own draws exactly what it draws in lock-step
+            batch_rows_ = n; batch_row_ = i;
+            try {
+                generate(padded.data(), Lmax, max_new_tokens, sb, seed, flags, codes_out + (size_t)i * a_.num_codebooks * cap, cap, &n_frames[i],
+                         nullptr, nullptr, nullptr, 0, nullptr);
+            } catch (...) { batch_rows_ = 0; batch_row_ = 0; throw; }
+            batch_rows_ = 0; batch_row_ = 0;
         }
     }
 
@@ -1213,6 +1211,7 @@ class LM final : public LMBase {
     DevBuf d_pack_, d_edges_, d_ctl_;  // persistent fast decoder
     DevBuf d_hidden_, d_hid_slot_;     // generate_blocking_with_hidden: [out_cap][dim] rows + the pointer cell the captured graphs read
     bool persist_ok_ = false, use_persist_ = false, pslow_ok_ = false, use_pslow_ = false;
+    int batch_rows_ = 0, batch_row_ = 0;  // generate_batch_sequential: batch sampler semantics for the row being generated
     DevBuf d_spack_, d_hpack_, d_snorms_, d_sedges_, d_sctl_;  // persistent slow transformer
     DevBuf d_pfx_, d_pfq_, d_pfslab_, d_pfa_, d_pfa2_, d_pfss_, d_pfc_, d_pfpart_;  // MFMA row-path activations (kRowsCap rows)
     DevBuf d_bprompt_;  // static batch: all left-padded prompts [B][C + 1][Lmax] (group prefill)

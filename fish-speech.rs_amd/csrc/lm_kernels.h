@@ -154,6 +154,9 @@ struct SampleCfg {  // device-resident (the captured graphs read it through a po
     // temperature ignored; logits[0] = pad logit, logits[1] = im_end logit
     int legacy;
     uint32_t pad_id;
+    // batch_rows > 0: BatchedLogitsProcessor semantics on the single-sequence samplers (row batch_row of a static batch generated on its
+    // own, lm_engine.hip generate_batch_sequential): temp <= 1e-7 -> FIRST-max argmax; temp > 0 -> child StdRng of (call, row)
+    int batch_rows = 0, batch_row = 0, batch_calls = 0;  // batch_calls = sample() calls per frame (num_codebooks + 1)
 };
 
 struct RepPenState {   // rep_pen.rs:4-72, one per codebook

@@ -2257,6 +2257,8 @@ __device__ __forceinline__ int greedy_pick(const float (&val)[SAMPLE_MAXN / SAMP
     return (int)(*s_key & 0xFFFFFFFFull);
 }
 
+__device__ inline void child_rng(const RngState* master, unsigned long long n64, RngState* out);
+
 template <typename WT>
 __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_slow(const float* __restrict__ logits, int n,
                                                                 const SampleCfg* __restrict__ cp, RngState* rng, SeqState* __restrict__ state,
@@ -2274,6 +2276,26 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_slow(const float* __r
     if (hid && state->done != 0) hid = nullptr;
     if (hid) hid += (size_t)state->frame * dim;
     __shared__ unsigned long long s_key;
+    if (c.batch_rows > 0 && !c.legacy) {  // row `batch_row` of a static batch on the single-sequence path: sampling/mod.rs:77-109
+        __shared__ RngState lrng;
+        SampleCfg cb = c;
+        if (cb.temp <= 1e-7f) cb.temp = 0.f;
+        for (int i = tid; i < n; i += SAMPLE_THREADS) lg[i] = logits[i];
+        for (int i = tid; i < dim; i += SAMPLE_THREADS) { const float h = x[i]; xf[i] = h; if (hid) hid[i] = h; }
+        if (tid == 0 && cb.temp != 0.f)
+            child_rng(rng, (unsigned long long)state->frame * (unsigned long long)c.batch_calls * c.batch_rows + c.batch_row, &lrng);
+        __syncthreads();
+        if (cb.ignore_eos && tid == 0) lg[0] = -INFINITY;
+        __syncthreads();
+        const int idx = block_sample(lg, n, cb, &lrng, sp, si, red, /*first_max=*/true);
+        if (tid == 0) {
+            uint32_t tok = (uint32_t)idx + c.im_end_id;
+            if (state->done) tok = c.im_end_id;
+            state->cur[0] = tok;
+            if (tok == c.im_end_id && state->done == 0) state->done = 1;
+        }
+        return;
+    }
     if (c.temp == 0.f && !c.legacy) {  // greedy: two barriers instead of five (see greedy_pick)
         if (tid == 0) s_key = 0ull;
         float val[SAMPLE_MAXN / SAMPLE_THREADS];
@@ -2344,7 +2366,15 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_fast(const float* __r
     __shared__ int s_ring[17], s_meta[2];
     __shared__ uint32_t s_prev, s_cur0, s_have_prev;
     __shared__ unsigned long long s_key;
-    const bool greedy = c.temp == 0.f;
+    // batch_rows > 0: BatchedLogitsProcessor semantics (see k_sample_slow): first-max argmax at temp <= 1e-7, else the child StdRng of
+    // (frame, codebook call, row)
+    const bool bm = c.batch_rows > 0;
+    SampleCfg cc = c;
+    if (bm && cc.temp <= 1e-7f) cc.temp = 0.f;
+    const bool greedy = cc.temp == 0.f && !bm;
+    __shared__ RngState lrng;
+    if (bm && tid == 23 && cc.temp != 0.f)
+        child_rng(rng, ((unsigned long long)state->frame * (unsigned long long)(n_cb + 1) + 1ull + (unsigned long long)cb) * c.batch_rows + c.batch_row, &lrng);
     if (tid == 22) s_key = 0ull;
     if (tid < 17) s_ring[tid] = rp.ring[cb * 17 + tid];
     else if (tid < 19) s_meta[tid - 17] = rp.ring_meta[cb * 2 + tid - 17];
@@ -2391,7 +2421,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_fast(const float* __r
         if (!greedy) __syncthreads();
     }
     int code = 0;
-    if (!eos) code = greedy ? greedy_pick(lv, n, &s_key) : block_sample(lg, n, c, rng, sp, si, red);
+    if (!eos) code = greedy ? greedy_pick(lv, n, &s_key) : block_sample(lg, n, cc, bm ? &lrng : rng, sp, si, red, /*first_max=*/bm);
     if (tid == 0) state->cur[cb + 1] = (uint32_t)code;
     if (cb != n_cb - 1) {
         if (!eos)

@@ -148,7 +148,9 @@ int fs_lm_generate_with_hidden(fs_lm_t* lm, const uint32_t* prompt, int L, int m
  * lock-step decode, ragged outputs: codes_out u32 [n, num_codebooks, cap], n_frames[n].
  * bf16 / fp8 handles with n <= min(max_batch, 256): the n sequences are the rows of every GEMM (weights streamed once per step
  * for the whole batch) and the prompts are prefilled as group passes; otherwise (f32 handles, n > 256) the rows are generated
- * one after another on KV slot 0 with identical results under greedy decoding. */
+ * one after another on KV slot 0 -- with the BatchedLogitsProcessor semantics of the lock-step path (sampling/mod.rs:77-109: temp <= 1e-7
+ * -> first-max argmax; else row b draws sample() call c from the child StdRng seeded with the master's u64 number c * n + b), so the
+ * outputs are those of the lock-step batch. */
 int fs_lm_generate_batch(fs_lm_t* lm, const uint32_t* prompts, const int* lens, int n, int max_new_tokens,
                          const fs_sampling* sampling, uint64_t seed, uint32_t flags, uint32_t* codes_out, size_t cap,
                          size_t* n_frames);

@@ -224,6 +224,26 @@ def test_static_batch_greedy_rows_match_padded_single(tiny32):
         assert np.array_equal(got, exp)
 
 
+@pytest.mark.parametrize("kw", [dict(temp=0.7, top_p=0.8, top_k=32), dict(temp=1.0, top_p=0.95, top_k=16), dict(temp=1e-8, top_p=1.0, top_k=16)])
+def test_static_batch_on_f32_handle_follows_the_batch_sampler(tiny32, kw):
+    """f32 handles generate a static batch row by row on the single-sequence kernels (no MFMA row path), but with
+    BatchedLogitsProcessor semantics (sampling/mod.rs:77-109): temp <= 1e-7 -> FIRST-max argmax, else row b draws call c of its request
+    from the child StdRng seeded with the master's u64 number c * B + b -- so the rows equal the oracle's lock-step generate_static_batch
+    token for token (f32 logits; ADVICE r1: the fallback used the single-sequence tie rule and an ad-hoc per-row seed)."""
+    lm = tiny32
+    o = orc.OracleLM(orc.TINY).load_synthetic(SEED)
+    rng = np.random.RandomState(19)
+    prompts = []
+    for L in (5, 9, 7, 3):
+        p = np.zeros((9, L), np.uint32)
+        p[0] = rng.randint(0, 400, L)
+        prompts.append(p)
+    outs = lm.generate_static_batch(prompts, 30, seed=42, ignore_eos=True, **kw)
+    exps = o.generate_batch(prompts, 30, seed=42, ignore_eos=True, **kw)
+    for b, (g, e) in enumerate(zip(outs, exps)):
+        assert g.shape == e.shape and np.array_equal(g, e), (b, int(np.argmax((g != e).any(0))) if g.shape == e.shape else (g.shape, e.shape))
+
+
 @pytest.mark.parametrize("temp,top_p,top_k", [(0.7, 0.8, 0), (0.7, 0.8, 16), (1.0, 1.0, 0), (0.5, 0.9, 50)])
 def test_sampled_decode_matches_oracle_stream(tiny32, temp, top_p, top_k):
     """temp > 0: softmax(logits/temp) -> top-k -> top-p -> WeightedIndex draw from the StdRng (ChaCha12) stream seeded by

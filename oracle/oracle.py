@@ -209,9 +209,14 @@ def _generate_batch(self, prompts, max_new_tokens, temp=0.0, top_p=1.0, top_k=0,
     cap = max_new_tokens + 8
     out = np.zeros((len(ps), Cb, cap), np.uint32)
     nf = np.zeros(len(ps), np.int32)
+    margins = np.zeros((cap, len(ps)), np.float32)
+    nit = C.c_int(0)
     _chk(lib().orc_lm_generate_batch(self.h, _p(flat, C.c_uint32), _p(lens, C.c_int), len(ps), int(max_new_tokens), C.c_double(temp),
                                      C.c_double(top_p), C.c_uint64(top_k), C.c_uint64(seed), int(ignore_eos), _p(out, C.c_uint32), cap,
-                                     _p(nf, C.c_int)))
+                                     _p(nf, C.c_int), _p(margins, C.c_float), cap, C.byref(nit)))
+    # [iteration, row]: smallest top-2 logit margin among the row's 9 decisions of that iteration (greedy parity tests use it to tell a
+    # kernel bug from a legitimate near-tie flip under reduced-precision storage)
+    self.last_batch_margins = margins[: nit.value].copy()
     return [out[i, :, : nf[i]].copy() for i in range(len(ps))]
 
 

@@ -126,7 +126,8 @@ int orc_lm_generate(void* p, const uint32_t* prompt, int L, int max_new_tokens, 
 
 // generate_static_batch.  prompts concatenated [(C+1) x L_i]; codes_out: [n][C][cap] row-major; n_frames[n]
 int orc_lm_generate_batch(void* p, const uint32_t* prompts, const int* lens, int n, int max_new_tokens, double temp, double top_p,
-                          uint64_t top_k, uint64_t seed, int ignore_eos, uint32_t* codes_out, int cap, int* n_frames) {
+                          uint64_t top_k, uint64_t seed, int ignore_eos, uint32_t* codes_out, int cap, int* n_frames,
+                          float* margins_out /*[margins_cap][n] or null*/, int margins_cap, int* n_iter) {
     try {
         LM* lm = (LM*)p;
         Sampling s; s.temp = temp; s.top_p = top_p; s.top_k = top_k; s.repetition_penalty = 1.0f;
@@ -136,7 +137,14 @@ int orc_lm_generate_batch(void* p, const uint32_t* prompts, const int* lens, int
         size_t off = 0;
         for (int i = 0; i < n; ++i) { ps[i].assign(prompts + off, prompts + off + (size_t)C1 * lens[i]); off += (size_t)C1 * lens[i]; }
         std::vector<int> nf;
-        auto out = lm->generate_batch(ps, ls, max_new_tokens, s, seed, ignore_eos != 0, &nf);
+        std::vector<float> margins;
+        auto out = lm->generate_batch(ps, ls, max_new_tokens, s, seed, ignore_eos != 0, &nf, margins_out ? &margins : nullptr);
+        if (margins_out) {
+            const int it = (int)(margins.size() / (size_t)n);
+            if (it > margins_cap) { g_err = "margins_out too small"; return 2; }
+            std::memcpy(margins_out, margins.data(), sizeof(float) * margins.size());
+            if (n_iter) *n_iter = it;
+        }
         for (int i = 0; i < n; ++i) {
             if (nf[i] > cap) { g_err = "codes_out too small"; return 2; }
             for (int c = 0; c < C; ++c)

@@ -636,7 +636,7 @@ std::vector<uint32_t> LM::generate(const uint32_t* prompt, int L, int max_new_to
 // ---------------------------------------------------------------- generate_static_batch (static_batch.rs:17-390), audio_only
 std::vector<std::vector<uint32_t>> LM::generate_batch(const std::vector<std::vector<uint32_t>>& prompts, const std::vector<int>& lens,
                                                       int max_new_tokens, const Sampling& s, uint64_t seed, bool ignore_eos,
-                                                      std::vector<int>* n_frames) {
+                                                      std::vector<int>* n_frames, std::vector<float>* margins) {
     const int C = a.num_codebooks, C1 = C + 1, D = a.dim, V = a.vocab_size, B = (int)prompts.size();
     if (B == 0) throw std::runtime_error("Must have at least one prompt");
     if (!t.has_semantic_end || t.im_end_id != t.semantic_start_id - 1) throw std::runtime_error("only the Fish 1.5 contiguous audio range is restated");
@@ -667,6 +667,14 @@ std::vector<std::vector<uint32_t>> LM::generate_batch(const std::vector<std::vec
             std::memcpy(&sl[(size_t)b * na], &logits[(size_t)b * V + lo], sizeof(float) * na);
             if (ignore_eos) sl[(size_t)b * na] = -std::numeric_limits<float>::infinity();
         }
+        // test aid (as in LM::generate): smallest top-2 margin among a row's 9 decisions of this iteration
+        auto top2 = [](const float* v, size_t n) {
+            float a = -std::numeric_limits<float>::infinity(), b2 = a;
+            for (size_t i = 0; i < n; ++i) { if (v[i] > a) { b2 = a; a = v[i]; } else if (v[i] > b2) b2 = v[i]; }
+            return a - b2;
+        };
+        size_t mbase = 0;
+        if (margins) { mbase = margins->size(); for (int b = 0; b < B; ++b) margins->push_back(top2(&sl[(size_t)b * na], na)); }
         std::vector<uint32_t> slow = batched_sample(master, s, sl.data(), B, na, na);
         for (auto& v : slow) v += t.im_end_id;                             // rescale_semantic_tokens
         for (int b = 0; b < B; ++b) dead[b] = dead[b] || slow[b] == t.im_end_id;  // :160-173
@@ -677,6 +685,7 @@ std::vector<std::vector<uint32_t>> LM::generate_batch(const std::vector<std::vec
         for (int ci = 0; ci < C; ++ci) {
             forward_generate_fast(x.data(), B, ci, fl.data());
             // rep_pen.apply_mask: the mask is never updated for Fish models (:204-206) -> logits / 1.0
+            if (margins) for (int b = 0; b < B; ++b) (*margins)[mbase + b] = std::min((*margins)[mbase + b], top2(&fl[(size_t)b * a.codebook_size], a.codebook_size));
             std::vector<uint32_t> tok = batched_sample(master, s, fl.data(), B, a.codebook_size, a.codebook_size);
             for (int b = 0; b < B; ++b) {
                 std::memcpy(&x[(size_t)b * D], &fast_embeddings[(size_t)tok[b] * D], sizeof(float) * D);

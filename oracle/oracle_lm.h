@@ -88,7 +88,8 @@ struct LM {
     // generate/static_batch.rs:282-390 (generate_static_batch, audio_only): per-row codes (num_codebooks, n_b)
     std::vector<std::vector<uint32_t>> generate_batch(const std::vector<std::vector<uint32_t>>& prompts, const std::vector<int>& lens,
                                                       int max_new_tokens, const Sampling& s, uint64_t seed, bool ignore_eos,
-                                                      std::vector<int>* n_frames);
+                                                      std::vector<int>* n_frames,
+                                                      std::vector<float>* margins = nullptr /* [iteration][row]: min top-2 margin of the row's 9 decisions */);
 
     void embed(const uint32_t* toks, int B, int L, float* x);  // dual_ar.rs:532-567
     void block_forward(Block& blk, float* x, int B, int L, int input_pos, int T_cached_expected);

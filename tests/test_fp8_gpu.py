@@ -202,7 +202,15 @@ def test_fp8_static_batch_mfma_rows_vs_oracle():
         assert [g.shape for g in got] == [e.shape for e in exp] == [(8, M - 11 + 2)] * 5
         agree = [int(np.argmin((g == e).all(0))) if not (g == e).all() else g.shape[1] for g, e in zip(got, exp)]
         print("fp8 static batch", sampling, "identical frame prefix per row:", agree, "of", got[0].shape[1])
-        assert min(agree) >= 8, agree
+        if sampling["temp"] == 0.0:  # greedy: a row may leave the oracle's stream only at a near-tie of the oracle (its own margins are the referee)
+            m = o.last_batch_margins
+            for b, (g, e) in enumerate(zip(got, exp)):
+                if not np.array_equal(g, e):
+                    f = int(np.argmax((g != e).any(0)))
+                    mf = float(min(m[f, b], m[f - 1, b])) if f > 0 else float(m[f, b])  # (the slow token of iteration f - 1 shows in frame f)
+                    assert mf < 5e-3, f"fp8 row {b} left the oracle's stream at frame {f} on a margin of {mf:.2e}"
+        else:
+            assert min(agree) >= 8, agree
     lm.close()
 
 

@@ -20,6 +20,25 @@ LMG = np.load(os.path.join(G, "lm_tiny.npz"))
 SEED = int(LMG["seed"])
 TOL32 = dict(rtol=2e-4, atol=5e-5)
 TOLBF = dict(rtol=2e-3, atol=2e-3)
+NEAR_TIE = 5e-3  # bf16 handles: logits within TOLBF of the oracle's, so a greedy decision can flip only where the oracle's top-2 margin is ~2 x that
+
+
+def _rows_leave_oracle_only_at_near_ties(got, exp, o, what=""):
+    """Greedy static batch vs the oracle's generate_static_batch restatement: row b may leave the oracle's token stream only at a frame
+    whose smallest top-2 logit margin over the row's 9 decisions (oracle.last_batch_margins[frame, row]) is below NEAR_TIE -- a kernel
+    bug (wrong row / position / panel mapping) diverges on ordinary margins.  Returns the number of rows that flipped."""
+    flips = 0
+    m = o.last_batch_margins
+    for b, (g, e) in enumerate(zip(got, exp)):
+        assert g.shape == e.shape, (what, b, g.shape, e.shape)
+        if np.array_equal(g, e):
+            continue
+        f = int(np.argmax((g != e).any(0)))
+        # the slow token is not part of the output: a flipped slow token of iteration f - 1 first shows in frame f (through the next input)
+        mf = float(min(m[f, b], m[f - 1, b])) if f > 0 else float(m[f, b])
+        assert mf < NEAR_TIE, f"{what} row {b} left the oracle's stream at frame {f} on a margin of {mf:.2e}"
+        flips += 1
+    return flips
 
 
 def _tiny(dtype, max_batch=1):
@@ -304,7 +323,10 @@ def test_static_batch_mfma_rows_vs_oracle(sampling):
     assert [g.shape for g in got] == [e.shape for e in exp] == [(8, M - 11 + 2)] * 5
     agree = [int(np.argmin((g == e).all(0))) if not (g == e).all() else g.shape[1] for g, e in zip(got, exp)]
     print("static batch", sampling, "identical frame prefix per row:", agree, "of", got[0].shape[1])
-    assert min(agree) >= 8, agree  # bf16 near-ties may flip late in a free run; a kernel bug shows at frame 0-1
+    if sampling["temp"] == 0.0:
+        _rows_leave_oracle_only_at_near_ties(got, exp, o, "B=5")
+    else:
+        assert min(agree) >= 8, agree  # sampled: a CDF boundary within the bf16 logit noise of a draw moves the stream; a kernel bug shows at frame 0-1
     # EOS path: rows finish at different frames; dead rows are stepped but not recorded (static_batch.rs:160-173,328-331)
     got = lm.generate_static_batch(prompts, 150, seed=42, **sampling)
     exp = o.generate_batch(prompts, 150, seed=42, **sampling)
@@ -357,9 +379,8 @@ def test_static_batch_more_rows_than_one_mfma_panel():
     got = lm.generate_static_batch(prompts, M, seed=42, temp=0.0, top_p=1.0, top_k=0, ignore_eos=True)
     exp = o.generate_batch(prompts, M, seed=42, temp=0.0, top_p=1.0, top_k=0, ignore_eos=True)
     assert [g.shape for g in got] == [e.shape for e in exp]
-    agree = [int(np.argmin((g == e).all(0))) if not (g == e).all() else g.shape[1] for g, e in zip(got, exp)]
-    print("B=40 identical frame prefix per row: min", min(agree), "of", got[0].shape[1])
-    assert min(agree) >= 8, agree
+    flips = _rows_leave_oracle_only_at_near_ties(got, exp, o, "B=40")
+    print(f"B=40: {40 - flips}/40 rows identical to the oracle over {got[0].shape[1]} frames, {flips} left it at a near-tie")
     # sampled: per-row child RNG streams are indexed by (call, row) with B = 40
     got = lm.generate_static_batch(prompts, M, seed=42, temp=0.7, top_p=0.8, top_k=32, ignore_eos=True)
     exp = o.generate_batch(prompts, M, seed=42, temp=0.7, top_p=0.8, top_k=32, ignore_eos=True)
@@ -412,9 +433,8 @@ def test_mid_static_batch_group_prefill_vs_oracle(B, span, monkeypatch):
     got = lm.generate_static_batch(prompts, M, **kw)
     exp = o.generate_batch(prompts, M, **kw)
     assert [g.shape for g in got] == [e.shape for e in exp]
-    agree = [int(np.argmin((g == e).all(0))) if not (g == e).all() else g.shape[1] for g, e in zip(got, exp)]
-    print(f"B={B} group prefill: identical frame prefix per row min {min(agree)} of {got[0].shape[1]}")
-    assert min(agree) >= 6, agree
+    flips = _rows_leave_oracle_only_at_near_ties(got, exp, o, f"B={B} group prefill")
+    print(f"B={B} group prefill: {B - flips}/{B} rows identical to the oracle over {got[0].shape[1]} frames")
     monkeypatch.setenv("FISHRT_NO_GROUP_PREFILL", "1")
     seq = lm.generate_static_batch(prompts, M, **kw)
     monkeypatch.delenv("FISHRT_NO_GROUP_PREFILL")
@@ -473,11 +493,10 @@ def test_static_batch_sizes_around_panel_boundaries_vs_oracle(which):
         got = lm.generate_static_batch(prompts, M, **kw)
         exp = o.generate_batch(prompts, M, **kw)
         assert [g.shape for g in got] == [e.shape for e in exp]
-        agree = [int(np.argmin((g == e).all(0))) if not (g == e).all() else g.shape[1] for g, e in zip(got, exp)]
-        # bf16 near-ties (flat logits of random weights) flip a few rows somewhere in a 14-frame free run (measured 5 of 64 rows, at
-        # frames 2..13, i.e. ~0.06 % of the greedy decisions); a wrong row / position / panel mapping breaks every row at frame 0
-        nf = got[0].shape[1]
-        assert sum(a == nf for a in agree) >= 0.85 * B and min(agree) >= 1 and np.mean(agree) >= 0.9 * nf, (B, agree)
+        # bf16 near-ties (flat logits of random weights) flip a few rows somewhere in a 14-frame free run; every flip must sit on a
+        # near-tie of the oracle (a wrong row / position / panel mapping breaks rows on ordinary margins, at frame 0)
+        flips = _rows_leave_oracle_only_at_near_ties(got, exp, o, f"{which} B={B}")
+        assert flips <= max(2, B // 4), (B, flips)
     lm.close()
 
 
@@ -492,16 +511,15 @@ def test_static_batch_single_token_prompts_and_max_rows():
         got = lm.generate_static_batch(prompts, max(lens) + 6, **kw)
         exp = o.generate_batch(prompts, max(lens) + 6, **kw)
         assert [g.shape for g in got] == [e.shape for e in exp]
-        assert all(np.array_equal(g[:, :3], e[:, :3]) for g, e in zip(got, exp)), lens
+        _rows_leave_oracle_only_at_near_ties(got, exp, o, f"lens {lens}")
     lens = [2 + (i * 7) % 13 for i in range(256)]
     prompts = _batch_prompts(99, lens)
     got = lm.generate_static_batch(prompts, max(lens) + 4, **kw)
     exp = o.generate_batch(prompts, max(lens) + 4, **kw)
     assert len(got) == 256 and [g.shape for g in got] == [e.shape for e in exp]
-    same0 = sum(int(np.array_equal(g[:, 0], e[:, 0])) for g, e in zip(got, exp))
-    full = sum(int(np.array_equal(g, e)) for g, e in zip(got, exp))
-    print(f"256 rows: first frame identical on {same0}, all 6 frames on {full}")
-    assert same0 >= 250 and full >= 0.85 * 256
+    flips = _rows_leave_oracle_only_at_near_ties(got, exp, o, "256 rows")
+    print(f"256 rows: {256 - flips} identical to the oracle over all 6 frames, {flips} left it at a near-tie")
+    assert flips <= 32
     lm.close()
     # more prompts than the handle's max_batch: rows are generated one after another on KV slot 0 (same tokens under greedy decoding)
     small = fishrt.DualARTransformer(MID, fcfg.TINY_TOKENS, 0, "bf16", 4).load_synthetic(SEED)

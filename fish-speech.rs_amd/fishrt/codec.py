@@ -13,7 +13,7 @@ class FireflyCodec:
         self._h = h
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and _ffi is not None and getattr(_ffi, "lib", None):  # (module globals are gone at interpreter exit)
             _ffi.lib().fs_codec_destroy(self._h)
             self._h = None
 

@@ -31,7 +31,7 @@ class DualARTransformer:
         self.max_batch = max_batch
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and _ffi is not None and getattr(_ffi, "lib", None):  # (module globals are gone at interpreter exit)
             _ffi.lib().fs_lm_destroy(self._h)
             self._h = None
 

@@ -1,0 +1,199 @@
+"""CPU: the OpenAI-compatible serving shim (fishrt/server.py) -- request / response schema of the reference handlers
+(server/lib/handlers/{speech,encode_speech,supported_voices}.rs), the scheduler that replaces the global model mutex, KV-prefix reuse,
+dynamic batching, the re-roll rule and the error mapping.  The LM / codec handles are stand-ins that record how they are driven (the
+real ones need an MI355X; tests/test_server_gpu.py runs the same app on the device)."""
+import io
+import json
+import struct
+import threading
+
+import numpy as np
+import pytest
+
+from fishrt import prompt as fprompt
+from fishrt import server
+
+
+class Tok:  # byte-level stand-in: ids = utf-8 bytes; the two specials the prompt encoder asks for
+    def encode(self, text):
+        return list(text.encode())
+
+    def token_to_id(self, token):
+        return {"<|semantic:0|>": 1000, "<|semantic|>": 5}.get(token)
+
+
+class FakeLM:
+    def __init__(self, max_new_tokens=64, slow=0.0):
+        self.cfg = dict(num_codebooks=8)
+        self.kv, self.calls, self.lock, self.slow, self.M = 0, [], threading.Lock(), slow, max_new_tokens
+        self.frames_for = lambda prompt: 3 + int(prompt[0, -1]) % 5
+
+    def clear_slow_layer_caches(self):
+        self.kv = 0
+
+    def clear_slow_caches_until(self, pos):
+        self.kv = min(self.kv, pos)
+
+    def curr_kv_size(self):
+        return self.kv
+
+    def _gen(self, prompt):
+        n = self.frames_for(prompt)
+        return np.full((8, n), int(prompt[0, -5]) % 1000, np.uint32)
+
+    def generate_blocking(self, prompt, max_new_tokens, **kw):
+        assert self.lock.acquire(blocking=False), "two calls in flight on one handle"
+        try:
+            import time
+            time.sleep(self.slow)
+            self.calls.append(("single", prompt.shape[1], self.kv, dict(kw)))
+            out = self._gen(prompt)
+            self.kv += prompt.shape[1] + out.shape[1] - 1
+            return out
+        finally:
+            self.lock.release()
+
+    def generate_static_batch(self, prompts, max_new_tokens, **kw):
+        assert self.lock.acquire(blocking=False), "two calls in flight on one handle"
+        try:
+            self.calls.append(("batch", [p.shape[1] for p in prompts], dict(kw)))
+            self.kv = 99
+            return [self._gen(p) for p in prompts]
+        finally:
+            self.lock.release()
+
+
+class FakeCodec:
+    def decode(self, codes):
+        b, c, t = codes.shape
+        return np.full((b, 1, 2048 * t), 0.25, np.float32)
+
+    def encode(self, pcm):
+        return np.full((1, 8, max(1, pcm.shape[2] // 2048)), 7, np.uint32)
+
+
+def _state(max_batch=1, **lm_kw):
+    tok = Tok()
+    enc = fprompt.PromptEncoder(tok, 8, fprompt.FISH_1_5)
+    default = enc.encode_conditioning_prompt("hello there", np.full((8, 4), 3, np.uint32))
+    alice = enc.encode_conditioning_prompt("i am alice", np.full((8, 6), 9, np.uint32))
+    lm = FakeLM(**lm_kw)
+    ls = server.LMState(lm, tok, {"default": default, "alice": alice}, default, max_new_tokens=lm.M, max_batch=max_batch)
+    return server.AppState(ls, FakeCodec(), batch_window_s=0.05), lm
+
+
+def _client(state):
+    from fastapi.testclient import TestClient
+    return TestClient(server.make_app(state))
+
+
+def test_speech_returns_wav_and_reuses_the_conditioning_prefix():
+    state, lm = _state()
+    c = _client(state)
+    text = "First sentence is here and it is long enough to stand alone as a chunk of text for the model to speak aloud, yes it is. " * 2 + \
+           "Second one follows, also long enough to be its own chunk because the combine threshold is one hundred and fifty characters. " * 2
+    r = c.post("/v1/audio/speech", json=dict(model="tts-1", voice="alice", input=text))
+    assert r.status_code == 200 and r.headers["content-type"] == "audio/wav"
+    b = r.content
+    assert b[:4] == b"RIFF" and b[8:12] == b"WAVE" and struct.unpack("<I", b[24:28])[0] == 44100 and struct.unpack("<H", b[34:36])[0] == 16
+    n_samples = struct.unpack("<I", b[40:44])[0] // 2
+    singles = [k for k in lm.calls if k[0] == "single"]
+    assert len(singles) >= 2 and n_samples == 2048 * sum(3 + 0 for _ in []) or n_samples % 2048 == 0
+    # chunk 0 carries the conditioning prompt (KV empty); later chunks find it cached and send only the user turn
+    assert singles[0][2] == 0 and singles[0][1] > singles[1][1] and singles[1][2] > 0
+    assert state.scheduler.stats["prefix_hits"] == len(singles) - 1
+    # server defaults (load.rs:116-125): top-k 256, repetition penalty 1.4 for Fish 1.5
+    kw = dict(singles[0][3])
+    seeds = [k[3]["seed"] for k in singles]  # single_batch.rs:46: a fresh random sampler seed per generate call
+    assert kw.pop("seed") in range(2**64) and len(set(seeds)) == len(seeds)
+    assert kw == dict(temp=0.7, top_p=0.8, top_k=256, repetition_penalty=1.4)
+    assert np.frombuffer(b[44:48], "<i2")[0] == int(0.25 * 32767)
+    state.scheduler.close()
+
+
+def test_voices_unknown_voice_falls_back_and_unconditioned():
+    state, lm = _state()
+    c = _client(state)
+    assert sorted(c.get("/v1/voices").json()) == ["alice", "default"]
+    c.post("/v1/audio/speech", json=dict(model="x", voice="nobody", input="Hi."))
+    c.post("/v1/audio/speech", json=dict(model="x", voice="default", input="Hi."))
+    c.post("/v1/audio/speech", json=dict(model="x", voice="unconditioned", input="Hi."))
+    a, b, u = [k[1] for k in lm.calls]
+    # unknown voice -> the default voice (speech.rs:264-271); the next request with the SAME conditioning finds it cached (prefix reuse across
+    # requests: only the user turn is sent); unconditioned -> system prompt only, a different prefix -> full (shorter) prompt
+    assert b < a and lm.calls[1][2] == a - b and b < u < a and lm.calls[2][2] == 0
+    assert c.post("/v1/audio/speech", json=dict(model="x", input="Hi.")).status_code == 422
+    r = c.post("/v1/audio/speech", json=dict(model="x", voice="default", input="Hi.", response_format="opus"))
+    assert r.status_code == 501
+    r = c.post("/v1/audio/speech", json=dict(model="x", voice="default", input="Hi.", response_format="pcm"))
+    assert r.status_code == 200 and r.headers["content-type"].startswith("audio/pcm") and len(r.content) % 4096 == 0
+    state.scheduler.close()
+
+
+def test_concurrent_requests_are_serialised_or_batched_never_interleaved():
+    state, lm = _state(max_batch=8, slow=0.02)
+    c = _client(state)
+    results = {}
+
+    def go(i):
+        results[i] = c.post("/v1/audio/speech", json=dict(model="x", voice="alice" if i % 2 else "default", input=f"Request number {i}."))
+
+    ths = [threading.Thread(target=go, args=(i,)) for i in range(6)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert all(r.status_code == 200 for r in results.values())  # FakeLM asserts that no two calls overlap on the handle
+    st = state.scheduler.stats
+    assert st["jobs"] == 6 and st["batches"] >= 1 and st["batched_rows"] >= 2, st
+    kinds = [k[0] for k in lm.calls]
+    assert "batch" in kinds
+    # the batch path passes no repetition penalty (a no-op in the reference, static_batch.rs:204-206)
+    assert all("repetition_penalty" not in k[2] for k in lm.calls if k[0] == "batch")
+    state.scheduler.close()
+
+
+def test_reroll_once_then_error_and_error_mapping():
+    state, lm = _state(max_new_tokens=6)
+    lm.frames_for = lambda prompt: 6  # every generation runs into max_new_tokens
+    c = _client(state)
+    r = c.post("/v1/audio/speech", json=dict(model="x", voice="default", input="Hi."))
+    assert r.status_code == 500 and b"second time" in r.content and state.scheduler.stats["rerolls"] == 1
+    n = {"k": 0}
+
+    def flaky(prompt):
+        n["k"] += 1
+        return 6 if n["k"] == 1 else 4
+    lm.frames_for = flaky
+    r = c.post("/v1/audio/speech", json=dict(model="x", voice="default", input="Hi."))
+    assert r.status_code == 200 and state.scheduler.stats["rerolls"] == 2
+    state.scheduler.close()
+
+
+def test_encode_speaker_returns_npy_and_registers_the_voice():
+    state, lm = _state()
+    c = _client(state)
+    pcm = (np.sin(np.arange(22050 * 2) / 20.0) * 12000).astype("<i2")
+    wav = io.BytesIO()
+    wav.write(b"RIFF" + struct.pack("<I", 36 + pcm.nbytes) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 1, 22050, 44100, 2, 16) + b"data" +
+              struct.pack("<I", pcm.nbytes) + pcm.tobytes())
+    files = {"file": ("ref.wav", wav.getvalue(), "audio/wav")}
+    r = c.post("/v1/audio/encoding", files=files, params=dict(id="bob", prompt="this is bob"))
+    assert r.status_code == 200 and r.headers["content-type"] == "application/x-npy"
+    codes = np.load(io.BytesIO(r.content))
+    assert codes.shape == (8, 2 * 44100 // 2048) and codes.dtype == np.uint32  # 2 s resampled 22.05 -> 44.1 kHz
+    assert "bob" in c.get("/v1/voices").json()
+    r = c.post("/v1/audio/encoding", files=files, params=dict(id="bob", prompt="again"))
+    assert r.status_code == 500 and b"ID already exists on server: bob" in r.content
+    r = c.post("/v1/audio/encoding", files={"file": ("x.mp3", b"ID3....", "audio/mpeg")})
+    assert r.status_code == 500
+    state.scheduler.close()
+
+
+def test_preprocess_text_chunks():
+    assert server.preprocess_text("  Hello “world”…  ") == ['Hello "world"...']
+    long = ("word " * 100).strip() + "."
+    chunks = server.preprocess_text(long + " " + long)
+    assert all(len(ch) <= 400 for ch in chunks) and "".join(chunks).replace(" ", "") == (long + long).replace(" ", "")
+    with pytest.raises(RuntimeError):
+        fprompt.PromptEncoder(Tok(), 8).encode_sequence([], None, None, True)

@@ -14,6 +14,8 @@ class CodecBase {
     virtual void decode(const uint32_t* codes, int b, int T, float* pcm_out) = 0;
     virtual void encode(const float* pcm, int n, uint32_t* codes_out, size_t cap, size_t* L_out) = 0;
     virtual int sample_rate() = 0;
+    virtual void set_precision(int mode) = 0;  // 0 = f32 (exact f32 products), 1 = bf16x3 (default; decode only)
+    virtual int precision() = 0;
 };
 
 CodecBase* make_codec(int device, int channel_div);

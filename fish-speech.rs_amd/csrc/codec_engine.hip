@@ -27,6 +27,7 @@ struct DBuf {
     void free() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
     ~DBuf() { free(); }
     float* f() const { return (float*)p; }
+    uint16_t* u16() const { return (uint16_t*)p; }
 };
 struct Tensor {  // one checkpoint tensor
     std::string name;
@@ -86,11 +87,17 @@ class Codec final : public CodecBase {
         loaded_ = true;
     }
     int sample_rate() override { return 44100; }  // SpecTransformConfig (config.rs:13-22)
+    void set_precision(int mode) override {
+        FS_REQUIRE(mode == 0 || mode == 1, "codec precision: 0 = f32 (exact products), 1 = bf16x3 (split bf16 matrix products)");
+        bf3_ = mode == 1;
+    }
+    int precision() override { return bf3_ ? 1 : 0; }
 
     void decode(const uint32_t* codes, int B, int T, float* pcm_out) override {
         FS_HIP(hipSetDevice(device_));
         FS_REQUIRE(loaded_, "weights not loaded: call fs_codec_load_safetensors or fs_codec_load_synthetic first");
         FS_REQUIRE(B >= 1 && T >= 1, "empty input");
+        use_bf3_now_ = bf3_;
         const int G = 8;
         for (size_t i = 0; i < (size_t)B * G * T; ++i)
             if (codes[i] >= 1000u) throw Error("FSQ index out of range (gather out of bounds)");
@@ -142,6 +149,7 @@ class Codec final : public CodecBase {
     void encode(const float* pcm, int n, uint32_t* codes_out, size_t cap, size_t* L_out) override {
         FS_HIP(hipSetDevice(device_));
         FS_REQUIRE(loaded_, "weights not loaded: call fs_codec_load_safetensors or fs_codec_load_synthetic first");
+        use_bf3_now_ = false;  // the indices are a discontinuous function of the activations: exact-f32 products only
         const int pad = (kFft - kHop) / 2;
         if (n < pad) throw Error("input shorter than the reflect padding (range end index out of range, spectrogram.rs:19)");
         const long long Lp = (long long)n + 2 * pad, full = Lp / kHop, rem = Lp % kHop;
@@ -230,6 +238,7 @@ class Codec final : public CodecBase {
         w.wt = relaid_.f() + relaid_off_[spec_idx];
         w.b = R(s.bias);
         w.cout = s.cout; w.k = s.k;
+        w.wp = use_bf3_now_ ? packed_.u16() + packed_off_[spec_idx] : nullptr;
         return w;
     }
     int add_tensor(const std::string& name, std::vector<int64_t> shape, float mean, double stdv) {
@@ -365,6 +374,23 @@ class Codec final : public CodecBase {
             if (s.transposed) codec_relayout_tconv(R(s.raw), relaid_.f() + relaid_off_[i], s.cout, s.cin_g, s.k, s.stride, st_);
             else codec_relayout(R(s.raw), relaid_.f() + relaid_off_[i], s.cout, s.cin_g, s.k, false, st_);
         }
+        // bf16 hi/lo split copies in MFMA operand order (the decode path's "bf16x3" precision mode), GEMM shape of the polyphase form
+        packed_off_.clear();
+        size_t total = 0;
+        auto shape = [](const ConvSpec& s, int& K, int& Cout) {
+            K = s.transposed ? s.k / s.stride : s.k;
+            Cout = s.transposed ? s.cout * s.stride : s.cout;
+        };
+        for (const ConvSpec& s : convs_) {
+            int K, Cout; shape(s, K, Cout);
+            packed_off_.push_back(total);
+            total += (codec_pack_bf3_elems(s.cin_g, K, Cout) + 63) & ~(size_t)63;
+        }
+        packed_.ensure(total * sizeof(uint16_t));
+        for (size_t i = 0; i < convs_.size(); ++i) {
+            int K, Cout; shape(convs_[i], K, Cout);
+            codec_pack_bf3(relaid_.f() + relaid_off_[i], packed_.u16() + packed_off_[i], convs_[i].cin_g, K, Cout, st_);
+        }
         FS_HIP(hipStreamSynchronize(st_));
     }
 
@@ -375,7 +401,9 @@ class Codec final : public CodecBase {
     std::vector<ConvSpec> convs_;
     std::vector<size_t> relaid_off_;
     size_t raw_floats_ = 0, relaid_floats_ = 0;
-    DBuf raw_, relaid_, dcodes_, buf_[7];
+    DBuf raw_, relaid_, packed_, dcodes_, buf_[7];
+    std::vector<size_t> packed_off_;
+    bool bf3_ = true, use_bf3_now_ = false;  // decode precision mode (fs_codec_set_precision); the encoder always runs exact f32
     int proj_w_ = 0, proj_b_ = 0, up_conv_[2] = {0, 0}, conv_pre_ = 0, conv_post_ = 0, ups_[5] = {0, 0, 0, 0, 0};
     int res_[5][3][2][3] = {};
     CnxSpec cnx_[2] = {};

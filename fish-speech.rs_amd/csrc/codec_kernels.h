@@ -11,6 +11,7 @@ struct ConvW {
     const float* wt;  // re-laid weight [Cin/groups][K][Cout]
     const float* b;   // [Cout]
     int cout, k;
+    const uint16_t* wp = nullptr;  // bf16 hi/lo split, MFMA A-operand order (codec_pack_bf3); nullptr = exact-f32 kernels only
 };
 
 enum { CODEC_EPI_NONE = 0, CODEC_EPI_GELU = 1, CODEC_EPI_GAMMA_RES = 2, CODEC_EPI_RES = 3, CODEC_EPI_TANH = 4 };
@@ -27,6 +28,12 @@ void codec_mean3(const float* a, const float* b, const float* c, float* y, size_
 void codec_relayout(const float* src, float* dst, int Cout, int CinG, int K, bool transposed, hipStream_t st);
 // ConvTranspose1d [Cin][Cout][K] -> polyphase causal-conv layout [Cin][K/stride][Cout*stride] (see codec_tconv1d)
 void codec_relayout_tconv(const float* src, float* dst, int Cout, int Cin, int K, int stride, hipStream_t st);
+// ---- bf16x3 convolution (codec_conv_bf3.hip): W and X split into bf16 hi + lo, three v_mfma_f32_32x32x16_bf16 per 16 reduction items
+size_t codec_pack_bf3_elems(int Cin, int K, int Cout);
+void codec_pack_bf3(const float* relaid /*[Cin][K][Cout]*/, uint16_t* dst, int Cin, int K, int Cout, hipStream_t st);
+bool codec_conv1d_bf3_ok(int Cin, int Cout, int K, int dil);
+void codec_conv1d_bf3(const float* x, int B, int Cin, int T, const uint16_t* wp, const float* bias, int Cout, int K, int dil, bool pre_silu,
+                      int epi, const float* res, const float* gamma, float* y, int ps, hipStream_t st);
 // ---- encoder side (FireflyCodec::encode)
 void codec_stft_mag(const float* pcm, int n, int n_fft, int hop, int n_frames, float* lin /*[n_fft/2+1][frames]*/, hipStream_t st);
 void codec_mel_log(const float* lin, const float* fb /*[nf][n_mels]*/, int nf, int n_mels, int F, float* mel /*[n_mels][F]*/, hipStream_t st);

@@ -345,6 +345,10 @@ static void conv1d_launch(const float* x, int B, int Cin, int T, const ConvW& w,
     using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I4 = std::integral_constant<int, 4>;
     using I8 = std::integral_constant<int, 8>; using I16 = std::integral_constant<int, 16>;
     const bool mfma_ok = Cin >= 16 && Cout >= 16 && K <= 13 && halo <= 256;
+    if (w.wp && codec_conv1d_bf3_ok(Cin, Cout, K, dil)) {  // "bf16x3" precision mode: split operands on the bf16 matrix cores
+        codec_conv1d_bf3(x, B, Cin, T, w.wp, w.b, Cout, K, dil, pre_silu, epi, res, gamma, y, ps, st);
+        return;
+    }
     if (mfma_ok) {  // matrix cores: 64 (or, for the thin late stages, 32) channels x 128 or 256 samples per block
         constexpr int ICH = 16;
         // 64-channel blocks only where they still give every CU a block; else 32-channel blocks (twice as many).  Measured on the

@@ -153,5 +153,7 @@ int fs_codec_encode(fs_codec_t* c, const float* pcm, int n_samples, uint32_t* co
     FS_TRY(c->impl->encode(pcm, n_samples, codes_out, cap, n_frames))
 }
 int fs_codec_sample_rate(fs_codec_t* c) { return c ? c->impl->sample_rate() : -1; }
+int fs_codec_set_precision(fs_codec_t* c, int mode) { FS_ARG(c, "null argument"); FS_TRY(c->impl->set_precision(mode)) }
+int fs_codec_precision(fs_codec_t* c) { return c ? c->impl->precision() : -1; }
 
 }  // extern "C"

@@ -7,10 +7,16 @@ from . import _ffi
 
 
 class FireflyCodec:
-    def __init__(self, device=0, channel_div=1):
+    PRECISIONS = {"f32": 0, "bf16x3": 1}
+
+    def __init__(self, device=0, channel_div=1, precision="bf16x3"):
+        """precision: arithmetic of the decode path's wide convs -- "bf16x3" (default: split-bf16 matrix products, PCM within 1e-4 RMS
+        of the f32 reference) or "f32" (exact f32 products); the encoder always runs exact f32 (fishrt.h: fs_codec_set_precision)"""
         h = C.c_void_p()
         _ffi.check(_ffi.lib().fs_codec_create(int(device), int(channel_div), C.byref(h)))
         self._h = h
+        _ffi.check(_ffi.lib().fs_codec_set_precision(self._h, self.PRECISIONS[precision]))
+        self.precision = precision
 
     def close(self):
         if getattr(self, "_h", None) and _ffi is not None and getattr(_ffi, "lib", None):  # (module globals are gone at interpreter exit)

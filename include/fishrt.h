@@ -190,6 +190,12 @@ int fs_codec_decode(fs_codec_t* c, const uint32_t* codes, int b, int T, float* p
 int fs_codec_encode(fs_codec_t* c, const float* pcm, int n_samples, uint32_t* codes_out, size_t cap, size_t* n_frames);
 /* FireflyCodec.sample_rate (codec/firefly.rs:13) */
 int fs_codec_sample_rate(fs_codec_t* c);
+/* Arithmetic of the decode path's wide convolutions (no reference counterpart: the reference runs the codec in f32,
+ * server/lib/utils/load.rs:161-164).  mode 1 (default) = "bf16x3": each f32 operand split into bf16 hi + lo, three bf16 matrix
+ * products per term, f32 accumulation -- PCM within the 1e-4 RMS acceptance bound of the f32 reference (measured ~1e-5);
+ * mode 0 = exact f32 products on the f32 matrix cores (~1e-6 of the oracle, ~2-3x slower).  The encoder always uses mode 0. */
+int fs_codec_set_precision(fs_codec_t* c, int mode);
+int fs_codec_precision(fs_codec_t* c);
 
 #ifdef __cplusplus
 }

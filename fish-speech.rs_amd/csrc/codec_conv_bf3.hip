@@ -24,6 +24,8 @@
 // The global loads of stage n+1 are in flight (registers) while stage n runs on the matrix cores.  Layers whose whole weight
 // set fits the stage (Cin <= 16 * NIBS: the thin 16/32-channel late stages) keep it resident in LDS and loop over time tiles.
 #include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
 #include <set>
 
 #include "codec_kernels.h"
@@ -66,13 +68,120 @@ __global__ void k_pack_bf3(const float* __restrict__ src, uint16_t* __restrict__
     }
 }
 
+// Activation planes: the split form of a (C, T) activation that the next convolution consumes,
+//   planes[part (0 = hi, 1 = lo)][C/8][CODEC_PLANE_PAD + T][8 bf16]      (per batch item; C % 16 == 0)
+// i.e. exactly the 16-byte MFMA B-operand slots of the x window, so staging is a straight copy (LDS-DMA: no registers, no VALU) or
+// no staging at all (thin layers load their B operands straight from the planes).  The producing kernel writes them from its
+// epilogue (SiLU of the consumer already applied): one activation is activated and split once, not once per (output-channel
+// block, 16-channel stage) of the consumer.  Every (part, group) row starts with CODEC_PLANE_PAD zero slots -- the causal left
+// padding -- written by the producer's first time tile, so a consumer never tests t >= 0; slots at t >= T may hold anything
+// (causality: they only feed outputs at t >= T, which are not stored; the engine over-allocates the tail).
+constexpr int PP = CODEC_PLANE_PAD;
+
+__device__ __forceinline__ void c3_zero_pad(uint16_t* pb, int CG, int T, int g_first, int n_groups, int tid, int nthreads) {
+    const u32x4 z{0u, 0u, 0u, 0u};
+    for (int e = tid; e < n_groups * 2 * PP; e += nthreads) {
+        const int slot = e % PP, gp = e / PP, g = g_first + (gp >> 1), part = gp & 1;
+        if (g < CG) *reinterpret_cast<u32x4*>(pb + ((size_t)(part * CG + g) * (PP + T) + slot) * 8) = z;
+    }
+}
+
+// f32 (C, T) -> planes, optional SiLU.  One thread per (8-channel group, t).
+__global__ void k_act_split(const float* __restrict__ x, int C, int T, int silu, uint16_t* __restrict__ planes) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y, CG = C >> 3;
+    const float* xb = x + (size_t)blockIdx.z * C * T;
+    uint16_t* pb = planes + (size_t)blockIdx.z * 2 * CG * (PP + T) * 8;
+    if (blockIdx.x == 0) c3_zero_pad(pb, CG, T, g, 1, threadIdx.x, blockDim.x);
+    if (t >= T) return;
+    u32x4 vh, vl;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float a = xb[(size_t)(g * 8 + 2 * e) * T + t], b = xb[(size_t)(g * 8 + 2 * e + 1) * T + t];
+        if (silu) { a = c3_silu(a); b = c3_silu(b); }
+        uint32_t ah, al, bh, bl;
+        c3_split(a, ah, al); c3_split(b, bh, bl);
+        vh[e] = ah | (bh << 16); vl[e] = al | (bl << 16);
+    }
+    *reinterpret_cast<u32x4*>(pb + ((size_t)g * (PP + T) + PP + t) * 8) = vh;
+    *reinterpret_cast<u32x4*>(pb + ((size_t)(CG + g) * (PP + T) + PP + t) * 8) = vl;
+}
+
+// ParallelBlock mean (hifi_gan.rs:114-117) straight into planes: split(silu?(((a + b) + c) / 3))
+__global__ void k_mean3_planes(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c, int C, int T, int silu,
+                               uint16_t* __restrict__ planes) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y, CG = C >> 3;
+    const size_t boff = (size_t)blockIdx.z * C * T;
+    uint16_t* pb = planes + (size_t)blockIdx.z * 2 * CG * (PP + T) * 8;
+    if (blockIdx.x == 0) c3_zero_pad(pb, CG, T, g, 1, threadIdx.x, blockDim.x);
+    if (t >= T) return;
+    const float third = (float)(1.0 / 3.0);
+    u32x4 vh, vl;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const size_t i0 = boff + (size_t)(g * 8 + 2 * e) * T + t, i1 = i0 + T;
+        float u = ((a[i0] + b[i0]) + c[i0]) * third, v = ((a[i1] + b[i1]) + c[i1]) * third;
+        if (silu) { u = c3_silu(u); v = c3_silu(v); }
+        uint32_t uh, ul, wh, wl;
+        c3_split(u, uh, ul); c3_split(v, wh, wl);
+        vh[e] = uh | (wh << 16); vl[e] = ul | (wl << 16);
+    }
+    *reinterpret_cast<u32x4*>(pb + ((size_t)g * (PP + T) + PP + t) * 8) = vh;
+    *reinterpret_cast<u32x4*>(pb + ((size_t)(CG + g) * (PP + T) + PP + t) * 8) = vl;
+}
+
+// Epilogue shared by the conv kernels.  D[row][col] of v_mfma_f32_32x32x*: register r of lane (h, c) holds row (r/4)*8 + h*4 + r%4,
+// column c.  ob = first GEMM row of the wave's 32-row tile, tbase = first sample of its NT 32-sample tiles; y / res already carry
+// the batch offset, ypb is the batch item's plane base (or null).
+template <int NT>
+__device__ __forceinline__ void c3_epilogue(const f32x16 (&acc)[NT], int ob, int tbase, int h, int c, int Cout, int T, int ps,
+                                            const float* __restrict__ bias, int epi, const float* __restrict__ res,
+                                            const float* __restrict__ gamma, float* __restrict__ y, uint16_t* __restrict__ ypb,
+                                            int post_silu) {
+    const int CGo = Cout >> 3;
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int t = tbase + j * 32 + c;
+            float v4[4];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int o = ob + q4 * 8 + h * 4 + rr;
+                float v = 0.f;
+                if (o < Cout && t < T) {
+                    v = acc[j][q4 * 4 + rr] + bias[o / ps];
+                    const size_t oi = (size_t)(o / ps) * T * ps + (size_t)t * ps + o % ps;  // (polyphase rows: see k_conv1d)
+                    if (epi == CODEC_EPI_GELU) v = c3_gelu(v);
+                    else if (epi == CODEC_EPI_GAMMA_RES) v = res[oi] + gamma[o] * v;
+                    else if (epi == CODEC_EPI_RES) v = res[oi] + v;
+                    else if (epi == CODEC_EPI_TANH) v = tanhf(v);
+                    if (y) y[oi] = v;
+                }
+                v4[rr] = v;
+            }
+            const int ob8 = ob + q4 * 8;  // first channel of this lane pair's 8-channel group
+            if (ypb && ob8 < Cout && t < T) {
+                uint32_t hi[4], lo[4];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) c3_split(post_silu ? c3_silu(v4[rr]) : v4[rr], hi[rr], lo[rr]);
+                uint16_t* d = ypb + ((size_t)(ob8 >> 3) * (PP + T) + PP + t) * 8 + h * 4;
+                *reinterpret_cast<uint2*>(d) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
+                *reinterpret_cast<uint2*>(d + (size_t)CGo * (PP + T) * 8) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // one 8-row group at a time: bounds the residual loads / row addresses in flight (VGPRs)
+    }
+}
+
+// ---- f32 input (the first convs of the decode path, whose producers are not plane writers): registers -> SiLU / split -> LDS.
 // OT: output channels per block (64 | 32); TT: samples per block; NIBS: 16-channel blocks per stage; KMAX: largest tap count the
-// register prefetch is sized for; NPX: window positions per thread (XS = TT + halo <= 256 * NPX)
+// register prefetch is sized for; NPX: window positions per thread (XS = TT + halo <= 256 * NPX).
+// Outputs: f32 `y` (may be null when only planes are wanted) and / or planes `yp` (ps == 1 only) = split(post_silu ? silu(v) : v)
 template <int OT, int TT, int NIBS, int KMAX, int NPX>
 __global__ __launch_bounds__(256) void k_conv1d_bf3(const float* __restrict__ x, int Cin, int T, const uint16_t* __restrict__ wp, int Cp,
                                                     const float* __restrict__ bias, int Cout, int K, int dil, int pre_silu, int epi,
                                                     const float* __restrict__ res, const float* __restrict__ gamma, float* __restrict__ y,
-                                                    int ps, int ntiles) {
+                                                    uint16_t* __restrict__ yp, int post_silu, int ps, int ntiles) {
     constexpr int WT_ = OT == 64 ? TT / 2 : TT / 4;  // samples per wave
     constexpr int NT = WT_ / 32;                     // 32-sample MFMA tiles per wave
     static_assert(NT >= 1 && (OT == 64 || OT == 32), "block shape");
@@ -187,25 +296,155 @@ __global__ __launch_bounds__(256) void k_conv1d_bf3(const float* __restrict__ x,
                 }
             }
         }
-        // D[row][col]: register r of lane (h, c) holds row (r/4)*8 + h*4 + r%4, column c
+        uint16_t* ypb = yp ? yp + (size_t)blockIdx.z * 2 * (Cout >> 3) * (PP + T) * 8 : nullptr;
+        if (ypb && t0 == 0) c3_zero_pad(ypb, Cout >> 3, T, o0 >> 3, OT / 8, tid, 256);
+        c3_epilogue<NT>(acc, o0 + ob, t0 + tb, h, c, Cout, T, ps, bias, epi, res ? res + boff_out : nullptr, gamma, y ? y + boff_out : nullptr,
+                        ypb, post_silu);
+    }
+}
+
+// ---- plane input, wide layers (Cin >= 64): one 16-channel block per stage, x window and weight tile staged by LDS-DMA
+// (global_load_lds_dwordx4: 64 consecutive 16-byte slots per wave instruction, destination = wave-uniform base + lane * 16, source =
+// uniform base + lane * 16: no per-lane address arithmetic, no staging registers).  Two or three blocks share a CU (LDS 42..65 KB
+// each), so one block's DMA wait overlaps another's MFMA phase.  Requires Cin % 16 == 0.
+template <int OT, int TT, int KMAX>
+__global__ __launch_bounds__(256, 2) void k_conv1d_bf3p(const uint16_t* __restrict__ xp, int Cin, int T, const uint16_t* __restrict__ wp,
+                                                        int Cp, const float* __restrict__ bias, int Cout, int K, int dil, int epi,
+                                                        const float* __restrict__ res, const float* __restrict__ gamma,
+                                                        float* __restrict__ y, uint16_t* __restrict__ yp, int post_silu, int ps) {
+    constexpr int WT_ = OT == 64 ? TT / 2 : TT / 4, NT = WT_ / 32;
+    static_assert(NT >= 1 && (OT == 64 || OT == 32), "block shape");
+    constexpr int NWP = (KMAX * 4 * OT + 255) / 256;  // weight DMA pieces (256 chunks each) per stage, upper bound
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int halo = (K - 1) * dil, XSP = (TT + halo + 63) & ~63;
+    const int nib = Cin >> 4, CGi = Cin >> 3;
+    u32x4* xs = reinterpret_cast<u32x4*>(smem_raw);  // [4][XSP]
+    u32x4* ws = xs + 4 * XSP;                        // [K][4][OT]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, c = lane & 31;
+    const int ob = OT == 64 ? (wave & 1) * 32 : 0, tb = OT == 64 ? (wave >> 1) * WT_ : wave * WT_;
+    const int o0 = blockIdx.y * OT, t0 = blockIdx.x * TT;
+    const size_t boff_out = (size_t)blockIdx.z * Cout * T;
+    const size_t row = (size_t)(PP + T);  // slots per (part, group) row
+    const u32x4* xpb = reinterpret_cast<const u32x4*>(xp) + (size_t)blockIdx.z * 2 * CGi * row + (PP + t0 - halo) + lane;
+    // weight chunk (piece j, wave, lane) = chunk index e = j*256 + wave*64 + lane -> row kp = e / OT, column e % OT
+    const int wl_off = OT == 64 ? lane : (lane >> 5) * Cp + (lane & 31);
+    const u32x4* wpl = reinterpret_cast<const u32x4*>(wp) + o0 + wl_off;
+    const int wtotal = K * 4 * OT;  // chunks per stage: a multiple of 64, so a piece is whole per wave
+    auto dma = [&](const u32x4* src, u32x4* dst_wave_base) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst_wave_base, 16, 0, 0);
+    };
+    f32x16 acc[NT];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int o = o0 + ob + (r >> 2) * 8 + h * 4 + (r & 3);
-            if (o >= Cout) continue;
-            const float bv = bias[o / ps];
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int ib = 0; ib < nib; ++ib) {
+        __syncthreads();  // previous stage's LDS reads are done
+        // x window: 4 planes (hi / lo x channel half) of XSP slots
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const u32x4* src = xpb + ((size_t)((p >> 1) * CGi + 2 * ib + (p & 1))) * row;
+            for (int q = wave * 64; q < XSP; q += 256) dma(src + q, xs + p * XSP + q);
+        }
+        // weight tile [K][4][OT] of this channel block: chunk rows are Cp apart in global memory
+        {
+            const u32x4* src = wpl + (size_t)ib * K * 4 * Cp;
+            constexpr int RPP = 256 / OT;  // chunk rows per piece
+#pragma unroll
+            for (int j = 0; j < NWP; ++j)
+                if (j * 256 + wave * 64 < wtotal) dma(src + (size_t)(j * RPP + (OT == 64 ? wave : wave * 2)) * Cp, ws + j * 256 + wave * 64);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const u32x4* wl = ws + h * OT + ob + c;
+        const u32x4* xl = xs + h * XSP + tb + c;
+        for (int k = 0; k < K; ++k) {
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, wl[k * 4 * OT]), al = __builtin_bit_cast(bf16x8, wl[(k * 4 + 2) * OT]);
+            const u32x4* xk = xl + k * dil;
+            // (per accumulator the order stays hi*hi, hi*lo, lo*hi; the NT tiles are interleaved so that dependent MFMAs are NT apart)
+            bf16x8 bh[NT], bl[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) { bh[j] = __builtin_bit_cast(bf16x8, xk[32 * j]); bl[j] = __builtin_bit_cast(bf16x8, xk[2 * XSP + 32 * j]); }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[j], 0, 0, 0);
+        }
+    }
+    uint16_t* ypb = yp ? yp + (size_t)blockIdx.z * 2 * (Cout >> 3) * row * 8 : nullptr;
+    if (ypb && t0 == 0) c3_zero_pad(ypb, Cout >> 3, T, o0 >> 3, OT / 8, tid, 256);
+    c3_epilogue<NT>(acc, o0 + ob, t0 + tb, h, c, Cout, T, ps, bias, epi, res ? res + boff_out : nullptr, gamma, y ? y + boff_out : nullptr, ypb,
+                    post_silu);
+}
+
+// ---- plane input, thin layers (Cin = 16 * NIB <= 32: the 16 / 32-channel late stages, 40 % of the decode's samples x convs).
+// These are bound by activation traffic, not by the matrix cores, so nothing is staged and nothing synchronises: the block's weight
+// set (<= 45 KB) is loaded into LDS once, then every wave walks over its own 32-channel x (32 * NT)-sample tiles and loads its MFMA
+// B operands -- 16-byte plane slots, 512 contiguous bytes per half-wave -- straight from global memory (the K taps of a tile re-read
+// the same window from L1/L2).  No barrier after the weight load, so a CU keeps as many independent waves in flight as registers allow.
+template <int K, int NIB, int NT>
+__global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void k_conv1d_bf3t(const uint16_t* __restrict__ xp, int T, const uint16_t* __restrict__ wp, int Cp,
+                                                        const float* __restrict__ bias, int Cout, int dil, int epi,
+                                                        const float* __restrict__ res, const float* __restrict__ gamma,
+                                                        float* __restrict__ y, uint16_t* __restrict__ yp, int post_silu, int ps, int nwt) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32x4* ws = reinterpret_cast<u32x4*>(smem_raw);  // [NIB][K][4][32]
+    constexpr int CGi = NIB * 2, WCH = NIB * K * 4 * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, c = lane & 31;
+    const int o0 = blockIdx.y * 32, halo = (K - 1) * dil;
+    const size_t row = (size_t)(PP + T);
+    for (int e = tid; e < WCH; e += 256) {
+        const int kp = e >> 5, o = e & 31;  // kp = (ib * K + k) * 4 + plane
+        ws[e] = *reinterpret_cast<const u32x4*>(wp + ((size_t)kp * Cp + o0 + o) * 8);
+    }
+    __syncthreads();
+    const u32x4* xpb = reinterpret_cast<const u32x4*>(xp) + (size_t)blockIdx.z * 2 * CGi * row + PP - halo + c;
+    const size_t boff_out = (size_t)blockIdx.z * Cout * T;
+    uint16_t* ypb = yp ? yp + (size_t)blockIdx.z * 2 * (Cout >> 3) * row * 8 : nullptr;
+    if (ypb && blockIdx.x == 0) c3_zero_pad(ypb, Cout >> 3, T, o0 >> 3, 4, tid, 256);
+    for (int wt = blockIdx.x * 4 + wave; wt < nwt; wt += gridDim.x * 4) {
+        const int t0 = wt * (32 * NT);
+        f32x16 acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        // flattened (channel block, tap) loop with the next step's B operands in flight while this step runs on the matrix cores
+        const u32x4* xw = xpb + (size_t)h * row + t0;  // hi plane of this lane's channel half; lo plane = + CGi rows
+        auto bsrc = [&](int i) { return xw + (size_t)(2 * (i / K)) * row + (i % K) * dil; };
+        u32x4 bh[NT], bl[NT], nh[NT], nl[NT];
+        {
+            const u32x4* b0 = bsrc(0);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) { bh[j] = b0[32 * j]; bl[j] = b0[(size_t)CGi * row + 32 * j]; }
+        }
+#pragma unroll 2
+        for (int i = 0; i < NIB * K; ++i) {
+            if (i + 1 < NIB * K) {
+                const u32x4* b1 = bsrc(i + 1);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) { nh[j] = b1[32 * j]; nl[j] = b1[(size_t)CGi * row + 32 * j]; }
+            }
+            const u32x4* wl = ws + (i * 4 + h) * 32 + c;
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, wl[0]), al = __builtin_bit_cast(bf16x8, wl[64]);
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                const int t = t0 + tb + j * 32 + c;
-                if (t >= T) continue;
-                float v = acc[j][r] + bv;
-                const size_t oi = boff_out + (size_t)(o / ps) * T * ps + (size_t)t * ps + o % ps;  // (polyphase rows: see k_conv1d)
-                if (epi == CODEC_EPI_GELU) v = c3_gelu(v);
-                else if (epi == CODEC_EPI_GAMMA_RES) v = res[oi] + gamma[o] * v;
-                else if (epi == CODEC_EPI_RES) v = res[oi] + v;
-                else if (epi == CODEC_EPI_TANH) v = tanhf(v);
-                y[oi] = v;
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, bh[j]), acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, bl[j]), acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, __builtin_bit_cast(bf16x8, bh[j]), acc[j], 0, 0, 0);
             }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) { bh[j] = nh[j]; bl[j] = nl[j]; }
         }
+        int Tl = T;  // opaque per tile: keeps the epilogue's ~100 row addresses from being hoisted out of the tile loop (200+ VGPRs)
+        asm volatile("" : "+s"(Tl));
+        c3_epilogue<NT>(acc, o0, t0, h, c, Cout, Tl, ps, bias, epi, res ? res + boff_out : nullptr, gamma, y ? y + boff_out : nullptr, ypb,
+                        post_silu);
     }
 }
 
@@ -225,31 +464,90 @@ void codec_pack_bf3(const float* relaid, uint16_t* dst, int Cin, int K, int Cout
 
 bool codec_conv1d_bf3_ok(int Cin, int Cout, int K, int dil) { return Cin >= 16 && Cout >= 16 && K <= 13 && (K - 1) * dil <= 256; }
 
-// x (B, Cin, T) -> y; `Cout` = GEMM rows (channels * ps for a polyphase transposed conv)
-void codec_conv1d_bf3(const float* x, int B, int Cin, int T, const uint16_t* wp, const float* bias, int Cout, int K, int dil, bool pre_silu,
-                      int epi, const float* res, const float* gamma, float* y, int ps, hipStream_t st) {
+// x (B, Cin, T) f32 or xp (activation planes) -> y (f32, may be null) and / or yp (planes, ps == 1); `Cout` = GEMM rows (channels * ps
+// for a polyphase transposed conv)
+void codec_conv1d_bf3(const float* x, const uint16_t* xp, int B, int Cin, int T, const uint16_t* wp, const float* bias, int Cout, int K,
+                      int dil, bool pre_silu, int epi, const float* res, const float* gamma, float* y, uint16_t* yp, bool post_silu, int ps,
+                      hipStream_t st) {
     FS_REQUIRE(codec_conv1d_bf3_ok(Cin, Cout, K, dil), "conv shape outside the bf16x3 kernel's range");
+    FS_REQUIRE((x != nullptr) != (xp != nullptr), "exactly one of the f32 input and the plane input");
+    FS_REQUIRE(y || yp, "no output");
+    FS_REQUIRE(!yp || (ps == 1 && Cout % 8 == 0), "plane output needs a plain conv with a multiple of 8 channels");
     const int Cp = (Cout + 63) / 64 * 64, halo = (K - 1) * dil, nib = (Cin + 15) / 16;
-    auto go = [&](auto kern, int OT, int TT, int NIBS, bool loop_tiles) {
-        const int XS = TT + halo;
-        const size_t smem = 16 * ((size_t)NIBS * 4 * XS + (size_t)NIBS * K * 4 * OT);
+    auto raise_lds = [&](const void* kern, size_t smem) {
         FS_REQUIRE(smem <= 160 * 1024, "conv tile does not fit LDS");
         if (smem > 64 * 1024) {  // above the default dynamic-LDS limit: raise it once per kernel
             static thread_local std::set<const void*> raised;
-            if (raised.insert((const void*)kern).second)
-                FS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            if (raised.insert(kern).second) FS_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         }
+    };
+    if (xp) {
+        FS_REQUIRE(Cin % 16 == 0 && halo <= CODEC_PLANE_PAD, "plane input needs Cin % 16 == 0 and a halo within the plane padding");
+        if (nib <= 2 && (K == 2 || K == 3 || K == 7 || K == 11)) {
+            // thin late stages: B operands straight from the planes, weights resident in LDS, no barriers
+            static const int NT = getenv("FISHRT_BF3T_NT") ? atoi(getenv("FISHRT_BF3T_NT")) : 1;  // tuning knob: 32-sample tiles per wave (1: 3 blocks per CU, measured best | 2)
+            const int nwt = (T + 32 * NT - 1) / (32 * NT), ytiles = (Cout + 31) / 32;
+            const int gx = std::max(1, std::min((nwt + 3) / 4, (NT == 1 ? 768 : 512) / std::max(1, ytiles * B)));  // 2-3 blocks per CU, each walking over tiles
+            const size_t smem = (size_t)nib * K * 4 * 32 * 16;
+            auto go = [&](auto kern) {
+                raise_lds((const void*)kern, smem);
+                hipLaunchKernelGGL(kern, dim3(gx, ytiles, B), dim3(256), smem, st, xp, T, wp, Cp, bias, Cout, dil, epi, res, gamma, y, yp,
+                                   post_silu ? 1 : 0, ps, nwt);
+            };
+#define FS_THIN(KK)                                                   \
+    do {                                                              \
+        if (nib == 1 && NT == 1) go(k_conv1d_bf3t<KK, 1, 1>);         \
+        else if (nib == 1) go(k_conv1d_bf3t<KK, 1, 2>);               \
+        else if (NT == 1) go(k_conv1d_bf3t<KK, 2, 1>);                \
+        else go(k_conv1d_bf3t<KK, 2, 2>);                             \
+    } while (0)
+            if (K == 2) FS_THIN(2);
+            else if (K == 3) FS_THIN(3);
+            else if (K == 7) FS_THIN(7);
+            else FS_THIN(11);
+#undef FS_THIN
+        } else {
+            auto go = [&](auto kern, int OT, int TT) {
+                const int XSP = (TT + halo + 63) & ~63;
+                const size_t smem = 16 * ((size_t)4 * XSP + (size_t)K * 4 * OT);
+                raise_lds((const void*)kern, smem);
+                hipLaunchKernelGGL(kern, dim3((T + TT - 1) / TT, (Cout + OT - 1) / OT, B), dim3(256), smem, st, xp, Cin, T, wp, Cp, bias, Cout,
+                                   K, dil, epi, res, gamma, y, yp, post_silu ? 1 : 0, ps);
+            };
+            FS_REQUIRE(K <= 13, "tap count above the plane kernel's staging bound");
+            static const char* cfg = getenv("FISHRT_BF3P_CFG");  // tuning knob: "ot,tt" forces one tile shape
+            int fot = 0, ftt = 0;
+            if (cfg) sscanf(cfg, "%d,%d", &fot, &ftt);
+            if (fot == 64 && ftt == 256) go(k_conv1d_bf3p<64, 256, 13>, 64, 256);
+            else if (fot == 64 && ftt == 128) go(k_conv1d_bf3p<64, 128, 13>, 64, 128);
+            else if (fot == 32 && ftt == 256) go(k_conv1d_bf3p<32, 256, 13>, 32, 256);
+            else if (fot == 32 && ftt == 128) go(k_conv1d_bf3p<32, 128, 13>, 32, 128);
+            else {
+                // measured per tile shape (profiles/r02_vocoder_calls.txt): 32-channel blocks win everywhere (3 blocks per CU instead of 2);
+                // 256-sample blocks where that still leaves >= 1024 blocks, else 128
+                const long long b256 = (long long)((T + 255) / 256) * ((Cout + 31) / 32) * B;
+                if (b256 >= 1024) go(k_conv1d_bf3p<32, 256, 13>, 32, 256);
+                else go(k_conv1d_bf3p<32, 128, 13>, 32, 128);
+            }
+        }
+        FS_HIP(hipGetLastError());
+        return;
+    }
+    auto go = [&](auto kern, int OT, int TT, int NIBS, bool loop_tiles) {
+        const int XS = TT + halo;
+        const size_t smem = 16 * ((size_t)NIBS * 4 * XS + (size_t)NIBS * K * 4 * OT);
+        raise_lds((const void*)kern, smem);
         const int ntiles = (T + TT - 1) / TT, ytiles = (Cout + OT - 1) / OT;
         int gx = ntiles;
         if (loop_tiles) gx = std::max(1, std::min(ntiles, 1024 / std::max(1, ytiles * B)));  // weights stay in LDS over a loop of time tiles
         hipLaunchKernelGGL(kern, dim3(gx, ytiles, B), dim3(256), smem, st, x, Cin, T, wp, Cp, bias, Cout, K, dil, pre_silu ? 1 : 0, epi, res,
-                           gamma, y, ps, ntiles);
+                           gamma, y, yp, post_silu ? 1 : 0, ps, ntiles);
     };
     if (K == 1 && Cin >= 128) {
         // pointwise convs of the ConvNeXt blocks (frame-rate T, 512..2048 channels): 8 channel blocks per barrier pair
         go(k_conv1d_bf3<32, 128, 8, 1, 1>, 32, 128, 8, false);
     } else if (nib <= 2) {
-        // thin late stages (16 / 32 channels): the whole weight set is resident, the block walks over time tiles
+        // thin layers: the whole weight set is resident, the block walks over time tiles
         if (nib == 1) go(k_conv1d_bf3<32, 256, 1, 13, 2>, 32, 256, 1, true);
         else go(k_conv1d_bf3<32, 128, 2, 13, 2>, 32, 128, 2, true);
     } else {
@@ -261,6 +559,18 @@ void codec_conv1d_bf3(const float* x, int B, int Cin, int T, const uint16_t* wp,
         else if (wide) go(k_conv1d_bf3<32, 256, 1, 13, 2>, 32, 256, 1, false);
         else go(k_conv1d_bf3<32, 128, 1, 13, 2>, 32, 128, 1, false);
     }
+    FS_HIP(hipGetLastError());
+}
+
+void codec_act_split(const float* x, int B, int C, int T, bool silu, uint16_t* planes, hipStream_t st) {
+    FS_REQUIRE(C % 8 == 0, "activation planes need a multiple of 8 channels");
+    hipLaunchKernelGGL(k_act_split, dim3((T + 255) / 256, C / 8, B), dim3(256), 0, st, x, C, T, silu ? 1 : 0, planes);
+    FS_HIP(hipGetLastError());
+}
+
+void codec_mean3_planes(const float* a, const float* b, const float* c, int B, int C, int T, bool silu, uint16_t* planes, hipStream_t st) {
+    FS_REQUIRE(C % 8 == 0, "activation planes need a multiple of 8 channels");
+    hipLaunchKernelGGL(k_mean3_planes, dim3((T + 255) / 256, C / 8, B), dim3(256), 0, st, a, b, c, C, T, silu ? 1 : 0, planes);
     FS_HIP(hipGetLastError());
 }
 

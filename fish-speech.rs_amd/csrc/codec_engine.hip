@@ -122,14 +122,44 @@ class Codec final : public CodecBase {
             codec_conv1d(r, B, 4 * C_, Tc, conv(c.pw2), 1, false, CODEC_EPI_GAMMA_RES, t1, R(c.gamma), x, st_);
         }
         // HiFiGAN (hifi_gan.rs:208-216)
-        codec_conv1d(x, B, C_, Tc, conv(conv_pre_), 1, false, CODEC_EPI_NONE, nullptr, nullptr, t1, st_);
-        std::swap(x, t1);
         const int rates[5] = {8, 8, 2, 2, 2}, dils[3] = {1, 3, 5};
+        // bf16x3 mode: stages whose convs all fit the split-bf16 kernel exchange "activation planes" (bf16 hi / lo of silu(x), written by
+        // the producer's epilogue, codec_conv_bf3.hip) instead of f32: the consumer stages them by LDS-DMA and never re-activates
+        auto stage_planes = [&](int s) { return use_bf3_now_ && s < 5 && (C_ >> (s + 1)) >= 16 && (C_ >> s) % 16 == 0; };
+        uint16_t *xp = nullptr, *t1p = nullptr, *t2p = nullptr, *accp = nullptr;
+        if (stage_planes(0)) {
+            // 2 parts x 2 bytes = the f32 footprint, + the zero padding in front of every row + slack for window reads past T
+            for (auto& b : pbuf_) b.ensure(act * sizeof(float) + (size_t)B * C_ * CODEC_PLANE_PAD * 4 + (256 << 10));
+            xp = pbuf_[0].u16(); t1p = pbuf_[1].u16(); t2p = pbuf_[2].u16(); accp = pbuf_[3].u16();
+            codec_conv1d_planes(x, nullptr, B, C_, Tc, conv(conv_pre_), 1, false, CODEC_EPI_NONE, nullptr, nullptr, nullptr, xp, true, st_);
+        } else {
+            codec_conv1d(x, B, C_, Tc, conv(conv_pre_), 1, false, CODEC_EPI_NONE, nullptr, nullptr, t1, st_);
+            std::swap(x, t1);
+        }
         int ch = C_;
         for (int s = 0; s < 5; ++s) {
+            float* accs[3] = {acc0, acc1, acc2};
+            if (stage_planes(s)) {
+                codec_tconv1d_planes(xp, B, ch, Tc, conv(ups_[s]), rates[s], t1, st_);  // ups[i](silu(x)); xp holds split(silu(x))
+                ch /= 2; Tc *= rates[s];
+                codec_act_split(t1, B, ch, Tc, true, t1p, st_);
+                for (int j = 0; j < 3; ++j) {  // ResBlock1 (hifi_gan.rs:74-85): x += c2(silu(c1(silu(x)))), both convs dilated
+                    const float* cur = t1;
+                    const uint16_t* curp = t1p;
+                    for (int m = 0; m < 3; ++m) {
+                        codec_conv1d_planes(nullptr, curp, B, ch, Tc, conv(res_[s][j][0][m]), dils[m], true, CODEC_EPI_NONE, nullptr, nullptr,
+                                            nullptr, t2p, true, st_);
+                        codec_conv1d_planes(nullptr, t2p, B, ch, Tc, conv(res_[s][j][1][m]), dils[m], true, CODEC_EPI_RES, cur, nullptr, accs[j],
+                                            m < 2 ? accp : nullptr, true, st_);
+                        cur = accs[j]; curp = accp;
+                    }
+                }
+                if (stage_planes(s + 1)) codec_mean3_planes(acc0, acc1, acc2, B, ch, Tc, true, xp, st_);
+                else codec_mean3(acc0, acc1, acc2, x, (size_t)B * ch * Tc, st_);
+                continue;
+            }
             codec_tconv1d(x, B, ch, Tc, conv(ups_[s]), rates[s], true, t1, st_);  // ups[i](silu(x))
             ch /= 2; Tc *= rates[s];
-            float* accs[3] = {acc0, acc1, acc2};
             for (int j = 0; j < 3; ++j) {  // ResBlock1 (hifi_gan.rs:74-85): x += c2(silu(c1(silu(x)))), both convs dilated
                 const float* cur = t1;
                 for (int m = 0; m < 3; ++m) {
@@ -401,7 +431,7 @@ class Codec final : public CodecBase {
     std::vector<ConvSpec> convs_;
     std::vector<size_t> relaid_off_;
     size_t raw_floats_ = 0, relaid_floats_ = 0;
-    DBuf raw_, relaid_, packed_, dcodes_, buf_[7];
+    DBuf raw_, relaid_, packed_, dcodes_, buf_[7], pbuf_[4];
     std::vector<size_t> packed_off_;
     bool bf3_ = true, use_bf3_now_ = false;  // decode precision mode (fs_codec_set_precision); the encoder always runs exact f32
     int proj_w_ = 0, proj_b_ = 0, up_conv_[2] = {0, 0}, conv_pre_ = 0, conv_post_ = 0, ups_[5] = {0, 0, 0, 0, 0};

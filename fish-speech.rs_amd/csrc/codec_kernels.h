@@ -14,6 +14,7 @@ struct ConvW {
     const uint16_t* wp = nullptr;  // bf16 hi/lo split, MFMA A-operand order (codec_pack_bf3); nullptr = exact-f32 kernels only
 };
 
+constexpr int CODEC_PLANE_PAD = 64;  // zero slots in front of every activation-plane row (>= the largest halo of a plane consumer)
 enum { CODEC_EPI_NONE = 0, CODEC_EPI_GELU = 1, CODEC_EPI_GAMMA_RES = 2, CODEC_EPI_RES = 3, CODEC_EPI_TANH = 4 };
 
 void codec_fsq_project(const uint32_t* codes, int B, int G, int T, const float* pw, const float* pb, int dg, float* z, hipStream_t st);
@@ -32,8 +33,17 @@ void codec_relayout_tconv(const float* src, float* dst, int Cout, int Cin, int K
 size_t codec_pack_bf3_elems(int Cin, int K, int Cout);
 void codec_pack_bf3(const float* relaid /*[Cin][K][Cout]*/, uint16_t* dst, int Cin, int K, int Cout, hipStream_t st);
 bool codec_conv1d_bf3_ok(int Cin, int Cout, int K, int dil);
-void codec_conv1d_bf3(const float* x, int B, int Cin, int T, const uint16_t* wp, const float* bias, int Cout, int K, int dil, bool pre_silu,
-                      int epi, const float* res, const float* gamma, float* y, int ps, hipStream_t st);
+// input: f32 `x` (B, Cin, T) or activation planes `xp` ([B][2][Cin/8][T][8] bf16 hi / lo, the consumer's SiLU already applied);
+// output: f32 `y` and / or planes `yp` = split(post_silu ? silu(v) : v) (plain convs only)
+void codec_conv1d_bf3(const float* x, const uint16_t* xp, int B, int Cin, int T, const uint16_t* wp, const float* bias, int Cout, int K,
+                      int dil, bool pre_silu, int epi, const float* res, const float* gamma, float* y, uint16_t* yp, bool post_silu, int ps,
+                      hipStream_t st);
+void codec_act_split(const float* x, int B, int C, int T, bool silu, uint16_t* planes, hipStream_t st);
+void codec_mean3_planes(const float* a, const float* b, const float* c, int B, int C, int T, bool silu, uint16_t* planes, hipStream_t st);
+// conv / transposed conv of the plane data flow (decode path, bf16x3 mode): see codec_conv1d_bf3
+void codec_conv1d_planes(const float* x, const uint16_t* xp, int B, int Cin, int T, const ConvW& w, int dil, bool pre_silu, int epi,
+                         const float* res, const float* gamma, float* y, uint16_t* yp, bool post_silu, hipStream_t st);
+void codec_tconv1d_planes(const uint16_t* xp, int B, int Cin, int Tin, const ConvW& w, int stride, float* y, hipStream_t st);
 // ---- encoder side (FireflyCodec::encode)
 void codec_stft_mag(const float* pcm, int n, int n_fft, int hop, int n_frames, float* lin /*[n_fft/2+1][frames]*/, hipStream_t st);
 void codec_mel_log(const float* lin, const float* fb /*[nf][n_mels]*/, int nf, int n_mels, int F, float* mel /*[n_mels][F]*/, hipStream_t st);

@@ -125,6 +125,21 @@ int fs_lm_generate_batch(fs_lm_t* lm, const uint32_t* prompts, const int* lens, 
     FS_ARG(lm && prompts && lens && sampling && codes_out && n_frames, "null argument");
     FS_TRY(lm->impl->generate_batch(prompts, lens, n, max_new_tokens, *sampling, seed, flags, codes_out, cap, n_frames))
 }
+int fs_lm_session_begin(fs_lm_t* lm, const fs_sampling* sampling, uint64_t seed, uint32_t flags) {
+    FS_ARG(lm && sampling, "null argument");
+    FS_TRY(lm->impl->session_begin(*sampling, seed, flags))
+}
+int fs_lm_session_add(fs_lm_t* lm, const uint32_t* prompt, int L, int max_new_tokens, int* slot) {
+    FS_ARG(lm && prompt && slot, "null argument");
+    FS_TRY(*slot = lm->impl->session_add(prompt, L, max_new_tokens))
+}
+int fs_lm_session_step(fs_lm_t* lm, int n_frames, int* n_active) { FS_ARG(lm, "null argument"); FS_TRY(lm->impl->session_step(n_frames, n_active)) }
+int fs_lm_session_poll(fs_lm_t* lm, int slot, uint32_t* codes_out, size_t cap, size_t* n_frames, int* done) {
+    FS_ARG(lm, "null argument");
+    FS_TRY(lm->impl->session_poll(slot, codes_out, cap, n_frames, done))
+}
+int fs_lm_session_release(fs_lm_t* lm, int slot) { FS_ARG(lm, "null argument"); FS_TRY(lm->impl->session_release(slot)) }
+int fs_lm_session_end(fs_lm_t* lm) { FS_ARG(lm, "null argument"); FS_TRY(lm->impl->session_end()) }
 int fs_lm_last_stats(fs_lm_t* lm, fs_gen_stats* out) { FS_ARG(lm && out, "null argument"); FS_TRY(*out = lm->impl->last_stats()) }
 void* fs_lm_stream(fs_lm_t* lm) { return lm ? lm->impl->stream() : nullptr; }
 int fs_lm_bench_kernel(fs_lm_t* lm, int kind, int kv_len, int reps, float* us_per_launch) {

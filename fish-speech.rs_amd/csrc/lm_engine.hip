@@ -191,6 +191,7 @@ class LM final : public LMBase {
     void forward_generate(const uint32_t* toks, int B, int L, int input_pos, float* logits, float* hidden) override {
         use_device();
         require_loaded();
+        FS_REQUIRE(!sess_active_, "the handle is in session mode (fs_lm_session_end first)");
         FS_REQUIRE(B >= 1 && B <= B_, "batch size exceeds the handle's max_batch");
         FS_REQUIRE(L >= 1, "empty input");
         const int C1 = a_.num_codebooks + 1;
@@ -314,6 +315,7 @@ class LM final : public LMBase {
                   size_t* n_hidden) override {
         use_device();
         require_loaded();
+        FS_REQUIRE(!sess_active_, "the handle is in session mode (fs_lm_session_end first)");
         const int C = a_.num_codebooks, C1 = C + 1;
         FS_REQUIRE(L >= 1, "empty prompt");
         FS_REQUIRE(max_new_tokens >= 0, "negative max_new_tokens");
@@ -499,6 +501,7 @@ class LM final : public LMBase {
     void generate_batch(const uint32_t* prompts, const int* lens, int n, int max_new_tokens, const fs_sampling& s, uint64_t seed,
                         uint32_t flags, uint32_t* codes_out, size_t cap, size_t* n_frames) override {
         FS_REQUIRE(n >= 1, "Must have at least one prompt");  // static_batch.rs:69-71
+        FS_REQUIRE(!sess_active_, "the handle is in session mode (fs_lm_session_end first)");
         if (LmKernels<WT>::has_mfma_prefill() && n <= kRows && n <= B_ && a_.dim % 128 == 0 && a_.intermediate_size % 128 == 0 &&
             a_.num_codebooks <= 8 && !legacy_) {
             generate_batch_rows(prompts, lens, n, max_new_tokens, s, seed, flags, codes_out, cap, n_frames);
@@ -640,6 +643,172 @@ class LM final : public LMBase {
             seq_len_[b] = hs[b].pos;
         }
         stats_.frames = total;
+    }
+
+    // ---- continuous batching: the rows of the static-batch step as independent request slots.  No reference counterpart (the reference
+    // serialises requests behind one mutex, server/lib/state.rs:12-29, or runs lock-step static batches, static_batch.rs:282-390); a slot
+    // behaves exactly like row 0 of a one-prompt generate_static_batch: no left padding (its own positions / KV pages), first frame
+    // emitted unconditionally, BatchedLogitsProcessor sampling, no repetition penalty, 1 + max(0, max_new_tokens - L + 1) iterations.
+    // Requests join between steps (their prompt is prefilled on the row path while the other slots wait) and leave when done.
+    void session_begin(const fs_sampling& s, uint64_t seed, uint32_t flags) override {
+        use_device();
+        require_loaded();
+        FS_REQUIRE(!sess_active_, "a session is already open on this handle");
+        FS_REQUIRE(LmKernels<WT>::has_mfma_prefill() && B_ <= kRows && a_.dim % 128 == 0 && a_.intermediate_size % 128 == 0 &&
+                       a_.num_codebooks <= 8 && !legacy_ && t_.has_semantic_end && t_.im_end_id + 1 == t_.semantic_start_id,
+                   "sessions need the MFMA row path (bf16 / fp8 handle, Fish 1.5 token layout)");
+        clear_slow();
+        clear_fast();
+        ensure_prefill_buffers();
+        ensure_batch_buffers();
+        SampleCfg cfg = base_cfg();
+        cfg.temp = (float)s.temp; cfg.top_p = (float)s.top_p;
+        cfg.top_k = (int)std::min<uint64_t>(s.top_k, 1u << 30);
+        cfg.rep_pen = 1.0f; cfg.ignore_eos = (flags & FS_GEN_IGNORE_EOS) ? 1 : 0;
+        cfg.session = 1;
+        FS_HIP(hipMemcpyAsync(d_cfg_.p, &cfg, sizeof(cfg), hipMemcpyHostToDevice, st_));
+        RngState rng = {};
+        seed_key(seed, rng.key);
+        FS_HIP(hipMemcpyAsync(d_rng_.p, &rng, sizeof(rng), hipMemcpyHostToDevice, st_));
+        // empty slots: dead, frame 1 (so the frame-0 rule never fires), position 0 of a scratch page nobody reads
+        FS_REQUIRE(!free_pages_.empty(), "KV page pool exhausted");
+        sess_scratch_ = free_pages_.back();
+        free_pages_.pop_back();
+        sess_left_.assign(B_, -1);
+        sess_pos_.assign(B_, 0);
+        sess_hs_.assign(B_, SeqState{});
+        for (int b = 0; b < B_; ++b) park_slot(b);
+        if (d_sess_x_.n < sizeof(float) * (size_t)B_ * a_.dim) d_sess_x_.alloc(sizeof(float) * (size_t)B_ * a_.dim);
+        FS_HIP(hipMemsetAsync(d_pfx_.p, 0, sizeof(float) * (size_t)B_ * a_.dim, st_));
+        FS_HIP(hipStreamSynchronize(st_));
+        stats_ = {};
+        sess_active_ = true;
+    }
+    void park_slot(int b) {
+        SeqState ss = {};
+        ss.done = 1; ss.frame = 1;
+        sess_hs_[b] = ss;
+        FS_HIP(hipMemcpyAsync(state(b), &sess_hs_[b], sizeof(SeqState), hipMemcpyHostToDevice, st_));
+        FS_HIP(hipMemcpyAsync(d_page_table_.as<int>() + (size_t)b * max_pages_, &sess_scratch_, sizeof(int), hipMemcpyHostToDevice, st_));
+        FS_HIP(hipStreamSynchronize(st_));
+    }
+    int session_add(const uint32_t* prompt, int L, int max_new_tokens) override {
+        use_device();
+        FS_REQUIRE(sess_active_, "no open session");
+        FS_REQUIRE(L >= 1, "empty prompt");
+        if (L > a_.max_seq_len) throw Error("prompt exceeds max_seq_len (dual_ar.rs:623-624)");
+        int b = -1;
+        for (int i = 0; i < B_; ++i) if (sess_left_[i] < 0) { b = i; break; }
+        if (b < 0) return -1;
+        const int C1 = a_.num_codebooks + 1;
+        validate_tokens(prompt, 0, 1, L);
+        long long n_iter = 1 + std::max<long long>(0, (long long)max_new_tokens - L + 1);  // static_batch.rs:122,262-267
+        n_iter = std::min<long long>(n_iter, (long long)a_.max_seq_len - L + 1);           // a slot stops at max_seq_len instead of erroring
+        FS_REQUIRE(n_iter <= out_cap_, "generation longer than the output staging buffer");
+        ensure_capacity(b, L + (int)n_iter - 1);
+        const int Lp = L - 1;
+        if (Lp >= 1) {
+            // the row buffers are shared with the step: keep the live slots' next-frame inputs aside during the prefill passes
+            FS_HIP(hipMemcpyAsync(d_sess_x_.p, d_pfx_.p, sizeof(float) * (size_t)B_ * a_.dim, hipMemcpyDeviceToDevice, st_));
+            if (d_prompt_.n < sizeof(uint32_t) * (size_t)C1 * L) d_prompt_.alloc(sizeof(uint32_t) * (size_t)C1 * L);
+            FS_HIP(hipMemcpyAsync(d_prompt_.p, prompt, sizeof(uint32_t) * (size_t)C1 * L, hipMemcpyHostToDevice, st_));
+            SeqState ps = {};
+            ps.prompt_L = L;
+            FS_HIP(hipMemcpyAsync(state(b), &ps, sizeof(ps), hipMemcpyHostToDevice, st_));
+            seq_len_[b] = 0;
+            prefill_tokens(b, Lp, /*use_graph=*/false);
+            FS_HIP(hipMemcpyAsync(d_pfx_.p, d_sess_x_.p, sizeof(float) * (size_t)B_ * a_.dim, hipMemcpyDeviceToDevice, st_));
+            FS_HIP(hipStreamSynchronize(st_));
+        }
+        seq_len_[b] = Lp;
+        SeqState ss = {};
+        ss.pos = Lp; ss.prompt_L = L; ss.step = Lp;
+        for (int r = 0; r < C1; ++r) ss.cur[r] = prompt[(size_t)r * L + (L - 1)];
+        sess_hs_[b] = ss;
+        FS_HIP(hipMemcpyAsync(state(b), &sess_hs_[b], sizeof(SeqState), hipMemcpyHostToDevice, st_));
+        LmKernels<WT>::embed(d_, tok_emb_, cb_emb_, a_.num_codebooks, a_.codebook_size, d_cfg_.as<SampleCfg>(), nullptr, state(b),
+                             d_pfx_.as<float>() + (size_t)b * a_.dim, st_);
+        FS_HIP(hipStreamSynchronize(st_));
+        sess_left_[b] = (int)n_iter;
+        sess_pos_[b] = Lp;
+        stats_.prompt_tokens += (uint64_t)L;
+        return b;
+    }
+    void session_step(int n_frames, int* n_active) override {
+        use_device();
+        FS_REQUIRE(sess_active_, "no open session");
+        FS_HIP(hipEventRecord(ev_[1], st_));
+        int launched = 0;
+        while (launched < n_frames) {
+            int chunk = n_frames - launched, longest = 0, live = 0;
+            for (int b = 0; b < B_; ++b)
+                if (sess_left_[b] > 0 && !sess_hs_[b].done) { chunk = std::min(chunk, sess_left_[b]); longest = std::max(longest, sess_pos_[b]); ++live; }
+            if (!live) break;
+            for (int i = 0; i < chunk; ++i) {
+                set_bucket(longest + i + 1);
+                FS_HIP(hipGraphLaunch(batch_graph(B_), st_));
+            }
+            launched += chunk;
+            for (int b = 0; b < B_; ++b)
+                if (sess_left_[b] > 0 && !sess_hs_[b].done) {
+                    sess_left_[b] -= chunk; sess_pos_[b] += chunk;
+                    if (sess_left_[b] == 0) {  // iteration budget spent: the slot is finished whatever it sampled
+                        const int one = 1;
+                        FS_HIP(hipMemcpyAsync(&state(b)->done, &one, sizeof(int), hipMemcpyHostToDevice, st_));
+                    }
+                }
+            // (a slot that sampled <|im_end|> inside the chunk froze itself on the device; the host learns it below)
+            FS_HIP(hipMemcpyAsync(sess_hs_.data(), state(0), sizeof(SeqState) * B_, hipMemcpyDeviceToHost, st_));
+            FS_HIP(hipStreamSynchronize(st_));
+        }
+        FS_HIP(hipEventRecord(ev_[2], st_));
+        FS_HIP(hipEventSynchronize(ev_[2]));
+        float ms = 0;
+        FS_HIP(hipEventElapsedTime(&ms, ev_[1], ev_[2]));
+        stats_.decode_ms += ms;
+        stats_.graph_launches += (uint64_t)launched;
+        int act = 0;
+        uint64_t frames = 0;
+        for (int b = 0; b < B_; ++b) {
+            if (sess_left_[b] > 0 && !sess_hs_[b].done) ++act;
+            if (sess_left_[b] >= 0) frames += (uint64_t)sess_hs_[b].n_out;
+        }
+        stats_.frames = sess_released_frames_ + frames;
+        if (n_active) *n_active = act;
+    }
+    void session_poll(int slot, uint32_t* codes_out, size_t cap, size_t* n_frames, int* done) override {
+        use_device();
+        FS_REQUIRE(sess_active_ && slot >= 0 && slot < B_ && sess_left_[slot] >= 0, "not a live session slot");
+        const int C = a_.num_codebooks;
+        const size_t nb = (size_t)sess_hs_[slot].n_out;
+        if (codes_out) {
+            FS_REQUIRE(nb <= cap, "codes_out capacity too small for the generated frames");
+            for (int c = 0; c < C; ++c)
+                FS_HIP(hipMemcpyAsync(codes_out + (size_t)c * cap, d_out_.as<uint32_t>() + ((size_t)slot * C + c) * out_cap_, sizeof(uint32_t) * nb,
+                                      hipMemcpyDeviceToHost, st_));
+            FS_HIP(hipStreamSynchronize(st_));
+        }
+        if (n_frames) *n_frames = nb;
+        if (done) *done = (sess_hs_[slot].done != 0 || sess_left_[slot] == 0) ? 1 : 0;
+    }
+    void session_release(int slot) override {
+        use_device();
+        FS_REQUIRE(sess_active_ && slot >= 0 && slot < B_ && sess_left_[slot] >= 0, "not a live session slot");
+        sess_released_frames_ += (uint64_t)sess_hs_[slot].n_out;
+        truncate(slot, 0);
+        park_slot(slot);
+        sess_left_[slot] = -1;
+    }
+    void session_end() override {
+        if (!sess_active_) return;
+        use_device();
+        for (int b = 0; b < B_; ++b) truncate(b, 0);
+        free_pages_.push_back(sess_scratch_);
+        SampleCfg cfg = base_cfg();
+        FS_HIP(hipMemcpyAsync(d_cfg_.p, &cfg, sizeof(cfg), hipMemcpyHostToDevice, st_));
+        FS_HIP(hipStreamSynchronize(st_));
+        sess_active_ = false;
+        sess_released_frames_ = 0;
     }
 
     void generate_batch_sequential(const uint32_t* prompts, const int* lens, int n, int max_new_tokens, const fs_sampling& s, uint64_t seed,
@@ -971,7 +1140,8 @@ class LM final : public LMBase {
     // one static-batch frame for B rows: x rows (d_pfx_) hold the embedded inputs of position state(0)->pos
     void enqueue_batch_frame(int B) {
         const int C = a_.num_codebooks;
-        RowsCtx cs = rows_ctx(state(0), /*pos_step=*/0, /*pt_stride=*/max_pages_);
+        // lock-step static batch: every row at state(0)->pos (left-padded prompts); session: row m is its own sequence at state(m)->pos
+        RowsCtx cs = rows_ctx(state(0), /*pos_step=*/sess_active_ ? -1 : 0, /*pt_stride=*/max_pages_);
         cs.nc_launch = nc_launch_;
         for (int l = 0; l < a_.n_layer; ++l) LmKernels<WT>::rows_layer(d_, B, cs, slow_[l], slow_kv(l, 0), l == 0, st_);
         LmKernels<WT>::rows_finish(d_, B, cs, norm_w_, st_);
@@ -983,6 +1153,7 @@ class LM final : public LMBase {
             RowsCtx cf = cs;
             cf.X = d_xfrows_.as<float>();
             cf.state = d_fast_state_.as<SeqState>() + cbi;
+            cf.pos_step = 0;  // (the fast decoder's rows always sit at codebook position cbi)
             cf.pt_stride = 1;
             cf.nc_launch = 1;
             cf.small_attn = a_.num_codebooks <= 8;
@@ -1000,7 +1171,7 @@ class LM final : public LMBase {
         }
     }
     hipGraphExec_t batch_graph(int B) {
-        const int key = B * 1024 + nc_launch_;
+        const int key = (sess_active_ ? 1 << 24 : 0) + B * 1024 + nc_launch_;
         auto it = batch_graphs_.find(key);
         if (it != batch_graphs_.end()) return it->second;
         hipGraph_t g = nullptr;
@@ -1212,6 +1383,13 @@ class LM final : public LMBase {
     DevBuf d_hidden_, d_hid_slot_;     // generate_blocking_with_hidden: [out_cap][dim] rows + the pointer cell the captured graphs read
     bool persist_ok_ = false, use_persist_ = false, pslow_ok_ = false, use_pslow_ = false;
     int batch_rows_ = 0, batch_row_ = 0;  // generate_batch_sequential: batch sampler semantics for the row being generated
+    // continuous-batching session: per-slot remaining iterations (-1 = empty), host copy of the slot states, scratch KV page of empty slots
+    bool sess_active_ = false;
+    std::vector<int> sess_left_, sess_pos_;
+    std::vector<SeqState> sess_hs_;
+    int sess_scratch_ = 0;
+    uint64_t sess_released_frames_ = 0;
+    DevBuf d_sess_x_;
     DevBuf d_spack_, d_hpack_, d_snorms_, d_sedges_, d_sctl_;  // persistent slow transformer
     DevBuf d_pfx_, d_pfq_, d_pfslab_, d_pfa_, d_pfa2_, d_pfss_, d_pfc_, d_pfpart_;  // MFMA row-path activations (kRowsCap rows)
     DevBuf d_bprompt_;  // static batch: all left-padded prompts [B][C + 1][Lmax] (group prefill)

@@ -157,6 +157,9 @@ struct SampleCfg {  // device-resident (the captured graphs read it through a po
     // batch_rows > 0: BatchedLogitsProcessor semantics on the single-sequence samplers (row batch_row of a static batch generated on its
     // own, lm_engine.hip generate_batch_sequential): temp <= 1e-7 -> FIRST-max argmax; temp > 0 -> child StdRng of (call, row)
     int batch_rows = 0, batch_row = 0, batch_calls = 0;  // batch_calls = sample() calls per frame (num_codebooks + 1)
+    // continuous batching (fs_lm_session_*): the rows of the static-batch step are independent request slots -- a finished or empty slot
+    // stops stepping (position, frame counter and outputs frozen) instead of following the live rows in lock-step
+    int session = 0;
 };
 
 struct RepPenState {   // rep_pen.rs:4-72, one per codebook

@@ -252,6 +252,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_qkv(const float* __restrict__ x,
 template <typename WT, int DH> struct AttnGeom { static constexpr int TW = 16, NW = 8; };                          // bf16: 8 waves x 16 tokens = 128-token chunks
 template <int DH> struct AttnGeom<float, DH> { static constexpr int TW = 16, NW = 4; };                           // f32 :  64-token chunks
 
+// position of activation row m: pos_step 1 = consecutive tokens of one sequence (prefill), 0 = every row at state->pos (lock-step static
+// batch), -1 = row m is its own sequence with its own state (session slots, fs_lm_session_*)
+__device__ __forceinline__ int row_pos(const SeqState* __restrict__ state, int m, int pos_step) {
+    return pos_step < 0 ? state[m].pos : state->pos + m * pos_step;
+}
+
 template <typename WT, int DH, int NREP>
 __global__ __launch_bounds__((AttnGeom<WT, DH>::NW * 64)) void k_attn_decode(const float* __restrict__ q_all, KVView kv,
                                                      const SeqState* __restrict__ state, float* __restrict__ part_all,
@@ -325,7 +331,7 @@ __global__ __launch_bounds__((AttnGeom<WT, DH>::NW * 64)) void k_attn_decode(con
             for (int i = 0; i < EPL; ++i) qr[hp][i] *= s0;
     }
     FS_ISSUE_FENCE();
-    const int T = state->pos + 1 + (int)blockIdx.y * pos_step;  // the row's own K/V were appended by the qkv stage
+    const int T = row_pos(state, (int)blockIdx.y, pos_step) + 1;  // the row's own K/V were appended by the qkv stage
     if (c * CH >= T) return;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
@@ -864,6 +870,7 @@ struct GemmEpi {
     const float *cos_t, *sin_t;
     KVView kv; int H, Hk, Dh; RowMap rm; NormAux na;
     int pos0, rope_off, N;
+    const SeqState* states = nullptr;  // pos_step < 0: row m reads its own position (session slots)
 };
 template <int EPI, int ROWS>
 __device__ __forceinline__ void gemm_epilogue(float a, float b, int r, int m, int ml, int pr, const GemmEpi& g, const float* s_rms) {
@@ -908,7 +915,8 @@ __device__ __forceinline__ void gemm_epilogue(float a, float b, int r, int m, in
         Of[frag_off(m, r / 2, 1, ldo)] = l;
     } else {  // EPI_QKV: rope_i + scatter (q -> Y[m][r], k/v -> paged cache of row m's sequence)
         const int sq = rm.seq_rows > 0 ? m / rm.seq_rows : m;  // sequence of row m / its token index within the pass
-        const int pos = pos0 + (rm.seq_rows > 0 ? m - sq * rm.seq_rows : m * rm.pos_step), rpos = pos + rope_off;
+        int pos = pos0 + (rm.seq_rows > 0 ? m - sq * rm.seq_rows : m * rm.pos_step), rpos = pos + rope_off;
+        if (rm.pos_step < 0) { pos = g.states[m].pos; rpos = pos + g.states[m].rope_off; }
         const int* ptab = kv.page_table + (size_t)sq * rm.pt_stride;
         const int qdim = H * Dh, kdim = Hk * Dh, half = Dh / 2;
         if (r < qdim + kdim) {
@@ -967,7 +975,7 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* __restrict__ Xf, in
     const int kbeg = ((int)blockIdx.y * 4 + kq) * NKS * 32 + (lane >> 4) * 8;  // this lane's first k of every 32-wide step (weights)
     int pos0 = 0, rope_off = 0;
     if (EPI == EPI_QKV) { pos0 = state->pos; rope_off = state->rope_off; }  // requested up front: the epilogue must not start a dependent chain
-    const GemmEpi ge{Y, ldy, slab_stride, Of, ldo, cos_t, sin_t, kv, H, Hk, Dh, rm, na, pos0, rope_off, N};
+    const GemmEpi ge{Y, ldy, slab_stride, Of, ldo, cos_t, sin_t, kv, H, Hk, Dh, rm, na, pos0, rope_off, N, state};
     u32x4 wf[RT][NKS];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -1085,7 +1093,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_big(const bf16_t* __restrict__ 
     if (mp >= M) return;
     int pos0 = 0, rope_off = 0;
     if (EPI == EPI_QKV) { pos0 = state->pos; rope_off = state->rope_off; }
-    const GemmEpi ge{Y, ldy, slab_stride, Of, ldo, cos_t, sin_t, kv, H, Hk, Dh, rm, na, pos0, rope_off, N};
+    const GemmEpi ge{Y, ldy, slab_stride, Of, ldo, cos_t, sin_t, kv, H, Hk, Dh, rm, na, pos0, rope_off, N, state};
     const int ksw = (int)blockIdx.y * 32 + kh * NKS;  // this wave's first 32-deep k-step
     u32x4 wf[2][NKS];
 #pragma unroll
@@ -1191,7 +1199,7 @@ template <int DH>
 __global__ __launch_bounds__(256) void k_attn_combine(const float* __restrict__ part_all, int n_chunks_max, int chunk,
                                                       const SeqState* __restrict__ state, int pos_step, bf16_t* __restrict__ Ohi, int H) {
     const int m = blockIdx.x;
-    const int T = state->pos + 1 + m * pos_step, nc = (T + chunk - 1) / chunk;
+    const int T = row_pos(state, m, pos_step) + 1, nc = (T + chunk - 1) / chunk;
     const float* part = part_all + (size_t)m * H * n_chunks_max * (DH + 2);
     __shared__ float wl[32 * 128];
     for (int h = threadIdx.x; h < H; h += 256) {
@@ -1225,7 +1233,7 @@ __global__ __launch_bounds__(256) void k_attn_small_rows(const float* __restrict
                                                          int H, int Hk, int pos_step, int pt_stride, bf16_t* __restrict__ Ohi) {
     __shared__ float sc[32 * 8];
     const int m = blockIdx.x, tid = threadIdx.x;
-    const int T = state->pos + 1 + m * pos_step;
+    const int T = row_pos(state, m, pos_step) + 1;
     const int page = kv.page_table[(size_t)m * pt_stride];
     const int n_rep = H / Hk;
     const float* q = q_all + (size_t)m * H * DH;
@@ -1304,7 +1312,7 @@ __global__ __launch_bounds__((AttnGeom<WT, DH>::NW * 64)) void k_attn_rows(const
     __shared__ __attribute__((aligned(16))) WT sk[NW][TW * DH];
     __shared__ __attribute__((aligned(16))) WT sv[NW][TW * DH];
     __shared__ float sp[NW][NREP][NTS][DH + 2];
-    const int T = state->pos + 1 + mrow * pos_step;  // the row's own K/V were appended by the qkv stage
+    const int T = row_pos(state, mrow, pos_step) + 1;  // the row's own K/V were appended by the qkv stage
     const int nc_all = (T + CH - 1) / CH;
     const int c0 = PART ? (int)blockIdx.z * tpb : 0, nc = PART ? min(nc_all, c0 + tpb) : nc_all;  // this block's chunks [c0, nc)
     if (c0 >= nc) return;  // super-chunk past the current length (the graph bucket launches a power of two of them)
@@ -2536,17 +2544,21 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_fast_rows(const float
     __syncthreads();
     if (tid == 0) {
         const int frame = st->frame;
-        if (frame == 0 || !st->done) {  // first position unconditionally, then only while the row is active
-            const int o = st->n_out;
-            uint32_t* oc = out_codes + (size_t)b * n_cb * out_cap;
-            if (o < out_cap)
-                for (int cc = 0; cc < n_cb; ++cc) oc[(size_t)cc * out_cap + o] = cur[cc + 1];
-            st->n_out = o + 1;
+        // session slots (SampleCfg::session): a dead slot is frozen -- it neither emits nor advances -- from the frame after its last one
+        const bool frozen = c.session != 0 && st->done != 0 && frame > 0;
+        if (!frozen) {
+            if (frame == 0 || !st->done) {  // first position unconditionally, then only while the row is active
+                const int o = st->n_out;
+                uint32_t* oc = out_codes + (size_t)b * n_cb * out_cap;
+                if (o < out_cap)
+                    for (int cc = 0; cc < n_cb; ++cc) oc[(size_t)cc * out_cap + o] = cur[cc + 1];
+                st->n_out = o + 1;
+            }
+            for (int i = 0; i <= n_cb; ++i) { st->prev[i] = cur[i]; st->cur[i] = cur[i]; }
+            st->have_prev = 1;
+            st->pos += 1;  // dead rows keep stepping in lock-step (:255-261)
+            st->frame = frame + 1;
         }
-        for (int i = 0; i <= n_cb; ++i) { st->prev[i] = cur[i]; st->cur[i] = cur[i]; }
-        st->have_prev = 1;
-        st->pos += 1;  // dead rows keep stepping in lock-step (:255-261)
-        st->frame = frame + 1;
     }
     embed_tokens<WT>(tok_emb, cb_emb, dim, n_cb, cb_size, c.sem_lo, c.sem_hi, cur, 1, X + (size_t)b * dim, tid, SAMPLE_THREADS);
 }
@@ -2992,7 +3004,7 @@ void LmKernels<WT>::rows_layer(const ModelDims& d, int M, const RowsCtx& c, cons
                 hipLaunchKernelGGL((k_attn_small_rows<64>), dim3(M), dim3(256), 0, st, c.Q, kv, c.state, d.H, d.Hk, c.pos_step, c.pt_stride, c.A);
             else
                 hipLaunchKernelGGL((k_attn_small_rows<32>), dim3(M), dim3(256), 0, st, c.Q, kv, c.state, d.H, d.Hk, c.pos_step, c.pt_stride, c.A);
-        } else if (c.pos_step == 0 && !c.chunked_attn && ((d.Dh == 64 && (d.n_rep == 8 || d.n_rep == 2)) || (d.Dh == 32 && d.n_rep == 2))) {
+        } else if (c.pos_step <= 0 && !c.chunked_attn && ((d.Dh == 64 && (d.n_rep == 8 || d.n_rep == 2)) || (d.Dh == 32 && d.n_rep == 2))) {
             // static-batch decode: one fused node per layer (whole KV prefix per (kv head, row) block)
             // few rows: split the 8 query heads of a kv group over two blocks (64 -> 128 blocks at 32 rows)
             const int hs = (d.Dh == 64 && d.n_rep == 8) ? (d.Hk * M <= 64 ? 4 : (d.Hk * M < 256 ? 2 : 1)) : 1;

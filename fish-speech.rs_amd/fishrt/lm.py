@@ -151,6 +151,10 @@ class DualARTransformer:
                                                    out.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_size_t(cap), nf))
         return [out[i, :, : nf[i]].copy() for i in range(len(ps))]
 
+    def session(self, temp=0.7, top_p=0.9, top_k=50, seed=42, ignore_eos=False):
+        """continuous batching over this handle's max_batch slots (fishrt.h: fs_lm_session_*): `with lm.session(...) as s:`"""
+        return Session(self, temp, top_p, top_k, seed, ignore_eos)
+
     def last_stats(self):
         st = _ffi.GenStats()
         _ffi.check(_ffi.lib().fs_lm_last_stats(self._h, C.byref(st)))
@@ -164,6 +168,55 @@ class DualARTransformer:
         us = C.c_float(0)
         _ffi.check(_ffi.lib().fs_lm_bench_kernel(self._h, int(kind), int(kv_len), int(reps), C.byref(us)))
         return float(us.value)
+
+
+class Session:
+    """Request slots over the static-batch step (no reference counterpart; SURVEY.md section 8 f-4).  add() -> slot or None when full;
+    step(n) runs up to n frames for all live slots and returns how many are still generating; poll(slot) -> (codes (C, n), done);
+    release(slot) frees the slot.  A slot generates what a one-prompt generate_static_batch would (no repetition penalty)."""
+
+    def __init__(self, lm, temp, top_p, top_k, seed, ignore_eos):
+        self.lm, self._open = lm, False
+        s = _ffi.Sampling(float(temp), float(top_p), int(top_k), 1.0)
+        _ffi.check(_ffi.lib().fs_lm_session_begin(lm._h, C.byref(s), C.c_uint64(seed), 1 if ignore_eos else 0))
+        self._open = True
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def close(self):
+        if self._open:
+            self._open = False
+            _ffi.check(_ffi.lib().fs_lm_session_end(self.lm._h))
+
+    def add(self, prompt, max_new_tokens):
+        p = _u32(prompt)
+        slot = C.c_int(-1)
+        _ffi.check(_ffi.lib().fs_lm_session_add(self.lm._h, p.ctypes.data_as(C.POINTER(C.c_uint32)), int(p.shape[1]), int(max_new_tokens),
+                                                C.byref(slot)))
+        return None if slot.value < 0 else int(slot.value)
+
+    def step(self, n_frames=8):
+        act = C.c_int(0)
+        _ffi.check(_ffi.lib().fs_lm_session_step(self.lm._h, int(n_frames), C.byref(act)))
+        return int(act.value)
+
+    def poll(self, slot, codes=True):
+        n, done = C.c_size_t(0), C.c_int(0)
+        _ffi.check(_ffi.lib().fs_lm_session_poll(self.lm._h, int(slot), None, C.c_size_t(0), C.byref(n), C.byref(done)))
+        if not codes:
+            return int(n.value), bool(done.value)
+        cap = max(1, int(n.value))
+        out = np.zeros((self.lm.cfg["num_codebooks"], cap), np.uint32)
+        _ffi.check(_ffi.lib().fs_lm_session_poll(self.lm._h, int(slot), out.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_size_t(cap), C.byref(n),
+                                                 C.byref(done)))
+        return out[:, : n.value].copy(), bool(done.value)
+
+    def release(self, slot):
+        _ffi.check(_ffi.lib().fs_lm_session_release(self.lm._h, int(slot)))
 
 
 class LM:

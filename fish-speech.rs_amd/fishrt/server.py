@@ -17,10 +17,11 @@ caller supplies an encoder; audio decoding other than WAV; the text cleaner is a
 Scheduler.  One worker thread per LM handle (= per GPU) drains a queue of chunk jobs.  A job whose conditioning prefix equals the one
 sitting in the handle's KV cache skips the prefix (the reference's `assume_kv_cache`); jobs of different voices simply invalidate it
 (the reference's single mutex serialises requests and would reuse a stale prefix only by construction of one request at a time).  When
-several jobs are waiting (or a request asks for `batch_size`), up to `max_batch` of them go through ONE `generate_static_batch` step loop
-(the weights are streamed once per step for all rows), otherwise the batch-1 path with its persistent decode kernels.  The static-batch
-engine is lock-step (a row cannot join a running batch), so this is dynamic batching at chunk granularity, not token-level continuous
-batching.
+several jobs are in flight (or a request asks for `batch_size`) on a `max_batch > 1` handle, they share the static-batch decode step
+(the weights are streamed once per step for all rows) through CONTINUOUS batching: the handle's rows are request slots of a session
+(`fs_lm_session_*`), a job joins as soon as a slot is free and leaves when it is done -- token-level admission, no lock-step batches.
+A lone job takes the batch-1 path with its persistent decode kernels.  `Scheduler(continuous=False)` keeps the lock-step variant
+(jobs waiting together go through one `generate_static_batch` call).
 """
 import hashlib
 import io
@@ -98,9 +99,10 @@ class LMState:  # server/lib/state.rs:12-21
 
 
 class AppState:  # server/lib/state.rs:23-29
-    def __init__(self, lm_state, codec, sample_rate=44100, opus_encoder=None, preprocess=preprocess_text, batch_window_s=0.002):
+    def __init__(self, lm_state, codec, sample_rate=44100, opus_encoder=None, preprocess=preprocess_text, batch_window_s=0.002,
+                 continuous=True):
         self.lm, self.codec, self.sample_rate, self.opus_encoder, self.preprocess = lm_state, codec, sample_rate, opus_encoder, preprocess
-        self.scheduler = Scheduler(lm_state, batch_window_s)
+        self.scheduler = Scheduler(lm_state, batch_window_s, continuous)
 
 
 class _Job:
@@ -112,11 +114,15 @@ class _Job:
         return self.body if self.cond is None else np.ascontiguousarray(np.concatenate([self.cond, self.body], 1))
 
 
+_STOP = object()  # Scheduler.close() sentinel
+
+
 class Scheduler:
     """Replaces `state.lm.model.lock().await`: chunk jobs from all requests in one queue, one worker per handle."""
 
-    def __init__(self, lm_state, batch_window_s=0.002):
+    def __init__(self, lm_state, batch_window_s=0.002, continuous=True, step_frames=8):
         self.s, self.q, self.window = lm_state, queue.Queue(), batch_window_s
+        self.continuous, self.step_frames = continuous, step_frames
         self.cached_key = None
         self.stats = dict(jobs=0, single=0, batched_rows=0, batches=0, prefix_hits=0, rerolls=0)
         self._stop = False
@@ -130,14 +136,16 @@ class Scheduler:
 
     def close(self):
         self._stop = True
-        self.q.put(None)
+        self.q.put(_STOP)
         self.th.join(timeout=10)
 
     # -- worker
     def _run(self):
+        if self.s.max_batch > 1 and self.continuous and hasattr(self.s.lm, "session"):
+            return self._run_continuous()
         while True:
             j = self.q.get()
-            if j is None or self._stop:
+            if j is _STOP or self._stop:
                 return
             batch = [j]
             if self.s.max_batch > 1 and j.allow_batch:  # gather what else is waiting (or arrives within the window), up to max_batch rows
@@ -147,8 +155,8 @@ class Scheduler:
                         n = self.q.get(timeout=max(0.0, deadline - time.perf_counter()))
                     except queue.Empty:
                         break
-                    if n is None:
-                        self.q.put(None)
+                    if n is _STOP:
+                        self.q.put(_STOP)
                         break
                     batch.append(n)  # (a job that must not be batched still shares the gather; it runs alone below)
             runs_alone = [b for b in batch if not b.allow_batch]
@@ -164,6 +172,83 @@ class Scheduler:
                 for b in batch:
                     if not b.future.done():
                         b.future.set_exception(e)
+
+    def _run_continuous(self):
+        """Continuous batching (fishrt.h fs_lm_session_*): the handle's max_batch rows are request slots; a chunk job joins as soon as a slot
+        is free (its prompt is prefilled between two decode steps) and leaves when it samples <|im_end|> or runs out of budget -- no job waits
+        for a batch to form or for the slowest row of its batch.  A lone job (nothing else live or waiting) takes the batch-1 path instead:
+        persistent decode kernels, repetition penalty, conditioning-prefix reuse.  Jobs that must not be batched drain the session first."""
+        lm, sess, live, held = self.s.lm, None, {}, None
+
+        def fail_all(e):
+            for jb in list(live.values()) + ([held] if held is not None else []):
+                if not jb.future.done():
+                    jb.future.set_exception(e)
+            live.clear()
+
+        stopping = False
+        while True:
+            try:
+                # ---- intake: one job at a time is held until a slot (or the drained handle) is free for it
+                if held is None and not stopping:
+                    if live:
+                        try:
+                            held = self.q.get_nowait()
+                        except queue.Empty:
+                            pass
+                    else:
+                        if sess is not None:  # idle: give the handle back (its other entry points work between bursts)
+                            sess.close()
+                            sess = None
+                        held = self.q.get()
+                    if held is _STOP:
+                        held, stopping = None, True
+                if stopping and not live:
+                    if sess is not None:
+                        sess.close()
+                    return
+                if held is not None:
+                    lone = not live and self.q.empty()
+                    if not held.allow_batch or lone:
+                        if not live:  # drain first; then the batch-1 path
+                            if sess is not None:
+                                sess.close()
+                                sess = None
+                            j, held = held, None
+                            self._single(j)
+                            continue
+                    else:
+                        if sess is None:
+                            sa = self.s.default_sampling_args
+                            sess = lm.session(temp=sa.temp, top_p=sa.top_p, top_k=sa.top_k, seed=self.s.seed_source() & (2**64 - 1))
+                            self.cached_key = None
+                        slot = sess.add(held.full_prompt(), self.s.max_new_tokens)
+                        if slot is not None:
+                            live[slot] = held
+                            held = None
+                            self.stats["jobs"] += 1
+                            self.stats["batched_rows"] += 1
+                            self.stats["peak_live"] = max(self.stats.get("peak_live", 0), len(live))
+                            continue  # admit more before stepping
+                # ---- one scheduling quantum of decode steps for every live slot
+                if live:
+                    sess.step(self.step_frames)
+                    self.stats["batches"] += 1
+                    for slot in list(live):
+                        n, done = sess.poll(slot, codes=False)
+                        if done:
+                            codes, _ = sess.poll(slot)
+                            sess.release(slot)
+                            live.pop(slot).future.set_result(self._codes_out(codes))
+            except BaseException as e:  # every in-flight request gets the error (AppError -> HTTP 500); the session is rebuilt
+                fail_all(e)
+                held = None
+                try:
+                    if sess is not None:
+                        sess.close()
+                except BaseException:
+                    pass
+                sess = None
 
     def _codes_out(self, codes):
         if self.s.model_type != fprompt.FISH_1_5:  # speech.rs:63-68: Fish <= 1.4 codes are shifted by one

@@ -155,13 +155,33 @@ int fs_lm_generate_batch(fs_lm_t* lm, const uint32_t* prompts, const int* lens, 
                          const fs_sampling* sampling, uint64_t seed, uint32_t flags, uint32_t* codes_out, size_t cap,
                          size_t* n_frames);
 
+/* ---- continuous batching (no reference counterpart: the reference server serialises requests behind one mutex, server/lib/state.rs:12-29,
+ * or runs lock-step batches, generate/static_batch.rs:282-390; SURVEY.md section 8 f-4 asks for a scheduler that replaces the mutex).
+ * A session turns the max_batch rows of the static-batch decode step into independent request SLOTS: requests join between steps (their
+ * prompt is prefilled on the matrix-core row path while the other slots wait) and leave when finished; every step streams the weights
+ * once for all live slots.  A slot behaves exactly like row 0 of a ONE-prompt fs_lm_generate_batch call: no left padding (own positions
+ * and KV pages), first frame emitted unconditionally, BatchedLogitsProcessor sampling (sampling/mod.rs:77-109; repetition penalty is
+ * ignored like static_batch.rs:204-206), 1 + max(0, max_new_tokens - L + 1) iterations (static_batch.rs:122), stopping early at
+ * <|im_end|> or at max_seq_len.  With temp <= 1e-7 a slot's codes are independent of what the other slots do.
+ * bf16 / fp8 handles with the Fish 1.5 token layout only; while a session is open the handle's other entry points fail. */
+int fs_lm_session_begin(fs_lm_t* lm, const fs_sampling* sampling, uint64_t seed, uint32_t flags /* FS_GEN_IGNORE_EOS */);
+/* prompt u32 [C+1, L] row-major; *slot = the slot taken, or -1 when all max_batch slots are busy (not an error) */
+int fs_lm_session_add(fs_lm_t* lm, const uint32_t* prompt, int L, int max_new_tokens, int* slot);
+/* run up to n_frames decode steps for all live slots (stops early when none is live); *n_active = slots still generating afterwards */
+int fs_lm_session_step(fs_lm_t* lm, int n_frames, int* n_active);
+/* frames of `slot` so far: codes_out u32 [C, cap] row-major (may be NULL to query only), *n_frames, *done = 1 once the slot has finished */
+int fs_lm_session_poll(fs_lm_t* lm, int slot, uint32_t* codes_out, size_t cap, size_t* n_frames, int* done);
+/* give the slot (and its KV pages) back */
+int fs_lm_session_release(fs_lm_t* lm, int slot);
+int fs_lm_session_end(fs_lm_t* lm);
+
 /* timing of the last generate call, measured with HIP events on the handle's stream (the reference prints the
  * same quantities: single_batch.rs:233-246,291-304) */
 typedef struct fs_gen_stats {
     double prefill_ms, decode_ms;     /* decode_ms covers frames 1..n-1 exactly like `start_decode` (:261) */
     uint64_t frames, prompt_tokens, graph_launches;
-    uint64_t kernels_per_frame;       /* kernel nodes of one decode-frame graph replay of this call: 266 on the per-node path,
-                                         123 when the fast decoder ran as one persistent launch (FS_GEN_NO_PERSIST) */
+    uint64_t kernels_per_frame;       /* kernel launches per decode frame of this call: 266 on the per-node path (FS_GEN_NO_PERSIST), 146 with the
+                                         persistent slow kernel only (sampled requests), 3 with both persistent kernels (greedy requests) */
 } fs_gen_stats;
 int fs_lm_last_stats(fs_lm_t* lm, fs_gen_stats* out);
 /* the hipStream_t the handle launches on (for callers that bracket calls with their own HIP events) */

@@ -63,6 +63,45 @@ class FakeLM:
             self.lock.release()
 
 
+    def session(self, **kw):
+        return FakeSession(self, kw)
+
+
+class FakeSession:
+    """stand-in for fishrt.lm.Session: 4 slots; a slot emits one frame per step until its request's length is reached"""
+
+    def __init__(self, lm, kw):
+        assert lm.lock.acquire(blocking=False), "session opened while a call is in flight on the handle"
+        self.lm, self.slots, self.kw = lm, {}, kw
+        lm.calls.append(("session", dict(kw)))
+
+    def close(self):
+        self.lm.calls.append(("session_end", len(self.slots)))
+        self.lm.lock.release()
+
+    def add(self, prompt, max_new_tokens):
+        free = [i for i in range(4) if i not in self.slots]
+        if not free:
+            return None
+        self.slots[free[0]] = [self.lm._gen(prompt), 0]
+        self.lm.calls.append(("add", prompt.shape[1], len(self.slots)))
+        return free[0]
+
+    def step(self, n):
+        live = 0
+        for v in self.slots.values():
+            v[1] = min(v[0].shape[1], v[1] + n)
+            live += v[1] < v[0].shape[1]
+        return live
+
+    def poll(self, slot, codes=True):
+        full, n = self.slots[slot]
+        return (full[:, :n].copy(), n == full.shape[1]) if codes else (n, n == full.shape[1])
+
+    def release(self, slot):
+        del self.slots[slot]
+
+
 class FakeCodec:
     def decode(self, codes):
         b, c, t = codes.shape
@@ -72,14 +111,14 @@ class FakeCodec:
         return np.full((1, 8, max(1, pcm.shape[2] // 2048)), 7, np.uint32)
 
 
-def _state(max_batch=1, **lm_kw):
+def _state(max_batch=1, continuous=True, **lm_kw):
     tok = Tok()
     enc = fprompt.PromptEncoder(tok, 8, fprompt.FISH_1_5)
     default = enc.encode_conditioning_prompt("hello there", np.full((8, 4), 3, np.uint32))
     alice = enc.encode_conditioning_prompt("i am alice", np.full((8, 6), 9, np.uint32))
     lm = FakeLM(**lm_kw)
     ls = server.LMState(lm, tok, {"default": default, "alice": alice}, default, max_new_tokens=lm.M, max_batch=max_batch)
-    return server.AppState(ls, FakeCodec(), batch_window_s=0.05), lm
+    return server.AppState(ls, FakeCodec(), batch_window_s=0.05, continuous=continuous), lm
 
 
 def _client(state):
@@ -130,24 +169,50 @@ def test_voices_unknown_voice_falls_back_and_unconditioned():
     state.scheduler.close()
 
 
-def test_concurrent_requests_are_serialised_or_batched_never_interleaved():
-    state, lm = _state(max_batch=8, slow=0.02)
-    c = _client(state)
+def _fire(c, n):
     results = {}
 
     def go(i):
         results[i] = c.post("/v1/audio/speech", json=dict(model="x", voice="alice" if i % 2 else "default", input=f"Request number {i}."))
 
-    ths = [threading.Thread(target=go, args=(i,)) for i in range(6)]
+    ths = [threading.Thread(target=go, args=(i,)) for i in range(n)]
     for t in ths:
         t.start()
     for t in ths:
         t.join()
+    return results
+
+
+def test_concurrent_requests_share_a_continuous_batching_session():
+    """max_batch > 1: jobs in flight together become slots of one session (fs_lm_session_*); more jobs than slots wait for a release; the
+    session is closed when the burst is over and the handle's batch-1 path works again"""
+    state, lm = _state(max_batch=8, slow=0.02)
+    lm.frames_for = lambda prompt: 20 + int(prompt[0, -5]) % 30  # several scheduling quanta per job
+    c = _client(state)
+    results = _fire(c, 7)
     assert all(r.status_code == 200 for r in results.values())  # FakeLM asserts that no two calls overlap on the handle
     st = state.scheduler.stats
+    assert st["jobs"] == 7 and st["batched_rows"] >= 4 and st["peak_live"] >= 2, st
+    adds = [k for k in lm.calls if k[0] == "add"]
+    assert max(k[2] for k in adds) <= 4 and len(adds) == st["batched_rows"]          # the fake has 4 slots: later jobs joined after a release
+    sess = [k for k in lm.calls if k[0] == "session"]
+    assert sess and all("repetition_penalty" not in k[1] for k in sess)               # (a no-op on the batch path, static_batch.rs:204-206)
+    assert [k[0] for k in lm.calls].count("session") == [k[0] for k in lm.calls].count("session_end")
+    # afterwards a lone request takes the batch-1 path again
+    n_single = st["single"]
+    assert c.post("/v1/audio/speech", json=dict(model="x", voice="default", input="Alone.")).status_code == 200
+    assert state.scheduler.stats["single"] == n_single + 1 and lm.calls[-1][0] == "single"
+    state.scheduler.close()
+
+
+def test_lock_step_variant_batches_waiting_jobs():
+    state, lm = _state(max_batch=8, continuous=False, slow=0.02)
+    c = _client(state)
+    results = _fire(c, 6)
+    assert all(r.status_code == 200 for r in results.values())
+    st = state.scheduler.stats
     assert st["jobs"] == 6 and st["batches"] >= 1 and st["batched_rows"] >= 2, st
-    kinds = [k[0] for k in lm.calls]
-    assert "batch" in kinds
+    assert "batch" in [k[0] for k in lm.calls] and "session" not in [k[0] for k in lm.calls]
     # the batch path passes no repetition penalty (a no-op in the reference, static_batch.rs:204-206)
     assert all("repetition_penalty" not in k[2] for k in lm.calls if k[0] == "batch")
     state.scheduler.close()

@@ -193,7 +193,7 @@ def run_config3(args, lm_factory, dist, rank, world, cfg, tok):
                    "requests": n_req, "batch_per_gpu": B, "frames_per_request": frames,
                    "parallelism": f"request shards x{world}; prompt broadcast + code all-gather over RCCL, no per-token collective"},
         "rtf": round((frames_total / FRAME_RATE) / dt, 2),
-        "rccl_ranks": int(seen), "frames_per_rank": [int(v) for v in fa.sum(axis=1)],
+        "rccl_ranks": int(seen), "weight_broadcast": wbcast, "frames_per_rank": [int(v) for v in fa.sum(axis=1)],
         "decode_step_us_rank0": round(step_s * 1e6, 1), "prefill_s_per_job_rank0": round(pre_s, 3),
         "roofline": {"bound": "hbm", "kernel": "static-batch decode step (one graph replay, B = 32 rows on the MFMA row path)",
                      "achieved": round((frame_bytes(cfg, tok, 0) + B * 12288 * (float(lens.mean()) + frames / 2)) / step_s / 1e9, 2),
@@ -237,7 +237,21 @@ def main():
     if args.config == 3:
         return run_config3(args, lambda B: fishrt.DualARTransformer(cfg, tok, local_rank, "bf16", max_batch=B).load_synthetic(SEED),
                            dist, rank, world, cfg, tok)
-    lm = fishrt.DualARTransformer(cfg, tok, local_rank, "bf16").load_synthetic(SEED)
+    # replica start-up: rank 0 materialises the weights, the other ranks receive the arena over RCCL / xGMI
+    lm = fishrt.DualARTransformer(cfg, tok, local_rank, "bf16")
+    wbcast = None
+    if dist is not None:
+        if rank == 0:
+            lm.load_synthetic(SEED)
+        fanout.barrier(dist)
+        t0 = time.perf_counter()
+        nbytes = fanout.broadcast_weights(dist, lm, src=0)
+        fanout.barrier(dist)
+        dtb = time.perf_counter() - t0
+        wbcast = {"bytes": int(nbytes), "ms": round(dtb * 1e3, 1), "GBps_per_receiver": round(nbytes / dtb / 1e9, 1),
+                  "how": "fs_lm_weights_arena -> torch.distributed.broadcast (RCCL) in 256 MB pieces -> fs_lm_weights_adopt"}
+    else:
+        lm.load_synthetic(SEED)
     prompt = default_voice_prompt(tok)
     L = prompt.shape[1]
     M = args.frames + L - 2  # budget counts prompt tokens (single_batch.rs:61,77): frames = M - L + 2
@@ -269,6 +283,7 @@ def main():
     # fan-in of every rank's codes: one all-gather over RCCL after the timed region
     ca, fa, seen = fanout.all_gather_codes(dist, out[None], np.array([out.shape[1]], np.int32))
     assert seen == world and ca.shape == (world, 1, 8, args.frames)
+    assert (ca == ca[0]).all(), "replicas disagree on the greedy tokens of the same request (weight broadcast / load mismatch)"
 
     frames_total = args.frames * args.steps * world
     value = frames_total / dt

@@ -125,6 +125,11 @@ int fs_lm_generate_batch(fs_lm_t* lm, const uint32_t* prompts, const int* lens, 
     FS_ARG(lm && prompts && lens && sampling && codes_out && n_frames, "null argument");
     FS_TRY(lm->impl->generate_batch(prompts, lens, n, max_new_tokens, *sampling, seed, flags, codes_out, cap, n_frames))
 }
+int fs_lm_weights_arena(fs_lm_t* lm, void** dev_ptr, size_t* bytes) {
+    FS_ARG(lm && dev_ptr && bytes, "null argument");
+    FS_TRY(lm->impl->weights_arena(dev_ptr, bytes))
+}
+int fs_lm_weights_adopt(fs_lm_t* lm) { FS_ARG(lm, "null argument"); FS_TRY(lm->impl->weights_adopt()) }
 int fs_lm_session_begin(fs_lm_t* lm, const fs_sampling* sampling, uint64_t seed, uint32_t flags) {
     FS_ARG(lm && sampling, "null argument");
     FS_TRY(lm->impl->session_begin(*sampling, seed, flags))

@@ -14,6 +14,9 @@ class LMBase {
     virtual ~LMBase() {}
     virtual void load_synthetic(uint64_t seed) = 0;
     virtual void load_safetensors(const std::string& path) = 0;
+    // replica start-up over RCCL: the device weight arena as raw bytes, and "the arena now holds a loaded model"
+    virtual void weights_arena(void** dev_ptr, size_t* bytes) = 0;
+    virtual void weights_adopt() = 0;
     virtual void forward_generate(const uint32_t* toks, int B, int L, int input_pos, float* logits, float* hidden) = 0;
     virtual void forward_generate_fast(const float* x, int B, int input_pos, float* logits) = 0;
     virtual void fast_embed(const uint32_t* ids, int n, float* out) = 0;

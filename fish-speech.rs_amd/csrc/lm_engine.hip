@@ -187,6 +187,22 @@ class LM final : public LMBase {
         pack_persist();
     }
 
+    // The arena is a pure function of (model args, token config, dtype, checkpoint): one rank loads the checkpoint, the others receive
+    // the bytes (ncclBroadcast over xGMI instead of N disk reads + N conversions) and derive the load-time extras themselves.
+    void weights_arena(void** dev_ptr, size_t* bytes) override {
+        use_device();
+        FS_HIP(hipStreamSynchronize(st_));
+        *dev_ptr = arena_.p; *bytes = arena_bytes_;
+    }
+    void weights_adopt() override {
+        use_device();
+        FS_REQUIRE(!sess_active_, "the handle is in session mode (fs_lm_session_end first)");
+        FS_HIP(hipDeviceSynchronize());  // the bytes were written by another stream (the communicator's)
+        loaded_ = true;
+        refresh_legacy_head();
+        pack_persist();
+    }
+
     // ------------------------------------------------------------------------------------------ teacher-forced API
     void forward_generate(const uint32_t* toks, int B, int L, int input_pos, float* logits, float* hidden) override {
         use_device();

@@ -1,8 +1,8 @@
 """Multi-GPU request fan-out: the reference has no distributed layer, requests are independent
 sequences, so the only multi-GPU mode is REPLICAS -- one process per GPU, each with its own fishrt handle; request i goes
 to rank i mod world.  torch.distributed (backend "nccl" == RCCL on ROCm, "gloo" in CPU tests) is used only for control:
-barrier, max-reduce of the timed region, and the fan-in of the (KB-sized) code arrays.  Nothing on the per-token path
-crosses GPUs."""
+barrier, max-reduce of the timed region, the start-up weight broadcast, the prompt broadcast and the fan-in of the (KB-sized)
+code arrays.  Nothing on the per-token path crosses GPUs."""
 import os
 
 
@@ -75,6 +75,42 @@ def gather_results(dist, n_requests, local_results):
 
 def _dev(dist):
     return "cuda" if dist.get_backend() == "nccl" else "cpu"
+
+
+class _DeviceBytes:
+    """a raw device allocation as a CUDA-array-interface object (torch.as_tensor wraps it without a copy)"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def broadcast_weights(dist, lm, src=0, chunk_bytes=256 << 20):
+    """rank `src` has loaded the checkpoint; every other rank's handle (same model args / dtype, not loaded) receives the
+    weight arena over the communicator (RCCL broadcast over xGMI: one checkpoint read + conversion instead of N) and adopts it.  `lm` is a
+    DualARTransformer, or any object with weights_arena() -> (ptr, nbytes) / adopt_weights() (tests pass a host-memory double:
+    weights_host() -> numpy u8).  Returns the bytes moved."""
+    if dist is None:
+        return 0
+    import torch
+    me = dist.get_rank()
+    if hasattr(lm, "weights_host"):  # host-memory double (gloo tests)
+        t = torch.from_numpy(lm.weights_host())
+    else:
+        ptr, n = lm.weights_arena()
+        t = torch.as_tensor(_DeviceBytes(ptr, n), device="cuda")
+    n = int(t.numel())
+    sizes = torch.tensor([n, -n], dtype=torch.int64, device=t.device)  # max and -min in one reduction: every rank sees a mismatch
+    dist.all_reduce(sizes, op=dist.ReduceOp.MAX)
+    hi, lo = int(sizes[0].item()), -int(sizes[1].item())
+    if hi != lo:
+        raise RuntimeError(f"weight arenas differ across ranks ({lo}..{hi} bytes, {n} here): same model args and dtype on every rank")
+    for o in range(0, n, chunk_bytes):  # chunks: bounded communicator staging, overlappable launches
+        dist.broadcast(t[o:o + chunk_bytes], src)
+    if t.is_cuda:
+        torch.cuda.synchronize()
+    if me != src:
+        lm.adopt_weights()
+    return n
 
 
 def broadcast_prompts(dist, packed=None, lens=None, src=0):

@@ -151,6 +151,16 @@ class DualARTransformer:
                                                    out.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_size_t(cap), nf))
         return [out[i, :, : nf[i]].copy() for i in range(len(ps))]
 
+    def weights_arena(self):
+        """(device pointer, bytes) of the handle's weight arena (fishrt.h: fs_lm_weights_arena) -- for fanout.broadcast_weights"""
+        ptr, n = C.c_void_p(), C.c_size_t(0)
+        _ffi.check(_ffi.lib().fs_lm_weights_arena(self._h, C.byref(ptr), C.byref(n)))
+        return int(ptr.value), int(n.value)
+
+    def adopt_weights(self):
+        _ffi.check(_ffi.lib().fs_lm_weights_adopt(self._h))
+        return self
+
     def session(self, temp=0.7, top_p=0.9, top_k=50, seed=42, ignore_eos=False):
         """continuous batching over this handle's max_batch slots (fishrt.h: fs_lm_session_*): `with lm.session(...) as s:`"""
         return Session(self, temp, top_p, top_k, seed, ignore_eos)

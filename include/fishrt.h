@@ -155,6 +155,14 @@ int fs_lm_generate_batch(fs_lm_t* lm, const uint32_t* prompts, const int* lens, 
                          const fs_sampling* sampling, uint64_t seed, uint32_t flags, uint32_t* codes_out, size_t cap,
                          size_t* n_frames);
 
+/* ---- replica start-up (no reference counterpart: the reference has no distributed layer).  The handle's device
+ * weight arena -- every checkpoint tensor in the handle's storage type, laid out by its tensor plan -- is a pure function of (model args,
+ * token config, dtype, checkpoint), so N replicas need ONE checkpoint read: rank 0 loads, fs_lm_weights_arena() gives every rank the
+ * device pointer + size to hand to ncclBroadcast (torch.distributed.broadcast: fishrt/fanout.py broadcast_weights), and the receivers
+ * call fs_lm_weights_adopt() (marks the handle loaded and builds the load-time derived data: persistent-kernel weight images etc.). */
+int fs_lm_weights_arena(fs_lm_t* lm, void** dev_ptr, size_t* bytes);
+int fs_lm_weights_adopt(fs_lm_t* lm);
+
 /* ---- continuous batching (no reference counterpart: the reference server serialises requests behind one mutex, server/lib/state.rs:12-29,
  * or runs lock-step batches, generate/static_batch.rs:282-390; SURVEY.md section 8 f-4 asks for a scheduler that replaces the mutex).
  * A session turns the max_batch rows of the static-batch decode step into independent request SLOTS: requests join between steps (their

@@ -45,4 +45,30 @@ for r in range(world):
         assert (ca[r, k] == 100 * i + 1).all() and fa[r, k] == 1 + (i % 4)
 if rank == 0:
     print("FANIN_OK", world, flush=True)
+
+
+# weight-arena broadcast -- rank 0 "loaded the checkpoint", the others receive the bytes and adopt them
+class HostArena:
+    def __init__(self, n, loaded):
+        self.buf = (np.arange(n, dtype=np.uint64) * 2654435761 % 251).astype(np.uint8) if loaded else np.zeros(n, np.uint8)
+        self.adopted = False
+
+    def weights_host(self):
+        return self.buf
+
+    def adopt_weights(self):
+        self.adopted = True
+
+
+h = HostArena(3_000_001, rank == 0)
+moved = fanout.broadcast_weights(dist, h, src=0, chunk_bytes=1 << 20)  # 3 chunks, the last one ragged
+ref = HostArena(3_000_001, True).buf
+assert moved == 3_000_001 and np.array_equal(h.buf, ref) and h.adopted == (rank != 0)
+try:  # arenas of different sizes (different model args on some rank) are an error on every rank, not a hang
+    fanout.broadcast_weights(dist, HostArena(1000 + rank, True))
+    raise SystemExit("size mismatch not detected")
+except RuntimeError as e:
+    assert "differ across ranks" in str(e)
+if rank == 0:
+    print("WEIGHTS_OK", world, flush=True)
 dist.destroy_process_group()

@@ -24,7 +24,7 @@ def test_gloo_world2_fanout():
            "--master-port", "29517", os.path.join(ROOT, "tests", "dist_worker.py"), "2"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
-    assert "FANOUT_OK 2" in p.stdout and "FANIN_OK 2" in p.stdout
+    assert "FANOUT_OK 2" in p.stdout and "FANIN_OK 2" in p.stdout and "WEIGHTS_OK 2" in p.stdout
 
 
 def test_bench_gpus2_self_launch_dry_run():

@@ -229,7 +229,13 @@ def main():
               f"ranks itself) or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`", file=sys.stderr)
         sys.exit(2)
     have_gpu = fishrt.lib().fs_device_count() > 0
-    dist = fanout.init(("nccl" if have_gpu else "gloo") if world > 1 else None)  # nccl == RCCL: control plane + request fan-out only
+    # test hooks for a ONE-GPU box: FISHRT_BENCH_DEVICE pins every rank to one device, FISHRT_BENCH_BACKEND=gloo replaces RCCL (which
+    # refuses two ranks on one GPU) -- together they run the whole N > 1 path, weight broadcast included, on device memory
+    if "FISHRT_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["FISHRT_BENCH_DEVICE"])
+        torch.cuda.set_device(local_rank)
+    backend = os.environ.get("FISHRT_BENCH_BACKEND", "nccl") if have_gpu else "gloo"
+    dist = fanout.init(backend if world > 1 else None)  # nccl == RCCL: control plane + request fan-out only
     if not have_gpu:
         dry_run(args, dist, rank, world)
 

@@ -40,6 +40,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float c3_silu(float x) { return x / (1.f + __expf(-x)); }
+// plane outputs only (the value is split to 2 x bf16 right after): v_rcp_f32 (1 ulp) instead of the IEEE division sequence
+__device__ __forceinline__ float c3_silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float c3_gelu(float x) { return 0.5f * x * (1.f + tanhf(0.7978845608028654f * x * (1.f + 0.044715f * x * x))); }
 __device__ __forceinline__ uint32_t c3_bf16(float f) {  // round to nearest even (finite inputs)
     uint32_t u = __float_as_uint(f);
@@ -77,6 +79,18 @@ __global__ void k_pack_bf3(const float* __restrict__ src, uint16_t* __restrict__
 // padding -- written by the producer's first time tile, so a consumer never tests t >= 0; slots at t >= T may hold anything
 // (causality: they only feed outputs at t >= T, which are not stored; the engine over-allocates the tail).
 constexpr int PP = CODEC_PLANE_PAD;
+
+#ifdef FS_C3_PROF  // tools/ubench_conv.hip only: cycles spent per phase of k_conv1d_bf3p, summed over the blocks' wave 0
+__device__ unsigned long long g_c3prof[8];
+#define C3_TICK(slot)                                                                 \
+    do {                                                                              \
+        const unsigned long long t_ = __builtin_readcyclecounter();                   \
+        c3_acc[slot] += t_ - c3_t0;                                                   \
+        c3_t0 = t_;                                                                   \
+    } while (0)
+#else
+#define C3_TICK(slot) do {} while (0)
+#endif
 
 __device__ __forceinline__ void c3_zero_pad(uint16_t* pb, int CG, int T, int g_first, int n_groups, int tid, int nthreads) {
     const u32x4 z{0u, 0u, 0u, 0u};
@@ -132,44 +146,77 @@ __global__ void k_mean3_planes(const float* __restrict__ a, const float* __restr
 // Epilogue shared by the conv kernels.  D[row][col] of v_mfma_f32_32x32x*: register r of lane (h, c) holds row (r/4)*8 + h*4 + r%4,
 // column c.  ob = first GEMM row of the wave's 32-row tile, tbase = first sample of its NT 32-sample tiles; y / res already carry
 // the batch offset, ypb is the batch item's plane base (or null).
-template <int NT>
-__device__ __forceinline__ void c3_epilogue(const f32x16 (&acc)[NT], int ob, int tbase, int h, int c, int Cout, int T, int ps,
-                                            const float* __restrict__ bias, int epi, const float* __restrict__ res,
-                                            const float* __restrict__ gamma, float* __restrict__ y, uint16_t* __restrict__ ypb,
-                                            int post_silu) {
+// Epilogue of one wave's NT 32x32 accumulator tiles, for ONE compile-time kind E (CODEC_EPI_*) and PS1 = "plain conv" (ps == 1).
+// Branch-free up to the stores: the 16 bias values and the 16 * NT residual values of a lane are requested up front through clamped
+// (always valid) addresses, so one memory round trip covers the tile -- with a validity branch around every output the loads were
+// issued one at a time and the epilogue took half of a block's life; with a runtime kind switch every output carried the GELU /
+// tanh / polyphase code (7 k instructions).
+template <int NT, int E, bool PS1>
+__device__ __forceinline__ void c3_epilogue_k(const f32x16 (&acc)[NT], int ob, int tbase, int h, int c, int Cout, int T, int ps,
+                                              const float* __restrict__ bias, const float* __restrict__ res, const float* __restrict__ gamma,
+                                              float* __restrict__ y, uint16_t* __restrict__ ypb, int post_silu) {
+    constexpr bool RES = E == CODEC_EPI_RES || E == CODEC_EPI_GAMMA_RES;
     const int CGo = Cout >> 3;
+    float bv[16], gv[16], rv[NT][16];
+    size_t oi[NT][16];
 #pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) {
+    for (int r = 0; r < 16; ++r) {
+        const int o = min(ob + (r >> 2) * 8 + h * 4 + (r & 3), Cout - 1), oc = PS1 ? o : o / ps;
+        bv[r] = bias[oc];
+        if (E == CODEC_EPI_GAMMA_RES) gv[r] = gamma[o];
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            const int t = tbase + j * 32 + c;
+            const int t = min(tbase + j * 32 + c, T - 1);
+            oi[j][r] = PS1 ? (size_t)o * T + t : (size_t)oc * T * ps + (size_t)t * ps + o % ps;  // (polyphase rows: see k_conv1d)
+            if (RES) rv[j][r] = res[oi[j][r]];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int t = tbase + j * 32 + c;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
             float v4[4];
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-                const int o = ob + q4 * 8 + h * 4 + rr;
-                float v = 0.f;
-                if (o < Cout && t < T) {
-                    v = acc[j][q4 * 4 + rr] + bias[o / ps];
-                    const size_t oi = (size_t)(o / ps) * T * ps + (size_t)t * ps + o % ps;  // (polyphase rows: see k_conv1d)
-                    if (epi == CODEC_EPI_GELU) v = c3_gelu(v);
-                    else if (epi == CODEC_EPI_GAMMA_RES) v = res[oi] + gamma[o] * v;
-                    else if (epi == CODEC_EPI_RES) v = res[oi] + v;
-                    else if (epi == CODEC_EPI_TANH) v = tanhf(v);
-                    if (y) y[oi] = v;
-                }
+                const int r = q4 * 4 + rr, o = ob + q4 * 8 + h * 4 + rr;
+                float v = acc[j][r] + bv[r];
+                if (E == CODEC_EPI_GELU) v = c3_gelu(v);
+                else if (E == CODEC_EPI_GAMMA_RES) v = rv[j][r] + gv[r] * v;
+                else if (E == CODEC_EPI_RES) v = rv[j][r] + v;
+                else if (E == CODEC_EPI_TANH) v = tanhf(v);
+                if (y && o < Cout && t < T) y[oi[j][r]] = v;
                 v4[rr] = v;
             }
             const int ob8 = ob + q4 * 8;  // first channel of this lane pair's 8-channel group
             if (ypb && ob8 < Cout && t < T) {
                 uint32_t hi[4], lo[4];
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) c3_split(post_silu ? c3_silu(v4[rr]) : v4[rr], hi[rr], lo[rr]);
+                for (int rr = 0; rr < 4; ++rr) c3_split(post_silu ? c3_silu_fast(v4[rr]) : v4[rr], hi[rr], lo[rr]);
                 uint16_t* d = ypb + ((size_t)(ob8 >> 3) * (PP + T) + PP + t) * 8 + h * 4;
                 *reinterpret_cast<uint2*>(d) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
                 *reinterpret_cast<uint2*>(d + (size_t)CGo * (PP + T) * 8) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
             }
         }
-        __builtin_amdgcn_sched_barrier(0);  // one 8-row group at a time: bounds the residual loads / row addresses in flight (VGPRs)
+    }
+}
+
+// D[row][col] of v_mfma_f32_32x32x*: register r of lane (h, c) holds row (r/4)*8 + h*4 + r%4, column c.  ob = first GEMM row of the wave's
+// 32-row tile, tbase = first sample of its NT 32-sample tiles; y / res already carry the batch offset, ypb is the batch item's plane base
+// (or null).  EPI >= 0: compile-time kind (the plane kernels are instantiated per kind); EPI < 0: runtime `epi` (one specialised loop each).
+template <int NT, int EPI = -1, bool PS1 = false>
+__device__ __forceinline__ void c3_epilogue(const f32x16 (&acc)[NT], int ob, int tbase, int h, int c, int Cout, int T, int ps,
+                                            const float* __restrict__ bias, int epi, const float* __restrict__ res,
+                                            const float* __restrict__ gamma, float* __restrict__ y, uint16_t* __restrict__ ypb,
+                                            int post_silu) {
+    if constexpr (EPI >= 0) {
+        c3_epilogue_k<NT, EPI, PS1>(acc, ob, tbase, h, c, Cout, T, ps, bias, res, gamma, y, ypb, post_silu);
+    } else {
+        if (epi == CODEC_EPI_GELU) c3_epilogue_k<NT, CODEC_EPI_GELU, false>(acc, ob, tbase, h, c, Cout, T, ps, bias, res, gamma, y, ypb, post_silu);
+        else if (epi == CODEC_EPI_GAMMA_RES) c3_epilogue_k<NT, CODEC_EPI_GAMMA_RES, false>(acc, ob, tbase, h, c, Cout, T, ps, bias, res, gamma, y, ypb, post_silu);
+        else if (epi == CODEC_EPI_RES) c3_epilogue_k<NT, CODEC_EPI_RES, false>(acc, ob, tbase, h, c, Cout, T, ps, bias, res, gamma, y, ypb, post_silu);
+        else if (epi == CODEC_EPI_TANH) c3_epilogue_k<NT, CODEC_EPI_TANH, false>(acc, ob, tbase, h, c, Cout, T, ps, bias, res, gamma, y, ypb, post_silu);
+        else c3_epilogue_k<NT, CODEC_EPI_NONE, false>(acc, ob, tbase, h, c, Cout, T, ps, bias, res, gamma, y, ypb, post_silu);
     }
 }
 
@@ -307,19 +354,19 @@ __global__ __launch_bounds__(256) void k_conv1d_bf3(const float* __restrict__ x,
 // (global_load_lds_dwordx4: 64 consecutive 16-byte slots per wave instruction, destination = wave-uniform base + lane * 16, source =
 // uniform base + lane * 16: no per-lane address arithmetic, no staging registers).  Two or three blocks share a CU (LDS 42..65 KB
 // each), so one block's DMA wait overlaps another's MFMA phase.  Requires Cin % 16 == 0.
-template <int OT, int TT, int KMAX>
+template <int OT, int TT, int KMAX, int EPI, bool PS1, int NIBS = 1>
 __global__ __launch_bounds__(256, 2) void k_conv1d_bf3p(const uint16_t* __restrict__ xp, int Cin, int T, const uint16_t* __restrict__ wp,
                                                         int Cp, const float* __restrict__ bias, int Cout, int K, int dil, int epi,
                                                         const float* __restrict__ res, const float* __restrict__ gamma,
                                                         float* __restrict__ y, uint16_t* __restrict__ yp, int post_silu, int ps) {
     constexpr int WT_ = OT == 64 ? TT / 2 : TT / 4, NT = WT_ / 32;
     static_assert(NT >= 1 && (OT == 64 || OT == 32), "block shape");
-    constexpr int NWP = (KMAX * 4 * OT + 255) / 256;  // weight DMA pieces (256 chunks each) per stage, upper bound
+    constexpr int NWP = (NIBS * KMAX * 4 * OT + 255) / 256;  // weight DMA pieces (256 chunks each) per stage, upper bound
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int halo = (K - 1) * dil, XSP = (TT + halo + 63) & ~63;
-    const int nib = Cin >> 4, CGi = Cin >> 3;
-    u32x4* xs = reinterpret_cast<u32x4*>(smem_raw);  // [4][XSP]
-    u32x4* ws = xs + 4 * XSP;                        // [K][4][OT]
+    const int nst = (Cin >> 4) / NIBS, CGi = Cin >> 3;  // stages of NIBS 16-channel blocks (NIBS > 1: pointwise convs, K = 1)
+    u32x4* xs = reinterpret_cast<u32x4*>(smem_raw);  // [NIBS][4][XSP]
+    u32x4* ws = xs + NIBS * 4 * XSP;                 // [NIBS][K][4][OT]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, c = lane & 31;
     const int ob = OT == 64 ? (wave & 1) * 32 : 0, tb = OT == 64 ? (wave >> 1) * WT_ : wave * WT_;
@@ -330,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void k_conv1d_bf3p(const uint16_t* __restri
     // weight chunk (piece j, wave, lane) = chunk index e = j*256 + wave*64 + lane -> row kp = e / OT, column e % OT
     const int wl_off = OT == 64 ? lane : (lane >> 5) * Cp + (lane & 31);
     const u32x4* wpl = reinterpret_cast<const u32x4*>(wp) + o0 + wl_off;
-    const int wtotal = K * 4 * OT;  // chunks per stage: a multiple of 64, so a piece is whole per wave
+    const int wtotal = NIBS * K * 4 * OT;  // chunks per stage: a multiple of 64, so a piece is whole per wave
     auto dma = [&](const u32x4* src, u32x4* dst_wave_base) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst_wave_base, 16, 0, 0);
@@ -340,45 +387,64 @@ __global__ __launch_bounds__(256, 2) void k_conv1d_bf3p(const uint16_t* __restri
     for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    for (int ib = 0; ib < nib; ++ib) {
+#ifdef FS_C3_PROF
+    unsigned long long c3_acc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long c3_t0 = __builtin_readcyclecounter();
+#endif
+    for (int st = 0; st < nst; ++st) {
         __syncthreads();  // previous stage's LDS reads are done
-        // x window: 4 planes (hi / lo x channel half) of XSP slots
+        C3_TICK(0);
+        // x window: per 16-channel block 4 planes (hi / lo x channel half) of XSP slots
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const u32x4* src = xpb + ((size_t)((p >> 1) * CGi + 2 * ib + (p & 1))) * row;
-            for (int q = wave * 64; q < XSP; q += 256) dma(src + q, xs + p * XSP + q);
-        }
-        // weight tile [K][4][OT] of this channel block: chunk rows are Cp apart in global memory
+        for (int b = 0; b < NIBS; ++b)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const u32x4* src = xpb + ((size_t)((p >> 1) * CGi + 2 * (st * NIBS + b) + (p & 1))) * row;
+                for (int q = wave * 64; q < XSP; q += 256) dma(src + q, xs + (b * 4 + p) * XSP + q);
+            }
+        // weight tiles [NIBS][K][4][OT] of these channel blocks: consecutive chunk rows of the packed tensor, Cp apart in global memory
         {
-            const u32x4* src = wpl + (size_t)ib * K * 4 * Cp;
+            const u32x4* src = wpl + (size_t)st * NIBS * K * 4 * Cp;
             constexpr int RPP = 256 / OT;  // chunk rows per piece
 #pragma unroll
             for (int j = 0; j < NWP; ++j)
                 if (j * 256 + wave * 64 < wtotal) dma(src + (size_t)(j * RPP + (OT == 64 ? wave : wave * 2)) * Cp, ws + j * 256 + wave * 64);
         }
+        C3_TICK(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        C3_TICK(2);
         __syncthreads();
-        const u32x4* wl = ws + h * OT + ob + c;
-        const u32x4* xl = xs + h * XSP + tb + c;
-        for (int k = 0; k < K; ++k) {
-            const bf16x8 ah = __builtin_bit_cast(bf16x8, wl[k * 4 * OT]), al = __builtin_bit_cast(bf16x8, wl[(k * 4 + 2) * OT]);
-            const u32x4* xk = xl + k * dil;
-            // (per accumulator the order stays hi*hi, hi*lo, lo*hi; the NT tiles are interleaved so that dependent MFMAs are NT apart)
-            bf16x8 bh[NT], bl[NT];
+        C3_TICK(3);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) { bh[j] = __builtin_bit_cast(bf16x8, xk[32 * j]); bl[j] = __builtin_bit_cast(bf16x8, xk[2 * XSP + 32 * j]); }
+        for (int b = 0; b < NIBS; ++b) {
+            const u32x4* wl = ws + (b * K * 4 + h) * OT + ob + c;
+            const u32x4* xl = xs + (b * 4 + h) * XSP + tb + c;
+            for (int k = 0; k < K; ++k) {
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, wl[k * 4 * OT]), al = __builtin_bit_cast(bf16x8, wl[(k * 4 + 2) * OT]);
+                const u32x4* xk = xl + k * dil;
+                // (per accumulator the order stays hi*hi, hi*lo, lo*hi; the NT tiles are interleaved so that dependent MFMAs are NT apart)
+                bf16x8 bh[NT], bl[NT];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[j], 0, 0, 0);
+                for (int j = 0; j < NT; ++j) { bh[j] = __builtin_bit_cast(bf16x8, xk[32 * j]); bl[j] = __builtin_bit_cast(bf16x8, xk[2 * XSP + 32 * j]); }
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[j], 0, 0, 0);
+                for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[j], 0, 0, 0);
+                for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[j], 0, 0, 0);
+            }
         }
+        C3_TICK(4);
     }
     uint16_t* ypb = yp ? yp + (size_t)blockIdx.z * 2 * (Cout >> 3) * row * 8 : nullptr;
     if (ypb && t0 == 0) c3_zero_pad(ypb, Cout >> 3, T, o0 >> 3, OT / 8, tid, 256);
-    c3_epilogue<NT>(acc, o0 + ob, t0 + tb, h, c, Cout, T, ps, bias, epi, res ? res + boff_out : nullptr, gamma, y ? y + boff_out : nullptr, ypb,
-                    post_silu);
+    c3_epilogue<NT, EPI, PS1>(acc, o0 + ob, t0 + tb, h, c, Cout, T, ps, bias, epi, res ? res + boff_out : nullptr, gamma,
+                              y ? y + boff_out : nullptr, ypb, post_silu);
+    C3_TICK(5);
+#ifdef FS_C3_PROF
+    if (threadIdx.x == 0)
+        for (int i = 0; i < 6; ++i) atomicAdd(&g_c3prof[i], c3_acc[i]);
+#endif
 }
 
 // ---- plane input, thin layers (Cin = 16 * NIB <= 32: the 16 / 32-channel late stages, 40 % of the decode's samples x convs).
@@ -386,7 +452,7 @@ __global__ __launch_bounds__(256, 2) void k_conv1d_bf3p(const uint16_t* __restri
 // set (<= 45 KB) is loaded into LDS once, then every wave walks over its own 32-channel x (32 * NT)-sample tiles and loads its MFMA
 // B operands -- 16-byte plane slots, 512 contiguous bytes per half-wave -- straight from global memory (the K taps of a tile re-read
 // the same window from L1/L2).  No barrier after the weight load, so a CU keeps as many independent waves in flight as registers allow.
-template <int K, int NIB, int NT>
+template <int K, int NIB, int NT, int EPI, bool PS1>
 __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void k_conv1d_bf3t(const uint16_t* __restrict__ xp, int T, const uint16_t* __restrict__ wp, int Cp,
                                                         const float* __restrict__ bias, int Cout, int dil, int epi,
                                                         const float* __restrict__ res, const float* __restrict__ gamma,
@@ -443,8 +509,8 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void k_conv1d_bf3t(const uint
         }
         int Tl = T;  // opaque per tile: keeps the epilogue's ~100 row addresses from being hoisted out of the tile loop (200+ VGPRs)
         asm volatile("" : "+s"(Tl));
-        c3_epilogue<NT>(acc, o0, t0, h, c, Cout, Tl, ps, bias, epi, res ? res + boff_out : nullptr, gamma, y ? y + boff_out : nullptr, ypb,
-                        post_silu);
+        c3_epilogue<NT, EPI, PS1>(acc, o0, t0, h, c, Cout, Tl, ps, bias, epi, res ? res + boff_out : nullptr, gamma, y ? y + boff_out : nullptr,
+                                  ypb, post_silu);
     }
 }
 
@@ -483,29 +549,54 @@ void codec_conv1d_bf3(const float* x, const uint16_t* xp, int B, int Cin, int T,
     };
     if (xp) {
         FS_REQUIRE(Cin % 16 == 0 && halo <= CODEC_PLANE_PAD, "plane input needs Cin % 16 == 0 and a halo within the plane padding");
+        const bool resid = epi == CODEC_EPI_RES, ps1 = ps == 1;
+        if (K == 1 && nib % 8 == 0) {
+            // pointwise convs (ConvNeXt MLPs, the k = s = 2 upsampling convs in polyphase form): 8 channel blocks per stage
+            FS_REQUIRE(epi == CODEC_EPI_NONE || ((epi == CODEC_EPI_GELU || epi == CODEC_EPI_GAMMA_RES) && ps1), "pointwise plane conv: epilogue kind");
+            constexpr int OT = 32, TT = 128, NIBS = 8;
+            const size_t smem = 16 * ((size_t)NIBS * 4 * TT + (size_t)NIBS * 4 * OT);
+            auto go = [&](auto kern) {
+                raise_lds((const void*)kern, smem);
+                hipLaunchKernelGGL(kern, dim3((T + TT - 1) / TT, (Cout + OT - 1) / OT, B), dim3(256), smem, st, xp, Cin, T, wp, Cp, bias, Cout, K, dil,
+                                   epi, res, gamma, y, yp, post_silu ? 1 : 0, ps);
+            };
+            if (epi == CODEC_EPI_GELU) go(k_conv1d_bf3p<OT, TT, 1, CODEC_EPI_GELU, true, NIBS>);
+            else if (epi == CODEC_EPI_GAMMA_RES) go(k_conv1d_bf3p<OT, TT, 1, CODEC_EPI_GAMMA_RES, true, NIBS>);
+            else if (ps1) go(k_conv1d_bf3p<OT, TT, 1, CODEC_EPI_NONE, true, NIBS>);
+            else go(k_conv1d_bf3p<OT, TT, 1, CODEC_EPI_NONE, false, NIBS>);
+            FS_HIP(hipGetLastError());
+            return;
+        }
+        FS_REQUIRE(epi == CODEC_EPI_NONE || (epi == CODEC_EPI_RES && ps == 1), "plane-input convs: plain or residual epilogue only");
         if (nib <= 2 && (K == 2 || K == 3 || K == 7 || K == 11)) {
-            // thin late stages: B operands straight from the planes, weights resident in LDS, no barriers
-            static const int NT = getenv("FISHRT_BF3T_NT") ? atoi(getenv("FISHRT_BF3T_NT")) : 1;  // tuning knob: 32-sample tiles per wave (1: 3 blocks per CU, measured best | 2)
+            // thin late stages: B operands straight from the planes, weights resident in LDS, no barriers; one 32-sample tile per wave step
+            // (3 blocks per CU; two tiles per step measured 7 % slower)
+            constexpr int NT = 1;
             const int nwt = (T + 32 * NT - 1) / (32 * NT), ytiles = (Cout + 31) / 32;
-            const int gx = std::max(1, std::min((nwt + 3) / 4, (NT == 1 ? 768 : 512) / std::max(1, ytiles * B)));  // 2-3 blocks per CU, each walking over tiles
+            const int gx = std::max(1, std::min((nwt + 3) / 4, 768 / std::max(1, ytiles * B)));  // 3 blocks per CU, each walking over tiles
             const size_t smem = (size_t)nib * K * 4 * 32 * 16;
             auto go = [&](auto kern) {
                 raise_lds((const void*)kern, smem);
                 hipLaunchKernelGGL(kern, dim3(gx, ytiles, B), dim3(256), smem, st, xp, T, wp, Cp, bias, Cout, dil, epi, res, gamma, y, yp,
                                    post_silu ? 1 : 0, ps, nwt);
             };
-#define FS_THIN(KK)                                                   \
-    do {                                                              \
-        if (nib == 1 && NT == 1) go(k_conv1d_bf3t<KK, 1, 1>);         \
-        else if (nib == 1) go(k_conv1d_bf3t<KK, 1, 2>);               \
-        else if (NT == 1) go(k_conv1d_bf3t<KK, 2, 1>);                \
-        else go(k_conv1d_bf3t<KK, 2, 2>);                             \
+#define FS_THIN2(KK, NIB)                                                                        \
+    do {                                                                                         \
+        if (resid) go(k_conv1d_bf3t<KK, NIB, NT, CODEC_EPI_RES, true>);                          \
+        else if (ps1) go(k_conv1d_bf3t<KK, NIB, NT, CODEC_EPI_NONE, true>);                      \
+        else go(k_conv1d_bf3t<KK, NIB, NT, CODEC_EPI_NONE, false>);                              \
+    } while (0)
+#define FS_THIN(KK)                            \
+    do {                                       \
+        if (nib == 1) FS_THIN2(KK, 1);         \
+        else FS_THIN2(KK, 2);                  \
     } while (0)
             if (K == 2) FS_THIN(2);
             else if (K == 3) FS_THIN(3);
             else if (K == 7) FS_THIN(7);
             else FS_THIN(11);
 #undef FS_THIN
+#undef FS_THIN2
         } else {
             auto go = [&](auto kern, int OT, int TT) {
                 const int XSP = (TT + halo + 63) & ~63;
@@ -515,20 +606,20 @@ void codec_conv1d_bf3(const float* x, const uint16_t* xp, int B, int Cin, int T,
                                    K, dil, epi, res, gamma, y, yp, post_silu ? 1 : 0, ps);
             };
             FS_REQUIRE(K <= 13, "tap count above the plane kernel's staging bound");
-            static const char* cfg = getenv("FISHRT_BF3P_CFG");  // tuning knob: "ot,tt" forces one tile shape
-            int fot = 0, ftt = 0;
-            if (cfg) sscanf(cfg, "%d,%d", &fot, &ftt);
-            if (fot == 64 && ftt == 256) go(k_conv1d_bf3p<64, 256, 13>, 64, 256);
-            else if (fot == 64 && ftt == 128) go(k_conv1d_bf3p<64, 128, 13>, 64, 128);
-            else if (fot == 32 && ftt == 256) go(k_conv1d_bf3p<32, 256, 13>, 32, 256);
-            else if (fot == 32 && ftt == 128) go(k_conv1d_bf3p<32, 128, 13>, 32, 128);
-            else {
-                // measured per tile shape (profiles/r02_vocoder_calls.txt): 32-channel blocks win everywhere (3 blocks per CU instead of 2);
-                // 256-sample blocks where that still leaves >= 1024 blocks, else 128
-                const long long b256 = (long long)((T + 255) / 256) * ((Cout + 31) / 32) * B;
-                if (b256 >= 1024) go(k_conv1d_bf3p<32, 256, 13>, 32, 256);
-                else go(k_conv1d_bf3p<32, 128, 13>, 32, 128);
-            }
+            // measured per tile shape (profiles/r02_vocoder_calls.txt): 32-channel blocks win everywhere (3 blocks per CU; 64-channel blocks
+            // and double-buffered stages -- 1..2 blocks per CU -- were 5..30 % slower); 256-sample blocks where >= 1024 blocks remain
+            static const char* cfg = getenv("FISHRT_BF3P_TT");  // tuning knob: force 128 / 256-sample blocks
+            const long long b256 = (long long)((T + 255) / 256) * ((Cout + 31) / 32) * B;
+            const int TT = cfg ? atoi(cfg) : (b256 >= 1024 ? 256 : 128);
+#define FS_WIDE(TTv)                                                                             \
+    do {                                                                                         \
+        if (resid) go(k_conv1d_bf3p<32, TTv, 13, CODEC_EPI_RES, true>, 32, TTv);                 \
+        else if (ps1) go(k_conv1d_bf3p<32, TTv, 13, CODEC_EPI_NONE, true>, 32, TTv);             \
+        else go(k_conv1d_bf3p<32, TTv, 13, CODEC_EPI_NONE, false>, 32, TTv);                     \
+    } while (0)
+            if (TT == 256) FS_WIDE(256);
+            else FS_WIDE(128);
+#undef FS_WIDE
         }
         FS_HIP(hipGetLastError());
         return;

@@ -113,10 +113,28 @@ class Codec final : public CodecBase {
         codec_fsq_project((const uint32_t*)dcodes_.p, B, G, T, R(proj_w_), R(proj_b_), C_ / G, x, st_);
         int Tc = T;
         // upsample.0 then upsample.1 (quantizer.rs:126-133): transposed conv (k = s = 2) + ConvNeXt block
+        // bf16x3 mode with 16-channel-block widths: the pointwise convs read and write activation planes as well (codec_conv_bf3.hip)
+        const bool bb_planes = use_bf3_now_ && C_ % 128 == 0;
+        uint16_t *bp0 = nullptr, *bp1 = nullptr;
+        if (bb_planes) {
+            for (auto& pb : pbuf_) pb.ensure(act * sizeof(float) + (size_t)B * C_ * CODEC_PLANE_PAD * 4 + (256 << 10));
+            bp0 = pbuf_[0].u16(); bp1 = pbuf_[1].u16();
+            codec_act_split(x, B, C_, Tc, false, bp0, st_);
+        }
         for (int i = 0; i < 2; ++i) {
+            const CnxSpec& c = cnx_[i];
+            if (bb_planes) {
+                codec_tconv1d_planes(bp0, B, C_, Tc, conv(up_conv_[i]), 2, t1, st_);
+                Tc *= 2;
+                codec_dwconv_ln(t1, B, C_, Tc, R(c.dw), R(c.db), R(c.lnw), R(c.lnb), t2, st_);
+                codec_act_split(t2, B, C_, Tc, false, bp0, st_);
+                codec_conv1d_planes(nullptr, bp0, B, C_, Tc, conv(c.pw1), 1, false, CODEC_EPI_GELU, nullptr, nullptr, nullptr, bp1, false, st_);
+                // pwconv2 + gamma + residual: the sum feeds the next transposed conv / conv_pre as planes (no SiLU in front of either)
+                codec_conv1d_planes(nullptr, bp1, B, 4 * C_, Tc, conv(c.pw2), 1, false, CODEC_EPI_GAMMA_RES, t1, R(c.gamma), nullptr, bp0, false, st_);
+                continue;
+            }
             codec_tconv1d(x, B, C_, Tc, conv(up_conv_[i]), 2, false, t1, st_);
             Tc *= 2;
-            const CnxSpec& c = cnx_[i];
             codec_dwconv_ln(t1, B, C_, Tc, R(c.dw), R(c.db), R(c.lnw), R(c.lnb), t2, st_);
             codec_conv1d(t2, B, C_, Tc, conv(c.pw1), 1, false, CODEC_EPI_GELU, nullptr, nullptr, r, st_);
             codec_conv1d(r, B, 4 * C_, Tc, conv(c.pw2), 1, false, CODEC_EPI_GAMMA_RES, t1, R(c.gamma), x, st_);
@@ -130,8 +148,9 @@ class Codec final : public CodecBase {
         if (stage_planes(0)) {
             // 2 parts x 2 bytes = the f32 footprint, + the zero padding in front of every row + slack for window reads past T
             for (auto& b : pbuf_) b.ensure(act * sizeof(float) + (size_t)B * C_ * CODEC_PLANE_PAD * 4 + (256 << 10));
-            xp = pbuf_[0].u16(); t1p = pbuf_[1].u16(); t2p = pbuf_[2].u16(); accp = pbuf_[3].u16();
-            codec_conv1d_planes(x, nullptr, B, C_, Tc, conv(conv_pre_), 1, false, CODEC_EPI_NONE, nullptr, nullptr, nullptr, xp, true, st_);
+            xp = pbuf_[2].u16(); t1p = pbuf_[1].u16(); t2p = pbuf_[3].u16(); accp = pbuf_[4].u16();
+            if (bb_planes) codec_conv1d_planes(nullptr, bp0, B, C_, Tc, conv(conv_pre_), 1, false, CODEC_EPI_NONE, nullptr, nullptr, nullptr, xp, true, st_);
+            else codec_conv1d_planes(x, nullptr, B, C_, Tc, conv(conv_pre_), 1, false, CODEC_EPI_NONE, nullptr, nullptr, nullptr, xp, true, st_);
         } else {
             codec_conv1d(x, B, C_, Tc, conv(conv_pre_), 1, false, CODEC_EPI_NONE, nullptr, nullptr, t1, st_);
             std::swap(x, t1);
@@ -431,7 +450,7 @@ class Codec final : public CodecBase {
     std::vector<ConvSpec> convs_;
     std::vector<size_t> relaid_off_;
     size_t raw_floats_ = 0, relaid_floats_ = 0;
-    DBuf raw_, relaid_, packed_, dcodes_, buf_[7], pbuf_[4];
+    DBuf raw_, relaid_, packed_, dcodes_, buf_[7], pbuf_[5];
     std::vector<size_t> packed_off_;
     bool bf3_ = true, use_bf3_now_ = false;  // decode precision mode (fs_codec_set_precision); the encoder always runs exact f32
     int proj_w_ = 0, proj_b_ = 0, up_conv_[2] = {0, 0}, conv_pre_ = 0, conv_post_ = 0, ups_[5] = {0, 0, 0, 0, 0};

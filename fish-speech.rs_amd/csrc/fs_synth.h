@@ -8,7 +8,8 @@
 //     h   = mix(fnv1a64(name) ^ seed  +  (i+1) * 0x9E3779B97F4A7C15)
 //     s   = sum of the four 16-bit fields of h  - 131070
 //     val = mean + (float)s * (float)(std / 37837.2272)
-// tests/test_synth_gpu.py cross-checks this implementation against the test oracle's independent copy.
+// tests/test_lm_gpu.py::test_synthetic_weights_match_oracle_spec and tests/test_safetensors_gpu.py cross-check this implementation against
+// the test oracle's independent copy (oracle/fsgen.h).
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -11,7 +11,7 @@
 //     s   = (h & 0xFFFF) + ((h>>16)&0xFFFF) + ((h>>32)&0xFFFF) + (h>>48) - 131070   (Irwin-Hall n=4)
 //     val = mean + (float)s * (float)(std / 37837.2272)          [one f32 multiply, one f32 add]
 // The product library has its own copy of this spec (csrc/fs_synth.h); the two are
-// cross-checked by tests/test_synth.py.  The oracle never ships in the product path.
+// cross-checked by tests/test_oracle_known_answers.py::test_synth_generator_spec (spec values) and tests/test_lm_gpu.py::test_synthetic_weights_match_oracle_spec (vs the product).  The oracle never ships in the product path.
 #pragma once
 #include <cstdint>
 #include <cmath>

@@ -193,7 +193,7 @@ def run_config3(args, lm_factory, dist, rank, world, cfg, tok):
                    "requests": n_req, "batch_per_gpu": B, "frames_per_request": frames,
                    "parallelism": f"request shards x{world}; prompt broadcast + code all-gather over RCCL, no per-token collective"},
         "rtf": round((frames_total / FRAME_RATE) / dt, 2),
-        "rccl_ranks": int(seen), "weight_broadcast": wbcast, "frames_per_rank": [int(v) for v in fa.sum(axis=1)],
+        "rccl_ranks": int(seen), "frames_per_rank": [int(v) for v in fa.sum(axis=1)],
         "decode_step_us_rank0": round(step_s * 1e6, 1), "prefill_s_per_job_rank0": round(pre_s, 3),
         "roofline": {"bound": "hbm", "kernel": "static-batch decode step (one graph replay, B = 32 rows on the MFMA row path)",
                      "achieved": round((frame_bytes(cfg, tok, 0) + B * 12288 * (float(lens.mean()) + frames / 2)) / step_s / 1e9, 2),
@@ -320,7 +320,7 @@ def main():
                                "one request per step per GPU (prefill included in the timed region)",
                    "prompt_positions": L, "frames_per_request": args.frames, "requests_per_step": world,
                    "parallelism": f"replicas x{world} (no data-path collective; codes all-gathered over RCCL after the run)"},
-        "rtf": round((frames_total / FRAME_RATE) / dt, 2), "rccl_ranks": int(seen), "frames_per_rank": [int(v) for v in fa.sum(axis=1) * args.steps],
+        "rtf": round((frames_total / FRAME_RATE) / dt, 2), "rccl_ranks": int(seen), "weight_broadcast": wbcast, "frames_per_rank": [int(v) for v in fa.sum(axis=1) * args.steps],
         "decode_frames_per_s_per_gpu": round(1.0 / t_frame, 2), "prefill_ms": round(pre_ms, 3),
         "roofline": {"bound": "hbm", "kernel": f"decode frame = one hipGraph replay of {kpf} kernels (24 slow blocks x 5 + head + sample, then "
                                                + ("the 8 codebook passes of the fast decoder as ONE persistent launch" if kpf < 200 else "8 x (4 fast blocks x 4 + head + sample)")

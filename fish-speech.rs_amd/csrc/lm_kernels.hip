@@ -2492,10 +2492,13 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_slow_rows(const float
     if (c.temp <= 1e-7f) c.temp = 0.f;  // sampling/mod.rs:80
     for (int i = tid; i < n; i += SAMPLE_THREADS) lg[i] = logits[(size_t)b * ld + i];
     for (int i = tid; i < dim; i += SAMPLE_THREADS) XF[(size_t)b * dim + i] = X[(size_t)b * dim + i];  // hidden_states (:175)
-    if (tid == 0 && c.temp != 0.f) child_rng(master, (unsigned long long)st->frame * calls_per_frame * B + b, &lrng);
     __syncthreads();
     if (c.ignore_eos && tid == 0) lg[0] = -INFINITY;
     __syncthreads();
+    // the child StdRng (two ChaCha12 blocks + the PCG expansion: ~3 us of dependent integer work) is derived by the thread that also
+    // computes the draw's word inside block_sample -- the last one -- while wave 0 already selects; nobody else reads lrng before the
+    // barrier in front of the pick
+    if (tid == SAMPLE_THREADS - 1 && c.temp != 0.f) child_rng(master, (unsigned long long)st->frame * calls_per_frame * B + b, &lrng);
     const int idx = block_sample(lg, n, c, &lrng, sp, si, red, /*first_max=*/true);
     if (tid == 0) {
         const uint32_t tok = (uint32_t)idx + c.im_end_id;  // rescale_semantic_tokens (utils.rs:45-46)
@@ -2522,9 +2525,9 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_fast_rows(const float
     if (c.temp <= 1e-7f) c.temp = 0.f;
     // the batch repetition-penalty mask is never updated for Fish models (static_batch.rs:204-206): logits / 1.0
     for (int i = tid; i < n; i += SAMPLE_THREADS) lg[i] = logits[(size_t)b * n + i];
-    if (tid == 0 && c.temp != 0.f)
-        child_rng(master, ((unsigned long long)st->frame * (n_cb + 1) + 1 + cb) * B + b, &lrng);
     __syncthreads();
+    if (tid == SAMPLE_THREADS - 1 && c.temp != 0.f)  // (see k_sample_slow_rows: off wave 0's critical path)
+        child_rng(master, ((unsigned long long)st->frame * (n_cb + 1) + 1 + cb) * B + b, &lrng);
     const int code = block_sample(lg, n, c, &lrng, sp, si, red, /*first_max=*/true);
     if (tid == 0) st->cur[cb + 1] = (uint32_t)code;
     if (cb != n_cb - 1) {

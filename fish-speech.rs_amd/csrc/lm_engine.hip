@@ -481,7 +481,9 @@ class LM final : public LMBase {
             FS_HIP(hipMemcpy(ctl, d_sctl_.p, sizeof(ctl), hipMemcpyDeviceToHost));
             if (ctl[1]) {
                 FS_HIP(hipMemset(d_sctl_.as<uint32_t>() + 1, 0, 4));
-                throw Error("persistent slow-transformer kernel: a grid-wide wait timed out (are all 256 CUs available to this process?)");
+                pslow_ok_ = persist_ok_ = false;  // this handle stays on the per-node graphs from now on: only this request is lost
+                throw Error("persistent slow-transformer kernel: a grid-wide wait timed out (are all 256 CUs available to this process?); "
+                            "the handle falls back to per-node launches for its next calls");
             }
         }
         if (use_persist_) {
@@ -489,7 +491,9 @@ class LM final : public LMBase {
             FS_HIP(hipMemcpy(ctl, d_ctl_.p, sizeof(ctl), hipMemcpyDeviceToHost));
             if (ctl[1] || ctl[2]) {
                 FS_HIP(hipMemset(d_ctl_.as<uint32_t>() + 1, 0, 8));
-                throw Error(ctl[1] ? "persistent fast-decoder kernel: a grid-wide wait timed out (are all 256 CUs available to this process?)"
+                if (ctl[1]) pslow_ok_ = persist_ok_ = false;  // (see above)
+                throw Error(ctl[1] ? "persistent fast-decoder kernel: a grid-wide wait timed out (are all 256 CUs available to this process?); "
+                                     "the handle falls back to per-node launches for its next calls"
                                    : "persistent fast-decoder kernel launched with temp != 0");
             }
         }

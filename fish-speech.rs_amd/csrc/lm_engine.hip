@@ -127,6 +127,8 @@ class LM final : public LMBase {
         for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
         for (auto& e : ev_batch_) if (e) (void)hipEventDestroy(e);
         if (h_pin_) (void)hipHostFree(h_pin_);
+        if (ev_pf_) (void)hipEventDestroy(ev_pf_);
+        if (st_pf_) (void)hipStreamDestroy(st_pf_);
         if (st_) (void)hipStreamDestroy(st_);
     }
 
@@ -697,8 +699,8 @@ class LM final : public LMBase {
         sess_left_.assign(B_, -1);
         sess_pos_.assign(B_, 0);
         sess_hs_.assign(B_, SeqState{});
+        sess_pend_.slot = -1;
         for (int b = 0; b < B_; ++b) park_slot(b);
-        if (d_sess_x_.n < sizeof(float) * (size_t)B_ * a_.dim) d_sess_x_.alloc(sizeof(float) * (size_t)B_ * a_.dim);
         FS_HIP(hipMemsetAsync(d_pfx_.p, 0, sizeof(float) * (size_t)B_ * a_.dim, st_));
         FS_HIP(hipStreamSynchronize(st_));
         stats_ = {};
@@ -712,47 +714,100 @@ class LM final : public LMBase {
         FS_HIP(hipMemcpyAsync(d_page_table_.as<int>() + (size_t)b * max_pages_, &sess_scratch_, sizeof(int), hipMemcpyHostToDevice, st_));
         FS_HIP(hipStreamSynchronize(st_));
     }
+    // A joining request is prefilled on its own stream with its own row buffers, staging SeqState (index B_) and page-table row (B_),
+    // so the decode steps of the live slots go on underneath; the slot itself stays parked (scratch page, frozen) until the prefill has
+    // finished and activate_pending() -- between two steps -- hands it its page-table row, state and first input embedding.
+    // One prefill is in flight at a time: a second add first waits for (and activates) the previous one.
     int session_add(const uint32_t* prompt, int L, int max_new_tokens) override {
         use_device();
         FS_REQUIRE(sess_active_, "no open session");
         FS_REQUIRE(L >= 1, "empty prompt");
         if (L > a_.max_seq_len) throw Error("prompt exceeds max_seq_len (dual_ar.rs:623-624)");
         int b = -1;
-        for (int i = 0; i < B_; ++i) if (sess_left_[i] < 0) { b = i; break; }
+        for (int i = 0; i < B_; ++i) if (sess_left_[i] == -1) { b = i; break; }
         if (b < 0) return -1;
         const int C1 = a_.num_codebooks + 1;
         validate_tokens(prompt, 0, 1, L);
         long long n_iter = 1 + std::max<long long>(0, (long long)max_new_tokens - L + 1);  // static_batch.rs:122,262-267
         n_iter = std::min<long long>(n_iter, (long long)a_.max_seq_len - L + 1);           // a slot stops at max_seq_len instead of erroring
         FS_REQUIRE(n_iter <= out_cap_, "generation longer than the output staging buffer");
-        ensure_capacity(b, L + (int)n_iter - 1);
+        ensure_prefill2_buffers();
+        activate_pending(/*wait=*/true);
+        alloc_pages(b, L + (int)n_iter - 1);
         const int Lp = L - 1;
+        sess_pend_ = {b, L, (int)n_iter, {}};
+        sess_pend_.prompt.assign(prompt, prompt + (size_t)C1 * L);  // (kept until activation: the copy below may read it asynchronously)
         if (Lp >= 1) {
-            // the row buffers are shared with the step: keep the live slots' next-frame inputs aside during the prefill passes
-            FS_HIP(hipMemcpyAsync(d_sess_x_.p, d_pfx_.p, sizeof(float) * (size_t)B_ * a_.dim, hipMemcpyDeviceToDevice, st_));
-            if (d_prompt_.n < sizeof(uint32_t) * (size_t)C1 * L) d_prompt_.alloc(sizeof(uint32_t) * (size_t)C1 * L);
-            FS_HIP(hipMemcpyAsync(d_prompt_.p, prompt, sizeof(uint32_t) * (size_t)C1 * L, hipMemcpyHostToDevice, st_));
-            SeqState ps = {};
-            ps.prompt_L = L;
-            FS_HIP(hipMemcpyAsync(state(b), &ps, sizeof(ps), hipMemcpyHostToDevice, st_));
-            seq_len_[b] = 0;
-            prefill_tokens(b, Lp, /*use_graph=*/false);
-            FS_HIP(hipMemcpyAsync(d_pfx_.p, d_sess_x_.p, sizeof(float) * (size_t)B_ * a_.dim, hipMemcpyDeviceToDevice, st_));
-            FS_HIP(hipStreamSynchronize(st_));
+            const auto& pg = seq_pages_[b];
+            FS_HIP(hipMemcpyAsync(d_page_table_.as<int>() + (size_t)B_ * max_pages_, pg.data(), sizeof(int) * pg.size(), hipMemcpyHostToDevice, st_pf_));
+            if (d2_prompt_.n < sizeof(uint32_t) * (size_t)C1 * L) d2_prompt_.alloc(sizeof(uint32_t) * (size_t)C1 * L);
+            FS_HIP(hipMemcpyAsync(d2_prompt_.p, sess_pend_.prompt.data(), sizeof(uint32_t) * (size_t)C1 * L, hipMemcpyHostToDevice, st_pf_));
+            sess_stage_ = SeqState{};
+            sess_stage_.prompt_L = L;
+            FS_HIP(hipMemcpyAsync(state(B_), &sess_stage_, sizeof(SeqState), hipMemcpyHostToDevice, st_pf_));
+            RowsCtx c = rows_ctx2(state(B_), /*pos_step=*/1, /*pt_stride=*/0);
+            for (int done = 0; done < Lp;) {
+                const int M = std::min(a_.head_dim == 64 ? kRowsCap : kPartRows, Lp - done);
+                c.nc_launch = chunk_bucket(done + M);
+                LmKernels<WT>::prefill_embed(d_, tok_emb_, cb_emb_, a_.num_codebooks, a_.codebook_size, d_cfg_.as<SampleCfg>(),
+                                             d2_prompt_.as<uint32_t>(), state(B_), M, d2_pfx_.as<float>(), st_pf_);
+                for (int l = 0; l < a_.n_layer; ++l) LmKernels<WT>::rows_layer(d_, M, c, slow_[l], slow_kv(l, B_), l == 0, st_pf_);
+                LmKernels<WT>::rows_finish(d_, M, c, nullptr, st_pf_);
+                launch_advance_n(state(B_), M, st_pf_);
+                done += M;
+            }
         }
+        FS_HIP(hipEventRecord(ev_pf_, st_pf_));
+        sess_left_[b] = -2;  // reserved: prefilling
+        stats_.prompt_tokens += (uint64_t)L;
+        return b;
+    }
+    // the pending request (if its prefill has finished, or after waiting for it) becomes a live slot; called between steps only
+    void activate_pending(bool wait) {
+        if (sess_pend_.slot < 0) return;
+        if (!wait) {
+            const hipError_t q = hipEventQuery(ev_pf_);
+            if (q == hipErrorNotReady) return;
+            FS_HIP(q);
+        }
+        FS_HIP(hipEventSynchronize(ev_pf_));
+        const int b = sess_pend_.slot, L = sess_pend_.L, Lp = L - 1, C1 = a_.num_codebooks + 1;
+        const auto& pg = seq_pages_[b];
+        FS_HIP(hipMemcpyAsync(d_page_table_.as<int>() + (size_t)b * max_pages_, pg.data(), sizeof(int) * pg.size(), hipMemcpyHostToDevice, st_));
         seq_len_[b] = Lp;
         SeqState ss = {};
         ss.pos = Lp; ss.prompt_L = L; ss.step = Lp;
-        for (int r = 0; r < C1; ++r) ss.cur[r] = prompt[(size_t)r * L + (L - 1)];
+        for (int r = 0; r < C1; ++r) ss.cur[r] = sess_pend_.prompt[(size_t)r * L + (L - 1)];
         sess_hs_[b] = ss;
         FS_HIP(hipMemcpyAsync(state(b), &sess_hs_[b], sizeof(SeqState), hipMemcpyHostToDevice, st_));
         LmKernels<WT>::embed(d_, tok_emb_, cb_emb_, a_.num_codebooks, a_.codebook_size, d_cfg_.as<SampleCfg>(), nullptr, state(b),
                              d_pfx_.as<float>() + (size_t)b * a_.dim, st_);
         FS_HIP(hipStreamSynchronize(st_));
-        sess_left_[b] = (int)n_iter;
+        sess_left_[b] = sess_pend_.n_iter;
         sess_pos_[b] = Lp;
-        stats_.prompt_tokens += (uint64_t)L;
-        return b;
+        sess_pend_.slot = -1;
+    }
+    void alloc_pages(int b, int n_tokens) {  // ensure_capacity without the upload: the row of a parked slot must keep pointing at the scratch page
+        FS_REQUIRE(n_tokens <= a_.max_seq_len, "sequence longer than max_seq_len");
+        const int need = (n_tokens + KV_PAGE - 1) / KV_PAGE;
+        auto& pg = seq_pages_[b];
+        FS_REQUIRE((int)free_pages_.size() >= need - (int)pg.size(), "KV page pool exhausted");
+        while ((int)pg.size() < need) { pg.push_back(free_pages_.back()); free_pages_.pop_back(); }
+    }
+    void ensure_prefill2_buffers() {
+        if (d2_pfx_.p) return;
+        FS_HIP(hipStreamCreateWithFlags(&st_pf_, hipStreamNonBlocking));
+        FS_HIP(hipEventCreateWithFlags(&ev_pf_, hipEventDisableTiming));
+        d2_pfx_.alloc(d_pfx_.n); d2_pfq_.alloc(d_pfq_.n); d2_pfslab_.alloc(d_pfslab_.n); d2_pfa_.alloc(d_pfa_.n); d2_pfa2_.alloc(d_pfa2_.n);
+        d2_pfss_.alloc(d_pfss_.n); d2_pfc_.alloc(d_pfc_.n); d2_pfpart_.alloc(d_pfpart_.n);
+        for (DevBuf* bf : {&d2_pfx_, &d2_pfa_, &d2_pfa2_, &d2_pfss_, &d2_pfc_, &d2_pfpart_}) FS_HIP(hipMemsetAsync(bf->p, 0, bf->n, st_pf_));
+        FS_HIP(hipStreamSynchronize(st_pf_));
+    }
+    RowsCtx rows_ctx2(const SeqState* st, int pos_step, int pt_stride) {
+        RowsCtx c = rows_ctx(st, pos_step, pt_stride);
+        c.X = d2_pfx_.as<float>(); c.Q = d2_pfq_.as<float>(); c.part = d2_pfpart_.as<float>(); c.P = d2_pfslab_.as<float>();
+        c.A = d2_pfa_.as<uint16_t>(); c.C = d2_pfc_.as<uint16_t>(); c.A2 = d2_pfa2_.as<uint16_t>(); c.ss = d2_pfss_.as<float>();
+        return c;
     }
     void session_step(int n_frames, int* n_active) override {
         use_device();
@@ -760,9 +815,11 @@ class LM final : public LMBase {
         FS_HIP(hipEventRecord(ev_[1], st_));
         int launched = 0;
         while (launched < n_frames) {
+            activate_pending(/*wait=*/false);  // a finished prefill joins here, between two replays of the step graph
             int chunk = n_frames - launched, longest = 0, live = 0;
             for (int b = 0; b < B_; ++b)
                 if (sess_left_[b] > 0 && !sess_hs_[b].done) { chunk = std::min(chunk, sess_left_[b]); longest = std::max(longest, sess_pos_[b]); ++live; }
+            if (!live && sess_pend_.slot >= 0) { activate_pending(true); continue; }  // nothing else to run: wait for the joining request
             if (!live) break;
             for (int i = 0; i < chunk; ++i) {
                 set_bucket(longest + i + 1);
@@ -790,7 +847,7 @@ class LM final : public LMBase {
         int act = 0;
         uint64_t frames = 0;
         for (int b = 0; b < B_; ++b) {
-            if (sess_left_[b] > 0 && !sess_hs_[b].done) ++act;
+            if ((sess_left_[b] > 0 && !sess_hs_[b].done) || sess_left_[b] == -2) ++act;  // (-2: still prefilling)
             if (sess_left_[b] >= 0) frames += (uint64_t)sess_hs_[b].n_out;
         }
         stats_.frames = sess_released_frames_ + frames;
@@ -798,9 +855,9 @@ class LM final : public LMBase {
     }
     void session_poll(int slot, uint32_t* codes_out, size_t cap, size_t* n_frames, int* done) override {
         use_device();
-        FS_REQUIRE(sess_active_ && slot >= 0 && slot < B_ && sess_left_[slot] >= 0, "not a live session slot");
+        FS_REQUIRE(sess_active_ && slot >= 0 && slot < B_ && sess_left_[slot] != -1, "not a live session slot");
         const int C = a_.num_codebooks;
-        const size_t nb = (size_t)sess_hs_[slot].n_out;
+        const size_t nb = sess_left_[slot] == -2 ? 0 : (size_t)sess_hs_[slot].n_out;  // (-2: still prefilling)
         if (codes_out) {
             FS_REQUIRE(nb <= cap, "codes_out capacity too small for the generated frames");
             for (int c = 0; c < C; ++c)
@@ -809,11 +866,12 @@ class LM final : public LMBase {
             FS_HIP(hipStreamSynchronize(st_));
         }
         if (n_frames) *n_frames = nb;
-        if (done) *done = (sess_hs_[slot].done != 0 || sess_left_[slot] == 0) ? 1 : 0;
+        if (done) *done = (sess_left_[slot] != -2 && (sess_hs_[slot].done != 0 || sess_left_[slot] == 0)) ? 1 : 0;
     }
     void session_release(int slot) override {
         use_device();
-        FS_REQUIRE(sess_active_ && slot >= 0 && slot < B_ && sess_left_[slot] >= 0, "not a live session slot");
+        FS_REQUIRE(sess_active_ && slot >= 0 && slot < B_ && sess_left_[slot] != -1, "not a live session slot");
+        if (sess_pend_.slot == slot) activate_pending(true);
         sess_released_frames_ += (uint64_t)sess_hs_[slot].n_out;
         truncate(slot, 0);
         park_slot(slot);
@@ -822,6 +880,7 @@ class LM final : public LMBase {
     void session_end() override {
         if (!sess_active_) return;
         use_device();
+        if (sess_pend_.slot >= 0) { (void)hipEventSynchronize(ev_pf_); sess_pend_.slot = -1; }
         for (int b = 0; b < B_; ++b) truncate(b, 0);
         free_pages_.push_back(sess_scratch_);
         SampleCfg cfg = base_cfg();
@@ -990,7 +1049,7 @@ class LM final : public LMBase {
         // unconditionally and mask them afterwards, which needs finite (not uninitialised) contents
         kv_pool_.alloc((size_t)a_.n_layer * 2 * n_pages_ * page_elems_ * sizeof(KT));
         FS_HIP(hipMemset(kv_pool_.p, 0, kv_pool_.n));
-        d_page_table_.alloc(sizeof(int) * (size_t)B_ * max_pages_);
+        d_page_table_.alloc(sizeof(int) * (size_t)(B_ + 1) * max_pages_);  // + the staging row of a session's joining request
         FS_HIP(hipMemset(d_page_table_.p, 0, d_page_table_.n));
         for (int p = n_pages_ - 1; p >= 0; --p) free_pages_.push_back(p);
         seq_pages_.assign(B_, {});
@@ -1012,7 +1071,7 @@ class LM final : public LMBase {
         d_logits_fast_.alloc(sizeof(float) * a_.codebook_size);
         d_hid_slot_.alloc(sizeof(float*));
         FS_HIP(hipMemset(d_hid_slot_.p, 0, sizeof(float*)));
-        d_state_.alloc(sizeof(SeqState) * B_);
+        d_state_.alloc(sizeof(SeqState) * (B_ + 1));  // + the staging state of a session's joining request
         FS_HIP(hipMemset(d_state_.p, 0, d_state_.n));
         d_cfg_.alloc(sizeof(SampleCfg));
         SampleCfg c = base_cfg();
@@ -1409,7 +1468,12 @@ class LM final : public LMBase {
     std::vector<SeqState> sess_hs_;
     int sess_scratch_ = 0;
     uint64_t sess_released_frames_ = 0;
-    DevBuf d_sess_x_;
+    struct PendingAdd { int slot = -1, L = 0, n_iter = 0; std::vector<uint32_t> prompt; };
+    PendingAdd sess_pend_;
+    SeqState sess_stage_ = {};
+    hipStream_t st_pf_ = nullptr;
+    hipEvent_t ev_pf_ = nullptr;
+    DevBuf d2_pfx_, d2_pfq_, d2_pfslab_, d2_pfa_, d2_pfa2_, d2_pfss_, d2_pfc_, d2_pfpart_, d2_prompt_;  // row buffers of the session's prefill stream
     DevBuf d_spack_, d_hpack_, d_snorms_, d_sedges_, d_sctl_;  // persistent slow transformer
     DevBuf d_pfx_, d_pfq_, d_pfslab_, d_pfa_, d_pfa2_, d_pfss_, d_pfc_, d_pfpart_;  // MFMA row-path activations (kRowsCap rows)
     DevBuf d_bprompt_;  // static batch: all left-padded prompts [B][C + 1][Lmax] (group prefill)

@@ -165,15 +165,16 @@ int fs_lm_weights_adopt(fs_lm_t* lm);
 
 /* ---- continuous batching (no reference counterpart: the reference server serialises requests behind one mutex, server/lib/state.rs:12-29,
  * or runs lock-step batches, generate/static_batch.rs:282-390; SURVEY.md section 8 f-4 asks for a scheduler that replaces the mutex).
- * A session turns the max_batch rows of the static-batch decode step into independent request SLOTS: requests join between steps (their
- * prompt is prefilled on the matrix-core row path while the other slots wait) and leave when finished; every step streams the weights
- * once for all live slots.  A slot behaves exactly like row 0 of a ONE-prompt fs_lm_generate_batch call: no left padding (own positions
+ * A session turns the max_batch rows of the static-batch decode step into independent request SLOTS: a request's prompt is prefilled on
+ * the matrix-core row path on a second stream while the other slots keep stepping, it joins between two steps once that has finished,
+ * and leaves when done; every step streams the weights once for all live slots.  A slot behaves exactly like row 0 of a ONE-prompt fs_lm_generate_batch call: no left padding (own positions
  * and KV pages), first frame emitted unconditionally, BatchedLogitsProcessor sampling (sampling/mod.rs:77-109; repetition penalty is
  * ignored like static_batch.rs:204-206), 1 + max(0, max_new_tokens - L + 1) iterations (static_batch.rs:122), stopping early at
  * <|im_end|> or at max_seq_len.  With temp <= 1e-7 a slot's codes are independent of what the other slots do.
  * bf16 / fp8 handles with the Fish 1.5 token layout only; while a session is open the handle's other entry points fail. */
 int fs_lm_session_begin(fs_lm_t* lm, const fs_sampling* sampling, uint64_t seed, uint32_t flags /* FS_GEN_IGNORE_EOS */);
-/* prompt u32 [C+1, L] row-major; *slot = the slot taken, or -1 when all max_batch slots are busy (not an error) */
+/* prompt u32 [C+1, L] row-major (copied); *slot = the slot taken, or -1 when all max_batch slots are busy (not an error).  Returns once the
+ * prefill is enqueued (one prefill in flight: a second add first waits for the previous one); the slot starts generating in a later step */
 int fs_lm_session_add(fs_lm_t* lm, const uint32_t* prompt, int L, int max_new_tokens, int* slot);
 /* run up to n_frames decode steps for all live slots (stops early when none is live); *n_active = slots still generating afterwards */
 int fs_lm_session_step(fs_lm_t* lm, int n_frames, int* n_active);

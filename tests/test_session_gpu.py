@@ -143,3 +143,41 @@ def test_sampled_session_full_size_shapes():
     assert st["frames"] == sum(c.shape[1] for c in done_codes.values())
     print(f"sampled session: {st['frames']} frames in {st['decode_ms']:.1f} ms of decode steps ({st['graph_launches']} launches)")
     lm.close()
+
+
+def test_fullsize_greedy_session_vs_oracle_one_prompt_batches():
+    """Fish-1.5 shapes (dim 1024, 24 + 4 layers, audio range 2037, codebooks 1024), bf16, 8 slots, 5 requests joining at different steps:
+    every slot == the oracle's one-prompt generate_static_batch on the same bf16-rounded weights, except at oracle near-ties"""
+    SEEDW = 0xF15E5EED
+    lm = fishrt.DualARTransformer(fcfg.FISH_1_5, fcfg.FISH_1_5_TOKENS, 0, "bf16", max_batch=8).load_synthetic(SEEDW)
+    o = orc.OracleLM(orc.FISH15).load_synthetic(SEEDW, bf16=True)
+    o.set_kv_round_bf16(True)
+    rng = np.random.RandomState(21)
+    im_end, sem0 = fcfg.FISH_1_5_TOKENS["im_end_id"], fcfg.FISH_1_5_TOKENS["semantic_start_id"]
+    reqs = []
+    for L, frames in ((12, 14), (31, 10), (7, 16), (20, 12), (1, 9)):
+        p = np.zeros((9, L), np.uint32)
+        p[0] = rng.randint(0, im_end, L)
+        k = min(L - 1, 4)
+        if k > 0:
+            p[0, 1 : 1 + k] = sem0 + rng.randint(0, 1024, k)
+            p[1:, 1 : 1 + k] = rng.randint(0, 1024, (8, k))
+        reqs.append((p, frames + L - 2))
+    got = {}
+    with lm.session(temp=0.0, top_p=1.0, top_k=0, ignore_eos=True) as s:
+        live, nxt = {}, 0
+        while nxt < len(reqs) or live:
+            if nxt < len(reqs):  # one new request per round: each joins while the earlier ones are mid-flight
+                live[s.add(*reqs[nxt])] = nxt
+                nxt += 1
+            s.step(3)
+            for slot in list(live):
+                if s.poll(slot, codes=False)[1]:
+                    got[live.pop(slot)] = s.poll(slot)[0]
+                    s.release(slot)
+    flips = 0
+    for i, (p, mx) in enumerate(reqs):
+        flips += _check_vs_oracle(o, p, mx, got[i], f"full-size request {i}", ignore_eos=True)
+    print(f"full-size session: {len(reqs) - flips}/{len(reqs)} requests identical to the oracle's one-prompt static batch")
+    assert flips <= 2
+    lm.close()

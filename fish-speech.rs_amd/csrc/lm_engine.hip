@@ -733,9 +733,14 @@ class LM final : public LMBase {
         FS_REQUIRE(n_iter <= out_cap_, "generation longer than the output staging buffer");
         ensure_prefill2_buffers();
         activate_pending(/*wait=*/true);
+        {   // not enough free KV pages right now: like "all slots busy" (pages come back when slots are released), not an error
+            const int need = (L + (int)n_iter - 1 + KV_PAGE - 1) / KV_PAGE;
+            if ((int)free_pages_.size() < need - (int)seq_pages_[b].size()) return -1;
+        }
         alloc_pages(b, L + (int)n_iter - 1);
         const int Lp = L - 1;
         sess_pend_ = {b, L, (int)n_iter, {}};
+        sess_left_[b] = -2;  // reserved: prefilling
         sess_pend_.prompt.assign(prompt, prompt + (size_t)C1 * L);  // (kept until activation: the copy below may read it asynchronously)
         if (Lp >= 1) {
             const auto& pg = seq_pages_[b];
@@ -758,7 +763,6 @@ class LM final : public LMBase {
             }
         }
         FS_HIP(hipEventRecord(ev_pf_, st_pf_));
-        sess_left_[b] = -2;  // reserved: prefilling
         stats_.prompt_tokens += (uint64_t)L;
         return b;
     }

@@ -173,7 +173,8 @@ int fs_lm_weights_adopt(fs_lm_t* lm);
  * <|im_end|> or at max_seq_len.  With temp <= 1e-7 a slot's codes are independent of what the other slots do.
  * bf16 / fp8 handles with the Fish 1.5 token layout only; while a session is open the handle's other entry points fail. */
 int fs_lm_session_begin(fs_lm_t* lm, const fs_sampling* sampling, uint64_t seed, uint32_t flags /* FS_GEN_IGNORE_EOS */);
-/* prompt u32 [C+1, L] row-major (copied); *slot = the slot taken, or -1 when all max_batch slots are busy (not an error).  Returns once the
+/* prompt u32 [C+1, L] row-major (copied); *slot = the slot taken, or -1 when all max_batch slots are busy or the KV page pool cannot hold
+ * the request right now (not an error: retry after a release).  Returns once the
  * prefill is enqueued (one prefill in flight: a second add first waits for the previous one); the slot starts generating in a later step */
 int fs_lm_session_add(fs_lm_t* lm, const uint32_t* prompt, int L, int max_new_tokens, int* slot);
 /* run up to n_frames decode steps for all live slots (stops early when none is live); *n_active = slots still generating afterwards */

@@ -9,7 +9,7 @@
 //     s   = sum of the four 16-bit fields of h  - 131070
 //     val = mean + (float)s * (float)(std / 37837.2272)
 // tests/test_lm_gpu.py::test_synthetic_weights_match_oracle_spec and tests/test_safetensors_gpu.py cross-check this implementation against
-// the test oracle's independent copy (oracle/fsgen.h).
+// the test oracle's independent copy.
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -38,10 +38,11 @@ def _check_vs_oracle(o, prompt, max_new, got, what, **kw):
     return 1
 
 
-@pytest.mark.parametrize("cfg", [fcfg.TINY, MID], ids=["hd32", "hd64"])
-def test_slots_equal_one_prompt_static_batches_whatever_the_neighbours_do(cfg):
-    lm = fishrt.DualARTransformer(cfg, fcfg.TINY_TOKENS, 0, "bf16", max_batch=4).load_synthetic(SEED)
-    o = orc.OracleLM(orc.TINY | {k: cfg[k] for k in ("dim", "n_head", "n_local_heads", "head_dim", "intermediate_size")}).load_synthetic(SEED, bf16=True)
+@pytest.mark.parametrize("cfg,dtype", [(fcfg.TINY, "bf16"), (MID, "bf16"), (MID, "fp8")], ids=["hd32", "hd64", "hd64-fp8"])
+def test_slots_equal_one_prompt_static_batches_whatever_the_neighbours_do(cfg, dtype):
+    lm = fishrt.DualARTransformer(cfg, fcfg.TINY_TOKENS, 0, dtype, max_batch=4).load_synthetic(SEED)
+    o = orc.OracleLM(orc.TINY | {k: cfg[k] for k in ("dim", "n_head", "n_local_heads", "head_dim", "intermediate_size")})
+    o.load_synthetic(SEED, bf16=dtype == "bf16", fp8=dtype == "fp8")  # fp8: the oracle's FS_FP8 weight mode (same bytes and row scales)
     o.set_kv_round_bf16(True)
     rng = np.random.RandomState(7)
     lens = [9, 1, 40, 17, 23, 5, 64, 12, 31]

@@ -834,8 +834,13 @@ class LM final : public LMBase {
                 if (sess_left_[b] > 0 && !sess_hs_[b].done) {
                     sess_left_[b] -= chunk; sess_pos_[b] += chunk;
                     if (sess_left_[b] == 0) {  // iteration budget spent: the slot is finished whatever it sampled
-                        const int one = 1;
+                        // Its last iteration left pos = L + n_iter - 1, one token PAST its page allocation (and == max_seq_len when the
+                        // budget was clamped), and a frozen slot still rides the step graphs, whose QKV epilogue writes K/V at pos: park
+                        // the write on the scratch page at position 0 (n_out and the codes stay) before the next replay can run.
+                        static const int one = 1, zero = 0;
                         FS_HIP(hipMemcpyAsync(&state(b)->done, &one, sizeof(int), hipMemcpyHostToDevice, st_));
+                        FS_HIP(hipMemcpyAsync(&state(b)->pos, &zero, sizeof(int), hipMemcpyHostToDevice, st_));
+                        FS_HIP(hipMemcpyAsync(d_page_table_.as<int>() + (size_t)b * max_pages_, &sess_scratch_, sizeof(int), hipMemcpyHostToDevice, st_));
                     }
                 }
             // (a slot that sampled <|im_end|> inside the chunk froze itself on the device; the host learns it below)

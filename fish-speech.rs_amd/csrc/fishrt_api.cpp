@@ -75,6 +75,9 @@ int fs_selftest_sample_rows(int device_id, const float* logits, int B, int n, co
     FS_TRY(fs::debug_sample_rows(device_id, logits, B, n, s->temp, s->top_p, s->top_k, seed, call_index, out))
 }
 
+int fs_lm_debug_capture(fs_lm_t* lm, int n_frames) { FS_ARG(lm, "null argument"); FS_TRY(lm->impl->debug_capture(n_frames)) }
+int fs_lm_debug_read(fs_lm_t* lm, float* out, int n_frames) { FS_ARG(lm && out, "null argument"); FS_TRY(lm->impl->debug_read(out, n_frames)) }
+
 int fs_lm_create(const fs_model_args* args, const fs_token_cfg* tok, int device_id, fs_dtype dtype, int max_batch, fs_lm_t** out) {
     FS_ARG(args && tok && out, "null argument");
     FS_TRY({ *out = nullptr; fs::LMBase* p = fs::make_lm(*args, *tok, device_id, dtype, max_batch); *out = new fs_lm{p}; })

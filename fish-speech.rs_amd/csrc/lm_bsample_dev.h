@@ -1,0 +1,370 @@
+// Block-parallel top-k / top-p / WeightedIndex sampler (device code; include inside namespace fs).
+//
+// Same decision procedure, the same f32 operations in the same order, as the one-wave sampler of lm_kernels.hip (wave_topk_select +
+// wave_pick) and as oracle::LogitsProcessor (candle LogitsProcessor / BatchedLogitsProcessor, sampling/mod.rs:51-132; rand 0.8.5
+// WeightedIndex<f32> + UniformFloat<f32>): softmax(logits / temp) with an f64 denominator -> the top_k largest probabilities (ties: lower
+// index first), kept in ascending index order -> if top_p < their sequential f32 sum: zero every probability from the rank (descending
+// order) at which the running f32 sum has reached top_p -> cumulative f32 weights in index order -> first entry whose cumulative weight
+// exceeds the uniform draw.  What is different is WHO does the work: all NT threads of the block instead of one wave, so the call costs a
+// few microseconds instead of 12-13 -- it sits on the critical path of every codebook decision of a sampled request, 8 times per frame,
+// on every workgroup of the persistent fast decoder (lm_persist.hip), and once per row in the batched samplers.
+//   A  softmax: thread t owns the EPT consecutive candidates t*EPT ..; block max and the f64 sum meet in LDS (2 barriers)
+//   B  k-th largest probability by radix select over the 30-bit patterns (8 + 8 + 8 + 6 bits): every thread counts its candidates into a
+//      256-bin LDS histogram (ds_add), wave 0 scans the bins (4 per lane, DPP scan) while wave 1 clears the other histogram (2 barriers
+//      per pass)
+//   C  keep p > T and the first ties in index order: two block prefix scans (wave DPP scan + one LDS hop each), compaction into the
+//      index-ordered arrays kp / ki; a tree sum of the kept probabilities decides whether a top-p cut is possible at all
+//   D  in parallel: wave 0 runs the sequential ascending-index f32 sum of the kept probabilities (leaving the prefix sums, which ARE the
+//      WeightedIndex cumulative weights when nothing is cut); if a cut is possible the other waves rank the entries by counting
+//      (thread j: #{i: p_i > p_j or (p_i == p_j and i < j)}) and scatter the probabilities into descending order
+//   E  top-p (only if top_p < sum): wave 0 walks the descending array until the running sum reaches top_p; entries ranked at or after the
+//      cut are zeroed in parallel; the surviving weights (typically a few dozen) are compacted and summed by wave 0
+//   F  draw: every thread tests its own entry against the uniform draw; LDS atomicMin / atomicMax pick the first / last non-zero entry
+// Requirements: NT a multiple of 64, NT >= top_k + 64, top_k <= 256, n <= NT * EPT <= 2048.  All NT threads must call.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+constexpr int BS_MAXK = 256;
+
+// rand 0.8.5 StdRng == ChaCha12 (rand_chacha 0.3.1): word `n` of the keystream, 64-bit block counter, stream id 0.
+__device__ inline uint32_t chacha12_word(const uint32_t* key, unsigned long long n) {
+    const unsigned long long ctr = n >> 4;
+    uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key[0], key[1], key[2], key[3],
+                      key[4], key[5], key[6], key[7], (uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+    uint32_t w[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) w[i] = s[i];
+#define FS_ROTL(v, c) (((v) << (c)) | ((v) >> (32 - (c))))
+#define FS_QR(a, b, c, d)                                   \
+    w[a] += w[b]; w[d] = FS_ROTL(w[d] ^ w[a], 16); w[c] += w[d]; w[b] = FS_ROTL(w[b] ^ w[c], 12); \
+    w[a] += w[b]; w[d] = FS_ROTL(w[d] ^ w[a], 8);  w[c] += w[d]; w[b] = FS_ROTL(w[b] ^ w[c], 7);
+    for (int r = 0; r < 6; ++r) {
+        FS_QR(0, 4, 8, 12) FS_QR(1, 5, 9, 13) FS_QR(2, 6, 10, 14) FS_QR(3, 7, 11, 15)
+        FS_QR(0, 5, 10, 15) FS_QR(1, 6, 11, 12) FS_QR(2, 7, 8, 13) FS_QR(3, 4, 9, 14)
+    }
+#undef FS_QR
+#undef FS_ROTL
+    uint32_t out = 0;
+    const int idx = (int)(n & 15);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) if (i == idx) out = w[i] + s[i];
+    return out;
+}
+
+
+struct alignas(16) BSampLds {  // LDS scratch of one call (7.9 KB)
+    float kp[BS_MAXK + 32];    // kept probabilities, ascending token index
+    float cumk[BS_MAXK + 32];  // their sequential prefix sums (later: of the compacted survivors)
+    float sp[BS_MAXK + 32];    // kept probabilities, descending (later: compacted survivors)
+    int ki[BS_MAXK];           // token index of kept entry j
+    int rnk[BS_MAXK];          // descending-order rank of kept entry j (later: position of survivor j)
+    uint32_t hist[2][256];
+    double wsum[16];
+    float wmax[16];
+    int wcnt[2][16];
+    int misc[16];  // 0 bin, 1 above, 2 cut, 3 first, 4 last, 5 n_surv, 6 sum bits, 7 chosen bits, 8 any
+};
+
+#ifdef BS_PROF
+__device__ unsigned long long g_bs_ts[16];
+#define BS_TS(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_bs_ts[i] = clock64(); } while (0)
+#else
+#define BS_TS(i) do {} while (0)
+#endif
+
+template <int CTRL>
+__device__ __forceinline__ float bs_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float bs_wave_sum(float v) {
+    v += bs_dpp<0xB1>(v); v += bs_dpp<0x4E>(v); v += bs_dpp<0x141>(v); v += bs_dpp<0x140>(v);
+    return (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 15)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31))) +
+           (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 47)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)));
+}
+__device__ __forceinline__ float bs_wave_max(float m) {
+    m = fmaxf(m, bs_dpp<0xB1>(m)); m = fmaxf(m, bs_dpp<0x4E>(m)); m = fmaxf(m, bs_dpp<0x141>(m)); m = fmaxf(m, bs_dpp<0x140>(m));
+    return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 15)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 31))),
+                 fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 47)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 63))));
+}
+// inclusive prefix sum over the 64 lanes (DPP row shifts + row broadcasts: no LDS, no scalar hop)
+__device__ __forceinline__ int bs_wave_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
+    return v;
+}
+// 32 consecutive floats of an LDS array with eight independent 16-byte reads; entries >= n read as +0.0 (x + 0.0f == x for the
+// non-negative sums taken here)
+__device__ __forceinline__ void bs_fetch32(const float* a, int j, int n, float (&v)[32]) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float4 t = *reinterpret_cast<const float4*>(a + j + 4 * q);
+        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
+    if (j + 32 > n) {
+#pragma unroll
+        for (int e = 0; e < 32; ++e) if (j + e >= n) v[e] = 0.f;
+    }
+}
+
+// lv: this thread's EPT logits (already penalised / masked), candidates tid * EPT + s; entries at or beyond n are ignored.
+// word: the StdRng output word this draw would consume.  Returns the picked candidate index on every thread; *consumed = 1 iff the
+// draw consumed `word` (rand's WeightedIndex needs a positive total).
+template <int NT, int EPT>
+__device__ int bsample(const float (&lv)[EPT], int n, int kk, float inv_t, float top_p, uint32_t word, int* consumed, BSampLds& S) {
+    static_assert(NT % 64 == 0 && NT >= BS_MAXK + 64 && NT * EPT <= 2048, "block shape");
+    constexpr int W = NT / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int base = tid * EPT;
+    BS_TS(0);
+    // ---- A: softmax
+    for (int i = tid; i < 512; i += NT) (&S.hist[0][0])[i] = 0u;
+    if (tid == 0) { S.misc[3] = 0x7FFFFFFF; S.misc[4] = -1; S.misc[2] = kk; }
+    uint32_t u[EPT];
+    {
+        float v[EPT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < EPT; ++s) {
+            v[s] = (base + s < n) ? lv[s] * inv_t : -INFINITY;
+            mx = fmaxf(mx, v[s]);
+        }
+        mx = bs_wave_max(mx);
+        if (lane == 0) S.wmax[wv] = mx;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < W; ++w) mx = fmaxf(mx, S.wmax[w]);
+        double part = 0.0;
+#pragma unroll
+        for (int s = 0; s < EPT; ++s) {
+            v[s] = (base + s < n) ? expf(v[s] - mx) : 0.f;
+            part += (double)v[s];
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) part += __shfl_xor(part, m, 64);
+        if (lane == 0) S.wsum[wv] = part;
+        __syncthreads();
+        double dsum = 0.0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) dsum += S.wsum[w];
+        const float denom = (float)dsum;
+#pragma unroll
+        for (int s = 0; s < EPT; ++s) u[s] = __float_as_uint(v[s] / denom);  // 0 for slots past n
+    }
+    BS_TS(1);
+    // ---- B: T = the kk-th largest pattern (#{u > T} < kk <= #{u >= T}); slots past n count as zeros, exactly as in the one-wave version
+    uint32_t prefix = 0u;
+    int krem = kk;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = pass == 0 ? 22 : (pass == 1 ? 14 : (pass == 2 ? 6 : 0)), bits = pass == 3 ? 6 : 8;
+        uint32_t* h = S.hist[pass & 1];
+#pragma unroll
+        for (int s = 0; s < EPT; ++s)
+            if (pass == 0 || (u[s] >> (shift + bits)) == prefix) atomicAdd(&h[(u[s] >> shift) & ((1u << bits) - 1u)], 1u);
+        __syncthreads();
+        if (wv == 0) {
+            const uint4 hv = *reinterpret_cast<const uint4*>(h + lane * 4);
+            const int h4[4] = {(int)hv.x, (int)hv.y, (int)hv.z, (int)hv.w};
+            const int mine = (h4[0] + h4[1]) + (h4[2] + h4[3]);
+            const int incl = bs_wave_scan(mine);
+            int above = __builtin_amdgcn_readlane(incl, 63) - incl;  // candidates in bins of higher lanes
+#pragma unroll
+            for (int j = 3; j >= 0; --j) {  // exactly one (lane, j) holds the krem-th candidate from the top
+                if (above < krem && krem <= above + h4[j]) { S.misc[0] = lane * 4 + j; S.misc[1] = above; }
+                above += h4[j];
+            }
+        } else if (wv == 1) {
+            *reinterpret_cast<uint4*>(S.hist[(pass + 1) & 1] + lane * 4) = make_uint4(0u, 0u, 0u, 0u);
+        }
+        __syncthreads();
+        prefix = (prefix << bits) | (uint32_t)S.misc[0];
+        krem -= S.misc[1];
+    }
+    const uint32_t T = prefix;
+    BS_TS(2);
+    // ---- C: keep p > T and the first kk - #{p > T} ties in index order (thread-major, then slot)
+    const int nvalid = min(max(n - base, 0), EPT);  // only matters for ties at T == 0
+    int pos;
+    uint32_t keepbits = 0u;
+    {
+        int my_gt = 0, my_eq = 0;
+#pragma unroll
+        for (int s = 0; s < EPT; ++s) { my_gt += u[s] > T ? 1 : 0; my_eq += (u[s] == T && s < nvalid) ? 1 : 0; }
+        const int packed = my_gt | (my_eq << 16);  // both counts stay below 2^12
+        const int incl = bs_wave_scan(packed);
+        if (lane == 63) S.wcnt[0][wv] = incl;
+        __syncthreads();
+        int lower = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) { const int c = S.wcnt[0][w]; total += c; lower += w < wv ? c : 0; }
+        const int r_ties = kk - (total & 0xFFFF);  // ties to keep (>= 1)
+        int run_eq = ((incl + lower) >> 16) - my_eq;  // ties in lower threads
+        int my_keep = 0;
+#pragma unroll
+        for (int s = 0; s < EPT; ++s) {
+            const bool eq = u[s] == T && s < nvalid;
+            const bool keep = u[s] > T || (eq && run_eq < r_ties);
+            run_eq += eq ? 1 : 0;
+            keepbits |= keep ? (1u << s) : 0u;
+            my_keep += keep ? 1 : 0;
+        }
+        const int incl2 = bs_wave_scan(my_keep);
+        if (lane == 63) S.wcnt[1][wv] = incl2;
+        __syncthreads();
+        pos = incl2 - my_keep;
+#pragma unroll
+        for (int w = 0; w < W; ++w) pos += w < wv ? S.wcnt[1][w] : 0;
+    }
+    float kept = 0.f;
+#pragma unroll
+    for (int s = 0; s < EPT; ++s)
+        if (keepbits & (1u << s)) {
+            S.kp[pos] = __uint_as_float(u[s]);
+            S.ki[pos] = base + s;
+            kept += __uint_as_float(u[s]);
+            ++pos;
+        }
+    if (tid < 8 && kk + tid < BS_MAXK + 32) S.kp[kk + tid] = 0.f;  // (the rank loop reads whole groups of 8)
+    kept = bs_wave_sum(kept);
+    if (lane == 0) S.wmax[wv] = kept;  // (wmax was last read before the second softmax barrier)
+    __syncthreads();
+    // Is a top-p cut POSSIBLE?  The exact test compares top_p with the SEQUENTIAL f32 sum (below); any other summation order differs
+    // from it by at most kk ulps of the total (< 2e-5 relative), so a tree sum with a 1e-4 margin decides the common "no cut" case
+    // without waiting for the chain -- and then nobody needs the descending order at all.
+    float approx = 0.f;
+#pragma unroll
+    for (int w = 0; w < W; ++w) approx += S.wmax[w];
+    const bool maybe_topp = top_p > 0.f && top_p < approx * 1.0001f;
+    BS_TS(3);
+    // ---- D: ascending-index sum (wave 0) || ranks by counting (threads 64 .. 64 + kk)
+    if (wv == 0) {
+        float cum = 0.f;
+        for (int j = 0; j < kk; j += 32) {
+            float v[32];
+            bs_fetch32(S.kp, j, kk, v);
+#pragma unroll
+            for (int e = 0; e < 32; ++e) { cum += v[e]; v[e] = cum; }
+            if (lane == 0) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(S.cumk + j + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+            }
+        }
+        if (lane == 0) S.misc[6] = __float_as_int(cum);
+    } else if (maybe_topp && tid - 64 < ((kk + 63) & ~63)) {
+        // rank of entry j in descending order = #{i : p_i > p_j or (p_i == p_j and i < j)} (ties: the lower position first).  Patterns are
+        // < 2^30, so they compare as signed ints and "p_i >= p_j" is "p_i > p_j - 1".  A wave holds 64 consecutive j: entries below its
+        // first j are "i < j" for every lane, entries above its last are "i > j", only its own 64 need the per-lane choice.  Entries
+        // kk .. kk8 are zero (never counted: 0 > p_j is false).
+        const int j = tid - 64, jb = __builtin_amdgcn_readfirstlane(j & ~63), kk8 = (kk + 7) & ~7;
+        const int pj = __float_as_int(S.kp[min(j, kk - 1)]), pjm1 = pj - 1;
+        int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+        auto count8 = [&](int i, auto thr) {
+            const float4 a = *reinterpret_cast<const float4*>(S.kp + i), b4 = *reinterpret_cast<const float4*>(S.kp + i + 4);
+            r0 += __float_as_int(a.x) > thr(i) ? 1 : 0; r1 += __float_as_int(a.y) > thr(i + 1) ? 1 : 0;
+            r2 += __float_as_int(a.z) > thr(i + 2) ? 1 : 0; r3 += __float_as_int(a.w) > thr(i + 3) ? 1 : 0;
+            r0 += __float_as_int(b4.x) > thr(i + 4) ? 1 : 0; r1 += __float_as_int(b4.y) > thr(i + 5) ? 1 : 0;
+            r2 += __float_as_int(b4.z) > thr(i + 6) ? 1 : 0; r3 += __float_as_int(b4.w) > thr(i + 7) ? 1 : 0;
+        };
+        const int lo_end = min(jb, kk8), mid_end = min(jb + 64, kk8);
+        for (int i = 0; i < lo_end; i += 8) count8(i, [&](int) { return pjm1; });
+        for (int i = lo_end; i < mid_end; i += 8) count8(i, [&](int ii) { return ii < j ? pjm1 : pj; });
+        for (int i = mid_end; i < kk8; i += 8) count8(i, [&](int) { return pj; });
+        const int r = (r0 + r1) + (r2 + r3);
+        if (j < kk) {
+            S.rnk[j] = r;
+            S.sp[r] = __int_as_float(pj);
+        }
+    }
+    __syncthreads();
+    BS_TS(4);
+    const float sum_p = __int_as_float(S.misc[6]);
+    const bool do_topp = maybe_topp && !(top_p <= 0.f || top_p >= sum_p);  // (maybe_topp is implied: see its margin)
+    const float* cumw = S.cumk;  // cumulative weights of the entries the draw runs over
+    const int* wpos = nullptr;   // their positions in (kp, ki); null: identity
+    int cnt = kk;
+    float total = sum_p;
+    if (do_topp) {
+        // ---- E: the first rank whose EXCLUSIVE running sum (descending order) has reached top_p == 1 + first q with inclusive sum >= top_p
+        if (wv == 0) {
+            float cum = 0.f;
+            int first = -1;
+            for (int j = 0; j < kk && first < 0; j += 32) {
+                float v[32];
+                bs_fetch32(S.sp, j, kk, v);
+#pragma unroll
+                for (int e = 0; e < 32; ++e) { cum += v[e]; v[e] = cum; }
+#pragma unroll
+                for (int e = 31; e >= 0; --e) if (j + e < kk && v[e] >= top_p) first = j + e;
+            }
+            if (lane == 0) S.misc[2] = first < 0 ? kk : first + 1;
+        }
+        __syncthreads();
+        const int cut = S.misc[2];
+        if (tid < kk && S.rnk[tid] >= cut) S.kp[tid] = 0.f;
+        __syncthreads();
+        // compact the non-zero weights in index order (zero weights do not move a cumulative f32 sum and are never picked)
+        if (wv == 0) {
+            const float4 wv4 = *reinterpret_cast<const float4*>(S.kp + lane * 4);
+            const float ws[4] = {wv4.x, wv4.y, wv4.z, wv4.w};
+            int mine = 0;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) mine += (lane * 4 + s < kk && ws[s] != 0.f) ? 1 : 0;
+            const int incl = bs_wave_scan(mine);
+            const int m = __builtin_amdgcn_readlane(incl, 63);
+            int p2 = incl - mine;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                if (lane * 4 + s < kk && ws[s] != 0.f) { S.sp[p2] = ws[s]; S.rnk[p2] = lane * 4 + s; ++p2; }
+            float cum = 0.f;  // (one wave: its LDS operations stay in order)
+            for (int j = 0; j < m; j += 32) {
+                float v[32];
+                bs_fetch32(S.sp, j, m, v);
+#pragma unroll
+                for (int e = 0; e < 32; ++e) { cum += v[e]; v[e] = cum; }
+                if (lane == 0) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(S.cumk + j + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+                }
+            }
+            if (lane == 0) { S.misc[5] = m; S.misc[6] = __float_as_int(cum); }
+        }
+        __syncthreads();
+        cnt = S.misc[5];
+        total = __int_as_float(S.misc[6]);
+        wpos = S.rnk;
+    }
+    BS_TS(5);
+    // ---- F: WeightedIndex::sample -- UniformFloat<f32>::sample_single over [0, total), first entry whose cumulative weight exceeds it
+    if (!(total > 0.f) || cnt == 0) {
+        *consumed = 0;
+        const int res = S.ki[0];
+        __syncthreads();
+        return res;
+    }
+    *consumed = 1;
+    const float max_rand = __uint_as_float((0xFFFFFFFFu >> 9) | (127u << 23)) - 1.0f;
+    float scale = total;
+    while (scale * max_rand + 0.f >= total) scale = __uint_as_float(__float_as_uint(scale) - 1u);
+    const float chosen = (__uint_as_float((word >> 9) | (127u << 23)) - 1.0f) * scale + 0.f;
+    if (wv * 64 < cnt) {  // one LDS atomic per wave, not per entry (same-address LDS atomics serialise)
+        const bool nz = tid < cnt && (do_topp || S.kp[tid] != 0.f);  // (compacted entries are non-zero by construction)
+        const unsigned long long m_nz = __ballot(nz), m_hit = __ballot(nz && cumw[tid] > chosen);
+        if (lane == 0) {
+            if (m_nz) atomicMax(&S.misc[4], wv * 64 + 63 - __builtin_clzll(m_nz));
+            if (m_hit) atomicMin(&S.misc[3], wv * 64 + __builtin_ctzll(m_hit));
+        }
+    }
+    __syncthreads();
+    const int f = S.misc[3], l = S.misc[4];
+    const int jsel = f != 0x7FFFFFFF ? f : l;
+    const int res = jsel < 0 ? S.ki[0] : S.ki[wpos ? wpos[jsel] : jsel];
+    __syncthreads();  // the scratch may be re-used by the caller
+    BS_TS(6);
+    return res;
+}

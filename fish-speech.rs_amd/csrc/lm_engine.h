@@ -37,6 +37,8 @@ class LMBase {
     virtual void session_poll(int slot, uint32_t* codes_out, size_t cap, size_t* n_frames, int* done) = 0;
     virtual void session_release(int slot) = 0;
     virtual void session_end() = 0;
+    virtual void debug_capture(int n_frames) = 0;
+    virtual void debug_read(float* out, int n_frames) = 0;
     virtual fs_gen_stats last_stats() = 0;
     virtual void* stream() = 0;
     // measurement hook: average duration (us) of ONE launch of decode kernel `kind` (0 qkv, 1 attention, 2 wo, 3 ffn_up, 4 ffn_down) as a

@@ -272,6 +272,25 @@ class LM final : public LMBase {
         for (int b = 0; b < B_; ++b) truncate(b, std::min(seq_len_[b], pos));
     }
     int kv_len() override { return seq_len_[0]; }
+    // test hook (fs_lm_debug_capture / fs_lm_debug_read): the persistent fast decoder records, for the first n generator iterations of
+    // each generate call, the (penalised, masked) logits every one of the 9 decisions of a frame saw and the index it picked
+    void debug_capture(int n_frames) override {
+        use_device();
+        FS_REQUIRE(n_frames >= 0 && n_frames <= 4096, "bad frame count");
+        FS_HIP(hipStreamSynchronize(st_));
+        cap_frames_ = n_frames;
+        if (n_frames) { d_cap_.alloc(sizeof(float) * (size_t)n_frames * 9 * 2048); FS_HIP(hipMemset(d_cap_.p, 0, d_cap_.n)); }
+        else d_cap_ = DevBuf();
+        for (auto& kv : graphs_) { (void)hipGraphExecDestroy(kv.second.first); (void)hipGraphExecDestroy(kv.second.second); }
+        graphs_.clear();  // the captured launches carry the buffer pointer
+        g_frame_ = g_step_ = nullptr;
+    }
+    void debug_read(float* out, int n_frames) override {
+        use_device();
+        FS_REQUIRE(n_frames >= 0 && n_frames <= cap_frames_, "more frames than were captured");
+        FS_HIP(hipStreamSynchronize(st_));
+        FS_HIP(hipMemcpy(out, d_cap_.p, sizeof(float) * (size_t)n_frames * 9 * 2048, hipMemcpyDeviceToHost));
+    }
     fs_gen_stats last_stats() override { return stats_; }
     void* stream() override { return (void*)st_; }
 
@@ -362,7 +381,10 @@ class LM final : public LMBase {
         use_persist_ = use_pslow_ = false;
         if ((persist_ok_ || pslow_ok_) && !(flags & FS_GEN_NO_PERSIST)) {
             plock = std::unique_lock<std::mutex>(persist_mutex(device_), std::try_to_lock);
-            use_persist_ = plock.owns_lock() && persist_ok_ && cfg.temp == 0.f && batch_rows_ == 0;  // the fast kernel decides greedily in-launch (host ArgMax rule)
+            // the fast kernel decides in-launch: greedily (host ArgMax rule), or with the block-parallel top-k / top-p sampler when top_k <= 256
+            persist_sampled_ = cfg.temp != 0.f;
+            use_persist_ = plock.owns_lock() && persist_ok_ && batch_rows_ == 0 &&
+                           (cfg.temp == 0.f || fast_persist_samples(cfg.temp, cfg.top_k, a_.codebook_size));
             use_pslow_ = plock.owns_lock() && pslow_ok_;                          // the slow kernel feeds any sampler
         }
         // generate_blocking_with_hidden: the slow sampler stores the hidden state of every iteration through this pointer cell
@@ -395,7 +417,8 @@ class LM final : public LMBase {
         launch_frame(0);
         FS_HIP(hipEventRecord(ev_[1], st_));
         stats_.graph_launches = (uint64_t)L;
-        stats_.kernels_per_frame = (uint64_t)((use_pslow_ ? 2 : a_.n_layer * 5 + 2) + (use_persist_ ? 1 : a_.num_codebooks * (a_.n_fast_layer * 4 + 2)));
+        stats_.kernels_per_frame = (uint64_t)((use_pslow_ ? 1 : a_.n_layer * 5 + 1) + (fold_slow_sampler() ? 0 : 1) +
+                                              (use_persist_ ? 1 : a_.num_codebooks * (a_.n_fast_layer * 4 + 2)));
         // decode: one graph replay per frame, enqueued in batches of CHUNK.  Behind every batch the stream copies the generator state
         // and the batch's code columns into pinned memory and records an event; the host looks at batch b (done flag, frame callback)
         // while batch b + 1 is already running, so the GPU never waits for the host between batches
@@ -496,7 +519,7 @@ class LM final : public LMBase {
                 if (ctl[1]) pslow_ok_ = persist_ok_ = false;  // (see above)
                 throw Error(ctl[1] ? "persistent fast-decoder kernel: a grid-wide wait timed out (are all 256 CUs available to this process?); "
                                      "the handle falls back to per-node launches for its next calls"
-                                   : "persistent fast-decoder kernel launched with temp != 0");
+                                   : "persistent fast-decoder kernel launched with a sampling configuration it was not built for");
             }
         }
         if (clamped && !hs->done && !stop)
@@ -1341,6 +1364,8 @@ class LM final : public LMBase {
         A.prof = getenv("FISHRT_PERSIST_PROF") ? reinterpret_cast<unsigned long long*>(d_sctl_.as<uint32_t>() + 16) : nullptr;
         return A;
     }
+    // the persistent fast decoder takes the slow-token decision in its prologue (no k_sample_slow node) whenever it runs
+    bool fold_slow_sampler() const { return use_persist_ && !legacy_ && n_audio_ <= 2048; }
     FastPersistArgs persist_args() {
         FastPersistArgs A = {};
         A.wpack = d_pack_.p;
@@ -1349,8 +1374,11 @@ class LM final : public LMBase {
         A.fast_emb = fast_emb_; A.tok_emb = tok_emb_; A.cb_emb = cb_emb_;
         A.cos_t = d_cos_.as<float>(); A.sin_t = d_sin_.as<float>();
         A.eps = d_.eps;
-        A.xf = xf(0); A.x = x(0);
-        A.state = state(0); A.cfg = d_cfg_.as<SampleCfg>(); A.rp = rp_;
+        const bool fold = fold_slow_sampler();
+        A.xf = fold ? x(0) : xf(0); A.x = x(0);
+        A.slow_logits = fold ? d_logits_slow_.as<float>() : nullptr; A.n_slow = n_audio_; A.hid_slot = d_hid_slot_.as<float*>();
+        A.cap = d_cap_.as<float>(); A.cap_frames = cap_frames_;
+        A.state = state(0); A.cfg = d_cfg_.as<SampleCfg>(); A.rp = rp_; A.rng = d_rng_.as<RngState>();
         A.out_codes = d_out_.as<uint32_t>(); A.out_cap = out_cap_;
         A.edges = d_edges_.as<unsigned long long>();
         A.ctl = d_ctl_.as<uint32_t>();
@@ -1391,7 +1419,7 @@ class LM final : public LMBase {
     void set_bucket(int T) { nc_launch_ = chunk_bucket(T); }
     // graphs for the bucket currently in nc_launch_ (captured on first use)
     void use_graphs_for_bucket() {
-        const int key = nc_launch_ * 4 + (use_persist_ ? 2 : 0) + (use_pslow_ ? 1 : 0);
+        const int key = nc_launch_ * 8 + (use_persist_ && persist_sampled_ ? 4 : 0) + (use_persist_ ? 2 : 0) + (use_pslow_ ? 1 : 0);
         auto it = graphs_.find(key);
         if (it == graphs_.end()) {
             g_frame_ = nullptr; g_step_ = nullptr;
@@ -1422,9 +1450,10 @@ class LM final : public LMBase {
         // audio-range head: rows [im_end, V) only (constrain_probs_to_audio, utils.rs:13-16)
         LmKernels<WT>::head(d_, x(0), norm_w_, slow_head_w(), slow_head_s(), n_audio_, d_logits_slow_.as<float>(), st_);
         }
-        SampleKernels<WT>::sample_slow(d_, d_logits_slow_.as<float>(), n_audio_, d_cfg_.as<SampleCfg>(), d_rng_.as<RngState>(), state(0),
-                                       x(0), xf(0), st_, d_hid_slot_.as<float*>());
-        if (use_persist_) launch_fast_persist(persist_args(), st_);
+        if (!fold_slow_sampler())
+            SampleKernels<WT>::sample_slow(d_, d_logits_slow_.as<float>(), n_audio_, d_cfg_.as<SampleCfg>(), d_rng_.as<RngState>(), state(0),
+                                           x(0), xf(0), st_, d_hid_slot_.as<float*>());
+        if (use_persist_) launch_fast_persist(persist_args(), persist_sampled_, st_);
         else
         for (int cbi = 0; cbi < C; ++cbi) {
             enqueue_fast_layers(0, cbi, cbi);
@@ -1468,8 +1497,10 @@ class LM final : public LMBase {
     DevBuf d_x_, d_xf_, d_q_, d_part_, d_act_, d_logits_slow_, d_logits_fast_, d_state_, d_cfg_, d_rng_, d_prompt_, d_out_;
     DevBuf d_rp_mask_, d_rp_seen_, d_rp_ring_, d_rp_meta_;
     DevBuf d_pack_, d_edges_, d_ctl_;  // persistent fast decoder
+    DevBuf d_cap_;                     // fs_lm_debug_capture
+    int cap_frames_ = 0;
     DevBuf d_hidden_, d_hid_slot_;     // generate_blocking_with_hidden: [out_cap][dim] rows + the pointer cell the captured graphs read
-    bool persist_ok_ = false, use_persist_ = false, pslow_ok_ = false, use_pslow_ = false;
+    bool persist_ok_ = false, use_persist_ = false, pslow_ok_ = false, use_pslow_ = false, persist_sampled_ = false;
     int batch_rows_ = 0, batch_row_ = 0;  // generate_batch_sequential: batch sampler semantics for the row being generated
     // continuous-batching session: per-slot remaining iterations (-1 = empty), host copy of the slot states, scratch KV page of empty slots
     bool sess_active_ = false;

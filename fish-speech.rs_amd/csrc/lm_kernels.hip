@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <algorithm>
+#include <string>
 #include <vector>
 
 #include "fs_common.h"
@@ -1626,30 +1627,7 @@ void fs_dbg_read_ts(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HI
 #else
 #define FS_TS(i) do {} while (0)
 #endif
-// rand 0.8.5 StdRng == ChaCha12 (rand_chacha 0.3.1): word `n` of the keystream, 64-bit block counter, stream id 0.
-__device__ inline uint32_t chacha12_word(const uint32_t* key, unsigned long long n) {
-    const unsigned long long ctr = n >> 4;
-    uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key[0], key[1], key[2], key[3],
-                      key[4], key[5], key[6], key[7], (uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
-    uint32_t w[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) w[i] = s[i];
-#define FS_ROTL(v, c) (((v) << (c)) | ((v) >> (32 - (c))))
-#define FS_QR(a, b, c, d)                                   \
-    w[a] += w[b]; w[d] = FS_ROTL(w[d] ^ w[a], 16); w[c] += w[d]; w[b] = FS_ROTL(w[b] ^ w[c], 12); \
-    w[a] += w[b]; w[d] = FS_ROTL(w[d] ^ w[a], 8);  w[c] += w[d]; w[b] = FS_ROTL(w[b] ^ w[c], 7);
-    for (int r = 0; r < 6; ++r) {
-        FS_QR(0, 4, 8, 12) FS_QR(1, 5, 9, 13) FS_QR(2, 6, 10, 14) FS_QR(3, 7, 11, 15)
-        FS_QR(0, 5, 10, 15) FS_QR(1, 6, 11, 12) FS_QR(2, 7, 8, 13) FS_QR(3, 4, 9, 14)
-    }
-#undef FS_QR
-#undef FS_ROTL
-    uint32_t out = 0;
-    const int idx = (int)(n & 15);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) if (i == idx) out = w[i] + s[i];
-    return out;
-}
+#include "lm_bsample_dev.h"  // chacha12_word + the block-parallel sampler
 
 // ---- single-thread sequential f32 chains over an LDS array (the sampler's sums must not depend on a reduction order, so
 // they are evaluated exactly as the scalar reference does: one running f32 sum in ascending order).  A naive loop pays the
@@ -2566,6 +2544,25 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_fast_rows(const float
     embed_tokens<WT>(tok_emb, cb_emb, dim, n_cb, cb_size, c.sem_lo, c.sem_hi, cur, 1, X + (size_t)b * dim, tid, SAMPLE_THREADS);
 }
 
+// test hook of the block-parallel sampler (lm_bsample_dev.h) with the static-batch RNG derivation of k_sample_slow_rows
+template <int NT, int EPT>
+__global__ __launch_bounds__(NT) void k_bsample_rows_test(const float* __restrict__ logits, int n, const SampleCfg* __restrict__ cp,
+                                                          const RngState* __restrict__ master, int B, int call, uint32_t* __restrict__ out) {
+    __shared__ BSampLds S;
+    __shared__ RngState lrng;
+    __shared__ uint32_t s_word;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const SampleCfg c = *cp;
+    float lv[EPT];
+#pragma unroll
+    for (int s = 0; s < EPT; ++s) { const int i = tid * EPT + s; lv[s] = i < n ? logits[(size_t)b * n + i] : 0.f; }
+    if (tid == NT - 1) { child_rng(master, (unsigned long long)call * B + b, &lrng); s_word = chacha12_word(lrng.key, 0); }
+    __syncthreads();
+    int consumed = 0;
+    const int idx = bsample<NT, EPT>(lv, n, c.top_k, (float)(1.0 / (double)c.temp), c.top_p, s_word, &consumed, S);
+    if (tid == 0) out[b] = (uint32_t)idx;
+}
+
 __global__ void k_reppen_reset(RepPenState rp, int n_cb, int cb_size) {
     const int n = n_cb * cb_size;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { rp.mask[i] = 1.0f; rp.seen[i] = 0; }
@@ -3123,12 +3120,26 @@ void debug_sample_rows(int device, const float* logits, int B, int n, double tem
     std::vector<SeqState> hs(B);
     for (auto& s : hs) { s = SeqState{}; s.frame = call_index; }
     FS_HIP(hipMemcpy(d_st, hs.data(), sizeof(SeqState) * B, hipMemcpyHostToDevice));
+    // FISHRT_SAMPLER_IMPL=par512: the block-parallel sampler the persistent fast decoder uses (lm_bsample_dev.h), 512 threads per row
+    const char* impl = getenv("FISHRT_SAMPLER_IMPL");
+    const bool par = impl && std::string(impl) == "par512" && temp > 1e-7 && top_k > 0 && top_k <= 256 && (int)top_k < n && n <= 2048;
+    if (par) {
+        uint32_t* d_out = nullptr;
+        FS_HIP(hipMalloc(&d_out, sizeof(uint32_t) * B));
+        if (n <= 1024) hipLaunchKernelGGL((k_bsample_rows_test<512, 2>), dim3(B), dim3(512), 0, nullptr, d_logits, n, d_cfg, d_rng, B, call_index, d_out);
+        else hipLaunchKernelGGL((k_bsample_rows_test<512, 4>), dim3(B), dim3(512), 0, nullptr, d_logits, n, d_cfg, d_rng, B, call_index, d_out);
+        FS_LAUNCH_CHECK();
+        FS_HIP(hipDeviceSynchronize());
+        FS_HIP(hipMemcpy(out, d_out, sizeof(uint32_t) * B, hipMemcpyDeviceToHost));
+        (void)hipFree(d_out);
+    } else {
     hipLaunchKernelGGL((k_sample_slow_rows<bf16_t>), dim3(B), dim3(SAMPLE_THREADS), 0, nullptr, d_logits, n, n, d_cfg, d_rng, B, 1, d_st,
                        (const float*)nullptr, (float*)nullptr, 0);
     FS_LAUNCH_CHECK();
     FS_HIP(hipDeviceSynchronize());
     FS_HIP(hipMemcpy(hs.data(), d_st, sizeof(SeqState) * B, hipMemcpyDeviceToHost));
     for (int b = 0; b < B; ++b) out[b] = hs[b].cur[0];
+    }
     (void)hipFree(d_logits); (void)hipFree(d_cfg); (void)hipFree(d_rng); (void)hipFree(d_st);
 }
 

@@ -38,15 +38,21 @@ struct FastPersistArgs {
     const float* sin_t;
     float eps;
     const float* xf;            // [1024] hidden state of the slow transformer (input of codebook pass 0)
+    const float* slow_logits;   // null, or [n_slow] audio-range logits of this step: the slow-token decision runs inside this launch
+    int n_slow;                 // <= 2048
+    float* cap;                 // null, or [cap_frames][9][2048] (fs_lm_debug_capture): the logits every decision of a frame saw + its pick
+    int cap_frames;
+    float* const* hid_slot;     // with slow_logits: device pointer cell (may hold null) of the hidden-state rows [iteration][1024]
     float* x;                   // [1024] out: embedded input of the next slow step
     SeqState* state;
     const SampleCfg* cfg;
     RepPenState rp;
+    RngState* rng;              // the request's StdRng stream position (sampled requests: 8 words per frame, written back by workgroup 0)
     uint32_t* out_codes;
     int out_cap;
     unsigned long long* edges;  // [PF_RING][PF_REPL][PF_EDGE_CAP] granules (zeroed once at allocation)
     unsigned long long* prof;   // null, or [16]: workgroup 0 accumulates 10 ns ticks per stage kind (FISHRT_PERSIST_PROF=1)
-    uint32_t* ctl;              // [0] launch counter (tag epoch), [1] spin-timeout count (host checks it), [2] launches with temp != 0 (refused)
+    uint32_t* ctl;              // [0] launch counter (tag epoch), [1] spin-timeout count (host checks it), [2] launches whose sampling configuration does not match the instantiation
 };
 
 // ---- persistent slow-transformer kernel (lm_persist_slow.hip): one launch = the 24 blocks + the audio-range head of one decode step
@@ -85,7 +91,9 @@ size_t fast_persist_pack_bytes();
 size_t fast_persist_edge_bytes();
 // re-lays the four fast blocks' matrices + fast_output into the per-lane image (device to device, once per weight load)
 void launch_fast_persist_pack(const LayerW* fast, const void* head_w, void* pack, hipStream_t st);
-void launch_fast_persist(const FastPersistArgs& a, hipStream_t st);
+void launch_fast_persist(const FastPersistArgs& a, bool sampled, hipStream_t st);
+// true when the in-launch sampler covers this configuration (0 < top_k <= 256 candidates kept, sampling/mod.rs:51-132); temp == 0 is the greedy kernel
+bool fast_persist_samples(float temp, int top_k, int cb_size);
 // self-test hook of the multi-value wave reductions: out[w][i] = sum over the 64 lanes of in[lane][i] for N in {4, 16, 32}
 void launch_pf_reduce_selftest(const float* in /*[64][32]*/, float* out /*[3][32]*/, hipStream_t st);
 

@@ -36,6 +36,7 @@ namespace fs {
 namespace {
 
 #include "lm_persist_dev.h"
+#include "lm_bsample_dev.h"
 
 // LDS carve (bytes).  Everything lives in ONE dynamic array (guide: Guideline 17)
 constexpr int L_W2 = 0;                                   // [16 chunks][512 lanes] x 16 B
@@ -49,8 +50,11 @@ constexpr int L_SC = L_RED + 2 * 8 * PF_RED * 4;                   // [16 heads]
 constexpr int L_AMAX = L_SC + 16 * 8 * 4;                  // [2][8 waves] {value, index}
 constexpr int L_ROPE = L_AMAX + 2 * 8 * 8;                 // cos [8][32], sin [8][32]
 constexpr int L_RING = L_ROPE + 2 * 8 * 32 * 4;            // rep-pen ring [8][17], meta [8][2], prev [16], misc [16]
-constexpr int L_END = L_RING + (8 * 17 + 8 * 2 + 16 + 16) * 4;
+constexpr int L_WORDS = L_RING + (8 * 17 + 8 * 2 + 16 + 16) * 4;  // StdRng output words of this frame's draws [8] (sampled requests)
+constexpr int L_END = L_WORDS + 16 * 4;
 static_assert(L_END <= 160 * 1024, "LDS budget");
+// the sampler's scratch (lm_bsample_dev.h) aliases q / residual copy / row partials / scores / argmax slots: all dead during a decision
+static_assert(L_QS % 16 == 0 && L_QS + (int)sizeof(BSampLds) <= L_ROPE, "sampler scratch must fit the stage scratch it aliases");
 
 }  // namespace
 
@@ -88,6 +92,11 @@ __global__ __launch_bounds__(PF_THREADS) void k_pf_pack(LayerW w0, LayerW w1, La
 }
 
 // ------------------------------------------------------------------------------------------------ the frame kernel
+// SAMPLED: temp > 0 with 0 < top_k <= 256 (the server default, server/lib/utils/load.rs:116-125): the decision is the block-parallel
+// top-k / top-p / WeightedIndex sampler of lm_bsample_dev.h, run redundantly by every workgroup on the same logits and the same StdRng
+// word, so every workgroup still knows the next input without another edge.  A separate instantiation: the greedy kernel keeps its
+// register allocation.
+template <bool SAMPLED>
 __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4* w2s = reinterpret_cast<u32x4*>(smem + L_W2);
@@ -104,6 +113,8 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
     int* s_meta = s_ring + 8 * 17;
     uint32_t* s_prev = reinterpret_cast<uint32_t*>(s_meta + 8 * 2);
     uint32_t* s_misc = s_prev + 16;  // [0] cur0, [1] have_prev, [2] done, [3] epoch, [4..11] codes of this frame
+    uint32_t* s_words = reinterpret_cast<uint32_t*>(smem + L_WORDS);
+    BSampLds& samp = *reinterpret_cast<BSampLds*>(smem + L_QS);
 
     const int tid_k = threadIdx.x, b = blockIdx.x;
     int tid = tid_k, lane = tid & 63, wave = tid >> 6;
@@ -125,16 +136,76 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
         rope_c[i] = A.cos_t[i];
         rope_s[i] = A.sin_t[i];
     }
+    const unsigned long long consumed0 = SAMPLED ? A.rng->consumed : 0ull;  // (a per-frame input: read before the first publish)
+    // this frame's StdRng words (slow draw + 8 codebook draws): ~2.4 us of dependent integer work, nine lanes of the last wave
+    if (SAMPLED && tid >= PF_THREADS - 64 && tid < PF_THREADS - 64 + 9)
+        s_words[tid - (PF_THREADS - 64)] = chacha12_word(A.rng->key, consumed0 + (unsigned)(tid - (PF_THREADS - 64)));
     __syncthreads();
-    const uint32_t cur0 = s_misc[0];
+    uint32_t cur0 = s_misc[0];
     const bool have_prev = s_misc[1] != 0;
-    const int done_in = (int)s_misc[2];
+    int done_in = (int)s_misc[2];
     const unsigned epoch = s_misc[3];
     if (done_in == 2) return;  // generator already terminated: replays leave position / outputs untouched
+    const bool cfg_ok = SAMPLED ? (cfg.temp > 0.f && cfg.top_k > 0 && cfg.top_k <= BS_MAXK) : cfg.temp == 0.f;
+    if (!cfg_ok && tid == 0 && b == 0) atomicAdd(A.ctl + 2, 1u);  // the host picks the instantiation by the sampling configuration
+    int n_draws = 0;
+    // ---- the slow-token decision of this frame, folded in (A.slow_logits != null; otherwise k_sample_slow ran in front of this launch):
+    // logits over [im_end, V) (constrain_probs_to_audio, utils.rs:13-16) -> sample -> token = index + im_end (rescale_semantic_tokens,
+    // utils.rs:45-46), single_batch.rs:102-144.  Every workgroup decides redundantly on the same logits (and the same StdRng word), so
+    // the token -- needed for the <|im_end|> test here and for the next input's embedding at the end -- needs no edge.
+    if (A.slow_logits) {
+        const int n = A.n_slow;
+        float lv[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int i = 4 * tid + s;
+            lv[s] = i < n ? A.slow_logits[i] : -INFINITY;
+            if (i == 0 && cfg.ignore_eos) lv[s] = -INFINITY;
+        }
+        if (b == 0) {  // hidden_states of this iteration (generate_blocking_with_hidden, single_batch.rs:250,264-266)
+            float* hid = A.hid_slot ? *A.hid_slot : nullptr;
+            if (hid) *reinterpret_cast<float2*>(hid + (size_t)A.state->frame * 1024 + 2 * tid) = *reinterpret_cast<const float2*>(A.xf + 2 * tid);
+        }
+        float* cap = (A.cap && b == 0 && A.state->frame < A.cap_frames) ? A.cap + (size_t)A.state->frame * 9 * 2048 : nullptr;
+        if (cap) *reinterpret_cast<float4*>(cap + 4 * tid) = make_float4(lv[0], lv[1], lv[2], lv[3]);  // (fs_lm_debug_capture)
+        int idx;
+        if (SAMPLED) {
+            int used = 0;
+            idx = bsample<PF_THREADS, 4>(lv, n, cfg.top_k, (float)(1.0 / (double)cfg.temp), cfg.top_p, s_words[0], &used, samp);
+            n_draws += used;
+        } else {  // host ArgMax rule: the LAST maximal index (per thread ascending, then value / index maxima)
+            float bv = lv[0];
+            int bi = 4 * tid;
+#pragma unroll
+            for (int s = 1; s < 4; ++s) if (!(lv[s] < bv)) { bv = lv[s]; bi = 4 * tid + s; }
+            if (bi >= n) bi = -1;
+            float wm = bv;
+            wm = fmaxf(wm, pf_dpp<PF_XOR1>(wm)); wm = fmaxf(wm, pf_dpp<PF_XOR2>(wm));
+            wm = fmaxf(wm, pf_dpp<PF_HALF_MIRROR>(wm)); wm = fmaxf(wm, pf_dpp<PF_MIRROR>(wm));
+            wm = fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(wm), 15)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wm), 31))),
+                       fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(wm), 47)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wm), 63))));
+            int ci = (bv == wm) ? bi : -1;
+            ci = max(ci, __builtin_amdgcn_mov_dpp(ci, PF_XOR1, 0xF, 0xF, false)); ci = max(ci, __builtin_amdgcn_mov_dpp(ci, PF_XOR2, 0xF, 0xF, false));
+            ci = max(ci, __builtin_amdgcn_mov_dpp(ci, PF_HALF_MIRROR, 0xF, 0xF, false)); ci = max(ci, __builtin_amdgcn_mov_dpp(ci, PF_MIRROR, 0xF, 0xF, false));
+            ci = max(max(__builtin_amdgcn_readlane(ci, 15), __builtin_amdgcn_readlane(ci, 31)), max(__builtin_amdgcn_readlane(ci, 47), __builtin_amdgcn_readlane(ci, 63)));
+            if (lane == 0) { amax[wave * 2] = wm; amax[wave * 2 + 1] = __int_as_float(ci); }
+            __syncthreads();
+            float gv = amax[0];
+            idx = __float_as_int(amax[1]);
+#pragma unroll
+            for (int w = 1; w < 8; ++w) {
+                const float v2 = amax[w * 2];
+                const int i2 = __float_as_int(amax[w * 2 + 1]);
+                if (v2 > gv || (v2 == gv && i2 > idx)) { gv = v2; idx = i2; }
+            }
+            __syncthreads();  // amax is written again by the first codebook decision
+        }
+        if (cap && tid == 0) cap[2047] = (float)idx;
+        cur0 = (uint32_t)max(idx, 0) + cfg.im_end_id;
+        if (cur0 == cfg.im_end_id) done_in = 1;  // terminated by THIS frame (workgroup 0 records token and flag at the end of the frame)
+    }
     const bool eos = cur0 == cfg.im_end_id;  // single_batch.rs:153-156: push zeros, skip the fast decoder
     if (eos && b != 0) return;
-    const bool greedy = cfg.temp == 0.f;
-    if (!greedy && tid == 0 && b == 0) atomicAdd(A.ctl + 2, 1u);  // the host never launches this kernel with temp != 0
 
     bool dead = false;
     float x0 = 0.f, x1 = 0.f;
@@ -151,9 +222,14 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
         }
 #pragma unroll
         for (int c = 0; c < PF_LDS_CHUNKS; ++c) w2s[c * PF_THREADS + tid] = wp[(size_t)(PF_REG_CHUNKS + c) * PF_THREADS];
-        float2 nwr[2 * PF_LAYERS + 1];  // this lane's slice of the nine RMSNorm weight vectors
+        // this lane's slice of the nine RMSNorm weight vectors: resident in the greedy kernel; the sampled kernel needs those 18 registers
+        // for the sampler's temporaries and re-reads the (L2-resident) pair in front of each stage's sweep instead
+        float2 nwr[2 * PF_LAYERS + 1];
+        if (!SAMPLED) {
 #pragma unroll
-        for (int i = 0; i < 2 * PF_LAYERS + 1; ++i) nwr[i] = *reinterpret_cast<const float2*>(A.norms[i] + 2 * tid);
+            for (int i = 0; i < 2 * PF_LAYERS + 1; ++i) nwr[i] = *reinterpret_cast<const float2*>(A.norms[i] + 2 * tid);
+        }
+        auto norm_w = [&](int i, int t) { return SAMPLED ? *reinterpret_cast<const float2*>(A.norms[i] + 2 * t) : nwr[i]; };
         // repetition-penalty mask of this lane's two candidates of every codebook: bit 2 cb + k <=> mask[cb][2 tid + k] != 1
         uint32_t mbits = 0;
 #pragma unroll
@@ -184,7 +260,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
                 // ================= S1: (gather x) -> RMSNorm -> Wqkv rows -> publish 5 values
                 {
                     tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
-                    const float2 nw = nwr[2 * l];
+                    const float2 nw = norm_w(2 * l, tid);
                     if (l > 0) {
                         u32x4 v;
                         pf_sweep1(my_edges + (size_t)(e & 3) * PF_REPL * PF_EDGE_CAP, tid, tag0 + e + 1, v, dead, A.ctl);
@@ -295,7 +371,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
                 // ================= S3: gather h -> RMSNorm -> 16 SwiGLU pairs of W13 -> publish 16 activations
                 {
                     tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
-                    const float2 nw = nwr[2 * l + 1];
+                    const float2 nw = norm_w(2 * l + 1, tid);
                     u32x4 v;
                     pf_sweep1(my_edges + (size_t)(e & 3) * PF_REPL * PF_EDGE_CAP, tid, tag0 + e + 1, v, dead, A.ctl);
                     ++e;
@@ -365,7 +441,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
             // ================= head: gather x -> fast_norm -> 4 rows of fast_output -> publish 4 logits
             {
                 tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
-                const float2 nw = nwr[2 * PF_LAYERS];
+                const float2 nw = norm_w(2 * PF_LAYERS, tid);
                 u32x4 v;
                 pf_sweep1(my_edges + (size_t)(e & 3) * PF_REPL * PF_EDGE_CAP, tid, tag0 + e + 1, v, dead, A.ctl);
                 ++e;
@@ -423,6 +499,17 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
                     }
                     lv0 = lv0 / m0; lv1 = lv1 / m1;
                 }
+                float* cap = (A.cap && b == 0 && A.slow_logits && A.state->frame < A.cap_frames) ? A.cap + ((size_t)A.state->frame * 9 + 1 + cb) * 2048 : nullptr;
+                if (cap) *reinterpret_cast<float2*>(cap + 2 * tid) = make_float2(lv0, lv1);  // the penalised logits this decision sees
+                int gi;
+                if (SAMPLED) {
+                    int used = 0;
+                    __syncthreads();  // (the scratch aliases this stage's own LDS: nobody is still reading the previous decision's)
+                    const float lvv[2] = {lv0, lv1};
+                    gi = bsample<PF_THREADS, 2>(lvv, 1024, cfg.top_k, (float)(1.0 / (double)cfg.temp), cfg.top_p, s_words[n_draws], &used, samp);
+                    n_draws += used;
+                    PF_TICK(6);
+                } else {
                 // per lane: ascending index, the later equal value wins
                 float bv = lv0;
                 int bi = 2 * tid;
@@ -439,7 +526,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
                 if (lane == 0) { amax[(par * 8 + wave) * 2] = wm; amax[(par * 8 + wave) * 2 + 1] = __int_as_float(ci); }
                 __syncthreads();
                 float gv = amax[(par * 8) * 2];
-                int gi = __float_as_int(amax[(par * 8) * 2 + 1]);
+                gi = __float_as_int(amax[(par * 8) * 2 + 1]);
 #pragma unroll
                 for (int w = 1; w < 8; ++w) {
                     const float v2 = amax[(par * 8 + w) * 2];
@@ -448,7 +535,9 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
                 }
                 par ^= 1;
                     PF_TICK(6);
+                }
                 const uint32_t code = (uint32_t)max(gi, 0);
+                if (cap && tid == 0) cap[1024] = (float)code;
                 if (tid == 0) {
                     s_misc[4 + cb] = code;
                     if (b == 0) A.state->cur[cb + 1] = code;
@@ -474,6 +563,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
         SeqState* st = A.state;
         const int frame = st->frame;
         if (done_in == 1) st->done = 2;
+        if (A.slow_logits) st->cur[0] = cur0;
         if (frame == 0 || cur0 != cfg.im_end_id) {
             const int o = st->n_out;
             if (o < A.out_cap)
@@ -484,6 +574,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
         st->have_prev = 1;
         st->pos += 1;
         st->frame = frame + 1;
+        if (SAMPLED) A.rng->consumed = consumed0 + (unsigned long long)n_draws;
         A.ctl[0] = epoch + 1;
     }
     // next slow input: embed([slow, c0..c7]) (dual_ar.rs:532-567): token row first, then the codebook rows in order
@@ -544,15 +635,18 @@ void launch_fast_persist_pack(const LayerW* fast, const void* head_w, void* pack
     FS_HIP(hipGetLastError());
 }
 
-void launch_fast_persist(const FastPersistArgs& a, hipStream_t st) {
+void launch_fast_persist(const FastPersistArgs& a, bool sampled, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_persist), hipFuncAttributeMaxDynamicSharedMemorySize, L_END));
+        FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_persist<false>), hipFuncAttributeMaxDynamicSharedMemorySize, L_END));
+        FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_persist<true>), hipFuncAttributeMaxDynamicSharedMemorySize, L_END));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_fast_persist, dim3(PF_BLOCKS), dim3(PF_THREADS), L_END, st, a);
+    if (sampled) hipLaunchKernelGGL(k_fast_persist<true>, dim3(PF_BLOCKS), dim3(PF_THREADS), L_END, st, a);
+    else hipLaunchKernelGGL(k_fast_persist<false>, dim3(PF_BLOCKS), dim3(PF_THREADS), L_END, st, a);
     FS_HIP(hipGetLastError());
 }
+bool fast_persist_samples(float temp, int top_k, int cb_size) { return temp > 0.f && top_k > 0 && top_k <= BS_MAXK && top_k < cb_size; }
 
 void launch_pf_reduce_selftest(const float* in, float* out, hipStream_t st) {
     hipLaunchKernelGGL(k_pf_reduce_selftest, dim3(1), dim3(64), 0, st, in, out);

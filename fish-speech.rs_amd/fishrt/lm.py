@@ -170,6 +170,15 @@ class DualARTransformer:
         _ffi.check(_ffi.lib().fs_lm_last_stats(self._h, C.byref(st)))
         return {k: getattr(st, k) for k, _ in _ffi.GenStats._fields_}
 
+    def debug_capture(self, n_frames):
+        """test hook: record what the 9 decisions of each of the first n_frames iterations saw and picked (persistent path only)"""
+        _ffi.check(_ffi.lib().fs_lm_debug_capture(self._h, int(n_frames)))
+
+    def debug_read(self, n_frames):
+        out = np.zeros((int(n_frames), 9, 2048), np.float32)
+        _ffi.check(_ffi.lib().fs_lm_debug_read(self._h, out.ctypes.data_as(C.POINTER(C.c_float)), int(n_frames)))
+        return out
+
     def stream(self):
         return _ffi.lib().fs_lm_stream(self._h)
 

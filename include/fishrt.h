@@ -87,6 +87,15 @@ int fs_selftest(int device_id, const char* what);
 int fs_selftest_sample_rows(int device_id, const float* logits, int B, int n, const fs_sampling* s, uint64_t seed, int call_index,
                             uint32_t* out);
 
+/* Decision capture of the persistent batch-1 decode path (diagnostics / parity tests; no reference counterpart).  After
+ * fs_lm_debug_capture(lm, n) every fs_lm_generate call that takes the persistent fast decoder records, for its first n generator
+ * iterations, what each of the 9 decisions of a frame saw and chose: fs_lm_debug_read copies f32 [n][9][2048]; row 0 = the slow
+ * decision (entries [0, V - im_end): logits over the audio range after the <|im_end|> mask; entry 2047: the picked index), rows
+ * 1 + c = codebook c (entries [0, 1024): logits after the repetition penalty; entry 1024: the picked code).  n = 0 switches it off.
+ * The parity tests replay these rows through the CPU sampler: same logits, same StdRng stream => same picks, token for token. */
+int fs_lm_debug_capture(fs_lm_t* lm, int n_frames);
+int fs_lm_debug_read(fs_lm_t* lm, float* out, int n_frames);
+
 /* DualARTransformer::load (dual_ar.rs:460-529) is split in create + one of the load calls.
  * max_batch: number of independent sequences (KV caches) the handle can hold (1 for the single-batch generator). */
 int fs_lm_create(const fs_model_args* args, const fs_token_cfg* tok, int device_id, fs_dtype dtype, int max_batch,

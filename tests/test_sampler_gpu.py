@@ -4,6 +4,7 @@ top-p 0.8, temp 0.7) against the CPU oracle, whose RNG chain is pinned to public
  (2) the batch-1 sampler end to end on an f32 Fish-1.5 handle (f32 logits agree with the oracle to ~1e-6, so the sampled streams agree
      except where a uniform draw lands within that distance of a CDF boundary)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -34,15 +35,33 @@ def _orc_rows(logits, temp, top_p, top_k, seed, call):
     return out
 
 
+@pytest.fixture(params=["block1024", "par512"])
+def impl(request):
+    """block1024: the static-batch sampler kernel (one-wave top-k path inside a 1024-thread block); par512: the block-parallel sampler the
+    persistent fast decoder runs in-launch (csrc/lm_bsample_dev.h), 512 threads per row, same RNG derivation"""
+    old = os.environ.get("FISHRT_SAMPLER_IMPL")
+    if request.param == "par512":
+        os.environ["FISHRT_SAMPLER_IMPL"] = "par512"
+    else:
+        os.environ.pop("FISHRT_SAMPLER_IMPL", None)
+    yield request.param
+    if old is None:
+        os.environ.pop("FISHRT_SAMPLER_IMPL", None)
+    else:
+        os.environ["FISHRT_SAMPLER_IMPL"] = old
+
+
 @pytest.mark.parametrize("n", [2037, 1024])
-@pytest.mark.parametrize("temp,top_p,top_k", [(0.7, 0.8, 256), (0.7, 0.9, 50), (1.0, 1.0, 256), (0.7, 0.3, 256), (1e-8, 0.8, 256)])
-def test_static_batch_sampler_rows_token_exact(n, temp, top_p, top_k):
+@pytest.mark.parametrize("temp,top_p,top_k", [(0.7, 0.8, 256), (0.7, 0.9, 50), (1.0, 1.0, 256), (0.7, 0.3, 256), (1e-8, 0.8, 256), (0.7, 0.8, 1), (2.0, 0.99, 255)])
+def test_static_batch_sampler_rows_token_exact(n, temp, top_p, top_k, impl):
     rs = np.random.RandomState(n + top_k)
     total = agree = 0
     for call in (0, 1, 9, 300):
         for scale in (1.0, 4.0):  # flat (synthetic-weight-like) and peaked (trained-model-like) logit rows
             logits = np.ascontiguousarray((rs.randn(32, n) * scale).astype(np.float32))
             logits[3, 5] = logits[3, 900] = logits[3].max() + 1.0  # an exact tie at the top (first-max rule when temp <= 1e-7)
+            logits[4, 100:400] = logits[4, 100]                    # 300 equal candidates straddling the top-k boundary (ties: lower index first)
+            logits[5, 7:] = -80.0                                  # fewer non-zero probabilities than top_k (the rest underflow to 0)
             g, o = _gpu_rows(logits, temp, top_p, top_k, 42, call), _orc_rows(logits, temp, top_p, top_k, 42, call)
             assert np.array_equal(g, o), (call, scale, np.nonzero(g != o)[0], g[g != o], o[g != o])
             total += 32

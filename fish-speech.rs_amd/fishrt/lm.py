@@ -213,6 +213,8 @@ class Session:
 
     def add(self, prompt, max_new_tokens):
         p = _u32(prompt)
+        if p.ndim != 2 or p.shape[0] != self.lm.cfg["num_codebooks"] + 1 or p.shape[1] < 1:  # the C side reads (C + 1) * L words
+            raise ValueError(f"prompt must be u32 [{self.lm.cfg['num_codebooks'] + 1}, L >= 1], got {p.shape}")
         slot = C.c_int(-1)
         _ffi.check(_ffi.lib().fs_lm_session_add(self.lm._h, p.ctypes.data_as(C.POINTER(C.c_uint32)), int(p.shape[1]), int(max_new_tokens),
                                                 C.byref(slot)))

@@ -100,8 +100,9 @@ class LMState:  # server/lib/state.rs:12-21
 
 class AppState:  # server/lib/state.rs:23-29
     def __init__(self, lm_state, codec, sample_rate=44100, opus_encoder=None, preprocess=preprocess_text, batch_window_s=0.002,
-                 continuous=True):
+                 continuous=True, auto_batch=False):
         self.lm, self.codec, self.sample_rate, self.opus_encoder, self.preprocess = lm_state, codec, sample_rate, opus_encoder, preprocess
+        self.auto_batch = auto_batch  # True: every chunk may join the batching session (batch sampling semantics) without `batch_size`
         self.scheduler = Scheduler(lm_state, batch_window_s, continuous)
 
 
@@ -222,7 +223,12 @@ class Scheduler:
                             sa = self.s.default_sampling_args
                             sess = lm.session(temp=sa.temp, top_p=sa.top_p, top_k=sa.top_k, seed=self.s.seed_source() & (2**64 - 1))
                             self.cached_key = None
-                        slot = sess.add(held.full_prompt(), self.s.max_new_tokens)
+                        try:
+                            slot = sess.add(held.full_prompt(), self.s.max_new_tokens)
+                        except BaseException as e:  # a bad request (prompt longer than max_seq_len, ...) fails ALONE: the live slots go on
+                            held.future.set_exception(e)
+                            held = None
+                            continue
                         if slot is not None:
                             live[slot] = held
                             held = None
@@ -230,6 +236,12 @@ class Scheduler:
                             self.stats["batched_rows"] += 1
                             self.stats["peak_live"] = max(self.stats.get("peak_live", 0), len(live))
                             continue  # admit more before stepping
+                        if not live:  # nothing will ever free a slot / KV pages for it: the batch-1 path (or its error) instead of spinning
+                            sess.close()
+                            sess = None
+                            j, held = held, None
+                            self._single(j)
+                            continue
                 # ---- one scheduling quantum of decode steps for every live slot
                 if live:
                     sess.step(self.step_frames)
@@ -239,7 +251,13 @@ class Scheduler:
                         if done:
                             codes, _ = sess.poll(slot)
                             sess.release(slot)
-                            live.pop(slot).future.set_result(self._codes_out(codes))
+                            jb = live.pop(slot)
+                            if codes.shape[1] >= self.s.max_new_tokens:  # speech.rs:41-61 "Failed generation suspected. Rerolling once":
+                                self.stats["rerolls"] += 1               # the re-roll takes the batch-1 path once the session has drained
+                                jb.allow_batch, jb.reroll = False, True
+                                self.q.put(jb)
+                            else:
+                                jb.future.set_result(self._codes_out(codes))
             except BaseException as e:  # every in-flight request gets the error (AppError -> HTTP 500); the session is rebuilt
                 fail_all(e)
                 held = None
@@ -252,6 +270,8 @@ class Scheduler:
 
     def _codes_out(self, codes):
         if self.s.model_type != fprompt.FISH_1_5:  # speech.rs:63-68: Fish <= 1.4 codes are shifted by one
+            if (codes == 0).any():  # the reference's u32 subtraction would wrap and its codebook gather then fails: surface it the same way
+                raise RuntimeError("Fish <= 1.4 generation produced code 0 (no codebook entry -1)")
             codes = codes - np.uint32(1)
         return codes
 
@@ -269,6 +289,8 @@ class Scheduler:
             codes = lm.generate_blocking(prompt, self.s.max_new_tokens, seed=self.s.seed_source(), **sa.kw())
             lm.clear_slow_caches_until(j.n_cond)  # speech.rs:40
             self.cached_key = j.cond_key if j.cond is not None else None
+            if codes.shape[1] == self.s.max_new_tokens and getattr(j, "reroll", False):  # this WAS the re-roll of a session job
+                raise RuntimeError("Encoded input failed for second time. Bailing")
             if codes.shape[1] == self.s.max_new_tokens:  # speech.rs:41-61: "Failed generation suspected. Rerolling once"
                 self.stats["rerolls"] += 1
                 lm.clear_slow_layer_caches()
@@ -333,14 +355,16 @@ def generate_speech(state, req):
             if state.opus_encoder is None:
                 return 501, "application/json", json.dumps({"detail": "Opus / Ogg streaming is outside this shim (audio/opus.rs); use the default WAV "
                                                                       "response or response_format 'pcm'"}).encode()
-        # the reference batches only on request (`batch_size`); here every chunk may ride in a static batch whenever other chunks -- of this
-        # or of any other request -- are waiting, unless the handle was created for batch 1
-        futs = [state.scheduler.submit(cond, b, n_cond, state.lm.max_batch > 1) for b in bodies]
+        # like the reference (speech.rs:72-96) chunks are batched only when the request asks for it (`batch_size` > 1): the batch paths sample
+        # with BatchedLogitsProcessor semantics and no repetition penalty, so what a client hears must not depend on the server's load.
+        # `auto_batch` (server option, off by default) lets every chunk join the continuous-batching session when other work is in flight.
+        want_batch = int(req.get("batch_size") or 1) > 1 or getattr(state, "auto_batch", False)
+        futs = [state.scheduler.submit(cond, b, n_cond, state.lm.max_batch > 1 and want_batch) for b in bodies]
 
         def pcm_chunks():
             for f in futs:
                 codes = f.result()
-                pcm = state.codec.decode(np.ascontiguousarray(np.minimum(codes, 999)[None]))[0, 0]
+                pcm = state.codec.decode(np.ascontiguousarray(codes[None]))[0, 0]  # (an out-of-range code is an error, as in the reference)
                 yield pcm
 
         if fmt == "pcm":  # extension: chunked little-endian s16 PCM at the codec rate, one HTTP chunk per text chunk

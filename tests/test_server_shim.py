@@ -111,14 +111,14 @@ class FakeCodec:
         return np.full((1, 8, max(1, pcm.shape[2] // 2048)), 7, np.uint32)
 
 
-def _state(max_batch=1, continuous=True, **lm_kw):
+def _state(max_batch=1, continuous=True, auto_batch=False, **lm_kw):
     tok = Tok()
     enc = fprompt.PromptEncoder(tok, 8, fprompt.FISH_1_5)
     default = enc.encode_conditioning_prompt("hello there", np.full((8, 4), 3, np.uint32))
     alice = enc.encode_conditioning_prompt("i am alice", np.full((8, 6), 9, np.uint32))
     lm = FakeLM(**lm_kw)
     ls = server.LMState(lm, tok, {"default": default, "alice": alice}, default, max_new_tokens=lm.M, max_batch=max_batch)
-    return server.AppState(ls, FakeCodec(), batch_window_s=0.05, continuous=continuous), lm
+    return server.AppState(ls, FakeCodec(), batch_window_s=0.05, continuous=continuous, auto_batch=auto_batch), lm
 
 
 def _client(state):
@@ -169,11 +169,11 @@ def test_voices_unknown_voice_falls_back_and_unconditioned():
     state.scheduler.close()
 
 
-def _fire(c, n):
+def _fire(c, n, **extra):
     results = {}
 
     def go(i):
-        results[i] = c.post("/v1/audio/speech", json=dict(model="x", voice="alice" if i % 2 else "default", input=f"Request number {i}."))
+        results[i] = c.post("/v1/audio/speech", json=dict(model="x", voice="alice" if i % 2 else "default", input=f"Request number {i}.", **extra))
 
     ths = [threading.Thread(target=go, args=(i,)) for i in range(n)]
     for t in ths:
@@ -186,7 +186,7 @@ def _fire(c, n):
 def test_concurrent_requests_share_a_continuous_batching_session():
     """max_batch > 1: jobs in flight together become slots of one session (fs_lm_session_*); more jobs than slots wait for a release; the
     session is closed when the burst is over and the handle's batch-1 path works again"""
-    state, lm = _state(max_batch=8, slow=0.02)
+    state, lm = _state(max_batch=8, slow=0.02, auto_batch=True)
     lm.frames_for = lambda prompt: 20 + int(prompt[0, -5]) % 30  # several scheduling quanta per job
     c = _client(state)
     results = _fire(c, 7)
@@ -205,8 +205,70 @@ def test_concurrent_requests_share_a_continuous_batching_session():
     state.scheduler.close()
 
 
+def test_batching_is_opt_in_like_the_reference():
+    """speech.rs:72-96: chunks are batched only when the request passes batch_size; without it concurrent requests keep the full
+    single-sequence sampling semantics (repetition penalty, re-roll, prefix reuse) whatever the load"""
+    state, lm = _state(max_batch=8, slow=0.01)
+    c = _client(state)
+    results = _fire(c, 5)
+    assert all(r.status_code == 200 for r in results.values())
+    assert state.scheduler.stats["single"] == 5 and state.scheduler.stats.get("batched_rows", 0) == 0
+    assert all(k[0] == "single" and "repetition_penalty" in k[3] for k in lm.calls)
+    results = _fire(c, 5, batch_size=4)
+    assert all(r.status_code == 200 for r in results.values())
+    assert state.scheduler.stats["batched_rows"] >= 2 and "session" in [k[0] for k in lm.calls]
+    state.scheduler.close()
+
+
+def test_a_bad_request_fails_alone_and_a_request_no_slot_can_ever_hold_takes_the_single_path():
+    state, lm = _state(max_batch=8, slow=0.02, auto_batch=True)
+    lm.frames_for = lambda prompt: 30
+    real_add = FakeSession.add
+    seen = {"n": 0}
+
+    def add(self, prompt, max_new_tokens):
+        seen["n"] += 1
+        if seen["n"] == 3:
+            raise RuntimeError("prompt exceeds max_seq_len (dual_ar.rs:623-624)")
+        return real_add(self, prompt, max_new_tokens)
+    FakeSession.add = add
+    try:
+        c = _client(state)
+        results = _fire(c, 6)
+    finally:
+        FakeSession.add = real_add
+    codes = sorted(r.status_code for r in results.values())
+    assert codes == [200] * 5 + [500], codes  # exactly the offending request fails; the live slots finish
+    assert any(b"max_seq_len" in r.content for r in results.values())
+    # add() == None with nothing live (the KV pool can never hold the request): the job is handed to the batch-1 path, no busy loop
+    FakeSession.add = lambda self, prompt, max_new_tokens: None
+    try:
+        r = c.post("/v1/audio/speech", json=dict(model="x", voice="default", input="Too big for any slot."))
+    finally:
+        FakeSession.add = real_add
+    assert r.status_code == 200 and lm.calls[-1][0] == "single"
+    state.scheduler.close()
+
+
+def test_session_jobs_that_hit_max_new_tokens_are_rerolled_on_the_single_path():
+    state, lm = _state(max_batch=8, max_new_tokens=6, auto_batch=True, slow=0.01)
+    seen = {}
+
+    def frames(prompt):  # the first generation of every request runs into the budget, its re-roll does not
+        k = prompt[0, -40:].tobytes()  # the tail of the user turn: the same whether or not the conditioning prefix is sent
+        seen[k] = seen.get(k, 0) + 1
+        return 6 if seen[k] == 1 else 4
+    lm.frames_for = frames
+    c = _client(state)
+    results = _fire(c, 3)
+    assert all(r.status_code == 200 for r in results.values()), [r.content for r in results.values()]
+    assert state.scheduler.stats["rerolls"] == 3 and "add" in [k[0] for k in lm.calls]
+    assert all(v == 2 for v in seen.values())  # one re-roll each, session jobs included
+    state.scheduler.close()
+
+
 def test_lock_step_variant_batches_waiting_jobs():
-    state, lm = _state(max_batch=8, continuous=False, slow=0.02)
+    state, lm = _state(max_batch=8, continuous=False, slow=0.02, auto_batch=True)
     c = _client(state)
     results = _fire(c, 6)
     assert all(r.status_code == 200 for r in results.values())

@@ -255,7 +255,8 @@ def test_session_jobs_that_hit_max_new_tokens_are_rerolled_on_the_single_path():
     seen = {}
 
     def frames(prompt):  # the first generation of every request runs into the budget, its re-roll does not
-        k = prompt[0, -90:].tobytes()  # the tail of the user turn: the same whether or not the conditioning prefix is sent
+        raw = bytes(int(v) & 0xFF for v in prompt[0])  # the stand-in tokenizer is byte-level: the request's number identifies it,
+        k = raw[raw.rindex(b"number ") + 7]           # whether or not the conditioning prefix is part of the prompt
         seen[k] = seen.get(k, 0) + 1
         return 6 if seen[k] == 1 else 4
     lm.frames_for = frames

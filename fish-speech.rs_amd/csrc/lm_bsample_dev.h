@@ -116,7 +116,8 @@ __device__ __forceinline__ void bs_fetch32(const float* a, int j, int n, float (
 // word: the StdRng output word this draw would consume.  Returns the picked candidate index on every thread; *consumed = 1 iff the
 // draw consumed `word` (rand's WeightedIndex needs a positive total).
 template <int NT, int EPT>
-__device__ int bsample(const float (&lv)[EPT], int n, int kk, float inv_t, float top_p, uint32_t word, int* consumed, BSampLds& S) {
+__device__ int bsample(const float (&lv)[EPT], int n, int kk, float inv_t, float top_p, uint32_t word, int* consumed, BSampLds& S,
+                       bool batch = false, double top_p64 = 0.0) {  // batch: BatchedLogitsProcessor's f64 comparison (sampling/mod.rs:68)
     static_assert(NT % 64 == 0 && NT >= BS_MAXK + 64 && NT * EPT <= 2048, "block shape");
     constexpr int W = NT / 64;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -284,7 +285,7 @@ __device__ int bsample(const float (&lv)[EPT], int n, int kk, float inv_t, float
     __syncthreads();
     BS_TS(4);
     const float sum_p = __int_as_float(S.misc[6]);
-    const bool do_topp = maybe_topp && !(top_p <= 0.f || top_p >= sum_p);  // (maybe_topp is implied: see its margin)
+    const bool do_topp = maybe_topp && (batch ? !(top_p64 <= 0.0 || top_p64 >= (double)sum_p) : !(top_p <= 0.f || top_p >= sum_p));  // (maybe_topp is implied)
     const float* cumw = S.cumk;  // cumulative weights of the entries the draw runs over
     const int* wpos = nullptr;   // their positions in (kp, ki); null: identity
     int cnt = kk;

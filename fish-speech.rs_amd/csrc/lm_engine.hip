@@ -370,7 +370,7 @@ class LM final : public LMBase {
         ensure_capacity(0, n_cached + L + (int)n_iter - 1);
         // device-side setup
         SampleCfg cfg = base_cfg();
-        cfg.temp = (float)s.temp; cfg.top_p = (float)s.top_p;
+        cfg.temp = (float)s.temp; cfg.top_p = (float)s.top_p; cfg.top_p64 = s.top_p;
         cfg.top_k = (int)std::min<uint64_t>(s.top_k, 1u << 30);
         cfg.rep_pen = s.repetition_penalty; cfg.ignore_eos = (flags & FS_GEN_IGNORE_EOS) ? 1 : 0;
         cfg.batch_rows = batch_rows_; cfg.batch_row = batch_row_; cfg.batch_calls = a_.num_codebooks + 1;  // batch_rows > 0 only inside generate_batch_sequential
@@ -576,7 +576,7 @@ class LM final : public LMBase {
         ensure_prefill_buffers();
         ensure_batch_buffers();
         SampleCfg cfg = base_cfg();
-        cfg.temp = (float)s.temp; cfg.top_p = (float)s.top_p;
+        cfg.temp = (float)s.temp; cfg.top_p = (float)s.top_p; cfg.top_p64 = s.top_p;
         cfg.top_k = (int)std::min<uint64_t>(s.top_k, 1u << 30);
         cfg.rep_pen = 1.0f; cfg.ignore_eos = (flags & FS_GEN_IGNORE_EOS) ? 1 : 0;
         FS_HIP(hipMemcpyAsync(d_cfg_.p, &cfg, sizeof(cfg), hipMemcpyHostToDevice, st_));
@@ -707,7 +707,7 @@ class LM final : public LMBase {
         ensure_prefill_buffers();
         ensure_batch_buffers();
         SampleCfg cfg = base_cfg();
-        cfg.temp = (float)s.temp; cfg.top_p = (float)s.top_p;
+        cfg.temp = (float)s.temp; cfg.top_p = (float)s.top_p; cfg.top_p64 = s.top_p;
         cfg.top_k = (int)std::min<uint64_t>(s.top_k, 1u << 30);
         cfg.rep_pen = 1.0f; cfg.ignore_eos = (flags & FS_GEN_IGNORE_EOS) ? 1 : 0;
         cfg.session = 1;

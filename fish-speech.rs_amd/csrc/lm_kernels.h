@@ -160,6 +160,9 @@ struct SampleCfg {  // device-resident (the captured graphs read it through a po
     // continuous batching (fs_lm_session_*): the rows of the static-batch step are independent request slots -- a finished or empty slot
     // stops stepping (position, frame counter and outputs frozen) instead of following the live rows in lock-step
     int session = 0;
+    // BatchedLogitsProcessor compares top_p (f64) with `sum_p as f64` (sampling/mod.rs:68); the single-sequence LogitsProcessor narrows
+    // top_p to f32 first.  The batched samplers (k_sample_*_rows, batch_rows > 0) use this field for that one comparison.
+    double top_p64 = 0.0;
 };
 
 struct RepPenState {   // rep_pen.rs:4-72, one per codebook

@@ -1762,7 +1762,7 @@ __device__ __forceinline__ unsigned long long dpp_xor_lane_u64(unsigned long lon
 
 template <int EPL>
 __device__ void wave_topk_select(const float* lg, int n, int kk, float inv_t, float top_p, float* kp, int* ki, float* sp,
-                                 unsigned long long* keyb, float* cumsp) {
+                                 unsigned long long* keyb, float* cumsp, bool batch, double top_p64) {
     const int lane = threadIdx.x & 63;
     const int base = lane * EPL;
     uint32_t u[EPL];
@@ -1921,7 +1921,7 @@ __device__ void wave_topk_select(const float* lg, int n, int kk, float inv_t, fl
         }
     }
     const float sum_p = readlane(cum, 0);
-    const bool do_topp = !(top_p <= 0.f || top_p >= sum_p);
+    const bool do_topp = batch ? !(top_p64 <= 0.0 || top_p64 >= (double)sum_p) : !(top_p <= 0.f || top_p >= sum_p);  // sampling/mod.rs:68
     FS_TS(5);
     if (do_topp) {  // zero every prob once the running cumsum (descending order) reached top_p
         const float4 cq = *reinterpret_cast<const float4*>(cumsp + lane * 4);
@@ -2050,8 +2050,8 @@ __device__ int block_sample(float* lg /*LDS [n]*/, int n, const SampleCfg& c, Rn
             const int kk0 = c.top_k;
             FS_TS(0);
             if (tid < 64) {
-                if (n <= 1024) wave_topk_select<16>(lg, n, kk0, inv_t0, c.top_p, w_kp, w_ki, sp, w_key, w_cum);
-                else wave_topk_select<32>(lg, n, kk0, inv_t0, c.top_p, w_kp, w_ki, sp, w_key, w_cum);
+                if (n <= 1024) wave_topk_select<16>(lg, n, kk0, inv_t0, c.top_p, w_kp, w_ki, sp, w_key, w_cum, first_max, c.top_p64);
+                else wave_topk_select<32>(lg, n, kk0, inv_t0, c.top_p, w_kp, w_ki, sp, w_key, w_cum, first_max, c.top_p64);
             } else if (tid == SAMPLE_THREADS - 1) {
                 s_word0 = chacha12_word(rng->key, rng->consumed);
             }
@@ -2186,7 +2186,7 @@ __device__ int block_sample(float* lg /*LDS [n]*/, int n, const SampleCfg& c, Rn
         bool do_topp = true;
         if (use_k) {
             const float sum_p = seq_sum(kp, cnt);  // ascending index; entries outside the top-k are 0 (or absent)
-            do_topp = !(c.top_p <= 0.f || c.top_p >= sum_p);
+            do_topp = first_max ? !(c.top_p64 <= 0.0 || c.top_p64 >= (double)sum_p) : !(c.top_p <= 0.f || c.top_p >= sum_p);  // (first_max == batch semantics)
         }
         // zero every prob once the running cumsum (descending order) reached top_p
         s_cut = do_topp ? seq_topp_cut(sp, kk, c.top_p) : kk;
@@ -2559,7 +2559,7 @@ __global__ __launch_bounds__(NT) void k_bsample_rows_test(const float* __restric
     if (tid == NT - 1) { child_rng(master, (unsigned long long)call * B + b, &lrng); s_word = chacha12_word(lrng.key, 0); }
     __syncthreads();
     int consumed = 0;
-    const int idx = bsample<NT, EPT>(lv, n, c.top_k, (float)(1.0 / (double)c.temp), c.top_p, s_word, &consumed, S);
+    const int idx = bsample<NT, EPT>(lv, n, c.top_k, (float)(1.0 / (double)c.temp), c.top_p, s_word, &consumed, S, /*batch=*/true, c.top_p64);
     if (tid == 0) out[b] = (uint32_t)idx;
 }
 
@@ -3106,7 +3106,7 @@ void debug_sample_rows(int device, const float* logits, int B, int n, double tem
     FS_HIP(hipMalloc(&d_cfg, sizeof(SampleCfg))); FS_HIP(hipMalloc(&d_rng, sizeof(RngState))); FS_HIP(hipMalloc(&d_st, sizeof(SeqState) * B));
     FS_HIP(hipMemcpy(d_logits, logits, sizeof(float) * (size_t)B * n, hipMemcpyHostToDevice));
     SampleCfg c = {};
-    c.temp = (float)temp; c.top_p = (float)top_p; c.top_k = (int)std::min<uint64_t>(top_k, 1u << 30); c.rep_pen = 1.f;
+    c.temp = (float)temp; c.top_p = (float)top_p; c.top_k = (int)std::min<uint64_t>(top_k, 1u << 30); c.rep_pen = 1.f; c.top_p64 = top_p;
     FS_HIP(hipMemcpy(d_cfg, &c, sizeof(c), hipMemcpyHostToDevice));
     RngState r = {};
     unsigned long long state = seed;

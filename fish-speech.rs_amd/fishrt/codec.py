@@ -55,6 +55,11 @@ class FireflyCodec:
             raise ValueError("Data must be a contiguous array")
         if pcm_data.ndim != 3:
             raise ValueError("pcm_data must be a 3-D array (1, 1, n)")
+        if pcm_data.shape[0] != 1 or pcm_data.shape[1] != 1:
+            # the reference flattens whatever it is given into ONE clip (spectrogram.rs:33 `flatten_all`) and returns (1, 8, L): a batch
+            # would come back as the codes of its clips glued together.  Refuse it instead of reproducing that silently.
+            raise ValueError("encode takes one mono clip (1, 1, n): the reference concatenates batched clips into one (spectrogram.rs:33); "
+                             "call encode once per clip")
         pcm = pcm_data.astype(np.float32, copy=False).reshape(-1)
         cap = pcm.size // 2048 + 4
         codes = np.zeros((8, cap), np.uint32)

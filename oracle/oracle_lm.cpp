@@ -455,7 +455,9 @@ static uint32_t sample_topp(ChaCha12Rng& rng, std::vector<float>& probs, float t
 // top-k: the reference uses `select_nth_unstable_by`, whose output ORDER is unspecified; this restatement
 // (and the HIP path) fix the order to ascending token index, which leaves the sampling distribution unchanged.
 // top-k then top-p then WeightedIndex draw on a probability vector (shared by the single and the batched processor)
-static uint32_t sample_probs(ChaCha12Rng& rng, std::vector<float>& p, size_t top_k, float top_p) {
+// top_p64: BatchedLogitsProcessor::sample_single_top_p_k keeps top_p as f64 and compares it with `sum_p as f64` (sampling/mod.rs:68);
+// candle's LogitsProcessor (the single-sequence path) narrows it to f32 first.  NaN = the single-sequence rule.
+static uint32_t sample_probs(ChaCha12Rng& rng, std::vector<float>& p, size_t top_k, float top_p, double top_p64 = std::nan("")) {
     const size_t n = p.size();
     if (top_k == 0 || top_k >= n) return sample_topp(rng, p, top_p);
     std::vector<size_t> idx(n);
@@ -466,7 +468,8 @@ static uint32_t sample_probs(ChaCha12Rng& rng, std::vector<float>& p, size_t top
     std::vector<float> tk(top_k);
     float sum_p = 0.f;
     for (size_t i = 0; i < top_k; ++i) { tk[i] = p[keep[i]]; sum_p += tk[i]; }
-    uint32_t j = (top_p <= 0.f || top_p >= sum_p) ? weighted_index_sample(rng, tk) : sample_topp(rng, tk, top_p);
+    const bool all = std::isnan(top_p64) ? (top_p <= 0.f || top_p >= sum_p) : (top_p64 <= 0.0 || top_p64 >= (double)sum_p);
+    uint32_t j = all ? weighted_index_sample(rng, tk) : sample_topp(rng, tk, top_p);
     return (uint32_t)keep[j];
 }
 
@@ -500,7 +503,7 @@ std::vector<uint32_t> batched_sample(ChaCha12Rng& master, const Sampling& s, con
         ChaCha12Rng child(seeds[b]);
         std::vector<float> p;
         softmax_temp(logits + b * ld, n, inv_t, p);
-        out[b] = sample_probs(child, p, (size_t)s.top_k, (float)s.top_p);
+        out[b] = sample_probs(child, p, (size_t)s.top_k, (float)s.top_p, s.top_p);
     }
     return out;
 }

@@ -81,6 +81,8 @@ def test_gpu_encode_tiny_vs_oracle(otiny):
         c.encode(np.zeros((1, 1, 100), np.float32))
     with pytest.raises(ValueError):
         c.encode(np.zeros((1, 1, 5000), np.float32)[:, :, ::2])  # not contiguous
+    with pytest.raises(ValueError, match="one mono clip"):
+        c.encode(np.zeros((2, 1, 8192), np.float32))  # the reference would glue the two clips together (spectrogram.rs:33)
     # decode accepts what encode produces (same handle)
     pcm = c.decode(np.ascontiguousarray(got))
     assert pcm.shape == (1, 1, 2048 * got.shape[2]) and np.isfinite(pcm).all()

@@ -69,6 +69,20 @@ def test_static_batch_sampler_rows_token_exact(n, temp, top_p, top_k, impl):
     print(f"n={n} temp={temp} top_p={top_p} top_k={top_k}: {agree}/{total} rows identical")
 
 
+def test_batch_path_compares_top_p_in_f64(impl):
+    """sampling/mod.rs:68: `top_p >= sum_p as f64` with top_p kept as f64 -- for a top_p a hair below the f32 sum of the kept probabilities
+    the f64 rule takes the top-p branch where an f32 comparison (top_p rounds up to the sum) would draw from all k.  A sweep of top_p values
+    1e-9 apart across that sum: device and oracle must make the same choice at every one of them."""
+    rs = np.random.RandomState(5)
+    logits = np.ascontiguousarray((rs.randn(4, 1024) * 2.0).astype(np.float32))
+    p = np.exp((logits[0] / 0.7).astype(np.float64)); p /= p.sum()
+    s256 = float(np.sort(p)[-256:].sum())  # ~ the f32 sum the sampler compares with
+    for k in range(-40, 41):
+        top_p = s256 + k * 2.5e-9
+        g, o = _gpu_rows(logits, 0.7, top_p, 256, 42, 3), _orc_rows(logits, 0.7, top_p, 256, 42, 3)
+        assert np.array_equal(g, o), (k, top_p, g, o)
+
+
 def test_fish15_f32_sampled_stream_vs_oracle():
     """BASELINE configs[2] sampling at batch 1 on the f32 handle: 20 frames x 9 draws (slow n = 2037, fast n = 1024, top-k 256)"""
     cfg, tok = fcfg.FISH_1_5, fcfg.FISH_1_5_TOKENS

@@ -12,10 +12,14 @@ configs[3] instead (256 requests sharded i mod N, static batches of 32 per GPU, 
 ranks exercise the control path only (dry run, value null): libfishrt has no CPU path.
 
 Extra objects on the JSON line:
-  roofline     -- HBM roofline of the decode FRAME (one hipGraph replay = the unit of the hot loop: 123 kernels with the
-                  persistent fast decoder, 266 with --no-persistent):
+  roofline     -- HBM roofline of the decode FRAME (one hipGraph replay = the unit of the hot loop: the two persistent launches
+                  k_slow_persist + k_fast_persist; 266 kernels with --no-persistent):
                   achieved = B_frame(T_avg) / t_frame, t_frame from HIP events recorded on the engine's own stream
-                  (fs_lm_last_stats); B_frame is SURVEY.md §8(d)'s algorithmic-bytes formula.
+                  (fs_lm_last_stats); B_frame is SURVEY.md §8(d)'s algorithmic-bytes formula; frac_min prices the same time against
+                  B_min (fast-decoder weights counted once per frame: they stay on chip for the 8 passes).
+                  roofline.kernels itemises both launches of the timed region (HIP events around every launch of one more request
+                  in FS_GEN_TIME_KERNELS mode): algorithmic bytes per launch, average duration, both fractions; dominant_kernel is
+                  the longer of the two.  tools/check_roofline.py recomputes every number from this line + profiles/rNN_*.
   cpu_baseline -- the CPU restatement (oracle/, kind "port": the reference is Rust+candle and cannot be built here) timed
                   on this host on BASELINE.json configs[0] (rank 0, N=1 only), which also yields the greedy golden
                   token stream: the GPU f32 path must reproduce it bit-identically (reported under "parity").
@@ -71,6 +75,20 @@ def frame_bytes(cfg, tok, T, wbytes=2):
     kv_tok = cfg["n_layer"] * 2 * cfg["n_local_heads"] * cfg["head_dim"] * wbytes
     kv_fast = cfg["num_codebooks"] * cfg["n_fast_layer"] * 2 * cfg["n_local_heads"] * cfg["head_dim"] * wbytes * 4
     return slow + fast + kv_tok * T + kv_fast
+
+
+def frame_bytes_split(cfg, tok, T, wbytes=2):
+    """frame_bytes() per launch of the persistent path: (slow step incl. the audio-range head and the slow KV read, the 8 fast passes
+    as SURVEY.md §8(d) counts them -- weights streamed by every pass --, the fast decoder with its weights counted ONCE: what a launch
+    that keeps them on chip has to read, B_min's fast term)."""
+    D, I = cfg["dim"], cfg["intermediate_size"]
+    qkv = (cfg["n_head"] + 2 * cfg["n_local_heads"]) * cfg["head_dim"]
+    block = qkv * D + D * D + 3 * I * D + 2 * D
+    n_audio = cfg["vocab_size"] - tok["im_end_id"]
+    slow = wbytes * (cfg["n_layer"] * block + D + n_audio * D) + cfg["n_layer"] * 2 * cfg["n_local_heads"] * cfg["head_dim"] * wbytes * T
+    fast_pass = wbytes * (cfg["n_fast_layer"] * block + D + cfg["codebook_size"] * D)
+    kv_fast = cfg["num_codebooks"] * cfg["n_fast_layer"] * 2 * cfg["n_local_heads"] * cfg["head_dim"] * wbytes * 4
+    return slow, cfg["num_codebooks"] * fast_pass + kv_fast, fast_pass + kv_fast
 
 
 def config2_prompts(tok, n):
@@ -300,16 +318,33 @@ def main():
     T_avg = L + args.frames / 2.0
     bf = frame_bytes(cfg, tok, T_avg)
     achieved = bf / t_frame
-    # the dominant kernel of the frame by bytes: k_ffn_up (RMSNorm + W1||W3 GEMV + SwiGLU) of the slow transformer, measured live as a graph
-    # node over distinct layer weights with HIP events on the engine stream (fs_lm_bench_kernel); rocprof: profiles/
-    up_us = lm.bench_kernel(3, int(T_avg), 50)
-    up_bytes = 2 * (2 * cfg["intermediate_size"] * cfg["dim"]) + 8 * cfg["dim"] + 4 * cfg["intermediate_size"]
-    per_kernel = {}
-    for name, kind, nbytes in (("k_qkv", 0, 2 * (cfg["n_head"] + 2 * cfg["n_local_heads"]) * cfg["head_dim"] * cfg["dim"]),
-                               ("k_attn_decode", 1, int(T_avg) * 2 * cfg["n_local_heads"] * cfg["head_dim"] * 2),
-                               ("k_wo", 2, 2 * cfg["dim"] * cfg["dim"]), ("k_ffn_down", 4, 2 * cfg["dim"] * cfg["intermediate_size"])):
-        us = lm.bench_kernel(kind, int(T_avg), 50)
-        per_kernel[name] = {"avg_us": round(us, 2), "algorithmic_bytes": nbytes, "GBps": round(nbytes / us / 1e3, 1)}
+    # the kernels of the timed region, one by one: one more request in measurement mode (FS_GEN_TIME_KERNELS: the same two persistent
+    # launches per frame, a HIP event in front of / between / behind them on the engine stream); rocprofv3's averages for the same
+    # kernels are committed under profiles/ and checked against these by tools/check_roofline.py
+    kernels, dominant = {}, None
+    b_slow, b_fast, b_fast_min = frame_bytes_split(cfg, tok, T_avg)
+    if kpf == 2:
+        lm.clear_slow_layer_caches()
+        outk = lm.generate_blocking(prompt, M, time_kernels=True, **samp)
+        assert np.array_equal(outk, out), "measurement mode changed the tokens"
+        stk = lm.last_stats()
+        for name, us, nb, nb_min, what in (
+                ("k_slow_persist", stk["slow_kernel_us"], b_slow, b_slow, "one launch = forward_generate of one token: 24 blocks over the paged KV cache + norm + audio-range head"),
+                ("k_fast_persist", stk["fast_kernel_us"], b_fast, b_fast_min, "one launch = the slow-token decision + 8 x forward_generate_fast + 8 codebook decisions + next-input embedding; "
+                                                                            "algorithmic bytes count the weights once per pass (SURVEY.md 8d), bytes_min once per launch (they stay on chip)")):
+            kernels[name] = {"what": what, "avg_us": round(us, 2), "launches_per_frame": 1, "algorithmic_bytes_per_launch": int(nb),
+                             "achieved": round(nb / us / 1e3, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(nb / (us * 1e-6) / HBM_PEAK, 4),
+                             "bytes_min_per_launch": int(nb_min), "frac_min": round(nb_min / (us * 1e-6) / HBM_PEAK, 4)}
+        dn = max(kernels, key=lambda k: kernels[k]["avg_us"])
+        dominant = {"name": dn, **kernels[dn], "share_of_frame_time": round(kernels[dn]["avg_us"] / (t_frame * 1e6), 3),
+                    "note": "HIP events on the engine stream around every launch of a 256-frame request (fs_gen_stats.slow_kernel_us / fast_kernel_us)"}
+    else:  # per-node path (--no-persistent): the frame's biggest node by bytes, measured as a graph node over distinct layer weights
+        up_us = lm.bench_kernel(3, int(T_avg), 50)
+        up_bytes = 2 * (2 * cfg["intermediate_size"] * cfg["dim"]) + 8 * cfg["dim"] + 4 * cfg["intermediate_size"]
+        dominant = {"name": "k_ffn_up<bf16, 1024> (RMSNorm + W1||W3 GEMV + SwiGLU; 56 launches per frame)", "algorithmic_bytes_per_launch": up_bytes,
+                    "avg_us": round(up_us, 2), "achieved": round(up_bytes / up_us / 1e3, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                    "frac": round(up_bytes / (up_us * 1e-6) / HBM_PEAK, 4), "note": "graph node incl. the launch floor; fs_lm_bench_kernel"}
+    b_min = b_slow + b_fast_min
     traffic = offline_traffic(kpf)
     res = {
         "metric": "codec tokens/sec (frames/s; 1 frame = 1 slow + 8 codebook tokens = 2048 PCM samples), Fish-1.5 batch=1",
@@ -322,19 +357,16 @@ def main():
                    "parallelism": f"replicas x{world} (no data-path collective; codes all-gathered over RCCL after the run)"},
         "rtf": round((frames_total / FRAME_RATE) / dt, 2), "rccl_ranks": int(seen), "weight_broadcast": wbcast, "frames_per_rank": [int(v) for v in fa.sum(axis=1) * args.steps],
         "decode_frames_per_s_per_gpu": round(1.0 / t_frame, 2), "prefill_ms": round(pre_ms, 3),
-        "roofline": {"bound": "hbm", "kernel": f"decode frame = one hipGraph replay of {kpf} kernels (24 slow blocks x 5 + head + sample, then "
-                                               + ("the 8 codebook passes of the fast decoder as ONE persistent launch" if kpf < 200 else "8 x (4 fast blocks x 4 + head + sample)")
-                                               + "); HIP-event timed on the engine stream",
+        "roofline": {"bound": "hbm", "kernel": (f"decode frame = one hipGraph replay of {kpf} kernels: " +
+                                               ("k_slow_persist (24 slow blocks + head) then k_fast_persist (slow-token decision, 8 codebook passes, 8 decisions)" if kpf == 2 else
+                                                "24 slow blocks x 5 + head + sample, then 8 x (4 fast blocks x 4 + head + sample)")
+                                               + "; HIP-event timed on the engine stream"),
                      "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK, 4),
                      **traffic,
                      "algorithmic_bytes_per_frame": int(bf), "frame_us": round(t_frame * 1e6, 2), "kv_len_avg": T_avg, "kernels_per_frame": kpf,
-                     "dominant_kernel": {"name": "k_ffn_up<bf16, 1024> (RMSNorm + W1||W3 GEMV + SwiGLU; the slow transformer's 24 launches = 24 % of the frame's algorithmic bytes)",
-                                         "algorithmic_bytes_per_launch": up_bytes, "avg_us": round(up_us, 2),
-                                         "achieved": round(up_bytes / up_us / 1e3, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                                         "frac": round(up_bytes / (up_us * 1e-6) / HBM_PEAK, 4),
-                                         "note": "graph node incl. the 1.55 us launch floor; HIP events on the engine stream"},
-                     "other_kernels": per_kernel},
+                     "bytes_min_per_frame": int(b_min), "frac_min": round(b_min / t_frame / HBM_PEAK, 4),
+                     "kernels": kernels, "dominant_kernel": dominant},
     }
     if rank == 0 and world == 1 and not args.no_extras:
         res["extras"] = extras(cfg, tok)
@@ -347,16 +379,17 @@ def main():
 
 
 def offline_traffic(kernels_per_frame):
-    """roofline.traffic: HBM bytes per decode frame from the PMC passes summarised in profiles/r02_pmc_hbm_traffic.json (written by
+    """roofline.traffic: HBM bytes per decode frame from the PMC passes summarised in profiles/rNN_pmc_hbm_traffic.json (written by
     tools/pmc_traffic.py from `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs; counters cannot be read inside this process).
     The summary names the command, the counter corrections and the commit it was taken at; null when no summary matches the path."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
-    if os.path.exists(path):
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")), reverse=True):  # the newest round's summary
         with open(path) as f:
             t = json.load(f)
         key = "persistent" if kernels_per_frame < 200 else "per_node"
         if key in t:
-            return {"traffic": t[key]["hbm_bytes_per_frame"], "traffic_source": f"offline: profiles/r02_pmc_hbm_traffic.json[{key}] ({t[key].get('command', '')}; commit {t.get('commit', '?')})"}
+            return {"traffic": t[key]["hbm_bytes_per_frame"],
+                    "traffic_source": f"offline: profiles/{os.path.basename(path)}[{key}] ({t[key].get('command', '')}; commit {t.get('commit', '?')})"}
     return {"traffic": None, "traffic_source": "no PMC summary for this path under profiles/ (tools/pmc_traffic.sh)"}
 
 

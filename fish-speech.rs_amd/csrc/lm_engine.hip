@@ -409,8 +409,20 @@ class LM final : public LMBase {
         LmKernels<WT>::embed(d_, tok_emb_, cb_emb_, C, a_.codebook_size, d_cfg_.as<SampleCfg>(), d_prompt_.as<uint32_t>(), state(0),
                              x(0), st_);
         // frame `it` runs at KV length T = n_cached + L + it: pick the graph captured for that attention chunk bucket
+        // FS_GEN_TIME_KERNELS: the frame's two persistent launches one by one, a HIP event in front of / between / behind them
+        const bool time_k = (flags & FS_GEN_TIME_KERNELS) && use_persist_ && use_pslow_ && fold_slow_sampler();
+        std::vector<hipEvent_t> kev;
         auto launch_frame = [&](long long it_) {
             set_bucket(n_cached + L + (int)it_);
+            if (time_k && it_ >= 1) {
+                for (int i = 0; i < 3; ++i) { hipEvent_t e; FS_HIP(hipEventCreate(&e)); kev.push_back(e); }
+                FS_HIP(hipEventRecord(kev[kev.size() - 3], st_));
+                launch_slow_persist(pslow_args(), st_);
+                FS_HIP(hipEventRecord(kev[kev.size() - 2], st_));
+                launch_fast_persist(persist_args(), persist_sampled_, st_);
+                FS_HIP(hipEventRecord(kev[kev.size() - 1], st_));
+                return;
+            }
             use_graphs_for_bucket();
             FS_HIP(hipGraphLaunch(g_frame_, st_));
         };
@@ -485,6 +497,18 @@ class LM final : public LMBase {
         FS_HIP(hipEventElapsedTime(&ms01, ev_[0], ev_[1]));
         FS_HIP(hipEventElapsedTime(&ms12, ev_[1], ev_[2]));
         stats_.prefill_ms = ms01; stats_.decode_ms = ms12; stats_.frames = n; stats_.prompt_tokens = (uint64_t)L;
+        if (!kev.empty()) {
+            double ts = 0, tf = 0;
+            for (size_t i = 0; i < kev.size(); i += 3) {
+                float a = 0, b = 0;
+                FS_HIP(hipEventElapsedTime(&a, kev[i], kev[i + 1]));
+                FS_HIP(hipEventElapsedTime(&b, kev[i + 1], kev[i + 2]));
+                ts += a; tf += b;
+            }
+            stats_.slow_kernel_us = ts * 1e3 / (double)(kev.size() / 3);
+            stats_.fast_kernel_us = tf * 1e3 / (double)(kev.size() / 3);
+            for (hipEvent_t e : kev) (void)hipEventDestroy(e);
+        }
         if (use_persist_ && getenv("FISHRT_PERSIST_PROF")) {
             unsigned long long pr[16];
             FS_HIP(hipMemcpy(pr, d_ctl_.as<uint32_t>() + 16, sizeof(pr), hipMemcpyDeviceToHost));

@@ -25,7 +25,8 @@ class Sampling(C.Structure):  # fs_sampling  <->  SamplingArgs (sampling/mod.rs:
 
 class GenStats(C.Structure):
     _fields_ = [("prefill_ms", C.c_double), ("decode_ms", C.c_double), ("frames", C.c_uint64),
-                ("prompt_tokens", C.c_uint64), ("graph_launches", C.c_uint64), ("kernels_per_frame", C.c_uint64)]
+                ("prompt_tokens", C.c_uint64), ("graph_launches", C.c_uint64), ("kernels_per_frame", C.c_uint64),
+                ("slow_kernel_us", C.c_double), ("fast_kernel_us", C.c_double)]
 
 
 FRAME_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32))

@@ -95,9 +95,10 @@ class DualARTransformer:
 
     # ---- generation drivers
     def generate_blocking(self, prompt, max_new_tokens, temp=0.7, top_p=0.9, top_k=50, repetition_penalty=1.2, seed=0,
-                          ignore_eos=False, on_frame=None, persistent=True):
+                          ignore_eos=False, on_frame=None, persistent=True, time_kernels=False):
         """generate/single_batch.rs:308-324.  prompt u32 (C+1, L) -> codes u32 (C, n_frames).
-        persistent=False sets FS_GEN_NO_PERSIST (fast decoder on the per-node graph path; see include/fishrt.h)."""
+        persistent=False sets FS_GEN_NO_PERSIST (per-node graph path; see include/fishrt.h); time_kernels=True sets FS_GEN_TIME_KERNELS
+        (measurement mode: HIP events around each persistent kernel, last_stats()["slow_kernel_us" / "fast_kernel_us"])."""
         prompt = _u32(prompt)
         Cb = self.cfg["num_codebooks"]
         if prompt.ndim != 2 or prompt.shape[0] != Cb + 1:
@@ -110,7 +111,7 @@ class DualARTransformer:
         cb = _ffi.FRAME_CB(lambda user, idx, codes: int(bool(on_frame(idx, [codes[i] for i in range(Cb)])))) if on_frame \
             else C.cast(None, _ffi.FRAME_CB)
         _ffi.check(_ffi.lib().fs_lm_generate(self._h, prompt.ctypes.data_as(C.POINTER(C.c_uint32)), L, int(max_new_tokens),
-                                             C.byref(s), C.c_uint64(seed), (1 if ignore_eos else 0) | (0 if persistent else 2),
+                                             C.byref(s), C.c_uint64(seed), (1 if ignore_eos else 0) | (0 if persistent else 2) | (4 if time_kernels else 0),
                                              out.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_size_t(cap), C.byref(n), cb, None))
         return out[:, : n.value].copy()
 

@@ -133,12 +133,17 @@ int fs_lm_curr_kv_size(fs_lm_t* lm);                       /* dual_ar.rs:695-700
  *     rescale_semantic_tokens, generate/utils.rs:13-16,45-46); the gather branch for a non-adjacent <|im_end|> (:17-30,47-51) is
  *     rejected with an error.
  * flags: FS_GEN_IGNORE_EOS masks <|im_end|> (bench-only, fixed-length runs: SURVEY.md §8d).
- *        FS_GEN_NO_PERSIST keeps the fast decoder on the per-node graph path.  By default a greedy call (temp == 0) on a bf16 handle
- *        with the Fish geometry runs the 8 codebook passes of every frame as ONE persistent launch (csrc/lm_persist.hip: weights
- *        resident in VGPRs / LDS, in-launch hand-offs); that launch needs all 256 CUs of the device, so only one generate call per
- *        GPU uses it at a time (a concurrent call on another handle silently takes the per-node path). */
+ *        FS_GEN_NO_PERSIST keeps the whole frame on the per-node graph path.  By default a call on a bf16 handle with the Fish geometry
+ *        runs a frame as TWO persistent launches (csrc/lm_persist_slow.hip: the 24 slow blocks + head; csrc/lm_persist.hip: the slow-token
+ *        decision, the 8 codebook passes with weights resident in VGPRs / LDS and their 8 decisions -- greedy, or top-k / top-p sampled
+ *        in-launch when 0 < top_k <= 256 -- with in-launch hand-offs); those launches need all 256 CUs of the device, so only one
+ *        generate call per GPU uses them at a time (a concurrent call on another handle silently takes the per-node path). */
 #define FS_GEN_IGNORE_EOS 1u
 #define FS_GEN_NO_PERSIST 2u
+/* measurement mode (bench.py `roofline.kernels`): the two persistent kernels of every decode frame are launched one by one with a HIP event
+ * in front of, between and behind them instead of as one graph replay; same kernels, same arguments, same tokens -- only the host paces the
+ * frames, so decode_ms of such a call is not a throughput figure.  Ignored when the call does not take both persistent kernels. */
+#define FS_GEN_TIME_KERNELS 4u
 int fs_lm_generate(fs_lm_t* lm, const uint32_t* prompt, int L, int max_new_tokens, const fs_sampling* sampling,
                    uint64_t seed, uint32_t flags, uint32_t* codes_out, size_t cap, size_t* n_frames, fs_frame_cb cb,
                    void* cb_user);
@@ -200,7 +205,10 @@ typedef struct fs_gen_stats {
     double prefill_ms, decode_ms;     /* decode_ms covers frames 1..n-1 exactly like `start_decode` (:261) */
     uint64_t frames, prompt_tokens, graph_launches;
     uint64_t kernels_per_frame;       /* kernel launches per decode frame of this call: 266 on the per-node path (FS_GEN_NO_PERSIST), 146 with the
-                                         persistent slow kernel only (sampled requests), 3 with both persistent kernels (greedy requests) */
+                                         persistent slow kernel only (sampler settings outside the in-launch sampler), 2 with both persistent
+                                         kernels (greedy, and temp > 0 with 0 < top_k <= 256) */
+    double slow_kernel_us, fast_kernel_us;  /* FS_GEN_TIME_KERNELS: average duration of k_slow_persist / k_fast_persist over the decode frames
+                                               of this call (HIP events around every launch on the handle's stream); 0 otherwise */
 } fs_gen_stats;
 int fs_lm_last_stats(fs_lm_t* lm, fs_gen_stats* out);
 /* the hipStream_t the handle launches on (for callers that bracket calls with their own HIP events) */

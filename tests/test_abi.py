@@ -32,7 +32,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_ffi.ModelArgs) == 14 * 4
     assert ctypes.sizeof(_ffi.TokenCfg) == 5 * 4
     assert ctypes.sizeof(_ffi.Sampling) == 32
-    assert ctypes.sizeof(_ffi.GenStats) == 48
+    assert ctypes.sizeof(_ffi.GenStats) == 64
 
 
 def test_product_never_imports_oracle():

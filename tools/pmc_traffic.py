@@ -21,7 +21,8 @@ def load(d, name):
 
 res = {}
 try:
-    res["commit"] = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], cwd=sys.path[0]).decode().strip()
+    import os
+    res["commit"] = os.environ.get("FISHRT_COMMIT") or subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], cwd=sys.path[0]).decode().strip()
 except Exception:
     res["commit"] = "unknown"
 for mode in ("persistent", "per_node"):

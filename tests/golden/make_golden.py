@@ -479,6 +479,61 @@ def make_codec_golden():
 
 
 
+# ----------------------------------------------------------------------------- production-shape fixtures ("full-size single layer")
+# One Fish-1.5 BLOCK: dim 1024, 16 query / 2 kv heads x 64, SwiGLU 4096 -- the geometry every production kernel is specialised for (head_dim
+# 64 RoPE, GQA 16:2, K = 1024 / 4096 GEMVs) -- as a one-slow-layer / one-fast-layer model with a small vocabulary (the embedding / head tables
+# would be 400 MB each at 102k tokens and pin nothing new).  Cached lengths 1, 130 and 600: one token, just past one 128-token attention chunk /
+# two KV pages, several chunks.  Per length: prefill (causal mask) logits + hidden of the last position, one decode step on top (L == 1, no
+# mask), and four fast-decoder passes (positions 0..3) fed with hidden state / fast embeddings.
+B15 = dict(dim=1024, n_layer=1, n_fast_layer=1, n_head=16, n_local_heads=2, head_dim=64, intermediate_size=4096, num_codebooks=8,
+           codebook_size=1024, vocab_size=4096, max_seq_len=1024, norm_eps=1e-6, rope_base=1e6,
+           im_end_id=2000, pad_id=5, semantic_start_id=2001, semantic_end_id=3024, has_semantic_end=1)
+
+
+def make_block15_golden():
+    cfg, seed = B15, 0xF15E5EED
+    import json
+    out = dict(seed=np.uint64(seed), cfg_json=np.frombuffer(json.dumps(cfg).encode(), np.uint8))
+    rng = np.random.RandomState(15)
+    Tmax = 600
+    prompt = np.zeros((9, Tmax + 1), np.int64)
+    prompt[0] = rng.randint(0, cfg["im_end_id"], Tmax + 1)
+    vq = rng.rand(Tmax + 1) < 0.5  # half of the positions are VQ frames: semantic token + 8 codebook rows
+    prompt[0, vq] = cfg["semantic_start_id"] + rng.randint(0, 1024, int(vq.sum()))
+    prompt[1:, vq] = rng.randint(0, 1024, (8, int(vq.sum())))
+    out["prompt"] = prompt.astype(np.uint32)
+    for tag, bf16 in (("f32", False), ("bf16w", True)):
+        lm = TorchLM(cfg, seed, bf16=bf16)
+        for T in (1, 130, 600):
+            lm.clear_slow()
+            lg, hd, _ = lm.forward_generate(torch.from_numpy(prompt[:, :T]).unsqueeze(0), 0)
+            lg2, hd2, _ = lm.forward_generate(torch.from_numpy(prompt[:, T:T + 1]).unsqueeze(0), T)
+            out[f"{tag}_T{T}_prefill_logits"], out[f"{tag}_T{T}_prefill_hidden"] = lg.numpy()[0], hd.numpy()[0]
+            out[f"{tag}_T{T}_decode_logits"], out[f"{tag}_T{T}_decode_hidden"] = lg2.numpy()[0], hd2.numpy()[0]
+            lm.clear_fast()
+            x, fl = hd2, []
+            for pos in range(4):
+                f = lm.forward_generate_fast(x, pos)
+                fl.append(f.numpy()[0])
+                x = lm.fast_embeddings[int(prompt[1 + pos, T])].view(1, -1)  # a fixed code sequence, not the argmax: no tie sensitivity
+            out[f"{tag}_T{T}_fast_logits"] = np.stack(fl)
+            print(f"  block15 {tag} T={T}: |logits| {float(lg2.abs().max()):.3f}, |hidden| {float(hd2.abs().max()):.3f}, fast |logits| {np.abs(fl[-1]).max():.3f}")
+    np.savez_compressed(os.path.join(HERE, "lm_block15.npz"), **out)
+
+
+def make_codec_full_golden():
+    """The vocoder at its REAL width (512 -> 256 -> ... -> 16 channels, every HiFi-GAN stage full size) on 4 frames: 8192 PCM samples."""
+    seed = 0xC0DEC
+    rng = np.random.RandomState(9)
+    codes = rng.randint(0, 1000, (8, 4)).astype(np.uint32)
+    pcm, stages = torch_codec_decode(codes, seed, 512)
+    out = dict(codes=codes, seed=np.uint64(seed), pcm=pcm.numpy())
+    for i in (0, len(stages) // 2, len(stages) - 1):  # a few stage outputs (first, middle, last before conv_post), 64-sample tails
+        out[f"stage{i}_tail"] = stages[i][:, -64:].numpy()
+    print("  codec full width: pcm", tuple(pcm.shape), "rms", float(pcm.pow(2).mean().sqrt()))
+    np.savez_compressed(os.path.join(HERE, "codec_full.npz"), **out)
+
+
 # ----------------------------------------------------------------------------- Firefly encoder (tiny: dims / 8, depths 1,1,2,1)
 REF_MEL = "/root/reference/fish_speech_core/lib/audio/melfilters160.bytes"
 
@@ -611,7 +666,7 @@ def make_known_answers():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["known", "lm", "codec", "enc"]
+    which = sys.argv[1:] or ["known", "lm", "codec", "enc", "block15", "codecfull"]
     if "known" in which:
         make_known_answers()
     if "lm" in which:
@@ -620,4 +675,8 @@ if __name__ == "__main__":
         make_codec_golden()
     if "enc" in which:
         make_codec_enc_golden()  # needs /root/reference (mel table): build container only
+    if "block15" in which:
+        make_block15_golden()
+    if "codecfull" in which:
+        make_codec_full_golden()
     print("wrote", sorted(f for f in os.listdir(HERE) if f.endswith(".npz")))

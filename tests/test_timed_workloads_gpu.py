@@ -1,0 +1,115 @@
+"""GPU: the workloads bench.py times, checked for CORRECTNESS at full size (bench.py itself only checks determinism):
+ (a) BASELINE.json configs[1] in full -- the 367-position default-voice prompt, 256 frames, the two persistent launches per frame: the
+     logits of every one of the 256 x 9 decisions (fs_lm_debug_capture) against the CPU oracle teacher-forced on the GPU's own tokens,
+     bf16 protocol (bf16-rounded weights, bf16 K/V), and every recorded pick == the rule applied to the recorded logits;
+ (b) configs[2] shapes: Fish-1.5 generate_static_batch with 32 rows, greedy, against the oracle's static-batch restatement -- a row may
+     leave the oracle's stream only on a near-tie the oracle reports;
+ (c) the full-size vocoder on 64 frames against the oracle, both precision modes."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import bench
+import fishrt
+from fishrt import config as fcfg
+from oracle import oracle as orc
+from test_lm_gpu import _rows_leave_oracle_only_at_near_ties
+from test_persist_gpu import _RepPen
+
+SEED = 0xF15E5EED
+TOK = fcfg.FISH_1_5_TOKENS
+IM_END = TOK["im_end_id"]
+N_AUDIO = fcfg.FISH_1_5["vocab_size"] - IM_END
+BF16_TOL = 1e-2  # DESIGN.md parity protocol: bf16 K/V rounding-boundary flips feed back through 24 layers (measured ~7e-3 at logit scale 3)
+
+
+def _argmax_last(v):
+    return int(np.nonzero(v == v.max())[0][-1])
+
+
+def test_config1_full_workload_every_decision_vs_teacher_forced_oracle():
+    F, rp = 256, 1.2
+    p = bench.default_voice_prompt(TOK)
+    L = p.shape[1]
+    assert L == 367
+    lm = fishrt.DualARTransformer(fcfg.FISH_1_5, TOK, 0, "bf16").load_synthetic(SEED)
+    lm.debug_capture(F)
+    codes = lm.generate_blocking(p, F + L - 2, temp=0.0, top_p=1.0, top_k=0, repetition_penalty=rp, ignore_eos=True)
+    assert codes.shape == (8, F) and lm.last_stats()["kernels_per_frame"] == 2
+    cap = lm.debug_read(F)
+    lm.close()
+    slow_tok = cap[:, 0, 2047].astype(np.int64) + IM_END
+    assert np.array_equal(cap[:, 1:, 1024].astype(np.int64).T, codes.astype(np.int64))
+    # the recorded picks are the greedy rule (LAST maximal index) on the recorded logits
+    for f in range(F):
+        assert _argmax_last(cap[f, 0, :N_AUDIO]) + IM_END == slow_tok[f]
+        for c in range(8):
+            assert _argmax_last(cap[f, 1 + c, :1024]) == codes[c, f], (f, c)
+    # teacher-forced oracle on the GPU's tokens (bf16 protocol)
+    o = orc.OracleLM(orc.FISH15).load_synthetic(SEED, bf16=True)
+    o.set_kv_round_bf16(True)
+    rps = [_RepPen(1024, rp) for _ in range(8)]
+    femb = o.fast_embeddings()
+    cur, pos, prev = p, 0, None
+    worst_slow = worst_fast = 0.0
+    for f in range(F):
+        lg, hd = o.forward_generate(cur, pos, full_head=False)
+        s = lg[0, IM_END:].copy()
+        s[0] = -np.inf  # ignore_eos
+        d = np.abs(s[1:] - cap[f, 0, 1:N_AUDIO]).max()
+        worst_slow = max(worst_slow, float(d))
+        assert d < BF16_TOL, ("slow logits", f, d)
+        o.clear_fast()
+        x = hd[0]
+        for c in range(8):
+            fg = o.forward_generate_fast(x, c)[0]
+            if prev is not None:
+                fg = rps[c].apply(fg, int(prev[c + 1]))
+            d = np.abs(fg - cap[f, 1 + c, :1024]).max()
+            worst_fast = max(worst_fast, float(d))
+            assert d < BF16_TOL, ("fast logits", f, c, d)
+            x = femb[int(codes[c, f])]
+        frame = np.array([slow_tok[f]] + [int(v) for v in codes[:, f]], np.uint32)
+        pos += cur.shape[1]
+        prev, cur = frame, frame.reshape(9, 1)
+    print(f"configs[1] (367-position prompt, {F} frames, KV to {pos}): max |dlogit| vs the teacher-forced oracle: slow {worst_slow:.2e}, fast {worst_fast:.2e} "
+          f"over {F * 9} decisions (tolerance {BF16_TOL:.0e})")
+
+
+def test_fish15_static_batch_32_rows_vs_oracle():
+    B, frames = 32, 8
+    rng = np.random.RandomState(77)
+    lens = [int(v) for v in rng.randint(8, 25, B)]
+    prompts = []
+    for i, Ln in enumerate(lens):
+        q = np.zeros((9, Ln), np.uint32)
+        q[0] = np.random.RandomState(500 + i).randint(0, IM_END, Ln)
+        prompts.append(q)
+    M = max(lens) + frames - 2
+    kw = dict(seed=42, temp=0.0, top_p=1.0, top_k=0, ignore_eos=True)
+    lm = fishrt.DualARTransformer(fcfg.FISH_1_5, TOK, 0, "bf16", max_batch=B).load_synthetic(SEED)
+    got = lm.generate_static_batch(prompts, M, **kw)
+    lm.close()
+    o = orc.OracleLM(orc.FISH15).load_synthetic(SEED, bf16=True)
+    o.set_kv_round_bf16(True)
+    exp = o.generate_batch(prompts, M, **kw)
+    assert [g.shape for g in got] == [e.shape for e in exp] == [(8, frames)] * B
+    flips = _rows_leave_oracle_only_at_near_ties(got, exp, o, "Fish-1.5 B=32")
+    print(f"Fish-1.5 static batch, {B} rows x {frames} frames: {B - flips} rows identical to the oracle, {flips} left it on a near-tie the oracle reports")
+
+
+def test_full_size_vocoder_64_frames_vs_oracle():
+    G = os.path.join(os.path.dirname(__file__), "golden")
+    voice = np.ascontiguousarray(np.load(os.path.join(G, "default_voice_codes.npy")).astype(np.uint32)[:, 100:164])  # 64 frames
+    ref = orc.OracleCodec(tiny=False).load_synthetic(0xC0DEC).decode(voice)
+    sig = float(np.sqrt(np.mean(ref.astype(np.float64) ** 2)))
+    for precision, tol in (("bf16x3", 1e-4), ("f32", 1e-5)):
+        c = fishrt.FireflyCodec(0, precision=precision).load_synthetic(0xC0DEC)
+        pcm = c.decode(voice[None])[0, 0]
+        c.close()
+        r = float(np.sqrt(np.mean((pcm.astype(np.float64) - ref) ** 2)))
+        print(f"full-size vocoder, 64 frames [{precision}]: PCM rms diff {r:.2e} at signal rms {sig:.3f}")
+        assert pcm.shape == ref.shape == (2048 * 64,) and r < tol and sig > 1e-3

@@ -1338,7 +1338,8 @@ class LM final : public LMBase {
     // ---- persistent fast decoder (lm_persist.hip): per-lane weight image, edge buffers, control words
     void pack_persist() {
         persist_ok_ = false;
-        if constexpr (std::is_same<WT, bf16_t>::value) {
+        if constexpr (std::is_same<WT, bf16_t>::value || std::is_same<WT, fp8_t>::value) {
+            constexpr bool FP8 = std::is_same<WT, fp8_t>::value;
             if (getenv("FISHRT_NO_PERSIST")) return;
             if (!fast_persist_supported(d_, a_.n_fast_layer, a_.num_codebooks, a_.codebook_size)) return;
             hipDeviceProp_t prop;
@@ -1350,16 +1351,18 @@ class LM final : public LMBase {
                 FS_HIP(hipMemset(d_edges_.p, 0, d_edges_.n));
                 d_ctl_.alloc(256);
                 FS_HIP(hipMemset(d_ctl_.p, 0, d_ctl_.n));
+                if (FP8) d_fscl_.alloc(sizeof(float) * (size_t)PF_BLOCKS * PF_SCL);
             }
-            launch_fast_persist_pack(fast_.data(), fast_out_w_, d_pack_.p, st_);
+            launch_fast_persist_pack(fast_.data(), fast_out_w_, d_pack_.p, st_, FP8, fast_out_s_, d_fscl_.as<float>());
             FS_HIP(hipStreamSynchronize(st_));
             persist_ok_ = true;
             // slow transformer: same geometry, the audio-range head must fit 8 rows per workgroup
             pslow_ok_ = false;
             if (getenv("FISHRT_NO_PERSIST_SLOW") || n_audio_ > 8 * PF_BLOCKS) return;
             if (!d_spack_.p) {
-                d_spack_.alloc(slow_persist_pack_bytes(a_.n_layer));
+                d_spack_.alloc(slow_persist_pack_bytes(a_.n_layer, FP8));
                 d_hpack_.alloc((size_t)PF_BLOCKS * PS_HEAD_IMAGE);
+                if (FP8) d_sscl_.alloc(sizeof(float) * slow_persist_scale_floats(a_.n_layer));
                 d_snorms_.alloc(sizeof(float) * (size_t)(2 * a_.n_layer + 1) * a_.dim);
                 d_sedges_.alloc(slow_persist_edge_bytes());
                 FS_HIP(hipMemset(d_sedges_.p, 0, d_sedges_.n));
@@ -1369,7 +1372,9 @@ class LM final : public LMBase {
             std::vector<const float*> np;
             for (int l = 0; l < a_.n_layer; ++l) { np.push_back(slow_[l].attn_norm); np.push_back(slow_[l].ffn_norm); }
             np.push_back(norm_w_);
-            launch_slow_persist_pack(slow_.data(), a_.n_layer, slow_head_w(), n_audio_, np.data(), d_spack_.p, d_hpack_.p, d_snorms_.as<float>(), st_);
+            if (FP8) launch_slow_persist_pack_fp8(slow_.data(), a_.n_layer, slow_head_w(), slow_head_s(), n_audio_, np.data(), d_spack_.p, d_hpack_.p,
+                                                  d_sscl_.as<float>(), d_snorms_.as<float>(), st_);
+            else launch_slow_persist_pack(slow_.data(), a_.n_layer, slow_head_w(), n_audio_, np.data(), d_spack_.p, d_hpack_.p, d_snorms_.as<float>(), st_);
             FS_HIP(hipStreamSynchronize(st_));
             pslow_ok_ = true;
         }
@@ -1377,6 +1382,8 @@ class LM final : public LMBase {
     SlowPersistArgs pslow_args() {
         SlowPersistArgs A = {};
         A.wpack = d_spack_.p; A.hpack = d_hpack_.p; A.norms = d_snorms_.as<float>();
+        A.scales = d_sscl_.p ? d_sscl_.as<float>() : nullptr;
+        A.hscales = d_sscl_.p ? d_sscl_.as<float>() + (size_t)a_.n_layer * PF_BLOCKS * 48 : nullptr;
         A.n_layer = a_.n_layer; A.n_head_rows = n_audio_;
         A.cos_t = d_cos_.as<float>(); A.sin_t = d_sin_.as<float>(); A.eps = d_.eps;
         A.x = x(0); A.logits = d_logits_slow_.as<float>(); A.state = state(0);
@@ -1393,6 +1400,7 @@ class LM final : public LMBase {
     FastPersistArgs persist_args() {
         FastPersistArgs A = {};
         A.wpack = d_pack_.p;
+        A.scales = d_fscl_.p ? d_fscl_.as<float>() : nullptr;
         for (int l = 0; l < PF_LAYERS; ++l) { A.norms[2 * l] = fast_[l].attn_norm; A.norms[2 * l + 1] = fast_[l].ffn_norm; }
         A.norms[2 * PF_LAYERS] = fast_norm_w_;
         A.fast_emb = fast_emb_; A.tok_emb = tok_emb_; A.cb_emb = cb_emb_;
@@ -1521,6 +1529,7 @@ class LM final : public LMBase {
     DevBuf d_x_, d_xf_, d_q_, d_part_, d_act_, d_logits_slow_, d_logits_fast_, d_state_, d_cfg_, d_rng_, d_prompt_, d_out_;
     DevBuf d_rp_mask_, d_rp_seen_, d_rp_ring_, d_rp_meta_;
     DevBuf d_pack_, d_edges_, d_ctl_;  // persistent fast decoder
+    DevBuf d_fscl_, d_sscl_;           // FS_FP8 handles: row scales of the persistent kernels' images
     DevBuf d_cap_;                     // fs_lm_debug_capture
     int cap_frames_ = 0;
     DevBuf d_hidden_, d_hid_slot_;     // generate_blocking_with_hidden: [out_cap][dim] rows + the pointer cell the captured graphs read

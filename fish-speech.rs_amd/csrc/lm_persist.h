@@ -27,9 +27,11 @@ constexpr int PF_REG_DW = PF_LAYERS * (5 + 4 + 32) + 4;  // weight dwords (bf16 
 constexpr int PF_REG_CHUNKS = PF_REG_DW / 4;              // 42 x 16 B
 constexpr int PF_LDS_CHUNKS = PF_LAYERS * 4;              // w2 of every layer lives in LDS: 16 x 16 B per lane
 constexpr int PF_CHUNKS = PF_REG_CHUNKS + PF_LDS_CHUNKS;  // 58 x 16 B x 512 lanes = 475 KB per workgroup
+constexpr int PF_SCL = 200;                               // FS_FP8 handles: row scales per workgroup (4 layers x 48 + 4 head rows, padded)
 
 struct FastPersistArgs {
     const void* wpack;          // [PF_BLOCKS][PF_CHUNKS][PF_THREADS] x 16 B: per-lane weight image (launch_fast_persist_pack)
+    const float* scales;        // null, or [PF_BLOCKS][PF_SCL]: FS_FP8 handle -- the image holds the e4m3 weights widened to bf16, these are their row scales
     const float* norms[2 * PF_LAYERS + 1];  // attention_norm l, ffn_norm l (l = 0..3), fast_norm: f32 [1024]
     const void* fast_emb;       // bf16 [1024][1024]
     const void* tok_emb;        // bf16 [V][1024]
@@ -59,10 +61,14 @@ struct FastPersistArgs {
 constexpr int PS_EDGE_CAP = 16 * 16 * 66 + 64;  // largest edge: attention partials of 16 heads x 16 token slices x {o[64], m, l}
 constexpr size_t PS_LAYER_IMAGE = 116736;        // bytes per (layer, workgroup): Wqkv 5 rows, Wo 4, W13 32, W2 4 rows x 4096
 constexpr size_t PS_HEAD_IMAGE = 16384;          // bytes per workgroup: 8 head rows
+constexpr size_t PS_LAYER_IMAGE_FP8 = 59392;     // FS_FP8 handles: one e4m3 byte per weight (layout: lm_persist_slow.hip)
+constexpr size_t PS_HEAD_IMAGE_FP8 = 8192;
 
 struct SlowPersistArgs {
     const void* wpack;      // [n_layer][PF_BLOCKS][PS_LAYER_IMAGE] per-lane weight images (launch_slow_persist_pack)
     const void* hpack;      // [PF_BLOCKS][PS_HEAD_IMAGE] head rows [8b, 8b+8) (zero beyond n_head_rows)
+    const float* scales;    // FS_FP8 images: per-row f32 scales [n_layer][PF_BLOCKS][48] (null: bf16 images)
+    const float* hscales;   // FS_FP8: head row scales [PF_BLOCKS][8]
     const float* norms;     // [2 * n_layer + 1][1024] f32: attention_norm l, ffn_norm l, ..., norm
     int n_layer, n_head_rows;
     const float* cos_t;     // [max_seq_len][32]
@@ -79,7 +85,10 @@ struct SlowPersistArgs {
     unsigned long long* prof;
     uint32_t* ctl;          // [0] epoch, [1] timeouts
 };
-size_t slow_persist_pack_bytes(int n_layer);
+size_t slow_persist_pack_bytes(int n_layer, bool fp8 = false);
+size_t slow_persist_scale_floats(int n_layer);
+void launch_slow_persist_pack_fp8(const LayerW* layers, int n_layer, const void* head_w, const float* head_s, int n_head_rows,
+                                  const float* const* norm_ptrs, void* wpack, void* hpack, float* scales, float* norms_flat, hipStream_t st);
 size_t slow_persist_edge_bytes();
 void launch_slow_persist_pack(const LayerW* layers, int n_layer, const void* head_w, int n_head_rows, const float* const* norm_ptrs,
                               void* wpack, void* hpack, float* norms_flat, hipStream_t st);
@@ -90,7 +99,8 @@ bool fast_persist_supported(const ModelDims& d, int n_fast_layer, int n_cb, int 
 size_t fast_persist_pack_bytes();
 size_t fast_persist_edge_bytes();
 // re-lays the four fast blocks' matrices + fast_output into the per-lane image (device to device, once per weight load)
-void launch_fast_persist_pack(const LayerW* fast, const void* head_w, void* pack, hipStream_t st);
+void launch_fast_persist_pack(const LayerW* fast, const void* head_w, void* pack, hipStream_t st, bool fp8 = false, const float* head_s = nullptr,
+                              float* scales = nullptr);
 void launch_fast_persist(const FastPersistArgs& a, bool sampled, hipStream_t st);
 // true when the in-launch sampler covers this configuration (0 < top_k <= 256 candidates kept, sampling/mod.rs:51-132); temp == 0 is the greedy kernel
 bool fast_persist_samples(float temp, int top_k, int cb_size);

@@ -51,7 +51,8 @@ constexpr int L_AMAX = L_SC + 16 * 8 * 4;                  // [2][8 waves] {valu
 constexpr int L_ROPE = L_AMAX + 2 * 8 * 8;                 // cos [8][32], sin [8][32]
 constexpr int L_RING = L_ROPE + 2 * 8 * 32 * 4;            // rep-pen ring [8][17], meta [8][2], prev [16], misc [16]
 constexpr int L_WORDS = L_RING + (8 * 17 + 8 * 2 + 16 + 16) * 4;  // StdRng output words of this frame's draws [8] (sampled requests)
-constexpr int L_END = L_WORDS + 16 * 4;
+constexpr int L_SCL = L_WORDS + 16 * 4;  // FS_FP8 handles: this workgroup's row scales [PF_SCL]
+constexpr int L_END = L_SCL + PF_SCL * 4;
 static_assert(L_END <= 160 * 1024, "LDS budget");
 // the sampler's scratch (lm_bsample_dev.h) aliases q / residual copy / row partials / scores / argmax slots: all dead during a decision
 static_assert(L_QS % 16 == 0 && L_QS + (int)sizeof(BSampLds) <= L_ROPE, "sampler scratch must fit the stage scratch it aliases");
@@ -62,33 +63,61 @@ static_assert(L_QS % 16 == 0 && L_QS + (int)sizeof(BSampLds) <= L_ROPE, "sampler
 // chunk c < 42: dwords 4c .. 4c+3 of the lane's register image; dword d: layer l = d / 41, i = d % 41:
 //   i < 5: Wqkv row 5b + i;  i < 9: Wo row 4b + i - 5;  else W13 (interleaved) row 32b + i - 9;   d >= 164: fast_output row 4b + d - 164
 // each dword = elements (2t, 2t+1) of that row.  chunk 42 + 4l + q: {W2_l row 4b + r, elements (1024q + 2t, +1)}, r = 0..3
-__global__ __launch_bounds__(PF_THREADS) void k_pf_pack(LayerW w0, LayerW w1, LayerW w2, LayerW w3, const uint32_t* __restrict__ head,
+// FP8: the weights are e4m3 bytes; the image holds them widened to bf16 (exact: e4m3 is a subset of bf16), so the frame kernel is the same
+// and the per-row f32 scales multiply the K-summed row results in its publishing lanes (k_pf_pack_scales).
+template <bool FP8>
+__global__ __launch_bounds__(PF_THREADS) void k_pf_pack(LayerW w0, LayerW w1, LayerW w2, LayerW w3, const void* __restrict__ head,
                                                         u32x4* __restrict__ pack) {
     const int b = blockIdx.x, c = blockIdx.y, t = threadIdx.x;
     const LayerW* ws[4] = {&w0, &w1, &w2, &w3};
+    auto pair = [](const void* W, size_t idx) -> uint32_t {  // elements (2 idx, 2 idx + 1) of the flattened matrix as a bf16 pair
+        if constexpr (FP8) {
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            const f2 f = __builtin_amdgcn_cvt_pk_f32_fp8((uint32_t)reinterpret_cast<const uint16_t*>(W)[idx], false);
+            return (__float_as_uint(f.x) >> 16) | (__float_as_uint(f.y) & 0xFFFF0000u);
+        } else {
+            return reinterpret_cast<const uint32_t*>(W)[idx];
+        }
+    };
     u32x4 out;
     if (c < PF_REG_CHUNKS) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int d = 4 * c + k;
             uint32_t v;
-            if (d >= PF_LAYERS * 41) v = head[(size_t)(4 * b + d - PF_LAYERS * 41) * 512 + t];
+            if (d >= PF_LAYERS * 41) v = pair(head, (size_t)(4 * b + d - PF_LAYERS * 41) * 512 + t);
             else {
                 const LayerW& w = *ws[d / 41];
                 const int i = d % 41;
-                if (i < 5) v = reinterpret_cast<const uint32_t*>(w.wqkv)[(size_t)(5 * b + i) * 512 + t];
-                else if (i < 9) v = reinterpret_cast<const uint32_t*>(w.wo)[(size_t)(4 * b + i - 5) * 512 + t];
-                else v = reinterpret_cast<const uint32_t*>(w.w13)[(size_t)(32 * b + i - 9) * 512 + t];
+                if (i < 5) v = pair(w.wqkv, (size_t)(5 * b + i) * 512 + t);
+                else if (i < 9) v = pair(w.wo, (size_t)(4 * b + i - 5) * 512 + t);
+                else v = pair(w.w13, (size_t)(32 * b + i - 9) * 512 + t);
             }
             out[k] = v;
         }
     } else {
         const int l = (c - PF_REG_CHUNKS) / 4, q = (c - PF_REG_CHUNKS) % 4;
-        const uint32_t* W2 = reinterpret_cast<const uint32_t*>(ws[l]->w2);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) out[r] = W2[(size_t)(4 * b + r) * 2048 + 512 * q + t];
+        for (int r = 0; r < 4; ++r) out[r] = pair(ws[l]->w2, (size_t)(4 * b + r) * 2048 + 512 * q + t);
     }
     pack[((size_t)b * PF_CHUNKS + c) * PF_THREADS + t] = out;
+}
+// row scales of an FS_FP8 handle, per workgroup: layer l at [48 l]: Wqkv 5 at +0, Wo 4 at +8, W13 32 at +12, W2 4 at +44; fast_output 4 at [192]
+__global__ void k_pf_pack_scales(LayerW w0, LayerW w1, LayerW w2, LayerW w3, const float* __restrict__ head_s, float* __restrict__ out) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    const LayerW* ws[4] = {&w0, &w1, &w2, &w3};
+    if (t >= PF_SCL) return;
+    float sc = 0.f;
+    if (t >= 192) { if (t < 196) sc = head_s[4 * b + t - 192]; }
+    else {
+        const LayerW& w = *ws[t / 48];
+        const int i = t % 48;
+        if (i < 5) sc = w.s_qkv[5 * b + i];
+        else if (i >= 8 && i < 12) sc = w.s_o[4 * b + i - 8];
+        else if (i >= 12 && i < 44) sc = w.s_13[32 * b + i - 12];
+        else if (i >= 44) sc = w.s_2[4 * b + i - 44];
+    }
+    out[(size_t)b * PF_SCL + t] = sc;
 }
 
 // ------------------------------------------------------------------------------------------------ the frame kernel
@@ -114,6 +143,8 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
     uint32_t* s_prev = reinterpret_cast<uint32_t*>(s_meta + 8 * 2);
     uint32_t* s_misc = s_prev + 16;  // [0] cur0, [1] have_prev, [2] done, [3] epoch, [4..11] codes of this frame
     uint32_t* s_words = reinterpret_cast<uint32_t*>(smem + L_WORDS);
+    float* s_scl = reinterpret_cast<float*>(smem + L_SCL);
+    const bool fp8 = A.scales != nullptr;  // FS_FP8 handle: bf16-widened e4m3 image + row scales (wave-uniform)
     BSampLds& samp = *reinterpret_cast<BSampLds*>(smem + L_QS);
 
     const int tid_k = threadIdx.x, b = blockIdx.x;
@@ -131,6 +162,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
     else if (tid == 201) s_misc[1] = (uint32_t)A.state->have_prev;
     else if (tid == 202) s_misc[2] = (uint32_t)A.state->done;
     else if (tid == 203) s_misc[3] = A.ctl[0];
+    if (fp8 && tid < PF_SCL) s_scl[tid] = A.scales[(size_t)b * PF_SCL + tid];
     if (tid >= 256) {  // RoPE rows 0..7
         const int i = tid - 256;
         rope_c[i] = A.cos_t[i];
@@ -285,6 +317,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
                         float t = red[(par * 8) * PF_RED + r], tot = red[(par * 8) * PF_RED + 5];
 #pragma unroll
                         for (int w = 1; w < 8; ++w) { t += red[(par * 8 + w) * PF_RED + r]; tot += red[(par * 8 + w) * PF_RED + 5]; }
+                        if (fp8) t *= s_scl[48 * l + r];
                         pf_publish(edges, e, rr, 5 * b + r, tag0 + e + 1, t / sqrtf(tot / 1024.f + A.eps));
                     }
                     par ^= 1;
@@ -363,6 +396,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
                         float t = red[(par * 8) * PF_RED + r];
 #pragma unroll
                         for (int w = 1; w < 8; ++w) t += red[(par * 8 + w) * PF_RED + r];
+                        if (fp8) t *= s_scl[48 * l + 8 + r];
                         pf_publish(edges, e, rr, 4 * b + r, tag0 + e + 1, xres + t);
                     }
                     par ^= 1;
@@ -399,6 +433,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
                             tot += red[(par * 8 + w) * PF_RED + 32];
                         }
                         const float dn = sqrtf(tot / 1024.f + A.eps);
+                        if (fp8) { ga *= s_scl[48 * l + 12 + 2 * jj]; gb *= s_scl[48 * l + 12 + 2 * jj + 1]; }
                         ga /= dn; gb /= dn;
                         pf_publish(edges, e, rr, 16 * b + jj, tag0 + e + 1, (ga / (1.f + __expf(-ga))) * gb);  // candle silu = x / (1 + exp(-x))
                     }
@@ -432,6 +467,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
                         float t = red[(par * 8) * PF_RED + r];
 #pragma unroll
                         for (int w = 1; w < 8; ++w) t += red[(par * 8 + w) * PF_RED + r];
+                        if (fp8) t *= s_scl[48 * l + 44 + r];
                         pf_publish(edges, e, rr, 4 * b + r, tag0 + e + 1, xres + t);
                     }
                     par ^= 1;
@@ -461,6 +497,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
                     float t = red[(par * 8) * PF_RED + r], tot = red[(par * 8) * PF_RED + 4];
 #pragma unroll
                     for (int w = 1; w < 8; ++w) { t += red[(par * 8 + w) * PF_RED + r]; tot += red[(par * 8 + w) * PF_RED + 4]; }
+                    if (fp8) t *= s_scl[192 + r];
                     pf_publish(edges, e, rr, 4 * b + r, tag0 + e + 1, t / sqrtf(tot / 1024.f + A.eps));
                 }
                 par ^= 1;
@@ -629,9 +666,15 @@ bool fast_persist_supported(const ModelDims& d, int n_fast_layer, int n_cb, int 
 size_t fast_persist_pack_bytes() { return (size_t)PF_BLOCKS * PF_CHUNKS * PF_THREADS * 16; }
 size_t fast_persist_edge_bytes() { return (size_t)PF_RING * PF_REPL * PF_EDGE_CAP * 8; }
 
-void launch_fast_persist_pack(const LayerW* fast, const void* head_w, void* pack, hipStream_t st) {
-    hipLaunchKernelGGL(k_pf_pack, dim3(PF_BLOCKS, PF_CHUNKS), dim3(PF_THREADS), 0, st, fast[0], fast[1], fast[2], fast[3],
-                       reinterpret_cast<const uint32_t*>(head_w), reinterpret_cast<u32x4*>(pack));
+void launch_fast_persist_pack(const LayerW* fast, const void* head_w, void* pack, hipStream_t st, bool fp8, const float* head_s, float* scales) {
+    if (fp8) {
+        hipLaunchKernelGGL(k_pf_pack<true>, dim3(PF_BLOCKS, PF_CHUNKS), dim3(PF_THREADS), 0, st, fast[0], fast[1], fast[2], fast[3], head_w,
+                           reinterpret_cast<u32x4*>(pack));
+        hipLaunchKernelGGL(k_pf_pack_scales, dim3(PF_BLOCKS), dim3(256), 0, st, fast[0], fast[1], fast[2], fast[3], head_s, scales);
+    } else {
+        hipLaunchKernelGGL(k_pf_pack<false>, dim3(PF_BLOCKS, PF_CHUNKS), dim3(PF_THREADS), 0, st, fast[0], fast[1], fast[2], fast[3], head_w,
+                           reinterpret_cast<u32x4*>(pack));
+    }
     FS_HIP(hipGetLastError());
 }
 

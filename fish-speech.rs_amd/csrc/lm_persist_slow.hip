@@ -39,6 +39,22 @@ constexpr int PS_DROR8 = 0x128;  // DPP row_ror:8 -- lane l <- lane l ^ 8 inside
 // byte offsets inside a (layer, workgroup) weight image; every region is [chunk][512 lanes] x 16 B (B: x 4 B)
 constexpr size_t IM_QKV4 = 0, IM_QKV1 = 8192, IM_WO = 10240, IM_W13 = 18432, IM_W2 = 83968;
 static_assert(IM_W2 + 4 * 8192 == PS_LAYER_IMAGE, "image layout");
+// FS_FP8 images: one e4m3 byte per weight, so a lane's (2 t, 2 t + 1) pair of a row is 16 bits and a dword holds the pairs of TWO rows
+// (low half: the even row).  Regions: Wqkv rows 0..3 [512] x 8 B, row 4 [512] x 4 B, Wo [512] x 8 B, W13 [4][512] x 16 B (chunk c = rows
+// 8 c .. 8 c + 7), W2 [2][512] x 16 B (chunk h = K quarters 2 h, 2 h + 1; per quarter rows 0..3 in two dwords).  The per-row f32
+// scales (45 per layer and workgroup, padded to 48: Wqkv 5 at [0], Wo 4 at [8], W13 32 at [12], W2 4 at [44]) travel separately and
+// multiply the K-summed row result in the publishing lanes.
+constexpr size_t I8_QKV4 = 0, I8_QKV1 = 4096, I8_WO = 6144, I8_W13 = 10240, I8_W2 = 43008;
+static_assert(I8_W2 + 2 * 8192 == PS_LAYER_IMAGE_FP8, "fp8 image layout");
+constexpr int PS_SC = 48, SC_QKV = 0, SC_WO = 8, SC_W13 = 12, SC_W2 = 44;
+
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// two rows' (2 t, 2 t + 1) pairs in one dword: acc_even += row_even . c, acc_odd += row_odd . c
+__device__ __forceinline__ void pf_dot2x2_fp8(uint32_t w, float c0, float c1, float& acc_even, float& acc_odd) {
+    const f32x2_t a = __builtin_amdgcn_cvt_pk_f32_fp8(w, false), b2 = __builtin_amdgcn_cvt_pk_f32_fp8(w, true);
+    acc_even = fmaf(a.x, c0, acc_even); acc_even = fmaf(a.y, c1, acc_even);
+    acc_odd = fmaf(b2.x, c0, acc_odd); acc_odd = fmaf(b2.y, c1, acc_odd);
+}
 
 // LDS carve
 constexpr int S_XS = 0;                       // residual stream copy f32 [1024]
@@ -108,9 +124,59 @@ __global__ __launch_bounds__(PF_THREADS) void k_ps_pack_head(const uint32_t* __r
         reinterpret_cast<u32x4*>(image + (size_t)b * PS_HEAD_IMAGE)[c * PF_THREADS + t] = v;
     }
 }
+// FS_FP8 images (layout above).  W: row-major e4m3 bytes; a lane's pair of a row = one 16-bit load
+__global__ __launch_bounds__(PF_THREADS) void k_ps_pack_layer_fp8(LayerW w, unsigned char* __restrict__ image /*[PF_BLOCKS][PS_LAYER_IMAGE_FP8]*/,
+                                                                  float* __restrict__ scales /*[PF_BLOCKS][PS_SC]*/) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    unsigned char* im = image + (size_t)b * PS_LAYER_IMAGE_FP8;
+    const uint16_t* Wq = reinterpret_cast<const uint16_t*>(w.wqkv);  // [rows][512] pairs
+    const uint16_t* Wo = reinterpret_cast<const uint16_t*>(w.wo);
+    const uint16_t* W13 = reinterpret_cast<const uint16_t*>(w.w13);
+    const uint16_t* W2 = reinterpret_cast<const uint16_t*>(w.w2);    // [rows][2048] pairs
+    auto two = [](const uint16_t* W, size_t r0, size_t ld, int col) { return (uint32_t)W[r0 * ld + col] | ((uint32_t)W[(r0 + 1) * ld + col] << 16); };
+    reinterpret_cast<u32x2*>(im + I8_QKV4)[t] = u32x2{two(Wq, 5 * b, 512, t), two(Wq, 5 * b + 2, 512, t)};
+    reinterpret_cast<uint32_t*>(im + I8_QKV1)[t] = (uint32_t)Wq[(size_t)(5 * b + 4) * 512 + t];
+    reinterpret_cast<u32x2*>(im + I8_WO)[t] = u32x2{two(Wo, 4 * b, 512, t), two(Wo, 4 * b + 2, 512, t)};
+    for (int c = 0; c < 4; ++c) {
+        u32x4 v;
+        for (int k = 0; k < 4; ++k) v[k] = two(W13, 32 * b + 8 * c + 2 * k, 512, t);
+        reinterpret_cast<u32x4*>(im + I8_W13)[c * PF_THREADS + t] = v;
+    }
+    for (int h = 0; h < 2; ++h) {
+        u32x4 v;
+        for (int qq = 0; qq < 2; ++qq) {
+            const int col = 512 * (2 * h + qq) + t;
+            v[2 * qq] = two(W2, 4 * b, 2048, col);
+            v[2 * qq + 1] = two(W2, 4 * b + 2, 2048, col);
+        }
+        reinterpret_cast<u32x4*>(im + I8_W2)[h * PF_THREADS + t] = v;
+    }
+    if (t < PS_SC) {
+        float sc = 0.f;
+        if (t < 5) sc = w.s_qkv[5 * b + t];
+        else if (t >= SC_WO && t < SC_WO + 4) sc = w.s_o[4 * b + t - SC_WO];
+        else if (t >= SC_W13 && t < SC_W13 + 32) sc = w.s_13[32 * b + t - SC_W13];
+        else if (t >= SC_W2) sc = w.s_2[4 * b + t - SC_W2];
+        scales[(size_t)b * PS_SC + t] = sc;
+    }
+}
+__global__ __launch_bounds__(PF_THREADS) void k_ps_pack_head_fp8(const uint16_t* __restrict__ W, const float* __restrict__ ws, int n_rows,
+                                                                 unsigned char* __restrict__ image /*[PF_BLOCKS][PS_HEAD_IMAGE_FP8]*/,
+                                                                 float* __restrict__ scales /*[PF_BLOCKS][8]*/) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    u32x4 v;
+    for (int k = 0; k < 4; ++k) {
+        const int r0 = 8 * b + 2 * k;
+        const uint32_t lo = r0 < n_rows ? W[(size_t)r0 * 512 + t] : 0u, hi = r0 + 1 < n_rows ? W[(size_t)(r0 + 1) * 512 + t] : 0u;
+        v[k] = lo | (hi << 16);
+    }
+    reinterpret_cast<u32x4*>(image + (size_t)b * PS_HEAD_IMAGE_FP8)[t] = v;
+    if (t < 8) scales[b * 8 + t] = 8 * b + t < n_rows ? ws[8 * b + t] : 0.f;
+}
 __global__ void k_ps_copy_norm(const float* __restrict__ src, float* __restrict__ dst) { dst[blockIdx.x * 256 + threadIdx.x] = src[blockIdx.x * 256 + threadIdx.x]; }
 
 // ------------------------------------------------------------------------------------------------ the step kernel
+template <bool FP8>
 __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* xs = reinterpret_cast<float*>(smem + S_XS);
@@ -156,12 +222,24 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
     float x0 = x2.x, x1 = x2.y;
     __syncthreads();
 
-    const unsigned char* wimg = reinterpret_cast<const unsigned char*>(A.wpack) + (size_t)b * PS_LAYER_IMAGE;
-    const size_t layer_img = (size_t)PF_BLOCKS * PS_LAYER_IMAGE;
-    // weight registers, each filled one stage ahead
-    u32x4 wq4 = reinterpret_cast<const u32x4*>(wimg + IM_QKV4)[tid];
-    uint32_t wq1 = reinterpret_cast<const uint32_t*>(wimg + IM_QKV1)[tid];
-    u32x4 wo4, w13[8], w2r[4];
+    constexpr size_t LIMG = FP8 ? PS_LAYER_IMAGE_FP8 : PS_LAYER_IMAGE;
+    const unsigned char* wimg = reinterpret_cast<const unsigned char*>(A.wpack) + (size_t)b * LIMG;
+    const size_t layer_img = (size_t)PF_BLOCKS * LIMG;
+    // weight registers, each filled one stage ahead (bf16: a dword = one row's pair; fp8: two rows' pairs)
+    u32x4 wq4 = u32x4{0, 0, 0, 0}, wo4 = u32x4{0, 0, 0, 0}, w13[8], w2r[4];
+    u32x2 wq4f = u32x2{0, 0}, wo4f = u32x2{0, 0};
+    u32x4 w13f[4], w2f[2];
+    uint32_t wq1;
+    if constexpr (FP8) {
+        wq4f = reinterpret_cast<const u32x2*>(wimg + I8_QKV4)[tid];
+        wq1 = reinterpret_cast<const uint32_t*>(wimg + I8_QKV1)[tid];
+    } else {
+        wq4 = reinterpret_cast<const u32x4*>(wimg + IM_QKV4)[tid];
+        wq1 = reinterpret_cast<const uint32_t*>(wimg + IM_QKV1)[tid];
+    }
+    // fp8: this workgroup's row scales of the current layer (read by the publishing lanes, requested at the top of each stage)
+    const float* scl = FP8 ? A.scales + (size_t)b * PS_SC : nullptr;
+    const size_t scl_layer = (size_t)PF_BLOCKS * PS_SC;
     u32x4 kreg[2] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}}, vreg[2] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};  // zero unless this slice has cached tokens
     bool dead = false;
     unsigned e = 0;
@@ -199,12 +277,19 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
             if (att && n_tok > 0) load_kv_tile(l, 0);  // this layer's first K/V tile, under the qkv stage
             *reinterpret_cast<float2*>(xs + 2 * tid) = make_float2(x0, x1);
             const float xn0 = x0 * nw.x, xn1 = x1 * nw.y;
-            float a8[8];
-            a8[0] = pf_dot2(wq4.x, xn0, xn1, 0.f); a8[1] = pf_dot2(wq4.y, xn0, xn1, 0.f);
-            a8[2] = pf_dot2(wq4.z, xn0, xn1, 0.f); a8[3] = pf_dot2(wq4.w, xn0, xn1, 0.f);
-            a8[4] = pf_dot2(wq1, xn0, xn1, 0.f);
+            float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            float rsc = 1.f;
+            if constexpr (FP8) {
+                if (tid < 5 * PF_REPL) rsc = scl[(size_t)l * scl_layer + SC_QKV + tid % 5];
+                pf_dot2x2_fp8(wq4f.x, xn0, xn1, a8[0], a8[1]); pf_dot2x2_fp8(wq4f.y, xn0, xn1, a8[2], a8[3]);
+                pf_dot2x2_fp8(wq1, xn0, xn1, a8[4], a8[6]);  // (the odd half of this dword is zero)
+                a8[6] = 0.f;
+            } else {
+                a8[0] = pf_dot2(wq4.x, xn0, xn1, 0.f); a8[1] = pf_dot2(wq4.y, xn0, xn1, 0.f);
+                a8[2] = pf_dot2(wq4.z, xn0, xn1, 0.f); a8[3] = pf_dot2(wq4.w, xn0, xn1, 0.f);
+                a8[4] = pf_dot2(wq1, xn0, xn1, 0.f);
+            }
             a8[5] = fmaf(x1, x1, fmaf(x0, x0, 0.f));
-            a8[6] = 0.f; a8[7] = 0.f;
             const float r8 = pf_reduce<8>(a8, lane);
             if ((lane & 7) == 0) red[(par * 8 + wave) * PS_RED + (lane >> 3)] = r8;
             __syncthreads();
@@ -213,13 +298,15 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
                 float t = red[(par * 8) * PS_RED + r], tot = red[(par * 8) * PS_RED + 5];
 #pragma unroll
                 for (int w = 1; w < 8; ++w) { t += red[(par * 8 + w) * PS_RED + r]; tot += red[(par * 8 + w) * PS_RED + 5]; }
+                if constexpr (FP8) t *= rsc;
                 pub(e, rr, 5 * b + r, tag0 + e + 1, t / sqrtf(tot / 1024.f + A.eps));
             }
             par ^= 1;
             PS_TICK(1);
         }
         // ================= S2: attention of (head ah, slice as)
-        wo4 = reinterpret_cast<const u32x4*>(wl + IM_WO)[tid];  // next stage's weights
+        if constexpr (FP8) wo4f = reinterpret_cast<const u32x2*>(wl + I8_WO)[tid];  // next stage's weights
+        else wo4 = reinterpret_cast<const u32x4*>(wl + IM_WO)[tid];
         if (att) {
             tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
             const u64* eb = my_edges + (size_t)(e & 3) * ering;
@@ -381,9 +468,16 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
                 }
             }
             ++e;
-            w13[0] = reinterpret_cast<const u32x4*>(wl + IM_W13)[tid];  // next stage's weights (64 KB per CU), behind the sweep
+            float rsc = 1.f;
+            if constexpr (FP8) {
+                if (tid < 4 * PF_REPL) rsc = scl[(size_t)l * scl_layer + SC_WO + (tid & 3)];
 #pragma unroll
-            for (int c = 1; c < 8; ++c) w13[c] = reinterpret_cast<const u32x4*>(wl + IM_W13)[c * PF_THREADS + tid];
+                for (int c = 0; c < 4; ++c) w13f[c] = reinterpret_cast<const u32x4*>(wl + I8_W13)[c * PF_THREADS + tid];  // next stage's weights (32 KB per CU)
+            } else {
+                w13[0] = reinterpret_cast<const u32x4*>(wl + IM_W13)[tid];  // next stage's weights (64 KB per CU), behind the sweep
+#pragma unroll
+                for (int c = 1; c < 8; ++c) w13[c] = reinterpret_cast<const u32x4*>(wl + IM_W13)[c * PF_THREADS + tid];
+            }
 #pragma unroll
             for (int s = 0; s < 16; ++s) if (s < n_sl) mn = fmaxf(mn, sm[s]);
 #pragma unroll
@@ -396,9 +490,13 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
                     at0 = fmaf(wj, so0[s], at0);
                     at1 = fmaf(wj, so1[s], at1);
                 }
-            float a4[4];
-            a4[0] = pf_dot2(wo4.x, at0, at1, 0.f); a4[1] = pf_dot2(wo4.y, at0, at1, 0.f);
-            a4[2] = pf_dot2(wo4.z, at0, at1, 0.f); a4[3] = pf_dot2(wo4.w, at0, at1, 0.f);
+            float a4[4] = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (FP8) {
+                pf_dot2x2_fp8(wo4f.x, at0, at1, a4[0], a4[1]); pf_dot2x2_fp8(wo4f.y, at0, at1, a4[2], a4[3]);
+            } else {
+                a4[0] = pf_dot2(wo4.x, at0, at1, 0.f); a4[1] = pf_dot2(wo4.y, at0, at1, 0.f);
+                a4[2] = pf_dot2(wo4.z, at0, at1, 0.f); a4[3] = pf_dot2(wo4.w, at0, at1, 0.f);
+            }
             const float r4 = pf_reduce<4>(a4, lane);
             if ((lane & 15) == 0) red[(par * 8 + wave) * PS_RED + (lane >> 4)] = r4;
             float xres = 0.f;
@@ -409,6 +507,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
                 float t = red[(par * 8) * PS_RED + r];
 #pragma unroll
                 for (int w = 1; w < 8; ++w) t += red[(par * 8 + w) * PS_RED + r];
+                if constexpr (FP8) t *= rsc;
                 pub(e, rr, 4 * b + r, tag0 + e + 1, xres + t);
             }
             par ^= 1;
@@ -421,8 +520,14 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
             u32x4 v;
             pf_sweep1(my_edges + (size_t)(e & 3) * ering, tid, tag0 + e + 1, v, dead, A.ctl);
             ++e;
+            float rsa = 1.f, rsb = 1.f;
+            if constexpr (FP8) {
+                if (tid < 16 * PF_REPL) { rsa = scl[(size_t)l * scl_layer + SC_W13 + 2 * (tid & 15)]; rsb = scl[(size_t)l * scl_layer + SC_W13 + 2 * (tid & 15) + 1]; }
+                w2f[0] = reinterpret_cast<const u32x4*>(wl + I8_W2)[tid]; w2f[1] = reinterpret_cast<const u32x4*>(wl + I8_W2)[PF_THREADS + tid];  // next stage's weights
+            } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) w2r[q] = reinterpret_cast<const u32x4*>(wl + IM_W2)[q * PF_THREADS + tid];  // next stage's weights
+                for (int q = 0; q < 4; ++q) w2r[q] = reinterpret_cast<const u32x4*>(wl + IM_W2)[q * PF_THREADS + tid];  // next stage's weights
+            }
             x0 = __uint_as_float(v.x); x1 = __uint_as_float(v.z);
             *reinterpret_cast<float2*>(xs + 2 * tid) = make_float2(x0, x1);
             const float xn0 = x0 * nw.x, xn1 = x1 * nw.y;
@@ -430,12 +535,21 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
             if (lane == 0) red[(par * 8 + wave) * PS_RED + 32] = ssw;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                float a16[16];
+                float a16[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if constexpr (FP8) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const u32x4 w = w13[half * 4 + c];
-                    a16[4 * c] = pf_dot2(w.x, xn0, xn1, 0.f); a16[4 * c + 1] = pf_dot2(w.y, xn0, xn1, 0.f);
-                    a16[4 * c + 2] = pf_dot2(w.z, xn0, xn1, 0.f); a16[4 * c + 3] = pf_dot2(w.w, xn0, xn1, 0.f);
+                    for (int c = 0; c < 2; ++c) {  // rows 16 half + 8 c ..
+                        const u32x4 w = w13f[half * 2 + c];
+                        pf_dot2x2_fp8(w.x, xn0, xn1, a16[8 * c], a16[8 * c + 1]); pf_dot2x2_fp8(w.y, xn0, xn1, a16[8 * c + 2], a16[8 * c + 3]);
+                        pf_dot2x2_fp8(w.z, xn0, xn1, a16[8 * c + 4], a16[8 * c + 5]); pf_dot2x2_fp8(w.w, xn0, xn1, a16[8 * c + 6], a16[8 * c + 7]);
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const u32x4 w = w13[half * 4 + c];
+                        a16[4 * c] = pf_dot2(w.x, xn0, xn1, 0.f); a16[4 * c + 1] = pf_dot2(w.y, xn0, xn1, 0.f);
+                        a16[4 * c + 2] = pf_dot2(w.z, xn0, xn1, 0.f); a16[4 * c + 3] = pf_dot2(w.w, xn0, xn1, 0.f);
+                    }
                 }
                 const float r16 = pf_reduce<16>(a16, lane);
                 if ((lane & 3) == 0) red[(par * 8 + wave) * PS_RED + half * 16 + (lane >> 2)] = r16;
@@ -450,6 +564,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
                     tot += red[(par * 8 + w) * PS_RED + 32];
                 }
                 const float dn = sqrtf(tot / 1024.f + A.eps);
+                if constexpr (FP8) { ga *= rsa; gb *= rsb; }
                 ga /= dn; gb /= dn;
                 pub(e, rr, 16 * b + jj, tag0 + e + 1, (ga / (1.f + __expf(-ga))) * gb);
             }
@@ -462,17 +577,33 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
             u32x4 v[4];
             pf_sweep4(my_edges + (size_t)(e & 3) * ering, tid, tag0 + e + 1, v, dead, A.ctl);
             ++e;
+            float rsc = 1.f;
+            if constexpr (FP8) { if (tid < 4 * PF_REPL) rsc = scl[(size_t)l * scl_layer + SC_W2 + (tid & 3)]; }
             if (l + 1 < A.n_layer) {  // next layer's Wqkv rows
-                wq4 = reinterpret_cast<const u32x4*>(wl + layer_img + IM_QKV4)[tid];
-                wq1 = reinterpret_cast<const uint32_t*>(wl + layer_img + IM_QKV1)[tid];
+                if constexpr (FP8) {
+                    wq4f = reinterpret_cast<const u32x2*>(wl + layer_img + I8_QKV4)[tid];
+                    wq1 = reinterpret_cast<const uint32_t*>(wl + layer_img + I8_QKV1)[tid];
+                } else {
+                    wq4 = reinterpret_cast<const u32x4*>(wl + layer_img + IM_QKV4)[tid];
+                    wq1 = reinterpret_cast<const uint32_t*>(wl + layer_img + IM_QKV1)[tid];
+                }
             }
             float a4[4] = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (FP8) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const u32x4 w = w2f[q >> 1];
+                    const float c0 = __uint_as_float(v[q].x), c1 = __uint_as_float(v[q].z);
+                    pf_dot2x2_fp8((q & 1) ? w.z : w.x, c0, c1, a4[0], a4[1]); pf_dot2x2_fp8((q & 1) ? w.w : w.y, c0, c1, a4[2], a4[3]);
+                }
+            } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const u32x4 w = w2r[q];
                 const float c0 = __uint_as_float(v[q].x), c1 = __uint_as_float(v[q].z);
                 a4[0] = pf_dot2(w.x, c0, c1, a4[0]); a4[1] = pf_dot2(w.y, c0, c1, a4[1]);
                 a4[2] = pf_dot2(w.z, c0, c1, a4[2]); a4[3] = pf_dot2(w.w, c0, c1, a4[3]);
+            }
             }
             const float r4 = pf_reduce<4>(a4, lane);
             if ((lane & 15) == 0) red[(par * 8 + wave) * PS_RED + (lane >> 4)] = r4;
@@ -484,6 +615,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
                 float t = red[(par * 8) * PS_RED + r];
 #pragma unroll
                 for (int w = 1; w < 8; ++w) t += red[(par * 8 + w) * PS_RED + r];
+                if constexpr (FP8) t *= rsc;
                 pub(e, rr, 4 * b + r, tag0 + e + 1, xres + t);
             }
             par ^= 1;
@@ -494,17 +626,24 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
     {
         tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
         const float2 nw = *reinterpret_cast<const float2*>(A.norms + (size_t)(2 * A.n_layer) * 1024 + 2 * tid);
-        const u32x4* hp = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(A.hpack) + (size_t)b * PS_HEAD_IMAGE);
-        const u32x4 h0 = hp[tid], h1 = hp[PF_THREADS + tid];
+        const u32x4* hp = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(A.hpack) + (size_t)b * (FP8 ? PS_HEAD_IMAGE_FP8 : PS_HEAD_IMAGE));
+        const u32x4 h0 = hp[tid], h1 = FP8 ? u32x4{0, 0, 0, 0} : hp[PF_THREADS + tid];
+        float rsc = 1.f;
+        if constexpr (FP8) { if (tid < 8) rsc = A.hscales[8 * b + tid]; }
         u32x4 v;
         pf_sweep1(my_edges + (size_t)(e & 3) * ering, tid, tag0 + e + 1, v, dead, A.ctl);
         ++e;
         x0 = __uint_as_float(v.x); x1 = __uint_as_float(v.z);
         if (b == 0) *reinterpret_cast<float2*>(A.x + 2 * tid) = make_float2(x0, x1);
         const float xn0 = x0 * nw.x, xn1 = x1 * nw.y;
-        float a8[8];
-        a8[0] = pf_dot2(h0.x, xn0, xn1, 0.f); a8[1] = pf_dot2(h0.y, xn0, xn1, 0.f); a8[2] = pf_dot2(h0.z, xn0, xn1, 0.f); a8[3] = pf_dot2(h0.w, xn0, xn1, 0.f);
-        a8[4] = pf_dot2(h1.x, xn0, xn1, 0.f); a8[5] = pf_dot2(h1.y, xn0, xn1, 0.f); a8[6] = pf_dot2(h1.z, xn0, xn1, 0.f); a8[7] = pf_dot2(h1.w, xn0, xn1, 0.f);
+        float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if constexpr (FP8) {
+            pf_dot2x2_fp8(h0.x, xn0, xn1, a8[0], a8[1]); pf_dot2x2_fp8(h0.y, xn0, xn1, a8[2], a8[3]);
+            pf_dot2x2_fp8(h0.z, xn0, xn1, a8[4], a8[5]); pf_dot2x2_fp8(h0.w, xn0, xn1, a8[6], a8[7]);
+        } else {
+            a8[0] = pf_dot2(h0.x, xn0, xn1, 0.f); a8[1] = pf_dot2(h0.y, xn0, xn1, 0.f); a8[2] = pf_dot2(h0.z, xn0, xn1, 0.f); a8[3] = pf_dot2(h0.w, xn0, xn1, 0.f);
+            a8[4] = pf_dot2(h1.x, xn0, xn1, 0.f); a8[5] = pf_dot2(h1.y, xn0, xn1, 0.f); a8[6] = pf_dot2(h1.z, xn0, xn1, 0.f); a8[7] = pf_dot2(h1.w, xn0, xn1, 0.f);
+        }
         const float ssw = pf_wave_sum(fmaf(x1, x1, fmaf(x0, x0, 0.f)));
         const float r8 = pf_reduce<8>(a8, lane);
         if ((lane & 7) == 0) red[(par * 8 + wave) * PS_RED + (lane >> 3)] = r8;
@@ -514,6 +653,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
             float t = red[(par * 8) * PS_RED + tid], tot = red[(par * 8) * PS_RED + 8];
 #pragma unroll
             for (int w = 1; w < 8; ++w) { t += red[(par * 8 + w) * PS_RED + tid]; tot += red[(par * 8 + w) * PS_RED + 8]; }
+            if constexpr (FP8) t *= rsc;
             A.logits[8 * b + tid] = t / sqrtf(tot / 1024.f + A.eps);
         }
         PS_TICK(6);
@@ -526,7 +666,8 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-size_t slow_persist_pack_bytes(int n_layer) { return (size_t)n_layer * PF_BLOCKS * PS_LAYER_IMAGE; }
+size_t slow_persist_pack_bytes(int n_layer, bool fp8) { return (size_t)n_layer * PF_BLOCKS * (fp8 ? PS_LAYER_IMAGE_FP8 : PS_LAYER_IMAGE); }
+size_t slow_persist_scale_floats(int n_layer) { return (size_t)n_layer * PF_BLOCKS * PS_SC + (size_t)PF_BLOCKS * 8; }
 size_t slow_persist_edge_bytes() { return (size_t)PF_RING * PF_REPL * PS_EDGE_CAP * 8; }
 
 void launch_slow_persist_pack(const LayerW* layers, int n_layer, const void* head_w, int n_head_rows, const float* const* norm_ptrs,
@@ -541,13 +682,28 @@ void launch_slow_persist_pack(const LayerW* layers, int n_layer, const void* hea
     FS_HIP(hipGetLastError());
 }
 
+// FS_FP8 images + scales (scales: [n_layer][PF_BLOCKS][PS_SC] then [PF_BLOCKS][8] head scales)
+void launch_slow_persist_pack_fp8(const LayerW* layers, int n_layer, const void* head_w, const float* head_s, int n_head_rows,
+                                  const float* const* norm_ptrs, void* wpack, void* hpack, float* scales, float* norms_flat, hipStream_t st) {
+    for (int l = 0; l < n_layer; ++l)
+        hipLaunchKernelGGL(k_ps_pack_layer_fp8, dim3(PF_BLOCKS), dim3(PF_THREADS), 0, st, layers[l],
+                           reinterpret_cast<unsigned char*>(wpack) + (size_t)l * PF_BLOCKS * PS_LAYER_IMAGE_FP8, scales + (size_t)l * PF_BLOCKS * PS_SC);
+    hipLaunchKernelGGL(k_ps_pack_head_fp8, dim3(PF_BLOCKS), dim3(PF_THREADS), 0, st, reinterpret_cast<const uint16_t*>(head_w), head_s, n_head_rows,
+                       reinterpret_cast<unsigned char*>(hpack), scales + (size_t)n_layer * PF_BLOCKS * PS_SC);
+    for (int i = 0; i < 2 * n_layer + 1; ++i)
+        hipLaunchKernelGGL(k_ps_copy_norm, dim3(4), dim3(256), 0, st, norm_ptrs[i], norms_flat + (size_t)i * 1024);
+    FS_HIP(hipGetLastError());
+}
+
 void launch_slow_persist(const SlowPersistArgs& a, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_slow_persist), hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS));
+        FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_slow_persist<false>), hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS));
+        FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_slow_persist<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_slow_persist, dim3(PF_BLOCKS), dim3(PF_THREADS), PS_LDS, st, a);
+    if (a.scales) hipLaunchKernelGGL(k_slow_persist<true>, dim3(PF_BLOCKS), dim3(PF_THREADS), PS_LDS, st, a);
+    else hipLaunchKernelGGL(k_slow_persist<false>, dim3(PF_BLOCKS), dim3(PF_THREADS), PS_LDS, st, a);
     FS_HIP(hipGetLastError());
 }
 

@@ -113,3 +113,59 @@ def test_full_size_vocoder_64_frames_vs_oracle():
         r = float(np.sqrt(np.mean((pcm.astype(np.float64) - ref) ** 2)))
         print(f"full-size vocoder, 64 frames [{precision}]: PCM rms diff {r:.2e} at signal rms {sig:.3f}")
         assert pcm.shape == ref.shape == (2048 * 64,) and r < tol and sig > 1e-3
+
+
+@pytest.mark.parametrize("cfg_name", ["fish15", "fish14"])
+def test_fp8_persistent_path_every_decision_vs_fp8_oracle(cfg_name):
+    """FS_FP8 handles take the persistent kernels too (e4m3 weight images for the slow kernel, bf16-widened e4m3 + row scales for the
+    resident fast decoder): 48 frames on a 200-position prompt, the logits of all 48 x 9 decisions against the fp8-mode oracle (same
+    per-row e4m3 quantiser, computes on the dequantised values) teacher-forced on the GPU's tokens.  fish14 = BASELINE configs[4] shapes
+    (32k vocabulary, legacy 2-way slow token: its decision stays in k_sample_slow, the codebook decisions are in-launch)."""
+    F, rp = 48, 1.2
+    cfg, tok = (fcfg.FISH_1_5, TOK) if cfg_name == "fish15" else (fcfg.FISH_1_4, fcfg.FISH_1_4_TOKENS)
+    ocfg = dict(cfg, **tok)
+    rs = np.random.RandomState(3)
+    p = np.zeros((9, 200), np.uint32)
+    p[0] = rs.randint(6, min(tok["im_end_id"] if cfg_name == "fish15" else cfg["vocab_size"], cfg["vocab_size"]), 200)
+    lm = fishrt.DualARTransformer(cfg, tok, 0, "fp8").load_synthetic(SEED)
+    lm.debug_capture(F)
+    codes = lm.generate_blocking(p, F + 200 - 2, temp=0.0, top_p=1.0, top_k=0, repetition_penalty=rp, ignore_eos=True)
+    kpf = lm.last_stats()["kernels_per_frame"]
+    assert codes.shape == (8, F) and kpf == (2 if cfg_name == "fish15" else 3), kpf
+    cap = lm.debug_read(F)
+    lm.close()
+    o = orc.OracleLM(ocfg).load_synthetic(SEED, fp8=True)
+    o.set_kv_round_bf16(True)
+    rps = [_RepPen(1024, rp) for _ in range(8)]
+    femb = o.fast_embeddings()
+    im_end, n_audio = tok["im_end_id"], cfg["vocab_size"] - tok["im_end_id"]
+    cur, pos, prev, worst = p, 0, None, [0.0, 0.0]
+    for f in range(F):
+        lg, hd = o.forward_generate(cur, pos, full_head=(cfg_name == "fish14"))
+        if cfg_name == "fish15":
+            s = lg[0, im_end:].copy()
+            d = float(np.abs(s[1:] - cap[f, 0, 1:n_audio]).max())
+            worst[0] = max(worst[0], d)
+            assert d < BF16_TOL, ("slow logits", f, d)
+            slow = int(cap[f, 0, 2047]) + im_end
+            assert slow == _argmax_last(np.concatenate([[-np.inf], cap[f, 0, 1:n_audio]])) + im_end
+        else:
+            slow = tok["pad_id"]  # ignore_eos: the legacy 2-way draw always yields the <|semantic|> / pad token (single_batch.rs:104-124)
+        o.clear_fast()
+        x = hd[0]
+        for c in range(8):
+            fg = o.forward_generate_fast(x, c)[0]
+            if prev is not None:
+                fg = rps[c].apply(fg, int(prev[c + 1]))
+            if cfg_name == "fish15":  # (the capture hook lives in the folded prologue path: Fish 1.5 token layout)
+                d = float(np.abs(fg - cap[f, 1 + c, :1024]).max())
+                worst[1] = max(worst[1], d)
+                assert d < BF16_TOL, ("fast logits", f, c, d)
+            else:
+                # no capture on the legacy path: the pick itself must be the oracle's argmax or within the tolerance of it
+                assert fg.max() - fg[codes[c, f]] < 2 * BF16_TOL, (f, c, float(fg.max() - fg[codes[c, f]]))
+            x = femb[int(codes[c, f])]
+        frame = np.array([slow] + [int(v) for v in codes[:, f]], np.uint32)
+        pos += cur.shape[1]
+        prev, cur = frame, frame.reshape(9, 1)
+    print(f"fp8 persistent path [{cfg_name}], {F} frames: max |dlogit| vs the fp8-mode oracle: slow {worst[0]:.2e}, fast {worst[1]:.2e}")

@@ -514,8 +514,8 @@ class LM final : public LMBase {
             FS_HIP(hipMemcpy(pr, d_ctl_.as<uint32_t>() + 16, sizeof(pr), hipMemcpyDeviceToHost));
             FS_HIP(hipMemset(d_ctl_.as<uint32_t>() + 16, 0, sizeof(pr)));
             const double f = 0.01 / std::max<double>(1.0, (double)stats_.graph_launches - (double)L + 1);  // us per frame
-            fprintf(stderr, "persist prof (us/frame, workgroup 0; wait+work): preload %.1f  S1 %.1f+%.1f  S2 %.1f+%.1f  S3 %.1f+%.1f  S4 %.1f+%.1f  head %.1f+%.1f  decision %.1f+%.1f  tail %.1f\n",
-                    pr[0] * f, pr[9] * f, pr[1] * f, pr[10] * f, pr[2] * f, pr[11] * f, pr[3] * f, pr[12] * f, pr[4] * f, pr[13] * f, pr[5] * f, pr[14] * f, pr[6] * f, pr[7] * f);
+            fprintf(stderr, "persist prof (us/frame, workgroup 0; wait+work): preload %.1f  S1 %.1f+%.1f  S2 %.1f+%.1f  S3 %.1f+%.1f  S4 %.1f+%.1f  head %.1f+%.1f  decision %.1f+%.1f  tail %.1f | S3 split: gemv+reduce %.1f barrier %.1f epilogue %.1f\n",
+                    pr[0] * f, pr[9] * f, pr[1] * f, pr[10] * f, pr[2] * f, pr[11] * f, pr[3] * f, pr[12] * f, pr[4] * f, pr[13] * f, pr[5] * f, pr[14] * f, pr[6] * f, pr[7] * f, pr[8] * f, pr[15] * f, pr[3] * f);
         }
         if (use_pslow_) {
             if (getenv("FISHRT_PERSIST_PROF")) {

@@ -25,6 +25,7 @@ constexpr int PF_RING = 4;         // edge buffers in rotation
 constexpr int PF_LAYERS = 4;
 constexpr int PF_REG_DW = PF_LAYERS * (5 + 4 + 32) + 4;  // weight dwords (bf16 pairs) per lane held in VGPRs: wqkv, wo, w13 per layer + head
 constexpr int PF_REG_CHUNKS = PF_REG_DW / 4;              // 42 x 16 B
+constexpr int PF_ROW_CHUNKS = (PF_LAYERS * 9 + 4) / 4;    // of which 10 hold row pairs (Wqkv 5 + Wo 4 per layer, 4 head rows); 32 hold W13 MFMA fragments
 constexpr int PF_LDS_CHUNKS = PF_LAYERS * 4;              // w2 of every layer lives in LDS: 16 x 16 B per lane
 constexpr int PF_CHUNKS = PF_REG_CHUNKS + PF_LDS_CHUNKS;  // 58 x 16 B x 512 lanes = 475 KB per workgroup
 constexpr int PF_SCL = 200;                               // FS_FP8 handles: row scales per workgroup (4 layers x 48 + 4 head rows, padded)

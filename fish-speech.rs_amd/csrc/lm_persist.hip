@@ -38,6 +38,9 @@ namespace {
 #include "lm_persist_dev.h"
 #include "lm_bsample_dev.h"
 
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
 // LDS carve (bytes).  Everything lives in ONE dynamic array (guide: Guideline 17)
 constexpr int L_W2 = 0;                                   // [16 chunks][512 lanes] x 16 B
 constexpr int L_KC = L_W2 + PF_LDS_CHUNKS * PF_THREADS * 16;  // K cache: [4 layers][8 pos][64] bf16 pairs
@@ -52,7 +55,11 @@ constexpr int L_ROPE = L_AMAX + 2 * 8 * 8;                 // cos [8][32], sin [
 constexpr int L_RING = L_ROPE + 2 * 8 * 32 * 4;            // rep-pen ring [8][17], meta [8][2], prev [16], misc [16]
 constexpr int L_WORDS = L_RING + (8 * 17 + 8 * 2 + 16 + 16) * 4;  // StdRng output words of this frame's draws [8] (sampled requests)
 constexpr int L_SCL = L_WORDS + 16 * 4;  // FS_FP8 handles: this workgroup's row scales [PF_SCL]
-constexpr int L_END = L_SCL + PF_SCL * 4;
+constexpr int L_XR = L_SCL + PF_SCL * 4;  // this workgroup's own 4 elements of the residual stream (all a W2 / Wo epilogue reads back)
+constexpr int L_END = L_XR + 16;
+// S3's MFMA B operands: x . g split into three bf16 arrays [3][1024] + one zero slot, over the q scratch and the old residual copy
+constexpr int L_XB = L_QS;
+static_assert(L_XB + 3 * 2048 + 8 * 16 <= L_RED, "the bf16 activation arrays (+ a zero slot per wave) must not reach the row partials");
 static_assert(L_END <= 160 * 1024, "LDS budget");
 // the sampler's scratch (lm_bsample_dev.h) aliases q / residual copy / row partials / scores / argmax slots: all dead during a decision
 static_assert(L_QS % 16 == 0 && L_QS + (int)sizeof(BSampLds) <= L_ROPE, "sampler scratch must fit the stage scratch it aliases");
@@ -60,9 +67,11 @@ static_assert(L_QS % 16 == 0 && L_QS + (int)sizeof(BSampLds) <= L_ROPE, "sampler
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ weight image
-// chunk c < 42: dwords 4c .. 4c+3 of the lane's register image; dword d: layer l = d / 41, i = d % 41:
-//   i < 5: Wqkv row 5b + i;  i < 9: Wo row 4b + i - 5;  else W13 (interleaved) row 32b + i - 9;   d >= 164: fast_output row 4b + d - 164
-// each dword = elements (2t, 2t+1) of that row.  chunk 42 + 4l + q: {W2_l row 4b + r, elements (1024q + 2t, +1)}, r = 0..3
+// chunk c < 10: dwords 4c .. 4c+3 of the lane's row-pair image; dword d < 36: layer l = d / 9, i = d % 9: i < 5: Wqkv row 5b + i, else Wo row
+//   4b + i - 5; d >= 36: fast_output row 4b + d - 36.  Each dword = elements (2t, 2t+1) of that row.
+// chunk 10 + 8l + u: one MFMA A fragment (v_mfma_f32_16x16x32_bf16) of layer l's W13: row tile rt = u / 4 (interleaved rows 32b + 16rt + (lane & 15)),
+//   k-step j = u % 4 of the wave's K range: elements 128 wave + 32 j + 8 (lane >> 4) .. + 8 of that row.
+// chunk 42 + 4l + q: {W2_l row 4b + r, elements (1024q + 2t, +1)}, r = 0..3
 // FP8: the weights are e4m3 bytes; the image holds them widened to bf16 (exact: e4m3 is a subset of bf16), so the frame kernel is the same
 // and the per-row f32 scales multiply the K-summed row results in its publishing lanes (k_pf_pack_scales).
 template <bool FP8>
@@ -80,21 +89,25 @@ __global__ __launch_bounds__(PF_THREADS) void k_pf_pack(LayerW w0, LayerW w1, La
         }
     };
     u32x4 out;
-    if (c < PF_REG_CHUNKS) {
+    if (c < PF_ROW_CHUNKS) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int d = 4 * c + k;
             uint32_t v;
-            if (d >= PF_LAYERS * 41) v = pair(head, (size_t)(4 * b + d - PF_LAYERS * 41) * 512 + t);
+            if (d >= PF_LAYERS * 9) v = pair(head, (size_t)(4 * b + d - PF_LAYERS * 9) * 512 + t);
             else {
-                const LayerW& w = *ws[d / 41];
-                const int i = d % 41;
+                const LayerW& w = *ws[d / 9];
+                const int i = d % 9;
                 if (i < 5) v = pair(w.wqkv, (size_t)(5 * b + i) * 512 + t);
-                else if (i < 9) v = pair(w.wo, (size_t)(4 * b + i - 5) * 512 + t);
-                else v = pair(w.w13, (size_t)(32 * b + i - 9) * 512 + t);
+                else v = pair(w.wo, (size_t)(4 * b + i - 5) * 512 + t);
             }
             out[k] = v;
         }
+    } else if (c < PF_REG_CHUNKS) {
+        const int l = (c - PF_ROW_CHUNKS) / 8, u2 = (c - PF_ROW_CHUNKS) % 8, rt = u2 >> 2, j = u2 & 3, wv = t >> 6, ln = t & 63;
+        const size_t row = (size_t)(32 * b + 16 * rt + (ln & 15));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out[k] = pair(ws[l]->w13, row * 512 + (size_t)(64 * wv + 16 * j + 4 * (ln >> 4) + k));
     } else {
         const int l = (c - PF_REG_CHUNKS) / 4, q = (c - PF_REG_CHUNKS) % 4;
 #pragma unroll
@@ -132,7 +145,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
     uint32_t* kc = reinterpret_cast<uint32_t*>(smem + L_KC);
     uint32_t* vc = reinterpret_cast<uint32_t*>(smem + L_VC);
     float* qs = reinterpret_cast<float*>(smem + L_QS);
-    float* xs = reinterpret_cast<float*>(smem + L_XS);
+    float* xr = reinterpret_cast<float*>(smem + L_XR);
     float* red = reinterpret_cast<float*>(smem + L_RED);
     float* sc = reinterpret_cast<float*>(smem + L_SC);
     float* amax = reinterpret_cast<float*>(smem + L_AMAX);
@@ -246,12 +259,15 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
     if (!eos) {
         // ---- resident weights: 42 register chunks + 16 LDS chunks per lane
         const u32x4* wp = reinterpret_cast<const u32x4*>(A.wpack) + (size_t)b * PF_CHUNKS * PF_THREADS + tid;
-        uint32_t wr[PF_REG_DW];
+        uint32_t wr[4 * PF_ROW_CHUNKS];        // Wqkv / Wo / fast_output row pairs
+        u32x4 w13v[PF_LAYERS][8];              // W13 as MFMA A fragments: [layer][row tile * 4 + k-step]
 #pragma unroll
-        for (int c = 0; c < PF_REG_CHUNKS; ++c) {
+        for (int c = 0; c < PF_ROW_CHUNKS; ++c) {
             const u32x4 t4 = wp[(size_t)c * PF_THREADS];
             wr[4 * c] = t4.x; wr[4 * c + 1] = t4.y; wr[4 * c + 2] = t4.z; wr[4 * c + 3] = t4.w;
         }
+#pragma unroll
+        for (int c = PF_ROW_CHUNKS; c < PF_REG_CHUNKS; ++c) w13v[(c - PF_ROW_CHUNKS) / 8][(c - PF_ROW_CHUNKS) % 8] = wp[(size_t)c * PF_THREADS];
 #pragma unroll
         for (int c = 0; c < PF_LDS_CHUNKS; ++c) w2s[c * PF_THREADS + tid] = wp[(size_t)(PF_REG_CHUNKS + c) * PF_THREADS];
         // this lane's slice of the nine RMSNorm weight vectors: resident in the greedy kernel; the sampled kernel needs those 18 registers
@@ -277,7 +293,11 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every per-frame input has arrived before this workgroup's first publish
         // pin the weight image: keeps the optimiser from re-loading (sinking) any of it into the loop
 #pragma unroll
-        for (int d = 0; d < PF_REG_DW; ++d) asm volatile("" : "+v"(wr[d]));
+        for (int d = 0; d < 4 * PF_ROW_CHUNKS; ++d) asm volatile("" : "+v"(wr[d]));
+#pragma unroll
+        for (int l = 0; l < PF_LAYERS; ++l)
+#pragma unroll
+            for (int u2 = 0; u2 < 8; ++u2) asm volatile("" : "+v"(w13v[l][u2]));
 
         PF_TICK(0);
         unsigned e = 0;                       // edge counter of this launch
@@ -288,7 +308,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
             const int T = cb + 1;
 #pragma unroll
             for (int l = 0; l < PF_LAYERS; ++l) {
-                const uint32_t* wl = wr + 41 * l;
+                const uint32_t* wl = wr + 9 * l;
                 // ================= S1: (gather x) -> RMSNorm -> Wqkv rows -> publish 5 values
                 {
                     tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
@@ -300,7 +320,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
                         ++e;
                         PF_TICK(9);
                     }
-                    *reinterpret_cast<float2*>(xs + 2 * tid) = make_float2(x0, x1);
+                    if ((unsigned)(2 * tid - 4 * b) < 4u) *reinterpret_cast<float2*>(xr + 2 * tid - 4 * b) = make_float2(x0, x1);
                     // RMSNorm folded through the GEMV: W . ((x / d) * g) = (W . (x * g)) / d -- the row sums and sum(x^2) go through ONE
                     // reduction (no separate norm barrier); the publishing lanes divide by d
                     const float xn0 = x0 * nw.x, xn1 = x1 * nw.y;
@@ -318,7 +338,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
 #pragma unroll
                         for (int w = 1; w < 8; ++w) { t += red[(par * 8 + w) * PF_RED + r]; tot += red[(par * 8 + w) * PF_RED + 5]; }
                         if (fp8) t *= s_scl[48 * l + r];
-                        pf_publish(edges, e, rr, 5 * b + r, tag0 + e + 1, t / sqrtf(tot / 1024.f + A.eps));
+                        pf_publish(edges, e, rr, 5 * b + r, tag0 + e + 1, t * pf_rms_inv(tot, A.eps));
                     }
                     par ^= 1;
                     PF_TICK(1);
@@ -389,7 +409,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
                     const float r4 = pf_reduce<4>(a4, lane);
                     if ((lane & 15) == 0) red[(par * 8 + wave) * PF_RED + (lane >> 4)] = r4;
                     float xres = 0.f;
-                    if (tid < 4 * PF_REPL) xres = xs[4 * b + (tid & 3)];
+                    if (tid < 4 * PF_REPL) xres = xr[tid & 3];
                     __syncthreads();
                     if (tid < 4 * PF_REPL) {
                         const int r = tid & 3, rr = tid >> 2;
@@ -411,19 +431,53 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
                     ++e;
                     PF_TICK(11);
                     x0 = __uint_as_float(v.x); x1 = __uint_as_float(v.z);
-                    *reinterpret_cast<float2*>(xs + 2 * tid) = make_float2(x0, x1);
+                    if ((unsigned)(2 * tid - 4 * b) < 4u) *reinterpret_cast<float2*>(xr + 2 * tid - 4 * b) = make_float2(x0, x1);
                     const float xn0 = x0 * nw.x, xn1 = x1 * nw.y;  // RMSNorm folded through the GEMV (see S1)
                     const float ssw = pf_wave_sum(fmaf(x1, x1, fmaf(x0, x0, 0.f)));
                     if (lane == 0) red[(par * 8 + wave) * PF_RED + 32] = ssw;
+                    // The 32 x 1024 GEMV on the matrix cores.  x . g is split into three bf16 terms (truncation: hi + mid + lo == the f32 value
+                    // exactly) that become columns 0 / 1 / 2 of the B operand; a wave multiplies its 128-deep K slice of the two 16-row tiles
+                    // (8 x v_mfma_f32_16x16x32_bf16, A = the resident weight fragments) and the K reduction happens inside the instruction:
+                    // 24 VALU operations per lane instead of 128 unpack / FMA + a 70-instruction halving tree.
+                    {
+                        uint32_t* xb = reinterpret_cast<uint32_t*>(smem + L_XB);
+                        uint32_t pk[3];
+                        {
+                            const uint32_t h0 = __float_as_uint(xn0) & 0xFFFF0000u, h1 = __float_as_uint(xn1) & 0xFFFF0000u;
+                            const float r0 = xn0 - __uint_as_float(h0), r1 = xn1 - __uint_as_float(h1);
+                            const uint32_t m0 = __float_as_uint(r0) & 0xFFFF0000u, m1 = __float_as_uint(r1) & 0xFFFF0000u;
+                            const uint32_t l0 = __float_as_uint(r0 - __uint_as_float(m0)), l1 = __float_as_uint(r1 - __uint_as_float(m1));
+                            pk[0] = (h0 >> 16) | h1; pk[1] = (m0 >> 16) | m1; pk[2] = (l0 >> 16) | (l1 & 0xFFFF0000u);
+                        }
+                        // a wave's K slice [128 wave, +128) is exactly what its own 64 lanes swept: the LDS round trip is a transpose inside the
+                        // wave (its LDS operations execute in order), no workgroup barrier
+                        xb[tid] = pk[0]; xb[512 + tid] = pk[1]; xb[1024 + tid] = pk[2];
+                        if (lane < 4) xb[1536 + 4 * wave + lane] = 0u;
+                        __builtin_amdgcn_wave_barrier();
+                        const int n = lane & 15, q4 = lane >> 4;
+                        const u32x4* xbv = reinterpret_cast<const u32x4*>(smem + L_XB);
+                        const int zslot = 384 + wave;
+                        const int src = n < 3 ? n * 128 + 16 * wave + q4 : zslot;  // (+ 4 j per k-step below)
+                        f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        float a16[16];
+                        for (int j = 0; j < 4; ++j) {
+                            const bf16x8_t bv = __builtin_bit_cast(bf16x8_t, xbv[n < 3 ? src + 4 * j : zslot]);
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w13v[l][j]), bv, acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w13v[l][4 + j]), bv, acc1, 0, 0, 0);
+                        }
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) a16[r] = pf_dot2(wl[9 + half * 16 + r], xn0, xn1, 0.f);
-                        const float r16 = pf_reduce<16>(a16, lane);
-                        if ((lane & 3) == 0) red[(par * 8 + wave) * PF_RED + half * 16 + (lane >> 2)] = r16;
+                        for (int r = 0; r < 4; ++r) {  // columns 0 + 1 + 2 (row_shl: lane i reads lane i + 1 / i + 2 of its row of 16)
+                            acc0[r] += pf_dpp<0x101>(acc0[r]) + pf_dpp<0x102>(acc0[r]);
+                            acc1[r] += pf_dpp<0x101>(acc1[r]) + pf_dpp<0x102>(acc1[r]);
+                        }
+                        if (n == 0) {  // D[row 4 q4 + r][column 0]
+                            *reinterpret_cast<float4*>(red + (par * 8 + wave) * PF_RED + 4 * q4) = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
+                            *reinterpret_cast<float4*>(red + (par * 8 + wave) * PF_RED + 16 + 4 * q4) = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
+                        }
                     }
+                    PF_TICK(8);
                     __syncthreads();
+                    PF_TICK(15);
                     if (tid < 16 * PF_REPL) {
                         const int jj = tid & 15, rr = tid >> 4;
                         float ga = red[(par * 8) * PF_RED + 2 * jj], gb = red[(par * 8) * PF_RED + 2 * jj + 1], tot = red[(par * 8) * PF_RED + 32];
@@ -432,10 +486,10 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
                             ga += red[(par * 8 + w) * PF_RED + 2 * jj]; gb += red[(par * 8 + w) * PF_RED + 2 * jj + 1];
                             tot += red[(par * 8 + w) * PF_RED + 32];
                         }
-                        const float dn = sqrtf(tot / 1024.f + A.eps);
+                        const float dni = pf_rms_inv(tot, A.eps);
                         if (fp8) { ga *= s_scl[48 * l + 12 + 2 * jj]; gb *= s_scl[48 * l + 12 + 2 * jj + 1]; }
-                        ga /= dn; gb /= dn;
-                        pf_publish(edges, e, rr, 16 * b + jj, tag0 + e + 1, (ga / (1.f + __expf(-ga))) * gb);  // candle silu = x / (1 + exp(-x))
+                        ga *= dni; gb *= dni;
+                        pf_publish(edges, e, rr, 16 * b + jj, tag0 + e + 1, pf_silu(ga) * gb);  // candle silu = x / (1 + exp(-x))
                     }
                     par ^= 1;
                     PF_TICK(3);
@@ -460,7 +514,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
                     const float r4 = pf_reduce<4>(a4, lane);
                     if ((lane & 15) == 0) red[(par * 8 + wave) * PF_RED + (lane >> 4)] = r4;
                     float xres = 0.f;
-                    if (tid < 4 * PF_REPL) xres = xs[4 * b + (tid & 3)];
+                    if (tid < 4 * PF_REPL) xres = xr[tid & 3];
                     __syncthreads();
                     if (tid < 4 * PF_REPL) {
                         const int r = tid & 3, rr = tid >> 2;
@@ -486,7 +540,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
                 const float xn0 = x0 * nw.x, xn1 = x1 * nw.y;  // RMSNorm folded through the GEMV (see S1)
                 float a8[8];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) a8[r] = pf_dot2(wr[PF_LAYERS * 41 + r], xn0, xn1, 0.f);
+                for (int r = 0; r < 4; ++r) a8[r] = pf_dot2(wr[PF_LAYERS * 9 + r], xn0, xn1, 0.f);
                 a8[4] = fmaf(x1, x1, fmaf(x0, x0, 0.f));
                 a8[5] = 0.f; a8[6] = 0.f; a8[7] = 0.f;
                 const float r8 = pf_reduce<8>(a8, lane);
@@ -498,7 +552,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
 #pragma unroll
                     for (int w = 1; w < 8; ++w) { t += red[(par * 8 + w) * PF_RED + r]; tot += red[(par * 8 + w) * PF_RED + 4]; }
                     if (fp8) t *= s_scl[192 + r];
-                    pf_publish(edges, e, rr, 4 * b + r, tag0 + e + 1, t / sqrtf(tot / 1024.f + A.eps));
+                    pf_publish(edges, e, rr, 4 * b + r, tag0 + e + 1, t * pf_rms_inv(tot, A.eps));
                 }
                 par ^= 1;
                     PF_TICK(5);

@@ -34,6 +34,12 @@ __device__ __forceinline__ uint32_t f32_to_bf16_rne(float f) {
     return u >> 16;
 }
 
+// 1 / sqrt(mean(x^2) + eps) over 1024 elements (candle_nn::RmsNorm divides by the square root; v_rsq_f32 is within 1 ulp of that
+// quotient -- the publishing lanes sit on the critical path of every edge, and an IEEE sqrt + divide is ~60 dependent instructions)
+__device__ __forceinline__ float pf_rms_inv(float sumsq, float eps) { return __builtin_amdgcn_rsqf(fmaf(sumsq, 1.0f / 1024.f, eps)); }
+// candle silu = x / (1 + exp(-x)), with the hardware reciprocal (1 ulp)
+__device__ __forceinline__ float pf_silu(float x) { return x * __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+
 template <int CTRL>
 __device__ __forceinline__ float pf_dpp(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));

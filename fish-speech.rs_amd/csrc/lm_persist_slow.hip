@@ -299,7 +299,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
 #pragma unroll
                 for (int w = 1; w < 8; ++w) { t += red[(par * 8 + w) * PS_RED + r]; tot += red[(par * 8 + w) * PS_RED + 5]; }
                 if constexpr (FP8) t *= rsc;
-                pub(e, rr, 5 * b + r, tag0 + e + 1, t / sqrtf(tot / 1024.f + A.eps));
+                pub(e, rr, 5 * b + r, tag0 + e + 1, t * pf_rms_inv(tot, A.eps));
             }
             par ^= 1;
             PS_TICK(1);
@@ -563,10 +563,10 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
                     ga += red[(par * 8 + w) * PS_RED + 2 * jj]; gb += red[(par * 8 + w) * PS_RED + 2 * jj + 1];
                     tot += red[(par * 8 + w) * PS_RED + 32];
                 }
-                const float dn = sqrtf(tot / 1024.f + A.eps);
+                const float dni = pf_rms_inv(tot, A.eps);
                 if constexpr (FP8) { ga *= rsa; gb *= rsb; }
-                ga /= dn; gb /= dn;
-                pub(e, rr, 16 * b + jj, tag0 + e + 1, (ga / (1.f + __expf(-ga))) * gb);
+                ga *= dni; gb *= dni;
+                pub(e, rr, 16 * b + jj, tag0 + e + 1, pf_silu(ga) * gb);
             }
             par ^= 1;
             PS_TICK(4);
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
 #pragma unroll
             for (int w = 1; w < 8; ++w) { t += red[(par * 8 + w) * PS_RED + tid]; tot += red[(par * 8 + w) * PS_RED + 8]; }
             if constexpr (FP8) t *= rsc;
-            A.logits[8 * b + tid] = t / sqrtf(tot / 1024.f + A.eps);
+            A.logits[8 * b + tid] = t * pf_rms_inv(tot, A.eps);
         }
         PS_TICK(6);
     }

@@ -603,6 +603,7 @@ class LM final : public LMBase {
         cfg.temp = (float)s.temp; cfg.top_p = (float)s.top_p; cfg.top_p64 = s.top_p;
         cfg.top_k = (int)std::min<uint64_t>(s.top_k, 1u << 30);
         cfg.rep_pen = 1.0f; cfg.ignore_eos = (flags & FS_GEN_IGNORE_EOS) ? 1 : 0;
+        rows_par_ = rows_par_sampler_ok(s.temp, s.top_k, n_audio_, a_.codebook_size) && !getenv("FISHRT_ROWS_SAMPLER_1024");
         FS_HIP(hipMemcpyAsync(d_cfg_.p, &cfg, sizeof(cfg), hipMemcpyHostToDevice, st_));
         RngState rng = {};
         seed_key(seed, rng.key);  // BatchedLogitsProcessor::new(seed) (the reference passes 42, static_batch.rs:63)
@@ -735,6 +736,7 @@ class LM final : public LMBase {
         cfg.top_k = (int)std::min<uint64_t>(s.top_k, 1u << 30);
         cfg.rep_pen = 1.0f; cfg.ignore_eos = (flags & FS_GEN_IGNORE_EOS) ? 1 : 0;
         cfg.session = 1;
+        rows_par_ = rows_par_sampler_ok(s.temp, s.top_k, n_audio_, a_.codebook_size) && !getenv("FISHRT_ROWS_SAMPLER_1024");
         FS_HIP(hipMemcpyAsync(d_cfg_.p, &cfg, sizeof(cfg), hipMemcpyHostToDevice, st_));
         RngState rng = {};
         seed_key(seed, rng.key);
@@ -1269,6 +1271,7 @@ class LM final : public LMBase {
         FS_HIP(hipMemcpy(d_fast_state_.p, fs.data(), sizeof(SeqState) * 8, hipMemcpyHostToDevice));
         std::vector<int> tb(B_);
         for (int i = 0; i < B_; ++i) tb[i] = i;
+        d_rwords_.alloc(sizeof(uint32_t) * 16 * kRows);
         d_fast_table_.alloc(sizeof(int) * B_);
         FS_HIP(hipMemcpy(d_fast_table_.p, tb.data(), sizeof(int) * B_, hipMemcpyHostToDevice));
     }
@@ -1282,8 +1285,11 @@ class LM final : public LMBase {
         LmKernels<WT>::rows_finish(d_, B, cs, norm_w_, st_);
         LmKernels<WT>::rows_head(d_, B, cs, (const uint8_t*)out_w_ + (size_t)t_.im_end_id * a_.dim * sizeof(WT),
                                  kFp8 ? out_s_ + t_.im_end_id : nullptr, n_audio_, d_lrows_.as<float>(), ld_slow_, st_);
+        // block-parallel samplers (temp > 1e-7, top_k <= 256): the step's C + 1 StdRng words per row are derived up front
+        const uint32_t* words = rows_par_ ? d_rwords_.as<uint32_t>() : nullptr;
+        if (rows_par_) SampleKernels<WT>::rows_rng_words(d_rng_.as<RngState>(), B, C + 1, state(0), d_rwords_.as<uint32_t>(), st_);
         SampleKernels<WT>::sample_slow_rows(d_, d_lrows_.as<float>(), ld_slow_, n_audio_, d_cfg_.as<SampleCfg>(), d_rng_.as<RngState>(), B,
-                                            C + 1, state(0), cs.X, d_xfrows_.as<float>(), st_);
+                                            C + 1, state(0), cs.X, d_xfrows_.as<float>(), st_, words);
         for (int cbi = 0; cbi < C; ++cbi) {
             RowsCtx cf = cs;
             cf.X = d_xfrows_.as<float>();
@@ -1302,11 +1308,11 @@ class LM final : public LMBase {
             LmKernels<WT>::rows_head(d_, B, cf, fast_out_w_, kFp8 ? fast_out_s_ : nullptr, a_.codebook_size, d_lfast_.as<float>(), a_.codebook_size, st_);
             SampleKernels<WT>::sample_fast_rows(d_, d_lfast_.as<float>(), cbi, C, a_.codebook_size, d_cfg_.as<SampleCfg>(),
                                                 d_rng_.as<RngState>(), B, state(0), fast_emb_, d_xfrows_.as<float>(), tok_emb_, cb_emb_,
-                                                cs.X, d_out_.as<uint32_t>(), out_cap_, st_);
+                                                cs.X, d_out_.as<uint32_t>(), out_cap_, st_, words);
         }
     }
     hipGraphExec_t batch_graph(int B) {
-        const int key = (sess_active_ ? 1 << 24 : 0) + B * 1024 + nc_launch_;
+        const int key = (sess_active_ ? 1 << 24 : 0) + (rows_par_ ? 1 << 25 : 0) + B * 1024 + nc_launch_;
         auto it = batch_graphs_.find(key);
         if (it != batch_graphs_.end()) return it->second;
         hipGraph_t g = nullptr;
@@ -1550,7 +1556,8 @@ class LM final : public LMBase {
     DevBuf d_spack_, d_hpack_, d_snorms_, d_sedges_, d_sctl_;  // persistent slow transformer
     DevBuf d_pfx_, d_pfq_, d_pfslab_, d_pfa_, d_pfa2_, d_pfss_, d_pfc_, d_pfpart_;  // MFMA row-path activations (kRowsCap rows)
     DevBuf d_bprompt_;  // static batch: all left-padded prompts [B][C + 1][Lmax] (group prefill)
-    DevBuf d_xfrows_, d_lrows_, d_lfast_, d_fast_state_, d_fast_table_;  // static-batch generator
+    DevBuf d_xfrows_, d_lrows_, d_lfast_, d_fast_state_, d_fast_table_, d_rwords_;  // static-batch generator
+    bool rows_par_ = false;  // this batch / session samples with the block-parallel row samplers
     int ld_slow_ = 0, down_split_ = 4;
     bool batch_warm_ = false;
     std::map<int, hipGraphExec_t> batch_graphs_;

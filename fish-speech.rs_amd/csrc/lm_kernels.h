@@ -190,12 +190,17 @@ struct SampleKernels {
                             const void* tok_emb, const void* cb_emb, float* x, uint32_t* out_codes, int out_cap,
                             hipStream_t st);
     // static-batch generator (static_batch.rs): one block per batch row, child StdRng per (call, row)
+    // words != null: the block-parallel sampler (512 threads per row) with this step's pre-derived StdRng words (rows_rng_words);
+    // requires temp > 1e-7, 0 < top_k <= 256 < candidates (rows_par_sampler_ok)
     static void sample_slow_rows(const ModelDims& d, const float* logits, int ld, int n, const SampleCfg* c, const RngState* master, int B,
-                                 int calls_per_frame, SeqState* states, const float* X, float* XF, hipStream_t st);
+                                 int calls_per_frame, SeqState* states, const float* X, float* XF, hipStream_t st, const uint32_t* words = nullptr);
     static void sample_fast_rows(const ModelDims& d, const float* logits, int cb, int n_cb, int cb_size, const SampleCfg* c,
                                  const RngState* master, int B, SeqState* states, const void* fast_emb, float* XF, const void* tok_emb,
-                                 const void* cb_emb, float* X, uint32_t* out_codes, int out_cap, hipStream_t st);
+                                 const void* cb_emb, float* X, uint32_t* out_codes, int out_cap, hipStream_t st, const uint32_t* words = nullptr);
+    // words[b * 16 + call] = the StdRng word of sample() call `call` of this step for row b (child stream of master u64 number (frame * calls + call) * B + b)
+    static void rows_rng_words(const RngState* master, int B, int calls_per_frame, const SeqState* states, uint32_t* words, hipStream_t st);
 };
+bool rows_par_sampler_ok(double temp, uint64_t top_k, int n_slow, int cb_size);
 
 // dst[0] = src[r0], dst[1] = src[r1] (rows of `dim` elements): the 2-row head of the Fish <= 1.4 slow-token sampler
 template <typename WT>

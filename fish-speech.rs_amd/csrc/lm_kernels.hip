@@ -2544,6 +2544,96 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_fast_rows(const float
     embed_tokens<WT>(tok_emb, cb_emb, dim, n_cb, cb_size, c.sem_lo, c.sem_hi, cur, 1, X + (size_t)b * dim, tid, SAMPLE_THREADS);
 }
 
+// ---- the batched samplers on the block-parallel sampler (lm_bsample_dev.h): 512 threads per row, for temp > 1e-7 with 0 < top_k <= 256
+// (BASELINE configs[2]: top-k 256 / top-p 0.8).  The per-(call, row) child StdRng derivation -- two ChaCha12 blocks, the PCG expansion
+// and the word of the draw: ~5 us of dependent integer work -- no longer hides behind a 13 us one-wave selection, so it runs once per
+// step for all the step's calls: k_rows_rng_words, thread c of block b = call c of row b (the same master u64 numbers as above).
+constexpr int ROWS_WORDS_LD = 16;
+__global__ __launch_bounds__(64) void k_rows_rng_words(const RngState* __restrict__ master, int B, int calls_per_frame,
+                                                       const SeqState* __restrict__ states, uint32_t* __restrict__ words) {
+    const int b = blockIdx.x, c = threadIdx.x;
+    if (c >= calls_per_frame) return;
+    RngState child;
+    child_rng(master, ((unsigned long long)states[b].frame * calls_per_frame + c) * B + b, &child);
+    words[b * ROWS_WORDS_LD + c] = chacha12_word(child.key, 0);
+}
+constexpr int PAR_THREADS = 512;
+template <typename WT>
+__global__ __launch_bounds__(PAR_THREADS) void k_sample_slow_rows_par(const float* __restrict__ logits, int ld, int n, const SampleCfg* __restrict__ cp,
+                                                                       const uint32_t* __restrict__ words, SeqState* __restrict__ states,
+                                                                       const float* __restrict__ X, float* __restrict__ XF, int dim) {
+    __shared__ BSampLds S;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    SeqState* st = states + b;
+    const SampleCfg c = *cp;
+    float lv[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int i = tid * 4 + s;
+        lv[s] = i < n ? logits[(size_t)b * ld + i] : 0.f;
+        if (i == 0 && c.ignore_eos) lv[s] = -INFINITY;
+    }
+    for (int i = tid; i < dim; i += PAR_THREADS) XF[(size_t)b * dim + i] = X[(size_t)b * dim + i];  // hidden_states (:175)
+    int used = 0;
+    const int idx = bsample<PAR_THREADS, 4>(lv, n, c.top_k, (float)(1.0 / (double)c.temp), c.top_p, words[b * ROWS_WORDS_LD], &used, S, true, c.top_p64);
+    if (tid == 0) {
+        const uint32_t tok = (uint32_t)idx + c.im_end_id;  // rescale_semantic_tokens (utils.rs:45-46)
+        st->cur[0] = tok;
+        if (tok == c.im_end_id) st->done = 1;  // batch_item_is_dead |= newly dead (:160-173)
+    }
+}
+template <typename WT>
+__global__ __launch_bounds__(PAR_THREADS) void k_sample_fast_rows_par(const float* __restrict__ logits, int cb, int n_cb, int cb_size,
+                                                                       const SampleCfg* __restrict__ cp, const uint32_t* __restrict__ words, SeqState* __restrict__ states,
+                                                                       const WT* __restrict__ fast_emb, float* __restrict__ XF, const WT* __restrict__ tok_emb,
+                                                                       const WT* __restrict__ cb_emb, float* __restrict__ X, int dim,
+                                                                       uint32_t* __restrict__ out_codes, int out_cap) {
+    __shared__ BSampLds S;
+    const int tid = threadIdx.x, b = blockIdx.x, n = cb_size;
+    SeqState* st = states + b;
+    const SampleCfg c = *cp;
+    // the batch repetition-penalty mask is never updated for Fish models (static_batch.rs:204-206): logits / 1.0
+    float lv[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) { const int i = tid * 2 + s; lv[s] = i < n ? logits[(size_t)b * n + i] : 0.f; }
+    int used = 0;
+    const int code = bsample<PAR_THREADS, 2>(lv, n, c.top_k, (float)(1.0 / (double)c.temp), c.top_p, words[b * ROWS_WORDS_LD + 1 + cb], &used, S, true, c.top_p64);
+    if (tid == 0) st->cur[cb + 1] = (uint32_t)code;
+    if (cb != n_cb - 1) {
+        for (int d = tid; d < dim; d += PAR_THREADS) XF[(size_t)b * dim + d] = WTr<WT>::to_f32(fast_emb[(size_t)code * dim + d]);
+        return;
+    }
+    // ---- end of frame (static_batch.rs:224-267 + generate_static_batch :305-338): as k_sample_fast_rows
+    __syncthreads();
+    __shared__ uint32_t cur[16];
+    if (tid <= n_cb) {
+        const uint32_t slow = st->cur[0];
+        const bool is_audio = slow >= c.sem_lo;  // :229 (non-audio rows carry zero codes)
+        uint32_t v = tid == 0 ? slow : (tid == n_cb ? (uint32_t)code : st->cur[tid]);
+        if (tid > 0 && !is_audio) v = 0;
+        cur[tid] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int frame = st->frame;
+        const bool frozen = c.session != 0 && st->done != 0 && frame > 0;
+        if (!frozen) {
+            if (frame == 0 || !st->done) {
+                const int o = st->n_out;
+                uint32_t* oc = out_codes + (size_t)b * n_cb * out_cap;
+                if (o < out_cap)
+                    for (int cc = 0; cc < n_cb; ++cc) oc[(size_t)cc * out_cap + o] = cur[cc + 1];
+                st->n_out = o + 1;
+            }
+            for (int i = 0; i <= n_cb; ++i) { st->prev[i] = cur[i]; st->cur[i] = cur[i]; }
+            st->have_prev = 1;
+            st->pos += 1;
+            st->frame = frame + 1;
+        }
+    }
+    embed_tokens<WT>(tok_emb, cb_emb, dim, n_cb, cb_size, c.sem_lo, c.sem_hi, cur, 1, X + (size_t)b * dim, tid, PAR_THREADS);
+}
+
 // test hook of the block-parallel sampler (lm_bsample_dev.h) with the static-batch RNG derivation of k_sample_slow_rows
 template <int NT, int EPT>
 __global__ __launch_bounds__(NT) void k_bsample_rows_test(const float* __restrict__ logits, int n, const SampleCfg* __restrict__ cp,
@@ -2816,9 +2906,23 @@ void SampleKernels<WT>::sample_fast(const ModelDims& d, const float* logits, int
 }
 
 template <typename WT>
+void SampleKernels<WT>::rows_rng_words(const RngState* master, int B, int calls_per_frame, const SeqState* states, uint32_t* words, hipStream_t st) {
+    FS_REQUIRE(calls_per_frame <= ROWS_WORDS_LD, "too many sample() calls per frame");
+    hipLaunchKernelGGL(k_rows_rng_words, dim3(B), dim3(64), 0, st, master, B, calls_per_frame, states, words);
+    FS_LAUNCH_CHECK();
+}
+bool rows_par_sampler_ok(double temp, uint64_t top_k, int n_slow, int cb_size) {
+    return temp > 1e-7 && top_k > 0 && top_k <= (uint64_t)BS_MAXK && (int)top_k < cb_size && (int)top_k < n_slow && n_slow <= 2048 && cb_size <= 1024;
+}
+template <typename WT>
 void SampleKernels<WT>::sample_slow_rows(const ModelDims& d, const float* logits, int ld, int n, const SampleCfg* c, const RngState* master,
-                                         int B, int calls_per_frame, SeqState* states, const float* X, float* XF, hipStream_t st) {
+                                         int B, int calls_per_frame, SeqState* states, const float* X, float* XF, hipStream_t st, const uint32_t* words) {
     FS_REQUIRE(n <= SAMPLE_MAXN, "audio-range vocabulary larger than the sampler capacity");
+    if (words) {
+        hipLaunchKernelGGL((k_sample_slow_rows_par<KVT<WT>>), dim3(B), dim3(PAR_THREADS), 0, st, logits, ld, n, c, words, states, X, XF, d.dim);
+        FS_LAUNCH_CHECK();
+        return;
+    }
     hipLaunchKernelGGL((k_sample_slow_rows<KVT<WT>>), dim3(B), dim3(SAMPLE_THREADS), 0, st, logits, ld, n, c, master, B, calls_per_frame, states,
                        X, XF, d.dim);
     FS_LAUNCH_CHECK();
@@ -2827,8 +2931,15 @@ template <typename WT>
 void SampleKernels<WT>::sample_fast_rows(const ModelDims& d, const float* logits, int cb, int n_cb, int cb_size, const SampleCfg* c,
                                          const RngState* master, int B, SeqState* states, const void* fast_emb, float* XF,
                                          const void* tok_emb, const void* cb_emb, float* X, uint32_t* out_codes, int out_cap,
-                                         hipStream_t st) {
+                                         hipStream_t st, const uint32_t* words) {
     FS_REQUIRE(cb_size <= SAMPLE_MAXN, "codebook larger than the sampler capacity");
+    if (words) {
+        hipLaunchKernelGGL((k_sample_fast_rows_par<KVT<WT>>), dim3(B), dim3(PAR_THREADS), 0, st, logits, cb, n_cb, cb_size, c, words, states,
+                           reinterpret_cast<const KVT<WT>*>(fast_emb), XF, reinterpret_cast<const KVT<WT>*>(tok_emb), reinterpret_cast<const KVT<WT>*>(cb_emb), X, d.dim,
+                           out_codes, out_cap);
+        FS_LAUNCH_CHECK();
+        return;
+    }
     hipLaunchKernelGGL((k_sample_fast_rows<KVT<WT>>), dim3(B), dim3(SAMPLE_THREADS), 0, st, logits, cb, n_cb, cb_size, c, master, B, states,
                        (const KVT<WT>*)fast_emb, XF, (const KVT<WT>*)tok_emb, (const KVT<WT>*)cb_emb, X, d.dim, out_codes, out_cap);
     FS_LAUNCH_CHECK();

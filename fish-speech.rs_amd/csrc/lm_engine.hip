@@ -748,7 +748,7 @@ class LM final : public LMBase {
         sess_left_.assign(B_, -1);
         sess_pos_.assign(B_, 0);
         sess_hs_.assign(B_, SeqState{});
-        sess_pend_.slot = -1;
+        sess_queue_.clear(); sess_flight_.clear();
         for (int b = 0; b < B_; ++b) park_slot(b);
         FS_HIP(hipMemsetAsync(d_pfx_.p, 0, sizeof(float) * (size_t)B_ * a_.dim, st_));
         FS_HIP(hipStreamSynchronize(st_));
@@ -763,10 +763,14 @@ class LM final : public LMBase {
         FS_HIP(hipMemcpyAsync(d_page_table_.as<int>() + (size_t)b * max_pages_, &sess_scratch_, sizeof(int), hipMemcpyHostToDevice, st_));
         FS_HIP(hipStreamSynchronize(st_));
     }
-    // A joining request is prefilled on its own stream with its own row buffers, staging SeqState (index B_) and page-table row (B_),
-    // so the decode steps of the live slots go on underneath; the slot itself stays parked (scratch page, frozen) until the prefill has
-    // finished and activate_pending() -- between two steps -- hands it its page-table row, state and first input embedding.
-    // One prefill is in flight at a time: a second add first waits for (and activates) the previous one.
+    // Joining requests are prefilled on a second stream with their own row buffers, staging SeqState (index B_) and page-table rows
+    // (B_ ..), so the decode steps of the live slots go on underneath; a joining slot stays parked (scratch page, frozen) until its prefill
+    // has finished and activate_pending() -- between two steps -- hands it its page-table row, state and first input embedding.
+    // session_add only QUEUES the request; flush_pending() (first thing in session_step, or when the row buffers are full) prefills
+    // everything queued as GROUP passes: requests sorted by length, each pass = as many of them as fit the 2048 activation rows,
+    // right-padded to the longest of the pass (rows = sequences x tokens, RowMap.seq_rows; causal attention: a real token never sees a
+    // pad token, and the K/V a pad position writes into the slot's own pages lies beyond its length, where the first decode steps
+    // overwrite it before anything reads it).  A burst of 32 requests is admitted in 2-3 passes instead of 32.
     int session_add(const uint32_t* prompt, int L, int max_new_tokens) override {
         use_device();
         FS_REQUIRE(sess_active_, "no open session");
@@ -781,64 +785,125 @@ class LM final : public LMBase {
         n_iter = std::min<long long>(n_iter, (long long)a_.max_seq_len - L + 1);           // a slot stops at max_seq_len instead of erroring
         FS_REQUIRE(n_iter <= out_cap_, "generation longer than the output staging buffer");
         ensure_prefill2_buffers();
-        activate_pending(/*wait=*/true);
         {   // not enough free KV pages right now: like "all slots busy" (pages come back when slots are released), not an error
             const int need = (L + (int)n_iter - 1 + KV_PAGE - 1) / KV_PAGE;
             if ((int)free_pages_.size() < need - (int)seq_pages_[b].size()) return -1;
         }
         alloc_pages(b, L + (int)n_iter - 1);
-        const int Lp = L - 1;
-        sess_pend_ = {b, L, (int)n_iter, {}};
+        PendingAdd pa;
+        pa.slot = b; pa.L = L; pa.n_iter = (int)n_iter;
+        pa.prompt.assign(prompt, prompt + (size_t)C1 * L);
+        sess_queue_.push_back(std::move(pa));
         sess_left_[b] = -2;  // reserved: prefilling
-        sess_pend_.prompt.assign(prompt, prompt + (size_t)C1 * L);  // (kept until activation: the copy below may read it asynchronously)
-        if (Lp >= 1) {
-            const auto& pg = seq_pages_[b];
-            FS_HIP(hipMemcpyAsync(d_page_table_.as<int>() + (size_t)B_ * max_pages_, pg.data(), sizeof(int) * pg.size(), hipMemcpyHostToDevice, st_pf_));
-            if (d2_prompt_.n < sizeof(uint32_t) * (size_t)C1 * L) d2_prompt_.alloc(sizeof(uint32_t) * (size_t)C1 * L);
-            FS_HIP(hipMemcpyAsync(d2_prompt_.p, sess_pend_.prompt.data(), sizeof(uint32_t) * (size_t)C1 * L, hipMemcpyHostToDevice, st_pf_));
-            sess_stage_ = SeqState{};
-            sess_stage_.prompt_L = L;
-            FS_HIP(hipMemcpyAsync(state(B_), &sess_stage_, sizeof(SeqState), hipMemcpyHostToDevice, st_pf_));
-            RowsCtx c = rows_ctx2(state(B_), /*pos_step=*/1, /*pt_stride=*/0);
-            for (int done = 0; done < Lp;) {
-                const int M = std::min(a_.head_dim == 64 ? kRowsCap : kPartRows, Lp - done);
-                c.nc_launch = chunk_bucket(done + M);
-                LmKernels<WT>::prefill_embed(d_, tok_emb_, cb_emb_, a_.num_codebooks, a_.codebook_size, d_cfg_.as<SampleCfg>(),
-                                             d2_prompt_.as<uint32_t>(), state(B_), M, d2_pfx_.as<float>(), st_pf_);
-                for (int l = 0; l < a_.n_layer; ++l) LmKernels<WT>::rows_layer(d_, M, c, slow_[l], slow_kv(l, B_), l == 0, st_pf_);
-                LmKernels<WT>::rows_finish(d_, M, c, nullptr, st_pf_);
-                launch_advance_n(state(B_), M, st_pf_);
-                done += M;
-            }
-        }
-        FS_HIP(hipEventRecord(ev_pf_, st_pf_));
         stats_.prompt_tokens += (uint64_t)L;
         return b;
     }
-    // the pending request (if its prefill has finished, or after waiting for it) becomes a live slot; called between steps only
+    // launch the prefill of the next group of queued requests (ONE pass on the prefill stream, nothing waited for); no-op while an
+    // earlier group is still in flight -- the rest of the queue follows once that one has been activated
+    void flush_pending() {
+        if (sess_queue_.empty() || !sess_flight_.empty()) return;
+        const int C1 = a_.num_codebooks + 1, C = a_.num_codebooks;
+        std::stable_sort(sess_queue_.begin(), sess_queue_.end(), [](const PendingAdd& x, const PendingAdd& y) { return x.L > y.L; });
+        const bool flash = a_.head_dim == 64;
+        size_t i = 0;
+        int S = 1;
+        {
+            const int Lp = sess_queue_[i].L - 1;  // the longest of this pass (sorted): tokens that run through the slow transformer
+            if (Lp < 1) {                         // only single-token prompts are left: no pass, they go live at the next activation
+                FS_HIP(hipEventRecord(ev_pf_, st_pf_));
+                sess_flight_ = std::move(sess_queue_);
+                sess_queue_.clear();
+                return;
+            }
+            if (flash && Lp <= kRowsCap) {
+                const int fit = std::max(1, std::min(kRowsCap / Lp, B_));
+                while (i + S < sess_queue_.size() && S < fit && sess_queue_[i + S].L - 1 >= 1) {
+                    // pad positions write K/V up to Lp: the member must own pages that far (bounded: they go back with the slot)
+                    const int need = (Lp + KV_PAGE - 1) / KV_PAGE - (int)seq_pages_[sess_queue_[i + S].slot].size();
+                    if (need > 0 && (int)free_pages_.size() < need) break;
+                    ++S;
+                }
+            }
+            if (S == 1 || !flash) {  // one sequence, passes of <= kRowsCap rows
+                const PendingAdd& pa = sess_queue_[i];
+                const auto& pg = seq_pages_[pa.slot];
+                FS_HIP(hipMemcpyAsync(d_page_table_.as<int>() + (size_t)B_ * max_pages_, pg.data(), sizeof(int) * pg.size(), hipMemcpyHostToDevice, st_pf_));
+                if (d2_prompt_.n < sizeof(uint32_t) * (size_t)C1 * pa.L) d2_prompt_.alloc(sizeof(uint32_t) * (size_t)C1 * pa.L);
+                FS_HIP(hipMemcpyAsync(d2_prompt_.p, pa.prompt.data(), sizeof(uint32_t) * (size_t)C1 * pa.L, hipMemcpyHostToDevice, st_pf_));
+                sess_stage_ = SeqState{};
+                sess_stage_.prompt_L = pa.L;
+                FS_HIP(hipMemcpyAsync(state(B_), &sess_stage_, sizeof(SeqState), hipMemcpyHostToDevice, st_pf_));
+                RowsCtx c = rows_ctx2(state(B_), /*pos_step=*/1, /*pt_stride=*/0);
+                for (int done = 0; done < Lp;) {
+                    const int M = std::min(flash ? kRowsCap : kPartRows, Lp - done);
+                    c.nc_launch = chunk_bucket(done + M);
+                    LmKernels<WT>::prefill_embed(d_, tok_emb_, cb_emb_, C, a_.codebook_size, d_cfg_.as<SampleCfg>(),
+                                                 d2_prompt_.as<uint32_t>(), state(B_), M, d2_pfx_.as<float>(), st_pf_);
+                    for (int l = 0; l < a_.n_layer; ++l) LmKernels<WT>::rows_layer(d_, M, c, slow_[l], slow_kv(l, B_), l == 0, st_pf_);
+                    LmKernels<WT>::rows_finish(d_, M, c, nullptr, st_pf_);
+                    launch_advance_n(state(B_), M, st_pf_);
+                    done += M;
+                }
+            } else {
+                const size_t pstride = (size_t)C1 * Lp;
+                std::vector<uint32_t>& padded = sess_stage_prompts_;  // (members: alive until the pass has been activated)
+                std::vector<int>& rows = sess_stage_rows_;
+                padded.assign(pstride * S, 0u);
+                rows.assign((size_t)S * max_pages_, sess_scratch_);
+                for (int s = 0; s < S; ++s) {
+                    const PendingAdd& pa = sess_queue_[i + s];
+                    alloc_pages(pa.slot, std::max(pa.L + pa.n_iter - 1, Lp));
+                    const int n = pa.L - 1;
+                    for (int r = 0; r < C1; ++r) std::memcpy(&padded[pstride * s + (size_t)r * Lp], &pa.prompt[(size_t)r * pa.L], sizeof(uint32_t) * n);
+                    const auto& pg = seq_pages_[pa.slot];
+                    std::copy(pg.begin(), pg.end(), rows.begin() + (size_t)s * max_pages_);
+                }
+                if (d2_prompt_.n < sizeof(uint32_t) * padded.size()) d2_prompt_.alloc(sizeof(uint32_t) * padded.size());
+                FS_HIP(hipMemcpyAsync(d2_prompt_.p, padded.data(), sizeof(uint32_t) * padded.size(), hipMemcpyHostToDevice, st_pf_));
+                FS_HIP(hipMemcpyAsync(d_page_table_.as<int>() + (size_t)B_ * max_pages_, rows.data(), sizeof(int) * rows.size(), hipMemcpyHostToDevice, st_pf_));
+                sess_stage_ = SeqState{};
+                sess_stage_.prompt_L = Lp;
+                FS_HIP(hipMemcpyAsync(state(B_), &sess_stage_, sizeof(SeqState), hipMemcpyHostToDevice, st_pf_));
+                RowsCtx c = rows_ctx2(state(B_), /*pos_step=*/1, /*pt_stride=*/max_pages_);
+                c.seq_rows = Lp;
+                c.nc_launch = chunk_bucket(Lp);
+                const int M = S * Lp;
+                LmKernels<WT>::prefill_embed(d_, tok_emb_, cb_emb_, C, a_.codebook_size, d_cfg_.as<SampleCfg>(), d2_prompt_.as<uint32_t>(), state(B_), M,
+                                             d2_pfx_.as<float>(), st_pf_, Lp, pstride);
+                for (int l = 0; l < a_.n_layer; ++l) LmKernels<WT>::rows_layer(d_, M, c, slow_[l], slow_kv(l, B_), l == 0, st_pf_);
+            }
+        }
+        FS_HIP(hipEventRecord(ev_pf_, st_pf_));
+        sess_flight_.assign(std::make_move_iterator(sess_queue_.begin()), std::make_move_iterator(sess_queue_.begin() + S));
+        sess_queue_.erase(sess_queue_.begin(), sess_queue_.begin() + S);
+    }
+    // the requests whose prefill is in flight (if it has finished, or after waiting for it) become live slots; called between steps only
     void activate_pending(bool wait) {
-        if (sess_pend_.slot < 0) return;
+        if (sess_flight_.empty()) return;
         if (!wait) {
             const hipError_t q = hipEventQuery(ev_pf_);
             if (q == hipErrorNotReady) return;
             FS_HIP(q);
         }
         FS_HIP(hipEventSynchronize(ev_pf_));
-        const int b = sess_pend_.slot, L = sess_pend_.L, Lp = L - 1, C1 = a_.num_codebooks + 1;
-        const auto& pg = seq_pages_[b];
-        FS_HIP(hipMemcpyAsync(d_page_table_.as<int>() + (size_t)b * max_pages_, pg.data(), sizeof(int) * pg.size(), hipMemcpyHostToDevice, st_));
-        seq_len_[b] = Lp;
-        SeqState ss = {};
-        ss.pos = Lp; ss.prompt_L = L; ss.step = Lp;
-        for (int r = 0; r < C1; ++r) ss.cur[r] = sess_pend_.prompt[(size_t)r * L + (L - 1)];
-        sess_hs_[b] = ss;
-        FS_HIP(hipMemcpyAsync(state(b), &sess_hs_[b], sizeof(SeqState), hipMemcpyHostToDevice, st_));
-        LmKernels<WT>::embed(d_, tok_emb_, cb_emb_, a_.num_codebooks, a_.codebook_size, d_cfg_.as<SampleCfg>(), nullptr, state(b),
-                             d_pfx_.as<float>() + (size_t)b * a_.dim, st_);
+        const int C1 = a_.num_codebooks + 1;
+        for (const PendingAdd& pa : sess_flight_) {
+            const int b = pa.slot, L = pa.L, Lp = L - 1;
+            const auto& pg = seq_pages_[b];
+            FS_HIP(hipMemcpyAsync(d_page_table_.as<int>() + (size_t)b * max_pages_, pg.data(), sizeof(int) * pg.size(), hipMemcpyHostToDevice, st_));
+            seq_len_[b] = Lp;
+            SeqState ss = {};
+            ss.pos = Lp; ss.prompt_L = L; ss.step = Lp;
+            for (int r = 0; r < C1; ++r) ss.cur[r] = pa.prompt[(size_t)r * L + (L - 1)];
+            sess_hs_[b] = ss;
+            FS_HIP(hipMemcpyAsync(state(b), &sess_hs_[b], sizeof(SeqState), hipMemcpyHostToDevice, st_));
+            LmKernels<WT>::embed(d_, tok_emb_, cb_emb_, a_.num_codebooks, a_.codebook_size, d_cfg_.as<SampleCfg>(), nullptr, state(b),
+                                 d_pfx_.as<float>() + (size_t)b * a_.dim, st_);
+            sess_left_[b] = pa.n_iter;
+            sess_pos_[b] = Lp;
+        }
         FS_HIP(hipStreamSynchronize(st_));
-        sess_left_[b] = sess_pend_.n_iter;
-        sess_pos_[b] = Lp;
-        sess_pend_.slot = -1;
+        sess_flight_.clear();
     }
     void alloc_pages(int b, int n_tokens) {  // ensure_capacity without the upload: the row of a parked slot must keep pointing at the scratch page
         FS_REQUIRE(n_tokens <= a_.max_seq_len, "sequence longer than max_seq_len");
@@ -868,11 +933,16 @@ class LM final : public LMBase {
         FS_HIP(hipEventRecord(ev_[1], st_));
         int launched = 0;
         while (launched < n_frames) {
+            flush_pending();                   // queued requests start their (group) prefill on the second stream
             activate_pending(/*wait=*/false);  // a finished prefill joins here, between two replays of the step graph
             int chunk = n_frames - launched, longest = 0, live = 0;
             for (int b = 0; b < B_; ++b)
                 if (sess_left_[b] > 0 && !sess_hs_[b].done) { chunk = std::min(chunk, sess_left_[b]); longest = std::max(longest, sess_pos_[b]); ++live; }
-            if (!live && sess_pend_.slot >= 0) { activate_pending(true); continue; }  // nothing else to run: wait for the joining request
+            if (!live && (!sess_flight_.empty() || !sess_queue_.empty())) {
+                // nothing else to run (a burst into an idle session): admit everything queued, group pass after group pass, then step
+                while (!sess_flight_.empty() || !sess_queue_.empty()) { flush_pending(); activate_pending(true); }
+                continue;
+            }
             if (!live) break;
             for (int i = 0; i < chunk; ++i) {
                 set_bucket(longest + i + 1);
@@ -929,7 +999,7 @@ class LM final : public LMBase {
     void session_release(int slot) override {
         use_device();
         FS_REQUIRE(sess_active_ && slot >= 0 && slot < B_ && sess_left_[slot] != -1, "not a live session slot");
-        if (sess_pend_.slot == slot) activate_pending(true);
+        while (sess_left_[slot] == -2) { flush_pending(); activate_pending(true); }  // (its prefill is queued or in flight: let it finish first)
         sess_released_frames_ += (uint64_t)sess_hs_[slot].n_out;
         truncate(slot, 0);
         park_slot(slot);
@@ -938,7 +1008,8 @@ class LM final : public LMBase {
     void session_end() override {
         if (!sess_active_) return;
         use_device();
-        if (sess_pend_.slot >= 0) { (void)hipEventSynchronize(ev_pf_); sess_pend_.slot = -1; }
+        if (!sess_flight_.empty()) (void)hipEventSynchronize(ev_pf_);
+        sess_flight_.clear(); sess_queue_.clear();
         for (int b = 0; b < B_; ++b) truncate(b, 0);
         free_pages_.push_back(sess_scratch_);
         SampleCfg cfg = base_cfg();
@@ -1107,7 +1178,7 @@ class LM final : public LMBase {
         // unconditionally and mask them afterwards, which needs finite (not uninitialised) contents
         kv_pool_.alloc((size_t)a_.n_layer * 2 * n_pages_ * page_elems_ * sizeof(KT));
         FS_HIP(hipMemset(kv_pool_.p, 0, kv_pool_.n));
-        d_page_table_.alloc(sizeof(int) * (size_t)(B_ + 1) * max_pages_);  // + the staging row of a session's joining request
+        d_page_table_.alloc(sizeof(int) * (size_t)(2 * B_ + 1) * max_pages_);  // + the staging rows of a session's joining requests (one group pass)
         FS_HIP(hipMemset(d_page_table_.p, 0, d_page_table_.n));
         for (int p = n_pages_ - 1; p >= 0; --p) free_pages_.push_back(p);
         seq_pages_.assign(B_, {});
@@ -1395,7 +1466,7 @@ class LM final : public LMBase {
         A.x = x(0); A.logits = d_logits_slow_.as<float>(); A.state = state(0);
         A.kv_pool = kv_pool_.p; A.layer_half = (size_t)n_pages_ * page_elems_;
         A.page_table = d_page_table_.as<int>();
-        A.n_sl = std::min(nc_launch_, 16);
+        A.n_sl = std::min(nc_launch_, 16);  // (measured, round 3: half / a quarter as many slices -> S2 +44 / +115 us per frame, S3 only -10 / -12)
         A.edges = d_sedges_.as<unsigned long long>();
         A.ctl = d_sctl_.as<uint32_t>();
         A.prof = getenv("FISHRT_PERSIST_PROF") ? reinterpret_cast<unsigned long long*>(d_sctl_.as<uint32_t>() + 16) : nullptr;
@@ -1548,7 +1619,9 @@ class LM final : public LMBase {
     int sess_scratch_ = 0;
     uint64_t sess_released_frames_ = 0;
     struct PendingAdd { int slot = -1, L = 0, n_iter = 0; std::vector<uint32_t> prompt; };
-    PendingAdd sess_pend_;
+    std::vector<uint32_t> sess_stage_prompts_;
+    std::vector<int> sess_stage_rows_;
+    std::vector<PendingAdd> sess_queue_, sess_flight_;  // joining requests: queued by session_add / prefill launched (flush_pending)
     SeqState sess_stage_ = {};
     hipStream_t st_pf_ = nullptr;
     hipEvent_t ev_pf_ = nullptr;

@@ -182,3 +182,48 @@ def test_fullsize_greedy_session_vs_oracle_one_prompt_batches():
     print(f"full-size session: {len(reqs) - flips}/{len(reqs)} requests identical to the oracle's one-prompt static batch")
     assert flips <= 2
     lm.close()
+
+
+def test_budget_exhausted_slot_on_a_page_boundary_leaves_its_neighbours_alone():
+    """A slot whose budget ends with pos == a multiple of the KV page size (64) keeps riding the step graphs, frozen, until it is released;
+    its K/V write must be parked (scratch page) -- its own page table has no entry for that position, and a stale entry would point into
+    a page that now belongs to a neighbour.  Slots: A ends exactly on the boundary and is released late, B / C / D keep
+    running meanwhile, D re-uses pages freed earlier; every request must still equal its one-prompt static batch."""
+    lm = fishrt.DualARTransformer(MID, fcfg.TINY_TOKENS, 0, "bf16", max_batch=4).load_synthetic(SEED)
+    o = orc.OracleLM(orc.TINY | {k: MID[k] for k in ("dim", "n_head", "n_local_heads", "head_dim", "intermediate_size")})
+    o.load_synthetic(SEED, bf16=True)
+    o.set_kv_round_bf16(True)
+    rng = np.random.RandomState(11)
+    # request: (L, max_new_tokens); iterations = 1 + max(0, M - L + 1); final pos = L - 1 + iterations
+    reqs = {"E": (33, 33 + 20), "A": (20, 63), "B": (30, 30 + 150), "C": (7, 7 + 140), "D": (50, 50 + 60)}
+    assert reqs["A"][0] - 1 + (1 + reqs["A"][1] - reqs["A"][0] + 1) == 64
+    prompts = {k: _prompt(rng, L) for k, (L, _) in reqs.items()}
+    out = {}
+    with lm.session(temp=0.0, top_p=1.0, top_k=0, seed=42, ignore_eos=True) as s:
+        slot = {}
+        slot["E"] = s.add(prompts["E"], reqs["E"][1])  # E runs first and is released: its pages go back to the pool (LIFO)
+        while not s.poll(slot["E"], codes=False)[1]:
+            s.step(4)
+        out["E"] = s.poll(slot["E"])[0]
+        s.release(slot["E"])
+        for k in ("A", "B", "C"):
+            slot[k] = s.add(prompts[k], reqs[k][1])
+        released_a = False
+        d_added = False
+        for _ in range(80):
+            s.step(3)
+            if not d_added and s.poll(slot["A"], codes=False)[1]:  # A is done (frozen on the boundary) but NOT released yet
+                slot["D"] = s.add(prompts["D"], reqs["D"][1])
+                d_added = True
+            if d_added and not released_a and s.poll(slot["D"], codes=False)[0] > 30:
+                out["A"] = s.poll(slot["A"])[0]
+                s.release(slot["A"])
+                released_a = True
+            if all(s.poll(slot[k], codes=False)[1] for k in ("B", "C")) and d_added and s.poll(slot["D"], codes=False)[1]:
+                break
+        for k in ("B", "C", "D"):
+            out[k] = s.poll(slot[k])[0]
+        assert released_a and d_added
+    flips = sum(_check_vs_oracle(o, prompts[k], reqs[k][1], out[k], f"request {k}", ignore_eos=True) for k in reqs)
+    print(f"page-boundary session: {len(reqs) - flips}/{len(reqs)} requests identical to their one-prompt static batch")
+    lm.close()

@@ -1412,6 +1412,16 @@ class LM final : public LMBase {
         return c;
     }
 
+    // naps before the first sweep of each stage kind (64-clock units; tuned on MI355X, profiles/r03_poll_naps.txt); the environment
+    // variables ("a,b,c,d,e,f") override them for tuning runs
+    static constexpr int kNapsFast[6] = {16, 16, 20, 20, 20, 12}, kNapsSlow[6] = {24, 0, 8, 40, 32, 12};
+    static void set_naps(int (&naps)[6], const char* env, const int (&dflt)[6]) {
+        for (int i = 0; i < 6; ++i) naps[i] = dflt[i];
+        if (const char* v = getenv(env)) {
+            int i = 0;
+            for (const char* p = v; *p && i < 6; ++i) { naps[i] = atoi(p); while (*p && *p != ',') ++p; if (*p == ',') ++p; }
+        }
+    }
     // ---- persistent fast decoder (lm_persist.hip): per-lane weight image, edge buffers, control words
     void pack_persist() {
         persist_ok_ = false;
@@ -1470,6 +1480,7 @@ class LM final : public LMBase {
         A.edges = d_sedges_.as<unsigned long long>();
         A.ctl = d_sctl_.as<uint32_t>();
         A.prof = getenv("FISHRT_PERSIST_PROF") ? reinterpret_cast<unsigned long long*>(d_sctl_.as<uint32_t>() + 16) : nullptr;
+        set_naps(A.naps, "FISHRT_NAPS_SLOW", kNapsSlow);
         return A;
     }
     // the persistent fast decoder takes the slow-token decision in its prologue (no k_sample_slow node) whenever it runs
@@ -1492,6 +1503,7 @@ class LM final : public LMBase {
         A.edges = d_edges_.as<unsigned long long>();
         A.ctl = d_ctl_.as<uint32_t>();
         A.prof = getenv("FISHRT_PERSIST_PROF") ? reinterpret_cast<unsigned long long*>(d_ctl_.as<uint32_t>() + 16) : nullptr;
+        set_naps(A.naps, "FISHRT_NAPS_FAST", kNapsFast);
         return A;
     }
 

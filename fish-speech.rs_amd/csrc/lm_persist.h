@@ -56,6 +56,7 @@ struct FastPersistArgs {
     unsigned long long* edges;  // [PF_RING][PF_REPL][PF_EDGE_CAP] granules (zeroed once at allocation)
     unsigned long long* prof;   // null, or [16]: workgroup 0 accumulates 10 ns ticks per stage kind (FISHRT_PERSIST_PROF=1)
     uint32_t* ctl;              // [0] launch counter (tag epoch), [1] spin-timeout count (host checks it), [2] launches whose sampling configuration does not match the instantiation
+    int naps[6];                // 64-clock naps before the first sweep of S1 / S2 / S3 / S4 / head / decision (lm_persist_dev.h pf_nap_before_sweep)
 };
 
 // ---- persistent slow-transformer kernel (lm_persist_slow.hip): one launch = the 24 blocks + the audio-range head of one decode step
@@ -85,6 +86,7 @@ struct SlowPersistArgs {
     unsigned long long* edges;  // [PF_RING][PF_REPL][PS_EDGE_CAP]
     unsigned long long* prof;
     uint32_t* ctl;          // [0] epoch, [1] timeouts
+    int naps[6];            // 64-clock naps before the first sweep of S1 / S2 / S3 / S4 / S5 / head
 };
 size_t slow_persist_pack_bytes(int n_layer, bool fp8 = false);
 size_t slow_persist_scale_floats(int n_layer);

@@ -315,6 +315,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
                     const float2 nw = norm_w(2 * l, tid);
                     if (l > 0) {
                         u32x4 v;
+                        pf_nap_before_sweep(A.naps[0]);
                         pf_sweep1(my_edges + (size_t)(e & 3) * PF_REPL * PF_EDGE_CAP, tid, tag0 + e + 1, v, dead, A.ctl);
                         x0 = __uint_as_float(v.x); x1 = __uint_as_float(v.z);
                         ++e;
@@ -348,6 +349,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
                     tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
                     u32x4 vq, vk;
                     const u64* eb = my_edges + (size_t)(e & 3) * PF_REPL * PF_EDGE_CAP;
+                    pf_nap_before_sweep(A.naps[1]);
                     if (tid < 128) pf_sweep2(eb, tid, 512 + tid, tag0 + e + 1, vq, vk, dead, A.ctl);
                     else pf_sweep1(eb, tid, tag0 + e + 1, vq, dead, A.ctl);
                     ++e;
@@ -427,6 +429,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
                     tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
                     const float2 nw = norm_w(2 * l + 1, tid);
                     u32x4 v;
+                    pf_nap_before_sweep(A.naps[2]);
                     pf_sweep1(my_edges + (size_t)(e & 3) * PF_REPL * PF_EDGE_CAP, tid, tag0 + e + 1, v, dead, A.ctl);
                     ++e;
                     PF_TICK(11);
@@ -498,6 +501,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
                 {
                     tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
                     u32x4 v[4];
+                    pf_nap_before_sweep(A.naps[3]);
                     pf_sweep4(my_edges + (size_t)(e & 3) * PF_REPL * PF_EDGE_CAP, tid, tag0 + e + 1, v, dead, A.ctl);
                     ++e;
                     PF_TICK(12);
@@ -533,6 +537,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
                 tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
                 const float2 nw = norm_w(2 * PF_LAYERS, tid);
                 u32x4 v;
+                pf_nap_before_sweep(A.naps[4]);
                 pf_sweep1(my_edges + (size_t)(e & 3) * PF_REPL * PF_EDGE_CAP, tid, tag0 + e + 1, v, dead, A.ctl);
                 ++e;
                 PF_TICK(13);
@@ -561,6 +566,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
             {
                 tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
                 u32x4 v;
+                pf_nap_before_sweep(A.naps[5]);
                 pf_sweep1(my_edges + (size_t)(e & 3) * PF_REPL * PF_EDGE_CAP, tid, tag0 + e + 1, v, dead, A.ctl);
                 ++e;
                 PF_TICK(14);

@@ -131,6 +131,13 @@ __device__ __forceinline__ float pf_wave_sum(float v) {
 // (a few VALU ops) instead of being hoisted out of the pass loop into ~150 extra live registers
 __device__ __forceinline__ int pf_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 
+// A consumer knows that an edge cannot be complete before its producers have swept the previous edge, computed and published: polling
+// from the first instant only adds sweep traffic (every workgroup re-reads 8-32 KB per round) in front of the granules everybody is
+// waiting for.  Each stage therefore naps before its first sweep (units of 64 clocks, tuned per stage kind: profiles/r03_poll_naps.txt).
+__device__ __forceinline__ void pf_nap_before_sweep(int n) {
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+}
+
 // ---- edge sweeps: NL 16-byte units per lane (unit u = granules 2u, 2u+1), all of a lane's loads in flight, retried until both
 // tags of every unit match.  `dead` latches after a timeout: the thread then stops waiting for anything.
 __device__ __forceinline__ bool pf_tags_ok(const u32x4& v, unsigned tag) { return v.y == tag && v.w == tag; }

@@ -270,6 +270,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
             const float2 nw = *reinterpret_cast<const float2*>(A.norms + (size_t)(2 * l) * 1024 + 2 * tid);
             if (l > 0) {
                 u32x4 v;
+                pf_nap_before_sweep(A.naps[0]);
                 pf_sweep1(my_edges + (size_t)(e & 3) * ering, tid, tag0 + e + 1, v, dead, A.ctl);
                 x0 = __uint_as_float(v.x); x1 = __uint_as_float(v.z);
                 ++e;
@@ -313,6 +314,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
             if (tid < 96) {  // q of head ah (32 units), k / v of kv head ag (32 units each)
                 const int unit = tid < 32 ? 32 * ah + tid : (tid < 64 ? 512 + 32 * ag + (tid - 32) : 576 + 32 * ag + (tid - 64));
                 u32x4 v;
+                pf_nap_before_sweep(A.naps[1]);
                 pf_sweep1(eb, unit, tag0 + e + 1, v, dead, A.ctl);
                 const float a0 = __uint_as_float(v.x), a1 = __uint_as_float(v.z);
                 const int j = tid & 31;
@@ -443,6 +445,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
             float mn = -1e30f, L = 0.f, at0 = 0.f, at1 = 0.f;
             // two passes over the slices would need the maxima first: keep {m, l, o} of up to 16 slices in registers (n_sl <= 16)
             float sm[16], sl_[16], so0[16], so1[16];
+            pf_nap_before_sweep(A.naps[2]);
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int s0 = 4 * g4;  // compile-time: the slice arrays stay in registers
@@ -518,6 +521,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
             tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
             const float2 nw = *reinterpret_cast<const float2*>(A.norms + (size_t)(2 * l + 1) * 1024 + 2 * tid);
             u32x4 v;
+            pf_nap_before_sweep(A.naps[3]);
             pf_sweep1(my_edges + (size_t)(e & 3) * ering, tid, tag0 + e + 1, v, dead, A.ctl);
             ++e;
             float rsa = 1.f, rsb = 1.f;
@@ -575,6 +579,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
         {
             tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
             u32x4 v[4];
+            pf_nap_before_sweep(A.naps[4]);
             pf_sweep4(my_edges + (size_t)(e & 3) * ering, tid, tag0 + e + 1, v, dead, A.ctl);
             ++e;
             float rsc = 1.f;
@@ -631,6 +636,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
         float rsc = 1.f;
         if constexpr (FP8) { if (tid < 8) rsc = A.hscales[8 * b + tid]; }
         u32x4 v;
+        pf_nap_before_sweep(A.naps[5]);
         pf_sweep1(my_edges + (size_t)(e & 3) * ering, tid, tag0 + e + 1, v, dead, A.ctl);
         ++e;
         x0 = __uint_as_float(v.x); x1 = __uint_as_float(v.z);

@@ -465,22 +465,30 @@ def extras(cfg, tok):
         if name == "static_batch32":
             out["continuous_batching32"] = continuous_vs_lockstep(lmb, prompts_all[:64])
         lmb.close()
-    codec = fishrt.FireflyCodec(0).load_synthetic(0xC0DEC)
     codes = np.random.RandomState(1).randint(0, 1000, (1, 8, 256)).astype(np.uint32)
-    codec.decode(codes)
-    t0 = time.perf_counter()
-    pcm = codec.decode(codes)
-    dt = time.perf_counter() - t0
-    out["vocoder"] = {"workload": "FireflyCodec.decode of 256 frames (11.9 s of 44.1 kHz audio), default bf16x3 precision mode (split-bf16 matrix "
-                                  "products, PCM within 1e-4 RMS of the f32 oracle), host buffers in/out",
-                      "ms": round(dt * 1e3, 2), "rtf": round((256 / FRAME_RATE) / dt, 1), "tflops_equiv": round(2.65e9 * 256 / dt / 1e12, 2),
-                      "pcm_finite": bool(np.isfinite(pcm).all())}
-    codec.close()
-    codec = fishrt.FireflyCodec(0, precision="f32").load_synthetic(0xC0DEC)
-    codec.decode(codes)
-    t0 = time.perf_counter()
-    codec.decode(codes)
-    out["vocoder"]["ms_f32_mode"] = round((time.perf_counter() - t0) * 1e3, 2)
+    voc_ms, voc_pcm = {}, {}
+    for mode in ("f16", "bf16x3", "f32"):
+        codec = fishrt.FireflyCodec(0, precision=mode).load_synthetic(0xC0DEC)
+        codec.decode(codes)
+        best = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            voc_pcm[mode] = codec.decode(codes)
+            best = min(best, time.perf_counter() - t0)
+        voc_ms[mode] = best * 1e3
+        if mode != "f32":
+            codec.close()
+    ref64 = voc_pcm["f32"].astype(np.float64)
+    dt = voc_ms["f16"] / 1e3
+    out["vocoder"] = {"workload": "FireflyCodec.decode of 256 frames (11.9 s of 44.1 kHz audio), default f16 precision mode (single f16 matrix "
+                                  "operands, f32 accumulation and residual stream; bound: PCM within 1e-4 RMS of the f32 oracle), host buffers "
+                                  "in/out, best of 3",
+                      "ms": round(voc_ms["f16"], 2), "rtf": round((256 / FRAME_RATE) / dt, 1), "tflops_equiv": round(2.65e9 * 256 / dt / 1e12, 2),
+                      "pcm_finite": bool(np.isfinite(voc_pcm["f16"]).all()),
+                      "pcm_rms_vs_f32_mode": float(np.sqrt(np.mean((voc_pcm["f16"] - ref64) ** 2))),
+                      "ms_bf16x3_mode": round(voc_ms["bf16x3"], 2),
+                      "pcm_rms_bf16x3_vs_f32_mode": float(np.sqrt(np.mean((voc_pcm["bf16x3"] - ref64) ** 2))),
+                      "ms_f32_mode": round(voc_ms["f32"], 2), "signal_rms": float(np.sqrt(np.mean(ref64 ** 2)))}
     # FireflyCodec.encode of a 10 s clip (mel front-end + ConvNeXt encoder + FSQ), host buffers in/out
     t = np.arange(441000) / 44100.0
     clip = (0.3 * np.sin(2 * np.pi * 220.0 * t) + 0.05 * np.random.RandomState(2).randn(t.size)).astype(np.float32)[None, None]

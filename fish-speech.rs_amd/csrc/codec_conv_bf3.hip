@@ -47,25 +47,49 @@ __device__ __forceinline__ uint32_t c3_bf16(float f) {  // round to nearest even
     uint32_t u = __float_as_uint(f);
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
+__device__ __forceinline__ uint32_t c3_f16(float f) {  // round to nearest even, saturating (|f| > 65504 does not occur in the vocoder)
+    return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)__builtin_amdgcn_fmed3f(f, -65504.f, 65504.f));
+}
+// F16 = false: v = hi + lo in bf16 ("bf16x3"); F16 = true: one f16 value ("f16": `lo` is not used by any caller)
+template <bool F16>
 __device__ __forceinline__ void c3_split(float v, uint32_t& hi, uint32_t& lo) {
-    hi = c3_bf16(v);
-    lo = c3_bf16(v - __uint_as_float(hi << 16));
+    if constexpr (F16) {
+        hi = c3_f16(v);
+        lo = 0;
+    } else {
+        hi = c3_bf16(v);
+        lo = c3_bf16(v - __uint_as_float(hi << 16));
+    }
+}
+// one 16-item reduction step of an accumulator tile: (hi*hi, hi*lo, lo*hi) in bf16, or the single f16 product
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <bool F16>
+__device__ __forceinline__ f32x16 c3_mma(u32x4 ah, u32x4 al, u32x4 bh, u32x4 bl, f32x16 acc) {
+    if constexpr (F16) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bh), acc, 0, 0, 0);
+    } else {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl), acc, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh), acc, 0, 0, 0);
+    }
 }
 
 // dst[((ib*K + k)*4 + p) * Cp + o][e] from the re-laid f32 weight src[(i*K + k)*Cout + o]
+template <bool F16>
 __global__ void k_pack_bf3(const float* __restrict__ src, uint16_t* __restrict__ dst, int Cin, int K, int Cout, int Cp) {
+    constexpr int NPL = F16 ? 2 : 4;
     const int nib = (Cin + 15) / 16;
-    const size_t n = (size_t)nib * K * 4 * Cp * 8;
+    const size_t n = (size_t)nib * K * NPL * Cp * 8;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
         const int e = (int)(idx & 7);
         size_t r = idx >> 3;
         const int o = (int)(r % Cp); r /= Cp;
-        const int p = (int)(r & 3); r >>= 2;
+        const int p = (int)(r % NPL); r /= NPL;
         const int k = (int)(r % K);
         const int ib = (int)(r / K);
         const int i = ib * 16 + (p & 1) * 8 + e;
         uint32_t hi = 0, lo = 0;
-        if (i < Cin && o < Cout) c3_split(src[((size_t)i * K + k) * Cout + o], hi, lo);
+        if (i < Cin && o < Cout) c3_split<F16>(src[((size_t)i * K + k) * Cout + o], hi, lo);
         dst[idx] = (uint16_t)((p >> 1) ? lo : hi);
     }
 }
@@ -92,20 +116,23 @@ __device__ unsigned long long g_c3prof[8];
 #define C3_TICK(slot) do {} while (0)
 #endif
 
+template <bool F16>
 __device__ __forceinline__ void c3_zero_pad(uint16_t* pb, int CG, int T, int g_first, int n_groups, int tid, int nthreads) {
+    constexpr int NP = F16 ? 1 : 2;
     const u32x4 z{0u, 0u, 0u, 0u};
-    for (int e = tid; e < n_groups * 2 * PP; e += nthreads) {
-        const int slot = e % PP, gp = e / PP, g = g_first + (gp >> 1), part = gp & 1;
+    for (int e = tid; e < n_groups * NP * PP; e += nthreads) {
+        const int slot = e % PP, gp = e / PP, g = g_first + gp / NP, part = gp % NP;
         if (g < CG) *reinterpret_cast<u32x4*>(pb + ((size_t)(part * CG + g) * (PP + T) + slot) * 8) = z;
     }
 }
 
 // f32 (C, T) -> planes, optional SiLU.  One thread per (8-channel group, t).
+template <bool F16>
 __global__ void k_act_split(const float* __restrict__ x, int C, int T, int silu, uint16_t* __restrict__ planes) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y, CG = C >> 3;
     const float* xb = x + (size_t)blockIdx.z * C * T;
-    uint16_t* pb = planes + (size_t)blockIdx.z * 2 * CG * (PP + T) * 8;
-    if (blockIdx.x == 0) c3_zero_pad(pb, CG, T, g, 1, threadIdx.x, blockDim.x);
+    uint16_t* pb = planes + (size_t)blockIdx.z * (F16 ? 1 : 2) * CG * (PP + T) * 8;
+    if (blockIdx.x == 0) c3_zero_pad<F16>(pb, CG, T, g, 1, threadIdx.x, blockDim.x);
     if (t >= T) return;
     u32x4 vh, vl;
 #pragma unroll
@@ -113,20 +140,21 @@ __global__ void k_act_split(const float* __restrict__ x, int C, int T, int silu,
         float a = xb[(size_t)(g * 8 + 2 * e) * T + t], b = xb[(size_t)(g * 8 + 2 * e + 1) * T + t];
         if (silu) { a = c3_silu(a); b = c3_silu(b); }
         uint32_t ah, al, bh, bl;
-        c3_split(a, ah, al); c3_split(b, bh, bl);
+        c3_split<F16>(a, ah, al); c3_split<F16>(b, bh, bl);
         vh[e] = ah | (bh << 16); vl[e] = al | (bl << 16);
     }
     *reinterpret_cast<u32x4*>(pb + ((size_t)g * (PP + T) + PP + t) * 8) = vh;
-    *reinterpret_cast<u32x4*>(pb + ((size_t)(CG + g) * (PP + T) + PP + t) * 8) = vl;
+    if constexpr (!F16) *reinterpret_cast<u32x4*>(pb + ((size_t)(CG + g) * (PP + T) + PP + t) * 8) = vl;
 }
 
 // ParallelBlock mean (hifi_gan.rs:114-117) straight into planes: split(silu?(((a + b) + c) / 3))
+template <bool F16>
 __global__ void k_mean3_planes(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c, int C, int T, int silu,
                                uint16_t* __restrict__ planes) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y, CG = C >> 3;
     const size_t boff = (size_t)blockIdx.z * C * T;
-    uint16_t* pb = planes + (size_t)blockIdx.z * 2 * CG * (PP + T) * 8;
-    if (blockIdx.x == 0) c3_zero_pad(pb, CG, T, g, 1, threadIdx.x, blockDim.x);
+    uint16_t* pb = planes + (size_t)blockIdx.z * (F16 ? 1 : 2) * CG * (PP + T) * 8;
+    if (blockIdx.x == 0) c3_zero_pad<F16>(pb, CG, T, g, 1, threadIdx.x, blockDim.x);
     if (t >= T) return;
     const float third = (float)(1.0 / 3.0);
     u32x4 vh, vl;
@@ -136,11 +164,11 @@ __global__ void k_mean3_planes(const float* __restrict__ a, const float* __restr
         float u = ((a[i0] + b[i0]) + c[i0]) * third, v = ((a[i1] + b[i1]) + c[i1]) * third;
         if (silu) { u = c3_silu(u); v = c3_silu(v); }
         uint32_t uh, ul, wh, wl;
-        c3_split(u, uh, ul); c3_split(v, wh, wl);
+        c3_split<F16>(u, uh, ul); c3_split<F16>(v, wh, wl);
         vh[e] = uh | (wh << 16); vl[e] = ul | (wl << 16);
     }
     *reinterpret_cast<u32x4*>(pb + ((size_t)g * (PP + T) + PP + t) * 8) = vh;
-    *reinterpret_cast<u32x4*>(pb + ((size_t)(CG + g) * (PP + T) + PP + t) * 8) = vl;
+    if constexpr (!F16) *reinterpret_cast<u32x4*>(pb + ((size_t)(CG + g) * (PP + T) + PP + t) * 8) = vl;
 }
 
 // Epilogue shared by the conv kernels.  D[row][col] of v_mfma_f32_32x32x*: register r of lane (h, c) holds row (r/4)*8 + h*4 + r%4,
@@ -151,7 +179,7 @@ __global__ void k_mean3_planes(const float* __restrict__ a, const float* __restr
 // (always valid) addresses, so one memory round trip covers the tile -- with a validity branch around every output the loads were
 // issued one at a time and the epilogue took half of a block's life; with a runtime kind switch every output carried the GELU /
 // tanh / polyphase code (7 k instructions).
-template <int NT, int E, bool PS1>
+template <bool F16, int NT, int E, bool PS1>
 __device__ __forceinline__ void c3_epilogue_k(const f32x16 (&acc)[NT], int ob, int tbase, int h, int c, int Cout, int T, int ps,
                                               const float* __restrict__ bias, const float* __restrict__ res, const float* __restrict__ gamma,
                                               float* __restrict__ y, uint16_t* __restrict__ ypb, int post_silu) {
@@ -192,10 +220,11 @@ __device__ __forceinline__ void c3_epilogue_k(const f32x16 (&acc)[NT], int ob, i
             if (ypb && ob8 < Cout && t < T) {
                 uint32_t hi[4], lo[4];
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) c3_split(post_silu ? c3_silu_fast(v4[rr]) : v4[rr], hi[rr], lo[rr]);
+                for (int rr = 0; rr < 4; ++rr) c3_split<F16>(post_silu ? c3_silu_fast(v4[rr]) : v4[rr], hi[rr], lo[rr]);
                 uint16_t* d = ypb + ((size_t)(ob8 >> 3) * (PP + T) + PP + t) * 8 + h * 4;
                 *reinterpret_cast<uint2*>(d) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
-                *reinterpret_cast<uint2*>(d + (size_t)CGo * (PP + T) * 8) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+                if constexpr (!F16)
+                    *reinterpret_cast<uint2*>(d + (size_t)CGo * (PP + T) * 8) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
             }
         }
     }
@@ -204,19 +233,19 @@ __device__ __forceinline__ void c3_epilogue_k(const f32x16 (&acc)[NT], int ob, i
 // D[row][col] of v_mfma_f32_32x32x*: register r of lane (h, c) holds row (r/4)*8 + h*4 + r%4, column c.  ob = first GEMM row of the wave's
 // 32-row tile, tbase = first sample of its NT 32-sample tiles; y / res already carry the batch offset, ypb is the batch item's plane base
 // (or null).  EPI >= 0: compile-time kind (the plane kernels are instantiated per kind); EPI < 0: runtime `epi` (one specialised loop each).
-template <int NT, int EPI = -1, bool PS1 = false>
+template <bool F16, int NT, int EPI = -1, bool PS1 = false>
 __device__ __forceinline__ void c3_epilogue(const f32x16 (&acc)[NT], int ob, int tbase, int h, int c, int Cout, int T, int ps,
                                             const float* __restrict__ bias, int epi, const float* __restrict__ res,
                                             const float* __restrict__ gamma, float* __restrict__ y, uint16_t* __restrict__ ypb,
                                             int post_silu) {
     if constexpr (EPI >= 0) {
-        c3_epilogue_k<NT, EPI, PS1>(acc, ob, tbase, h, c, Cout, T, ps, bias, res, gamma, y, ypb, post_silu);
+        c3_epilogue_k<F16, NT, EPI, PS1>(acc, ob, tbase, h, c, Cout, T, ps, bias, res, gamma, y, ypb, post_silu);
     } else {
-        if (epi == CODEC_EPI_GELU) c3_epilogue_k<NT, CODEC_EPI_GELU, false>(acc, ob, tbase, h, c, Cout, T, ps, bias, res, gamma, y, ypb, post_silu);
-        else if (epi == CODEC_EPI_GAMMA_RES) c3_epilogue_k<NT, CODEC_EPI_GAMMA_RES, false>(acc, ob, tbase, h, c, Cout, T, ps, bias, res, gamma, y, ypb, post_silu);
-        else if (epi == CODEC_EPI_RES) c3_epilogue_k<NT, CODEC_EPI_RES, false>(acc, ob, tbase, h, c, Cout, T, ps, bias, res, gamma, y, ypb, post_silu);
-        else if (epi == CODEC_EPI_TANH) c3_epilogue_k<NT, CODEC_EPI_TANH, false>(acc, ob, tbase, h, c, Cout, T, ps, bias, res, gamma, y, ypb, post_silu);
-        else c3_epilogue_k<NT, CODEC_EPI_NONE, false>(acc, ob, tbase, h, c, Cout, T, ps, bias, res, gamma, y, ypb, post_silu);
+        if (epi == CODEC_EPI_GELU) c3_epilogue_k<F16, NT, CODEC_EPI_GELU, false>(acc, ob, tbase, h, c, Cout, T, ps, bias, res, gamma, y, ypb, post_silu);
+        else if (epi == CODEC_EPI_GAMMA_RES) c3_epilogue_k<F16, NT, CODEC_EPI_GAMMA_RES, false>(acc, ob, tbase, h, c, Cout, T, ps, bias, res, gamma, y, ypb, post_silu);
+        else if (epi == CODEC_EPI_RES) c3_epilogue_k<F16, NT, CODEC_EPI_RES, false>(acc, ob, tbase, h, c, Cout, T, ps, bias, res, gamma, y, ypb, post_silu);
+        else if (epi == CODEC_EPI_TANH) c3_epilogue_k<F16, NT, CODEC_EPI_TANH, false>(acc, ob, tbase, h, c, Cout, T, ps, bias, res, gamma, y, ypb, post_silu);
+        else c3_epilogue_k<F16, NT, CODEC_EPI_NONE, false>(acc, ob, tbase, h, c, Cout, T, ps, bias, res, gamma, y, ypb, post_silu);
     }
 }
 
@@ -224,7 +253,7 @@ __device__ __forceinline__ void c3_epilogue(const f32x16 (&acc)[NT], int ob, int
 // OT: output channels per block (64 | 32); TT: samples per block; NIBS: 16-channel blocks per stage; KMAX: largest tap count the
 // register prefetch is sized for; NPX: window positions per thread (XS = TT + halo <= 256 * NPX).
 // Outputs: f32 `y` (may be null when only planes are wanted) and / or planes `yp` (ps == 1 only) = split(post_silu ? silu(v) : v)
-template <int OT, int TT, int NIBS, int KMAX, int NPX>
+template <bool F16, int OT, int TT, int NIBS, int KMAX, int NPX>
 __global__ __launch_bounds__(256) void k_conv1d_bf3(const float* __restrict__ x, int Cin, int T, const uint16_t* __restrict__ wp, int Cp,
                                                     const float* __restrict__ bias, int Cout, int K, int dil, int pre_silu, int epi,
                                                     const float* __restrict__ res, const float* __restrict__ gamma, float* __restrict__ y,
@@ -232,19 +261,20 @@ __global__ __launch_bounds__(256) void k_conv1d_bf3(const float* __restrict__ x,
     constexpr int WT_ = OT == 64 ? TT / 2 : TT / 4;  // samples per wave
     constexpr int NT = WT_ / 32;                     // 32-sample MFMA tiles per wave
     static_assert(NT >= 1 && (OT == 64 || OT == 32), "block shape");
-    constexpr int NWC = (NIBS * KMAX * 4 * OT + 255) / 256;  // 16-byte weight chunks per thread per stage
+    constexpr int NPL = F16 ? 2 : 4;                         // operand planes per 16-channel block: parts x channel halves
+    constexpr int NWC = (NIBS * KMAX * NPL * OT + 255) / 256;  // 16-byte weight chunks per thread per stage
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int halo = (K - 1) * dil, XS = TT + halo;
     const int nib = (Cin + 15) >> 4, nst = (nib + NIBS - 1) / NIBS;
     const bool resident = nst == 1;
-    u32x4* xs = reinterpret_cast<u32x4*>(smem_raw);      // [NIBS][4][XS]
-    u32x4* ws = xs + NIBS * 4 * XS;                      // [NIBS][K][4][OT]
+    u32x4* xs = reinterpret_cast<u32x4*>(smem_raw);      // [NIBS][NPL][XS]
+    u32x4* ws = xs + NIBS * NPL * XS;                    // [NIBS][K][NPL][OT]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, c = lane & 31;
     const int ob = OT == 64 ? (wave & 1) * 32 : 0, tb = OT == 64 ? (wave >> 1) * WT_ : wave * WT_;
     const int o0 = blockIdx.y * OT;
     const size_t boff_in = (size_t)blockIdx.z * Cin * T, boff_out = (size_t)blockIdx.z * Cout * T;
-    const int wchunks = K * 4 * OT;  // per 16-channel block
+    const int wchunks = K * NPL * OT;  // per 16-channel block
 
     float xr[NPX][NIBS][16];
     u32x4 wr[NWC];
@@ -270,8 +300,8 @@ __global__ __launch_bounds__(256) void k_conv1d_bf3(const float* __restrict__ x,
                 if (tl < XS) {
                     uint32_t hi[16], lo[16];
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) c3_split(pre_silu ? c3_silu(xr[q][b][i]) : xr[q][b][i], hi[i], lo[i]);
-                    u32x4* d = xs + (b * 4) * XS + tl;
+                    for (int i = 0; i < 16; ++i) c3_split<F16>(pre_silu ? c3_silu(xr[q][b][i]) : xr[q][b][i], hi[i], lo[i]);
+                    u32x4* d = xs + (b * NPL) * XS + tl;
 #pragma unroll
                     for (int hf = 0; hf < 2; ++hf) {
                         u32x4 vh, vl;
@@ -281,7 +311,7 @@ __global__ __launch_bounds__(256) void k_conv1d_bf3(const float* __restrict__ x,
                             vl[e] = lo[hf * 8 + 2 * e] | (lo[hf * 8 + 2 * e + 1] << 16);
                         }
                         d[hf * XS] = vh;
-                        d[(2 + hf) * XS] = vl;
+                        if constexpr (!F16) d[(2 + hf) * XS] = vl;
                     }
                 }
             }
@@ -292,7 +322,7 @@ __global__ __launch_bounds__(256) void k_conv1d_bf3(const float* __restrict__ x,
         for (int j = 0; j < NWC; ++j) {
             const int e = j * 256 + tid, b = NIBS == 1 ? 0 : e / wchunks, r = e - b * wchunks, kp = r / OT, o = r % OT;
             const int ib = st * NIBS + b;
-            if (e < NIBS * wchunks && ib < nib) wr[j] = *reinterpret_cast<const u32x4*>(wp + (((size_t)ib * K * 4 + kp) * Cp + o0 + o) * 8);
+            if (e < NIBS * wchunks && ib < nib) wr[j] = *reinterpret_cast<const u32x4*>(wp + (((size_t)ib * K * NPL + kp) * Cp + o0 + o) * 8);
             else wr[j] = u32x4{0u, 0u, 0u, 0u};
         }
     };
@@ -328,24 +358,22 @@ __global__ __launch_bounds__(256) void k_conv1d_bf3(const float* __restrict__ x,
             }
             const int nb = min(NIBS, nib - st * NIBS);
             for (int b = 0; b < nb; ++b) {
-                const u32x4* wl = ws + (b * K * 4 + h) * OT + ob + c;
-                const u32x4* xl = xs + (b * 4 + h) * XS + tb + c;
+                const u32x4* wl = ws + (b * K * NPL + h) * OT + ob + c;
+                const u32x4* xl = xs + (b * NPL + h) * XS + tb + c;
                 for (int k = 0; k < K; ++k) {
-                    const bf16x8 ah = __builtin_bit_cast(bf16x8, wl[k * 4 * OT]), al = __builtin_bit_cast(bf16x8, wl[(k * 4 + 2) * OT]);
+                    const u32x4 ah = wl[k * NPL * OT], al = F16 ? ah : wl[(k * NPL + 2) * OT];
                     const u32x4* xk = xl + k * dil;
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
-                        const bf16x8 bh = __builtin_bit_cast(bf16x8, xk[32 * j]), bl = __builtin_bit_cast(bf16x8, xk[2 * XS + 32 * j]);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
+                        const u32x4 bh = xk[32 * j], bl = F16 ? bh : xk[2 * XS + 32 * j];
+                        acc[j] = c3_mma<F16>(ah, al, bh, bl, acc[j]);
                     }
                 }
             }
         }
-        uint16_t* ypb = yp ? yp + (size_t)blockIdx.z * 2 * (Cout >> 3) * (PP + T) * 8 : nullptr;
-        if (ypb && t0 == 0) c3_zero_pad(ypb, Cout >> 3, T, o0 >> 3, OT / 8, tid, 256);
-        c3_epilogue<NT>(acc, o0 + ob, t0 + tb, h, c, Cout, T, ps, bias, epi, res ? res + boff_out : nullptr, gamma, y ? y + boff_out : nullptr,
+        uint16_t* ypb = yp ? yp + (size_t)blockIdx.z * (F16 ? 1 : 2) * (Cout >> 3) * (PP + T) * 8 : nullptr;
+        if (ypb && t0 == 0) c3_zero_pad<F16>(ypb, Cout >> 3, T, o0 >> 3, OT / 8, tid, 256);
+        c3_epilogue<F16, NT>(acc, o0 + ob, t0 + tb, h, c, Cout, T, ps, bias, epi, res ? res + boff_out : nullptr, gamma, y ? y + boff_out : nullptr,
                         ypb, post_silu);
     }
 }
@@ -354,30 +382,31 @@ __global__ __launch_bounds__(256) void k_conv1d_bf3(const float* __restrict__ x,
 // (global_load_lds_dwordx4: 64 consecutive 16-byte slots per wave instruction, destination = wave-uniform base + lane * 16, source =
 // uniform base + lane * 16: no per-lane address arithmetic, no staging registers).  Two or three blocks share a CU (LDS 42..65 KB
 // each), so one block's DMA wait overlaps another's MFMA phase.  Requires Cin % 16 == 0.
-template <int OT, int TT, int KMAX, int EPI, bool PS1, int NIBS = 1>
+template <bool F16, int OT, int TT, int KMAX, int EPI, bool PS1, int NIBS = 1>
 __global__ __launch_bounds__(256, 2) void k_conv1d_bf3p(const uint16_t* __restrict__ xp, int Cin, int T, const uint16_t* __restrict__ wp,
                                                         int Cp, const float* __restrict__ bias, int Cout, int K, int dil, int epi,
                                                         const float* __restrict__ res, const float* __restrict__ gamma,
                                                         float* __restrict__ y, uint16_t* __restrict__ yp, int post_silu, int ps) {
     constexpr int WT_ = OT == 64 ? TT / 2 : TT / 4, NT = WT_ / 32;
     static_assert(NT >= 1 && (OT == 64 || OT == 32), "block shape");
-    constexpr int NWP = (NIBS * KMAX * 4 * OT + 255) / 256;  // weight DMA pieces (256 chunks each) per stage, upper bound
+    constexpr int NPL = F16 ? 2 : 4, NPART = F16 ? 1 : 2;       // operand planes per 16-channel block (parts x channel halves)
+    constexpr int NWP = (NIBS * KMAX * NPL * OT + 255) / 256;  // weight DMA pieces (256 chunks each) per stage, upper bound
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int halo = (K - 1) * dil, XSP = (TT + halo + 63) & ~63;
     const int nst = (Cin >> 4) / NIBS, CGi = Cin >> 3;  // stages of NIBS 16-channel blocks (NIBS > 1: pointwise convs, K = 1)
-    u32x4* xs = reinterpret_cast<u32x4*>(smem_raw);  // [NIBS][4][XSP]
-    u32x4* ws = xs + NIBS * 4 * XSP;                 // [NIBS][K][4][OT]
+    u32x4* xs = reinterpret_cast<u32x4*>(smem_raw);  // [NIBS][NPL][XSP]
+    u32x4* ws = xs + NIBS * NPL * XSP;               // [NIBS][K][NPL][OT]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, c = lane & 31;
     const int ob = OT == 64 ? (wave & 1) * 32 : 0, tb = OT == 64 ? (wave >> 1) * WT_ : wave * WT_;
     const int o0 = blockIdx.y * OT, t0 = blockIdx.x * TT;
     const size_t boff_out = (size_t)blockIdx.z * Cout * T;
     const size_t row = (size_t)(PP + T);  // slots per (part, group) row
-    const u32x4* xpb = reinterpret_cast<const u32x4*>(xp) + (size_t)blockIdx.z * 2 * CGi * row + (PP + t0 - halo) + lane;
+    const u32x4* xpb = reinterpret_cast<const u32x4*>(xp) + (size_t)blockIdx.z * NPART * CGi * row + (PP + t0 - halo) + lane;
     // weight chunk (piece j, wave, lane) = chunk index e = j*256 + wave*64 + lane -> row kp = e / OT, column e % OT
     const int wl_off = OT == 64 ? lane : (lane >> 5) * Cp + (lane & 31);
     const u32x4* wpl = reinterpret_cast<const u32x4*>(wp) + o0 + wl_off;
-    const int wtotal = NIBS * K * 4 * OT;  // chunks per stage: a multiple of 64, so a piece is whole per wave
+    const int wtotal = NIBS * K * NPL * OT;  // chunks per stage: a multiple of 64, so a piece is whole per wave
     auto dma = [&](const u32x4* src, u32x4* dst_wave_base) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst_wave_base, 16, 0, 0);
@@ -398,13 +427,13 @@ __global__ __launch_bounds__(256, 2) void k_conv1d_bf3p(const uint16_t* __restri
 #pragma unroll
         for (int b = 0; b < NIBS; ++b)
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
+            for (int p = 0; p < NPL; ++p) {
                 const u32x4* src = xpb + ((size_t)((p >> 1) * CGi + 2 * (st * NIBS + b) + (p & 1))) * row;
-                for (int q = wave * 64; q < XSP; q += 256) dma(src + q, xs + (b * 4 + p) * XSP + q);
+                for (int q = wave * 64; q < XSP; q += 256) dma(src + q, xs + (b * NPL + p) * XSP + q);
             }
         // weight tiles [NIBS][K][4][OT] of these channel blocks: consecutive chunk rows of the packed tensor, Cp apart in global memory
         {
-            const u32x4* src = wpl + (size_t)st * NIBS * K * 4 * Cp;
+            const u32x4* src = wpl + (size_t)st * NIBS * K * NPL * Cp;
             constexpr int RPP = 256 / OT;  // chunk rows per piece
 #pragma unroll
             for (int j = 0; j < NWP; ++j)
@@ -417,28 +446,37 @@ __global__ __launch_bounds__(256, 2) void k_conv1d_bf3p(const uint16_t* __restri
         C3_TICK(3);
 #pragma unroll
         for (int b = 0; b < NIBS; ++b) {
-            const u32x4* wl = ws + (b * K * 4 + h) * OT + ob + c;
-            const u32x4* xl = xs + (b * 4 + h) * XSP + tb + c;
+            const u32x4* wl = ws + (b * K * NPL + h) * OT + ob + c;
+            const u32x4* xl = xs + (b * NPL + h) * XSP + tb + c;
             for (int k = 0; k < K; ++k) {
-                const bf16x8 ah = __builtin_bit_cast(bf16x8, wl[k * 4 * OT]), al = __builtin_bit_cast(bf16x8, wl[(k * 4 + 2) * OT]);
                 const u32x4* xk = xl + k * dil;
-                // (per accumulator the order stays hi*hi, hi*lo, lo*hi; the NT tiles are interleaved so that dependent MFMAs are NT apart)
-                bf16x8 bh[NT], bl[NT];
+                if constexpr (F16) {
+                    const f16x8 a = __builtin_bit_cast(f16x8, wl[k * NPL * OT]);
+                    f16x8 bv[NT];
 #pragma unroll
-                for (int j = 0; j < NT; ++j) { bh[j] = __builtin_bit_cast(bf16x8, xk[32 * j]); bl[j] = __builtin_bit_cast(bf16x8, xk[2 * XSP + 32 * j]); }
+                    for (int j = 0; j < NT; ++j) bv[j] = __builtin_bit_cast(f16x8, xk[32 * j]);
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[j], 0, 0, 0);
+                    for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bv[j], acc[j], 0, 0, 0);
+                } else {
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, wl[k * 4 * OT]), al = __builtin_bit_cast(bf16x8, wl[(k * 4 + 2) * OT]);
+                    // (per accumulator the order stays hi*hi, hi*lo, lo*hi; the NT tiles are interleaved so that dependent MFMAs are NT apart)
+                    bf16x8 bh[NT], bl[NT];
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[j], 0, 0, 0);
+                    for (int j = 0; j < NT; ++j) { bh[j] = __builtin_bit_cast(bf16x8, xk[32 * j]); bl[j] = __builtin_bit_cast(bf16x8, xk[2 * XSP + 32 * j]); }
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[j], 0, 0, 0);
+                    for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[j], 0, 0, 0);
+                }
             }
         }
         C3_TICK(4);
     }
-    uint16_t* ypb = yp ? yp + (size_t)blockIdx.z * 2 * (Cout >> 3) * row * 8 : nullptr;
-    if (ypb && t0 == 0) c3_zero_pad(ypb, Cout >> 3, T, o0 >> 3, OT / 8, tid, 256);
-    c3_epilogue<NT, EPI, PS1>(acc, o0 + ob, t0 + tb, h, c, Cout, T, ps, bias, epi, res ? res + boff_out : nullptr, gamma,
+    uint16_t* ypb = yp ? yp + (size_t)blockIdx.z * NPART * (Cout >> 3) * row * 8 : nullptr;
+    if (ypb && t0 == 0) c3_zero_pad<F16>(ypb, Cout >> 3, T, o0 >> 3, OT / 8, tid, 256);
+    c3_epilogue<F16, NT, EPI, PS1>(acc, o0 + ob, t0 + tb, h, c, Cout, T, ps, bias, epi, res ? res + boff_out : nullptr, gamma,
                               y ? y + boff_out : nullptr, ypb, post_silu);
     C3_TICK(5);
 #ifdef FS_C3_PROF
@@ -452,27 +490,28 @@ __global__ __launch_bounds__(256, 2) void k_conv1d_bf3p(const uint16_t* __restri
 // set (<= 45 KB) is loaded into LDS once, then every wave walks over its own 32-channel x (32 * NT)-sample tiles and loads its MFMA
 // B operands -- 16-byte plane slots, 512 contiguous bytes per half-wave -- straight from global memory (the K taps of a tile re-read
 // the same window from L1/L2).  No barrier after the weight load, so a CU keeps as many independent waves in flight as registers allow.
-template <int K, int NIB, int NT, int EPI, bool PS1>
+template <bool F16, int K, int NIB, int NT, int EPI, bool PS1>
 __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void k_conv1d_bf3t(const uint16_t* __restrict__ xp, int T, const uint16_t* __restrict__ wp, int Cp,
                                                         const float* __restrict__ bias, int Cout, int dil, int epi,
                                                         const float* __restrict__ res, const float* __restrict__ gamma,
                                                         float* __restrict__ y, uint16_t* __restrict__ yp, int post_silu, int ps, int nwt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    u32x4* ws = reinterpret_cast<u32x4*>(smem_raw);  // [NIB][K][4][32]
-    constexpr int CGi = NIB * 2, WCH = NIB * K * 4 * 32;
+    u32x4* ws = reinterpret_cast<u32x4*>(smem_raw);  // [NIB][K][NPL][32]
+    constexpr int NPL = F16 ? 2 : 4, NPART = F16 ? 1 : 2;
+    constexpr int CGi = NIB * 2, WCH = NIB * K * NPL * 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, c = lane & 31;
     const int o0 = blockIdx.y * 32, halo = (K - 1) * dil;
     const size_t row = (size_t)(PP + T);
     for (int e = tid; e < WCH; e += 256) {
-        const int kp = e >> 5, o = e & 31;  // kp = (ib * K + k) * 4 + plane
+        const int kp = e >> 5, o = e & 31;  // kp = (ib * K + k) * NPL + plane
         ws[e] = *reinterpret_cast<const u32x4*>(wp + ((size_t)kp * Cp + o0 + o) * 8);
     }
     __syncthreads();
-    const u32x4* xpb = reinterpret_cast<const u32x4*>(xp) + (size_t)blockIdx.z * 2 * CGi * row + PP - halo + c;
+    const u32x4* xpb = reinterpret_cast<const u32x4*>(xp) + (size_t)blockIdx.z * NPART * CGi * row + PP - halo + c;
     const size_t boff_out = (size_t)blockIdx.z * Cout * T;
-    uint16_t* ypb = yp ? yp + (size_t)blockIdx.z * 2 * (Cout >> 3) * row * 8 : nullptr;
-    if (ypb && blockIdx.x == 0) c3_zero_pad(ypb, Cout >> 3, T, o0 >> 3, 4, tid, 256);
+    uint16_t* ypb = yp ? yp + (size_t)blockIdx.z * NPART * (Cout >> 3) * row * 8 : nullptr;
+    if (ypb && blockIdx.x == 0) c3_zero_pad<F16>(ypb, Cout >> 3, T, o0 >> 3, 4, tid, 256);
     for (int wt = blockIdx.x * 4 + wave; wt < nwt; wt += gridDim.x * 4) {
         const int t0 = wt * (32 * NT);
         f32x16 acc[NT];
@@ -487,44 +526,42 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void k_conv1d_bf3t(const uint
         {
             const u32x4* b0 = bsrc(0);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) { bh[j] = b0[32 * j]; bl[j] = b0[(size_t)CGi * row + 32 * j]; }
+            for (int j = 0; j < NT; ++j) { bh[j] = b0[32 * j]; bl[j] = F16 ? bh[j] : b0[(size_t)CGi * row + 32 * j]; }
         }
 #pragma unroll 2
         for (int i = 0; i < NIB * K; ++i) {
             if (i + 1 < NIB * K) {
                 const u32x4* b1 = bsrc(i + 1);
 #pragma unroll
-                for (int j = 0; j < NT; ++j) { nh[j] = b1[32 * j]; nl[j] = b1[(size_t)CGi * row + 32 * j]; }
+                for (int j = 0; j < NT; ++j) { nh[j] = b1[32 * j]; nl[j] = F16 ? nh[j] : b1[(size_t)CGi * row + 32 * j]; }
             }
-            const u32x4* wl = ws + (i * 4 + h) * 32 + c;
-            const bf16x8 ah = __builtin_bit_cast(bf16x8, wl[0]), al = __builtin_bit_cast(bf16x8, wl[64]);
+            const u32x4* wl = ws + (i * NPL + h) * 32 + c;
+            const u32x4 ah = wl[0], al = F16 ? ah : wl[64];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, bh[j]), acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, bl[j]), acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, __builtin_bit_cast(bf16x8, bh[j]), acc[j], 0, 0, 0);
-            }
+            for (int j = 0; j < NT; ++j) acc[j] = c3_mma<F16>(ah, al, bh[j], bl[j], acc[j]);
 #pragma unroll
             for (int j = 0; j < NT; ++j) { bh[j] = nh[j]; bl[j] = nl[j]; }
         }
         int Tl = T;  // opaque per tile: keeps the epilogue's ~100 row addresses from being hoisted out of the tile loop (200+ VGPRs)
         asm volatile("" : "+s"(Tl));
-        c3_epilogue<NT, EPI, PS1>(acc, o0, t0, h, c, Cout, Tl, ps, bias, epi, res ? res + boff_out : nullptr, gamma, y ? y + boff_out : nullptr,
+        c3_epilogue<F16, NT, EPI, PS1>(acc, o0, t0, h, c, Cout, Tl, ps, bias, epi, res ? res + boff_out : nullptr, gamma, y ? y + boff_out : nullptr,
                                   ypb, post_silu);
     }
 }
 
 }  // namespace
 
-size_t codec_pack_bf3_elems(int Cin, int K, int Cout) {
+size_t codec_pack_bf3_elems(int Cin, int K, int Cout, bool f16) {
     const int Cp = (Cout + 63) / 64 * 64;
-    return (size_t)((Cin + 15) / 16) * K * 4 * Cp * 8;
+    return (size_t)((Cin + 15) / 16) * K * (f16 ? 2 : 4) * Cp * 8;
 }
 
-void codec_pack_bf3(const float* relaid, uint16_t* dst, int Cin, int K, int Cout, hipStream_t st) {
+void codec_pack_bf3(const float* relaid, uint16_t* dst, int Cin, int K, int Cout, bool f16, hipStream_t st) {
     const int Cp = (Cout + 63) / 64 * 64;
-    const size_t n = codec_pack_bf3_elems(Cin, K, Cout);
-    hipLaunchKernelGGL(k_pack_bf3, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, st, relaid, dst, Cin, K, Cout, Cp);
+    const size_t n = codec_pack_bf3_elems(Cin, K, Cout, f16);
+    const dim3 grid((unsigned)std::min<size_t>((n + 255) / 256, 4096));
+    if (f16) hipLaunchKernelGGL(k_pack_bf3<true>, grid, dim3(256), 0, st, relaid, dst, Cin, K, Cout, Cp);
+    else hipLaunchKernelGGL(k_pack_bf3<false>, grid, dim3(256), 0, st, relaid, dst, Cin, K, Cout, Cp);
     FS_HIP(hipGetLastError());
 }
 
@@ -532,9 +569,11 @@ bool codec_conv1d_bf3_ok(int Cin, int Cout, int K, int dil) { return Cin >= 16 &
 
 // x (B, Cin, T) f32 or xp (activation planes) -> y (f32, may be null) and / or yp (planes, ps == 1); `Cout` = GEMM rows (channels * ps
 // for a polyphase transposed conv)
-void codec_conv1d_bf3(const float* x, const uint16_t* xp, int B, int Cin, int T, const uint16_t* wp, const float* bias, int Cout, int K,
-                      int dil, bool pre_silu, int epi, const float* res, const float* gamma, float* y, uint16_t* yp, bool post_silu, int ps,
-                      hipStream_t st) {
+template <bool F16>
+static void conv1d_bf3_impl(const float* x, const uint16_t* xp, int B, int Cin, int T, const uint16_t* wp, const float* bias, int Cout, int K,
+                            int dil, bool pre_silu, int epi, const float* res, const float* gamma, float* y, uint16_t* yp, bool post_silu, int ps,
+                            hipStream_t st) {
+    constexpr int NPL = F16 ? 2 : 4;
     FS_REQUIRE(codec_conv1d_bf3_ok(Cin, Cout, K, dil), "conv shape outside the bf16x3 kernel's range");
     FS_REQUIRE((x != nullptr) != (xp != nullptr), "exactly one of the f32 input and the plane input");
     FS_REQUIRE(y || yp, "no output");
@@ -554,16 +593,16 @@ void codec_conv1d_bf3(const float* x, const uint16_t* xp, int B, int Cin, int T,
             // pointwise convs (ConvNeXt MLPs, the k = s = 2 upsampling convs in polyphase form): 8 channel blocks per stage
             FS_REQUIRE(epi == CODEC_EPI_NONE || ((epi == CODEC_EPI_GELU || epi == CODEC_EPI_GAMMA_RES) && ps1), "pointwise plane conv: epilogue kind");
             constexpr int OT = 32, TT = 128, NIBS = 8;
-            const size_t smem = 16 * ((size_t)NIBS * 4 * TT + (size_t)NIBS * 4 * OT);
+            const size_t smem = 16 * ((size_t)NIBS * NPL * TT + (size_t)NIBS * NPL * OT);
             auto go = [&](auto kern) {
                 raise_lds((const void*)kern, smem);
                 hipLaunchKernelGGL(kern, dim3((T + TT - 1) / TT, (Cout + OT - 1) / OT, B), dim3(256), smem, st, xp, Cin, T, wp, Cp, bias, Cout, K, dil,
                                    epi, res, gamma, y, yp, post_silu ? 1 : 0, ps);
             };
-            if (epi == CODEC_EPI_GELU) go(k_conv1d_bf3p<OT, TT, 1, CODEC_EPI_GELU, true, NIBS>);
-            else if (epi == CODEC_EPI_GAMMA_RES) go(k_conv1d_bf3p<OT, TT, 1, CODEC_EPI_GAMMA_RES, true, NIBS>);
-            else if (ps1) go(k_conv1d_bf3p<OT, TT, 1, CODEC_EPI_NONE, true, NIBS>);
-            else go(k_conv1d_bf3p<OT, TT, 1, CODEC_EPI_NONE, false, NIBS>);
+            if (epi == CODEC_EPI_GELU) go(k_conv1d_bf3p<F16, OT, TT, 1, CODEC_EPI_GELU, true, NIBS>);
+            else if (epi == CODEC_EPI_GAMMA_RES) go(k_conv1d_bf3p<F16, OT, TT, 1, CODEC_EPI_GAMMA_RES, true, NIBS>);
+            else if (ps1) go(k_conv1d_bf3p<F16, OT, TT, 1, CODEC_EPI_NONE, true, NIBS>);
+            else go(k_conv1d_bf3p<F16, OT, TT, 1, CODEC_EPI_NONE, false, NIBS>);
             FS_HIP(hipGetLastError());
             return;
         }
@@ -574,7 +613,7 @@ void codec_conv1d_bf3(const float* x, const uint16_t* xp, int B, int Cin, int T,
             constexpr int NT = 1;
             const int nwt = (T + 32 * NT - 1) / (32 * NT), ytiles = (Cout + 31) / 32;
             const int gx = std::max(1, std::min((nwt + 3) / 4, 768 / std::max(1, ytiles * B)));  // 3 blocks per CU, each walking over tiles
-            const size_t smem = (size_t)nib * K * 4 * 32 * 16;
+            const size_t smem = (size_t)nib * K * NPL * 32 * 16;
             auto go = [&](auto kern) {
                 raise_lds((const void*)kern, smem);
                 hipLaunchKernelGGL(kern, dim3(gx, ytiles, B), dim3(256), smem, st, xp, T, wp, Cp, bias, Cout, dil, epi, res, gamma, y, yp,
@@ -582,9 +621,9 @@ void codec_conv1d_bf3(const float* x, const uint16_t* xp, int B, int Cin, int T,
             };
 #define FS_THIN2(KK, NIB)                                                                        \
     do {                                                                                         \
-        if (resid) go(k_conv1d_bf3t<KK, NIB, NT, CODEC_EPI_RES, true>);                          \
-        else if (ps1) go(k_conv1d_bf3t<KK, NIB, NT, CODEC_EPI_NONE, true>);                      \
-        else go(k_conv1d_bf3t<KK, NIB, NT, CODEC_EPI_NONE, false>);                              \
+        if (resid) go(k_conv1d_bf3t<F16, KK, NIB, NT, CODEC_EPI_RES, true>);                     \
+        else if (ps1) go(k_conv1d_bf3t<F16, KK, NIB, NT, CODEC_EPI_NONE, true>);                 \
+        else go(k_conv1d_bf3t<F16, KK, NIB, NT, CODEC_EPI_NONE, false>);                         \
     } while (0)
 #define FS_THIN(KK)                            \
     do {                                       \
@@ -600,22 +639,23 @@ void codec_conv1d_bf3(const float* x, const uint16_t* xp, int B, int Cin, int T,
         } else {
             auto go = [&](auto kern, int OT, int TT) {
                 const int XSP = (TT + halo + 63) & ~63;
-                const size_t smem = 16 * ((size_t)4 * XSP + (size_t)K * 4 * OT);
+                const size_t smem = 16 * ((size_t)NPL * XSP + (size_t)K * NPL * OT);
                 raise_lds((const void*)kern, smem);
                 hipLaunchKernelGGL(kern, dim3((T + TT - 1) / TT, (Cout + OT - 1) / OT, B), dim3(256), smem, st, xp, Cin, T, wp, Cp, bias, Cout,
                                    K, dil, epi, res, gamma, y, yp, post_silu ? 1 : 0, ps);
             };
             FS_REQUIRE(K <= 13, "tap count above the plane kernel's staging bound");
             // measured per tile shape (profiles/r02_vocoder_calls.txt): 32-channel blocks win everywhere (3 blocks per CU; 64-channel blocks
-            // and double-buffered stages -- 1..2 blocks per CU -- were 5..30 % slower); 256-sample blocks where >= 1024 blocks remain
+            // and double-buffered stages -- 1..2 blocks per CU -- were 5..30 % slower); 256-sample blocks where >= 1024 blocks remain.
+            // Re-measured for the f16 mode in round 3 (half the LDS per block): 64-channel blocks +0..10 %, forced 128 / 256 samples +1 %
             static const char* cfg = getenv("FISHRT_BF3P_TT");  // tuning knob: force 128 / 256-sample blocks
             const long long b256 = (long long)((T + 255) / 256) * ((Cout + 31) / 32) * B;
             const int TT = cfg ? atoi(cfg) : (b256 >= 1024 ? 256 : 128);
 #define FS_WIDE(TTv)                                                                             \
     do {                                                                                         \
-        if (resid) go(k_conv1d_bf3p<32, TTv, 13, CODEC_EPI_RES, true>, 32, TTv);                 \
-        else if (ps1) go(k_conv1d_bf3p<32, TTv, 13, CODEC_EPI_NONE, true>, 32, TTv);             \
-        else go(k_conv1d_bf3p<32, TTv, 13, CODEC_EPI_NONE, false>, 32, TTv);                     \
+        if (resid) go(k_conv1d_bf3p<F16, 32, TTv, 13, CODEC_EPI_RES, true>, 32, TTv);            \
+        else if (ps1) go(k_conv1d_bf3p<F16, 32, TTv, 13, CODEC_EPI_NONE, true>, 32, TTv);        \
+        else go(k_conv1d_bf3p<F16, 32, TTv, 13, CODEC_EPI_NONE, false>, 32, TTv);                \
     } while (0)
             if (TT == 256) FS_WIDE(256);
             else FS_WIDE(128);
@@ -626,7 +666,7 @@ void codec_conv1d_bf3(const float* x, const uint16_t* xp, int B, int Cin, int T,
     }
     auto go = [&](auto kern, int OT, int TT, int NIBS, bool loop_tiles) {
         const int XS = TT + halo;
-        const size_t smem = 16 * ((size_t)NIBS * 4 * XS + (size_t)NIBS * K * 4 * OT);
+        const size_t smem = 16 * ((size_t)NIBS * NPL * XS + (size_t)NIBS * K * NPL * OT);
         raise_lds((const void*)kern, smem);
         const int ntiles = (T + TT - 1) / TT, ytiles = (Cout + OT - 1) / OT;
         int gx = ntiles;
@@ -636,32 +676,44 @@ void codec_conv1d_bf3(const float* x, const uint16_t* xp, int B, int Cin, int T,
     };
     if (K == 1 && Cin >= 128) {
         // pointwise convs of the ConvNeXt blocks (frame-rate T, 512..2048 channels): 8 channel blocks per barrier pair
-        go(k_conv1d_bf3<32, 128, 8, 1, 1>, 32, 128, 8, false);
+        go(k_conv1d_bf3<F16, 32, 128, 8, 1, 1>, 32, 128, 8, false);
     } else if (nib <= 2) {
         // thin layers: the whole weight set is resident, the block walks over time tiles
-        if (nib == 1) go(k_conv1d_bf3<32, 256, 1, 13, 2>, 32, 256, 1, true);
-        else go(k_conv1d_bf3<32, 128, 2, 13, 2>, 32, 128, 2, true);
+        if (nib == 1) go(k_conv1d_bf3<F16, 32, 256, 1, 13, 2>, 32, 256, 1, true);
+        else go(k_conv1d_bf3<F16, 32, 128, 2, 13, 2>, 32, 128, 2, true);
     } else {
         const bool tall = Cout >= 64 && (long long)((T + 127) / 128) * ((Cout + 63) / 64) * B >= 256;
         const int OT = tall ? 64 : 32;
         const bool wide = (long long)((T + 255) / 256) * ((Cout + OT - 1) / OT) * B >= 512;
-        if (OT == 64 && wide) go(k_conv1d_bf3<64, 256, 1, 13, 2>, 64, 256, 1, false);
-        else if (OT == 64) go(k_conv1d_bf3<64, 128, 1, 13, 2>, 64, 128, 1, false);
-        else if (wide) go(k_conv1d_bf3<32, 256, 1, 13, 2>, 32, 256, 1, false);
-        else go(k_conv1d_bf3<32, 128, 1, 13, 2>, 32, 128, 1, false);
+        if (OT == 64 && wide) go(k_conv1d_bf3<F16, 64, 256, 1, 13, 2>, 64, 256, 1, false);
+        else if (OT == 64) go(k_conv1d_bf3<F16, 64, 128, 1, 13, 2>, 64, 128, 1, false);
+        else if (wide) go(k_conv1d_bf3<F16, 32, 256, 1, 13, 2>, 32, 256, 1, false);
+        else go(k_conv1d_bf3<F16, 32, 128, 1, 13, 2>, 32, 128, 1, false);
     }
     FS_HIP(hipGetLastError());
 }
 
-void codec_act_split(const float* x, int B, int C, int T, bool silu, uint16_t* planes, hipStream_t st) {
+void codec_conv1d_bf3(const float* x, const uint16_t* xp, int B, int Cin, int T, const uint16_t* wp, bool f16, const float* bias, int Cout, int K,
+                      int dil, bool pre_silu, int epi, const float* res, const float* gamma, float* y, uint16_t* yp, bool post_silu, int ps,
+                      hipStream_t st) {
+    if (f16) conv1d_bf3_impl<true>(x, xp, B, Cin, T, wp, bias, Cout, K, dil, pre_silu, epi, res, gamma, y, yp, post_silu, ps, st);
+    else conv1d_bf3_impl<false>(x, xp, B, Cin, T, wp, bias, Cout, K, dil, pre_silu, epi, res, gamma, y, yp, post_silu, ps, st);
+}
+
+void codec_act_split(const float* x, int B, int C, int T, bool silu, uint16_t* planes, bool f16, hipStream_t st) {
     FS_REQUIRE(C % 8 == 0, "activation planes need a multiple of 8 channels");
-    hipLaunchKernelGGL(k_act_split, dim3((T + 255) / 256, C / 8, B), dim3(256), 0, st, x, C, T, silu ? 1 : 0, planes);
+    const dim3 grid((T + 255) / 256, C / 8, B);
+    if (f16) hipLaunchKernelGGL(k_act_split<true>, grid, dim3(256), 0, st, x, C, T, silu ? 1 : 0, planes);
+    else hipLaunchKernelGGL(k_act_split<false>, grid, dim3(256), 0, st, x, C, T, silu ? 1 : 0, planes);
     FS_HIP(hipGetLastError());
 }
 
-void codec_mean3_planes(const float* a, const float* b, const float* c, int B, int C, int T, bool silu, uint16_t* planes, hipStream_t st) {
+void codec_mean3_planes(const float* a, const float* b, const float* c, int B, int C, int T, bool silu, uint16_t* planes, bool f16,
+                        hipStream_t st) {
     FS_REQUIRE(C % 8 == 0, "activation planes need a multiple of 8 channels");
-    hipLaunchKernelGGL(k_mean3_planes, dim3((T + 255) / 256, C / 8, B), dim3(256), 0, st, a, b, c, C, T, silu ? 1 : 0, planes);
+    const dim3 grid((T + 255) / 256, C / 8, B);
+    if (f16) hipLaunchKernelGGL(k_mean3_planes<true>, grid, dim3(256), 0, st, a, b, c, C, T, silu ? 1 : 0, planes);
+    else hipLaunchKernelGGL(k_mean3_planes<false>, grid, dim3(256), 0, st, a, b, c, C, T, silu ? 1 : 0, planes);
     FS_HIP(hipGetLastError());
 }
 

@@ -88,10 +88,11 @@ class Codec final : public CodecBase {
     }
     int sample_rate() override { return 44100; }  // SpecTransformConfig (config.rs:13-22)
     void set_precision(int mode) override {
-        FS_REQUIRE(mode == 0 || mode == 1, "codec precision: 0 = f32 (exact products), 1 = bf16x3 (split bf16 matrix products)");
-        bf3_ = mode == 1;
+        FS_REQUIRE(mode >= 0 && mode <= 2, "codec precision: 0 = f32 (exact products), 1 = bf16x3 (split bf16 matrix products), 2 = f16");
+        bf3_ = mode >= 1;
+        f16_ = mode == 2;
     }
-    int precision() override { return bf3_ ? 1 : 0; }
+    int precision() override { return f16_ ? 2 : (bf3_ ? 1 : 0); }
 
     void decode(const uint32_t* codes, int B, int T, float* pcm_out) override {
         FS_HIP(hipSetDevice(device_));
@@ -119,7 +120,7 @@ class Codec final : public CodecBase {
         if (bb_planes) {
             for (auto& pb : pbuf_) pb.ensure(act * sizeof(float) + (size_t)B * C_ * CODEC_PLANE_PAD * 4 + (256 << 10));
             bp0 = pbuf_[0].u16(); bp1 = pbuf_[1].u16();
-            codec_act_split(x, B, C_, Tc, false, bp0, st_);
+            codec_act_split(x, B, C_, Tc, false, bp0, f16_, st_);
         }
         for (int i = 0; i < 2; ++i) {
             const CnxSpec& c = cnx_[i];
@@ -127,7 +128,7 @@ class Codec final : public CodecBase {
                 codec_tconv1d_planes(bp0, B, C_, Tc, conv(up_conv_[i]), 2, t1, st_);
                 Tc *= 2;
                 codec_dwconv_ln(t1, B, C_, Tc, R(c.dw), R(c.db), R(c.lnw), R(c.lnb), t2, st_);
-                codec_act_split(t2, B, C_, Tc, false, bp0, st_);
+                codec_act_split(t2, B, C_, Tc, false, bp0, f16_, st_);
                 codec_conv1d_planes(nullptr, bp0, B, C_, Tc, conv(c.pw1), 1, false, CODEC_EPI_GELU, nullptr, nullptr, nullptr, bp1, false, st_);
                 // pwconv2 + gamma + residual: the sum feeds the next transposed conv / conv_pre as planes (no SiLU in front of either)
                 codec_conv1d_planes(nullptr, bp1, B, 4 * C_, Tc, conv(c.pw2), 1, false, CODEC_EPI_GAMMA_RES, t1, R(c.gamma), nullptr, bp0, false, st_);
@@ -161,7 +162,7 @@ class Codec final : public CodecBase {
             if (stage_planes(s)) {
                 codec_tconv1d_planes(xp, B, ch, Tc, conv(ups_[s]), rates[s], t1, st_);  // ups[i](silu(x)); xp holds split(silu(x))
                 ch /= 2; Tc *= rates[s];
-                codec_act_split(t1, B, ch, Tc, true, t1p, st_);
+                codec_act_split(t1, B, ch, Tc, true, t1p, f16_, st_);
                 for (int j = 0; j < 3; ++j) {  // ResBlock1 (hifi_gan.rs:74-85): x += c2(silu(c1(silu(x)))), both convs dilated
                     const float* cur = t1;
                     const uint16_t* curp = t1p;
@@ -173,7 +174,7 @@ class Codec final : public CodecBase {
                         cur = accs[j]; curp = accp;
                     }
                 }
-                if (stage_planes(s + 1)) codec_mean3_planes(acc0, acc1, acc2, B, ch, Tc, true, xp, st_);
+                if (stage_planes(s + 1)) codec_mean3_planes(acc0, acc1, acc2, B, ch, Tc, true, xp, f16_, st_);
                 else codec_mean3(acc0, acc1, acc2, x, (size_t)B * ch * Tc, st_);
                 continue;
             }
@@ -287,7 +288,8 @@ class Codec final : public CodecBase {
         w.wt = relaid_.f() + relaid_off_[spec_idx];
         w.b = R(s.bias);
         w.cout = s.cout; w.k = s.k;
-        w.wp = use_bf3_now_ ? packed_.u16() + packed_off_[spec_idx] : nullptr;
+        w.f16 = use_bf3_now_ && f16_;
+        w.wp = !use_bf3_now_ ? nullptr : (f16_ ? packed16_.u16() + packed16_off_[spec_idx] : packed_.u16() + packed_off_[spec_idx]);
         return w;
     }
     int add_tensor(const std::string& name, std::vector<int64_t> shape, float mean, double stdv) {
@@ -425,7 +427,8 @@ class Codec final : public CodecBase {
         }
         // bf16 hi/lo split copies in MFMA operand order (the decode path's "bf16x3" precision mode), GEMM shape of the polyphase form
         packed_off_.clear();
-        size_t total = 0;
+        packed16_off_.clear();
+        size_t total = 0, total16 = 0;
         auto shape = [](const ConvSpec& s, int& K, int& Cout) {
             K = s.transposed ? s.k / s.stride : s.k;
             Cout = s.transposed ? s.cout * s.stride : s.cout;
@@ -433,12 +436,16 @@ class Codec final : public CodecBase {
         for (const ConvSpec& s : convs_) {
             int K, Cout; shape(s, K, Cout);
             packed_off_.push_back(total);
-            total += (codec_pack_bf3_elems(s.cin_g, K, Cout) + 63) & ~(size_t)63;
+            total += (codec_pack_bf3_elems(s.cin_g, K, Cout, false) + 63) & ~(size_t)63;
+            packed16_off_.push_back(total16);
+            total16 += (codec_pack_bf3_elems(s.cin_g, K, Cout, true) + 63) & ~(size_t)63;
         }
         packed_.ensure(total * sizeof(uint16_t));
+        packed16_.ensure(total16 * sizeof(uint16_t));
         for (size_t i = 0; i < convs_.size(); ++i) {
             int K, Cout; shape(convs_[i], K, Cout);
-            codec_pack_bf3(relaid_.f() + relaid_off_[i], packed_.u16() + packed_off_[i], convs_[i].cin_g, K, Cout, st_);
+            codec_pack_bf3(relaid_.f() + relaid_off_[i], packed_.u16() + packed_off_[i], convs_[i].cin_g, K, Cout, false, st_);
+            codec_pack_bf3(relaid_.f() + relaid_off_[i], packed16_.u16() + packed16_off_[i], convs_[i].cin_g, K, Cout, true, st_);
         }
         FS_HIP(hipStreamSynchronize(st_));
     }
@@ -450,8 +457,9 @@ class Codec final : public CodecBase {
     std::vector<ConvSpec> convs_;
     std::vector<size_t> relaid_off_;
     size_t raw_floats_ = 0, relaid_floats_ = 0;
-    DBuf raw_, relaid_, packed_, dcodes_, buf_[7], pbuf_[5];
-    std::vector<size_t> packed_off_;
+    DBuf raw_, relaid_, packed_, packed16_, dcodes_, buf_[7], pbuf_[5];
+    std::vector<size_t> packed_off_, packed16_off_;
+    bool f16_ = true;   // with bf3_: the plane data flow carries single f16 operands (mode 2) instead of bf16 hi / lo pairs (mode 1)
     bool bf3_ = true, use_bf3_now_ = false;  // decode precision mode (fs_codec_set_precision); the encoder always runs exact f32
     int proj_w_ = 0, proj_b_ = 0, up_conv_[2] = {0, 0}, conv_pre_ = 0, conv_post_ = 0, ups_[5] = {0, 0, 0, 0, 0};
     int res_[5][3][2][3] = {};

@@ -11,7 +11,8 @@ struct ConvW {
     const float* wt;  // re-laid weight [Cin/groups][K][Cout]
     const float* b;   // [Cout]
     int cout, k;
-    const uint16_t* wp = nullptr;  // bf16 hi/lo split, MFMA A-operand order (codec_pack_bf3); nullptr = exact-f32 kernels only
+    const uint16_t* wp = nullptr;  // bf16 hi/lo split or single f16, MFMA A-operand order (codec_pack_bf3); nullptr = exact-f32 kernels only
+    bool f16 = false;              // format of `wp` (and of the activation planes exchanged with it): "f16" precision mode
 };
 
 constexpr int CODEC_PLANE_PAD = 64;  // zero slots in front of every activation-plane row (>= the largest halo of a plane consumer)
@@ -30,16 +31,17 @@ void codec_relayout(const float* src, float* dst, int Cout, int CinG, int K, boo
 // ConvTranspose1d [Cin][Cout][K] -> polyphase causal-conv layout [Cin][K/stride][Cout*stride] (see codec_tconv1d)
 void codec_relayout_tconv(const float* src, float* dst, int Cout, int Cin, int K, int stride, hipStream_t st);
 // ---- bf16x3 convolution (codec_conv_bf3.hip): W and X split into bf16 hi + lo, three v_mfma_f32_32x32x16_bf16 per 16 reduction items
-size_t codec_pack_bf3_elems(int Cin, int K, int Cout);
-void codec_pack_bf3(const float* relaid /*[Cin][K][Cout]*/, uint16_t* dst, int Cin, int K, int Cout, hipStream_t st);
+// (f16 = true: the same kernels with ONE f16 value per operand and one v_mfma_f32_32x32x16_f16 per 16 items -- the "f16" precision mode)
+size_t codec_pack_bf3_elems(int Cin, int K, int Cout, bool f16);
+void codec_pack_bf3(const float* relaid /*[Cin][K][Cout]*/, uint16_t* dst, int Cin, int K, int Cout, bool f16, hipStream_t st);
 bool codec_conv1d_bf3_ok(int Cin, int Cout, int K, int dil);
 // input: f32 `x` (B, Cin, T) or activation planes `xp` ([B][2][Cin/8][T][8] bf16 hi / lo, the consumer's SiLU already applied);
 // output: f32 `y` and / or planes `yp` = split(post_silu ? silu(v) : v) (plain convs only)
-void codec_conv1d_bf3(const float* x, const uint16_t* xp, int B, int Cin, int T, const uint16_t* wp, const float* bias, int Cout, int K,
+void codec_conv1d_bf3(const float* x, const uint16_t* xp, int B, int Cin, int T, const uint16_t* wp, bool f16, const float* bias, int Cout, int K,
                       int dil, bool pre_silu, int epi, const float* res, const float* gamma, float* y, uint16_t* yp, bool post_silu, int ps,
                       hipStream_t st);
-void codec_act_split(const float* x, int B, int C, int T, bool silu, uint16_t* planes, hipStream_t st);
-void codec_mean3_planes(const float* a, const float* b, const float* c, int B, int C, int T, bool silu, uint16_t* planes, hipStream_t st);
+void codec_act_split(const float* x, int B, int C, int T, bool silu, uint16_t* planes, bool f16, hipStream_t st);
+void codec_mean3_planes(const float* a, const float* b, const float* c, int B, int C, int T, bool silu, uint16_t* planes, bool f16, hipStream_t st);
 // conv / transposed conv of the plane data flow (decode path, bf16x3 mode): see codec_conv1d_bf3
 void codec_conv1d_planes(const float* x, const uint16_t* xp, int B, int Cin, int T, const ConvW& w, int dil, bool pre_silu, int epi,
                          const float* res, const float* gamma, float* y, uint16_t* yp, bool post_silu, hipStream_t st);

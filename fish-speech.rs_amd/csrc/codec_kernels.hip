@@ -346,7 +346,7 @@ static void conv1d_launch(const float* x, int B, int Cin, int T, const ConvW& w,
     using I8 = std::integral_constant<int, 8>; using I16 = std::integral_constant<int, 16>;
     const bool mfma_ok = Cin >= 16 && Cout >= 16 && K <= 13 && halo <= 256;
     if (w.wp && codec_conv1d_bf3_ok(Cin, Cout, K, dil)) {  // "bf16x3" precision mode: split operands on the bf16 matrix cores
-        codec_conv1d_bf3(x, nullptr, B, Cin, T, w.wp, w.b, Cout, K, dil, pre_silu, epi, res, gamma, y, nullptr, false, ps, st);
+        codec_conv1d_bf3(x, nullptr, B, Cin, T, w.wp, w.f16, w.b, Cout, K, dil, pre_silu, epi, res, gamma, y, nullptr, false, ps, st);
         return;
     }
     if (mfma_ok) {  // matrix cores: 64 (or, for the thin late stages, 32) channels x 128 or 256 samples per block
@@ -400,12 +400,12 @@ void codec_tconv1d(const float* x, int B, int Cin, int Tin, const ConvW& w, int 
 void codec_conv1d_planes(const float* x, const uint16_t* xp, int B, int Cin, int T, const ConvW& w, int dil, bool pre_silu, int epi,
                          const float* res, const float* gamma, float* y, uint16_t* yp, bool post_silu, hipStream_t st) {
     FS_REQUIRE(w.wp, "the plane data flow needs packed bf16x3 weights");
-    codec_conv1d_bf3(x, xp, B, Cin, T, w.wp, w.b, w.cout, w.k, dil, pre_silu, epi, res, gamma, y, yp, post_silu, 1, st);
+    codec_conv1d_bf3(x, xp, B, Cin, T, w.wp, w.f16, w.b, w.cout, w.k, dil, pre_silu, epi, res, gamma, y, yp, post_silu, 1, st);
 }
 
 void codec_tconv1d_planes(const uint16_t* xp, int B, int Cin, int Tin, const ConvW& w, int stride, float* y, hipStream_t st) {
     FS_REQUIRE(w.wp && w.k % stride == 0, "the plane data flow needs packed bf16x3 weights of a polyphase transposed conv");
-    codec_conv1d_bf3(nullptr, xp, B, Cin, Tin, w.wp, w.b, w.cout * stride, w.k / stride, 1, false, CODEC_EPI_NONE, nullptr, nullptr, y, nullptr,
+    codec_conv1d_bf3(nullptr, xp, B, Cin, Tin, w.wp, w.f16, w.b, w.cout * stride, w.k / stride, 1, false, CODEC_EPI_NONE, nullptr, nullptr, y, nullptr,
                      false, stride, st);
 }
 

@@ -7,11 +7,12 @@ from . import _ffi
 
 
 class FireflyCodec:
-    PRECISIONS = {"f32": 0, "bf16x3": 1}
+    PRECISIONS = {"f32": 0, "bf16x3": 1, "f16": 2}
 
-    def __init__(self, device=0, channel_div=1, precision="bf16x3"):
-        """precision: arithmetic of the decode path's wide convs -- "bf16x3" (default: split-bf16 matrix products, PCM within 1e-4 RMS
-        of the f32 reference) or "f32" (exact f32 products); the encoder always runs exact f32 (fishrt.h: fs_codec_set_precision)"""
+    def __init__(self, device=0, channel_div=1, precision="f16"):
+        """precision: arithmetic of the decode path's convs -- "f16" (default: single f16 operands on the matrix cores, f32 accumulation
+        and f32 residual stream; PCM 1.6e-5 RMS from the f32 reference at signal rms 0.031, bound 1e-4), "bf16x3" (split-bf16 matrix
+        products, 3e-7 RMS) or "f32" (exact f32 products); the encoder always runs exact f32 (fishrt.h: fs_codec_set_precision)"""
         h = C.c_void_p()
         _ffi.check(_ffi.lib().fs_codec_create(int(device), int(channel_div), C.byref(h)))
         self._h = h

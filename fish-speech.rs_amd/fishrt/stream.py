@@ -33,8 +33,12 @@ class StreamingSynth:
     column (no per-chunk rebuild).  stats: frames, lm_s, vocoder_busy_s, total_s, overlap_efficiency, first_audio_s (time from the call
     to the first PCM chunk)."""
 
-    def __init__(self, lm, codec, chunk=256, halo=HALO, first_chunk=32):
+    def __init__(self, lm, codec, chunk=256, halo=HALO, first_chunk=32, inline=False):
+        """inline: vocode a chunk inside the frame callback (the LM pauses for the 3-4 ms of a 256-frame chunk) instead of in the worker
+        thread.  On ONE device the persistent decode kernels hold every CU, so a concurrent vocoder only advances one kernel per LM kernel
+        boundary and both sides pay for the switching; time-slicing at chunk granularity costs the vocoder's own time and no more."""
         self.lm, self.codec, self.chunk, self.halo, self.first_chunk = lm, codec, chunk, halo, min(first_chunk, chunk)
+        self.inline = inline
 
     def __call__(self, prompt, max_new_tokens, **gen_kw):
         Cb = self.lm.cfg["num_codebooks"]
@@ -52,6 +56,8 @@ class StreamingSynth:
             if t_first[0] is None:
                 t_first[0] = time.perf_counter() - t0
 
+        inline_upto = [0]
+
         def worker():
             try:
                 done_upto = 0
@@ -60,6 +66,7 @@ class StreamingSynth:
                     final = n is None
                     if final:
                         n = n_frames[0]
+                        done_upto = max(done_upto, inline_upto[0])
                     while True:  # vocode every complete chunk available so far (the first one is shorter)
                         step = self.first_chunk if done_upto == 0 else self.chunk
                         if done_upto + step > n:
@@ -81,7 +88,12 @@ class StreamingSynth:
             n_frames[0] = idx + 1
             done = idx + 1
             if done == self.first_chunk or (done > self.first_chunk and (done - self.first_chunk) % self.chunk == 0):
-                q.put(done)
+                if self.inline:
+                    step = self.first_chunk if done == self.first_chunk else self.chunk
+                    vocode(done - step, done)
+                    inline_upto[0] = done
+                else:
+                    q.put(done)
             return bool(errors)  # stop generating if the vocoder thread died
 
         try:

@@ -75,7 +75,7 @@ def test_hip_block15_vs_independent_restatement(tag, dtype, tol):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision,rms_tol", [("f32", 2e-6), ("bf16x3", 2.5e-5)])
+@pytest.mark.parametrize("precision,rms_tol", [("f32", 2e-6), ("bf16x3", 2.5e-5), ("f16", 4e-5)])
 def test_hip_full_width_vocoder_vs_independent_restatement(precision, rms_tol):
     import fishrt
     c = fishrt.FireflyCodec(0, precision=precision).load_synthetic(int(CF["seed"]))

@@ -10,8 +10,10 @@ import numpy as np, fishrt
 from fishrt import config as fcfg
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 dtype = sys.argv[2] if len(sys.argv) > 2 else "fp8"
+vprec = sys.argv[3] if len(sys.argv) > 3 else "bf16x3"
+inline = len(sys.argv) > 4 and sys.argv[4] == "inline"
 lm = fishrt.DualARTransformer(fcfg.FISH_1_4, fcfg.FISH_1_4_TOKENS, 0, dtype).load_synthetic(0xF15E5EED)
-codec = fishrt.FireflyCodec(0).load_synthetic(0xC0DEC)
+codec = fishrt.FireflyCodec(0, precision=vprec).load_synthetic(0xC0DEC)
 rng = np.random.RandomState(4)
 L = 64
 p = np.zeros((9, L), np.uint32); p[0] = rng.randint(6, 32000, L)
@@ -26,10 +28,10 @@ for rep in range(2):
     t = time.perf_counter(); codes = lm.generate_blocking(p, M, **kw); t_lm = time.perf_counter() - t
     t = time.perf_counter(); pcm = Clamp(codec).decode(np.ascontiguousarray(codes[None])); t_voc = time.perf_counter() - t
     lm.clear_slow_layer_caches()
-    synth = fishrt.StreamingSynth(lm, Clamp(codec), chunk=256, first_chunk=32)
+    synth = fishrt.StreamingSynth(lm, Clamp(codec), chunk=256, first_chunk=32, inline=inline)
     c2, pcm2 = synth(p, M, **kw)
     st = synth.stats
     audio_s = frames / 21.535
-    print(f"[{dtype}] frames={codes.shape[1]}: LM alone {t_lm:.3f}s (RTF {audio_s/t_lm:.1f}), vocoder alone (one shot) {t_voc:.3f}s, sequential {t_lm+t_voc:.3f}s | "
+    print(f"[{dtype}, vocoder {vprec}{', inline' if inline else ''}] frames={codes.shape[1]}: LM alone {t_lm:.3f}s (RTF {audio_s/t_lm:.1f}), vocoder alone (one shot) {t_voc:.3f}s, sequential {t_lm+t_voc:.3f}s | "
           f"overlapped total {st['total_s']:.3f}s (RTF {audio_s/st['total_s']:.1f}), vocoder busy {st['vocoder_busy_s']:.3f}s, "
           f"first audio after {st['first_audio_s'] * 1e3:.0f} ms, overlap efficiency {st['overlap_efficiency']:.2f}, same codes {np.array_equal(codes, c2)}, pcm identical {np.array_equal(pcm[0,0], pcm2)}")

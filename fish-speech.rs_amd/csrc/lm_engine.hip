@@ -109,7 +109,12 @@ class LM final : public LMBase {
         d_.dim = a.dim; d_.inter = a.intermediate_size; d_.H = a.n_head; d_.Hk = a.n_local_heads; d_.Dh = a.head_dim;
         d_.n_rep = a.n_head / a.n_local_heads; d_.eps = a.norm_eps;
         legacy_ = !t.has_semantic_end;  // Fish <= 1.4: slow token is a 2-way {pad, im_end} draw (single_batch.rs:104-124)
-        n_audio_ = legacy_ ? 2 : a.vocab_size - (int)t.im_end_id;
+        // generic DualAR token layout (utils.rs:17-30): <|im_end|> does not directly precede the semantic range -- the slow head's
+        // candidates are [im_end] ++ [semantic_start, V) (literally: any control token behind the range, <|im_end|> itself included, stays a
+        // candidate), gathered into one head image at load time
+        generic_ = !legacy_ && t.im_end_id + 1 != t.semantic_start_id;
+        if (!legacy_) FS_REQUIRE(t.semantic_start_id >= 1 && t.semantic_start_id < (uint32_t)a.vocab_size, "semantic_start_id outside the vocabulary");
+        n_audio_ = legacy_ ? 2 : (generic_ ? a.vocab_size - (int)t.semantic_start_id + 1 : a.vocab_size - (int)t.im_end_id);
         if (legacy_) FS_REQUIRE(t.pad_id < (uint32_t)a.vocab_size, "pad_id outside the vocabulary");
         plan_tensors();
         alloc_runtime();
@@ -356,8 +361,6 @@ class LM final : public LMBase {
         const int C = a_.num_codebooks, C1 = C + 1;
         FS_REQUIRE(L >= 1, "empty prompt");
         FS_REQUIRE(max_new_tokens >= 0, "negative max_new_tokens");
-        if (!legacy_)
-            FS_REQUIRE(t_.im_end_id + 1 == t_.semantic_start_id, "im_end_id must directly precede the semantic range (utils.rs:13)");
         validate_tokens(prompt, (size_t)C1 * L, 1, L);
         const int n_cached = seq_len_[0];
         if (n_cached + L > a_.max_seq_len) throw Error("prompt exceeds max_seq_len (dual_ar.rs:623-624)");
@@ -586,7 +589,7 @@ class LM final : public LMBase {
         use_device();
         require_loaded();
         const int C = a_.num_codebooks, C1 = C + 1, B = n;
-        FS_REQUIRE(t_.has_semantic_end && t_.im_end_id + 1 == t_.semantic_start_id, "only the Fish 1.5 audio-range path is implemented");
+        FS_REQUIRE(t_.has_semantic_end, "static batches need a Fish 1.5 / DualAR token layout (semantic range)");
         int Lmax = 0;
         for (int i = 0; i < n; ++i) { FS_REQUIRE(lens[i] >= 1, "empty prompt"); Lmax = std::max(Lmax, lens[i]); }
         if (Lmax > a_.max_seq_len) throw Error("prompt exceeds max_seq_len (dual_ar.rs:623-624)");
@@ -725,7 +728,7 @@ class LM final : public LMBase {
         require_loaded();
         FS_REQUIRE(!sess_active_, "a session is already open on this handle");
         FS_REQUIRE(LmKernels<WT>::has_mfma_prefill() && B_ <= kRows && a_.dim % 128 == 0 && a_.intermediate_size % 128 == 0 &&
-                       a_.num_codebooks <= 8 && !legacy_ && t_.has_semantic_end && t_.im_end_id + 1 == t_.semantic_start_id,
+                       a_.num_codebooks <= 8 && !legacy_ && t_.has_semantic_end,
                    "sessions need the MFMA row path (bf16 / fp8 handle, Fish 1.5 token layout)");
         clear_slow();
         clear_fast();
@@ -1057,6 +1060,7 @@ class LM final : public LMBase {
         SampleCfg c = {};
         c.temp = 0.f; c.top_p = 1.f; c.top_k = 0; c.rep_pen = 1.f; c.ignore_eos = 0;
         c.im_end_id = t_.im_end_id;
+        c.audio_base = legacy_ ? t_.im_end_id : t_.semantic_start_id - 1;
         c.sem_lo = t_.semantic_start_id;
         c.sem_hi = t_.has_semantic_end ? t_.semantic_end_id : t_.semantic_start_id;  // dual_ar.rs:554-559
         c.legacy = legacy_ ? 1 : 0;
@@ -1222,18 +1226,32 @@ class LM final : public LMBase {
     // rows of output.weight read by the generator's slow head: [im_end, V) for Fish 1.5 (utils.rs:13-16); the gathered
     // {pad_id, im_end_id} pair for Fish <= 1.4
     const void* slow_head_w() {
-        if (!legacy_) return (const uint8_t*)out_w_ + (size_t)t_.im_end_id * a_.dim * sizeof(WT);
-        if (!d_legacy_head_.p) d_legacy_head_.alloc(sizeof(WT) * 2 * a_.dim + 256);
+        if (!legacy_ && !generic_) return (const uint8_t*)out_w_ + (size_t)t_.im_end_id * a_.dim * sizeof(WT);
+        if (!d_legacy_head_.p) d_legacy_head_.alloc(gathered_head_bytes() + sizeof(float) * n_audio_ + 256);
         return d_legacy_head_.p;
     }
+    size_t gathered_head_bytes() const { return ((sizeof(WT) * (size_t)n_audio_ * a_.dim) + 15) & ~(size_t)15; }
     // per-row scales of the same rows (fp8 weights only)
     const float* slow_head_s() {
         if (!kFp8) return nullptr;
-        if (!legacy_) return out_s_ + t_.im_end_id;
+        if (!legacy_ && !generic_) return out_s_ + t_.im_end_id;
         slow_head_w();
-        return (const float*)(d_legacy_head_.as<uint8_t>() + (((sizeof(WT) * 2 * a_.dim) + 15) & ~(size_t)15));
+        return (const float*)(d_legacy_head_.as<uint8_t>() + gathered_head_bytes());
     }
     void refresh_legacy_head() {
+        if (generic_) {  // [W[im_end]; W[semantic_start .. V)]
+            const size_t row = sizeof(WT) * (size_t)a_.dim;
+            uint8_t* dst = (uint8_t*)const_cast<void*>(slow_head_w());
+            FS_HIP(hipMemcpyAsync(dst, (const uint8_t*)out_w_ + t_.im_end_id * row, row, hipMemcpyDeviceToDevice, st_));
+            FS_HIP(hipMemcpyAsync(dst + row, (const uint8_t*)out_w_ + t_.semantic_start_id * row, row * (n_audio_ - 1), hipMemcpyDeviceToDevice, st_));
+            if (kFp8) {
+                float* ds = const_cast<float*>(slow_head_s());
+                FS_HIP(hipMemcpyAsync(ds, out_s_ + t_.im_end_id, sizeof(float), hipMemcpyDeviceToDevice, st_));
+                FS_HIP(hipMemcpyAsync(ds + 1, out_s_ + t_.semantic_start_id, sizeof(float) * (n_audio_ - 1), hipMemcpyDeviceToDevice, st_));
+            }
+            FS_HIP(hipStreamSynchronize(st_));
+            return;
+        }
         if (!legacy_) return;
         launch_gather_rows<WT>(out_w_, a_.dim, t_.pad_id, t_.im_end_id, const_cast<void*>(slow_head_w()), st_);
         if (kFp8) launch_gather_rows<float>(out_s_, 1, t_.pad_id, t_.im_end_id, const_cast<float*>(slow_head_s()), st_);
@@ -1354,8 +1372,7 @@ class LM final : public LMBase {
         cs.nc_launch = nc_launch_;
         for (int l = 0; l < a_.n_layer; ++l) LmKernels<WT>::rows_layer(d_, B, cs, slow_[l], slow_kv(l, 0), l == 0, st_);
         LmKernels<WT>::rows_finish(d_, B, cs, norm_w_, st_);
-        LmKernels<WT>::rows_head(d_, B, cs, (const uint8_t*)out_w_ + (size_t)t_.im_end_id * a_.dim * sizeof(WT),
-                                 kFp8 ? out_s_ + t_.im_end_id : nullptr, n_audio_, d_lrows_.as<float>(), ld_slow_, st_);
+        LmKernels<WT>::rows_head(d_, B, cs, slow_head_w(), slow_head_s(), n_audio_, d_lrows_.as<float>(), ld_slow_, st_);
         // block-parallel samplers (temp > 1e-7, top_k <= 256): the step's C + 1 StdRng words per row are derived up front
         const uint32_t* words = rows_par_ ? d_rwords_.as<uint32_t>() : nullptr;
         if (rows_par_) SampleKernels<WT>::rows_rng_words(d_rng_.as<RngState>(), B, C + 1, state(0), d_rwords_.as<uint32_t>(), st_);
@@ -1593,6 +1610,7 @@ class LM final : public LMBase {
     int device_, B_;
     ModelDims d_;
     int n_audio_ = 0;
+    bool generic_ = false;  // DualAR token layout with <|im_end|> away from the semantic range (see the constructor)
     bool legacy_ = false;
     DevBuf d_legacy_head_;
     hipStream_t st_ = nullptr;

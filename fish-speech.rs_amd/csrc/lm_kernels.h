@@ -150,6 +150,10 @@ struct SampleCfg {  // device-resident (the captured graphs read it through a po
     int ignore_eos;
     uint32_t im_end_id;
     uint32_t sem_lo, sem_hi;  // embed mask range (inclusive); Fish<=1.4: lo == hi == semantic id
+    // slow-token candidates (constrain_probs_to_audio / rescale_semantic_tokens, generate/utils.rs:6-56): candidate 0 = <|im_end|>,
+    // candidate i >= 1 = token audio_base + i, audio_base = semantic_start_id - 1.  Fish 1.5: audio_base == im_end_id (the adjacent
+    // layout, one contiguous slice of the head); generic DualAR layout: the head image is [W[im_end]; W[semantic_start .. V)].
+    uint32_t audio_base = 0;
     // Fish <= 1.4 slow token (single_batch.rs:104-124, sampling/mod.rs:8-26): 2-way softmax over {pad_id, im_end_id},
     // temperature ignored; logits[0] = pad logit, logits[1] = im_end logit
     int legacy;
@@ -164,6 +168,8 @@ struct SampleCfg {  // device-resident (the captured graphs read it through a po
     // top_p to f32 first.  The batched samplers (k_sample_*_rows, batch_rows > 0) use this field for that one comparison.
     double top_p64 = 0.0;
 };
+
+__host__ __device__ inline uint32_t audio_tok(const SampleCfg& c, int idx) { return idx > 0 ? c.audio_base + (uint32_t)idx : c.im_end_id; }
 
 struct RepPenState {   // rep_pen.rs:4-72, one per codebook
     float* mask;       // [n_cb][cb_size]

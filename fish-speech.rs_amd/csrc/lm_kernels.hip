@@ -2275,7 +2275,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_slow(const float* __r
         __syncthreads();
         const int idx = block_sample(lg, n, cb, &lrng, sp, si, red, /*first_max=*/true);
         if (tid == 0) {
-            uint32_t tok = (uint32_t)idx + c.im_end_id;
+            uint32_t tok = audio_tok(c, idx);
             if (state->done) tok = c.im_end_id;
             state->cur[0] = tok;
             if (tok == c.im_end_id && state->done == 0) state->done = 1;
@@ -2295,7 +2295,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_slow(const float* __r
         __syncthreads();
         const int idx = greedy_pick(val, n, &s_key);
         if (tid == 0) {
-            uint32_t tok = (uint32_t)idx + c.im_end_id;  // rescale_semantic_tokens (utils.rs:45-46)
+            uint32_t tok = audio_tok(c, idx);  // rescale_semantic_tokens (utils.rs:45-46)
             if (state->done) tok = c.im_end_id;
             state->cur[0] = tok;
             if (tok == c.im_end_id && state->done == 0) state->done = 1;
@@ -2327,7 +2327,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_slow(const float* __r
     __syncthreads();
     const int idx = block_sample(lg, n, c, rng, sp, si, red);
     if (tid == 0) {
-        uint32_t tok = (uint32_t)idx + c.im_end_id;  // rescale_semantic_tokens (utils.rs:45-46)
+        uint32_t tok = audio_tok(c, idx);  // rescale_semantic_tokens (utils.rs:45-46)
         if (state->done) tok = c.im_end_id;  // generator already terminated (single_batch.rs:86-88): stay terminated
         state->cur[0] = tok;
         if (tok == c.im_end_id && state->done == 0) state->done = 1;  // 1 = terminated by THIS frame, 2 = earlier
@@ -2479,7 +2479,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_slow_rows(const float
     if (tid == SAMPLE_THREADS - 1 && c.temp != 0.f) child_rng(master, (unsigned long long)st->frame * calls_per_frame * B + b, &lrng);
     const int idx = block_sample(lg, n, c, &lrng, sp, si, red, /*first_max=*/true);
     if (tid == 0) {
-        const uint32_t tok = (uint32_t)idx + c.im_end_id;  // rescale_semantic_tokens (utils.rs:45-46)
+        const uint32_t tok = audio_tok(c, idx);  // rescale_semantic_tokens (utils.rs:45-46)
         st->cur[0] = tok;
         if (tok == c.im_end_id) st->done = 1;  // batch_item_is_dead |= newly dead (:160-173)
     }
@@ -2577,7 +2577,7 @@ __global__ __launch_bounds__(PAR_THREADS) void k_sample_slow_rows_par(const floa
     int used = 0;
     const int idx = bsample<PAR_THREADS, 4>(lv, n, c.top_k, (float)(1.0 / (double)c.temp), c.top_p, words[b * ROWS_WORDS_LD], &used, S, true, c.top_p64);
     if (tid == 0) {
-        const uint32_t tok = (uint32_t)idx + c.im_end_id;  // rescale_semantic_tokens (utils.rs:45-46)
+        const uint32_t tok = audio_tok(c, idx);  // rescale_semantic_tokens (utils.rs:45-46)
         st->cur[0] = tok;
         if (tok == c.im_end_id) st->done = 1;  // batch_item_is_dead |= newly dead (:160-173)
     }

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
             __syncthreads();  // amax is written again by the first codebook decision
         }
         if (cap && tid == 0) cap[2047] = (float)idx;
-        cur0 = (uint32_t)max(idx, 0) + cfg.im_end_id;
+        cur0 = audio_tok(cfg, max(idx, 0));
         if (cur0 == cfg.im_end_id) done_in = 1;  // terminated by THIS frame (workgroup 0 records token and flag at the end of the frame)
     }
     const bool eos = cur0 == cfg.im_end_id;  // single_batch.rs:153-156: push zeros, skip the fast decoder

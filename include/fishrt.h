@@ -129,9 +129,10 @@ int fs_lm_curr_kv_size(fs_lm_t* lm);                       /* dual_ar.rs:695-700
  *   - sampling->top_k == 0 means "no top-k" when temp > 0.  The reference has no such setting: `select_nth_unstable_by(0, ..)` yields an
  *     empty candidate set (candle's single path then fails in WeightedIndex::new, the batch path falls to `unwrap_or(0)`,
  *     sampling/mod.rs:57-75).  With temp == 0 top_k is never looked at (argmax first), there as here.
- *   - Fish 1.5 handles require im_end_id + 1 == semantic_start_id (the contiguous branch of constrain_probs_to_audio /
- *     rescale_semantic_tokens, generate/utils.rs:13-16,45-46); the gather branch for a non-adjacent <|im_end|> (:17-30,47-51) is
- *     rejected with an error.
+ *   - both branches of constrain_probs_to_audio / rescale_semantic_tokens are implemented (generate/utils.rs:13-30,45-52): with
+ *     im_end_id + 1 == semantic_start_id (Fish 1.5) the slow head reads the contiguous rows [im_end, V); otherwise (generic DualAR token
+ *     layout) the candidates are [im_end] ++ [semantic_start, V) -- literally, so control tokens behind the range (<|im_end|> itself
+ *     included) stay candidates -- gathered into one head image at load time.  All generation paths take either layout.
  * flags: FS_GEN_IGNORE_EOS masks <|im_end|> (bench-only, fixed-length runs: SURVEY.md §8d).
  *        FS_GEN_NO_PERSIST keeps the whole frame on the per-node graph path.  By default a call on a bf16 handle with the Fish geometry
  *        runs a frame as TWO persistent launches (csrc/lm_persist_slow.hip: the 24 slow blocks + head; csrc/lm_persist.hip: the slow-token

@@ -285,7 +285,7 @@ void LM::forward_generate(const uint32_t* toks, int B, int L, int input_pos, flo
         if (full_vocab_head) {
             linear(nrm.data(), B, output.data(), a.vocab_size, D, logits);
         } else {  // test-speed option: only rows [im_end, V) are ever consumed downstream (utils.rs:15)
-            const int lo = (int)t.im_end_id;
+            const int lo = (int)std::min(t.im_end_id, t.has_semantic_end ? t.semantic_start_id : t.im_end_id);  // (generic layout: utils.rs:17-30)
             std::vector<float> part((size_t)B * (a.vocab_size - lo));
             linear(nrm.data(), B, &output[(size_t)lo * D], a.vocab_size - lo, D, part.data());
             for (int b = 0; b < B; ++b) {
@@ -583,12 +583,17 @@ std::vector<uint32_t> LM::generate(const uint32_t* prompt, int L, int max_new_to
         // slow token: constrain_probs_to_audio + sample + rescale (Fish 1.5 contiguous case, utils.rs:13-16,45-46)
         uint32_t semantic;
         if (t.has_semantic_end) {
-            if (t.im_end_id != t.semantic_start_id - 1) throw std::runtime_error("non-contiguous im_end/semantic range not restated");
-            const size_t lo = t.im_end_id;
-            std::vector<float> sl(logits.begin() + lo, logits.end());
+            // utils.rs:13-16: contiguous slice when <|im_end|> directly precedes the semantic range; :17-30: else cat(im_end logit, logits of
+            // [semantic_start, V)) -- whatever follows the range (control tokens, <|im_end|> itself) stays a candidate
+            const bool adjacent = t.im_end_id == t.semantic_start_id - 1;
+            std::vector<float> sl;
+            if (adjacent) sl.assign(logits.begin() + t.im_end_id, logits.end());
+            else { sl.push_back(logits[t.im_end_id]); sl.insert(sl.end(), logits.begin() + t.semantic_start_id, logits.end()); }
             if (ignore_eos) sl[0] = -std::numeric_limits<float>::infinity();
             if (margins) margins->push_back(top2_margin(sl.data(), sl.size()));
-            semantic = lp.sample(sl.data(), sl.size()) + t.im_end_id;
+            const uint32_t pick = lp.sample(sl.data(), sl.size());
+            // rescale_semantic_tokens (:45-52)
+            semantic = adjacent ? pick + t.im_end_id : (pick == 0 ? t.im_end_id : pick - 1 + t.semantic_start_id);
         } else {
             // Fish <= 1.4 (single_batch.rs:104-124): legacy_softmax_sample over {pad_id, im_end_id}, temperature ignored
             // (sampling/mod.rs:8-26).  The reference draws `rng.gen::<f32>()` from an unseeded thread_rng; the restatement
@@ -642,7 +647,7 @@ std::vector<std::vector<uint32_t>> LM::generate_batch(const std::vector<std::vec
                                                       std::vector<int>* n_frames, std::vector<float>* margins) {
     const int C = a.num_codebooks, C1 = C + 1, D = a.dim, V = a.vocab_size, B = (int)prompts.size();
     if (B == 0) throw std::runtime_error("Must have at least one prompt");
-    if (!t.has_semantic_end || t.im_end_id != t.semantic_start_id - 1) throw std::runtime_error("only the Fish 1.5 contiguous audio range is restated");
+    if (!t.has_semantic_end) throw std::runtime_error("static batches: only the Fish 1.5 / DualAR token layouts are restated");
     int Lmax = 0;
     for (int l : lens) Lmax = std::max(Lmax, l);
     // pad_prompts (:68-111): left pad with [im_end; 0...]; the mask is built but never applied (dual_ar.rs:589-615)
@@ -660,7 +665,8 @@ std::vector<std::vector<uint32_t>> LM::generate_batch(const std::vector<std::vec
     size_t input_pos = 0;
     int curL = Lmax;
     bool have_prompt = true, first = true;
-    const size_t lo = t.im_end_id, na = (size_t)V - lo;
+    const bool adjacent = t.im_end_id == t.semantic_start_id - 1;  // utils.rs:13 / :17-30 (see LM::generate)
+    const size_t lo = adjacent ? t.im_end_id : t.semantic_start_id - 1, na = (size_t)V - lo;
     while (true) {
         if (input_pos == 0) clear_slow();                                 // :118-121
         if (!have_prompt || input_pos > (size_t)max_new_tokens) break;    // :122
@@ -668,6 +674,7 @@ std::vector<std::vector<uint32_t>> LM::generate_batch(const std::vector<std::vec
         std::vector<float> sl((size_t)B * na);
         for (int b = 0; b < B; ++b) {
             std::memcpy(&sl[(size_t)b * na], &logits[(size_t)b * V + lo], sizeof(float) * na);
+            if (!adjacent) sl[(size_t)b * na] = logits[(size_t)b * V + t.im_end_id];  // candidate 0 = <|im_end|>, then [semantic_start, V)
             if (ignore_eos) sl[(size_t)b * na] = -std::numeric_limits<float>::infinity();
         }
         // test aid (as in LM::generate): smallest top-2 margin among a row's 9 decisions of this iteration
@@ -679,7 +686,7 @@ std::vector<std::vector<uint32_t>> LM::generate_batch(const std::vector<std::vec
         size_t mbase = 0;
         if (margins) { mbase = margins->size(); for (int b = 0; b < B; ++b) margins->push_back(top2(&sl[(size_t)b * na], na)); }
         std::vector<uint32_t> slow = batched_sample(master, s, sl.data(), B, na, na);
-        for (auto& v : slow) v += t.im_end_id;                             // rescale_semantic_tokens
+        for (auto& v : slow) v = adjacent ? v + t.im_end_id : (v == 0 ? t.im_end_id : v - 1 + t.semantic_start_id);  // rescale_semantic_tokens
         for (int b = 0; b < B; ++b) dead[b] = dead[b] || slow[b] == t.im_end_id;  // :160-173
         x = hidden;
         clear_fast();

@@ -185,23 +185,26 @@ __device__ __forceinline__ void c3_epilogue_k(const f32x16 (&acc)[NT], int ob, i
                                               float* __restrict__ y, uint16_t* __restrict__ ypb, int post_silu) {
     constexpr bool RES = E == CODEC_EPI_RES || E == CODEC_EPI_GAMMA_RES;
     const int CGo = Cout >> 3;
-    float bv[16], gv[16], rv[NT][16];
-    size_t oi[NT][16];
+    float bv[16], gv[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int o = min(ob + (r >> 2) * 8 + h * 4 + (r & 3), Cout - 1), oc = PS1 ? o : o / ps;
-        bv[r] = bias[oc];
+        const int o = min(ob + (r >> 2) * 8 + h * 4 + (r & 3), Cout - 1);
+        bv[r] = bias[PS1 ? o : o / ps];
         if (E == CODEC_EPI_GAMMA_RES) gv[r] = gamma[o];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int t = min(tbase + j * 32 + c, T - 1);
-            oi[j][r] = PS1 ? (size_t)o * T + t : (size_t)oc * T * ps + (size_t)t * ps + o % ps;  // (polyphase rows: see k_conv1d)
-            if (RES) rv[j][r] = res[oi[j][r]];
-        }
     }
+    // one 32-sample tile at a time (32-bit element offsets: every activation of a decode call is < 2^32 elements): the 16 residual values
+    // of a tile are requested together, so a tile is one memory round trip, and only one tile's addresses / residuals are live
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        const int t = tbase + j * 32 + c;
+        const int t = tbase + j * 32 + c, tc = min(t, T - 1);
+        uint32_t oi[16];
+        float rv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = min(ob + (r >> 2) * 8 + h * 4 + (r & 3), Cout - 1), oc = PS1 ? o : o / ps;
+            oi[r] = PS1 ? (uint32_t)o * (uint32_t)T + (uint32_t)tc : ((uint32_t)oc * (uint32_t)T + (uint32_t)tc) * (uint32_t)ps + (uint32_t)(o % ps);  // (polyphase rows: see k_conv1d)
+            if (RES) rv[r] = res[oi[r]];
+        }
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
             float v4[4];
@@ -210,10 +213,10 @@ __device__ __forceinline__ void c3_epilogue_k(const f32x16 (&acc)[NT], int ob, i
                 const int r = q4 * 4 + rr, o = ob + q4 * 8 + h * 4 + rr;
                 float v = acc[j][r] + bv[r];
                 if (E == CODEC_EPI_GELU) v = c3_gelu(v);
-                else if (E == CODEC_EPI_GAMMA_RES) v = rv[j][r] + gv[r] * v;
-                else if (E == CODEC_EPI_RES) v = rv[j][r] + v;
+                else if (E == CODEC_EPI_GAMMA_RES) v = rv[r] + gv[r] * v;
+                else if (E == CODEC_EPI_RES) v = rv[r] + v;
                 else if (E == CODEC_EPI_TANH) v = tanhf(v);
-                if (y && o < Cout && t < T) y[oi[j][r]] = v;
+                if (y && o < Cout && t < T) y[oi[r]] = v;
                 v4[rr] = v;
             }
             const int ob8 = ob + q4 * 8;  // first channel of this lane pair's 8-channel group
@@ -383,7 +386,7 @@ __global__ __launch_bounds__(256) void k_conv1d_bf3(const float* __restrict__ x,
 // uniform base + lane * 16: no per-lane address arithmetic, no staging registers).  Two or three blocks share a CU (LDS 42..65 KB
 // each), so one block's DMA wait overlaps another's MFMA phase.  Requires Cin % 16 == 0.
 template <bool F16, int OT, int TT, int KMAX, int EPI, bool PS1, int NIBS = 1>
-__global__ __launch_bounds__(256, 2) void k_conv1d_bf3p(const uint16_t* __restrict__ xp, int Cin, int T, const uint16_t* __restrict__ wp,
+__global__ __launch_bounds__(256, F16 ? 3 : 2) void k_conv1d_bf3p(const uint16_t* __restrict__ xp, int Cin, int T, const uint16_t* __restrict__ wp,
                                                         int Cp, const float* __restrict__ bias, int Cout, int K, int dil, int epi,
                                                         const float* __restrict__ res, const float* __restrict__ gamma,
                                                         float* __restrict__ y, uint16_t* __restrict__ yp, int post_silu, int ps) {

@@ -1,6 +1,6 @@
 """Coordinate descent over the pre-sweep naps of the persistent decode kernels (FISHRT_NAPS_FAST / FISHRT_NAPS_SLOW: 64-clock units
 before the first sweep of each stage kind) on the configs[1] workload; prints the decode us/frame after every improving move.
-usage: tune_naps.py [greedy|sampled] [dtype]"""
+usage: tune_naps.py [greedy|sampled] [dtype] [start naps, 12 comma-separated] [KV length of a random text prompt: tunes the slow kernel only]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,6 +13,12 @@ kw = dict(temp=0.0, top_p=1.0, top_k=0) if mode == "greedy" else dict(temp=0.7, 
 lm = fishrt.DualARTransformer(fcfg.FISH_1_5, fcfg.FISH_1_5_TOKENS, 0, dtype).load_synthetic(0xF15E5EED)
 p = bench.default_voice_prompt(fcfg.FISH_1_5_TOKENS)
 F = 192
+KV = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+if KV:
+    lm.close()
+    lm = fishrt.DualARTransformer(dict(fcfg.FISH_1_5, max_seq_len=8192), fcfg.FISH_1_5_TOKENS, 0, dtype).load_synthetic(0xF15E5EED)
+    p = np.zeros((9, KV), np.uint32); p[0] = np.random.RandomState(1).randint(0, 100000, KV)
+    F = 96
 M = F + p.shape[1] - 2
 
 
@@ -34,7 +40,7 @@ print(f"start {naps}: {cur:.1f} us/frame", flush=True)
 names = ["f.S1", "f.S2", "f.S3", "f.S4", "f.head", "f.dec", "s.S1", "s.S2", "s.S3", "s.S4", "s.S5", "s.head"]
 for sweep in range(3):
     improved = False
-    for i in range(12):
+    for i in (range(6, 12) if KV else range(12)):
         for v in (sorted(set([max(0, naps[i] - 8), max(0, naps[i] - 4), naps[i] + 4, naps[i] + 8, naps[i] + 16, 0, 2]))):
             if v == naps[i]:
                 continue

@@ -65,6 +65,8 @@ class StreamingSynth:
                     n = q.get()
                     final = n is None
                     if final:
+                        if errors:
+                            return
                         n = n_frames[0]
                         done_upto = max(done_upto, inline_upto[0])
                     while True:  # vocode every complete chunk available so far (the first one is shorter)
@@ -90,8 +92,11 @@ class StreamingSynth:
             if done == self.first_chunk or (done > self.first_chunk and (done - self.first_chunk) % self.chunk == 0):
                 if self.inline:
                     step = self.first_chunk if done == self.first_chunk else self.chunk
-                    vocode(done - step, done)
-                    inline_upto[0] = done
+                    try:
+                        vocode(done - step, done)
+                        inline_upto[0] = done
+                    except BaseException as e:  # (an exception must not escape a ctypes callback: record it, stop generating)
+                        errors.append(e)
                 else:
                     q.put(done)
             return bool(errors)  # stop generating if the vocoder thread died

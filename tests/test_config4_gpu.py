@@ -83,6 +83,35 @@ def test_fish14_fp8_4096_frames_streamed_pcm_equals_one_shot(lm14):
     codec.close()
 
 
+def test_streaming_synth_inline_mode_equals_threaded(lm14):
+    """inline=True vocodes each chunk inside the frame callback (the LM pauses) instead of in the worker thread: same codes, same PCM,
+    ragged tail included (frames not a multiple of the chunk), errors from the vocoder still reach the caller"""
+    p = _prompt14(24, 9)
+    frames = 300
+    M = frames + p.shape[1] - 2
+    kw = dict(temp=0.7, top_p=0.8, top_k=256, repetition_penalty=1.2, seed=5, ignore_eos=True)
+    codec = fishrt.FireflyCodec(0).load_synthetic(0xC0DEC)
+    outs = []
+    for inline in (False, True):
+        lm14.clear_slow_layer_caches()
+        synth = fishrt.StreamingSynth(lm14, _Clamp(codec), chunk=64, first_chunk=16, inline=inline)
+        outs.append(synth(p, M, **kw))
+        assert synth.stats["frames"] == frames and synth.stats["first_audio_s"] is not None
+    (c0, p0), (c1, p1) = outs
+    assert c0.shape == (8, frames) and np.array_equal(c0, c1)
+    assert p0.shape == (2048 * frames,) and np.array_equal(p0, p1)
+    one_shot = _Clamp(codec).decode(np.ascontiguousarray(c0[None]))[0, 0]
+    assert np.array_equal(p1, one_shot)
+
+    class Boom:
+        def decode(self, codes):
+            raise ValueError("vocoder exploded")
+    lm14.clear_slow_layer_caches()
+    with pytest.raises(ValueError, match="vocoder exploded"):
+        fishrt.StreamingSynth(lm14, Boom(), chunk=16, first_chunk=8, inline=True)(p, 24 + 40, temp=0.0, top_p=1.0, top_k=0, ignore_eos=True)
+    codec.close()
+
+
 def test_streaming_synth_surfaces_errors_and_never_hangs(lm14):
     """the worker always gets its sentinel; an exception in the vocoder thread or in generate_blocking reaches the caller"""
     class Boom:

@@ -22,6 +22,12 @@
 // after consuming edge e-2, so nobody still reads the buffer of edge e-4 (nor e-2).  Every spin is bounded; a timeout sets
 // ctl[1] and lets the thread run on (garbage tokens, no hang), the host turns it into an error.
 //
+// Round 3 additions: the slow-token decision of the frame is taken in this kernel's prologue (A.slow_logits), so a
+// frame is two launches; k_fast_persist<true> takes every decision with the block-parallel sampler of lm_bsample_dev.h (token-exact
+// top-k / top-p / WeightedIndex chain); FS_FP8 handles bring a bf16-widened e4m3 image + row scales (A.scales); the W13 stage runs on the
+// matrix cores (resident A fragments, the activation split into three bf16 terms as B columns); every stage sleeps A.naps[kind] x 64
+// clocks before its first sweep (pf_nap_before_sweep: early polling floods the memory side in front of the granules everybody waits for).
+//
 // State ordering inside a launch: per-frame inputs (SeqState, rep-pen ring / mask, sampler config) are read by every workgroup
 // BEFORE its first publish; only workgroup 0 writes them, and it cannot reach its first write before it has consumed a
 // full edge, i.e. before every workgroup has completed those reads.

@@ -20,6 +20,11 @@
 //   S4  gather h -> RMSNorm folded -> 16 SwiGLU pairs of W13                                   -> 4096 granules
 //   S5  gather the activations -> W2 rows [4b, 4b+4) + residual                                 -> 1024 granules
 //   head: gather x (= the pre-norm hidden state, also written to A.x) -> norm folded -> head rows [8b, 8b+8) -> A.logits (plain stores)
+//
+// Round 3 additions: k_slow_persist<true> streams e4m3 byte images (half the bytes; a dword holds the pairs of two
+// rows, v_cvt_pk_f32_fp8, per-row scales applied by the publishing lanes); rsq / rcp epilogues; every stage sleeps A.naps[kind] x 64 clocks
+// before its first sweep (pf_nap_before_sweep).  Measured and rejected: an LDS-ring loader wave for the weight stream, fewer attention
+// slices, retry naps inside the per-lane spin loop (profiles/r03_loader_engine.txt, r03_poll_naps.txt).
 #include "lm_persist.h"
 
 #include <hip/hip_runtime.h>

@@ -134,7 +134,7 @@ int fs_lm_curr_kv_size(fs_lm_t* lm);                       /* dual_ar.rs:695-700
  *     layout) the candidates are [im_end] ++ [semantic_start, V) -- literally, so control tokens behind the range (<|im_end|> itself
  *     included) stay candidates -- gathered into one head image at load time.  All generation paths take either layout.
  * flags: FS_GEN_IGNORE_EOS masks <|im_end|> (bench-only, fixed-length runs: SURVEY.md §8d).
- *        FS_GEN_NO_PERSIST keeps the whole frame on the per-node graph path.  By default a call on a bf16 handle with the Fish geometry
+ *        FS_GEN_NO_PERSIST keeps the whole frame on the per-node graph path.  By default a call on a bf16 or fp8 handle with the Fish geometry
  *        runs a frame as TWO persistent launches (csrc/lm_persist_slow.hip: the 24 slow blocks + head; csrc/lm_persist.hip: the slow-token
  *        decision, the 8 codebook passes with weights resident in VGPRs / LDS and their 8 decisions -- greedy, or top-k / top-p sampled
  *        in-launch when 0 < top_k <= 256 -- with in-launch hand-offs); those launches need all 256 CUs of the device, so only one

@@ -156,6 +156,26 @@ __device__ int bsample(const float (&lv)[EPT], int n, int kk, float inv_t, float
         const float denom = (float)dsum;
 #pragma unroll
         for (int s = 0; s < EPT; ++s) u[s] = __float_as_uint(v[s] / denom);  // 0 for slots past n
+        // ---- shortcut: the largest probability alone exceeds top_p (peaked rows: most decisions of a trained model).  The chain below
+        // would keep it in the top-k set, find top_p < sum (the f32 sum of the kept probabilities is >= any of them), rank it first (ties:
+        // the lower index) and cut right behind it (its cumulative sum 0 + p_max has reached top_p): the draw runs over ONE positive weight,
+        // consumes its word and returns that entry.  p_max = expf(0) / denom is known to every thread; only the lowest index carrying it
+        // has to be found.  (Strict inequality: at top_p == sum the reference takes the no-cut branch.)
+        const float pmax = 1.0f / denom;
+        const bool cut1 = batch ? (top_p64 > 0.0 && (double)pmax > top_p64 && pmax >= top_p) : (top_p > 0.f && pmax > top_p);
+        if (cut1) {
+            int mine = 0x7FFFFFFF;
+#pragma unroll
+            for (int s = EPT - 1; s >= 0; --s) if (base + s < n && u[s] == __float_as_uint(pmax)) mine = base + s;
+            mine = min(mine, __shfl_xor(mine, 32, 64)); mine = min(mine, __shfl_xor(mine, 16, 64)); mine = min(mine, __shfl_xor(mine, 8, 64));
+            mine = min(mine, __shfl_xor(mine, 4, 64)); mine = min(mine, __shfl_xor(mine, 2, 64)); mine = min(mine, __shfl_xor(mine, 1, 64));
+            if (lane == 0 && mine != 0x7FFFFFFF) atomicMin(&S.misc[3], mine);
+            __syncthreads();
+            const int pick = S.misc[3];
+            __syncthreads();  // (the next call re-initialises S.misc)
+            *consumed = 1;
+            return pick;
+        }
     }
     BS_TS(1);
     // ---- B: T = the kk-th largest pattern (#{u > T} < kk <= #{u >= T}); slots past n count as zeros, exactly as in the one-wave version

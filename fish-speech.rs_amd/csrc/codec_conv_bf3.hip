@@ -116,23 +116,30 @@ __device__ unsigned long long g_c3prof[8];
 #define C3_TICK(slot) do {} while (0)
 #endif
 
+// Streaming (fs_codec_stream_*): the PP slots in front of a row are the causal LEFT CONTEXT of the tensor -- zeros for the first chunk of a
+// stream (and for one-shot decoding), else the last PP slots of the same tensor in the previous chunk, kept in a per-tensor context
+//   ctx[part][C/8][PP][8]
+// `ci` = the context to copy in (null: zeros); producers also copy the last PP slots they write into `co` (null: not streaming).
+struct PlaneCtx { const uint16_t* ci; uint16_t* co; };
 template <bool F16>
-__device__ __forceinline__ void c3_zero_pad(uint16_t* pb, int CG, int T, int g_first, int n_groups, int tid, int nthreads) {
+__device__ __forceinline__ void c3_zero_pad(uint16_t* pb, int CG, int T, int g_first, int n_groups, int tid, int nthreads, const uint16_t* ci = nullptr) {
     constexpr int NP = F16 ? 1 : 2;
     const u32x4 z{0u, 0u, 0u, 0u};
     for (int e = tid; e < n_groups * NP * PP; e += nthreads) {
         const int slot = e % PP, gp = e / PP, g = g_first + gp / NP, part = gp % NP;
-        if (g < CG) *reinterpret_cast<u32x4*>(pb + ((size_t)(part * CG + g) * (PP + T) + slot) * 8) = z;
+        if (g < CG)
+            *reinterpret_cast<u32x4*>(pb + ((size_t)(part * CG + g) * (PP + T) + slot) * 8) =
+                ci ? *reinterpret_cast<const u32x4*>(ci + ((size_t)(part * CG + g) * PP + slot) * 8) : z;
     }
 }
 
 // f32 (C, T) -> planes, optional SiLU.  One thread per (8-channel group, t).
 template <bool F16>
-__global__ void k_act_split(const float* __restrict__ x, int C, int T, int silu, uint16_t* __restrict__ planes) {
+__global__ void k_act_split(const float* __restrict__ x, int C, int T, int silu, uint16_t* __restrict__ planes, PlaneCtx pc) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y, CG = C >> 3;
     const float* xb = x + (size_t)blockIdx.z * C * T;
     uint16_t* pb = planes + (size_t)blockIdx.z * (F16 ? 1 : 2) * CG * (PP + T) * 8;
-    if (blockIdx.x == 0) c3_zero_pad<F16>(pb, CG, T, g, 1, threadIdx.x, blockDim.x);
+    if (blockIdx.x == 0) c3_zero_pad<F16>(pb, CG, T, g, 1, threadIdx.x, blockDim.x, pc.ci);
     if (t >= T) return;
     u32x4 vh, vl;
 #pragma unroll
@@ -145,16 +152,20 @@ __global__ void k_act_split(const float* __restrict__ x, int C, int T, int silu,
     }
     *reinterpret_cast<u32x4*>(pb + ((size_t)g * (PP + T) + PP + t) * 8) = vh;
     if constexpr (!F16) *reinterpret_cast<u32x4*>(pb + ((size_t)(CG + g) * (PP + T) + PP + t) * 8) = vl;
+    if (pc.co && t >= T - PP) {
+        *reinterpret_cast<u32x4*>(pc.co + ((size_t)g * PP + (t - (T - PP))) * 8) = vh;
+        if constexpr (!F16) *reinterpret_cast<u32x4*>(pc.co + ((size_t)(CG + g) * PP + (t - (T - PP))) * 8) = vl;
+    }
 }
 
 // ParallelBlock mean (hifi_gan.rs:114-117) straight into planes: split(silu?(((a + b) + c) / 3))
 template <bool F16>
 __global__ void k_mean3_planes(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c, int C, int T, int silu,
-                               uint16_t* __restrict__ planes) {
+                               uint16_t* __restrict__ planes, PlaneCtx pc) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y, CG = C >> 3;
     const size_t boff = (size_t)blockIdx.z * C * T;
     uint16_t* pb = planes + (size_t)blockIdx.z * (F16 ? 1 : 2) * CG * (PP + T) * 8;
-    if (blockIdx.x == 0) c3_zero_pad<F16>(pb, CG, T, g, 1, threadIdx.x, blockDim.x);
+    if (blockIdx.x == 0) c3_zero_pad<F16>(pb, CG, T, g, 1, threadIdx.x, blockDim.x, pc.ci);
     if (t >= T) return;
     const float third = (float)(1.0 / 3.0);
     u32x4 vh, vl;
@@ -169,6 +180,10 @@ __global__ void k_mean3_planes(const float* __restrict__ a, const float* __restr
     }
     *reinterpret_cast<u32x4*>(pb + ((size_t)g * (PP + T) + PP + t) * 8) = vh;
     if constexpr (!F16) *reinterpret_cast<u32x4*>(pb + ((size_t)(CG + g) * (PP + T) + PP + t) * 8) = vl;
+    if (pc.co && t >= T - PP) {
+        *reinterpret_cast<u32x4*>(pc.co + ((size_t)g * PP + (t - (T - PP))) * 8) = vh;
+        if constexpr (!F16) *reinterpret_cast<u32x4*>(pc.co + ((size_t)(CG + g) * PP + (t - (T - PP))) * 8) = vl;
+    }
 }
 
 // Epilogue shared by the conv kernels.  D[row][col] of v_mfma_f32_32x32x*: register r of lane (h, c) holds row (r/4)*8 + h*4 + r%4,
@@ -182,7 +197,7 @@ __global__ void k_mean3_planes(const float* __restrict__ a, const float* __restr
 template <bool F16, int NT, int E, bool PS1>
 __device__ __forceinline__ void c3_epilogue_k(const f32x16 (&acc)[NT], int ob, int tbase, int h, int c, int Cout, int T, int ps,
                                               const float* __restrict__ bias, const float* __restrict__ res, const float* __restrict__ gamma,
-                                              float* __restrict__ y, uint16_t* __restrict__ ypb, int post_silu) {
+                                              float* __restrict__ y, uint16_t* __restrict__ ypb, int post_silu, uint16_t* __restrict__ yco = nullptr) {
     constexpr bool RES = E == CODEC_EPI_RES || E == CODEC_EPI_GAMMA_RES;
     const int CGo = Cout >> 3;
     float bv[16], gv[16];
@@ -228,6 +243,11 @@ __device__ __forceinline__ void c3_epilogue_k(const f32x16 (&acc)[NT], int ob, i
                 *reinterpret_cast<uint2*>(d) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
                 if constexpr (!F16)
                     *reinterpret_cast<uint2*>(d + (size_t)CGo * (PP + T) * 8) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+                if (yco && t >= T - PP) {  // streaming: the last PP slots are the next chunk's left context
+                    uint16_t* dc = yco + ((size_t)(ob8 >> 3) * PP + (t - (T - PP))) * 8 + h * 4;
+                    *reinterpret_cast<uint2*>(dc) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
+                    if constexpr (!F16) *reinterpret_cast<uint2*>(dc + (size_t)CGo * PP * 8) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+                }
             }
         }
     }
@@ -240,15 +260,15 @@ template <bool F16, int NT, int EPI = -1, bool PS1 = false>
 __device__ __forceinline__ void c3_epilogue(const f32x16 (&acc)[NT], int ob, int tbase, int h, int c, int Cout, int T, int ps,
                                             const float* __restrict__ bias, int epi, const float* __restrict__ res,
                                             const float* __restrict__ gamma, float* __restrict__ y, uint16_t* __restrict__ ypb,
-                                            int post_silu) {
+                                            int post_silu, uint16_t* __restrict__ yco = nullptr) {
     if constexpr (EPI >= 0) {
-        c3_epilogue_k<F16, NT, EPI, PS1>(acc, ob, tbase, h, c, Cout, T, ps, bias, res, gamma, y, ypb, post_silu);
+        c3_epilogue_k<F16, NT, EPI, PS1>(acc, ob, tbase, h, c, Cout, T, ps, bias, res, gamma, y, ypb, post_silu, yco);
     } else {
-        if (epi == CODEC_EPI_GELU) c3_epilogue_k<F16, NT, CODEC_EPI_GELU, false>(acc, ob, tbase, h, c, Cout, T, ps, bias, res, gamma, y, ypb, post_silu);
-        else if (epi == CODEC_EPI_GAMMA_RES) c3_epilogue_k<F16, NT, CODEC_EPI_GAMMA_RES, false>(acc, ob, tbase, h, c, Cout, T, ps, bias, res, gamma, y, ypb, post_silu);
-        else if (epi == CODEC_EPI_RES) c3_epilogue_k<F16, NT, CODEC_EPI_RES, false>(acc, ob, tbase, h, c, Cout, T, ps, bias, res, gamma, y, ypb, post_silu);
-        else if (epi == CODEC_EPI_TANH) c3_epilogue_k<F16, NT, CODEC_EPI_TANH, false>(acc, ob, tbase, h, c, Cout, T, ps, bias, res, gamma, y, ypb, post_silu);
-        else c3_epilogue_k<F16, NT, CODEC_EPI_NONE, false>(acc, ob, tbase, h, c, Cout, T, ps, bias, res, gamma, y, ypb, post_silu);
+        if (epi == CODEC_EPI_GELU) c3_epilogue_k<F16, NT, CODEC_EPI_GELU, false>(acc, ob, tbase, h, c, Cout, T, ps, bias, res, gamma, y, ypb, post_silu, yco);
+        else if (epi == CODEC_EPI_GAMMA_RES) c3_epilogue_k<F16, NT, CODEC_EPI_GAMMA_RES, false>(acc, ob, tbase, h, c, Cout, T, ps, bias, res, gamma, y, ypb, post_silu, yco);
+        else if (epi == CODEC_EPI_RES) c3_epilogue_k<F16, NT, CODEC_EPI_RES, false>(acc, ob, tbase, h, c, Cout, T, ps, bias, res, gamma, y, ypb, post_silu, yco);
+        else if (epi == CODEC_EPI_TANH) c3_epilogue_k<F16, NT, CODEC_EPI_TANH, false>(acc, ob, tbase, h, c, Cout, T, ps, bias, res, gamma, y, ypb, post_silu, yco);
+        else c3_epilogue_k<F16, NT, CODEC_EPI_NONE, false>(acc, ob, tbase, h, c, Cout, T, ps, bias, res, gamma, y, ypb, post_silu, yco);
     }
 }
 
@@ -260,7 +280,7 @@ template <bool F16, int OT, int TT, int NIBS, int KMAX, int NPX>
 __global__ __launch_bounds__(256) void k_conv1d_bf3(const float* __restrict__ x, int Cin, int T, const uint16_t* __restrict__ wp, int Cp,
                                                     const float* __restrict__ bias, int Cout, int K, int dil, int pre_silu, int epi,
                                                     const float* __restrict__ res, const float* __restrict__ gamma, float* __restrict__ y,
-                                                    uint16_t* __restrict__ yp, int post_silu, int ps, int ntiles) {
+                                                    uint16_t* __restrict__ yp, int post_silu, int ps, int ntiles, PlaneCtx pc) {
     constexpr int WT_ = OT == 64 ? TT / 2 : TT / 4;  // samples per wave
     constexpr int NT = WT_ / 32;                     // 32-sample MFMA tiles per wave
     static_assert(NT >= 1 && (OT == 64 || OT == 32), "block shape");
@@ -375,9 +395,9 @@ __global__ __launch_bounds__(256) void k_conv1d_bf3(const float* __restrict__ x,
             }
         }
         uint16_t* ypb = yp ? yp + (size_t)blockIdx.z * (F16 ? 1 : 2) * (Cout >> 3) * (PP + T) * 8 : nullptr;
-        if (ypb && t0 == 0) c3_zero_pad<F16>(ypb, Cout >> 3, T, o0 >> 3, OT / 8, tid, 256);
+        if (ypb && t0 == 0) c3_zero_pad<F16>(ypb, Cout >> 3, T, o0 >> 3, OT / 8, tid, 256, pc.ci);
         c3_epilogue<F16, NT>(acc, o0 + ob, t0 + tb, h, c, Cout, T, ps, bias, epi, res ? res + boff_out : nullptr, gamma, y ? y + boff_out : nullptr,
-                        ypb, post_silu);
+                        ypb, post_silu, ypb ? pc.co : nullptr);
     }
 }
 
@@ -389,7 +409,7 @@ template <bool F16, int OT, int TT, int KMAX, int EPI, bool PS1, int NIBS = 1>
 __global__ __launch_bounds__(256, F16 ? 3 : 2) void k_conv1d_bf3p(const uint16_t* __restrict__ xp, int Cin, int T, const uint16_t* __restrict__ wp,
                                                         int Cp, const float* __restrict__ bias, int Cout, int K, int dil, int epi,
                                                         const float* __restrict__ res, const float* __restrict__ gamma,
-                                                        float* __restrict__ y, uint16_t* __restrict__ yp, int post_silu, int ps) {
+                                                        float* __restrict__ y, uint16_t* __restrict__ yp, int post_silu, int ps, PlaneCtx pc) {
     constexpr int WT_ = OT == 64 ? TT / 2 : TT / 4, NT = WT_ / 32;
     static_assert(NT >= 1 && (OT == 64 || OT == 32), "block shape");
     constexpr int NPL = F16 ? 2 : 4, NPART = F16 ? 1 : 2;       // operand planes per 16-channel block (parts x channel halves)
@@ -478,9 +498,9 @@ __global__ __launch_bounds__(256, F16 ? 3 : 2) void k_conv1d_bf3p(const uint16_t
         C3_TICK(4);
     }
     uint16_t* ypb = yp ? yp + (size_t)blockIdx.z * NPART * (Cout >> 3) * row * 8 : nullptr;
-    if (ypb && t0 == 0) c3_zero_pad<F16>(ypb, Cout >> 3, T, o0 >> 3, OT / 8, tid, 256);
+    if (ypb && t0 == 0) c3_zero_pad<F16>(ypb, Cout >> 3, T, o0 >> 3, OT / 8, tid, 256, pc.ci);
     c3_epilogue<F16, NT, EPI, PS1>(acc, o0 + ob, t0 + tb, h, c, Cout, T, ps, bias, epi, res ? res + boff_out : nullptr, gamma,
-                              y ? y + boff_out : nullptr, ypb, post_silu);
+                              y ? y + boff_out : nullptr, ypb, post_silu, ypb ? pc.co : nullptr);
     C3_TICK(5);
 #ifdef FS_C3_PROF
     if (threadIdx.x == 0)
@@ -497,7 +517,7 @@ template <bool F16, int K, int NIB, int NT, int EPI, bool PS1>
 __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void k_conv1d_bf3t(const uint16_t* __restrict__ xp, int T, const uint16_t* __restrict__ wp, int Cp,
                                                         const float* __restrict__ bias, int Cout, int dil, int epi,
                                                         const float* __restrict__ res, const float* __restrict__ gamma,
-                                                        float* __restrict__ y, uint16_t* __restrict__ yp, int post_silu, int ps, int nwt) {
+                                                        float* __restrict__ y, uint16_t* __restrict__ yp, int post_silu, int ps, int nwt, PlaneCtx pc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4* ws = reinterpret_cast<u32x4*>(smem_raw);  // [NIB][K][NPL][32]
     constexpr int NPL = F16 ? 2 : 4, NPART = F16 ? 1 : 2;
@@ -514,7 +534,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void k_conv1d_bf3t(const uint
     const u32x4* xpb = reinterpret_cast<const u32x4*>(xp) + (size_t)blockIdx.z * NPART * CGi * row + PP - halo + c;
     const size_t boff_out = (size_t)blockIdx.z * Cout * T;
     uint16_t* ypb = yp ? yp + (size_t)blockIdx.z * NPART * (Cout >> 3) * row * 8 : nullptr;
-    if (ypb && blockIdx.x == 0) c3_zero_pad<F16>(ypb, Cout >> 3, T, o0 >> 3, 4, tid, 256);
+    if (ypb && blockIdx.x == 0) c3_zero_pad<F16>(ypb, Cout >> 3, T, o0 >> 3, 4, tid, 256, pc.ci);
     for (int wt = blockIdx.x * 4 + wave; wt < nwt; wt += gridDim.x * 4) {
         const int t0 = wt * (32 * NT);
         f32x16 acc[NT];
@@ -548,7 +568,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void k_conv1d_bf3t(const uint
         int Tl = T;  // opaque per tile: keeps the epilogue's ~100 row addresses from being hoisted out of the tile loop (200+ VGPRs)
         asm volatile("" : "+s"(Tl));
         c3_epilogue<F16, NT, EPI, PS1>(acc, o0, t0, h, c, Cout, Tl, ps, bias, epi, res ? res + boff_out : nullptr, gamma, y ? y + boff_out : nullptr,
-                                  ypb, post_silu);
+                                  ypb, post_silu, ypb ? pc.co : nullptr);
     }
 }
 
@@ -575,8 +595,10 @@ bool codec_conv1d_bf3_ok(int Cin, int Cout, int K, int dil) { return Cin >= 16 &
 template <bool F16>
 static void conv1d_bf3_impl(const float* x, const uint16_t* xp, int B, int Cin, int T, const uint16_t* wp, const float* bias, int Cout, int K,
                             int dil, bool pre_silu, int epi, const float* res, const float* gamma, float* y, uint16_t* yp, bool post_silu, int ps,
-                            hipStream_t st) {
+                            hipStream_t st, const uint16_t* ctx_in, uint16_t* ctx_out) {
     constexpr int NPL = F16 ? 2 : 4;
+    const PlaneCtx pc{ctx_in, ctx_out};
+    FS_REQUIRE((!ctx_in && !ctx_out) || (yp && B == 1 && T >= PP), "streaming contexts need a plane output, one item and >= 64 samples per chunk");
     FS_REQUIRE(codec_conv1d_bf3_ok(Cin, Cout, K, dil), "conv shape outside the bf16x3 kernel's range");
     FS_REQUIRE((x != nullptr) != (xp != nullptr), "exactly one of the f32 input and the plane input");
     FS_REQUIRE(y || yp, "no output");
@@ -600,7 +622,7 @@ static void conv1d_bf3_impl(const float* x, const uint16_t* xp, int B, int Cin, 
             auto go = [&](auto kern) {
                 raise_lds((const void*)kern, smem);
                 hipLaunchKernelGGL(kern, dim3((T + TT - 1) / TT, (Cout + OT - 1) / OT, B), dim3(256), smem, st, xp, Cin, T, wp, Cp, bias, Cout, K, dil,
-                                   epi, res, gamma, y, yp, post_silu ? 1 : 0, ps);
+                                   epi, res, gamma, y, yp, post_silu ? 1 : 0, ps, pc);
             };
             if (epi == CODEC_EPI_GELU) go(k_conv1d_bf3p<F16, OT, TT, 1, CODEC_EPI_GELU, true, NIBS>);
             else if (epi == CODEC_EPI_GAMMA_RES) go(k_conv1d_bf3p<F16, OT, TT, 1, CODEC_EPI_GAMMA_RES, true, NIBS>);
@@ -620,7 +642,7 @@ static void conv1d_bf3_impl(const float* x, const uint16_t* xp, int B, int Cin, 
             auto go = [&](auto kern) {
                 raise_lds((const void*)kern, smem);
                 hipLaunchKernelGGL(kern, dim3(gx, ytiles, B), dim3(256), smem, st, xp, T, wp, Cp, bias, Cout, dil, epi, res, gamma, y, yp,
-                                   post_silu ? 1 : 0, ps, nwt);
+                                   post_silu ? 1 : 0, ps, nwt, pc);
             };
 #define FS_THIN2(KK, NIB)                                                                        \
     do {                                                                                         \
@@ -645,7 +667,7 @@ static void conv1d_bf3_impl(const float* x, const uint16_t* xp, int B, int Cin, 
                 const size_t smem = 16 * ((size_t)NPL * XSP + (size_t)K * NPL * OT);
                 raise_lds((const void*)kern, smem);
                 hipLaunchKernelGGL(kern, dim3((T + TT - 1) / TT, (Cout + OT - 1) / OT, B), dim3(256), smem, st, xp, Cin, T, wp, Cp, bias, Cout,
-                                   K, dil, epi, res, gamma, y, yp, post_silu ? 1 : 0, ps);
+                                   K, dil, epi, res, gamma, y, yp, post_silu ? 1 : 0, ps, pc);
             };
             FS_REQUIRE(K <= 13, "tap count above the plane kernel's staging bound");
             // measured per tile shape (profiles/r02_vocoder_calls.txt): 32-channel blocks win everywhere (3 blocks per CU; 64-channel blocks
@@ -675,7 +697,7 @@ static void conv1d_bf3_impl(const float* x, const uint16_t* xp, int B, int Cin, 
         int gx = ntiles;
         if (loop_tiles) gx = std::max(1, std::min(ntiles, 1024 / std::max(1, ytiles * B)));  // weights stay in LDS over a loop of time tiles
         hipLaunchKernelGGL(kern, dim3(gx, ytiles, B), dim3(256), smem, st, x, Cin, T, wp, Cp, bias, Cout, K, dil, pre_silu ? 1 : 0, epi, res,
-                           gamma, y, yp, post_silu ? 1 : 0, ps, ntiles);
+                           gamma, y, yp, post_silu ? 1 : 0, ps, ntiles, pc);
     };
     if (K == 1 && Cin >= 128) {
         // pointwise convs of the ConvNeXt blocks (frame-rate T, 512..2048 channels): 8 channel blocks per barrier pair
@@ -698,25 +720,30 @@ static void conv1d_bf3_impl(const float* x, const uint16_t* xp, int B, int Cin, 
 
 void codec_conv1d_bf3(const float* x, const uint16_t* xp, int B, int Cin, int T, const uint16_t* wp, bool f16, const float* bias, int Cout, int K,
                       int dil, bool pre_silu, int epi, const float* res, const float* gamma, float* y, uint16_t* yp, bool post_silu, int ps,
-                      hipStream_t st) {
-    if (f16) conv1d_bf3_impl<true>(x, xp, B, Cin, T, wp, bias, Cout, K, dil, pre_silu, epi, res, gamma, y, yp, post_silu, ps, st);
-    else conv1d_bf3_impl<false>(x, xp, B, Cin, T, wp, bias, Cout, K, dil, pre_silu, epi, res, gamma, y, yp, post_silu, ps, st);
+                      hipStream_t st, const uint16_t* ctx_in, uint16_t* ctx_out) {
+    if (f16) conv1d_bf3_impl<true>(x, xp, B, Cin, T, wp, bias, Cout, K, dil, pre_silu, epi, res, gamma, y, yp, post_silu, ps, st, ctx_in, ctx_out);
+    else conv1d_bf3_impl<false>(x, xp, B, Cin, T, wp, bias, Cout, K, dil, pre_silu, epi, res, gamma, y, yp, post_silu, ps, st, ctx_in, ctx_out);
 }
 
-void codec_act_split(const float* x, int B, int C, int T, bool silu, uint16_t* planes, bool f16, hipStream_t st) {
+void codec_act_split(const float* x, int B, int C, int T, bool silu, uint16_t* planes, bool f16, hipStream_t st, const uint16_t* ctx_in,
+                     uint16_t* ctx_out) {
     FS_REQUIRE(C % 8 == 0, "activation planes need a multiple of 8 channels");
+    FS_REQUIRE((!ctx_in && !ctx_out) || (B == 1 && T >= PP), "streaming contexts need one item and >= 64 samples per chunk");
     const dim3 grid((T + 255) / 256, C / 8, B);
-    if (f16) hipLaunchKernelGGL(k_act_split<true>, grid, dim3(256), 0, st, x, C, T, silu ? 1 : 0, planes);
-    else hipLaunchKernelGGL(k_act_split<false>, grid, dim3(256), 0, st, x, C, T, silu ? 1 : 0, planes);
+    const PlaneCtx pc{ctx_in, ctx_out};
+    if (f16) hipLaunchKernelGGL(k_act_split<true>, grid, dim3(256), 0, st, x, C, T, silu ? 1 : 0, planes, pc);
+    else hipLaunchKernelGGL(k_act_split<false>, grid, dim3(256), 0, st, x, C, T, silu ? 1 : 0, planes, pc);
     FS_HIP(hipGetLastError());
 }
 
 void codec_mean3_planes(const float* a, const float* b, const float* c, int B, int C, int T, bool silu, uint16_t* planes, bool f16,
-                        hipStream_t st) {
+                        hipStream_t st, const uint16_t* ctx_in, uint16_t* ctx_out) {
     FS_REQUIRE(C % 8 == 0, "activation planes need a multiple of 8 channels");
+    FS_REQUIRE((!ctx_in && !ctx_out) || (B == 1 && T >= PP), "streaming contexts need one item and >= 64 samples per chunk");
     const dim3 grid((T + 255) / 256, C / 8, B);
-    if (f16) hipLaunchKernelGGL(k_mean3_planes<true>, grid, dim3(256), 0, st, a, b, c, C, T, silu ? 1 : 0, planes);
-    else hipLaunchKernelGGL(k_mean3_planes<false>, grid, dim3(256), 0, st, a, b, c, C, T, silu ? 1 : 0, planes);
+    const PlaneCtx pc{ctx_in, ctx_out};
+    if (f16) hipLaunchKernelGGL(k_mean3_planes<true>, grid, dim3(256), 0, st, a, b, c, C, T, silu ? 1 : 0, planes, pc);
+    else hipLaunchKernelGGL(k_mean3_planes<false>, grid, dim3(256), 0, st, a, b, c, C, T, silu ? 1 : 0, planes, pc);
     FS_HIP(hipGetLastError());
 }
 

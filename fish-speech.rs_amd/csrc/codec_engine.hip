@@ -94,11 +94,59 @@ class Codec final : public CodecBase {
     }
     int precision() override { return f16_ ? 2 : (bf3_ ? 1 : 0); }
 
-    void decode(const uint32_t* codes, int B, int T, float* pcm_out) override {
+    void decode(const uint32_t* codes, int B, int T, float* pcm_out) override { decode_impl(codes, B, T, pcm_out, false); }
+
+    // ---- stateful streaming (no reference counterpart; the reference vocodes an utterance in one piece, server/lib/handlers/speech.rs:98-129).
+    // Every conv of the 1.4+/1.5 codec is causal, so chunk i of a stream needs, per conv input, only the last `halo` samples of chunk i-1:
+    // the producers keep the last CODEC_PLANE_PAD slots of every plane tensor (CODEC_CTX_F32 samples of the three f32 conv inputs) in a
+    // per-tensor context and the next chunk starts from them instead of from zeros -- the PCM of the chunks, concatenated, is bit-identical
+    // to decoding the whole sequence at once, with no frame decoded twice.
+    void stream_begin() override {
+        FS_HIP(hipSetDevice(device_));
+        FS_REQUIRE(loaded_, "weights not loaded: call fs_codec_load_safetensors or fs_codec_load_synthetic first");
+        FS_REQUIRE(bf3_ && C_ % 128 == 0 && (C_ >> 5) >= 16, "streaming state needs the plane data flow: f16 / bf16x3 precision, full-size codec");
+        for (int i = 0; i < 2; ++i) {
+            sctx_p_[i].ensure((size_t)kCtxSlots * ctx_slot_bytes());
+            sctx_f_[i].ensure((size_t)3 * C_ * CODEC_CTX_F32 * sizeof(float));
+            FS_HIP(hipMemsetAsync(sctx_p_[i].p, 0, (size_t)kCtxSlots * ctx_slot_bytes(), st_));
+            FS_HIP(hipMemsetAsync(sctx_f_[i].p, 0, (size_t)3 * C_ * CODEC_CTX_F32 * sizeof(float), st_));
+        }
+        FS_HIP(hipStreamSynchronize(st_));
+        stream_chunk_ = 0;
+        stream_prec_ = precision();
+    }
+    void stream_decode(const uint32_t* codes, int T, float* pcm_out) override {
+        FS_REQUIRE(stream_chunk_ >= 0, "fs_codec_stream_begin first");
+        FS_REQUIRE(precision() == stream_prec_, "the precision mode changed inside a stream");
+        FS_REQUIRE(T >= kStreamMinFrames, "a streamed chunk needs >= 16 frames (64 samples at the vocoder's lowest rate)");
+        decode_impl(codes, 1, T, pcm_out, true);
+        ++stream_chunk_;
+    }
+    void stream_end() override { stream_chunk_ = -1; }
+
+    static constexpr int kCtxSlots = 96, kStreamMinFrames = 16;
+    size_t ctx_slot_bytes() const { return (size_t)2 * (C_ / 8) * CODEC_PLANE_PAD * 16; }  // 2 parts x C/8 groups x PAD slots x 16 B (largest tensor)
+
+    void decode_impl(const uint32_t* codes, int B, int T, float* pcm_out, bool streaming) {
         FS_HIP(hipSetDevice(device_));
         FS_REQUIRE(loaded_, "weights not loaded: call fs_codec_load_safetensors or fs_codec_load_synthetic first");
         FS_REQUIRE(B >= 1 && T >= 1, "empty input");
         use_bf3_now_ = bf3_;
+        // streaming: context slot k of this chunk is read from the buffer the previous chunk wrote and written to the other one
+        int slot = 0, fslot = 0;
+        struct PC { const uint16_t* ci; uint16_t* co; };
+        auto pctx = [&]() -> PC {
+            if (!streaming) return PC{nullptr, nullptr};
+            FS_REQUIRE(slot < kCtxSlots, "streaming context slots exhausted");
+            const size_t off = (size_t)slot++ * ctx_slot_bytes();
+            return PC{reinterpret_cast<const uint16_t*>((const uint8_t*)sctx_p_[stream_chunk_ & 1].p + off), reinterpret_cast<uint16_t*>((uint8_t*)sctx_p_[(stream_chunk_ + 1) & 1].p + off)};
+        };
+        struct FC { const float* ci; float* co; };
+        auto fctx = [&]() -> FC {
+            if (!streaming) return FC{nullptr, nullptr};
+            const size_t off = (size_t)fslot++ * C_ * CODEC_CTX_F32;
+            return FC{sctx_f_[stream_chunk_ & 1].f() + off, sctx_f_[(stream_chunk_ + 1) & 1].f() + off};
+        };
         const int G = 8;
         for (size_t i = 0; i < (size_t)B * G * T; ++i)
             if (codes[i] >= 1000u) throw Error("FSQ index out of range (gather out of bounds)");
@@ -127,11 +175,16 @@ class Codec final : public CodecBase {
             if (bb_planes) {
                 codec_tconv1d_planes(bp0, B, C_, Tc, conv(up_conv_[i]), 2, t1, st_);
                 Tc *= 2;
-                codec_dwconv_ln(t1, B, C_, Tc, R(c.dw), R(c.db), R(c.lnw), R(c.lnb), t2, st_);
+                const FC fd = fctx();  // the depthwise k = 7 conv reads 6 samples of left context
+                codec_dwconv_ln(t1, B, C_, Tc, R(c.dw), R(c.db), R(c.lnw), R(c.lnb), t2, st_, fd.ci);
+                if (streaming) codec_save_tail_f32(t1, C_, Tc, fd.co, st_);
                 codec_act_split(t2, B, C_, Tc, false, bp0, f16_, st_);
                 codec_conv1d_planes(nullptr, bp0, B, C_, Tc, conv(c.pw1), 1, false, CODEC_EPI_GELU, nullptr, nullptr, nullptr, bp1, false, st_);
-                // pwconv2 + gamma + residual: the sum feeds the next transposed conv / conv_pre as planes (no SiLU in front of either)
-                codec_conv1d_planes(nullptr, bp1, B, 4 * C_, Tc, conv(c.pw2), 1, false, CODEC_EPI_GAMMA_RES, t1, R(c.gamma), nullptr, bp0, false, st_);
+                // pwconv2 + gamma + residual: the sum feeds the next transposed conv / conv_pre as planes (no SiLU in front of either);
+                // only conv_pre (after the second block) reads left context from it
+                const PC pb = i == 1 ? pctx() : PC{nullptr, nullptr};
+                codec_conv1d_planes(nullptr, bp1, B, 4 * C_, Tc, conv(c.pw2), 1, false, CODEC_EPI_GAMMA_RES, t1, R(c.gamma), nullptr, bp0, false, st_,
+                                    pb.ci, pb.co);
                 continue;
             }
             codec_tconv1d(x, B, C_, Tc, conv(up_conv_[i]), 2, false, t1, st_);
@@ -150,8 +203,9 @@ class Codec final : public CodecBase {
             // 2 parts x 2 bytes = the f32 footprint, + the zero padding in front of every row + slack for window reads past T
             for (auto& b : pbuf_) b.ensure(act * sizeof(float) + (size_t)B * C_ * CODEC_PLANE_PAD * 4 + (256 << 10));
             xp = pbuf_[2].u16(); t1p = pbuf_[1].u16(); t2p = pbuf_[3].u16(); accp = pbuf_[4].u16();
-            if (bb_planes) codec_conv1d_planes(nullptr, bp0, B, C_, Tc, conv(conv_pre_), 1, false, CODEC_EPI_NONE, nullptr, nullptr, nullptr, xp, true, st_);
-            else codec_conv1d_planes(x, nullptr, B, C_, Tc, conv(conv_pre_), 1, false, CODEC_EPI_NONE, nullptr, nullptr, nullptr, xp, true, st_);
+            const PC px = pctx();
+            if (bb_planes) codec_conv1d_planes(nullptr, bp0, B, C_, Tc, conv(conv_pre_), 1, false, CODEC_EPI_NONE, nullptr, nullptr, nullptr, xp, true, st_, px.ci, px.co);
+            else codec_conv1d_planes(x, nullptr, B, C_, Tc, conv(conv_pre_), 1, false, CODEC_EPI_NONE, nullptr, nullptr, nullptr, xp, true, st_, px.ci, px.co);
         } else {
             codec_conv1d(x, B, C_, Tc, conv(conv_pre_), 1, false, CODEC_EPI_NONE, nullptr, nullptr, t1, st_);
             std::swap(x, t1);
@@ -162,20 +216,24 @@ class Codec final : public CodecBase {
             if (stage_planes(s)) {
                 codec_tconv1d_planes(xp, B, ch, Tc, conv(ups_[s]), rates[s], t1, st_);  // ups[i](silu(x)); xp holds split(silu(x))
                 ch /= 2; Tc *= rates[s];
-                codec_act_split(t1, B, ch, Tc, true, t1p, f16_, st_);
+                const PC p1 = pctx();
+                codec_act_split(t1, B, ch, Tc, true, t1p, f16_, st_, p1.ci, p1.co);
                 for (int j = 0; j < 3; ++j) {  // ResBlock1 (hifi_gan.rs:74-85): x += c2(silu(c1(silu(x)))), both convs dilated
                     const float* cur = t1;
                     const uint16_t* curp = t1p;
                     for (int m = 0; m < 3; ++m) {
+                        const PC pa = pctx(), pb2 = m < 2 ? pctx() : PC{nullptr, nullptr};
                         codec_conv1d_planes(nullptr, curp, B, ch, Tc, conv(res_[s][j][0][m]), dils[m], true, CODEC_EPI_NONE, nullptr, nullptr,
-                                            nullptr, t2p, true, st_);
+                                            nullptr, t2p, true, st_, pa.ci, pa.co);
                         codec_conv1d_planes(nullptr, t2p, B, ch, Tc, conv(res_[s][j][1][m]), dils[m], true, CODEC_EPI_RES, cur, nullptr, accs[j],
-                                            m < 2 ? accp : nullptr, true, st_);
+                                            m < 2 ? accp : nullptr, true, st_, pb2.ci, pb2.co);
                         cur = accs[j]; curp = accp;
                     }
                 }
-                if (stage_planes(s + 1)) codec_mean3_planes(acc0, acc1, acc2, B, ch, Tc, true, xp, f16_, st_);
-                else codec_mean3(acc0, acc1, acc2, x, (size_t)B * ch * Tc, st_);
+                if (stage_planes(s + 1)) {
+                    const PC pm = pctx();
+                    codec_mean3_planes(acc0, acc1, acc2, B, ch, Tc, true, xp, f16_, st_, pm.ci, pm.co);
+                } else codec_mean3(acc0, acc1, acc2, x, (size_t)B * ch * Tc, st_);
                 continue;
             }
             codec_tconv1d(x, B, ch, Tc, conv(ups_[s]), rates[s], true, t1, st_);  // ups[i](silu(x))
@@ -190,7 +248,9 @@ class Codec final : public CodecBase {
             }
             codec_mean3(acc0, acc1, acc2, x, (size_t)B * ch * Tc, st_);
         }
-        codec_conv1d(x, B, ch, Tc, conv(conv_post_), 1, true, CODEC_EPI_TANH, nullptr, nullptr, t1, st_);
+        const FC fp = fctx();  // conv_post (k = 13 on the 16-channel f32 mean)
+        codec_conv1d(x, B, ch, Tc, conv(conv_post_), 1, true, CODEC_EPI_TANH, nullptr, nullptr, t1, st_, fp.ci);
+        if (streaming) codec_save_tail_f32(x, ch, Tc, fp.co, st_);
         FS_HIP(hipMemcpyAsync(pcm_out, t1, sizeof(float) * (size_t)B * Tc, hipMemcpyDeviceToHost, st_));
         FS_HIP(hipStreamSynchronize(st_));
     }
@@ -458,6 +518,8 @@ class Codec final : public CodecBase {
     std::vector<size_t> relaid_off_;
     size_t raw_floats_ = 0, relaid_floats_ = 0;
     DBuf raw_, relaid_, packed_, packed16_, dcodes_, buf_[7], pbuf_[5];
+    DBuf sctx_p_[2], sctx_f_[2];            // streaming contexts (plane tensors / f32 conv inputs), ping-pong per chunk
+    int stream_chunk_ = -1, stream_prec_ = 0;  // -1: no stream open
     std::vector<size_t> packed_off_, packed16_off_;
     bool f16_ = true;   // with bf3_: the plane data flow carries single f16 operands (mode 2) instead of bf16 hi / lo pairs (mode 1)
     bool bf3_ = true, use_bf3_now_ = false;  // decode precision mode (fs_codec_set_precision); the encoder always runs exact f32

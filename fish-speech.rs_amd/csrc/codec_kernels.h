@@ -21,11 +21,14 @@ enum { CODEC_EPI_NONE = 0, CODEC_EPI_GELU = 1, CODEC_EPI_GAMMA_RES = 2, CODEC_EP
 void codec_fsq_project(const uint32_t* codes, int B, int G, int T, const float* pw, const float* pb, int dg, float* z, hipStream_t st);
 // causal conv1d, stride 1: y = epi(bias + W * pre(x)); x (B, Cin, T) -> y (B, Cout, T)
 void codec_conv1d(const float* x, int B, int Cin, int T, const ConvW& w, int dil, bool pre_silu, int epi, const float* res,
-                  const float* gamma, float* y, hipStream_t st);
+                  const float* gamma, float* y, hipStream_t st, const float* ctx = nullptr);
 // transposed conv1d with right trim: x (B, Cin, Tin) -> y (B, Cout, Tin * stride); w = polyphase layout (codec_relayout_tconv)
 void codec_tconv1d(const float* x, int B, int Cin, int Tin, const ConvW& w, int stride, bool pre_silu, float* y, hipStream_t st);
+// f32 left contexts of the streaming decode: ctx [C][CODEC_CTX_F32] = the last CODEC_CTX_F32 samples of the previous chunk (null = zeros)
+constexpr int CODEC_CTX_F32 = 16;
 void codec_dwconv_ln(const float* x, int B, int C, int T, const float* dw, const float* db, const float* lnw, const float* lnb, float* y,
-                     hipStream_t st);
+                     hipStream_t st, const float* ctx = nullptr);
+void codec_save_tail_f32(const float* x, int C, int T, float* ctx_out, hipStream_t st);
 void codec_mean3(const float* a, const float* b, const float* c, float* y, size_t n, hipStream_t st);
 void codec_relayout(const float* src, float* dst, int Cout, int CinG, int K, bool transposed, hipStream_t st);
 // ConvTranspose1d [Cin][Cout][K] -> polyphase causal-conv layout [Cin][K/stride][Cout*stride] (see codec_tconv1d)
@@ -39,12 +42,18 @@ bool codec_conv1d_bf3_ok(int Cin, int Cout, int K, int dil);
 // output: f32 `y` and / or planes `yp` = split(post_silu ? silu(v) : v) (plain convs only)
 void codec_conv1d_bf3(const float* x, const uint16_t* xp, int B, int Cin, int T, const uint16_t* wp, bool f16, const float* bias, int Cout, int K,
                       int dil, bool pre_silu, int epi, const float* res, const float* gamma, float* y, uint16_t* yp, bool post_silu, int ps,
-                      hipStream_t st);
-void codec_act_split(const float* x, int B, int C, int T, bool silu, uint16_t* planes, bool f16, hipStream_t st);
-void codec_mean3_planes(const float* a, const float* b, const float* c, int B, int C, int T, bool silu, uint16_t* planes, bool f16, hipStream_t st);
+                      hipStream_t st, const uint16_t* ctx_in = nullptr, uint16_t* ctx_out = nullptr);
+// Streaming (fs_codec_stream_*): `ctx_in` = the left context of the plane tensor being written ([parts][C/8][CODEC_PLANE_PAD][8], the last
+// CODEC_PLANE_PAD slots of the same tensor in the previous chunk; null = zeros, i.e. the start of a signal), `ctx_out` receives this
+// chunk's last CODEC_PLANE_PAD slots.  B == 1 and T >= CODEC_PLANE_PAD.
+void codec_act_split(const float* x, int B, int C, int T, bool silu, uint16_t* planes, bool f16, hipStream_t st, const uint16_t* ctx_in = nullptr,
+                     uint16_t* ctx_out = nullptr);
+void codec_mean3_planes(const float* a, const float* b, const float* c, int B, int C, int T, bool silu, uint16_t* planes, bool f16, hipStream_t st,
+                        const uint16_t* ctx_in = nullptr, uint16_t* ctx_out = nullptr);
 // conv / transposed conv of the plane data flow (decode path, bf16x3 mode): see codec_conv1d_bf3
 void codec_conv1d_planes(const float* x, const uint16_t* xp, int B, int Cin, int T, const ConvW& w, int dil, bool pre_silu, int epi,
-                         const float* res, const float* gamma, float* y, uint16_t* yp, bool post_silu, hipStream_t st);
+                         const float* res, const float* gamma, float* y, uint16_t* yp, bool post_silu, hipStream_t st,
+                         const uint16_t* ctx_in = nullptr, uint16_t* ctx_out = nullptr);
 void codec_tconv1d_planes(const uint16_t* xp, int B, int Cin, int Tin, const ConvW& w, int stride, float* y, hipStream_t st);
 // ---- encoder side (FireflyCodec::encode)
 void codec_stft_mag(const float* pcm, int n, int n_fft, int hop, int n_frames, float* lin /*[n_fft/2+1][frames]*/, hipStream_t st);

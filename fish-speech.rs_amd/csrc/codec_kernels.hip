@@ -61,7 +61,8 @@ enum { CEPI_NONE = 0, CEPI_GELU = 1, CEPI_GAMMA_RES = 2, CEPI_RES = 3, CEPI_TANH
 template <int CPT, int TPT, int ICH>
 __global__ __launch_bounds__(256) void k_conv1d(const float* __restrict__ x, int Cin, int T, const float* __restrict__ wt /*[Cin][K][Cout]*/,
                                                 const float* __restrict__ bias, int Cout, int K, int dil, int pre_silu, int epi,
-                                                const float* __restrict__ res, const float* __restrict__ gamma, float* __restrict__ y, int ps) {
+                                                const float* __restrict__ res, const float* __restrict__ gamma, float* __restrict__ y, int ps,
+                                                const float* __restrict__ ctx /*streaming: [Cin][CODEC_CTX_F32] left context, or null*/) {
     constexpr int OT = 8 * CPT, TT = 32 * TPT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int halo = (K - 1) * dil;
@@ -82,6 +83,7 @@ __global__ __launch_bounds__(256) void k_conv1d(const float* __restrict__ x, int
             const int i = e / XS, tl = e % XS;
             const int t = t0 + tl - halo;
             float v = (t >= 0 && t < T) ? x[boff_in + (size_t)(i0 + i) * T + t] : 0.f;
+            if (ctx && t < 0 && t >= -CODEC_CTX_F32) v = ctx[(size_t)(i0 + i) * CODEC_CTX_F32 + CODEC_CTX_F32 + t];
             if (pre_silu) v = dsilu(v);
             xs[i * XS + tl] = v;
         }
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(256) void k_conv1d_mfma(const float* __restrict__ x
 // One block per time step (C <= 1024 threads-strided); output stays (C, T) for the pointwise convs (k = 1) that follow.
 __global__ __launch_bounds__(256) void k_dwconv_ln(const float* __restrict__ x, int C, int T, const float* __restrict__ dw /*[C][7]*/,
                                                    const float* __restrict__ db, const float* __restrict__ lnw,
-                                                   const float* __restrict__ lnb, float* __restrict__ y) {
+                                                   const float* __restrict__ lnb, float* __restrict__ y, const float* __restrict__ ctx) {
     __shared__ float red[256];
     __shared__ float vals[1024];
     const int t = blockIdx.x;
@@ -264,6 +266,7 @@ __global__ __launch_bounds__(256) void k_dwconv_ln(const float* __restrict__ x, 
         for (int k = 0; k < 7; ++k) {
             const int tt = t + k - 6;
             if (tt >= 0) a = fmaf(dw[c * 7 + k], x[boff + (size_t)c * T + tt], a);
+            else if (ctx) a = fmaf(dw[c * 7 + k], ctx[(size_t)c * CODEC_CTX_F32 + CODEC_CTX_F32 + tt], a);  // streaming: the previous chunk's tail
         }
         a += db[c];
         vals[c] = a;
@@ -331,16 +334,17 @@ void codec_fsq_project(const uint32_t* codes, int B, int G, int T, const float* 
 }
 
 static void conv1d_launch(const float* x, int B, int Cin, int T, const ConvW& w, int dil, bool pre_silu, int epi, const float* res,
-                          const float* gamma, float* y, int ps, hipStream_t st) {
+                          const float* gamma, float* y, int ps, hipStream_t st, const float* ctx = nullptr) {
     const int K = w.k, Cout = w.cout;
     const int halo = (K - 1) * dil;
+    FS_REQUIRE(!ctx || (B == 1 && halo <= CODEC_CTX_F32 && Cout < 16), "f32 streaming context: one item, halo <= 16, the VALU conv kernel");
     auto launch = [&](auto cpt, auto tpt, auto ich) {
         constexpr int CPT = decltype(cpt)::value, TPT = decltype(tpt)::value, ICH = decltype(ich)::value;
         constexpr int OT = 8 * CPT, TT = 32 * TPT;
         const size_t smem = sizeof(float) * ((size_t)ICH * (TT + halo) + (size_t)ICH * K * OT);
         FS_REQUIRE(smem <= 64 * 1024, "conv tile does not fit LDS");
         hipLaunchKernelGGL((k_conv1d<CPT, TPT, ICH>), dim3((T + TT - 1) / TT, (Cout + OT - 1) / OT, B), dim3(256), smem, st, x, Cin, T,
-                           w.wt, w.b, Cout, K, dil, pre_silu ? 1 : 0, epi, res, gamma, y, ps);
+                           w.wt, w.b, Cout, K, dil, pre_silu ? 1 : 0, epi, res, gamma, y, ps, ctx);
     };
     using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I4 = std::integral_constant<int, 4>;
     using I8 = std::integral_constant<int, 8>; using I16 = std::integral_constant<int, 16>;
@@ -382,8 +386,8 @@ static void conv1d_launch(const float* x, int B, int Cin, int T, const ConvW& w,
 }
 
 void codec_conv1d(const float* x, int B, int Cin, int T, const ConvW& w, int dil, bool pre_silu, int epi, const float* res,
-                  const float* gamma, float* y, hipStream_t st) {
-    conv1d_launch(x, B, Cin, T, w, dil, pre_silu, epi, res, gamma, y, 1, st);
+                  const float* gamma, float* y, hipStream_t st, const float* ctx) {
+    conv1d_launch(x, B, Cin, T, w, dil, pre_silu, epi, res, gamma, y, 1, st, ctx);
 }
 
 // Transposed conv (stride s, K = s * Kc taps, right trim K - s: utils/mod.rs:110-122) as ONE causal conv with Kc taps and
@@ -398,9 +402,10 @@ void codec_tconv1d(const float* x, int B, int Cin, int Tin, const ConvW& w, int 
 }
 
 void codec_conv1d_planes(const float* x, const uint16_t* xp, int B, int Cin, int T, const ConvW& w, int dil, bool pre_silu, int epi,
-                         const float* res, const float* gamma, float* y, uint16_t* yp, bool post_silu, hipStream_t st) {
+                         const float* res, const float* gamma, float* y, uint16_t* yp, bool post_silu, hipStream_t st,
+                         const uint16_t* ctx_in, uint16_t* ctx_out) {
     FS_REQUIRE(w.wp, "the plane data flow needs packed bf16x3 weights");
-    codec_conv1d_bf3(x, xp, B, Cin, T, w.wp, w.f16, w.b, w.cout, w.k, dil, pre_silu, epi, res, gamma, y, yp, post_silu, 1, st);
+    codec_conv1d_bf3(x, xp, B, Cin, T, w.wp, w.f16, w.b, w.cout, w.k, dil, pre_silu, epi, res, gamma, y, yp, post_silu, 1, st, ctx_in, ctx_out);
 }
 
 void codec_tconv1d_planes(const uint16_t* xp, int B, int Cin, int Tin, const ConvW& w, int stride, float* y, hipStream_t st) {
@@ -409,10 +414,20 @@ void codec_tconv1d_planes(const uint16_t* xp, int B, int Cin, int Tin, const Con
                      false, stride, st);
 }
 
+__global__ void k_save_tail_f32(const float* __restrict__ x, int T, float* __restrict__ ctx) {
+    ctx[(size_t)blockIdx.x * CODEC_CTX_F32 + threadIdx.x] = x[(size_t)blockIdx.x * T + T - CODEC_CTX_F32 + threadIdx.x];
+}
+void codec_save_tail_f32(const float* x, int C, int T, float* ctx_out, hipStream_t st) {
+    FS_REQUIRE(T >= CODEC_CTX_F32, "chunk shorter than the f32 streaming context");
+    hipLaunchKernelGGL(k_save_tail_f32, dim3(C), dim3(CODEC_CTX_F32), 0, st, x, T, ctx_out);
+    FS_LAUNCH_CHECK();
+}
+
 void codec_dwconv_ln(const float* x, int B, int C, int T, const float* dw, const float* db, const float* lnw, const float* lnb, float* y,
-                     hipStream_t st) {
+                     hipStream_t st, const float* ctx) {
     FS_REQUIRE(C <= 1024, "ConvNeXt width above 1024 channels");
-    hipLaunchKernelGGL(k_dwconv_ln, dim3(T, B), dim3(256), 0, st, x, C, T, dw, db, lnw, lnb, y);
+    FS_REQUIRE(!ctx || B == 1, "f32 streaming context: one item");
+    hipLaunchKernelGGL(k_dwconv_ln, dim3(T, B), dim3(256), 0, st, x, C, T, dw, db, lnw, lnb, y, ctx);
     FS_LAUNCH_CHECK();
 }
 

@@ -176,6 +176,12 @@ int fs_codec_encode(fs_codec_t* c, const float* pcm, int n_samples, uint32_t* co
     FS_TRY(c->impl->encode(pcm, n_samples, codes_out, cap, n_frames))
 }
 int fs_codec_sample_rate(fs_codec_t* c) { return c ? c->impl->sample_rate() : -1; }
+int fs_codec_stream_begin(fs_codec_t* c) { FS_ARG(c, "null argument"); FS_TRY(c->impl->stream_begin()) }
+int fs_codec_stream_decode(fs_codec_t* c, const uint32_t* codes, int T, float* pcm_out) {
+    FS_ARG(c && codes && pcm_out, "null argument");
+    FS_TRY(c->impl->stream_decode(codes, T, pcm_out))
+}
+int fs_codec_stream_end(fs_codec_t* c) { FS_ARG(c, "null argument"); FS_TRY(c->impl->stream_end()) }
 int fs_codec_set_precision(fs_codec_t* c, int mode) { FS_ARG(c, "null argument"); FS_TRY(c->impl->set_precision(mode)) }
 int fs_codec_precision(fs_codec_t* c) { return c ? c->impl->precision() : -1; }
 

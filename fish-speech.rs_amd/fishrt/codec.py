@@ -50,6 +50,29 @@ class FireflyCodec:
                                               pcm.ctypes.data_as(C.POINTER(C.c_float))))
         return pcm
 
+    # ---- stateful streaming (fishrt.h fs_codec_stream_*): chunks of ONE code sequence, left context kept on the device
+    STREAM_MIN_FRAMES = 16
+
+    def stream_begin(self):
+        _ffi.check(_ffi.lib().fs_codec_stream_begin(self._h))
+        return self
+
+    def stream_decode(self, codes):
+        """codes u32 (8, T) or (1, 8, T), T >= 16: the next chunk of the stream -> f32 (2048 T,) PCM.  Concatenated over a stream the result
+        is bit-identical to decode() of the whole sequence; no frame is decoded twice."""
+        codes = np.ascontiguousarray(codes, np.uint32)
+        if codes.ndim == 3 and codes.shape[0] == 1:
+            codes = codes[0]
+        if codes.ndim != 2 or codes.shape[0] != 8:
+            raise ValueError("a streamed chunk must have shape (8, T)")
+        T = codes.shape[1]
+        pcm = np.empty(2048 * T, np.float32)
+        _ffi.check(_ffi.lib().fs_codec_stream_decode(self._h, codes.ctypes.data_as(C.POINTER(C.c_uint32)), T, pcm.ctypes.data_as(C.POINTER(C.c_float))))
+        return pcm
+
+    def stream_end(self):
+        _ffi.check(_ffi.lib().fs_codec_stream_end(self._h))
+
     def encode(self, pcm_data):
         """codec.rs:73-94: f32 (1, 1, n) mono 44.1 kHz PCM (the samples are flattened, spectrogram.rs:33) -> u32 (1, 8, L)."""
         if not isinstance(pcm_data, np.ndarray) or not pcm_data.flags["C_CONTIGUOUS"]:

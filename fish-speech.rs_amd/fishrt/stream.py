@@ -33,12 +33,16 @@ class StreamingSynth:
     column (no per-chunk rebuild).  stats: frames, lm_s, vocoder_busy_s, total_s, overlap_efficiency, first_audio_s (time from the call
     to the first PCM chunk)."""
 
-    def __init__(self, lm, codec, chunk=256, halo=HALO, first_chunk=32, inline=False):
+    def __init__(self, lm, codec, chunk=256, halo=HALO, first_chunk=32, inline=False, stateful=None):
         """inline: vocode a chunk inside the frame callback (the LM pauses for the 3-4 ms of a 256-frame chunk) instead of in the worker
         thread.  On ONE device the persistent decode kernels hold every CU, so a concurrent vocoder only advances one kernel per LM kernel
         boundary and both sides pay for the switching; time-slicing at chunk granularity costs the vocoder's own time and no more."""
         self.lm, self.codec, self.chunk, self.halo, self.first_chunk = lm, codec, chunk, halo, min(first_chunk, chunk)
         self.inline = inline
+        # stateful: the codec carries the convolutions' left context between chunks on the device (fs_codec_stream_*): no frame is decoded
+        # twice; chunks shorter than 16 frames (a stream's tail) still take the halo path.  Default: whenever the codec offers it.
+        # (stateful=True: required; None: used when the codec can open a stream -- the reduced test topology and the f32 mode cannot)
+        self.stateful = stateful
 
     def __call__(self, prompt, max_new_tokens, **gen_kw):
         Cb = self.lm.cfg["num_codebooks"]
@@ -49,9 +53,22 @@ class StreamingSynth:
         t_busy, t_first = [0.0], [None]
         t0 = time.perf_counter()
 
+        min_frames = getattr(self.codec, "STREAM_MIN_FRAMES", 16)
+        stateful = bool(self.stateful) or (self.stateful is None and hasattr(self.codec, "stream_decode"))
+        if stateful:
+            try:
+                self.codec.stream_begin()
+            except Exception:
+                if self.stateful:
+                    raise
+                stateful = False
+
         def vocode(a, b):
             t1 = time.perf_counter()
-            pcm_parts.append(decode_chunk(self.codec, codes, a, b, self.halo))
+            if stateful and b - a >= min_frames:
+                pcm_parts.append(self.codec.stream_decode(np.ascontiguousarray(codes[:, a:b])))
+            else:
+                pcm_parts.append(decode_chunk(self.codec, codes, a, b, self.halo))
             t_busy[0] += time.perf_counter() - t1
             if t_first[0] is None:
                 t_first[0] = time.perf_counter() - t0
@@ -107,11 +124,16 @@ class StreamingSynth:
         finally:
             q.put(None)  # the worker always gets its sentinel, also when generate_blocking raises
             th.join()
+            if stateful:
+                try:
+                    self.codec.stream_end()
+                except Exception:
+                    pass
         if errors:
             raise errors[0]
         t_all = time.perf_counter() - t0
         assert out.shape[1] == n_frames[0] and Cb == out.shape[0] and np.array_equal(out, codes[:, : n_frames[0]])
         pcm = np.concatenate(pcm_parts) if pcm_parts else np.zeros(0, np.float32)
-        self.stats = dict(frames=n_frames[0], lm_s=t_lm, vocoder_busy_s=t_busy[0], total_s=t_all, first_audio_s=t_first[0],
+        self.stats = dict(stateful=stateful, frames=n_frames[0], lm_s=t_lm, vocoder_busy_s=t_busy[0], total_s=t_all, first_audio_s=t_first[0],
                           overlap_efficiency=(t_lm + t_busy[0] - t_all) / max(t_busy[0], 1e-9))
         return out, pcm

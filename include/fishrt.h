@@ -236,6 +236,15 @@ int fs_codec_decode(fs_codec_t* c, const uint32_t* codes, int b, int T, float* p
  * -> FireflyEncoder::encode (codec/encoder.rs:38-42: ConvNeXt backbone, downsample x4, grouped FSQ).  codes_out: u32 [8, cap]
  * row-major, *n_frames = L = mel_frames / 4 codes per group.  (channel_div > 1 handles use a reduced backbone depth (1,1,2,1).) */
 int fs_codec_encode(fs_codec_t* c, const float* pcm, int n_samples, uint32_t* codes_out, size_t cap, size_t* n_frames);
+/* Stateful streaming decode (no reference counterpart: the reference vocodes an utterance in one piece, server/lib/handlers/speech.rs:98-129).
+ * Every convolution of the 1.4+ / 1.5 codec is causal (codec/utils/mod.rs:53-62,110-122), so the chunks of ONE code sequence can be decoded
+ * one after the other with the convolutions' left context carried on the device: fs_codec_stream_begin, then fs_codec_stream_decode per
+ * chunk (codes u32 [8, T] row-major, T >= 16 frames; pcm_out f32 [2048 T]), then fs_codec_stream_end.  The concatenated PCM is bit-identical
+ * to fs_codec_decode of the whole sequence and no frame is decoded twice.  Needs the plane data flow (precision mode 1 or 2, full-size codec);
+ * the precision mode must not change inside a stream; one stream per handle. */
+int fs_codec_stream_begin(fs_codec_t* c);
+int fs_codec_stream_decode(fs_codec_t* c, const uint32_t* codes, int T, float* pcm_out);
+int fs_codec_stream_end(fs_codec_t* c);
 /* FireflyCodec.sample_rate (codec/firefly.rs:13) */
 int fs_codec_sample_rate(fs_codec_t* c);
 /* Arithmetic of the decode path's convolutions (no reference counterpart: the reference runs the codec in f32,

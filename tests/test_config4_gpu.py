@@ -59,6 +59,17 @@ class _Clamp:  # random synthetic weights emit codebook entries up to 1023; the 
     def decode(self, codes):
         return self.c.decode(np.minimum(codes, 999))
 
+    STREAM_MIN_FRAMES = 16
+
+    def stream_begin(self):
+        self.c.stream_begin()
+
+    def stream_decode(self, codes):
+        return self.c.stream_decode(np.minimum(codes, 999))
+
+    def stream_end(self):
+        self.c.stream_end()
+
 
 def test_fish14_fp8_4096_frames_streamed_pcm_equals_one_shot(lm14):
     codec = fishrt.FireflyCodec(0).load_synthetic(0xC0DEC)

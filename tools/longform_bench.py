@@ -23,6 +23,10 @@ M = frames + L - 2
 class Clamp:
     def __init__(s, c): s.c = c
     def decode(s, codes): return s.c.decode(np.minimum(codes, 999))
+    STREAM_MIN_FRAMES = 16
+    def stream_begin(s): s.c.stream_begin()
+    def stream_decode(s, codes): return s.c.stream_decode(np.minimum(codes, 999))
+    def stream_end(s): s.c.stream_end()
 for rep in range(2):
     lm.clear_slow_layer_caches()
     t = time.perf_counter(); codes = lm.generate_blocking(p, M, **kw); t_lm = time.perf_counter() - t

@@ -129,6 +129,74 @@ __global__ __launch_bounds__(256) void k_conv1d(const float* __restrict__ x, int
     }
 }
 
+// ---- one output channel (HiFi-GAN conv_post: 16 -> 1, k = 13, tanh, over 2048 T samples).  k_conv1d's block shape (8 output channels
+// x 256 samples) leaves 7 of 8 threads idle there (73 us for 34 MB of input).  Here a block stages silu(x) of all input channels for 512
+// samples once and every thread produces four consecutive ones from 20 window values held in registers; same fmaf chain (channel-major, then taps), same silu / tanh as k_conv1d, so the
+// result is bit-identical to it.  ctx: streaming left context [Cin][CODEC_CTX_F32] or null.
+template <int CIN>
+__global__ __launch_bounds__(128) void k_conv1d_one(const float* __restrict__ x, int T, const float* __restrict__ wt /*[CIN][K][1]*/,
+                                                    const float* __restrict__ bias, int K, int pre_silu, int epi, float* __restrict__ y,
+                                                    const float* __restrict__ ctx) {
+    constexpr int TT = 512, HMAX = CODEC_CTX_F32;  // 128 threads x 4 consecutive samples
+    __shared__ __attribute__((aligned(16))) float xs[CIN][TT + HMAX];
+    __shared__ float ws[CIN * (HMAX + 1)];
+    const int halo = K - 1, t0 = blockIdx.x * TT;
+    const size_t boff = (size_t)blockIdx.z * CIN * T;
+    // window position tl <-> sample t0 + tl - HMAX (the window always starts HMAX samples early, so that a thread's 4 + 16 values sit at
+    // 16-byte aligned offsets; taps index it at HMAX - halo + k)
+    // (row-wise, no index division; the CIN loads of a window position are in flight together)
+    for (int tl = threadIdx.x; tl < TT + HMAX; tl += 128) {
+        const int t = t0 + tl - HMAX, tc = min(max(t, 0), T - 1);
+        const bool inside = t >= 0 && t < T, from_ctx = ctx && t < 0 && t >= -CODEC_CTX_F32;
+        float v[CIN];
+#pragma unroll
+        for (int i = 0; i < CIN; ++i) v[i] = x[boff + (size_t)i * T + tc];
+#pragma unroll
+        for (int i = 0; i < CIN; ++i) {
+            float u = inside ? v[i] : 0.f;
+            if (from_ctx) u = ctx[(size_t)i * CODEC_CTX_F32 + CODEC_CTX_F32 + t];
+            xs[i][tl] = pre_silu ? dsilu(u) : u;
+        }
+    }
+    for (int e = threadIdx.x; e < CIN * K; e += 128) ws[e] = wt[e];
+    __syncthreads();
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int base = 4 * threadIdx.x;  // window offset of this thread's first sample minus HMAX
+    for (int i = 0; i < CIN; ++i) {
+        float v[4 + HMAX];
+#pragma unroll
+        for (int q = 0; q < (4 + HMAX) / 4; ++q) {
+            const float4 f = *reinterpret_cast<const float4*>(&xs[i][base + 4 * q]);
+            v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
+        }
+        // sample j of this thread sits at v[HMAX + j]; tap k reads v[HMAX + j - halo + k]  (fully unrolled for K = 13: register indexing)
+        if (K == 13) {
+#pragma unroll
+            for (int k = 0; k < 13; ++k) {
+                const float w = ws[i * 13 + k];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = fmaf(w, v[HMAX + j - 12 + k], acc[j]);
+            }
+        } else {
+            for (int k = 0; k < K; ++k) {
+                const float w = ws[i * K + k];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = fmaf(w, xs[i][base + HMAX + j - halo + k], acc[j]);
+            }
+        }
+    }
+    const float b = bias[0];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int t = t0 + base + j;
+        if (t >= T) continue;
+        float v = acc[j] + b;
+        if (epi == CEPI_TANH) v = tanhf(v);
+        else if (epi == CEPI_GELU) v = dgelu(v);
+        y[(size_t)blockIdx.z * T + t] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ causal conv1d on the matrix cores
 // Same contract as k_conv1d, for the wide layers (Cout >= 64): the convolution is the GEMM Y[o][t] = sum_{(i,k)} W[o][(i,k)] *
 // X[(i,k)][t] with X[(i,k)][t] = pre(x[i][t + k*dil - halo]), evaluated with v_mfma_f32_32x32x2_f32 -- f32 in, f32 accumulate, so
@@ -349,6 +417,11 @@ static void conv1d_launch(const float* x, int B, int Cin, int T, const ConvW& w,
     using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I4 = std::integral_constant<int, 4>;
     using I8 = std::integral_constant<int, 8>; using I16 = std::integral_constant<int, 16>;
     const bool mfma_ok = Cin >= 16 && Cout >= 16 && K <= 13 && halo <= 256;
+    if (Cout == 1 && Cin == 16 && dil == 1 && ps == 1 && K - 1 <= CODEC_CTX_F32 && (epi == CODEC_EPI_NONE || epi == CODEC_EPI_TANH || epi == CODEC_EPI_GELU)) {
+        hipLaunchKernelGGL((k_conv1d_one<16>), dim3((T + 511) / 512, 1, B), dim3(128), 0, st, x, T, w.wt, w.b, K, pre_silu ? 1 : 0, epi, y, ctx);
+        FS_LAUNCH_CHECK();
+        return;
+    }
     if (w.wp && codec_conv1d_bf3_ok(Cin, Cout, K, dil)) {  // "bf16x3" precision mode: split operands on the bf16 matrix cores
         codec_conv1d_bf3(x, nullptr, B, Cin, T, w.wp, w.f16, w.b, Cout, K, dil, pre_silu, epi, res, gamma, y, nullptr, false, ps, st);
         return;

@@ -128,6 +128,12 @@ int fs_lm_generate_batch(fs_lm_t* lm, const uint32_t* prompts, const int* lens, 
     FS_ARG(lm && prompts && lens && sampling && codes_out && n_frames, "null argument");
     FS_TRY(lm->impl->generate_batch(prompts, lens, n, max_new_tokens, *sampling, seed, flags, codes_out, cap, n_frames))
 }
+int fs_lm_generate_multi(fs_lm_t* lm, const uint32_t* prompts, const int* lens, int n, const int* max_new_tokens, const fs_sampling* samplings,
+                         const uint64_t* seeds, uint32_t flags, uint32_t* codes_out, size_t cap, size_t* n_frames) {
+    FS_ARG(lm && prompts && lens && max_new_tokens && samplings && seeds && codes_out && n_frames, "null argument");
+    FS_TRY(lm->impl->generate_multi(prompts, lens, n, max_new_tokens, samplings, seeds, flags, codes_out, cap, n_frames))
+}
+int fs_lm_debug_read_row(fs_lm_t* lm, int row, float* out, int n_frames) { FS_ARG(lm && out, "null argument"); FS_TRY(lm->impl->debug_read_row(row, out, n_frames)) }
 int fs_lm_weights_arena(fs_lm_t* lm, void** dev_ptr, size_t* bytes) {
     FS_ARG(lm && dev_ptr && bytes, "null argument");
     FS_TRY(lm->impl->weights_arena(dev_ptr, bytes))

@@ -30,6 +30,9 @@ class LMBase {
     virtual void generate_batch(const uint32_t* prompts, const int* lens, int n, int max_new_tokens,
                                 const fs_sampling& s, uint64_t seed, uint32_t flags, uint32_t* codes_out, size_t cap,
                                 size_t* n_frames) = 0;
+    // R concurrent batch-1 requests (fishrt.h: fs_lm_generate_multi)
+    virtual void generate_multi(const uint32_t* prompts, const int* lens, int n, const int* max_new_tokens, const fs_sampling* samplings,
+                                const uint64_t* seeds, uint32_t flags, uint32_t* codes_out, size_t cap, size_t* n_frames) = 0;
     // continuous batching over the static-batch step (fishrt.h: fs_lm_session_*)
     virtual void session_begin(const fs_sampling& s, uint64_t seed, uint32_t flags) = 0;
     virtual int session_add(const uint32_t* prompt, int L, int max_new_tokens) = 0;
@@ -39,6 +42,7 @@ class LMBase {
     virtual void session_end() = 0;
     virtual void debug_capture(int n_frames) = 0;
     virtual void debug_read(float* out, int n_frames) = 0;
+    virtual void debug_read_row(int row, float* out, int n_frames) = 0;
     virtual fs_gen_stats last_stats() = 0;
     virtual void* stream() = 0;
     // measurement hook: average duration (us) of ONE launch of decode kernel `kind` (0 qkv, 1 attention, 2 wo, 3 ffn_up, 4 ffn_down) as a

@@ -22,6 +22,7 @@
 #include "fs_synth.h"
 #include "lm_kernels.h"
 #include "lm_persist.h"
+#include "lm_persist_rows.h"
 #include "safetensors.h"
 
 namespace fs {
@@ -295,6 +296,14 @@ class LM final : public LMBase {
         FS_REQUIRE(n_frames >= 0 && n_frames <= cap_frames_, "more frames than were captured");
         FS_HIP(hipStreamSynchronize(st_));
         FS_HIP(hipMemcpy(out, d_cap_.p, sizeof(float) * (size_t)n_frames * 9 * 2048, hipMemcpyDeviceToHost));
+    }
+    void debug_read_row(int row, float* out, int n_frames) override {
+        use_device();
+        FS_REQUIRE(row >= 0 && row < PR_MAX_ROWS && d_rcap_.p, "no request-row capture (fs_lm_debug_capture, then fs_lm_generate_multi)");
+        FS_REQUIRE(n_frames >= 0 && n_frames <= cap_frames_, "more frames than were captured");
+        FS_REQUIRE(sizeof(float) * ((size_t)row + 1) * cap_frames_ * 9 * 2048 <= d_rcap_.n, "row beyond the captured rows");
+        FS_HIP(hipStreamSynchronize(st_));
+        FS_HIP(hipMemcpy(out, d_rcap_.as<float>() + (size_t)row * cap_frames_ * 9 * 2048, sizeof(float) * (size_t)n_frames * 9 * 2048, hipMemcpyDeviceToHost));
     }
     fs_gen_stats last_stats() override { return stats_; }
     void* stream() override { return (void*)st_; }
@@ -1052,6 +1061,172 @@ class LM final : public LMBase {
         }
     }
 
+
+    // ---- R concurrent batch-1 requests on ONE device (lm_persist_rows.hip; no reference counterpart beyond the lock-step static batch,
+    // generate/static_batch.rs:117-274).  Row i is generate_blocking(prompt_i, max_new_tokens_i, sampling_i) on its own KV slot, sampler,
+    // repetition-penalty state and RNG stream (single_batch.rs:76-214) -- the same tokens as its own fs_lm_generate call on a cleared
+    // cache (other summation order inside the kernels: greedy tokens can differ at near-ties only); every decode frame runs the slow
+    // transformer of all rows as ONE persistent launch (weights streamed once for all rows) and the fast decoder as one launch per
+    // group of <= 4 rows.  Handles that cannot take that path (f32 / fp8, Fish <= 1.4, sampler settings outside the in-launch sampler,
+    // another call holding the device's persistent kernels) run the requests one after the other.
+    void generate_multi(const uint32_t* prompts, const int* lens, int n, const int* max_new_tokens, const fs_sampling* samplings,
+                        const uint64_t* seeds, uint32_t flags, uint32_t* codes_out, size_t cap, size_t* n_frames) override {
+        use_device();
+        require_loaded();
+        FS_REQUIRE(!sess_active_, "the handle is in session mode (fs_lm_session_end first)");
+        FS_REQUIRE(n >= 1, "Must have at least one prompt");
+        const int C = a_.num_codebooks, C1 = C + 1;
+        std::vector<size_t> poff(n);
+        {
+            size_t off = 0;
+            for (int i = 0; i < n; ++i) { FS_REQUIRE(lens[i] >= 1, "empty prompt"); FS_REQUIRE(max_new_tokens[i] >= 0, "negative max_new_tokens"); poff[i] = off; off += (size_t)C1 * lens[i]; }
+        }
+        bool rows_ok = n >= 2 && n <= PR_MAX_ROWS && n <= B_ && pslow_ok_ && persist_ok_ && !kFp8 && !legacy_ && n_audio_ <= 2048 &&
+                       !(flags & FS_GEN_NO_PERSIST) && !getenv("FISHRT_NO_ROWS");
+        for (int i = 0; i < n && rows_ok; ++i) {
+            const fs_sampling& s = samplings[i];
+            if (s.temp != 0.0) rows_ok = false;  // (sampled rows: the in-launch sampler per row is not wired into the row kernels yet)
+        }
+        std::unique_lock<std::mutex> plock;
+        if (rows_ok) { plock = std::unique_lock<std::mutex>(persist_mutex(device_), std::try_to_lock); rows_ok = plock.owns_lock(); }
+        if (!rows_ok) {
+            if (plock.owns_lock()) plock.unlock();
+            double pf = 0, dc = 0; uint64_t fr = 0, pt = 0, gl = 0;
+            for (int i = 0; i < n; ++i) {
+                clear_slow();
+                generate(prompts + poff[i], lens[i], max_new_tokens[i], samplings[i], seeds[i], flags, codes_out + (size_t)i * C * cap, cap, &n_frames[i],
+                         nullptr, nullptr, nullptr, 0, nullptr);
+                pf += stats_.prefill_ms; dc += stats_.decode_ms; fr += stats_.frames; pt += stats_.prompt_tokens; gl += stats_.graph_launches;
+            }
+            stats_.prefill_ms = pf; stats_.decode_ms = dc; stats_.frames = fr; stats_.prompt_tokens = pt; stats_.graph_launches = gl;
+            return;
+        }
+        const int R = n <= 2 ? 2 : (n <= 4 ? 4 : 8);
+        ensure_rows(R);
+        clear_slow();
+        clear_fast();
+        std::vector<long long> n_iter(n);
+        long long max_iter = 0;
+        for (int i = 0; i < n; ++i) {
+            validate_tokens(prompts + poff[i], 0, 1, lens[i]);
+            if (lens[i] > a_.max_seq_len) throw Error("prompt exceeds max_seq_len (dual_ar.rs:623-624)");
+            n_iter[i] = 1 + std::max<long long>(0, (long long)max_new_tokens[i] - lens[i] + 1);  // single_batch.rs:61,77,193-197
+            n_iter[i] = std::min<long long>(n_iter[i], (long long)a_.max_seq_len - lens[i] + 1);   // (a row stops at max_seq_len)
+            FS_REQUIRE(n_iter[i] <= out_cap_, "generation longer than the output staging buffer");
+            max_iter = std::max(max_iter, n_iter[i]);
+            ensure_capacity(i, lens[i] + (int)n_iter[i] - 1);
+        }
+        // per-row device state: sampling configuration, iteration budget, generator state (rows >= n: terminated)
+        std::vector<SampleCfg> cfgs(R);
+        std::vector<int> budget(R, 0);
+        for (int i = 0; i < R; ++i) {
+            SampleCfg cfg = base_cfg();
+            if (i < n) {
+                const fs_sampling& s = samplings[i];
+                cfg.temp = (float)s.temp; cfg.top_p = (float)s.top_p; cfg.top_p64 = s.top_p;
+                cfg.top_k = (int)std::min<uint64_t>(s.top_k, 1u << 30);
+                cfg.rep_pen = s.repetition_penalty; cfg.ignore_eos = (flags & FS_GEN_IGNORE_EOS) ? 1 : 0;
+                budget[i] = (int)n_iter[i];
+            }
+            cfgs[i] = cfg;
+        }
+        FS_HIP(hipMemcpyAsync(d_rcfg_.p, cfgs.data(), sizeof(SampleCfg) * R, hipMemcpyHostToDevice, st_));
+        FS_HIP(hipMemcpyAsync(d_rbudget_.p, budget.data(), sizeof(int) * R, hipMemcpyHostToDevice, st_));
+        float* nullp = nullptr;
+        FS_HIP(hipMemcpyAsync(d_hid_slot_.p, &nullp, sizeof(nullp), hipMemcpyHostToDevice, st_));
+        if (cap_frames_) { d_rcap_.alloc(sizeof(float) * (size_t)R * cap_frames_ * 9 * 2048); FS_HIP(hipMemsetAsync(d_rcap_.p, 0, d_rcap_.n, st_)); }
+        stats_ = {};
+        FS_HIP(hipEventRecord(ev_[0], st_));
+        for (int i = 0; i < R; ++i) {
+            SeqState ss = {};
+            if (i >= n) { ss.done = 2; FS_HIP(hipMemcpyAsync(state(i), &ss, sizeof(ss), hipMemcpyHostToDevice, st_)); continue; }
+            const int L = lens[i];
+            ss.prompt_L = L;
+            FS_HIP(hipMemcpyAsync(state(i), &ss, sizeof(ss), hipMemcpyHostToDevice, st_));
+            FS_HIP(hipMemcpyAsync(d_prompt_.p, prompts + poff[i], sizeof(uint32_t) * C1 * L, hipMemcpyHostToDevice, st_));
+            FS_HIP(hipMemcpyAsync(d_cfg_.p, &cfgs[i], sizeof(SampleCfg), hipMemcpyHostToDevice, st_));  // (embed reads the semantic range from d_cfg_)
+            RngState rng = {};
+            seed_key(seeds[i], rng.key);
+            FS_HIP(hipMemcpyAsync(d_rrng_.as<RngState>() + i, &rng, sizeof(rng), hipMemcpyHostToDevice, st_));
+            launch_reppen_reset(rows_rp(i), C, a_.codebook_size, st_);
+            prefill_tokens(i, L - 1, /*use_graph=*/false);
+            LmKernels<WT>::embed(d_, tok_emb_, cb_emb_, C, a_.codebook_size, d_cfg_.as<SampleCfg>(), d_prompt_.as<uint32_t>(), state(i), x(i), st_);
+            FS_HIP(hipStreamSynchronize(st_));  // d_prompt_ / d_cfg_ are reused by the next row
+            seq_len_[i] = L - 1;
+            stats_.prompt_tokens += (uint64_t)L;
+        }
+        use_persist_ = true; use_pslow_ = true; persist_sampled_ = false;
+        std::vector<SeqState> hs(R);
+        auto all_done = [&]() {
+            FS_HIP(hipMemcpyAsync(hs.data(), state(0), sizeof(SeqState) * R, hipMemcpyDeviceToHost, st_));
+            FS_HIP(hipStreamSynchronize(st_));
+            for (int i = 0; i < n; ++i) if (hs[i].done != 2) return false;
+            return true;
+        };
+        int maxL = 0;
+        for (int i = 0; i < n; ++i) maxL = std::max(maxL, lens[i]);
+        const bool rows_fast = !getenv("FISHRT_ROWS_FAST_SINGLE");
+        auto launch_frame = [&](long long it_) {
+            set_bucket(maxL + (int)it_);
+            RowsSlowArgs S = rows_slow_args(R);
+            launch_rows_slow(S, R, st_);
+            if (rows_fast) {
+                for (int r0 = 0; r0 < n; r0 += PR_FAST_ROWS) {
+                    const int Rf = std::min(PR_FAST_ROWS, R - r0) >= 4 ? 4 : (std::min(PR_FAST_ROWS, R - r0) >= 2 ? 2 : 1);
+                    launch_rows_fast(rows_fast_args(r0, Rf), Rf, st_);
+                }
+            } else {
+                static const int two = 2;
+                for (int i = 0; i < n; ++i) {
+                    if (it_ >= n_iter[i]) { if (it_ == n_iter[i]) FS_HIP(hipMemcpyAsync(&state(i)->done, &two, sizeof(int), hipMemcpyHostToDevice, st_)); continue; }
+                    launch_fast_persist(persist_args(i), false, st_);
+                }
+            }
+        };
+        launch_frame(0);
+        FS_HIP(hipEventRecord(ev_[1], st_));
+        long long it = 1;
+        while (it < max_iter) {
+            const long long end = std::min<long long>(max_iter, it + 32);
+            for (; it < end; ++it) launch_frame(it);
+            if (it < max_iter && all_done()) break;
+        }
+        if (!rows_fast) {  // rows whose budget ended exactly at max_iter still need their flag
+            static const int two = 2;
+            for (int i = 0; i < n; ++i) FS_HIP(hipMemcpyAsync(&state(i)->done, &two, sizeof(int), hipMemcpyHostToDevice, st_));
+        }
+        FS_HIP(hipEventRecord(ev_[2], st_));
+        FS_HIP(hipMemcpyAsync(hs.data(), state(0), sizeof(SeqState) * R, hipMemcpyDeviceToHost, st_));
+        FS_HIP(hipStreamSynchronize(st_));
+        use_persist_ = use_pslow_ = false;
+        float ms01 = 0, ms12 = 0;
+        FS_HIP(hipEventElapsedTime(&ms01, ev_[0], ev_[1]));
+        FS_HIP(hipEventElapsedTime(&ms12, ev_[1], ev_[2]));
+        stats_.prefill_ms = ms01; stats_.decode_ms = ms12; stats_.graph_launches = (uint64_t)it;
+        stats_.kernels_per_frame = (uint64_t)(1 + (rows_fast ? (n + PR_FAST_ROWS - 1) / PR_FAST_ROWS : n));
+        for (DevBuf* cb : {&d_rctl_s_, &d_rctl_f_, &d_ctl_}) {
+            uint32_t ctl[4] = {0, 0, 0, 0};
+            FS_HIP(hipMemcpy(ctl, cb->p, sizeof(ctl), hipMemcpyDeviceToHost));
+            if (ctl[1] || ctl[2]) {
+                FS_HIP(hipMemset((uint32_t*)cb->p + 1, 0, 8));
+                throw Error("request-row persistent kernels: a grid-wide wait timed out (are all 256 CUs available to this process?)");
+            }
+        }
+        std::vector<uint32_t> tmp((size_t)n * C * out_cap_);
+        FS_HIP(hipMemcpy(tmp.data(), d_out_.p, sizeof(uint32_t) * tmp.size(), hipMemcpyDeviceToHost));
+        uint64_t total = 0;
+        for (int i = 0; i < n; ++i) {
+            const size_t nb = (size_t)hs[i].n_out;
+            FS_REQUIRE(nb <= cap, "codes_out capacity too small for the generated frames");
+            for (int c = 0; c < C; ++c)
+                std::memcpy(codes_out + ((size_t)i * C + c) * cap, tmp.data() + ((size_t)i * C + c) * out_cap_, sizeof(uint32_t) * nb);
+            n_frames[i] = nb;
+            total += nb;
+            seq_len_[i] = hs[i].pos;
+        }
+        stats_.frames = total;
+    }
+
   private:
     void use_device() { FS_HIP(hipSetDevice(device_)); }
     void require_loaded() { FS_REQUIRE(loaded_, "weights not loaded: call fs_lm_load_safetensors or fs_lm_load_synthetic first"); }
@@ -1527,6 +1702,92 @@ class LM final : public LMBase {
         return A;
     }
 
+
+    // ---- request rows (lm_persist_rows.hip): MFMA weight images, row edge buffers, per-row sampler / repetition-penalty state
+    void ensure_rows(int R) {
+        if constexpr (std::is_same<WT, bf16_t>::value) {
+            if (!d_rimg_.p) {
+                d_rimg_.alloc(slow_persist_pack_bytes(a_.n_layer, false));
+                d_rhimg_.alloc((size_t)PF_BLOCKS * PS_HEAD_IMAGE);
+                launch_rows_pack(slow_.data(), a_.n_layer, slow_head_w(), n_audio_, d_rimg_.p, d_rhimg_.p, st_);
+                d_redges_s_.alloc(rows_slow_edge_bytes(PR_MAX_ROWS));
+                FS_HIP(hipMemsetAsync(d_redges_s_.p, 0, d_redges_s_.n, st_));
+                d_redges_f_.alloc(rows_fast_edge_bytes(PR_FAST_ROWS));
+                FS_HIP(hipMemsetAsync(d_redges_f_.p, 0, d_redges_f_.n, st_));
+                d_rctl_s_.alloc(256); d_rctl_f_.alloc(256);
+                FS_HIP(hipMemsetAsync(d_rctl_s_.p, 0, 256, st_));
+                FS_HIP(hipMemsetAsync(d_rctl_f_.p, 0, 256, st_));
+                d_rlogits_.alloc(sizeof(float) * PR_MAX_ROWS * PR_LD);
+                d_rcfg_.alloc(sizeof(SampleCfg) * PR_MAX_ROWS);
+                d_rrng_.alloc(sizeof(RngState) * PR_MAX_ROWS);
+                d_rbudget_.alloc(sizeof(int) * PR_MAX_ROWS);
+                const size_t ncb = a_.num_codebooks, cbs = a_.codebook_size;
+                d_rrp_mask_.alloc(sizeof(float) * PR_MAX_ROWS * ncb * cbs);
+                d_rrp_seen_.alloc((size_t)PR_MAX_ROWS * ncb * cbs);
+                d_rrp_ring_.alloc(sizeof(int) * PR_MAX_ROWS * ncb * 17);
+                d_rrp_meta_.alloc(sizeof(int) * PR_MAX_ROWS * ncb * 2);
+                FS_HIP(hipStreamSynchronize(st_));
+            }
+            (void)R;
+        } else {
+            throw Error("request rows need a bf16 handle");
+        }
+    }
+    RepPenState rows_rp(int i) {
+        const size_t ncb = a_.num_codebooks, cbs = a_.codebook_size;
+        RepPenState rp;
+        rp.mask = d_rrp_mask_.as<float>() + (size_t)i * ncb * cbs; rp.seen = d_rrp_seen_.as<uint8_t>() + (size_t)i * ncb * cbs;
+        rp.ring = d_rrp_ring_.as<int>() + (size_t)i * ncb * 17; rp.ring_meta = d_rrp_meta_.as<int>() + (size_t)i * ncb * 2;
+        return rp;
+    }
+    static constexpr int kNapsRowsSlow[6] = {24, 0, 8, 40, 32, 12}, kNapsRowsFast[6] = {16, 16, 20, 20, 20, 12};
+    RowsSlowArgs rows_slow_args(int R) {
+        RowsSlowArgs A = {};
+        A.wimg = d_rimg_.p; A.himg = d_rhimg_.p; A.norms = d_snorms_.as<float>();
+        A.n_layer = a_.n_layer; A.n_head_rows = n_audio_;
+        A.cos_t = d_cos_.as<float>(); A.sin_t = d_sin_.as<float>(); A.eps = d_.eps;
+        A.x = x(0); A.logits = d_rlogits_.as<float>(); A.state = state(0);
+        A.kv_pool = kv_pool_.p; A.layer_half = (size_t)n_pages_ * page_elems_;
+        A.page_table = d_page_table_.as<int>(); A.pt_stride = max_pages_;
+        A.n_sl = std::max(1, std::min(nc_launch_, 16 / R));
+        A.edges = d_redges_s_.as<unsigned long long>();
+        A.ctl = d_rctl_s_.as<uint32_t>();
+        A.prof = getenv("FISHRT_PERSIST_PROF") ? reinterpret_cast<unsigned long long*>(d_rctl_s_.as<uint32_t>() + 16) : nullptr;
+        set_naps(A.naps, "FISHRT_NAPS_ROWS_SLOW", kNapsRowsSlow);
+        return A;
+    }
+    RowsFastArgs rows_fast_args(int r0, int Rf) {
+        RowsFastArgs A = {};
+        (void)Rf;
+        A.wpack = d_pack_.p;
+        for (int l = 0; l < PF_LAYERS; ++l) { A.norms[2 * l] = fast_[l].attn_norm; A.norms[2 * l + 1] = fast_[l].ffn_norm; }
+        A.norms[2 * PF_LAYERS] = fast_norm_w_;
+        A.fast_emb = fast_emb_; A.tok_emb = tok_emb_; A.cb_emb = cb_emb_;
+        A.cos_t = d_cos_.as<float>(); A.sin_t = d_sin_.as<float>(); A.eps = d_.eps;
+        A.xf = x(r0); A.x = x(r0);
+        A.slow_logits = d_rlogits_.as<float>() + (size_t)r0 * PR_LD; A.n_slow = n_audio_;
+        A.cap = cap_frames_ ? d_rcap_.as<float>() + (size_t)r0 * cap_frames_ * 9 * 2048 : nullptr; A.cap_frames = cap_frames_;
+        A.state = state(r0); A.cfg = d_rcfg_.as<SampleCfg>() + r0; A.budget = d_rbudget_.as<int>() + r0;
+        const RepPenState rp = rows_rp(r0);
+        A.rp_mask = rp.mask; A.rp_ring = rp.ring; A.rp_meta = rp.ring_meta;
+        A.out_codes = d_out_.as<uint32_t>() + (size_t)r0 * a_.num_codebooks * out_cap_; A.out_cap = out_cap_;
+        A.edges = d_redges_f_.as<unsigned long long>();
+        A.ctl = d_rctl_f_.as<uint32_t>();
+        A.prof = getenv("FISHRT_PERSIST_PROF") ? reinterpret_cast<unsigned long long*>(d_rctl_f_.as<uint32_t>() + 16) : nullptr;
+        set_naps(A.naps, "FISHRT_NAPS_ROWS_FAST", kNapsRowsFast);
+        return A;
+    }
+    // the batch-1 fast kernel on row i of a multi-request call (FISHRT_ROWS_FAST_SINGLE: reference composition for the row fast kernel)
+    FastPersistArgs persist_args(int i) {
+        FastPersistArgs A = persist_args();
+        A.xf = x(i); A.x = x(i);
+        A.slow_logits = d_rlogits_.as<float>() + (size_t)i * PR_LD;
+        A.cap = cap_frames_ ? d_rcap_.as<float>() + (size_t)i * cap_frames_ * 9 * 2048 : nullptr;
+        A.state = state(i); A.cfg = d_rcfg_.as<SampleCfg>() + i; A.rp = rows_rp(i); A.rng = d_rrng_.as<RngState>() + i;
+        A.out_codes = d_out_.as<uint32_t>() + (size_t)i * a_.num_codebooks * out_cap_;
+        return A;
+    }
+
     // ---- kernel sequences
     void enqueue_slow_layers(int b) {
         for (int l = 0; l < a_.n_layer; ++l) {
@@ -1668,6 +1929,8 @@ class LM final : public LMBase {
     bool batch_warm_ = false;
     std::map<int, hipGraphExec_t> batch_graphs_;
     RepPenState rp_ = {};
+    DevBuf d_rimg_, d_rhimg_, d_redges_s_, d_redges_f_, d_rctl_s_, d_rctl_f_, d_rlogits_, d_rcfg_, d_rrng_, d_rbudget_;  // request rows (lm_persist_rows.hip)
+    DevBuf d_rrp_mask_, d_rrp_seen_, d_rrp_ring_, d_rrp_meta_, d_rcap_;
     void* h_pin_ = nullptr;
     hipGraphExec_t g_frame_ = nullptr, g_step_ = nullptr;
     hipEvent_t ev_[3] = {nullptr, nullptr, nullptr};

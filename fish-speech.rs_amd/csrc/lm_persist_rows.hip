@@ -1,0 +1,1263 @@
+// Persistent slow-transformer kernel for R concurrent batch-1 requests (see lm_persist_rows.h): one launch = forward_generate for ONE new
+// token of each of R independent sequences (24 blocks over each row's own paged KV + final norm + audio-range head).
+//
+// Reference semantics (per row identical to lm_persist_slow.hip / the per-node kernels, other summation order):
+//   forward_generate   fish_speech_core/lib/lm/dual_ar.rs:574-635 (L == 1: no mask, :360)
+//   Attention::forward dual_ar.rs:281-384;  FeedForward :160-165;  TransformerBlock :429-440;  constrain_probs_to_audio generate/utils.rs:13-16
+//   multi-request counterpart in the reference: the lock-step static batch, generate/static_batch.rs:117-274
+//
+// Structure = lm_persist_slow.hip (256 co-resident workgroups x 512 threads, all-gather edges of 8-byte {value, tag} granules, every
+// stage's weight slice streamed one stage ahead), with two changes that make a stage serve R rows for little more than one:
+//   * every GEMV runs on the matrix cores: the workgroup's weight rows are MFMA A fragments (streamed ONCE per stage for all rows), the R
+//     activation vectors -- split into three bf16 terms, exactly -- are the B columns (3 per row; 4 rows per 16-column tile); the K range
+//     is split over the 8 waves, each wave transposing its own swept K slice through 4 KB of LDS without a workgroup barrier;
+//   * the attention stage has R x 16 heads x n_sl slices = at most 256 work items, one per workgroup, each over its row's own page table.
+// Edge buffers carry a row dimension: [ring][replica][row][granules].
+#include "lm_persist_rows.h"
+
+#include <hip/hip_runtime.h>
+
+#include "fs_common.h"
+
+namespace fs {
+
+namespace {
+
+#include "lm_persist_dev.h"
+#include "lm_persist_rows_dev.h"
+
+constexpr int PS_DROR8 = 0x128;  // DPP row_ror:8
+
+// byte offsets inside a (layer, workgroup) A-fragment image (same total as the VALU image: no padding rows are stored)
+//   Wqkv: [8 waves][4 k-steps][4 q4][5 rows] x 16 B      rows 5b .., k = 128 wave + 32 j + 8 q4 .. + 8
+//   Wo  : [8][4][4][4 rows] x 16 B                       rows 4b ..
+//   W13 : [2 tiles][8][4][64 lanes] x 16 B               rows 32b + 16 tile + (lane & 15) (interleaved w1 / w3)
+//   W2  : [8][16][4][4 rows] x 16 B                      rows 4b .., k-step j: k = 1024 (j >> 2) + 128 wave + 32 (j & 3) + 8 q4 .. + 8
+constexpr size_t IR_QKV = 0, IR_WO = 10240, IR_W13 = 18432, IR_W2 = 83968;
+static_assert(IR_W2 + 32768 == PS_LAYER_IMAGE, "image layout");
+
+constexpr int RW = 36;  // row partials per (wave, request row): up to 32 weight rows + the sum of squares
+
+template <int R>
+struct SlowLds {
+    static constexpr int RPC = R < 4 ? R : 4, NCT = R / RPC;
+    static constexpr int XB = 0;                               // [8 waves][NCT][256] x 16 B staging tiles
+    static constexpr int XR = XB + 8 * NCT * 4096;             // [R][4] this workgroup's own residual elements
+    static constexpr int RED = XR + R * 16;                    // [2][8][R][RW]
+    static constexpr int QS = RED + 2 * 8 * R * RW * 4;        // attention item: rope'd q [64]
+    static constexpr int KN = QS + 256;
+    static constexpr int VN = KN + 256;
+    static constexpr int PART = VN + 256;                      // [8][72]
+    static constexpr int WMAX = PART + 8 * 72 * 4;
+    static constexpr int PAGES = WMAX + 64;                    // int [160]
+    static constexpr int END = PAGES + 160 * 4;
+    static constexpr int BYTES = END < 96 * 1024 ? 96 * 1024 : END;  // > half of the CU's LDS: one workgroup per CU
+};
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ weight images
+__global__ __launch_bounds__(PF_THREADS) void k_pr_pack_layer(LayerW w, unsigned char* __restrict__ image /*[PF_BLOCKS][PS_LAYER_IMAGE]*/) {
+    const int b = blockIdx.x, t = threadIdx.x, wave = t >> 6, lane = t & 63, m = lane & 15, q4 = lane >> 4;
+    unsigned char* im = image + (size_t)b * PS_LAYER_IMAGE;
+    const u32x4* Wq = reinterpret_cast<const u32x4*>(w.wqkv);   // row-major bf16: 128 x 16 B per 1024-wide row
+    const u32x4* Wo = reinterpret_cast<const u32x4*>(w.wo);
+    const u32x4* W13 = reinterpret_cast<const u32x4*>(w.w13);
+    const u32x4* W2 = reinterpret_cast<const u32x4*>(w.w2);     // 512 x 16 B per 4096-wide row
+    for (int j = 0; j < 4; ++j) {
+        const int ku = 16 * wave + 4 * j + q4;  // 16-byte unit of the row: elements 8 ku ..
+        if (m < 5) reinterpret_cast<u32x4*>(im + IR_QKV)[((wave * 4 + j) * 4 + q4) * 5 + m] = Wq[(size_t)(5 * b + m) * 128 + ku];
+        if (m < 4) reinterpret_cast<u32x4*>(im + IR_WO)[((wave * 4 + j) * 4 + q4) * 4 + m] = Wo[(size_t)(4 * b + m) * 128 + ku];
+        for (int tile = 0; tile < 2; ++tile)
+            reinterpret_cast<u32x4*>(im + IR_W13)[((tile * 8 + wave) * 4 + j) * 64 + lane] = W13[(size_t)(32 * b + 16 * tile + m) * 128 + ku];
+    }
+    for (int j = 0; j < 16; ++j) {
+        const int ku = 128 * (j >> 2) + 16 * wave + 4 * (j & 3) + q4;
+        if (m < 4) reinterpret_cast<u32x4*>(im + IR_W2)[((wave * 16 + j) * 4 + q4) * 4 + m] = W2[(size_t)(4 * b + m) * 512 + ku];
+    }
+}
+// head rows [8b, 8b+8): [8 waves][4 k-steps][4 q4][8 rows] x 16 B (zero beyond n_rows)
+__global__ __launch_bounds__(PF_THREADS) void k_pr_pack_head(const u32x4* __restrict__ W, int n_rows, unsigned char* __restrict__ image) {
+    const int b = blockIdx.x, t = threadIdx.x, wave = t >> 6, lane = t & 63, m = lane & 15, q4 = lane >> 4;
+    if (m >= 8) return;
+    for (int j = 0; j < 4; ++j) {
+        const int row = 8 * b + m, ku = 16 * wave + 4 * j + q4;
+        reinterpret_cast<u32x4*>(image + (size_t)b * PS_HEAD_IMAGE)[((wave * 4 + j) * 4 + q4) * 8 + m] = row < n_rows ? W[(size_t)row * 128 + ku] : u32x4{0, 0, 0, 0};
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ the step kernel
+template <int R>
+__global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
+    using L = SlowLds<R>;
+    constexpr int RPC = L::RPC, NCT = L::NCT, NSLM = 16 / R;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* xr = reinterpret_cast<float*>(smem + L::XR);
+    float* red = reinterpret_cast<float*>(smem + L::RED);
+    float* qs = reinterpret_cast<float*>(smem + L::QS);
+    float* knew = reinterpret_cast<float*>(smem + L::KN);
+    float* vnew = reinterpret_cast<float*>(smem + L::VN);
+    float* part = reinterpret_cast<float*>(smem + L::PART);
+    float* wmax = reinterpret_cast<float*>(smem + L::WMAX);
+    int* s_pages = reinterpret_cast<int*>(smem + L::PAGES);
+
+    const int tid_k = threadIdx.x, b = blockIdx.x;
+    int tid = tid_k, lane = tid & 63, wave = tid >> 6;
+    const int rep = b & (PF_REPL - 1);
+    constexpr size_t ering = (size_t)PF_REPL * R * PS_EDGE_CAP;
+    auto ebase = [&](unsigned e, int rr, int r) -> u64* { return A.edges + (size_t)(e & (PF_RING - 1)) * ering + ((size_t)rr * R + r) * PS_EDGE_CAP; };
+    auto pub = [&](unsigned e, int rr, int r, int index, unsigned tag, float value) {
+        gu64* g = (gu64*)(ebase(e, rr, r) + index);
+        __hip_atomic_store(g, ((u64)tag << 32) | (u64)__float_as_uint(value), PF_RLX_AGENT);
+    };
+
+    // ---- rows of this launch (uniform): a row whose generator has terminated is skipped by every workgroup
+    unsigned act = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) if (A.state[r].done == 0) act |= 1u << r;
+    if (!act) return;
+    const int first = __builtin_ctz(act);
+    const unsigned epoch = A.ctl[0];
+    const unsigned tag0 = epoch * 256u;
+    // ---- attention item of this workgroup: (row ar, query head ah, token slice as)
+    const int n_sl = A.n_sl;
+    const bool item = b < R * 16 * n_sl;
+    const int ar = item ? b / (16 * n_sl) : first, ah = item ? (b / n_sl) & 15 : 0, as = item ? b % n_sl : 0, ag = ah >> 3;
+    const bool att = item && ((act >> ar) & 1u);
+    const int pos = A.state[ar].pos;             // cached tokens of row ar; its new token sits at index pos
+    const int rpos = pos + A.state[ar].rope_off;
+    const int chunk_t = (pos + n_sl - 1) / n_sl;
+    const int t0 = min(pos, as * chunk_t), t1 = min(pos, (as + 1) * chunk_t);
+    const bool last_slice = att && as == n_sl - 1;
+    const int n_tok = t1 - t0;
+    const int n_tiles = att ? max((n_tok + 127) / 128, last_slice ? 1 : 0) : 0;
+    const int* ptab = A.page_table + (size_t)ar * A.pt_stride;
+    if (att) {
+        const int p0 = t0 >> 6;
+        for (int i = tid; i < 160; i += PF_THREADS) s_pages[i] = (n_tok > 0 && p0 + i <= ((t1 - 1) >> 6)) ? ptab[p0 + i] : 0;
+    }
+    const int page_new = ptab[pos >> 6];
+    float x0[R], x1[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float2 x2 = *reinterpret_cast<const float2*>(A.x + (size_t)r * 1024 + 2 * tid);
+        x0[r] = x2.x; x1[r] = x2.y;
+    }
+    __syncthreads();
+
+    const unsigned char* wimg = reinterpret_cast<const unsigned char*>(A.wimg) + (size_t)b * PS_LAYER_IMAGE;
+    const size_t layer_img = (size_t)PF_BLOCKS * PS_LAYER_IMAGE;
+    const u32x4 zero4 = u32x4{0, 0, 0, 0};
+    u32x4 wq[4], wo[4], w13[8], w2[16];
+    {
+        const int m = lane & 15, q4 = lane >> 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wq[j] = m < 5 ? reinterpret_cast<const u32x4*>(wimg + IR_QKV)[((wave * 4 + j) * 4 + q4) * 5 + m] : zero4;
+    }
+    u32x4 kreg[2] = {zero4, zero4}, vreg[2] = {zero4, zero4};
+    bool dead = false;
+    unsigned e = 0;
+    int par = 0;
+    unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = A.prof ? wall_clock64() : 0;
+#define PS_TICK(k) do { if (A.prof) { const unsigned long long n_ = wall_clock64(); tk[k] += n_ - t_last; t_last = n_; } } while (0)
+
+    auto load_kv_tile = [&](int l, int tile) {
+        const uint16_t* kpool = reinterpret_cast<const uint16_t*>(A.kv_pool) + (size_t)l * 2 * A.layer_half;
+        const uint16_t* vpool = kpool + A.layer_half;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + PF_THREADS * u;
+            const int t = min(t0 + tile * 128 + (i >> 3), max(t1 - 1, t0));
+            const int pg = s_pages[(t >> 6) - (t0 >> 6)];
+            const size_t off = ((size_t)(pg * 2 + ag) * KV_PAGE + (t & 63)) * 64 + (size_t)(i & 7) * 8;
+            kreg[u] = *reinterpret_cast<const u32x4*>(kpool + off);
+            vreg[u] = *reinterpret_cast<const u32x4*>(vpool + off);
+        }
+    };
+    // sweep of one 1024-wide vector per row: unit tid of every active row's region (an inactive row's pointer aliases an active one)
+    auto sweep_x = [&](unsigned ee, u32x4 (&v)[R]) {
+        const u64* bs[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) bs[r] = ebase(ee, rep, ((act >> r) & 1u) ? r : first);
+        pr_sweep_rows<R>(bs, (unsigned)tid * 16u, tag0 + ee + 1, v, dead, A.ctl);
+    };
+
+#pragma unroll 1
+    for (int l = 0; l < A.n_layer; ++l) {
+        const unsigned char* wl = wimg + (size_t)l * layer_img;
+        // ================= S1: (gather x) -> RMSNorm folded -> Wqkv rows [5b, 5b+5) of every row
+        {
+            tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
+            const int n = lane & 15, q4 = lane >> 4;
+            uint32_t* xt = reinterpret_cast<uint32_t*>(smem + L::XB + wave * NCT * 4096);
+            float* redw = red + (par * 8 + wave) * R * RW;
+            const float2 nw = *reinterpret_cast<const float2*>(A.norms + (size_t)(2 * l) * 1024 + 2 * tid);
+            if (l > 0) {
+                u32x4 v[R];
+                pf_nap_before_sweep(A.naps[0]);
+                sweep_x(e, v);
+#pragma unroll
+                for (int r = 0; r < R; ++r) { x0[r] = __uint_as_float(v[r].x); x1[r] = __uint_as_float(v[r].z); }
+                ++e;
+            }
+            if (att && n_tok > 0) load_kv_tile(l, 0);
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if ((act >> r) & 1u) {
+                    if ((unsigned)(2 * tid - 4 * b) < 4u) *reinterpret_cast<float2*>(xr + r * 4 + 2 * tid - 4 * b) = make_float2(x0[r], x1[r]);
+                    pr_stage_pair(xt + (r / RPC) * 1024, 3 * (r % RPC), lane, x0[r] * nw.x, x1[r] * nw.y);
+                    const float ss = pf_wave_sum(fmaf(x1[r], x1[r], x0[r] * x0[r]));
+                    if (lane == 0) redw[r * RW + 32] = ss;
+                }
+            __builtin_amdgcn_wave_barrier();
+            f32x4_t acc[1][NCT];
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) acc[0][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            pr_mfma_seg<1, NCT>(wq, 4, 0, reinterpret_cast<const u32x4*>(xt), n, q4, acc);
+            pr_extract<1, NCT, RPC, 5, RW>(acc, redw, n, q4);
+            __syncthreads();
+            for (int idx = tid; idx < 5 * R * PF_REPL; idx += PF_THREADS) {
+                const int m = idx % 5, r = (idx / 5) % R, rr = idx / (5 * R);
+                if ((act >> r) & 1u) {
+                    const float* rp = red + (par * 8) * R * RW + r * RW;
+                    float t = rp[m], tot = rp[32];
+#pragma unroll
+                    for (int w = 1; w < 8; ++w) { t += rp[w * R * RW + m]; tot += rp[w * R * RW + 32]; }
+                    pub(e, rr, r, 5 * b + m, tag0 + e + 1, t * pf_rms_inv(tot, A.eps));
+                }
+            }
+            par ^= 1;
+            PS_TICK(1);
+        }
+        // ================= S2: attention item (row ar, head ah, slice as)
+        {
+            const int m = lane & 15, q4 = lane >> 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wo[j] = m < 4 ? reinterpret_cast<const u32x4*>(wl + IR_WO)[((wave * 4 + j) * 4 + q4) * 4 + m] : zero4;
+        }
+        if (att) {
+            tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
+            const u64* eb = ebase(e, rep, ar);
+            if (tid < 96) {
+                const int unit = tid < 32 ? 32 * ah + tid : (tid < 64 ? 512 + 32 * ag + (tid - 32) : 576 + 32 * ag + (tid - 64));
+                u32x4 v;
+                pf_nap_before_sweep(A.naps[1]);
+                pf_sweep1(eb, unit, tag0 + e + 1, v, dead, A.ctl);
+                const float a0 = __uint_as_float(v.x), a1 = __uint_as_float(v.z);
+                const int j = tid & 31;
+                const float c = A.cos_t[(size_t)rpos * 32 + j], s = A.sin_t[(size_t)rpos * 32 + j];
+                if (tid < 32) {
+                    *reinterpret_cast<float2*>(qs + 2 * j) = make_float2((a0 * c - a1 * s) * 0.125f, (a0 * s + a1 * c) * 0.125f);
+                } else if (tid < 64) {
+                    const uint32_t k0 = f32_to_bf16_rne(a0 * c - a1 * s), k1 = f32_to_bf16_rne(a0 * s + a1 * c);
+                    *reinterpret_cast<float2*>(knew + 2 * j) = make_float2(bf_lo(k0), bf_lo(k1));
+                    if (last_slice && (ah & 7) == 0)
+                        reinterpret_cast<uint32_t*>(reinterpret_cast<uint16_t*>(A.kv_pool) + (size_t)l * 2 * A.layer_half +
+                                                    ((size_t)(page_new * 2 + ag) * KV_PAGE + (pos & 63)) * 64)[j] = k0 | (k1 << 16);
+                } else {
+                    const uint32_t v0 = f32_to_bf16_rne(a0), v1 = f32_to_bf16_rne(a1);
+                    *reinterpret_cast<float2*>(vnew + 2 * j) = make_float2(bf_lo(v0), bf_lo(v1));
+                    if (last_slice && (ah & 7) == 0)
+                        reinterpret_cast<uint32_t*>(reinterpret_cast<uint16_t*>(A.kv_pool) + (size_t)l * 2 * A.layer_half + A.layer_half +
+                                                    ((size_t)(page_new * 2 + ag) * KV_PAGE + (pos & 63)) * 64)[j] = v0 | (v1 << 16);
+                }
+            }
+            ++e;
+            __syncthreads();
+            float run_m = -1e30f, run_l = 0.f, run_o = 0.f;
+            const int du = tid & 7;
+            float qv[8];
+            {
+                const float4 q0 = *reinterpret_cast<const float4*>(qs + du * 8), q1 = *reinterpret_cast<const float4*>(qs + du * 8 + 4);
+                qv[0] = q0.x; qv[1] = q0.y; qv[2] = q0.z; qv[3] = q0.w; qv[4] = q1.x; qv[5] = q1.y; qv[6] = q1.z; qv[7] = q1.w;
+            }
+            for (int tile = 0; tile < n_tiles; ++tile) {
+                if (tile > 0) load_kv_tile(l, tile);
+                float sc[3];
+                bool valid[3];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int t = t0 + tile * 128 + ((tid + PF_THREADS * u) >> 3);
+                    valid[u] = t < t1;
+                    const u32x4 kk = kreg[u];
+                    float a = 0.f;
+                    a = fmaf(qv[0], bf_lo(kk.x), a); a = fmaf(qv[1], bf_hi(kk.x), a); a = fmaf(qv[2], bf_lo(kk.y), a); a = fmaf(qv[3], bf_hi(kk.y), a);
+                    a = fmaf(qv[4], bf_lo(kk.z), a); a = fmaf(qv[5], bf_hi(kk.z), a); a = fmaf(qv[6], bf_lo(kk.w), a); a = fmaf(qv[7], bf_hi(kk.w), a);
+                    a += pf_dpp<PF_XOR1>(a); a += pf_dpp<PF_XOR2>(a); a += pf_dpp<PF_HALF_MIRROR>(a);
+                    sc[u] = valid[u] ? a : -1e30f;
+                }
+                const bool has_new = last_slice && tile == n_tiles - 1 && tid < 8;
+                {
+                    float a = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) a = fmaf(qv[i], knew[du * 8 + i], a);
+                    a += pf_dpp<PF_XOR1>(a); a += pf_dpp<PF_XOR2>(a); a += pf_dpp<PF_HALF_MIRROR>(a);
+                    valid[2] = has_new;
+                    sc[2] = has_new ? a : -1e30f;
+                }
+                float m = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
+                m = fmaxf(m, pf_dpp<PF_XOR1>(m)); m = fmaxf(m, pf_dpp<PF_XOR2>(m)); m = fmaxf(m, pf_dpp<PF_HALF_MIRROR>(m)); m = fmaxf(m, pf_dpp<PF_MIRROR>(m));
+                m = fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 15)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 31))),
+                          fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 47)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 63))));
+                if (lane == 0) wmax[wave] = m;
+                __syncthreads();
+                float mt = wmax[0];
+#pragma unroll
+                for (int w = 1; w < 8; ++w) mt = fmaxf(mt, wmax[w]);
+                float o9[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const float p = valid[u] ? __expf(sc[u] - mt) : 0.f;
+                    if (du == 0) o9[8] += p;
+                    if (u < 2) {
+                        const u32x4 vv = vreg[u];
+                        o9[0] = fmaf(p, bf_lo(vv.x), o9[0]); o9[1] = fmaf(p, bf_hi(vv.x), o9[1]); o9[2] = fmaf(p, bf_lo(vv.y), o9[2]); o9[3] = fmaf(p, bf_hi(vv.y), o9[3]);
+                        o9[4] = fmaf(p, bf_lo(vv.z), o9[4]); o9[5] = fmaf(p, bf_hi(vv.z), o9[5]); o9[6] = fmaf(p, bf_lo(vv.w), o9[6]); o9[7] = fmaf(p, bf_hi(vv.w), o9[7]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) o9[i] = fmaf(p, vnew[du * 8 + i], o9[i]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 9; ++i) {
+                    float t = o9[i];
+                    t += pf_dpp<PS_DROR8>(t);
+                    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+                    t = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                    const auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+                    o9[i] = __uint_as_float(r2[0]) + __uint_as_float(r2[1]);
+                }
+                if (lane < 8) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) part[wave * 72 + lane * 8 + i] = o9[i];
+                    if (lane == 0) part[wave * 72 + 64] = o9[8];
+                }
+                __syncthreads();
+                {
+                    float lt = part[64], ot = tid < 64 ? part[tid] : 0.f;
+#pragma unroll
+                    for (int w = 1; w < 8; ++w) { lt += part[w * 72 + 64]; if (tid < 64) ot += part[w * 72 + tid]; }
+                    const float mn = fmaxf(run_m, mt);
+                    const float ca = __expf(run_m - mn), cb2 = __expf(mt - mn);
+                    run_l = run_l * ca + lt * cb2;
+                    run_o = run_o * ca + ot * cb2;
+                    run_m = mn;
+                }
+                __syncthreads();
+            }
+            const int base = (ah * n_sl + as) * 66;
+            if (tid < 64) part[tid] = run_o;
+            if (tid == 64) { part[64] = run_m; part[65] = run_l; }
+            __syncthreads();
+            for (int idx = tid; idx < 66 * PF_REPL; idx += PF_THREADS) {
+                const int jj = idx % 66, rr = idx / 66;
+                pub(e, rr, ar, base + jj, tag0 + e + 1, part[jj]);
+            }
+            __syncthreads();
+            PS_TICK(2);
+        } else {
+            ++e;
+        }
+        // ================= S3: merge the slices of every (row, head) -> Wo rows [4b, 4b+4) + residual
+        {
+            tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
+            const int n = lane & 15, q4 = lane >> 4;
+            uint32_t* xt = reinterpret_cast<uint32_t*>(smem + L::XB + wave * NCT * 4096);
+            float* redw = red + (par * 8 + wave) * R * RW;
+            const int h = tid >> 5, j = tid & 31;
+            float mM[R], mL[R], mO0[R], mO1[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) { mM[r] = -1e30f; mL[r] = 0.f; mO0[r] = 0.f; mO1[r] = 0.f; }
+            const unsigned off_o = (unsigned)((h * n_sl * 66 + 2 * j) * 8), off_ml = (unsigned)((h * n_sl * 66 + 64) * 8);
+            pf_nap_before_sweep(A.naps[2]);
+#pragma unroll
+            for (int round = 0; round < 2; ++round) {
+                // slot = 8 round + k: row slot / NSLM, slice slot % NSLM (a slot past n_sl, or of an inactive row, aliases (first, 0))
+                bool any = false;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int r = (8 * round + k) / NSLM, s = (8 * round + k) % NSLM;
+                    any |= s < n_sl && ((act >> r) & 1u);
+                }
+                if (any) {
+                    const u64* sb[8];
+                    u32x4 vo[8], vm[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int r = (8 * round + k) / NSLM, s = (8 * round + k) % NSLM;
+                        const bool ok = s < n_sl && ((act >> r) & 1u);
+                        sb[k] = ebase(e, rep, ok ? r : first) + (ok ? s : 0) * 66;
+                    }
+                    pr_sweep_att8(sb, off_o, off_ml, tag0 + e + 1, vo, vm, dead, A.ctl);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int r = (8 * round + k) / NSLM, s = (8 * round + k) % NSLM;
+                        if (s < n_sl && ((act >> r) & 1u)) {  // online flash-decoding merge, slices in ascending order
+                            const float ms = __uint_as_float(vm[k].x), ls = __uint_as_float(vm[k].z);
+                            const float mn = fmaxf(mM[r], ms);
+                            const float ca = __expf(mM[r] - mn), cb2 = __expf(ms - mn);
+                            mL[r] = mL[r] * ca + ls * cb2;
+                            mO0[r] = mO0[r] * ca + __uint_as_float(vo[k].x) * cb2;
+                            mO1[r] = mO1[r] * ca + __uint_as_float(vo[k].z) * cb2;
+                            mM[r] = mn;
+                        }
+                    }
+                }
+            }
+            ++e;
+            {   // next stage's weights (64 KB per CU), behind the sweep
+                const u32x4* wp = reinterpret_cast<const u32x4*>(wl + IR_W13);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) w13[t * 4 + jj] = wp[((t * 8 + wave) * 4 + jj) * 64 + lane];
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if ((act >> r) & 1u) {
+                    const float inv = 1.f / mL[r];
+                    pr_stage_pair(xt + (r / RPC) * 1024, 3 * (r % RPC), lane, mO0[r] * inv, mO1[r] * inv);
+                }
+            __builtin_amdgcn_wave_barrier();
+            f32x4_t acc[1][NCT];
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) acc[0][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            pr_mfma_seg<1, NCT>(wo, 4, 0, reinterpret_cast<const u32x4*>(xt), n, q4, acc);
+            pr_extract<1, NCT, RPC, 4, RW>(acc, redw, n, q4);
+            __syncthreads();
+            for (int idx = tid; idx < 4 * R * PF_REPL; idx += PF_THREADS) {
+                const int m = idx & 3, r = (idx >> 2) % R, rr = idx / (4 * R);
+                if ((act >> r) & 1u) {
+                    const float* rp = red + (par * 8) * R * RW + r * RW;
+                    float t = rp[m];
+#pragma unroll
+                    for (int w = 1; w < 8; ++w) t += rp[w * R * RW + m];
+                    pub(e, rr, r, 4 * b + m, tag0 + e + 1, xr[r * 4 + m] + t);
+                }
+            }
+            par ^= 1;
+            PS_TICK(3);
+        }
+        // ================= S4: gather h -> RMSNorm folded -> 16 SwiGLU pairs of every row
+        {
+            tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
+            const int n = lane & 15, q4 = lane >> 4;
+            uint32_t* xt = reinterpret_cast<uint32_t*>(smem + L::XB + wave * NCT * 4096);
+            float* redw = red + (par * 8 + wave) * R * RW;
+            const float2 nw = *reinterpret_cast<const float2*>(A.norms + (size_t)(2 * l + 1) * 1024 + 2 * tid);
+            u32x4 v[R];
+            pf_nap_before_sweep(A.naps[3]);
+            sweep_x(e, v);
+            ++e;
+            {   // next stage's weights
+                const int m = lane & 15;
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) w2[jj] = m < 4 ? reinterpret_cast<const u32x4*>(wl + IR_W2)[((wave * 16 + jj) * 4 + q4) * 4 + m] : zero4;
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if ((act >> r) & 1u) {
+                    const float a = __uint_as_float(v[r].x), c = __uint_as_float(v[r].z);
+                    if ((unsigned)(2 * tid - 4 * b) < 4u) *reinterpret_cast<float2*>(xr + r * 4 + 2 * tid - 4 * b) = make_float2(a, c);
+                    pr_stage_pair(xt + (r / RPC) * 1024, 3 * (r % RPC), lane, a * nw.x, c * nw.y);
+                    const float ss = pf_wave_sum(fmaf(c, c, a * a));
+                    if (lane == 0) redw[r * RW + 32] = ss;
+                }
+            __builtin_amdgcn_wave_barrier();
+            f32x4_t acc[2][NCT];
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) { acc[0][c] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[1][c] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+            pr_mfma_seg<2, NCT>(w13, 4, 0, reinterpret_cast<const u32x4*>(xt), n, q4, acc);
+            pr_extract<2, NCT, RPC, 32, RW>(acc, redw, n, q4);
+            __syncthreads();
+            for (int idx = tid; idx < 16 * R * PF_REPL; idx += PF_THREADS) {
+                const int jj = idx & 15, r = (idx >> 4) % R, rr = idx / (16 * R);
+                if ((act >> r) & 1u) {
+                    const float* rp = red + (par * 8) * R * RW + r * RW;
+                    float ga = rp[2 * jj], gb = rp[2 * jj + 1], tot = rp[32];
+#pragma unroll
+                    for (int w = 1; w < 8; ++w) { ga += rp[w * R * RW + 2 * jj]; gb += rp[w * R * RW + 2 * jj + 1]; tot += rp[w * R * RW + 32]; }
+                    const float dni = pf_rms_inv(tot, A.eps);
+                    ga *= dni; gb *= dni;
+                    pub(e, rr, r, 16 * b + jj, tag0 + e + 1, pf_silu(ga) * gb);
+                }
+            }
+            par ^= 1;
+            PS_TICK(4);
+        }
+        // ================= S5: gather the activations -> W2 rows [4b, 4b+4) + residual
+        {
+            tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
+            const int n = lane & 15, q4 = lane >> 4;
+            uint32_t* xt = reinterpret_cast<uint32_t*>(smem + L::XB + wave * NCT * 4096);
+            float* redw = red + (par * 8 + wave) * R * RW;
+            f32x4_t acc[1][NCT];
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) acc[0][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            unsigned offs[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) offs[q] = (unsigned)(tid + PF_THREADS * q) * 16u;
+            pf_nap_before_sweep(A.naps[4]);
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                const u64* bs[RPC];
+                u32x4 v[RPC][4];
+#pragma unroll
+                for (int i = 0; i < RPC; ++i) bs[i] = ebase(e, rep, ((act >> (c * RPC + i)) & 1u) ? c * RPC + i : first);
+                pr_sweep_seg4<RPC>(bs, offs, tag0 + e + 1, v, dead, A.ctl);
+                if (c == NCT - 1 && l + 1 < A.n_layer) {  // next layer's Wqkv rows
+                    const int m = lane & 15;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) wq[jj] = m < 5 ? reinterpret_cast<const u32x4*>(wl + layer_img + IR_QKV)[((wave * 4 + jj) * 4 + q4) * 5 + m] : zero4;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {  // the wave's four 128-deep K segments go through the same staging tile, one after the other
+#pragma unroll
+                    for (int i = 0; i < RPC; ++i)
+                        if ((act >> (c * RPC + i)) & 1u) pr_stage_pair(xt + c * 1024, 3 * i, lane, __uint_as_float(v[i][q].x), __uint_as_float(v[i][q].z));
+                    __builtin_amdgcn_wave_barrier();
+                    f32x4_t a1[1][1] = {{acc[0][c]}};
+                    pr_mfma_seg<1, 1>(w2, 16, 4 * q, reinterpret_cast<const u32x4*>(xt + c * 1024), n, q4, a1);
+                    acc[0][c] = a1[0][0];
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            ++e;
+            pr_extract<1, NCT, RPC, 4, RW>(acc, redw, n, q4);
+            __syncthreads();
+            for (int idx = tid; idx < 4 * R * PF_REPL; idx += PF_THREADS) {
+                const int m = idx & 3, r = (idx >> 2) % R, rr = idx / (4 * R);
+                if ((act >> r) & 1u) {
+                    const float* rp = red + (par * 8) * R * RW + r * RW;
+                    float t = rp[m];
+#pragma unroll
+                    for (int w = 1; w < 8; ++w) t += rp[w * R * RW + m];
+                    pub(e, rr, r, 4 * b + m, tag0 + e + 1, xr[r * 4 + m] + t);
+                }
+            }
+            par ^= 1;
+            PS_TICK(5);
+        }
+    }
+    // ================= head: gather the final x (the hidden state handed to the fast decoder) -> norm folded -> 8 rows
+    {
+        tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
+        const int n = lane & 15, q4 = lane >> 4;
+        uint32_t* xt = reinterpret_cast<uint32_t*>(smem + L::XB + wave * NCT * 4096);
+        float* redw = red + (par * 8 + wave) * R * RW;
+        const float2 nw = *reinterpret_cast<const float2*>(A.norms + (size_t)(2 * A.n_layer) * 1024 + 2 * tid);
+        u32x4 hd[4];
+        {
+            const int m = lane & 15;
+            const u32x4* hp = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(A.himg) + (size_t)b * PS_HEAD_IMAGE);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) hd[jj] = m < 8 ? hp[((wave * 4 + jj) * 4 + q4) * 8 + m] : zero4;
+        }
+        u32x4 v[R];
+        pf_nap_before_sweep(A.naps[5]);
+        sweep_x(e, v);
+        ++e;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if ((act >> r) & 1u) {
+                const float a = __uint_as_float(v[r].x), c = __uint_as_float(v[r].z);
+                if (b == 0) *reinterpret_cast<float2*>(A.x + (size_t)r * 1024 + 2 * tid) = make_float2(a, c);
+                pr_stage_pair(xt + (r / RPC) * 1024, 3 * (r % RPC), lane, a * nw.x, c * nw.y);
+                const float ss = pf_wave_sum(fmaf(c, c, a * a));
+                if (lane == 0) redw[r * RW + 32] = ss;
+            }
+        __builtin_amdgcn_wave_barrier();
+        f32x4_t acc[1][NCT];
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) acc[0][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        pr_mfma_seg<1, NCT>(hd, 4, 0, reinterpret_cast<const u32x4*>(xt), n, q4, acc);
+        pr_extract<1, NCT, RPC, 8, RW>(acc, redw, n, q4);
+        __syncthreads();
+        if (tid < 8 * R) {
+            const int m = tid & 7, r = tid >> 3;
+            if (((act >> r) & 1u) && 8 * b + m < A.n_head_rows) {
+                const float* rp = red + (par * 8) * R * RW + r * RW;
+                float t = rp[m], tot = rp[32];
+#pragma unroll
+                for (int w = 1; w < 8; ++w) { t += rp[w * R * RW + m]; tot += rp[w * R * RW + 32]; }
+                A.logits[(size_t)r * PR_LD + 8 * b + m] = t * pf_rms_inv(tot, A.eps);
+            }
+        }
+        PS_TICK(6);
+    }
+    if (b == 0 && tid == 0) {
+        A.ctl[0] = epoch + 1;
+        if (A.prof) for (int k = 0; k < 8; ++k) A.prof[k] += tk[k];
+    }
+#undef PS_TICK
+}
+
+// ================================================================================================ fast decoder, R request rows
+// One launch = the slow-token decision + forward_generate_fast x 8 + the 8 codebook decisions of ONE audio frame of each of R requests
+// (dual_ar.rs:638-673, single_batch.rs:102-210), greedy decoding.  Same residency as k_fast_persist (lm_persist.hip: row pairs of Wqkv /
+// Wo / fast_output + the W13 MFMA fragments of all four layers in 168 VGPRs per lane), except that W2 is streamed one stage ahead from
+// the same image (its 128 KB of LDS hold the R rows' fast-decoder K/V caches instead); every stage serves the R rows: the W13 stage as
+// 3 R matrix-core columns, the 4-5-row stages on the VALU with ONE halving tree over all rows' partial sums.
+namespace {
+
+constexpr int FRW = 36;  // row partials per (wave, request row)
+
+template <int R>
+struct FastLds {
+    static constexpr int KC = 0;                                 // [R][4 layers][8 pos][64] bf16 pairs
+    static constexpr int VC = KC + R * PF_LAYERS * 8 * 64 * 4;
+    static constexpr int QS = VC + R * PF_LAYERS * 8 * 64 * 4;   // [R][1024] rope'd q
+    static constexpr int XB = QS + R * 4096;                     // [8 waves][256] x 16 B staging tiles (one column tile: R <= 4)
+    static constexpr int XR = XB + 8 * 4096;                     // [R][4]
+    static constexpr int RED = XR + R * 16;                      // [2][8][R][FRW]
+    static constexpr int SC = RED + 2 * 8 * R * FRW * 4;         // [R][16][8]
+    static constexpr int AMAX = SC + R * 128 * 4;                // [2][R][8][2]
+    static constexpr int ROPE = AMAX + 2 * R * 8 * 2 * 4;        // cos [8][32], sin [8][32]
+    static constexpr int RING = ROPE + 2 * 8 * 32 * 4;           // per row: ring [8][17], meta [8][2], prev [16], misc [16]
+    static constexpr int RING_ROW = 8 * 17 + 16 + 16 + 16;
+    static constexpr int END = RING + R * RING_ROW * 4;
+    static constexpr int BYTES = END < 96 * 1024 ? 96 * 1024 : END;
+    static_assert(END <= 160 * 1024, "LDS budget");
+};
+
+// R rows x {q unit, k/v unit}: unit a of row i = b[i] + off_a, unit b = b[i] + off_b
+template <int N>
+__device__ __forceinline__ void pr_sweep_rows2(const u64* const (&b)[N], unsigned off_a, unsigned off_b, unsigned tag, u32x4 (&va)[N], u32x4 (&vb)[N],
+                                               bool& dead, uint32_t* ctl) {
+    static_assert(N == 1 || N == 2 || N == 4, "row counts");
+    for (unsigned spins = 0;; ++spins) {
+        if constexpr (N == 1) {
+            asm volatile("global_load_dwordx4 %0, %2, %4 sc1\n\tglobal_load_dwordx4 %1, %3, %4 sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(va[0]), "=&v"(vb[0]) : "v"(off_a), "v"(off_b), "s"(b[0]) : "memory");
+        } else if constexpr (N == 2) {
+            asm volatile("global_load_dwordx4 %0, %4, %6 sc1\n\tglobal_load_dwordx4 %2, %5, %6 sc1\n\t"
+                         "global_load_dwordx4 %1, %4, %7 sc1\n\tglobal_load_dwordx4 %3, %5, %7 sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(va[0]), "=&v"(va[1]), "=&v"(vb[0]), "=&v"(vb[1]) : "v"(off_a), "v"(off_b), "s"(b[0]), "s"(b[1]) : "memory");
+        } else {
+            asm volatile("global_load_dwordx4 %0, %8, %10 sc1\n\tglobal_load_dwordx4 %4, %9, %10 sc1\n\t"
+                         "global_load_dwordx4 %1, %8, %11 sc1\n\tglobal_load_dwordx4 %5, %9, %11 sc1\n\t"
+                         "global_load_dwordx4 %2, %8, %12 sc1\n\tglobal_load_dwordx4 %6, %9, %12 sc1\n\t"
+                         "global_load_dwordx4 %3, %8, %13 sc1\n\tglobal_load_dwordx4 %7, %9, %13 sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(va[0]), "=&v"(va[1]), "=&v"(va[2]), "=&v"(va[3]), "=&v"(vb[0]), "=&v"(vb[1]), "=&v"(vb[2]), "=&v"(vb[3])
+                         : "v"(off_a), "v"(off_b), "s"(b[0]), "s"(b[1]), "s"(b[2]), "s"(b[3]) : "memory");
+        }
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < N; ++i) ok &= pr_ok(va[i], tag) && pr_ok(vb[i], tag);
+        PR_SPIN_TAIL(ok)
+    }
+}
+
+// host ArgMax rule (LAST maximal index) over one wave: candidate (bv, bi) per lane -> {max value, largest index holding it}
+__device__ __forceinline__ void pr_wave_argmax(float bv, int bi, float& wm, int& ci) {
+    wm = bv;
+    wm = fmaxf(wm, pf_dpp<PF_XOR1>(wm)); wm = fmaxf(wm, pf_dpp<PF_XOR2>(wm));
+    wm = fmaxf(wm, pf_dpp<PF_HALF_MIRROR>(wm)); wm = fmaxf(wm, pf_dpp<PF_MIRROR>(wm));
+    wm = fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(wm), 15)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wm), 31))),
+               fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(wm), 47)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wm), 63))));
+    ci = (bv == wm) ? bi : -1;
+    ci = max(ci, __builtin_amdgcn_mov_dpp(ci, PF_XOR1, 0xF, 0xF, false)); ci = max(ci, __builtin_amdgcn_mov_dpp(ci, PF_XOR2, 0xF, 0xF, false));
+    ci = max(ci, __builtin_amdgcn_mov_dpp(ci, PF_HALF_MIRROR, 0xF, 0xF, false)); ci = max(ci, __builtin_amdgcn_mov_dpp(ci, PF_MIRROR, 0xF, 0xF, false));
+    ci = max(max(__builtin_amdgcn_readlane(ci, 15), __builtin_amdgcn_readlane(ci, 31)), max(__builtin_amdgcn_readlane(ci, 47), __builtin_amdgcn_readlane(ci, 63)));
+}
+
+// sum of N = 8, 16 or 32 per-lane values over the wave; lane with (lane & (64 / N - 1)) == 0 holds the total of value lane / (64 / N)
+template <int N>
+__device__ __forceinline__ float pr_reduce(float (&v)[N], int lane) {
+    if constexpr (N == 4 || N == 8 || N == 16 || N == 32) return pf_reduce<N>(v, lane);
+}
+
+}  // namespace
+
+template <int R>
+__global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
+    using L = FastLds<R>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* kc = reinterpret_cast<uint32_t*>(smem + L::KC);
+    uint32_t* vc = reinterpret_cast<uint32_t*>(smem + L::VC);
+    float* qs = reinterpret_cast<float*>(smem + L::QS);
+    float* xr = reinterpret_cast<float*>(smem + L::XR);
+    float* red = reinterpret_cast<float*>(smem + L::RED);
+    float* sc = reinterpret_cast<float*>(smem + L::SC);
+    float* amax = reinterpret_cast<float*>(smem + L::AMAX);
+    float* rope_c = reinterpret_cast<float*>(smem + L::ROPE);
+    float* rope_s = rope_c + 8 * 32;
+    int* s_ring = reinterpret_cast<int*>(smem + L::RING);  // per row: [0,136) ring, [136,152) meta, [152,168) prev, [168,184) misc
+    constexpr int RR = L::RING_ROW;
+
+    const int tid_k = threadIdx.x, b = blockIdx.x;
+    int tid = tid_k, lane = tid & 63, wave = tid >> 6;
+    const int rep = b & (PF_REPL - 1);
+    constexpr size_t ering = (size_t)PF_REPL * R * PF_EDGE_CAP;
+    auto ebase = [&](unsigned e, int rr, int r) -> u64* { return A.edges + (size_t)(e & (PF_RING - 1)) * ering + ((size_t)rr * R + r) * PF_EDGE_CAP; };
+    auto pub = [&](unsigned e, int rr, int r, int index, unsigned tag, float value) {
+        gu64* g = (gu64*)(ebase(e, rr, r) + index);
+        __hip_atomic_store(g, ((u64)tag << 32) | (u64)__float_as_uint(value), PF_RLX_AGENT);
+    };
+
+    // ---- per-frame inputs (read by every workgroup before its first publish; written by workgroup 0 only, behind full edges)
+    for (int i = tid; i < R * 168; i += PF_THREADS) {
+        const int r = i / 168, k = i % 168;
+        int v;
+        if (k < 136) v = A.rp_ring[r * 136 + k];
+        else if (k < 152) v = A.rp_meta[r * 16 + k - 136];
+        else v = (int)A.state[r].prev[k - 152];
+        s_ring[r * RR + k] = v;
+    }
+    if (tid < R) {
+        s_ring[tid * RR + 168 + 1] = A.state[tid].have_prev;
+        s_ring[tid * RR + 168 + 2] = A.state[tid].done;
+    }
+    if (tid == 64) s_ring[168 + 3] = (int)A.ctl[0];
+    if (tid >= 256) { const int i = tid - 256; rope_c[i] = A.cos_t[i]; rope_s[i] = A.sin_t[i]; }
+    __syncthreads();
+    const unsigned epoch = (unsigned)s_ring[168 + 3];
+    unsigned live = 0, hp = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) { if (s_ring[r * RR + 168 + 2] == 0) live |= 1u << r; if (s_ring[r * RR + 168 + 1] != 0) hp |= 1u << r; }
+    if (!live) return;
+    SampleCfg cfg[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) cfg[r] = A.cfg[r];
+    int frame[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) frame[r] = A.state[r].frame;
+
+    // ---- the slow-token decision of every live row (constrain_probs_to_audio utils.rs:13-16, rescale_semantic_tokens :45-46,
+    // single_batch.rs:102-144), redundantly on every workgroup
+    uint32_t cur0[R];
+    {
+        const int n = A.n_slow;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float lv[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int i = 4 * tid + s;
+                lv[s] = (i < n && ((live >> r) & 1u)) ? A.slow_logits[(size_t)r * PR_LD + i] : -INFINITY;
+                if (i == 0 && cfg[r].ignore_eos) lv[s] = -INFINITY;
+            }
+            float* cap = (A.cap && b == 0 && ((live >> r) & 1u) && frame[r] < A.cap_frames) ? A.cap + ((size_t)r * A.cap_frames + frame[r]) * 9 * 2048 : nullptr;
+            if (cap) *reinterpret_cast<float4*>(cap + 4 * tid) = make_float4(lv[0], lv[1], lv[2], lv[3]);
+            float bv = lv[0];
+            int bi = 4 * tid;
+#pragma unroll
+            for (int s = 1; s < 4; ++s) if (!(lv[s] < bv)) { bv = lv[s]; bi = 4 * tid + s; }
+            if (bi >= n) bi = -1;
+            float wm; int ci;
+            pr_wave_argmax(bv, bi, wm, ci);
+            if (lane == 0) { amax[(r * 8 + wave) * 2] = wm; amax[(r * 8 + wave) * 2 + 1] = __int_as_float(ci); }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float gv = amax[(r * 8) * 2];
+            int idx = __float_as_int(amax[(r * 8) * 2 + 1]);
+#pragma unroll
+            for (int w = 1; w < 8; ++w) {
+                const float v2 = amax[(r * 8 + w) * 2];
+                const int i2 = __float_as_int(amax[(r * 8 + w) * 2 + 1]);
+                if (v2 > gv || (v2 == gv && i2 > idx)) { gv = v2; idx = i2; }
+            }
+            if (A.cap && b == 0 && tid == 0 && ((live >> r) & 1u) && frame[r] < A.cap_frames)
+                A.cap[((size_t)r * A.cap_frames + frame[r]) * 9 * 2048 + 2047] = (float)idx;
+            cur0[r] = audio_tok(cfg[r], max(idx, 0));
+        }
+        __syncthreads();
+    }
+    unsigned run = 0;  // rows whose fast decoder runs: live and not terminated by <|im_end|> this frame (single_batch.rs:153-156)
+#pragma unroll
+    for (int r = 0; r < R; ++r) if (((live >> r) & 1u) && cur0[r] != cfg[r].im_end_id) run |= 1u << r;
+    if (!run && b != 0) return;
+
+    bool dead = false;
+    unsigned long long tk[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = A.prof ? wall_clock64() : 0;
+#define PF_TICK(k) do { if (A.prof) { const unsigned long long n_ = wall_clock64(); tk[k] += n_ - t_last; t_last = n_; } } while (0)
+    if (run) {
+        const int first = __builtin_ctz(run);
+        const u32x4* wp = reinterpret_cast<const u32x4*>(A.wpack) + (size_t)b * PF_CHUNKS * PF_THREADS + tid;
+        uint32_t wr[4 * PF_ROW_CHUNKS];
+        u32x4 w13v[PF_LAYERS][8];
+#pragma unroll
+        for (int c = 0; c < PF_ROW_CHUNKS; ++c) {
+            const u32x4 t4 = wp[(size_t)c * PF_THREADS];
+            wr[4 * c] = t4.x; wr[4 * c + 1] = t4.y; wr[4 * c + 2] = t4.z; wr[4 * c + 3] = t4.w;
+        }
+#pragma unroll
+        for (int c = PF_ROW_CHUNKS; c < PF_REG_CHUNKS; ++c) w13v[(c - PF_ROW_CHUNKS) / 8][(c - PF_ROW_CHUNKS) % 8] = wp[(size_t)c * PF_THREADS];
+        // repetition-penalty mask bits of this lane's two candidates of every codebook, per row
+        uint32_t mbits[R];
+        float x0[R], x1[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            mbits[r] = 0; x0[r] = 0.f; x1[r] = 0.f;
+            if ((run >> r) & 1u) {
+#pragma unroll
+                for (int cbi = 0; cbi < 8; ++cbi) {
+                    const float2 m2 = *reinterpret_cast<const float2*>(A.rp_mask + ((size_t)r * 8 + cbi) * 1024 + 2 * tid);
+                    mbits[r] |= (m2.x != 1.0f ? 1u : 0u) << (2 * cbi);
+                    mbits[r] |= (m2.y != 1.0f ? 1u : 0u) << (2 * cbi + 1);
+                }
+                const float2 xin = *reinterpret_cast<const float2*>(A.xf + (size_t)r * 1024 + 2 * tid);
+                x0[r] = xin.x; x1[r] = xin.y;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int d = 0; d < 4 * PF_ROW_CHUNKS; ++d) asm volatile("" : "+v"(wr[d]));
+#pragma unroll
+        for (int l = 0; l < PF_LAYERS; ++l)
+#pragma unroll
+            for (int u2 = 0; u2 < 8; ++u2) asm volatile("" : "+v"(w13v[l][u2]));
+        PF_TICK(0);
+        unsigned e = 0;
+        const unsigned tag0 = epoch * 256u;
+        int par = 0;
+        auto sweep_x = [&](unsigned ee, u32x4 (&v)[R]) {
+            const u64* bs[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) bs[r] = ebase(ee, rep, ((run >> r) & 1u) ? r : first);
+            pr_sweep_rows<R>(bs, (unsigned)tid * 16u, tag0 + ee + 1, v, dead, A.ctl);
+        };
+#pragma unroll 1
+        for (int cb = 0; cb < 8; ++cb) {
+            const int T = cb + 1;
+#pragma unroll
+            for (int l = 0; l < PF_LAYERS; ++l) {
+                const uint32_t* wl = wr + 9 * l;
+                // ================= S1: (gather x) -> RMSNorm folded -> Wqkv rows of every row
+                {
+                    tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
+                    const float2 nw = *reinterpret_cast<const float2*>(A.norms[2 * l] + 2 * tid);
+                    if (l > 0) {
+                        u32x4 v[R];
+                        pf_nap_before_sweep(A.naps[0]);
+                        sweep_x(e, v);
+#pragma unroll
+                        for (int r = 0; r < R; ++r) { x0[r] = __uint_as_float(v[r].x); x1[r] = __uint_as_float(v[r].z); }
+                        ++e;
+                        PF_TICK(9);
+                    }
+                    float a[8 * R];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        if ((unsigned)(2 * tid - 4 * b) < 4u) *reinterpret_cast<float2*>(xr + r * 4 + 2 * tid - 4 * b) = make_float2(x0[r], x1[r]);
+                        const float xn0 = x0[r] * nw.x, xn1 = x1[r] * nw.y;
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) a[8 * r + i] = pf_dot2(wl[i], xn0, xn1, 0.f);
+                        a[8 * r + 5] = fmaf(x1[r], x1[r], x0[r] * x0[r]);
+                        a[8 * r + 6] = 0.f; a[8 * r + 7] = 0.f;
+                    }
+                    const float tot = pf_reduce<8 * R>(a, lane);
+                    constexpr int SH = R == 4 ? 1 : (R == 2 ? 2 : 3);  // value index = lane >> SH
+                    if ((lane & ((1 << SH) - 1)) == 0) red[(par * 8 + wave) * R * FRW + ((lane >> SH) >> 3) * FRW + ((lane >> SH) & 7)] = tot;
+                    __syncthreads();
+                    for (int idx = tid; idx < 5 * R * PF_REPL; idx += PF_THREADS) {
+                        const int m = idx % 5, r = (idx / 5) % R, rr = idx / (5 * R);
+                        if ((run >> r) & 1u) {
+                            const float* rp = red + (par * 8) * R * FRW + r * FRW;
+                            float t = rp[m], ss = rp[5];
+#pragma unroll
+                            for (int w = 1; w < 8; ++w) { t += rp[w * R * FRW + m]; ss += rp[w * R * FRW + 5]; }
+                            pub(e, rr, r, 5 * b + m, tag0 + e + 1, t * pf_rms_inv(ss, A.eps));
+                        }
+                    }
+                    par ^= 1;
+                    PF_TICK(1);
+                }
+                // ================= S2: gather qkv -> RoPE, KV append, attention over T <= 8 tokens -> Wo rows + residual
+                {
+                    tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
+                    u32x4 vq[R], vk[R];
+                    {
+                        const u64* bs[R];
+#pragma unroll
+                        for (int r = 0; r < R; ++r) bs[r] = ebase(e, rep, ((run >> r) & 1u) ? r : first);
+                        pf_nap_before_sweep(A.naps[1]);
+                        if (tid < 128) pr_sweep_rows2<R>(bs, (unsigned)tid * 16u, (unsigned)(512 + tid) * 16u, tag0 + e + 1, vq, vk, dead, A.ctl);
+                        else pr_sweep_rows<R>(bs, (unsigned)tid * 16u, tag0 + e + 1, vq, dead, A.ctl);
+                    }
+                    ++e;
+                    PF_TICK(10);
+                    const int j = tid & 31;
+                    const float c = rope_c[cb * 32 + j], s = rope_s[cb * 32 + j];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const float qa = __uint_as_float(vq[r].x), qb = __uint_as_float(vq[r].z);
+                        *reinterpret_cast<float2*>(qs + r * 1024 + 2 * tid) = make_float2(qa * c - qb * s, qa * s + qb * c);
+                        if (tid < 64) {
+                            const float ka = __uint_as_float(vk[r].x), kb = __uint_as_float(vk[r].z);
+                            kc[((r * PF_LAYERS + l) * 8 + cb) * 64 + tid] = f32_to_bf16_rne(ka * c - kb * s) | (f32_to_bf16_rne(ka * s + kb * c) << 16);
+                        } else if (tid < 128) {
+                            vc[((r * PF_LAYERS + l) * 8 + cb) * 64 + tid - 64] = f32_to_bf16_rne(__uint_as_float(vk[r].x)) | (f32_to_bf16_rne(__uint_as_float(vk[r].z)) << 16);
+                        }
+                    }
+                    __syncthreads();
+                    const int h = tid >> 5, g = h >> 3, p = (tid >> 2) & 7, qd = tid & 3;
+                    float a[4 * R];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        {
+                            const float scale = 0.125f;
+                            const float4* qp = reinterpret_cast<const float4*>(qs + r * 1024 + h * 64 + qd * 16);
+                            const u32x4* kp = reinterpret_cast<const u32x4*>(kc + ((r * PF_LAYERS + l) * 8 + p) * 64 + g * 32 + qd * 8);
+                            float acc = 0.f;
+#pragma unroll
+                            for (int i = 0; i < 2; ++i) {
+                                const u32x4 kw = kp[i];
+                                const float4 q0 = qp[2 * i], q1 = qp[2 * i + 1];
+                                acc = fmaf(q0.x, bf_lo(kw.x) * scale, acc); acc = fmaf(q0.y, bf_hi(kw.x) * scale, acc);
+                                acc = fmaf(q0.z, bf_lo(kw.y) * scale, acc); acc = fmaf(q0.w, bf_hi(kw.y) * scale, acc);
+                                acc = fmaf(q1.x, bf_lo(kw.z) * scale, acc); acc = fmaf(q1.y, bf_hi(kw.z) * scale, acc);
+                                acc = fmaf(q1.z, bf_lo(kw.w) * scale, acc); acc = fmaf(q1.w, bf_hi(kw.w) * scale, acc);
+                            }
+                            acc += pf_dpp<PF_XOR1>(acc);
+                            acc += pf_dpp<PF_XOR2>(acc);
+                            if (qd == 0) sc[r * 128 + h * 8 + p] = acc;
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        float at0, at1;
+                        {
+                            float mn = -1e30f;
+#pragma unroll
+                            for (int t = 0; t < 8; ++t) if (t < T) mn = fmaxf(mn, sc[r * 128 + h * 8 + t]);
+                            float Ls = 0.f, O0 = 0.f, O1 = 0.f;
+#pragma unroll
+                            for (int t = 0; t < 8; ++t)
+                                if (t < T) {
+                                    const float pr = __expf(sc[r * 128 + h * 8 + t] - mn);
+                                    Ls += pr;
+                                    const uint32_t vw = vc[((r * PF_LAYERS + l) * 8 + t) * 64 + g * 32 + j];
+                                    O0 = fmaf(pr, bf_lo(vw), O0);
+                                    O1 = fmaf(pr, bf_hi(vw), O1);
+                                }
+                            const float inv = 1.f / Ls;
+                            at0 = O0 * inv; at1 = O1 * inv;
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) a[4 * r + i] = pf_dot2(wl[5 + i], at0, at1, 0.f);
+                    }
+                    const float tot = pf_reduce<4 * R>(a, lane);
+                    constexpr int SH = R == 4 ? 2 : (R == 2 ? 3 : 4);
+                    if ((lane & ((1 << SH) - 1)) == 0) red[(par * 8 + wave) * R * FRW + ((lane >> SH) >> 2) * FRW + ((lane >> SH) & 3)] = tot;
+                    __syncthreads();
+                    for (int idx = tid; idx < 4 * R * PF_REPL; idx += PF_THREADS) {
+                        const int m = idx & 3, r = (idx >> 2) % R, rr = idx / (4 * R);
+                        if ((run >> r) & 1u) {
+                            const float* rp = red + (par * 8) * R * FRW + r * FRW;
+                            float t = rp[m];
+#pragma unroll
+                            for (int w = 1; w < 8; ++w) t += rp[w * R * FRW + m];
+                            pub(e, rr, r, 4 * b + m, tag0 + e + 1, xr[r * 4 + m] + t);
+                        }
+                    }
+                    par ^= 1;
+                    PF_TICK(2);
+                }
+                // ================= S3: gather h -> RMSNorm folded -> 16 SwiGLU pairs of every row on the matrix cores
+                u32x4 w2r[4];
+                {
+                    tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
+                    const int n = lane & 15, q4 = lane >> 4;
+                    uint32_t* xt = reinterpret_cast<uint32_t*>(smem + L::XB + wave * 4096);
+                    float* redw = red + (par * 8 + wave) * R * FRW;
+                    const float2 nw = *reinterpret_cast<const float2*>(A.norms[2 * l + 1] + 2 * tid);
+                    u32x4 v[R];
+                    pf_nap_before_sweep(A.naps[2]);
+                    sweep_x(e, v);
+                    ++e;
+                    PF_TICK(11);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) w2r[q] = wp[(size_t)(PF_REG_CHUNKS + 4 * l + q) * PF_THREADS];  // next stage's weights (32 KB per CU)
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const float xa = __uint_as_float(v[r].x), xb2 = __uint_as_float(v[r].z);
+                        if ((unsigned)(2 * tid - 4 * b) < 4u) *reinterpret_cast<float2*>(xr + r * 4 + 2 * tid - 4 * b) = make_float2(xa, xb2);
+                        pr_stage_pair(xt, 3 * r, lane, xa * nw.x, xb2 * nw.y);
+                        const float ss = pf_wave_sum(fmaf(xb2, xb2, xa * xa));
+                        if (lane == 0) redw[r * FRW + 32] = ss;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    f32x4_t acc[2][1] = {{f32x4_t{0.f, 0.f, 0.f, 0.f}}, {f32x4_t{0.f, 0.f, 0.f, 0.f}}};
+                    pr_mfma_seg<2, 1>(&w13v[l][0], 4, 0, reinterpret_cast<const u32x4*>(xt), n, q4, acc);
+                    pr_extract<2, 1, R, 32, FRW>(acc, redw, n, q4);
+                    PF_TICK(8);
+                    __syncthreads();
+                    for (int idx = tid; idx < 16 * R * PF_REPL; idx += PF_THREADS) {
+                        const int jj = idx & 15, r = (idx >> 4) % R, rr = idx / (16 * R);
+                        if ((run >> r) & 1u) {
+                            const float* rp = red + (par * 8) * R * FRW + r * FRW;
+                            float ga = rp[2 * jj], gb = rp[2 * jj + 1], ss = rp[32];
+#pragma unroll
+                            for (int w = 1; w < 8; ++w) { ga += rp[w * R * FRW + 2 * jj]; gb += rp[w * R * FRW + 2 * jj + 1]; ss += rp[w * R * FRW + 32]; }
+                            const float dni = pf_rms_inv(ss, A.eps);
+                            ga *= dni; gb *= dni;
+                            pub(e, rr, r, 16 * b + jj, tag0 + e + 1, pf_silu(ga) * gb);
+                        }
+                    }
+                    par ^= 1;
+                    PF_TICK(3);
+                }
+                // ================= S4: gather the 4096 activations of every row -> W2 rows (streamed) + residual
+                {
+                    tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
+                    constexpr int RH = R < 2 ? R : 2;  // rows per sweep (8 x 16 B in flight per lane)
+                    float a[4 * R];
+                    unsigned offs[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) offs[q] = (unsigned)(tid + PF_THREADS * q) * 16u;
+                    pf_nap_before_sweep(A.naps[3]);
+#pragma unroll
+                    for (int r0 = 0; r0 < R; r0 += RH) {
+                        const u64* bs[RH];
+                        u32x4 v[RH][4];
+#pragma unroll
+                        for (int i = 0; i < RH; ++i) bs[i] = ebase(e, rep, ((run >> (r0 + i)) & 1u) ? r0 + i : first);
+                        pr_sweep_seg4<RH>(bs, offs, tag0 + e + 1, v, dead, A.ctl);
+#pragma unroll
+                        for (int i = 0; i < RH; ++i) {
+                            float a4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const u32x4 w = w2r[q];
+                                const float c0 = __uint_as_float(v[i][q].x), c1 = __uint_as_float(v[i][q].z);
+                                a4[0] = pf_dot2(w.x, c0, c1, a4[0]); a4[1] = pf_dot2(w.y, c0, c1, a4[1]);
+                                a4[2] = pf_dot2(w.z, c0, c1, a4[2]); a4[3] = pf_dot2(w.w, c0, c1, a4[3]);
+                            }
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) a[4 * (r0 + i) + k] = a4[k];
+                        }
+                    }
+                    ++e;
+                    PF_TICK(12);
+                    const float tot = pf_reduce<4 * R>(a, lane);
+                    constexpr int SH = R == 4 ? 2 : (R == 2 ? 3 : 4);
+                    if ((lane & ((1 << SH) - 1)) == 0) red[(par * 8 + wave) * R * FRW + ((lane >> SH) >> 2) * FRW + ((lane >> SH) & 3)] = tot;
+                    __syncthreads();
+                    for (int idx = tid; idx < 4 * R * PF_REPL; idx += PF_THREADS) {
+                        const int m = idx & 3, r = (idx >> 2) % R, rr = idx / (4 * R);
+                        if ((run >> r) & 1u) {
+                            const float* rp = red + (par * 8) * R * FRW + r * FRW;
+                            float t = rp[m];
+#pragma unroll
+                            for (int w = 1; w < 8; ++w) t += rp[w * R * FRW + m];
+                            pub(e, rr, r, 4 * b + m, tag0 + e + 1, xr[r * 4 + m] + t);
+                        }
+                    }
+                    par ^= 1;
+                    PF_TICK(4);
+                }
+            }
+            // ================= head: gather x -> fast_norm folded -> 4 rows of fast_output per row
+            {
+                tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
+                const float2 nw = *reinterpret_cast<const float2*>(A.norms[2 * PF_LAYERS] + 2 * tid);
+                u32x4 v[R];
+                pf_nap_before_sweep(A.naps[4]);
+                sweep_x(e, v);
+                ++e;
+                PF_TICK(13);
+                float a[8 * R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float xa = __uint_as_float(v[r].x), xb2 = __uint_as_float(v[r].z);
+                    const float xn0 = xa * nw.x, xn1 = xb2 * nw.y;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a[8 * r + i] = pf_dot2(wr[PF_LAYERS * 9 + i], xn0, xn1, 0.f);
+                    a[8 * r + 4] = fmaf(xb2, xb2, xa * xa);
+                    a[8 * r + 5] = 0.f; a[8 * r + 6] = 0.f; a[8 * r + 7] = 0.f;
+                }
+                const float tot = pf_reduce<8 * R>(a, lane);
+                constexpr int SH = R == 4 ? 1 : (R == 2 ? 2 : 3);
+                if ((lane & ((1 << SH) - 1)) == 0) red[(par * 8 + wave) * R * FRW + ((lane >> SH) >> 3) * FRW + ((lane >> SH) & 7)] = tot;
+                __syncthreads();
+                for (int idx = tid; idx < 4 * R * PF_REPL; idx += PF_THREADS) {
+                    const int m = idx & 3, r = (idx >> 2) % R, rr = idx / (4 * R);
+                    if ((run >> r) & 1u) {
+                        const float* rp = red + (par * 8) * R * FRW + r * FRW;
+                        float t = rp[m], ss = rp[4];
+#pragma unroll
+                        for (int w = 1; w < 8; ++w) { t += rp[w * R * FRW + m]; ss += rp[w * R * FRW + 4]; }
+                        pub(e, rr, r, 4 * b + m, tag0 + e + 1, t * pf_rms_inv(ss, A.eps));
+                    }
+                }
+                par ^= 1;
+                PF_TICK(5);
+            }
+            // ================= decisions: gather the 1024 logits of every row -> rep-pen -> argmax (LAST maximal index) -> next input
+            {
+                tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
+                u32x4 v[R];
+                pf_nap_before_sweep(A.naps[5]);
+                sweep_x(e, v);
+                ++e;
+                PF_TICK(14);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (!((run >> r) & 1u)) continue;
+                    float lv0 = __uint_as_float(v[r].x), lv1 = __uint_as_float(v[r].z);
+                    const int* ring = s_ring + r * RR;
+                    const int* meta = ring + 136;
+                    const bool have_prev = (hp >> r) & 1u;
+                    // SingleBatchedRepPenProcessor::apply (rep_pen.rs:37-65)
+                    int last = -1, dropped = -1, head = 0, len = 0;
+                    bool drop = false;
+                    if (have_prev) {
+                        last = ring[152 + cb + 1];
+                        head = (meta[cb * 2] + 16) % 17;
+                        len = meta[cb * 2 + 1] + 1;
+                        drop = len > 16;
+                        if (drop) dropped = ring[cb * 17 + (head + len - 1) % 17];
+                    }
+                    const float pen = cfg[r].rep_pen;
+                    float m0 = ((mbits[r] >> (2 * cb)) & 1u) ? pen : 1.0f, m1 = ((mbits[r] >> (2 * cb + 1)) & 1u) ? pen : 1.0f;
+                    if (have_prev) {
+                        const float o0 = m0, o1 = m1;
+                        const int i0 = 2 * tid, i1 = 2 * tid + 1;
+                        if (i0 == last) m0 = pen;
+                        if (i0 == dropped && m0 == pen) m0 = 1.0f;
+                        if (i1 == last) m1 = pen;
+                        if (i1 == dropped && m1 == pen) m1 = 1.0f;
+                        if (b == 0) {
+                            float* mk = A.rp_mask + ((size_t)r * 8 + cb) * 1024;
+                            if (m0 != o0) mk[i0] = m0;
+                            if (m1 != o1) mk[i1] = m1;
+                            if (tid == 0) { A.rp_ring[r * 136 + cb * 17 + head] = last; A.rp_meta[r * 16 + cb * 2] = head; A.rp_meta[r * 16 + cb * 2 + 1] = drop ? 16 : len; }
+                        }
+                        lv0 = lv0 / m0; lv1 = lv1 / m1;
+                    }
+                    float* cap = (A.cap && b == 0 && frame[r] < A.cap_frames) ? A.cap + (((size_t)r * A.cap_frames + frame[r]) * 9 + 1 + cb) * 2048 : nullptr;
+                    if (cap) *reinterpret_cast<float2*>(cap + 2 * tid) = make_float2(lv0, lv1);
+                    float bv = lv0;
+                    int bi = 2 * tid;
+                    if (!(lv1 < bv)) { bv = lv1; bi = 2 * tid + 1; }
+                    float wm; int ci;
+                    pr_wave_argmax(bv, bi, wm, ci);
+                    if (lane == 0) { amax[((par * R + r) * 8 + wave) * 2] = wm; amax[((par * R + r) * 8 + wave) * 2 + 1] = __int_as_float(ci); }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (!((run >> r) & 1u)) continue;
+                    float gv = amax[((par * R + r) * 8) * 2];
+                    int gi = __float_as_int(amax[((par * R + r) * 8) * 2 + 1]);
+#pragma unroll
+                    for (int w = 1; w < 8; ++w) {
+                        const float v2 = amax[((par * R + r) * 8 + w) * 2];
+                        const int i2 = __float_as_int(amax[((par * R + r) * 8 + w) * 2 + 1]);
+                        if (v2 > gv || (v2 == gv && i2 > gi)) { gv = v2; gi = i2; }
+                    }
+                    const uint32_t code = (uint32_t)max(gi, 0);
+                    if (A.cap && b == 0 && tid == 0 && frame[r] < A.cap_frames)
+                        A.cap[(((size_t)r * A.cap_frames + frame[r]) * 9 + 1 + cb) * 2048 + 1024] = (float)code;
+                    if (tid == 0) s_ring[r * RR + 168 + 4 + cb] = (int)code;
+                    if (cb != 7) {
+                        const uint32_t ew = reinterpret_cast<const uint32_t*>(A.fast_emb)[(size_t)code * 512 + tid];
+                        x0[r] = bf_lo(ew); x1[r] = bf_hi(ew);
+                    }
+                }
+                par ^= 1;
+                PF_TICK(6);
+            }
+        }
+    }
+    if (b != 0) return;
+    // ---- end of frame, workgroup 0 only, row by row (single_batch.rs:185-210 + generate_blocking :250,264-266)
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (!((live >> r) & 1u)) continue;
+        const bool eos = !((run >> r) & 1u);
+        SeqState* st = A.state + r;
+        int* misc = s_ring + r * RR + 168;
+        if (tid == 0) {
+            const int fr = st->frame;
+            uint32_t codes[8];
+            for (int c = 0; c < 8; ++c) codes[c] = eos ? 0u : (uint32_t)misc[4 + c];
+            st->cur[0] = cur0[r];
+            for (int c = 0; c < 8; ++c) st->cur[c + 1] = codes[c];
+            if (fr == 0 || !eos) {
+                const int o = st->n_out;
+                if (o < A.out_cap)
+                    for (int c = 0; c < 8; ++c) A.out_codes[((size_t)r * 8 + c) * A.out_cap + o] = codes[c];
+                st->n_out = o + 1;
+            }
+            st->prev[0] = cur0[r];
+            for (int c = 0; c < 8; ++c) st->prev[c + 1] = codes[c];
+            st->have_prev = 1;
+            st->pos += 1;
+            st->frame = fr + 1;
+            if (eos || fr + 1 >= A.budget[r]) st->done = 2;
+        }
+        // next slow input: embed([slow, c0..c7]) (dual_ar.rs:532-567)
+        {
+            const uint32_t sem = cur0[r];
+            const float mk = (sem >= cfg[r].sem_lo && sem <= cfg[r].sem_hi) ? 1.f : 0.f;
+            const uint32_t* te = reinterpret_cast<const uint32_t*>(A.tok_emb);
+            const uint32_t* ce = reinterpret_cast<const uint32_t*>(A.cb_emb);
+            const uint32_t w0 = te[(size_t)sem * 512 + tid];
+            float e0 = 0.f + bf_lo(w0), e1 = 0.f + bf_hi(w0);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const uint32_t code = eos ? 0u : (uint32_t)misc[4 + c];
+                const uint32_t wv = ce[((size_t)c * 1024 + code) * 512 + tid];
+                e0 += bf_lo(wv) * mk;
+                e1 += bf_hi(wv) * mk;
+            }
+            *reinterpret_cast<float2*>(A.x + (size_t)r * 1024 + 2 * tid) = make_float2(e0, e1);
+        }
+    }
+    if (tid == 0) A.ctl[0] = epoch + 1;
+    PF_TICK(7);
+    if (A.prof && tid == 0) for (int k = 0; k < 16; ++k) A.prof[k] += tk[k];
+#undef PF_TICK
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+size_t rows_slow_edge_bytes(int R) { return (size_t)PF_RING * PF_REPL * R * PS_EDGE_CAP * 8; }
+
+void launch_rows_pack(const LayerW* layers, int n_layer, const void* head_w, int n_head_rows, void* wimg, void* himg, hipStream_t st) {
+    for (int l = 0; l < n_layer; ++l)
+        hipLaunchKernelGGL(k_pr_pack_layer, dim3(PF_BLOCKS), dim3(PF_THREADS), 0, st, layers[l],
+                           reinterpret_cast<unsigned char*>(wimg) + (size_t)l * PF_BLOCKS * PS_LAYER_IMAGE);
+    hipLaunchKernelGGL(k_pr_pack_head, dim3(PF_BLOCKS), dim3(PF_THREADS), 0, st, reinterpret_cast<const u32x4*>(head_w), n_head_rows,
+                       reinterpret_cast<unsigned char*>(himg));
+    FS_HIP(hipGetLastError());
+}
+
+template <int R>
+static void launch_rows_slow_r(const RowsSlowArgs& a, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_slow_rows<R>), hipFuncAttributeMaxDynamicSharedMemorySize, SlowLds<R>::BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_slow_rows<R>, dim3(PF_BLOCKS), dim3(PF_THREADS), SlowLds<R>::BYTES, st, a);
+    FS_HIP(hipGetLastError());
+}
+size_t rows_fast_edge_bytes(int R) { return (size_t)PF_RING * PF_REPL * R * PF_EDGE_CAP * 8; }
+template <int R>
+static void launch_rows_fast_r(const RowsFastArgs& a, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_rows<R>), hipFuncAttributeMaxDynamicSharedMemorySize, FastLds<R>::BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_fast_rows<R>, dim3(PF_BLOCKS), dim3(PF_THREADS), FastLds<R>::BYTES, st, a);
+    FS_HIP(hipGetLastError());
+}
+void launch_rows_fast(const RowsFastArgs& a, int R, hipStream_t st) {
+    if (R == 1) launch_rows_fast_r<1>(a, st);
+    else if (R == 2) launch_rows_fast_r<2>(a, st);
+    else if (R == 4) launch_rows_fast_r<4>(a, st);
+    else throw Error("launch_rows_fast: R must be 1, 2 or 4");
+}
+void launch_rows_slow(const RowsSlowArgs& a, int R, hipStream_t st) {
+    FS_REQUIRE(R * a.n_sl <= 16 && a.n_sl >= 1, "rows x attention slices exceed the 256 attention items of a launch");
+    if (R == 2) launch_rows_slow_r<2>(a, st);
+    else if (R == 4) launch_rows_slow_r<4>(a, st);
+    else if (R == 8) launch_rows_slow_r<8>(a, st);
+    else throw Error("launch_rows_slow: R must be 2, 4 or 8");
+}
+
+}  // namespace fs

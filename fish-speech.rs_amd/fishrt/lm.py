@@ -152,6 +152,29 @@ class DualARTransformer:
                                                    out.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_size_t(cap), nf))
         return [out[i, :, : nf[i]].copy() for i in range(len(ps))]
 
+    def generate_multi(self, prompts, max_new_tokens, temp=0.0, top_p=1.0, top_k=0, repetition_penalty=1.2, seeds=None,
+                       ignore_eos=False, persistent=True):
+        """R concurrent generate_blocking requests on this handle (fishrt.h: fs_lm_generate_multi): prompts = list of u32 (C+1, L_i);
+        max_new_tokens / temp / top_p / top_k / repetition_penalty: one value for all requests or one per request -> list of (C, n_i)."""
+        Cb = self.cfg["num_codebooks"]
+        ps = [_u32(p) for p in prompts]
+        n = len(ps)
+        per = lambda v: list(v) if isinstance(v, (list, tuple, np.ndarray)) else [v] * n
+        mnt, temps, tps, tks, rps = per(max_new_tokens), per(temp), per(top_p), per(top_k), per(repetition_penalty)
+        lens = np.array([p.shape[1] for p in ps], np.int32)
+        flat = np.concatenate([p.reshape(-1) for p in ps])
+        mn = np.array(mnt, np.int32)
+        cap = max(max(1, int(m) - int(l) + 2) for m, l in zip(mnt, lens)) + 1
+        out = np.zeros((n, Cb, cap), np.uint32)
+        nf = (C.c_size_t * n)()
+        ss = (_ffi.Sampling * n)(*[_ffi.Sampling(float(temps[i]), float(tps[i]), int(tks[i]), float(rps[i])) for i in range(n)])
+        sd = np.array(list(seeds) if seeds is not None else [0] * n, np.uint64)
+        _ffi.check(_ffi.lib().fs_lm_generate_multi(self._h, flat.ctypes.data_as(C.POINTER(C.c_uint32)), lens.ctypes.data_as(C.POINTER(C.c_int)), n,
+                                                   mn.ctypes.data_as(C.POINTER(C.c_int)), ss, sd.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                   (1 if ignore_eos else 0) | (0 if persistent else 2),
+                                                   out.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_size_t(cap), nf))
+        return [out[i, :, : nf[i]].copy() for i in range(n)]
+
     def weights_arena(self):
         """(device pointer, bytes) of the handle's weight arena (fishrt.h: fs_lm_weights_arena) -- for fanout.broadcast_weights"""
         ptr, n = C.c_void_p(), C.c_size_t(0)
@@ -178,6 +201,12 @@ class DualARTransformer:
     def debug_read(self, n_frames):
         out = np.zeros((int(n_frames), 9, 2048), np.float32)
         _ffi.check(_ffi.lib().fs_lm_debug_read(self._h, out.ctypes.data_as(C.POINTER(C.c_float)), int(n_frames)))
+        return out
+
+    def debug_read_row(self, row, n_frames):
+        """the capture of request `row` of the last generate_multi call"""
+        out = np.zeros((int(n_frames), 9, 2048), np.float32)
+        _ffi.check(_ffi.lib().fs_lm_debug_read_row(self._h, int(row), out.ctypes.data_as(C.POINTER(C.c_float)), int(n_frames)))
         return out
 
     def stream(self):

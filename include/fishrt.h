@@ -95,6 +95,8 @@ int fs_selftest_sample_rows(int device_id, const float* logits, int B, int n, co
  * The parity tests replay these rows through the CPU sampler: same logits, same StdRng stream => same picks, token for token. */
 int fs_lm_debug_capture(fs_lm_t* lm, int n_frames);
 int fs_lm_debug_read(fs_lm_t* lm, float* out, int n_frames);
+/* the same record of request `row` of the last fs_lm_generate_multi call (every request row is captured) */
+int fs_lm_debug_read_row(fs_lm_t* lm, int row, float* out, int n_frames);
 
 /* DualARTransformer::load (dual_ar.rs:460-529) is split in create + one of the load calls.
  * max_batch: number of independent sequences (KV caches) the handle can hold (1 for the single-batch generator). */
@@ -168,6 +170,20 @@ int fs_lm_generate_with_hidden(fs_lm_t* lm, const uint32_t* prompt, int L, int m
  * outputs are those of the lock-step batch. */
 int fs_lm_generate_batch(fs_lm_t* lm, const uint32_t* prompts, const int* lens, int n, int max_new_tokens,
                          const fs_sampling* sampling, uint64_t seed, uint32_t flags, uint32_t* codes_out, size_t cap,
+                         size_t* n_frames);
+
+/* R concurrent batch-1 requests on ONE device (round 4; the reference's only multi-request generator is the lock-step static batch,
+ * generate/static_batch.rs:117-274, which changes the sampler semantics; its server serialises requests behind one mutex,
+ * server/lib/state.rs:12-29).  Request i IS generate_blocking(prompt_i, max_new_tokens[i], samplings[i]) with sampler seed seeds[i] on a
+ * cleared cache (generate/single_batch.rs:76-214: its own KV, repetition-penalty window, RNG stream, <|im_end|> / budget rules) -- the
+ * tokens of its own fs_lm_generate call (the kernels sum in another order, so greedy tokens may differ where two candidates are within
+ * rounding of each other).  prompts: the n prompts u32 [C+1, L_i] concatenated; codes_out u32 [n, C, cap]; n_frames[n].
+ * bf16 handles with the Fish 1.5 geometry and token layout, 2 <= n <= min(8, max_batch), greedy sampling (temp == 0): every decode frame
+ * is ONE persistent launch of the slow transformer for all requests (csrc/lm_persist_rows.hip: the weights are streamed once per frame,
+ * the requests are matrix-core columns) plus one fast-decoder launch per group of <= 4 requests.  Any other handle / sampler setting /
+ * n runs the requests one after the other through fs_lm_generate.  The slow KV cache of every slot is cleared first. */
+int fs_lm_generate_multi(fs_lm_t* lm, const uint32_t* prompts, const int* lens, int n, const int* max_new_tokens,
+                         const fs_sampling* samplings, const uint64_t* seeds, uint32_t flags, uint32_t* codes_out, size_t cap,
                          size_t* n_frames);
 
 /* ---- replica start-up (no reference counterpart: the reference has no distributed layer).  The handle's device

@@ -1204,6 +1204,18 @@ class LM final : public LMBase {
         FS_HIP(hipEventElapsedTime(&ms12, ev_[1], ev_[2]));
         stats_.prefill_ms = ms01; stats_.decode_ms = ms12; stats_.graph_launches = (uint64_t)it;
         stats_.kernels_per_frame = (uint64_t)(1 + (rows_fast ? (n + PR_FAST_ROWS - 1) / PR_FAST_ROWS : n));
+        if (getenv("FISHRT_PERSIST_PROF")) {
+            unsigned long long pr[16];
+            const double f = 0.01 / std::max<double>(1.0, (double)it);  // us per frame (wall_clock64 ticks are 10 ns)
+            FS_HIP(hipMemcpy(pr, d_rctl_s_.as<uint32_t>() + 16, sizeof(pr), hipMemcpyDeviceToHost));
+            FS_HIP(hipMemset(d_rctl_s_.as<uint32_t>() + 16, 0, sizeof(pr)));
+            fprintf(stderr, "rows slow prof R=%d (us/frame, workgroup 0): S1 %.1f  S2 %.1f  S3 sweep %.1f + %.1f  S4 sweep %.1f gemm %.1f barrier %.1f publish %.1f  S5 sweep+gemm %.1f barrier %.1f publish %.1f  head %.1f\n",
+                    R, pr[1] * f, pr[2] * f, pr[8] * f, pr[3] * f, pr[9] * f, pr[10] * f, pr[11] * f, pr[4] * f, pr[12] * f, pr[13] * f, pr[5] * f, pr[6] * f);
+            FS_HIP(hipMemcpy(pr, d_rctl_f_.as<uint32_t>() + 16, sizeof(pr), hipMemcpyDeviceToHost));
+            FS_HIP(hipMemset(d_rctl_f_.as<uint32_t>() + 16, 0, sizeof(pr)));
+            fprintf(stderr, "rows fast prof (us/frame summed over the fast launches, workgroup 0; wait+work): preload %.1f  S1 %.1f+%.1f  S2 %.1f+%.1f  S3 %.1f+%.1f  S4 %.1f+%.1f  head %.1f+%.1f  decision %.1f+%.1f  tail %.1f\n",
+                    pr[0] * f, pr[9] * f, pr[1] * f, pr[10] * f, pr[2] * f, pr[11] * f, (pr[3] + pr[8]) * f, pr[12] * f, pr[4] * f, pr[13] * f, pr[5] * f, pr[14] * f, pr[6] * f, pr[7] * f);
+        }
         for (DevBuf* cb : {&d_rctl_s_, &d_rctl_f_, &d_ctl_}) {
             uint32_t ctl[4] = {0, 0, 0, 0};
             FS_HIP(hipMemcpy(ctl, cb->p, sizeof(ctl), hipMemcpyDeviceToHost));
@@ -1710,6 +1722,8 @@ class LM final : public LMBase {
                 d_rimg_.alloc(slow_persist_pack_bytes(a_.n_layer, false));
                 d_rhimg_.alloc((size_t)PF_BLOCKS * PS_HEAD_IMAGE);
                 launch_rows_pack(slow_.data(), a_.n_layer, slow_head_w(), n_audio_, d_rimg_.p, d_rhimg_.p, st_);
+                d_rpairs_.alloc((size_t)PF_BLOCKS * 40 * PF_THREADS * 4);
+                launch_rows_pack_rowpairs(d_pack_.p, d_rpairs_.p, st_);
                 d_redges_s_.alloc(rows_slow_edge_bytes(PR_MAX_ROWS));
                 FS_HIP(hipMemsetAsync(d_redges_s_.p, 0, d_redges_s_.n, st_));
                 d_redges_f_.alloc(rows_fast_edge_bytes(PR_FAST_ROWS));
@@ -1740,7 +1754,7 @@ class LM final : public LMBase {
         rp.ring = d_rrp_ring_.as<int>() + (size_t)i * ncb * 17; rp.ring_meta = d_rrp_meta_.as<int>() + (size_t)i * ncb * 2;
         return rp;
     }
-    static constexpr int kNapsRowsSlow[6] = {24, 0, 8, 40, 32, 12}, kNapsRowsFast[6] = {16, 16, 20, 20, 20, 12};
+    static constexpr int kNapsRowsSlow[6] = {24, 4, 8, 40, 24, 28}, kNapsRowsFast[6] = {16, 16, 16, 0, 20, 20};  // tools/tune_naps_rows.py at R = 4 (999 -> 989 us per frame)
     RowsSlowArgs rows_slow_args(int R) {
         RowsSlowArgs A = {};
         A.wimg = d_rimg_.p; A.himg = d_rhimg_.p; A.norms = d_snorms_.as<float>();
@@ -1759,7 +1773,7 @@ class LM final : public LMBase {
     RowsFastArgs rows_fast_args(int r0, int Rf) {
         RowsFastArgs A = {};
         (void)Rf;
-        A.wpack = d_pack_.p;
+        A.wpack = d_pack_.p; A.rowpairs = d_rpairs_.as<uint32_t>();
         for (int l = 0; l < PF_LAYERS; ++l) { A.norms[2 * l] = fast_[l].attn_norm; A.norms[2 * l + 1] = fast_[l].ffn_norm; }
         A.norms[2 * PF_LAYERS] = fast_norm_w_;
         A.fast_emb = fast_emb_; A.tok_emb = tok_emb_; A.cb_emb = cb_emb_;
@@ -1930,7 +1944,7 @@ class LM final : public LMBase {
     std::map<int, hipGraphExec_t> batch_graphs_;
     RepPenState rp_ = {};
     DevBuf d_rimg_, d_rhimg_, d_redges_s_, d_redges_f_, d_rctl_s_, d_rctl_f_, d_rlogits_, d_rcfg_, d_rrng_, d_rbudget_;  // request rows (lm_persist_rows.hip)
-    DevBuf d_rrp_mask_, d_rrp_seen_, d_rrp_ring_, d_rrp_meta_, d_rcap_;
+    DevBuf d_rrp_mask_, d_rrp_seen_, d_rrp_ring_, d_rrp_meta_, d_rcap_, d_rpairs_;
     void* h_pin_ = nullptr;
     hipGraphExec_t g_frame_ = nullptr, g_step_ = nullptr;
     hipEvent_t ev_[3] = {nullptr, nullptr, nullptr};

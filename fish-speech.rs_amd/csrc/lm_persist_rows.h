@@ -46,7 +46,8 @@ struct RowsSlowArgs {
 };
 
 struct RowsFastArgs {
-    const void* wpack;          // the batch-1 fast image (launch_fast_persist_pack): row pairs + W13 fragments in registers; W2 is streamed
+    const void* wpack;          // the batch-1 fast image (launch_fast_persist_pack): W13 fragments stay in registers; W2 is streamed from it
+    const uint32_t* rowpairs;   // [PF_BLOCKS][40][512]: the image's row-pair dwords, dword-major (launch_rows_pack_rowpairs), streamed
     const float* norms[2 * PF_LAYERS + 1];
     const void* fast_emb;
     const void* tok_emb;
@@ -78,6 +79,7 @@ size_t rows_slow_edge_bytes(int R);
 size_t rows_fast_edge_bytes(int R);
 // re-lays the slow blocks + the audio-range head into MFMA A-fragment images (device to device, once per weight load)
 void launch_rows_pack(const LayerW* layers, int n_layer, const void* head_w, int n_head_rows, void* wimg, void* himg, hipStream_t st);
+void launch_rows_pack_rowpairs(const void* fast_pack, void* out /*PF_BLOCKS * 40 * 512 * 4 bytes*/, hipStream_t st);
 void launch_rows_slow(const RowsSlowArgs& a, int R, hipStream_t st);   // R in {2, 4, 8}
 void launch_rows_fast(const RowsFastArgs& a, int R, hipStream_t st);   // R in {1, 2, 4}
 

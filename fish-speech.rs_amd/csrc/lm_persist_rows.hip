@@ -150,15 +150,18 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
     const u32x4 zero4 = u32x4{0, 0, 0, 0};
     u32x4 wq[4], wo[4], w13[8], w2[16];
     {
-        const int m = lane & 15, q4 = lane >> 4;
+        // (lanes m >= rows load row (rows - 1) again instead of being predicated off: their products land in D rows nobody reads, and with
+        // unconditional loads the compiler can COUNT the loads in flight -- behind a predicated prefetch it waits vmcnt(0) at the next use of
+        // anything loaded earlier, i.e. for the whole prefetch)
+        const int m = min(lane & 15, 4), q4 = lane >> 4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wq[j] = m < 5 ? reinterpret_cast<const u32x4*>(wimg + IR_QKV)[((wave * 4 + j) * 4 + q4) * 5 + m] : zero4;
+        for (int j = 0; j < 4; ++j) wq[j] = reinterpret_cast<const u32x4*>(wimg + IR_QKV)[((wave * 4 + j) * 4 + q4) * 5 + m];
     }
     u32x4 kreg[2] = {zero4, zero4}, vreg[2] = {zero4, zero4};
     bool dead = false;
     unsigned e = 0;
     int par = 0;
-    unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = A.prof ? wall_clock64() : 0;
+    unsigned long long tk[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = A.prof ? wall_clock64() : 0;
 #define PS_TICK(k) do { if (A.prof) { const unsigned long long n_ = wall_clock64(); tk[k] += n_ - t_last; t_last = n_; } } while (0)
 
     auto load_kv_tile = [&](int l, int tile) {
@@ -202,13 +205,13 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
             }
             if (att && n_tok > 0) load_kv_tile(l, 0);
 #pragma unroll
-            for (int r = 0; r < R; ++r)
-                if ((act >> r) & 1u) {
-                    if ((unsigned)(2 * tid - 4 * b) < 4u) *reinterpret_cast<float2*>(xr + r * 4 + 2 * tid - 4 * b) = make_float2(x0[r], x1[r]);
-                    pr_stage_pair(xt + (r / RPC) * 1024, 3 * (r % RPC), lane, x0[r] * nw.x, x1[r] * nw.y);
-                    const float ss = pf_wave_sum(fmaf(x1[r], x1[r], x0[r] * x0[r]));
-                    if (lane == 0) redw[r * RW + 32] = ss;
-                }
+            for (int r = 0; r < R; ++r) {  // (unguarded: an inactive row's inputs alias an active row's, nothing of it is published, and
+                                           // per-row branches would keep the scheduler from interleaving the rows' chains)
+                if ((unsigned)(2 * tid - 4 * b) < 4u) *reinterpret_cast<float2*>(xr + r * 4 + 2 * tid - 4 * b) = make_float2(x0[r], x1[r]);
+                pr_stage_pair(xt + (r / RPC) * 1024, 3 * (r % RPC), lane, x0[r] * nw.x, x1[r] * nw.y);
+                const float ss = pf_wave_sum(fmaf(x1[r], x1[r], x0[r] * x0[r]));
+                if (lane == 0) redw[r * RW + 32] = ss;
+            }
             __builtin_amdgcn_wave_barrier();
             f32x4_t acc[1][NCT];
 #pragma unroll
@@ -231,9 +234,9 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
         }
         // ================= S2: attention item (row ar, head ah, slice as)
         {
-            const int m = lane & 15, q4 = lane >> 4;
+            const int m = min(lane & 15, 3), q4 = lane >> 4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) wo[j] = m < 4 ? reinterpret_cast<const u32x4*>(wl + IR_WO)[((wave * 4 + j) * 4 + q4) * 4 + m] : zero4;
+            for (int j = 0; j < 4; ++j) wo[j] = reinterpret_cast<const u32x4*>(wl + IR_WO)[((wave * 4 + j) * 4 + q4) * 4 + m];
         }
         if (att) {
             tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
@@ -405,6 +408,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
                 }
             }
             ++e;
+            PS_TICK(8);
             {   // next stage's weights (64 KB per CU), behind the sweep
                 const u32x4* wp = reinterpret_cast<const u32x4*>(wl + IR_W13);
 #pragma unroll
@@ -413,11 +417,10 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
                     for (int jj = 0; jj < 4; ++jj) w13[t * 4 + jj] = wp[((t * 8 + wave) * 4 + jj) * 64 + lane];
             }
 #pragma unroll
-            for (int r = 0; r < R; ++r)
-                if ((act >> r) & 1u) {
-                    const float inv = 1.f / mL[r];
-                    pr_stage_pair(xt + (r / RPC) * 1024, 3 * (r % RPC), lane, mO0[r] * inv, mO1[r] * inv);
-                }
+            for (int r = 0; r < R; ++r) {
+                const float inv = ((act >> r) & 1u) ? 1.f / mL[r] : 0.f;
+                pr_stage_pair(xt + (r / RPC) * 1024, 3 * (r % RPC), lane, mO0[r] * inv, mO1[r] * inv);
+            }
             __builtin_amdgcn_wave_barrier();
             f32x4_t acc[1][NCT];
 #pragma unroll
@@ -449,27 +452,29 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
             pf_nap_before_sweep(A.naps[3]);
             sweep_x(e, v);
             ++e;
+            PS_TICK(9);
             {   // next stage's weights
-                const int m = lane & 15;
+                const int m = min(lane & 15, 3);
 #pragma unroll
-                for (int jj = 0; jj < 16; ++jj) w2[jj] = m < 4 ? reinterpret_cast<const u32x4*>(wl + IR_W2)[((wave * 16 + jj) * 4 + q4) * 4 + m] : zero4;
+                for (int jj = 0; jj < 16; ++jj) w2[jj] = reinterpret_cast<const u32x4*>(wl + IR_W2)[((wave * 16 + jj) * 4 + q4) * 4 + m];
             }
 #pragma unroll
-            for (int r = 0; r < R; ++r)
-                if ((act >> r) & 1u) {
-                    const float a = __uint_as_float(v[r].x), c = __uint_as_float(v[r].z);
-                    if ((unsigned)(2 * tid - 4 * b) < 4u) *reinterpret_cast<float2*>(xr + r * 4 + 2 * tid - 4 * b) = make_float2(a, c);
-                    pr_stage_pair(xt + (r / RPC) * 1024, 3 * (r % RPC), lane, a * nw.x, c * nw.y);
-                    const float ss = pf_wave_sum(fmaf(c, c, a * a));
-                    if (lane == 0) redw[r * RW + 32] = ss;
-                }
+            for (int r = 0; r < R; ++r) {
+                const float a = __uint_as_float(v[r].x), c = __uint_as_float(v[r].z);
+                if ((unsigned)(2 * tid - 4 * b) < 4u) *reinterpret_cast<float2*>(xr + r * 4 + 2 * tid - 4 * b) = make_float2(a, c);
+                pr_stage_pair(xt + (r / RPC) * 1024, 3 * (r % RPC), lane, a * nw.x, c * nw.y);
+                const float ss = pf_wave_sum(fmaf(c, c, a * a));
+                if (lane == 0) redw[r * RW + 32] = ss;
+            }
             __builtin_amdgcn_wave_barrier();
             f32x4_t acc[2][NCT];
 #pragma unroll
             for (int c = 0; c < NCT; ++c) { acc[0][c] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[1][c] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
             pr_mfma_seg<2, NCT>(w13, 4, 0, reinterpret_cast<const u32x4*>(xt), n, q4, acc);
             pr_extract<2, NCT, RPC, 32, RW>(acc, redw, n, q4);
+            PS_TICK(10);
             __syncthreads();
+            PS_TICK(11);
             for (int idx = tid; idx < 16 * R * PF_REPL; idx += PF_THREADS) {
                 const int jj = idx & 15, r = (idx >> 4) % R, rr = idx / (16 * R);
                 if ((act >> r) & 1u) {
@@ -506,15 +511,14 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
                 for (int i = 0; i < RPC; ++i) bs[i] = ebase(e, rep, ((act >> (c * RPC + i)) & 1u) ? c * RPC + i : first);
                 pr_sweep_seg4<RPC>(bs, offs, tag0 + e + 1, v, dead, A.ctl);
                 if (c == NCT - 1 && l + 1 < A.n_layer) {  // next layer's Wqkv rows
-                    const int m = lane & 15;
+                    const int m = min(lane & 15, 4);
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) wq[jj] = m < 5 ? reinterpret_cast<const u32x4*>(wl + layer_img + IR_QKV)[((wave * 4 + jj) * 4 + q4) * 5 + m] : zero4;
+                    for (int jj = 0; jj < 4; ++jj) wq[jj] = reinterpret_cast<const u32x4*>(wl + layer_img + IR_QKV)[((wave * 4 + jj) * 4 + q4) * 5 + m];
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {  // the wave's four 128-deep K segments go through the same staging tile, one after the other
 #pragma unroll
-                    for (int i = 0; i < RPC; ++i)
-                        if ((act >> (c * RPC + i)) & 1u) pr_stage_pair(xt + c * 1024, 3 * i, lane, __uint_as_float(v[i][q].x), __uint_as_float(v[i][q].z));
+                    for (int i = 0; i < RPC; ++i) pr_stage_pair(xt + c * 1024, 3 * i, lane, __uint_as_float(v[i][q].x), __uint_as_float(v[i][q].z));
                     __builtin_amdgcn_wave_barrier();
                     f32x4_t a1[1][1] = {{acc[0][c]}};
                     pr_mfma_seg<1, 1>(w2, 16, 4 * q, reinterpret_cast<const u32x4*>(xt + c * 1024), n, q4, a1);
@@ -523,8 +527,10 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
                 }
             }
             ++e;
+            PS_TICK(12);
             pr_extract<1, NCT, RPC, 4, RW>(acc, redw, n, q4);
             __syncthreads();
+            PS_TICK(13);
             for (int idx = tid; idx < 4 * R * PF_REPL; idx += PF_THREADS) {
                 const int m = idx & 3, r = (idx >> 2) % R, rr = idx / (4 * R);
                 if ((act >> r) & 1u) {
@@ -548,24 +554,23 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
         const float2 nw = *reinterpret_cast<const float2*>(A.norms + (size_t)(2 * A.n_layer) * 1024 + 2 * tid);
         u32x4 hd[4];
         {
-            const int m = lane & 15;
+            const int m = min(lane & 15, 7);
             const u32x4* hp = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(A.himg) + (size_t)b * PS_HEAD_IMAGE);
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) hd[jj] = m < 8 ? hp[((wave * 4 + jj) * 4 + q4) * 8 + m] : zero4;
+            for (int jj = 0; jj < 4; ++jj) hd[jj] = hp[((wave * 4 + jj) * 4 + q4) * 8 + m];
         }
         u32x4 v[R];
         pf_nap_before_sweep(A.naps[5]);
         sweep_x(e, v);
         ++e;
 #pragma unroll
-        for (int r = 0; r < R; ++r)
-            if ((act >> r) & 1u) {
-                const float a = __uint_as_float(v[r].x), c = __uint_as_float(v[r].z);
-                if (b == 0) *reinterpret_cast<float2*>(A.x + (size_t)r * 1024 + 2 * tid) = make_float2(a, c);
-                pr_stage_pair(xt + (r / RPC) * 1024, 3 * (r % RPC), lane, a * nw.x, c * nw.y);
-                const float ss = pf_wave_sum(fmaf(c, c, a * a));
-                if (lane == 0) redw[r * RW + 32] = ss;
-            }
+        for (int r = 0; r < R; ++r) {
+            const float a = __uint_as_float(v[r].x), c = __uint_as_float(v[r].z);
+            if (b == 0 && ((act >> r) & 1u)) *reinterpret_cast<float2*>(A.x + (size_t)r * 1024 + 2 * tid) = make_float2(a, c);
+            pr_stage_pair(xt + (r / RPC) * 1024, 3 * (r % RPC), lane, a * nw.x, c * nw.y);
+            const float ss = pf_wave_sum(fmaf(c, c, a * a));
+            if (lane == 0) redw[r * RW + 32] = ss;
+        }
         __builtin_amdgcn_wave_barrier();
         f32x4_t acc[1][NCT];
 #pragma unroll
@@ -587,9 +592,18 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
     }
     if (b == 0 && tid == 0) {
         A.ctl[0] = epoch + 1;
-        if (A.prof) for (int k = 0; k < 8; ++k) A.prof[k] += tk[k];
+        if (A.prof) for (int k = 0; k < 16; ++k) A.prof[k] += tk[k];
     }
 #undef PS_TICK
+}
+
+// dword-major copy of the batch-1 image's 40 row-pair dwords per lane (lm_persist.hip k_pf_pack chunks 0..9): [PF_BLOCKS][40][512] u32, so
+// that a stage's 4-5 row pairs are coalesced 4-byte loads -- the row kernel streams them one stage ahead instead of holding them
+__global__ __launch_bounds__(PF_THREADS) void k_pr_pack_rowpairs(const u32x4* __restrict__ pack, uint32_t* __restrict__ out) {
+    const int b = blockIdx.x, c = blockIdx.y, t = threadIdx.x;
+    const u32x4 v = pack[((size_t)b * PF_CHUNKS + c) * PF_THREADS + t];
+    uint32_t* o = out + ((size_t)b * 40 + 4 * c) * PF_THREADS + t;
+    o[0] = v.x; o[PF_THREADS] = v.y; o[2 * PF_THREADS] = v.z; o[3 * PF_THREADS] = v.w;
 }
 
 // ================================================================================================ fast decoder, R request rows
@@ -613,9 +627,10 @@ struct FastLds {
     static constexpr int SC = RED + 2 * 8 * R * FRW * 4;         // [R][16][8]
     static constexpr int AMAX = SC + R * 128 * 4;                // [2][R][8][2]
     static constexpr int ROPE = AMAX + 2 * R * 8 * 2 * 4;        // cos [8][32], sin [8][32]
-    static constexpr int RING = ROPE + 2 * 8 * 32 * 4;           // per row: ring [8][17], meta [8][2], prev [16], misc [16]
-    static constexpr int RING_ROW = 8 * 17 + 16 + 16 + 16;
-    static constexpr int END = RING + R * RING_ROW * 4;
+    static constexpr int RING = ROPE + 2 * 8 * 32 * 4;           // per row: ring [8][17], meta [8][2], prev [16], misc [16], cfg [8]
+    static constexpr int RING_ROW = 8 * 17 + 16 + 16 + 16 + 8;
+    static constexpr int MB = RING + R * RING_ROW * 4;           // [R][512] repetition-penalty mask bits of each lane's two candidates
+    static constexpr int END = MB + R * 512 * 4;
     static constexpr int BYTES = END < 96 * 1024 ? 96 * 1024 : END;
     static_assert(END <= 160 * 1024, "LDS budget");
 };
@@ -648,17 +663,26 @@ __device__ __forceinline__ void pr_sweep_rows2(const u64* const (&b)[N], unsigne
     }
 }
 
-// host ArgMax rule (LAST maximal index) over one wave: candidate (bv, bi) per lane -> {max value, largest index holding it}
+// host ArgMax rule (LAST maximal index) over one wave: candidate (bv, bi) per lane -> {max value, largest index holding it} in every lane.
+// All-VALU butterflies (DPP + permlane swaps): the readlane form costs a VALU -> SALU hop (~32 cycles) per step
+__device__ __forceinline__ float pr_wave_max_f(float v) {
+    v = fmaxf(v, pf_dpp<PF_XOR1>(v)); v = fmaxf(v, pf_dpp<PF_XOR2>(v)); v = fmaxf(v, pf_dpp<PF_HALF_MIRROR>(v)); v = fmaxf(v, pf_dpp<PF_MIRROR>(v));
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    const auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r2[0]), __uint_as_float(r2[1]));
+}
+__device__ __forceinline__ int pr_wave_max_i(int v) {
+    v = max(v, __builtin_amdgcn_mov_dpp(v, PF_XOR1, 0xF, 0xF, false)); v = max(v, __builtin_amdgcn_mov_dpp(v, PF_XOR2, 0xF, 0xF, false));
+    v = max(v, __builtin_amdgcn_mov_dpp(v, PF_HALF_MIRROR, 0xF, 0xF, false)); v = max(v, __builtin_amdgcn_mov_dpp(v, PF_MIRROR, 0xF, 0xF, false));
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    v = max((int)r[0], (int)r[1]);
+    const auto r2 = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    return max((int)r2[0], (int)r2[1]);
+}
 __device__ __forceinline__ void pr_wave_argmax(float bv, int bi, float& wm, int& ci) {
-    wm = bv;
-    wm = fmaxf(wm, pf_dpp<PF_XOR1>(wm)); wm = fmaxf(wm, pf_dpp<PF_XOR2>(wm));
-    wm = fmaxf(wm, pf_dpp<PF_HALF_MIRROR>(wm)); wm = fmaxf(wm, pf_dpp<PF_MIRROR>(wm));
-    wm = fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(wm), 15)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wm), 31))),
-               fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(wm), 47)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wm), 63))));
-    ci = (bv == wm) ? bi : -1;
-    ci = max(ci, __builtin_amdgcn_mov_dpp(ci, PF_XOR1, 0xF, 0xF, false)); ci = max(ci, __builtin_amdgcn_mov_dpp(ci, PF_XOR2, 0xF, 0xF, false));
-    ci = max(ci, __builtin_amdgcn_mov_dpp(ci, PF_HALF_MIRROR, 0xF, 0xF, false)); ci = max(ci, __builtin_amdgcn_mov_dpp(ci, PF_MIRROR, 0xF, 0xF, false));
-    ci = max(max(__builtin_amdgcn_readlane(ci, 15), __builtin_amdgcn_readlane(ci, 31)), max(__builtin_amdgcn_readlane(ci, 47), __builtin_amdgcn_readlane(ci, 63)));
+    wm = pr_wave_max_f(bv);
+    ci = pr_wave_max_i((bv == wm) ? bi : -1);
 }
 
 // sum of N = 8, 16 or 32 per-lane values over the wave; lane with (lane & (64 / N - 1)) == 0 holds the total of value lane / (64 / N)
@@ -675,15 +699,18 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* kc = reinterpret_cast<uint32_t*>(smem + L::KC);
     uint32_t* vc = reinterpret_cast<uint32_t*>(smem + L::VC);
-    float* qs = reinterpret_cast<float*>(smem + L::QS);
+    float* qs = reinterpret_cast<float*>(smem + L::QS);   // S2: rope'd q of every row; between a decision and the next S1: the rows' next inputs
     float* xr = reinterpret_cast<float*>(smem + L::XR);
     float* red = reinterpret_cast<float*>(smem + L::RED);
     float* sc = reinterpret_cast<float*>(smem + L::SC);
     float* amax = reinterpret_cast<float*>(smem + L::AMAX);
     float* rope_c = reinterpret_cast<float*>(smem + L::ROPE);
     float* rope_s = rope_c + 8 * 32;
-    int* s_ring = reinterpret_cast<int*>(smem + L::RING);  // per row: [0,136) ring, [136,152) meta, [152,168) prev, [168,184) misc
+    int* s_ring = reinterpret_cast<int*>(smem + L::RING);  // per row: [0,136) ring, [136,152) meta, [152,168) prev, [168,184) misc, [184,192) cfg
+    uint32_t* s_mb = reinterpret_cast<uint32_t*>(smem + L::MB);
     constexpr int RR = L::RING_ROW;
+    // misc: [0] slow token, [1] have_prev, [2] done, [3] epoch (row 0), [4..11] codes of this frame
+    // cfg : [0] rep_pen bits, [1] ignore_eos, [2] im_end_id, [3] audio_base, [4] sem_lo, [5] sem_hi
 
     const int tid_k = threadIdx.x, b = blockIdx.x;
     int tid = tid_k, lane = tid & 63, wave = tid >> 6;
@@ -705,40 +732,40 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
         s_ring[r * RR + k] = v;
     }
     if (tid < R) {
-        s_ring[tid * RR + 168 + 1] = A.state[tid].have_prev;
-        s_ring[tid * RR + 168 + 2] = A.state[tid].done;
+        int* misc = s_ring + tid * RR + 168;
+        misc[1] = A.state[tid].have_prev;
+        misc[2] = A.state[tid].done;
+        const SampleCfg& c = A.cfg[tid];
+        misc[16] = __float_as_int(c.rep_pen); misc[17] = c.ignore_eos; misc[18] = (int)c.im_end_id; misc[19] = (int)c.audio_base;
+        misc[20] = (int)c.sem_lo; misc[21] = (int)c.sem_hi;
     }
     if (tid == 64) s_ring[168 + 3] = (int)A.ctl[0];
     if (tid >= 256) { const int i = tid - 256; rope_c[i] = A.cos_t[i]; rope_s[i] = A.sin_t[i]; }
     __syncthreads();
-    const unsigned epoch = (unsigned)s_ring[168 + 3];
+    const unsigned epoch = __builtin_amdgcn_readfirstlane((unsigned)s_ring[168 + 3]);
     unsigned live = 0, hp = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) { if (s_ring[r * RR + 168 + 2] == 0) live |= 1u << r; if (s_ring[r * RR + 168 + 1] != 0) hp |= 1u << r; }
+    live = __builtin_amdgcn_readfirstlane(live); hp = __builtin_amdgcn_readfirstlane(hp);  // (read from LDS: uniform by construction)
     if (!live) return;
-    SampleCfg cfg[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) cfg[r] = A.cfg[r];
-    int frame[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) frame[r] = A.state[r].frame;
 
     // ---- the slow-token decision of every live row (constrain_probs_to_audio utils.rs:13-16, rescale_semantic_tokens :45-46,
     // single_batch.rs:102-144), redundantly on every workgroup
-    uint32_t cur0[R];
+    unsigned run = 0;  // rows whose fast decoder runs: live and not terminated by <|im_end|> this frame (single_batch.rs:153-156)
     {
         const int n = A.n_slow;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
+            const bool lv_r = (live >> r) & 1u;
             float lv[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int i = 4 * tid + s;
-                lv[s] = (i < n && ((live >> r) & 1u)) ? A.slow_logits[(size_t)r * PR_LD + i] : -INFINITY;
-                if (i == 0 && cfg[r].ignore_eos) lv[s] = -INFINITY;
+                lv[s] = (i < n && lv_r) ? A.slow_logits[(size_t)r * PR_LD + i] : -INFINITY;
+                if (i == 0 && s_ring[r * RR + 168 + 17]) lv[s] = -INFINITY;
             }
-            float* cap = (A.cap && b == 0 && ((live >> r) & 1u) && frame[r] < A.cap_frames) ? A.cap + ((size_t)r * A.cap_frames + frame[r]) * 9 * 2048 : nullptr;
-            if (cap) *reinterpret_cast<float4*>(cap + 4 * tid) = make_float4(lv[0], lv[1], lv[2], lv[3]);
+            if (A.cap && b == 0 && lv_r && A.state[r].frame < A.cap_frames)
+                *reinterpret_cast<float4*>(A.cap + ((size_t)r * A.cap_frames + A.state[r].frame) * 9 * 2048 + 4 * tid) = make_float4(lv[0], lv[1], lv[2], lv[3]);
             float bv = lv[0];
             int bi = 4 * tid;
 #pragma unroll
@@ -759,15 +786,17 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                 const int i2 = __float_as_int(amax[(r * 8 + w) * 2 + 1]);
                 if (v2 > gv || (v2 == gv && i2 > idx)) { gv = v2; idx = i2; }
             }
-            if (A.cap && b == 0 && tid == 0 && ((live >> r) & 1u) && frame[r] < A.cap_frames)
-                A.cap[((size_t)r * A.cap_frames + frame[r]) * 9 * 2048 + 2047] = (float)idx;
-            cur0[r] = audio_tok(cfg[r], max(idx, 0));
+            const bool lv_r = (live >> r) & 1u;
+            if (A.cap && b == 0 && tid == 0 && lv_r && A.state[r].frame < A.cap_frames)
+                A.cap[((size_t)r * A.cap_frames + A.state[r].frame) * 9 * 2048 + 2047] = (float)idx;
+            const int* cf = s_ring + r * RR + 168 + 16;
+            const uint32_t c0 = idx > 0 ? (uint32_t)cf[3] + (uint32_t)idx : (uint32_t)cf[2];  // audio_tok()
+            if (lv_r && c0 != (uint32_t)cf[2]) run |= 1u << r;
+            if (tid == 0) s_ring[r * RR + 168 + 0] = (int)c0;
         }
         __syncthreads();
     }
-    unsigned run = 0;  // rows whose fast decoder runs: live and not terminated by <|im_end|> this frame (single_batch.rs:153-156)
-#pragma unroll
-    for (int r = 0; r < R; ++r) if (((live >> r) & 1u) && cur0[r] != cfg[r].im_end_id) run |= 1u << r;
+    run = __builtin_amdgcn_readfirstlane(run);
     if (!run && b != 0) return;
 
     bool dead = false;
@@ -775,36 +804,35 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
 #define PF_TICK(k) do { if (A.prof) { const unsigned long long n_ = wall_clock64(); tk[k] += n_ - t_last; t_last = n_; } } while (0)
     if (run) {
         const int first = __builtin_ctz(run);
-        const u32x4* wp = reinterpret_cast<const u32x4*>(A.wpack) + (size_t)b * PF_CHUNKS * PF_THREADS + tid;
-        uint32_t wr[4 * PF_ROW_CHUNKS];
+        // (uniform bases + 32-bit per-lane indices from the per-stage opaque thread id: 64-bit per-lane addresses of four unrolled layers
+        // would be hoisted out of the pass loop into dozens of registers)
+        const u32x4* wp = reinterpret_cast<const u32x4*>(A.wpack) + (size_t)b * PF_CHUNKS * PF_THREADS;
+        // row pairs (Wqkv 5 + Wo 4 per layer, 4 head rows): streamed one stage ahead from the dword-major image (L2-resident, 80 KB per CU)
+        const uint32_t* rpi = A.rowpairs + (size_t)b * 40 * PF_THREADS;
+        uint32_t wq5[5], wo4[4], wh4[4];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) wq5[i] = rpi[(unsigned)(i * PF_THREADS + tid)];
         u32x4 w13v[PF_LAYERS][8];
 #pragma unroll
-        for (int c = 0; c < PF_ROW_CHUNKS; ++c) {
-            const u32x4 t4 = wp[(size_t)c * PF_THREADS];
-            wr[4 * c] = t4.x; wr[4 * c + 1] = t4.y; wr[4 * c + 2] = t4.z; wr[4 * c + 3] = t4.w;
-        }
-#pragma unroll
-        for (int c = PF_ROW_CHUNKS; c < PF_REG_CHUNKS; ++c) w13v[(c - PF_ROW_CHUNKS) / 8][(c - PF_ROW_CHUNKS) % 8] = wp[(size_t)c * PF_THREADS];
-        // repetition-penalty mask bits of this lane's two candidates of every codebook, per row
-        uint32_t mbits[R];
-        float x0[R], x1[R];
-#pragma unroll
+        for (int c = PF_ROW_CHUNKS; c < PF_REG_CHUNKS; ++c) w13v[(c - PF_ROW_CHUNKS) / 8][(c - PF_ROW_CHUNKS) % 8] = wp[(unsigned)(c * PF_THREADS + tid)];
+        // per row: repetition-penalty mask bits of this lane's two candidates of every codebook, and the first pass's input -> LDS
+#pragma unroll 1
         for (int r = 0; r < R; ++r) {
-            mbits[r] = 0; x0[r] = 0.f; x1[r] = 0.f;
+            uint32_t mb = 0;
+            float2 xin = make_float2(0.f, 0.f);
             if ((run >> r) & 1u) {
 #pragma unroll
                 for (int cbi = 0; cbi < 8; ++cbi) {
                     const float2 m2 = *reinterpret_cast<const float2*>(A.rp_mask + ((size_t)r * 8 + cbi) * 1024 + 2 * tid);
-                    mbits[r] |= (m2.x != 1.0f ? 1u : 0u) << (2 * cbi);
-                    mbits[r] |= (m2.y != 1.0f ? 1u : 0u) << (2 * cbi + 1);
+                    mb |= (m2.x != 1.0f ? 1u : 0u) << (2 * cbi);
+                    mb |= (m2.y != 1.0f ? 1u : 0u) << (2 * cbi + 1);
                 }
-                const float2 xin = *reinterpret_cast<const float2*>(A.xf + (size_t)r * 1024 + 2 * tid);
-                x0[r] = xin.x; x1[r] = xin.y;
+                xin = *reinterpret_cast<const float2*>(A.xf + (size_t)r * 1024 + 2 * tid);
             }
+            s_mb[r * 512 + tid] = mb;
+            *reinterpret_cast<float2*>(qs + r * 1024 + 2 * tid) = xin;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int d = 0; d < 4 * PF_ROW_CHUNKS; ++d) asm volatile("" : "+v"(wr[d]));
 #pragma unroll
         for (int l = 0; l < PF_LAYERS; ++l)
 #pragma unroll
@@ -824,33 +852,42 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
             const int T = cb + 1;
 #pragma unroll
             for (int l = 0; l < PF_LAYERS; ++l) {
-                const uint32_t* wl = wr + 9 * l;
                 // ================= S1: (gather x) -> RMSNorm folded -> Wqkv rows of every row
                 {
                     tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
-                    const float2 nw = *reinterpret_cast<const float2*>(A.norms[2 * l] + 2 * tid);
+                    const float2 nw = reinterpret_cast<const float2*>(A.norms[2 * l])[(unsigned)tid];
+                    u32x4 v[R];
                     if (l > 0) {
-                        u32x4 v[R];
                         pf_nap_before_sweep(A.naps[0]);
                         sweep_x(e, v);
-#pragma unroll
-                        for (int r = 0; r < R; ++r) { x0[r] = __uint_as_float(v[r].x); x1[r] = __uint_as_float(v[r].z); }
                         ++e;
                         PF_TICK(9);
                     }
-                    float a[8 * R];
 #pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        if ((unsigned)(2 * tid - 4 * b) < 4u) *reinterpret_cast<float2*>(xr + r * 4 + 2 * tid - 4 * b) = make_float2(x0[r], x1[r]);
-                        const float xn0 = x0[r] * nw.x, xn1 = x1[r] * nw.y;
+                    for (int i = 0; i < 4; ++i) wo4[i] = rpi[(unsigned)((9 * l + 5 + i) * PF_THREADS + tid)];  // next stage's row pairs
+                    // all rows' partial sums through halving trees of at most 16 values (two rows each: 32 live accumulators cost registers
+                    // the resident W13 fragments need)
+                    constexpr int RG = R < 2 ? R : 2;
 #pragma unroll
-                        for (int i = 0; i < 5; ++i) a[8 * r + i] = pf_dot2(wl[i], xn0, xn1, 0.f);
-                        a[8 * r + 5] = fmaf(x1[r], x1[r], x0[r] * x0[r]);
-                        a[8 * r + 6] = 0.f; a[8 * r + 7] = 0.f;
+                    for (int r0 = 0; r0 < R; r0 += RG) {
+                        float a[8 * RG];
+#pragma unroll
+                        for (int i2 = 0; i2 < RG; ++i2) {
+                            const int r = r0 + i2;
+                            float xa, xb2;
+                            if (l > 0) { xa = __uint_as_float(v[r].x); xb2 = __uint_as_float(v[r].z); }
+                            else { const float2 t2 = *reinterpret_cast<const float2*>(qs + r * 1024 + 2 * tid); xa = t2.x; xb2 = t2.y; }
+                            if ((unsigned)(2 * tid - 4 * b) < 4u) *reinterpret_cast<float2*>(xr + r * 4 + 2 * tid - 4 * b) = make_float2(xa, xb2);
+                            const float xn0 = xa * nw.x, xn1 = xb2 * nw.y;
+#pragma unroll
+                            for (int i = 0; i < 5; ++i) a[8 * i2 + i] = pf_dot2(wq5[i], xn0, xn1, 0.f);
+                            a[8 * i2 + 5] = fmaf(xb2, xb2, xa * xa);
+                            a[8 * i2 + 6] = 0.f; a[8 * i2 + 7] = 0.f;
+                        }
+                        const float tot = pf_reduce<8 * RG>(a, lane);
+                        constexpr int SH = RG == 2 ? 2 : 3;  // value index = lane >> SH
+                        if ((lane & ((1 << SH) - 1)) == 0) red[(par * 8 + wave) * R * FRW + (r0 + ((lane >> SH) >> 3)) * FRW + ((lane >> SH) & 7)] = tot;
                     }
-                    const float tot = pf_reduce<8 * R>(a, lane);
-                    constexpr int SH = R == 4 ? 1 : (R == 2 ? 2 : 3);  // value index = lane >> SH
-                    if ((lane & ((1 << SH) - 1)) == 0) red[(par * 8 + wave) * R * FRW + ((lane >> SH) >> 3) * FRW + ((lane >> SH) & 7)] = tot;
                     __syncthreads();
                     for (int idx = tid; idx < 5 * R * PF_REPL; idx += PF_THREADS) {
                         const int m = idx % 5, r = (idx / 5) % R, rr = idx / (5 * R);
@@ -868,37 +905,41 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                 // ================= S2: gather qkv -> RoPE, KV append, attention over T <= 8 tokens -> Wo rows + residual
                 {
                     tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
-                    u32x4 vq[R], vk[R];
                     {
+                        u32x4 vq[R], vk[R];
                         const u64* bs[R];
 #pragma unroll
                         for (int r = 0; r < R; ++r) bs[r] = ebase(e, rep, ((run >> r) & 1u) ? r : first);
                         pf_nap_before_sweep(A.naps[1]);
                         if (tid < 128) pr_sweep_rows2<R>(bs, (unsigned)tid * 16u, (unsigned)(512 + tid) * 16u, tag0 + e + 1, vq, vk, dead, A.ctl);
                         else pr_sweep_rows<R>(bs, (unsigned)tid * 16u, tag0 + e + 1, vq, dead, A.ctl);
-                    }
-                    ++e;
-                    PF_TICK(10);
-                    const int j = tid & 31;
-                    const float c = rope_c[cb * 32 + j], s = rope_s[cb * 32 + j];
+                        ++e;
+                        PF_TICK(10);
+                        const int j = tid & 31;
+                        const float c = rope_c[cb * 32 + j], s = rope_s[cb * 32 + j];
 #pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const float qa = __uint_as_float(vq[r].x), qb = __uint_as_float(vq[r].z);
-                        *reinterpret_cast<float2*>(qs + r * 1024 + 2 * tid) = make_float2(qa * c - qb * s, qa * s + qb * c);
-                        if (tid < 64) {
-                            const float ka = __uint_as_float(vk[r].x), kb = __uint_as_float(vk[r].z);
-                            kc[((r * PF_LAYERS + l) * 8 + cb) * 64 + tid] = f32_to_bf16_rne(ka * c - kb * s) | (f32_to_bf16_rne(ka * s + kb * c) << 16);
-                        } else if (tid < 128) {
-                            vc[((r * PF_LAYERS + l) * 8 + cb) * 64 + tid - 64] = f32_to_bf16_rne(__uint_as_float(vk[r].x)) | (f32_to_bf16_rne(__uint_as_float(vk[r].z)) << 16);
+                        for (int r = 0; r < R; ++r) {
+                            const float qa = __uint_as_float(vq[r].x), qb = __uint_as_float(vq[r].z);
+                            *reinterpret_cast<float2*>(qs + r * 1024 + 2 * tid) = make_float2(qa * c - qb * s, qa * s + qb * c);
+                            if (tid < 64) {
+                                const float ka = __uint_as_float(vk[r].x), kb = __uint_as_float(vk[r].z);
+                                kc[((r * PF_LAYERS + l) * 8 + cb) * 64 + tid] = f32_to_bf16_rne(ka * c - kb * s) | (f32_to_bf16_rne(ka * s + kb * c) << 16);
+                            } else if (tid < 128) {
+                                vc[((r * PF_LAYERS + l) * 8 + cb) * 64 + tid - 64] = f32_to_bf16_rne(__uint_as_float(vk[r].x)) | (f32_to_bf16_rne(__uint_as_float(vk[r].z)) << 16);
+                            }
                         }
                     }
                     __syncthreads();
-                    const int h = tid >> 5, g = h >> 3, p = (tid >> 2) & 7, qd = tid & 3;
-                    float a[4 * R];
+                    const int h = tid >> 5, g = h >> 3, p = (tid >> 2) & 7, qd = tid & 3, j = tid & 31;
+                    // rows in a REAL loop, two per iteration: unrolled over all rows the scheduler issues every row's LDS reads up front (~24 registers
+                    // per row), one at a time each row is a ~1 us chain of dependent LDS / transcendental / cross-lane latencies
+                    constexpr int RI = R < 2 ? R : 2;
+#pragma unroll 1
+                    for (int r0 = 0; r0 < R; r0 += RI) {
+                        float accs[RI];
 #pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        {
-                            const float scale = 0.125f;
+                        for (int i2 = 0; i2 < RI; ++i2) {
+                            const int r = r0 + i2;
                             const float4* qp = reinterpret_cast<const float4*>(qs + r * 1024 + h * 64 + qd * 16);
                             const u32x4* kp = reinterpret_cast<const u32x4*>(kc + ((r * PF_LAYERS + l) * 8 + p) * 64 + g * 32 + qd * 8);
                             float acc = 0.f;
@@ -906,18 +947,22 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                             for (int i = 0; i < 2; ++i) {
                                 const u32x4 kw = kp[i];
                                 const float4 q0 = qp[2 * i], q1 = qp[2 * i + 1];
-                                acc = fmaf(q0.x, bf_lo(kw.x) * scale, acc); acc = fmaf(q0.y, bf_hi(kw.x) * scale, acc);
-                                acc = fmaf(q0.z, bf_lo(kw.y) * scale, acc); acc = fmaf(q0.w, bf_hi(kw.y) * scale, acc);
-                                acc = fmaf(q1.x, bf_lo(kw.z) * scale, acc); acc = fmaf(q1.y, bf_hi(kw.z) * scale, acc);
-                                acc = fmaf(q1.z, bf_lo(kw.w) * scale, acc); acc = fmaf(q1.w, bf_hi(kw.w) * scale, acc);
+                                acc = fmaf(q0.x, bf_lo(kw.x), acc); acc = fmaf(q0.y, bf_hi(kw.x), acc);
+                                acc = fmaf(q0.z, bf_lo(kw.y), acc); acc = fmaf(q0.w, bf_hi(kw.y), acc);
+                                acc = fmaf(q1.x, bf_lo(kw.z), acc); acc = fmaf(q1.y, bf_hi(kw.z), acc);
+                                acc = fmaf(q1.z, bf_lo(kw.w), acc); acc = fmaf(q1.w, bf_hi(kw.w), acc);
                             }
                             acc += pf_dpp<PF_XOR1>(acc);
                             acc += pf_dpp<PF_XOR2>(acc);
-                            if (qd == 0) sc[r * 128 + h * 8 + p] = acc;
+                            accs[i2] = acc * 0.125f;  // 1 / sqrt(64) on K (dual_ar.rs:260): a power of two, exact wherever it is applied
                         }
+#pragma unroll
+                        for (int i2 = 0; i2 < RI; ++i2) if (qd == 0) sc[(r0 + i2) * 128 + h * 8 + p] = accs[i2];
                         __builtin_amdgcn_wave_barrier();
-                        float at0, at1;
-                        {
+                        float a[4 * RI];
+#pragma unroll
+                        for (int i2 = 0; i2 < RI; ++i2) {
+                            const int r = r0 + i2;
                             float mn = -1e30f;
 #pragma unroll
                             for (int t = 0; t < 8; ++t) if (t < T) mn = fmaxf(mn, sc[r * 128 + h * 8 + t]);
@@ -932,14 +977,14 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                                     O1 = fmaf(pr, bf_hi(vw), O1);
                                 }
                             const float inv = 1.f / Ls;
-                            at0 = O0 * inv; at1 = O1 * inv;
-                        }
+                            const float at0 = O0 * inv, at1 = O1 * inv;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) a[4 * r + i] = pf_dot2(wl[5 + i], at0, at1, 0.f);
+                            for (int i = 0; i < 4; ++i) a[4 * i2 + i] = pf_dot2(wo4[i], at0, at1, 0.f);
+                        }
+                        const float tot = pf_reduce<4 * RI>(a, lane);
+                        constexpr int SH = RI == 2 ? 3 : 4;
+                        if ((lane & ((1 << SH) - 1)) == 0) red[(par * 8 + wave) * R * FRW + (r0 + ((lane >> SH) >> 2)) * FRW + ((lane >> SH) & 3)] = tot;
                     }
-                    const float tot = pf_reduce<4 * R>(a, lane);
-                    constexpr int SH = R == 4 ? 2 : (R == 2 ? 3 : 4);
-                    if ((lane & ((1 << SH) - 1)) == 0) red[(par * 8 + wave) * R * FRW + ((lane >> SH) >> 2) * FRW + ((lane >> SH) & 3)] = tot;
                     __syncthreads();
                     for (int idx = tid; idx < 4 * R * PF_REPL; idx += PF_THREADS) {
                         const int m = idx & 3, r = (idx >> 2) % R, rr = idx / (4 * R);
@@ -961,26 +1006,30 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                     const int n = lane & 15, q4 = lane >> 4;
                     uint32_t* xt = reinterpret_cast<uint32_t*>(smem + L::XB + wave * 4096);
                     float* redw = red + (par * 8 + wave) * R * FRW;
-                    const float2 nw = *reinterpret_cast<const float2*>(A.norms[2 * l + 1] + 2 * tid);
-                    u32x4 v[R];
-                    pf_nap_before_sweep(A.naps[2]);
-                    sweep_x(e, v);
-                    ++e;
-                    PF_TICK(11);
+                    const float2 nw = reinterpret_cast<const float2*>(A.norms[2 * l + 1])[(unsigned)tid];
+                    {
+                        u32x4 v[R];
+                        pf_nap_before_sweep(A.naps[2]);
+                        sweep_x(e, v);
+                        ++e;
+                        PF_TICK(11);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) w2r[q] = wp[(size_t)(PF_REG_CHUNKS + 4 * l + q) * PF_THREADS];  // next stage's weights (32 KB per CU)
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const float xa = __uint_as_float(v[r].x), xb2 = __uint_as_float(v[r].z);
-                        if ((unsigned)(2 * tid - 4 * b) < 4u) *reinterpret_cast<float2*>(xr + r * 4 + 2 * tid - 4 * b) = make_float2(xa, xb2);
-                        pr_stage_pair(xt, 3 * r, lane, xa * nw.x, xb2 * nw.y);
-                        const float ss = pf_wave_sum(fmaf(xb2, xb2, xa * xa));
-                        if (lane == 0) redw[r * FRW + 32] = ss;
+                        for (int r = 0; r < R; ++r) {
+                            const float xa = __uint_as_float(v[r].x), xb2 = __uint_as_float(v[r].z);
+                            if ((unsigned)(2 * tid - 4 * b) < 4u) *reinterpret_cast<float2*>(xr + r * 4 + 2 * tid - 4 * b) = make_float2(xa, xb2);
+                            pr_stage_pair(xt, 3 * r, lane, xa * nw.x, xb2 * nw.y);
+                            const float ss = pf_wave_sum(fmaf(xb2, xb2, xa * xa));
+                            if (lane == 0) redw[r * FRW + 32] = ss;
+                        }
                     }
                     __builtin_amdgcn_wave_barrier();
                     f32x4_t acc[2][1] = {{f32x4_t{0.f, 0.f, 0.f, 0.f}}, {f32x4_t{0.f, 0.f, 0.f, 0.f}}};
                     pr_mfma_seg<2, 1>(&w13v[l][0], 4, 0, reinterpret_cast<const u32x4*>(xt), n, q4, acc);
                     pr_extract<2, 1, R, 32, FRW>(acc, redw, n, q4);
+                    // next stage's weights (32 KB per CU, the same image the batch-1 kernel keeps in LDS), requested behind everything this stage
+                    // needs from memory: a wave's loads return in order
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) w2r[q] = wp[(unsigned)((PF_REG_CHUNKS + 4 * l + q) * PF_THREADS + tid)];
                     PF_TICK(8);
                     __syncthreads();
                     for (int idx = tid; idx < 16 * R * PF_REPL; idx += PF_THREADS) {
@@ -1001,19 +1050,19 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                 // ================= S4: gather the 4096 activations of every row -> W2 rows (streamed) + residual
                 {
                     tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
-                    constexpr int RH = R < 2 ? R : 2;  // rows per sweep (8 x 16 B in flight per lane)
-                    float a[4 * R];
+                    constexpr int RH = R < 2 ? R : 2;  // rows per sweep (8 x 16 B in flight per lane; all four rows in one sweep measured slower: 1017 vs 995 us per frame)
                     unsigned offs[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) offs[q] = (unsigned)(tid + PF_THREADS * q) * 16u;
                     pf_nap_before_sweep(A.naps[3]);
-#pragma unroll
+#pragma unroll 1
                     for (int r0 = 0; r0 < R; r0 += RH) {
                         const u64* bs[RH];
                         u32x4 v[RH][4];
 #pragma unroll
                         for (int i = 0; i < RH; ++i) bs[i] = ebase(e, rep, ((run >> (r0 + i)) & 1u) ? r0 + i : first);
                         pr_sweep_seg4<RH>(bs, offs, tag0 + e + 1, v, dead, A.ctl);
+                        float a[4 * RH];
 #pragma unroll
                         for (int i = 0; i < RH; ++i) {
                             float a4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1025,14 +1074,21 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                                 a4[2] = pf_dot2(w.z, c0, c1, a4[2]); a4[3] = pf_dot2(w.w, c0, c1, a4[3]);
                             }
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) a[4 * (r0 + i) + k] = a4[k];
+                            for (int k = 0; k < 4; ++k) a[4 * i + k] = a4[k];
                         }
+                        const float tot = pf_reduce<4 * RH>(a, lane);
+                        constexpr int SH = RH == 4 ? 2 : (RH == 2 ? 3 : 4);
+                        if ((lane & ((1 << SH) - 1)) == 0) red[(par * 8 + wave) * R * FRW + (r0 + ((lane >> SH) >> 2)) * FRW + ((lane >> SH) & 3)] = tot;
                     }
                     ++e;
+                    if (l + 1 < PF_LAYERS) {
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) wq5[i] = rpi[(unsigned)((9 * (l + 1) + i) * PF_THREADS + tid)];
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) wh4[i] = rpi[(unsigned)((9 * PF_LAYERS + i) * PF_THREADS + tid)];
+                    }
                     PF_TICK(12);
-                    const float tot = pf_reduce<4 * R>(a, lane);
-                    constexpr int SH = R == 4 ? 2 : (R == 2 ? 3 : 4);
-                    if ((lane & ((1 << SH) - 1)) == 0) red[(par * 8 + wave) * R * FRW + ((lane >> SH) >> 2) * FRW + ((lane >> SH) & 3)] = tot;
                     __syncthreads();
                     for (int idx = tid; idx < 4 * R * PF_REPL; idx += PF_THREADS) {
                         const int m = idx & 3, r = (idx >> 2) % R, rr = idx / (4 * R);
@@ -1051,25 +1107,32 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
             // ================= head: gather x -> fast_norm folded -> 4 rows of fast_output per row
             {
                 tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
-                const float2 nw = *reinterpret_cast<const float2*>(A.norms[2 * PF_LAYERS] + 2 * tid);
+                const float2 nw = reinterpret_cast<const float2*>(A.norms[2 * PF_LAYERS])[(unsigned)tid];
                 u32x4 v[R];
                 pf_nap_before_sweep(A.naps[4]);
                 sweep_x(e, v);
                 ++e;
                 PF_TICK(13);
-                float a[8 * R];
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const float xa = __uint_as_float(v[r].x), xb2 = __uint_as_float(v[r].z);
-                    const float xn0 = xa * nw.x, xn1 = xb2 * nw.y;
+                for (int i = 0; i < 5; ++i) wq5[i] = rpi[(unsigned)(i * PF_THREADS + tid)];  // the next pass's first stage
+                constexpr int RG = R < 2 ? R : 2;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) a[8 * r + i] = pf_dot2(wr[PF_LAYERS * 9 + i], xn0, xn1, 0.f);
-                    a[8 * r + 4] = fmaf(xb2, xb2, xa * xa);
-                    a[8 * r + 5] = 0.f; a[8 * r + 6] = 0.f; a[8 * r + 7] = 0.f;
+                for (int r0 = 0; r0 < R; r0 += RG) {
+                    float a[8 * RG];
+#pragma unroll
+                    for (int i2 = 0; i2 < RG; ++i2) {
+                        const int r = r0 + i2;
+                        const float xa = __uint_as_float(v[r].x), xb2 = __uint_as_float(v[r].z);
+                        const float xn0 = xa * nw.x, xn1 = xb2 * nw.y;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) a[8 * i2 + i] = pf_dot2(wh4[i], xn0, xn1, 0.f);
+                        a[8 * i2 + 4] = fmaf(xb2, xb2, xa * xa);
+                        a[8 * i2 + 5] = 0.f; a[8 * i2 + 6] = 0.f; a[8 * i2 + 7] = 0.f;
+                    }
+                    const float tot = pf_reduce<8 * RG>(a, lane);
+                    constexpr int SH = RG == 2 ? 2 : 3;
+                    if ((lane & ((1 << SH) - 1)) == 0) red[(par * 8 + wave) * R * FRW + (r0 + ((lane >> SH) >> 3)) * FRW + ((lane >> SH) & 7)] = tot;
                 }
-                const float tot = pf_reduce<8 * R>(a, lane);
-                constexpr int SH = R == 4 ? 1 : (R == 2 ? 2 : 3);
-                if ((lane & ((1 << SH) - 1)) == 0) red[(par * 8 + wave) * R * FRW + ((lane >> SH) >> 3) * FRW + ((lane >> SH) & 7)] = tot;
                 __syncthreads();
                 for (int idx = tid; idx < 4 * R * PF_REPL; idx += PF_THREADS) {
                     const int m = idx & 3, r = (idx >> 2) % R, rr = idx / (4 * R);
@@ -1087,58 +1150,61 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
             // ================= decisions: gather the 1024 logits of every row -> rep-pen -> argmax (LAST maximal index) -> next input
             {
                 tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
-                u32x4 v[R];
-                pf_nap_before_sweep(A.naps[5]);
-                sweep_x(e, v);
-                ++e;
-                PF_TICK(14);
+                {
+                    u32x4 v[R];
+                    pf_nap_before_sweep(A.naps[5]);
+                    sweep_x(e, v);
+                    ++e;
+                    PF_TICK(14);
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    if (!((run >> r) & 1u)) continue;
-                    float lv0 = __uint_as_float(v[r].x), lv1 = __uint_as_float(v[r].z);
-                    const int* ring = s_ring + r * RR;
-                    const int* meta = ring + 136;
-                    const bool have_prev = (hp >> r) & 1u;
-                    // SingleBatchedRepPenProcessor::apply (rep_pen.rs:37-65)
-                    int last = -1, dropped = -1, head = 0, len = 0;
-                    bool drop = false;
-                    if (have_prev) {
-                        last = ring[152 + cb + 1];
-                        head = (meta[cb * 2] + 16) % 17;
-                        len = meta[cb * 2 + 1] + 1;
-                        drop = len > 16;
-                        if (drop) dropped = ring[cb * 17 + (head + len - 1) % 17];
-                    }
-                    const float pen = cfg[r].rep_pen;
-                    float m0 = ((mbits[r] >> (2 * cb)) & 1u) ? pen : 1.0f, m1 = ((mbits[r] >> (2 * cb + 1)) & 1u) ? pen : 1.0f;
-                    if (have_prev) {
-                        const float o0 = m0, o1 = m1;
-                        const int i0 = 2 * tid, i1 = 2 * tid + 1;
-                        if (i0 == last) m0 = pen;
-                        if (i0 == dropped && m0 == pen) m0 = 1.0f;
-                        if (i1 == last) m1 = pen;
-                        if (i1 == dropped && m1 == pen) m1 = 1.0f;
-                        if (b == 0) {
-                            float* mk = A.rp_mask + ((size_t)r * 8 + cb) * 1024;
-                            if (m0 != o0) mk[i0] = m0;
-                            if (m1 != o1) mk[i1] = m1;
-                            if (tid == 0) { A.rp_ring[r * 136 + cb * 17 + head] = last; A.rp_meta[r * 16 + cb * 2] = head; A.rp_meta[r * 16 + cb * 2 + 1] = drop ? 16 : len; }
+                    for (int r = 0; r < R; ++r) {  // (unguarded compute, guarded global writes: see k_slow_rows S1)
+                        const bool on = (run >> r) & 1u;
+                        float lv0 = __uint_as_float(v[r].x), lv1 = __uint_as_float(v[r].z);
+                        const int* ring = s_ring + r * RR;
+                        const int* meta = ring + 136;
+                        const bool have_prev = (hp >> r) & 1u;
+                        // SingleBatchedRepPenProcessor::apply (rep_pen.rs:37-65)
+                        int last = -1, dropped = -1, head = 0, len = 0;
+                        bool drop = false;
+                        if (have_prev) {
+                            last = ring[152 + cb + 1];
+                            head = (meta[cb * 2] + 16) % 17;
+                            len = meta[cb * 2 + 1] + 1;
+                            drop = len > 16;
+                            if (drop) dropped = ring[cb * 17 + (head + len - 1) % 17];
                         }
-                        lv0 = lv0 / m0; lv1 = lv1 / m1;
+                        const float pen = __int_as_float(ring[168 + 16]);
+                        const uint32_t mb = s_mb[r * 512 + tid];
+                        float m0 = ((mb >> (2 * cb)) & 1u) ? pen : 1.0f, m1 = ((mb >> (2 * cb + 1)) & 1u) ? pen : 1.0f;
+                        if (have_prev) {
+                            const float o0 = m0, o1 = m1;
+                            const int i0 = 2 * tid, i1 = 2 * tid + 1;
+                            if (i0 == last) m0 = pen;
+                            if (i0 == dropped && m0 == pen) m0 = 1.0f;
+                            if (i1 == last) m1 = pen;
+                            if (i1 == dropped && m1 == pen) m1 = 1.0f;
+                            if (b == 0 && on) {
+                                float* mk = A.rp_mask + ((size_t)r * 8 + cb) * 1024;
+                                if (m0 != o0) mk[i0] = m0;
+                                if (m1 != o1) mk[i1] = m1;
+                                if (tid == 0) { A.rp_ring[r * 136 + cb * 17 + head] = last; A.rp_meta[r * 16 + cb * 2] = head; A.rp_meta[r * 16 + cb * 2 + 1] = drop ? 16 : len; }
+                            }
+                            lv0 = lv0 / m0; lv1 = lv1 / m1;
+                        }
+                        if (A.cap && b == 0 && on && A.state[r].frame < A.cap_frames)
+                            *reinterpret_cast<float2*>(A.cap + (((size_t)r * A.cap_frames + A.state[r].frame) * 9 + 1 + cb) * 2048 + 2 * tid) = make_float2(lv0, lv1);
+                        float bv = lv0;
+                        int bi = 2 * tid;
+                        if (!(lv1 < bv)) { bv = lv1; bi = 2 * tid + 1; }
+                        float wm; int ci;
+                        pr_wave_argmax(bv, bi, wm, ci);
+                        if (lane == 0) { amax[((par * R + r) * 8 + wave) * 2] = wm; amax[((par * R + r) * 8 + wave) * 2 + 1] = __int_as_float(ci); }
                     }
-                    float* cap = (A.cap && b == 0 && frame[r] < A.cap_frames) ? A.cap + (((size_t)r * A.cap_frames + frame[r]) * 9 + 1 + cb) * 2048 : nullptr;
-                    if (cap) *reinterpret_cast<float2*>(cap + 2 * tid) = make_float2(lv0, lv1);
-                    float bv = lv0;
-                    int bi = 2 * tid;
-                    if (!(lv1 < bv)) { bv = lv1; bi = 2 * tid + 1; }
-                    float wm; int ci;
-                    pr_wave_argmax(bv, bi, wm, ci);
-                    if (lane == 0) { amax[((par * R + r) * 8 + wave) * 2] = wm; amax[((par * R + r) * 8 + wave) * 2 + 1] = __int_as_float(ci); }
                 }
                 __syncthreads();
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    if (!((run >> r) & 1u)) continue;
+                    const bool on = (run >> r) & 1u;
                     float gv = amax[((par * R + r) * 8) * 2];
                     int gi = __float_as_int(amax[((par * R + r) * 8) * 2 + 1]);
 #pragma unroll
@@ -1148,12 +1214,12 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                         if (v2 > gv || (v2 == gv && i2 > gi)) { gv = v2; gi = i2; }
                     }
                     const uint32_t code = (uint32_t)max(gi, 0);
-                    if (A.cap && b == 0 && tid == 0 && frame[r] < A.cap_frames)
-                        A.cap[(((size_t)r * A.cap_frames + frame[r]) * 9 + 1 + cb) * 2048 + 1024] = (float)code;
+                    if (A.cap && b == 0 && tid == 0 && on && A.state[r].frame < A.cap_frames)
+                        A.cap[(((size_t)r * A.cap_frames + A.state[r].frame) * 9 + 1 + cb) * 2048 + 1024] = (float)code;
                     if (tid == 0) s_ring[r * RR + 168 + 4 + cb] = (int)code;
-                    if (cb != 7) {
+                    if (cb != 7) {  // hidden_states = fast_embeddings(code) (single_batch.rs:181-183): the next pass's S1 reads it back (same lane)
                         const uint32_t ew = reinterpret_cast<const uint32_t*>(A.fast_emb)[(size_t)code * 512 + tid];
-                        x0[r] = bf_lo(ew); x1[r] = bf_hi(ew);
+                        *reinterpret_cast<float2*>(qs + r * 1024 + 2 * tid) = make_float2(bf_lo(ew), bf_hi(ew));
                     }
                 }
                 par ^= 1;
@@ -1164,17 +1230,18 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
     if (b != 0) return;
     // ---- end of frame, workgroup 0 only, row by row (single_batch.rs:185-210 + generate_blocking :250,264-266)
     __syncthreads();
-#pragma unroll
+#pragma unroll 1
     for (int r = 0; r < R; ++r) {
         if (!((live >> r) & 1u)) continue;
         const bool eos = !((run >> r) & 1u);
         SeqState* st = A.state + r;
-        int* misc = s_ring + r * RR + 168;
+        const int* misc = s_ring + r * RR + 168;
+        const uint32_t cur0 = (uint32_t)misc[0];
         if (tid == 0) {
             const int fr = st->frame;
             uint32_t codes[8];
             for (int c = 0; c < 8; ++c) codes[c] = eos ? 0u : (uint32_t)misc[4 + c];
-            st->cur[0] = cur0[r];
+            st->cur[0] = cur0;
             for (int c = 0; c < 8; ++c) st->cur[c + 1] = codes[c];
             if (fr == 0 || !eos) {
                 const int o = st->n_out;
@@ -1182,7 +1249,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                     for (int c = 0; c < 8; ++c) A.out_codes[((size_t)r * 8 + c) * A.out_cap + o] = codes[c];
                 st->n_out = o + 1;
             }
-            st->prev[0] = cur0[r];
+            st->prev[0] = cur0;
             for (int c = 0; c < 8; ++c) st->prev[c + 1] = codes[c];
             st->have_prev = 1;
             st->pos += 1;
@@ -1191,11 +1258,10 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
         }
         // next slow input: embed([slow, c0..c7]) (dual_ar.rs:532-567)
         {
-            const uint32_t sem = cur0[r];
-            const float mk = (sem >= cfg[r].sem_lo && sem <= cfg[r].sem_hi) ? 1.f : 0.f;
+            const float mk = (cur0 >= (uint32_t)misc[20] && cur0 <= (uint32_t)misc[21]) ? 1.f : 0.f;
             const uint32_t* te = reinterpret_cast<const uint32_t*>(A.tok_emb);
             const uint32_t* ce = reinterpret_cast<const uint32_t*>(A.cb_emb);
-            const uint32_t w0 = te[(size_t)sem * 512 + tid];
+            const uint32_t w0 = te[(size_t)cur0 * 512 + tid];
             float e0 = 0.f + bf_lo(w0), e1 = 0.f + bf_hi(w0);
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
@@ -1233,6 +1299,11 @@ static void launch_rows_slow_r(const RowsSlowArgs& a, hipStream_t st) {
         attr_set = true;
     }
     hipLaunchKernelGGL(k_slow_rows<R>, dim3(PF_BLOCKS), dim3(PF_THREADS), SlowLds<R>::BYTES, st, a);
+    FS_HIP(hipGetLastError());
+}
+void launch_rows_pack_rowpairs(const void* fast_pack, void* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_pr_pack_rowpairs, dim3(PF_BLOCKS, PF_ROW_CHUNKS), dim3(PF_THREADS), 0, st, reinterpret_cast<const u32x4*>(fast_pack),
+                       reinterpret_cast<uint32_t*>(out));
     FS_HIP(hipGetLastError());
 }
 size_t rows_fast_edge_bytes(int R) { return (size_t)PF_RING * PF_REPL * R * PF_EDGE_CAP * 8; }

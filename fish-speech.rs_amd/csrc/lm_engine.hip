@@ -1083,9 +1083,13 @@ class LM final : public LMBase {
         }
         bool rows_ok = n >= 2 && n <= PR_MAX_ROWS && n <= B_ && pslow_ok_ && persist_ok_ && !kFp8 && !legacy_ && n_audio_ <= 2048 &&
                        !(flags & FS_GEN_NO_PERSIST) && !getenv("FISHRT_NO_ROWS");
+        // one instantiation per launch: every request greedy, or every request within the in-launch sampler (temp > 0, 0 < top_k <= 256)
+        bool rows_sampled = samplings[0].temp != 0.0;
         for (int i = 0; i < n && rows_ok; ++i) {
             const fs_sampling& s = samplings[i];
-            if (s.temp != 0.0) rows_ok = false;  // (sampled rows: the in-launch sampler per row is not wired into the row kernels yet)
+            const int tk = (int)std::min<uint64_t>(s.top_k, 1u << 30);
+            if ((s.temp != 0.0) != rows_sampled) rows_ok = false;
+            if (rows_sampled && !fast_persist_samples((float)s.temp, tk, a_.codebook_size)) rows_ok = false;
         }
         std::unique_lock<std::mutex> plock;
         if (rows_ok) { plock = std::unique_lock<std::mutex>(persist_mutex(device_), std::try_to_lock); rows_ok = plock.owns_lock(); }
@@ -1155,7 +1159,7 @@ class LM final : public LMBase {
             seq_len_[i] = L - 1;
             stats_.prompt_tokens += (uint64_t)L;
         }
-        use_persist_ = true; use_pslow_ = true; persist_sampled_ = false;
+        use_persist_ = true; use_pslow_ = true; persist_sampled_ = rows_sampled;
         std::vector<SeqState> hs(R);
         auto all_done = [&]() {
             FS_HIP(hipMemcpyAsync(hs.data(), state(0), sizeof(SeqState) * R, hipMemcpyDeviceToHost, st_));
@@ -1173,13 +1177,13 @@ class LM final : public LMBase {
             if (rows_fast) {
                 for (int r0 = 0; r0 < n; r0 += PR_FAST_ROWS) {
                     const int Rf = std::min(PR_FAST_ROWS, R - r0) >= 4 ? 4 : (std::min(PR_FAST_ROWS, R - r0) >= 2 ? 2 : 1);
-                    launch_rows_fast(rows_fast_args(r0, Rf), Rf, st_);
+                    launch_rows_fast(rows_fast_args(r0, Rf), Rf, rows_sampled, st_);
                 }
             } else {
                 static const int two = 2;
                 for (int i = 0; i < n; ++i) {
                     if (it_ >= n_iter[i]) { if (it_ == n_iter[i]) FS_HIP(hipMemcpyAsync(&state(i)->done, &two, sizeof(int), hipMemcpyHostToDevice, st_)); continue; }
-                    launch_fast_persist(persist_args(i), false, st_);
+                    launch_fast_persist(persist_args(i), rows_sampled, st_);
                 }
             }
         };
@@ -1781,7 +1785,7 @@ class LM final : public LMBase {
         A.xf = x(r0); A.x = x(r0);
         A.slow_logits = d_rlogits_.as<float>() + (size_t)r0 * PR_LD; A.n_slow = n_audio_;
         A.cap = cap_frames_ ? d_rcap_.as<float>() + (size_t)r0 * cap_frames_ * 9 * 2048 : nullptr; A.cap_frames = cap_frames_;
-        A.state = state(r0); A.cfg = d_rcfg_.as<SampleCfg>() + r0; A.budget = d_rbudget_.as<int>() + r0;
+        A.state = state(r0); A.cfg = d_rcfg_.as<SampleCfg>() + r0; A.budget = d_rbudget_.as<int>() + r0; A.rng = d_rrng_.as<RngState>() + r0;
         const RepPenState rp = rows_rp(r0);
         A.rp_mask = rp.mask; A.rp_ring = rp.ring; A.rp_meta = rp.ring_meta;
         A.out_codes = d_out_.as<uint32_t>() + (size_t)r0 * a_.num_codebooks * out_cap_; A.out_cap = out_cap_;

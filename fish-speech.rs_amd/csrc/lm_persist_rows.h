@@ -64,6 +64,7 @@ struct RowsFastArgs {
     SeqState* state;            // [R]
     const SampleCfg* cfg;       // [R]
     const int* budget;          // [R] generator iterations allowed (a row is done when frame reaches it)
+    RngState* rng;              // [R] StdRng stream positions (sampled rows: up to 9 words per frame)
     float* rp_mask;             // [R][8][1024]
     int* rp_ring;               // [R][8][17]
     int* rp_meta;               // [R][8][2]
@@ -81,6 +82,6 @@ size_t rows_fast_edge_bytes(int R);
 void launch_rows_pack(const LayerW* layers, int n_layer, const void* head_w, int n_head_rows, void* wimg, void* himg, hipStream_t st);
 void launch_rows_pack_rowpairs(const void* fast_pack, void* out /*PF_BLOCKS * 40 * 512 * 4 bytes*/, hipStream_t st);
 void launch_rows_slow(const RowsSlowArgs& a, int R, hipStream_t st);   // R in {2, 4, 8}
-void launch_rows_fast(const RowsFastArgs& a, int R, hipStream_t st);   // R in {1, 2, 4}
+void launch_rows_fast(const RowsFastArgs& a, int R, bool sampled, hipStream_t st);   // R in {1, 2, 4}; sampled: every row temp > 0, 0 < top_k <= 256
 
 }  // namespace fs

@@ -25,6 +25,7 @@ namespace {
 
 #include "lm_persist_dev.h"
 #include "lm_persist_rows_dev.h"
+#include "lm_bsample_dev.h"
 
 constexpr int PS_DROR8 = 0x128;  // DPP row_ror:8
 
@@ -627,12 +628,13 @@ struct FastLds {
     static constexpr int SC = RED + 2 * 8 * R * FRW * 4;         // [R][16][8]
     static constexpr int AMAX = SC + R * 128 * 4;                // [2][R][8][2]
     static constexpr int ROPE = AMAX + 2 * R * 8 * 2 * 4;        // cos [8][32], sin [8][32]
-    static constexpr int RING = ROPE + 2 * 8 * 32 * 4;           // per row: ring [8][17], meta [8][2], prev [16], misc [16], cfg [8]
-    static constexpr int RING_ROW = 8 * 17 + 16 + 16 + 16 + 8;
+    static constexpr int RING = ROPE + 2 * 8 * 32 * 4;           // per row: ring [8][17], meta [8][2], prev [16], misc [16], cfg [16], StdRng words [16]
+    static constexpr int RING_ROW = 8 * 17 + 16 + 16 + 16 + 16 + 16;
     static constexpr int MB = RING + R * RING_ROW * 4;           // [R][512] repetition-penalty mask bits of each lane's two candidates
     static constexpr int END = MB + R * 512 * 4;
     static constexpr int BYTES = END < 96 * 1024 ? 96 * 1024 : END;
     static_assert(END <= 160 * 1024, "LDS budget");
+    static_assert(sizeof(BSampLds) <= 8 * 4096, "the sampler's scratch aliases the staging tiles (dead during a decision)");
 };
 
 // R rows x {q unit, k/v unit}: unit a of row i = b[i] + off_a, unit b = b[i] + off_b
@@ -693,7 +695,10 @@ __device__ __forceinline__ float pr_reduce(float (&v)[N], int lane) {
 
 }  // namespace
 
-template <int R>
+// SAMPLED: every row decides with the block-parallel top-k / top-p / WeightedIndex sampler of lm_bsample_dev.h (temp > 0, 0 < top_k <= 256:
+// the server default) on its own StdRng stream -- one row after the other (the sampler is a block-wide routine); the greedy instantiation
+// keeps its register allocation
+template <int R, bool SAMPLED>
 __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
     using L = FastLds<R>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -708,9 +713,11 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
     float* rope_s = rope_c + 8 * 32;
     int* s_ring = reinterpret_cast<int*>(smem + L::RING);  // per row: [0,136) ring, [136,152) meta, [152,168) prev, [168,184) misc, [184,192) cfg
     uint32_t* s_mb = reinterpret_cast<uint32_t*>(smem + L::MB);
+    BSampLds& samp = *reinterpret_cast<BSampLds*>(smem + L::XB);
     constexpr int RR = L::RING_ROW;
     // misc: [0] slow token, [1] have_prev, [2] done, [3] epoch (row 0), [4..11] codes of this frame
-    // cfg : [0] rep_pen bits, [1] ignore_eos, [2] im_end_id, [3] audio_base, [4] sem_lo, [5] sem_hi
+    // cfg : [0] rep_pen bits, [1] ignore_eos, [2] im_end_id, [3] audio_base, [4] sem_lo, [5] sem_hi, [6] temp bits, [7] top_p bits, [8] top_k
+    // words (SAMPLED): the StdRng output words of this frame's 9 draws
 
     const int tid_k = threadIdx.x, b = blockIdx.x;
     int tid = tid_k, lane = tid & 63, wave = tid >> 6;
@@ -738,6 +745,13 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
         const SampleCfg& c = A.cfg[tid];
         misc[16] = __float_as_int(c.rep_pen); misc[17] = c.ignore_eos; misc[18] = (int)c.im_end_id; misc[19] = (int)c.audio_base;
         misc[20] = (int)c.sem_lo; misc[21] = (int)c.sem_hi;
+        misc[22] = __float_as_int(c.temp); misc[23] = __float_as_int(c.top_p); misc[24] = c.top_k;
+        const bool ok = SAMPLED ? (c.temp > 0.f && c.top_k > 0 && c.top_k <= BS_MAXK) : c.temp == 0.f;
+        if (!ok && b == 0 && A.state[tid].done == 0) atomicAdd(A.ctl + 2, 1u);  // the host picks the instantiation by the sampling configuration
+    }
+    if (SAMPLED && tid >= PF_THREADS - 64 && tid < PF_THREADS - 64 + 9 * R) {  // this frame's StdRng words: ~2.4 us of dependent integer work each
+        const int k = tid - (PF_THREADS - 64), r = k / 9, i = k % 9;
+        s_ring[r * RR + 168 + 32 + i] = (int)chacha12_word(A.rng[r].key, A.rng[r].consumed + (unsigned)i);
     }
     if (tid == 64) s_ring[168 + 3] = (int)A.ctl[0];
     if (tid >= 256) { const int i = tid - 256; rope_c[i] = A.cos_t[i]; rope_s[i] = A.sin_t[i]; }
@@ -752,6 +766,9 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
     // ---- the slow-token decision of every live row (constrain_probs_to_audio utils.rs:13-16, rescale_semantic_tokens :45-46,
     // single_batch.rs:102-144), redundantly on every workgroup
     unsigned run = 0;  // rows whose fast decoder runs: live and not terminated by <|im_end|> this frame (single_batch.rs:153-156)
+    int n_draws[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) n_draws[r] = 0;
     {
         const int n = A.n_slow;
 #pragma unroll
@@ -766,6 +783,18 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
             }
             if (A.cap && b == 0 && lv_r && A.state[r].frame < A.cap_frames)
                 *reinterpret_cast<float4*>(A.cap + ((size_t)r * A.cap_frames + A.state[r].frame) * 9 * 2048 + 4 * tid) = make_float4(lv[0], lv[1], lv[2], lv[3]);
+            if (SAMPLED) {
+                int idx = 0;
+                if (lv_r) {
+                    int used = 0;
+                    const int* cf = s_ring + r * RR + 168 + 16;
+                    __syncthreads();  // (the sampler's scratch: nobody still reads the previous row's)
+                    idx = bsample<PF_THREADS, 4>(lv, n, cf[8], (float)(1.0 / (double)__int_as_float(cf[6])), __int_as_float(cf[7]),
+                                                 (uint32_t)s_ring[r * RR + 168 + 32], &used, samp);
+                    n_draws[r] += used;
+                }
+                if (tid == 0) amax[(r * 8) * 2 + 1] = __int_as_float(idx);
+            } else {
             float bv = lv[0];
             int bi = 4 * tid;
 #pragma unroll
@@ -774,17 +803,20 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
             float wm; int ci;
             pr_wave_argmax(bv, bi, wm, ci);
             if (lane == 0) { amax[(r * 8 + wave) * 2] = wm; amax[(r * 8 + wave) * 2 + 1] = __int_as_float(ci); }
+            }
         }
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             float gv = amax[(r * 8) * 2];
             int idx = __float_as_int(amax[(r * 8) * 2 + 1]);
+            if (!SAMPLED) {
 #pragma unroll
             for (int w = 1; w < 8; ++w) {
                 const float v2 = amax[(r * 8 + w) * 2];
                 const int i2 = __float_as_int(amax[(r * 8 + w) * 2 + 1]);
                 if (v2 > gv || (v2 == gv && i2 > idx)) { gv = v2; idx = i2; }
+            }
             }
             const bool lv_r = (live >> r) & 1u;
             if (A.cap && b == 0 && tid == 0 && lv_r && A.state[r].frame < A.cap_frames)
@@ -1193,12 +1225,26 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                         }
                         if (A.cap && b == 0 && on && A.state[r].frame < A.cap_frames)
                             *reinterpret_cast<float2*>(A.cap + (((size_t)r * A.cap_frames + A.state[r].frame) * 9 + 1 + cb) * 2048 + 2 * tid) = make_float2(lv0, lv1);
+                        if (SAMPLED) {
+                            int gi = 0;
+                            if (on) {
+                                int used = 0;
+                                const int* cf = ring + 168 + 16;
+                                const float lvv[2] = {lv0, lv1};
+                                __syncthreads();  // (the sampler's scratch aliases the staging tiles: every wave is past this pass's last S3 / previous row)
+                                gi = bsample<PF_THREADS, 2>(lvv, 1024, cf[8], (float)(1.0 / (double)__int_as_float(cf[6])), __int_as_float(cf[7]),
+                                                            (uint32_t)ring[168 + 32 + n_draws[r]], &used, samp);
+                                n_draws[r] += used;
+                            }
+                            if (tid == 0) amax[((par * R + r) * 8) * 2 + 1] = __int_as_float(gi);
+                        } else {
                         float bv = lv0;
                         int bi = 2 * tid;
                         if (!(lv1 < bv)) { bv = lv1; bi = 2 * tid + 1; }
                         float wm; int ci;
                         pr_wave_argmax(bv, bi, wm, ci);
                         if (lane == 0) { amax[((par * R + r) * 8 + wave) * 2] = wm; amax[((par * R + r) * 8 + wave) * 2 + 1] = __int_as_float(ci); }
+                        }
                     }
                 }
                 __syncthreads();
@@ -1207,11 +1253,13 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                     const bool on = (run >> r) & 1u;
                     float gv = amax[((par * R + r) * 8) * 2];
                     int gi = __float_as_int(amax[((par * R + r) * 8) * 2 + 1]);
+                    if (!SAMPLED) {
 #pragma unroll
                     for (int w = 1; w < 8; ++w) {
                         const float v2 = amax[((par * R + r) * 8 + w) * 2];
                         const int i2 = __float_as_int(amax[((par * R + r) * 8 + w) * 2 + 1]);
                         if (v2 > gv || (v2 == gv && i2 > gi)) { gv = v2; gi = i2; }
+                    }
                     }
                     const uint32_t code = (uint32_t)max(gi, 0);
                     if (A.cap && b == 0 && tid == 0 && on && A.state[r].frame < A.cap_frames)
@@ -1228,6 +1276,12 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
         }
     }
     if (b != 0) return;
+    int* n_draws_l = reinterpret_cast<int*>(amax);  // (dead: every decision is taken)
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) n_draws_l[r] = n_draws[r];
+    }
     // ---- end of frame, workgroup 0 only, row by row (single_batch.rs:185-210 + generate_blocking :250,264-266)
     __syncthreads();
 #pragma unroll 1
@@ -1255,6 +1309,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
             st->pos += 1;
             st->frame = fr + 1;
             if (eos || fr + 1 >= A.budget[r]) st->done = 2;
+            if (SAMPLED) A.rng[r].consumed += (unsigned long long)n_draws_l[r];
         }
         // next slow input: embed([slow, c0..c7]) (dual_ar.rs:532-567)
         {
@@ -1307,20 +1362,20 @@ void launch_rows_pack_rowpairs(const void* fast_pack, void* out, hipStream_t st)
     FS_HIP(hipGetLastError());
 }
 size_t rows_fast_edge_bytes(int R) { return (size_t)PF_RING * PF_REPL * R * PF_EDGE_CAP * 8; }
-template <int R>
+template <int R, bool SAMPLED>
 static void launch_rows_fast_r(const RowsFastArgs& a, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_rows<R>), hipFuncAttributeMaxDynamicSharedMemorySize, FastLds<R>::BYTES));
+        FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fast_rows<R, SAMPLED>), hipFuncAttributeMaxDynamicSharedMemorySize, FastLds<R>::BYTES));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_fast_rows<R>, dim3(PF_BLOCKS), dim3(PF_THREADS), FastLds<R>::BYTES, st, a);
+    hipLaunchKernelGGL((k_fast_rows<R, SAMPLED>), dim3(PF_BLOCKS), dim3(PF_THREADS), FastLds<R>::BYTES, st, a);
     FS_HIP(hipGetLastError());
 }
-void launch_rows_fast(const RowsFastArgs& a, int R, hipStream_t st) {
-    if (R == 1) launch_rows_fast_r<1>(a, st);
-    else if (R == 2) launch_rows_fast_r<2>(a, st);
-    else if (R == 4) launch_rows_fast_r<4>(a, st);
+void launch_rows_fast(const RowsFastArgs& a, int R, bool sampled, hipStream_t st) {
+    if (R == 1) { if (sampled) launch_rows_fast_r<1, true>(a, st); else launch_rows_fast_r<1, false>(a, st); }
+    else if (R == 2) { if (sampled) launch_rows_fast_r<2, true>(a, st); else launch_rows_fast_r<2, false>(a, st); }
+    else if (R == 4) { if (sampled) launch_rows_fast_r<4, true>(a, st); else launch_rows_fast_r<4, false>(a, st); }
     else throw Error("launch_rows_fast: R must be 1, 2 or 4");
 }
 void launch_rows_slow(const RowsSlowArgs& a, int R, hipStream_t st) {

@@ -178,10 +178,12 @@ int fs_lm_generate_batch(fs_lm_t* lm, const uint32_t* prompts, const int* lens, 
  * cleared cache (generate/single_batch.rs:76-214: its own KV, repetition-penalty window, RNG stream, <|im_end|> / budget rules) -- the
  * tokens of its own fs_lm_generate call (the kernels sum in another order, so greedy tokens may differ where two candidates are within
  * rounding of each other).  prompts: the n prompts u32 [C+1, L_i] concatenated; codes_out u32 [n, C, cap]; n_frames[n].
- * bf16 handles with the Fish 1.5 geometry and token layout, 2 <= n <= min(8, max_batch), greedy sampling (temp == 0): every decode frame
- * is ONE persistent launch of the slow transformer for all requests (csrc/lm_persist_rows.hip: the weights are streamed once per frame,
- * the requests are matrix-core columns) plus one fast-decoder launch per group of <= 4 requests.  Any other handle / sampler setting /
- * n runs the requests one after the other through fs_lm_generate.  The slow KV cache of every slot is cleared first. */
+ * bf16 handles with the Fish 1.5 geometry and token layout, 2 <= n <= min(8, max_batch), and either every request greedy (temp == 0) or
+ * every request inside the in-launch sampler (temp > 0, 0 < top_k <= 256: the server default): every decode frame is ONE persistent
+ * launch of the slow transformer for all requests (csrc/lm_persist_rows.hip: the weights are streamed once per frame, the requests are
+ * matrix-core columns) plus one fast-decoder launch per group of <= 4 requests, each request deciding on its own logits with its own
+ * StdRng stream and repetition-penalty window.  Any other handle / sampler mix / n runs the requests one after the other through
+ * fs_lm_generate.  The slow KV cache of every slot is cleared first. */
 int fs_lm_generate_multi(fs_lm_t* lm, const uint32_t* prompts, const int* lens, int n, const int* max_new_tokens,
                          const fs_sampling* samplings, const uint64_t* seeds, uint32_t flags, uint32_t* codes_out, size_t cap,
                          size_t* n_frames);

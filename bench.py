@@ -523,6 +523,42 @@ def extras(cfg, tok):
         out[name] = {"workload": f"configs[1] prompt, 128 frames, {dtype} weights, {kw}", "frame_us": round(st1["decode_ms"] * 1e3 / 127, 1),
                      "decode_frames_per_s": round(127 / (st1["decode_ms"] * 1e-3), 1), "prefill_ms": round(st1["prefill_ms"], 2)}
         lm1.close()
+    # R concurrent configs[1] requests through the request-row persistent kernels (fs_lm_generate_multi: each request IS its own
+    # generate_blocking call -- own KV, repetition-penalty window, sampler stream; every decode frame = one slow launch for all rows + one
+    # fast launch per <= 4 rows)
+    lm8 = fishrt.DualARTransformer(cfg, tok, 0, "bf16", max_batch=8).load_synthetic(SEED)
+    Lp, Fr = tokp.shape[1], 256
+    lm8.clear_slow_layer_caches()
+    ref1 = lm8.generate_blocking(tokp, Fr + Lp - 2, temp=0.0, top_p=1.0, top_k=0, repetition_penalty=1.2, ignore_eos=True)
+    one_us = lm8.last_stats()["decode_ms"] * 1e3 / (Fr - 1)
+    rows = {"workload": "R concurrent BASELINE.json configs[1] requests (default-voice prompt, 256 frames each) on ONE GPU through "
+                        "fs_lm_generate_multi; frame_us = one decode frame of all R requests (HIP events), decode_frames_per_s = R / frame; "
+                        "whole_job_frames_per_s includes the R prefills (host wall clock)",
+            "one_request_frame_us": round(one_us, 1)}
+    for R, kw in ((2, dict(temp=0.0, top_p=1.0, top_k=0)), (4, dict(temp=0.0, top_p=1.0, top_k=0)), (8, dict(temp=0.0, top_p=1.0, top_k=0)),
+                  (4, dict(temp=0.7, top_p=0.8, top_k=256))):
+        best, wall, outs = 1e9, 1e9, None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            outs = lm8.generate_multi([tokp] * R, Fr + Lp - 2, repetition_penalty=1.2, seeds=list(range(1, R + 1)), ignore_eos=True, **kw)
+            wall = min(wall, time.perf_counter() - t0)
+            stR = lm8.last_stats()
+            best = min(best, stR["decode_ms"] * 1e3 / (Fr - 1))
+        assert all(o.shape == (8, Fr) for o in outs) and stR["kernels_per_frame"] == 1 + (R + 3) // 4
+        T_avg = Lp + Fr / 2.0
+        bytes_frame = frame_bytes(cfg, tok, 0) + R * 12288 * T_avg  # SURVEY.md 8d "batch B": weights once per step, KV term x B
+        key = f"R{R}" + ("" if kw["temp"] == 0.0 else "_sampled")
+        rows[key] = {"frame_us": round(best, 1), "decode_frames_per_s": round(R * 1e6 / best, 1), "whole_job_frames_per_s": round(R * Fr / wall, 1),
+                     "speedup_vs_one_request_at_a_time": round(R * one_us / best, 2), "launches_per_frame": int(stR["kernels_per_frame"]),
+                     "roofline_frac": round(bytes_frame / (best * 1e-6) / HBM_PEAK, 4),
+                     "rows_identical_to_the_batch1_call": (int(sum(np.array_equal(o, ref1) for o in outs)) if kw["temp"] == 0.0 else None)}
+    lm8.close()
+    if "static_batch32" in out and "R8" in rows:
+        rows["vs_static_batch32"] = {"thirty_two_requests_as_4_launch_groups_of_8_us": round(4 * rows["R8"]["frame_us"], 1),
+                                     "static_batch32_step_us": out["static_batch32"]["step_us"],
+                                     "note": "the stage chain of the row kernels is latency-bound per launch group, so 32 rows as 4 x R = 8 cost 4 chains: the "
+                                             "MFMA row path (one chain of 373 nodes for all 32 rows) stays the B = 32 path; the row kernels are the 2..8-request path"}
+    out["persistent_rows"] = rows
     # N independent batch-1 request streams on this ONE GPU (own handle, HIP stream and host thread each; no lock-step batching):
     # the frame is a chain of dependent graph nodes whose launch gaps leave the chip idle, so independent chains interleave
     import threading

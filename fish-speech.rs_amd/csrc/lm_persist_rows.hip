@@ -131,7 +131,11 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
     const int t0 = min(pos, as * chunk_t), t1 = min(pos, (as + 1) * chunk_t);
     const bool last_slice = att && as == n_sl - 1;
     const int n_tok = t1 - t0;
-    const int n_tiles = att ? max((n_tok + 127) / 128, last_slice ? 1 : 0) : 0;
+    // a tile = 2 or 3 tokens per lane (128 / 192 tokens): with R rows a head has only 16 / R slices, so at R = 4 a 513..768-token cache would
+    // need a second, nearly empty tile round (three block barriers) per layer
+    const bool g3 = chunk_t > 128;
+    const int TS = g3 ? 192 : 128;
+    const int n_tiles = att ? max((n_tok + TS - 1) / TS, last_slice ? 1 : 0) : 0;
     const int* ptab = A.page_table + (size_t)ar * A.pt_stride;
     if (att) {
         const int p0 = t0 >> 6;
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) wq[j] = reinterpret_cast<const u32x4*>(wimg + IR_QKV)[((wave * 4 + j) * 4 + q4) * 5 + m];
     }
-    u32x4 kreg[2] = {zero4, zero4}, vreg[2] = {zero4, zero4};
+    u32x4 kreg[3] = {zero4, zero4, zero4}, vreg[3] = {zero4, zero4, zero4};
     bool dead = false;
     unsigned e = 0;
     int par = 0;
@@ -169,9 +173,10 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
         const uint16_t* kpool = reinterpret_cast<const uint16_t*>(A.kv_pool) + (size_t)l * 2 * A.layer_half;
         const uint16_t* vpool = kpool + A.layer_half;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < 3; ++u) {
+            if (u == 2 && !g3) break;
             const int i = tid + PF_THREADS * u;
-            const int t = min(t0 + tile * 128 + (i >> 3), max(t1 - 1, t0));
+            const int t = min(t0 + tile * TS + (i >> 3), max(t1 - 1, t0));
             const int pg = s_pages[(t >> 6) - (t0 >> 6)];
             const size_t off = ((size_t)(pg * 2 + ag) * KV_PAGE + (t & 63)) * 64 + (size_t)(i & 7) * 8;
             kreg[u] = *reinterpret_cast<const u32x4*>(kpool + off);
@@ -277,12 +282,14 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
             }
             for (int tile = 0; tile < n_tiles; ++tile) {
                 if (tile > 0) load_kv_tile(l, tile);
-                float sc[3];
-                bool valid[3];
+                float sc[4];
+                bool valid[4];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int t = t0 + tile * 128 + ((tid + PF_THREADS * u) >> 3);
-                    valid[u] = t < t1;
+                for (int u = 0; u < 3; ++u) {
+                    const int t = t0 + tile * TS + ((tid + PF_THREADS * u) >> 3);
+                    valid[u] = t < t1 && (u < 2 || g3);
+                    sc[u] = -1e30f;
+                    if (u == 2 && !g3) continue;
                     const u32x4 kk = kreg[u];
                     float a = 0.f;
                     a = fmaf(qv[0], bf_lo(kk.x), a); a = fmaf(qv[1], bf_hi(kk.x), a); a = fmaf(qv[2], bf_lo(kk.y), a); a = fmaf(qv[3], bf_hi(kk.y), a);
@@ -296,10 +303,10 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) a = fmaf(qv[i], knew[du * 8 + i], a);
                     a += pf_dpp<PF_XOR1>(a); a += pf_dpp<PF_XOR2>(a); a += pf_dpp<PF_HALF_MIRROR>(a);
-                    valid[2] = has_new;
-                    sc[2] = has_new ? a : -1e30f;
+                    valid[3] = has_new;
+                    sc[3] = has_new ? a : -1e30f;
                 }
-                float m = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
+                float m = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
                 m = fmaxf(m, pf_dpp<PF_XOR1>(m)); m = fmaxf(m, pf_dpp<PF_XOR2>(m)); m = fmaxf(m, pf_dpp<PF_HALF_MIRROR>(m)); m = fmaxf(m, pf_dpp<PF_MIRROR>(m));
                 m = fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 15)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 31))),
                           fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 47)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 63))));
@@ -310,10 +317,11 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
                 for (int w = 1; w < 8; ++w) mt = fmaxf(mt, wmax[w]);
                 float o9[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int u = 0; u < 3; ++u) {
+                for (int u = 0; u < 4; ++u) {
+                    if (u == 2 && !g3) continue;
                     const float p = valid[u] ? __expf(sc[u] - mt) : 0.f;
                     if (du == 0) o9[8] += p;
-                    if (u < 2) {
+                    if (u < 3) {
                         const u32x4 vv = vreg[u];
                         o9[0] = fmaf(p, bf_lo(vv.x), o9[0]); o9[1] = fmaf(p, bf_hi(vv.x), o9[1]); o9[2] = fmaf(p, bf_lo(vv.y), o9[2]); o9[3] = fmaf(p, bf_hi(vv.y), o9[3]);
                         o9[4] = fmaf(p, bf_lo(vv.z), o9[4]); o9[5] = fmaf(p, bf_hi(vv.z), o9[5]); o9[6] = fmaf(p, bf_lo(vv.w), o9[6]); o9[7] = fmaf(p, bf_hi(vv.w), o9[7]);
@@ -1087,13 +1095,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) offs[q] = (unsigned)(tid + PF_THREADS * q) * 16u;
                     pf_nap_before_sweep(A.naps[3]);
-#pragma unroll 1
-                    for (int r0 = 0; r0 < R; r0 += RH) {
-                        const u64* bs[RH];
-                        u32x4 v[RH][4];
-#pragma unroll
-                        for (int i = 0; i < RH; ++i) bs[i] = ebase(e, rep, ((run >> (r0 + i)) & 1u) ? r0 + i : first);
-                        pr_sweep_seg4<RH>(bs, offs, tag0 + e + 1, v, dead, A.ctl);
+                    auto rows_dot = [&](const u32x4 (&v)[RH][4], int r0) {  // rows r0 .. r0 + RH - 1: W2 row pairs . activations -> halving tree -> red
                         float a[4 * RH];
 #pragma unroll
                         for (int i = 0; i < RH; ++i) {
@@ -1111,6 +1113,31 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                         const float tot = pf_reduce<4 * RH>(a, lane);
                         constexpr int SH = RH == 4 ? 2 : (RH == 2 ? 3 : 4);
                         if ((lane & ((1 << SH) - 1)) == 0) red[(par * 8 + wave) * R * FRW + (r0 + ((lane >> SH) >> 2)) * FRW + ((lane >> SH) & 3)] = tot;
+                    };
+                    if constexpr (R == 4) {
+                        // rows 0, 1: blocking sweep; rows 2, 3: requested right behind it and waited for behind the arithmetic on rows 0, 1
+                        // (two blocking sweeps one after the other cost a second memory-side round trip per stage: 0.8 us)
+                        const u64 *bsA[2], *bsB[2];
+                        u32x4 vA[2][4], vB[2][4];
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            bsA[i] = ebase(e, rep, ((run >> i) & 1u) ? i : first);
+                            bsB[i] = ebase(e, rep, ((run >> (2 + i)) & 1u) ? 2 + i : first);
+                        }
+                        pr_sweep_seg4<2>(bsA, offs, tag0 + e + 1, vA, dead, A.ctl);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(w2r[q]));  // (the compiler's wait for the prefetched W2 rows lands HERE)
+                        pr_issue_seg4_2(bsB, offs, vB);
+                        rows_dot(vA, 0);
+                        if (!pr_finish_seg4_2(vB, tag0 + e + 1) && !dead) pr_sweep_seg4<2>(bsB, offs, tag0 + e + 1, vB, dead, A.ctl);
+                        rows_dot(vB, 2);
+                    } else {
+                        const u64* bs[RH];
+                        u32x4 v[RH][4];
+#pragma unroll
+                        for (int i = 0; i < RH; ++i) bs[i] = ebase(e, rep, ((run >> i) & 1u) ? i : first);
+                        pr_sweep_seg4<RH>(bs, offs, tag0 + e + 1, v, dead, A.ctl);
+                        rows_dot(v, 0);
                     }
                     ++e;
                     if (l + 1 < PF_LAYERS) {

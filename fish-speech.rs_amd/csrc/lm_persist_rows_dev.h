@@ -143,6 +143,28 @@ __device__ __forceinline__ void pr_sweep_seg4(const u64* const (&b)[NR], const u
     }
 }
 
+// the same 2 x 4 units issued WITHOUT waiting (speculative: the producers publish all their rows together, so when rows 0, 1 of an edge
+// are complete rows 2, 3 almost always are), and the wait + tag check behind the arithmetic on the first rows.  Nothing may touch v
+// between the two calls; the compiler's own loads must have been waited for before the issue (its next vmcnt wait would cover these)
+__device__ __forceinline__ void pr_issue_seg4_2(const u64* const (&b)[2], const unsigned (&off)[4], u32x4 (&v)[2][4]) {
+    asm volatile("global_load_dwordx4 %0, %8, %12 sc1\n\tglobal_load_dwordx4 %1, %9, %12 sc1\n\t"
+                 "global_load_dwordx4 %2, %10, %12 sc1\n\tglobal_load_dwordx4 %3, %11, %12 sc1\n\t"
+                 "global_load_dwordx4 %4, %8, %13 sc1\n\tglobal_load_dwordx4 %5, %9, %13 sc1\n\t"
+                 "global_load_dwordx4 %6, %10, %13 sc1\n\tglobal_load_dwordx4 %7, %11, %13 sc1"
+                 : "=&v"(v[0][0]), "=&v"(v[0][1]), "=&v"(v[0][2]), "=&v"(v[0][3]), "=&v"(v[1][0]), "=&v"(v[1][1]), "=&v"(v[1][2]), "=&v"(v[1][3])
+                 : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "s"(b[0]), "s"(b[1]) : "memory");
+}
+__device__ __forceinline__ bool pr_finish_seg4_2(u32x4 (&v)[2][4], unsigned tag) {
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[0][2]), "+v"(v[0][3]), "+v"(v[1][0]), "+v"(v[1][1]), "+v"(v[1][2]), "+v"(v[1][3]) : : "memory");
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ok &= pr_ok(v[i][q], tag);
+    return ok;
+}
+
 // 8 attention slices: per slice one o-pair unit (b[k] + off_o) and the {m, l} unit (b[k] + off_ml)
 __device__ __forceinline__ void pr_sweep_att8(const u64* const (&b)[8], unsigned off_o, unsigned off_ml, unsigned tag, u32x4 (&vo)[8], u32x4 (&vm)[8],
                                               bool& dead, uint32_t* ctl) {

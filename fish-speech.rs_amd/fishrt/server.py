@@ -310,6 +310,16 @@ class Scheduler:
         self.stats["batches"] += 1
         self.stats["batched_rows"] += len(jobs)
         kw = sa.kw()
+        if 2 <= len(jobs) <= 8 and len(jobs) <= getattr(lm, "max_batch", 0) and hasattr(lm, "generate_multi"):
+            # request rows (fishrt.h fs_lm_generate_multi): every job keeps the batch-1 semantics of _single -- its own repetition-penalty
+            # window and sampler stream -- while one persistent launch serves all of them
+            self.stats["row_batches"] = self.stats.get("row_batches", 0) + 1
+            outs = lm.generate_multi([j.full_prompt() for j in jobs], self.s.max_new_tokens, seeds=[self.s.seed_source() & (2**64 - 1) for _ in jobs], **kw)
+            lm.clear_slow_layer_caches()
+            self.cached_key = None
+            for j, o in zip(jobs, outs):
+                j.future.set_result(self._codes_out(o))
+            return
         kw.pop("repetition_penalty")  # the batch path's repetition penalty is a no-op in the reference (static_batch.rs:204-206)
         outs = lm.generate_static_batch([j.full_prompt() for j in jobs], self.s.max_new_tokens, **kw)
         lm.clear_slow_layer_caches()  # speech.rs:88

@@ -268,6 +268,30 @@ def test_session_jobs_that_hit_max_new_tokens_are_rerolled_on_the_single_path():
     state.scheduler.close()
 
 
+def test_lock_step_variant_runs_small_batches_as_request_rows():
+    """2..8 waiting jobs on a handle with fs_lm_generate_multi: one call, every job keeps its batch-1 semantics (repetition penalty passed,
+    one sampler seed per job) instead of the static batch's"""
+    state, lm = _state(max_batch=8, continuous=False, slow=0.02, auto_batch=True)
+    lm.max_batch = 8
+
+    def generate_multi(prompts, max_new_tokens, seeds=None, **kw):
+        assert lm.lock.acquire(blocking=False), "two calls in flight on one handle"
+        try:
+            lm.calls.append(("multi", [p.shape[1] for p in prompts], list(seeds), dict(kw)))
+            return [lm._gen(p) for p in prompts]
+        finally:
+            lm.lock.release()
+    lm.generate_multi = generate_multi
+    c = _client(state)
+    results = _fire(c, 6)
+    assert all(r.status_code == 200 for r in results.values())
+    multi = [k for k in lm.calls if k[0] == "multi"]
+    assert multi and "batch" not in [k[0] for k in lm.calls]
+    assert all("repetition_penalty" in k[3] and len(set(k[2])) == len(k[2]) == len(k[1]) for k in multi)
+    assert state.scheduler.stats.get("row_batches", 0) == len(multi)
+    state.scheduler.close()
+
+
 def test_lock_step_variant_batches_waiting_jobs():
     state, lm = _state(max_batch=8, continuous=False, slow=0.02, auto_batch=True)
     c = _client(state)

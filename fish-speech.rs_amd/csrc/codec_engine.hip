@@ -105,6 +105,8 @@ class Codec final : public CodecBase {
         FS_HIP(hipSetDevice(device_));
         FS_REQUIRE(loaded_, "weights not loaded: call fs_codec_load_safetensors or fs_codec_load_synthetic first");
         FS_REQUIRE(bf3_ && C_ % 128 == 0 && (C_ >> 5) >= 16, "streaming state needs the plane data flow: f16 / bf16x3 precision, full-size codec");
+        // one stream per handle: a second begin would silently zero the left context of the stream in progress
+        FS_REQUIRE(stream_chunk_ < 0, "a stream is already open on this codec handle (fs_codec_stream_end first)");
         for (int i = 0; i < 2; ++i) {
             sctx_p_[i].ensure((size_t)kCtxSlots * ctx_slot_bytes());
             sctx_f_[i].ensure((size_t)3 * C_ * CODEC_CTX_F32 * sizeof(float));

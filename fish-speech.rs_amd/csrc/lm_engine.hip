@@ -829,12 +829,21 @@ class LM final : public LMBase {
             }
             if (flash && Lp <= kRowsCap) {
                 const int fit = std::max(1, std::min(kRowsCap / Lp, B_));
+                // pad positions write K/V up to Lp: every member must own pages that far (bounded: they go back with the slot).  The extra
+                // pages are counted CUMULATIVELY over the group -- checked per member, several short-budget members could each pass and
+                // alloc_pages would then throw in the middle of the flush with the queue half consumed
+                auto extra = [&](const PendingAdd& pa) {
+                    const int want = (std::max(pa.L + pa.n_iter - 1, Lp) + KV_PAGE - 1) / KV_PAGE;
+                    return std::max(0, want - (int)seq_pages_[pa.slot].size());
+                };
+                int need_sum = extra(sess_queue_[i]);
                 while (i + S < sess_queue_.size() && S < fit && sess_queue_[i + S].L - 1 >= 1) {
-                    // pad positions write K/V up to Lp: the member must own pages that far (bounded: they go back with the slot)
-                    const int need = (Lp + KV_PAGE - 1) / KV_PAGE - (int)seq_pages_[sess_queue_[i + S].slot].size();
-                    if (need > 0 && (int)free_pages_.size() < need) break;
+                    const int need = extra(sess_queue_[i + S]);
+                    if (need_sum + need > (int)free_pages_.size()) break;
+                    need_sum += need;
                     ++S;
                 }
+                if (need_sum > (int)free_pages_.size()) S = 1;  // (the first member alone does not fit a group pass either: its own pages were reserved by session_add)
             }
             if (S == 1 || !flash) {  // one sequence, passes of <= kRowsCap rows
                 const PendingAdd& pa = sess_queue_[i];

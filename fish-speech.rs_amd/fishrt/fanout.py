@@ -48,6 +48,17 @@ def max_over_ranks(dist, value):
     return float(t.item())
 
 
+def min_over_ranks(dist, value):
+    """MIN-reduce a python number over all ranks (e.g. a success flag: 1 only if every rank succeeded)."""
+    if dist is None:
+        return float(value)
+    import torch
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return float(t.item())
+
+
 def sum_over_ranks(dist, value):
     if dist is None:
         return float(value)

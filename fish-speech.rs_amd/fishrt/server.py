@@ -252,12 +252,18 @@ class Scheduler:
                             codes, _ = sess.poll(slot)
                             sess.release(slot)
                             jb = live.pop(slot)
-                            if codes.shape[1] >= self.s.max_new_tokens:  # speech.rs:41-61 "Failed generation suspected. Rerolling once":
-                                self.stats["rerolls"] += 1               # the re-roll takes the batch-1 path once the session has drained
-                                jb.allow_batch, jb.reroll = False, True
-                                self.q.put(jb)
-                            else:
-                                jb.future.set_result(self._codes_out(codes))
+                            try:  # (jb has left `live`: from here on fail_all no longer sees it, so its future is resolved right here)
+                                if codes.shape[1] >= self.s.max_new_tokens:  # speech.rs:41-61 "Failed generation suspected. Rerolling once":
+                                    self.stats["rerolls"] += 1               # the re-roll takes the batch-1 path once the session has drained
+                                    jb.allow_batch, jb.reroll = False, True
+                                    if stopping:  # nothing takes jobs off the queue any more: fail it instead of orphaning its future
+                                        raise RuntimeError("the scheduler is shutting down; the re-roll of a failed generation was dropped")
+                                    self.q.put(jb)
+                                else:
+                                    jb.future.set_result(self._codes_out(codes))
+                            except BaseException as e:
+                                if not jb.future.done():
+                                    jb.future.set_exception(e)
             except BaseException as e:  # every in-flight request gets the error (AppError -> HTTP 500); the session is rebuilt
                 fail_all(e)
                 held = None

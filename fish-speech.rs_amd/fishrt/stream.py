@@ -62,12 +62,19 @@ class StreamingSynth:
                 if self.stateful:
                     raise
                 stateful = False
+        # A stateful stream advances the device-side left context only through stream_decode, which needs >= min_frames frames: a NON-final
+        # chunk below that would have to take the stateless halo path and the next stateful chunk would start from a stale context (wrong,
+        # discontinuous PCM).  So the chunk sizes of a stateful stream are raised to min_frames; only the final tail may be shorter (it is
+        # decoded with a halo from the codes, and nothing follows it).
+        first_chunk = max(self.first_chunk, min_frames) if stateful else self.first_chunk
+        chunk = max(self.chunk, min_frames) if stateful else self.chunk
 
-        def vocode(a, b):
+        def vocode(a, b, final=False):
             t1 = time.perf_counter()
             if stateful and b - a >= min_frames:
                 pcm_parts.append(self.codec.stream_decode(np.ascontiguousarray(codes[:, a:b])))
             else:
+                assert final or not stateful, "a non-final chunk of a stateful stream below the codec's minimum chunk"
                 pcm_parts.append(decode_chunk(self.codec, codes, a, b, self.halo))
             t_busy[0] += time.perf_counter() - t1
             if t_first[0] is None:
@@ -87,14 +94,14 @@ class StreamingSynth:
                         n = n_frames[0]
                         done_upto = max(done_upto, inline_upto[0])
                     while True:  # vocode every complete chunk available so far (the first one is shorter)
-                        step = self.first_chunk if done_upto == 0 else self.chunk
+                        step = first_chunk if done_upto == 0 else chunk
                         if done_upto + step > n:
                             break
                         vocode(done_upto, done_upto + step)
                         done_upto += step
                     if final:
                         if n > done_upto:
-                            vocode(done_upto, n)  # tail
+                            vocode(done_upto, n, final=True)  # tail
                         return
             except BaseException as e:  # surfaced by the caller after join
                 errors.append(e)
@@ -106,9 +113,9 @@ class StreamingSynth:
             codes[:, idx] = fr
             n_frames[0] = idx + 1
             done = idx + 1
-            if done == self.first_chunk or (done > self.first_chunk and (done - self.first_chunk) % self.chunk == 0):
+            if done == first_chunk or (done > first_chunk and (done - first_chunk) % chunk == 0):
                 if self.inline:
-                    step = self.first_chunk if done == self.first_chunk else self.chunk
+                    step = first_chunk if done == first_chunk else chunk
                     try:
                         vocode(done - step, done)
                         inline_upto[0] = done

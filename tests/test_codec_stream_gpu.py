@@ -45,6 +45,8 @@ def test_stream_errors():
     with pytest.raises(RuntimeError, match="stream_begin"):
         c.stream_decode(codes)
     c.stream_begin()
+    with pytest.raises(RuntimeError, match="already open"):  # a second begin would zero the running stream's left context
+        c.stream_begin()
     with pytest.raises(RuntimeError, match="16 frames"):
         c.stream_decode(codes[:, :8])
     c.stream_decode(codes)

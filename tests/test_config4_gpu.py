@@ -94,6 +94,26 @@ def test_fish14_fp8_4096_frames_streamed_pcm_equals_one_shot(lm14):
     codec.close()
 
 
+@pytest.mark.parametrize("inline", [False, True])
+def test_stateful_stream_with_chunks_below_the_codec_minimum_stays_bit_identical(lm14, inline):
+    """first_chunk = 8 / chunk = 12 on a stateful stream used to send non-final chunks through the stateless halo path, after
+    which the next stateful chunk started from a stale left context.  The sizes are raised to the codec's minimum now; PCM == one-shot."""
+    p = _prompt14(24, 21)
+    frames = 77
+    M = frames + p.shape[1] - 2
+    kw = dict(temp=0.7, top_p=0.8, top_k=256, repetition_penalty=1.2, seed=9, ignore_eos=True)
+    codec = fishrt.FireflyCodec(0).load_synthetic(0xC0DEC)
+    lm14.clear_slow_layer_caches()
+    codes = lm14.generate_blocking(p, M, **kw)
+    pcm = _Clamp(codec).decode(np.ascontiguousarray(codes[None]))[0, 0]
+    lm14.clear_slow_layer_caches()
+    synth = fishrt.StreamingSynth(lm14, _Clamp(codec), chunk=12, first_chunk=8, inline=inline)
+    c2, pcm2 = synth(p, M, **kw)
+    assert synth.stats["stateful"] and np.array_equal(c2, codes)
+    assert pcm2.shape == pcm.shape and np.array_equal(pcm2, pcm), float(np.abs(pcm2 - pcm).max())
+    codec.close()
+
+
 def test_streaming_synth_inline_mode_equals_threaded(lm14):
     """inline=True vocodes each chunk inside the frame callback (the LM pauses) instead of in the worker thread: same codes, same PCM,
     ragged tail included (frames not a multiple of the chunk), errors from the vocoder still reach the caller"""

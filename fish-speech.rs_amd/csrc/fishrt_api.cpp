@@ -181,6 +181,14 @@ int fs_codec_encode(fs_codec_t* c, const float* pcm, int n_samples, uint32_t* co
     FS_ARG(n_samples > 0, "empty input");
     FS_TRY(c->impl->encode(pcm, n_samples, codes_out, cap, n_frames))
 }
+int fs_codec_encode_batch(fs_codec_t* c, const float* pcm, int b, size_t stride, const int* n_samples, uint32_t* codes_out, size_t cap, size_t* n_frames) {
+    FS_ARG(c && pcm && n_samples && codes_out && n_frames, "null argument");
+    FS_ARG(b >= 1, "empty batch");
+    for (int i = 0; i < b; ++i) FS_ARG(n_samples[i] > 0 && (size_t)n_samples[i] <= stride, "clip length outside (0, stride]");
+    FS_TRY({
+        for (int i = 0; i < b; ++i) c->impl->encode(pcm + (size_t)i * stride, n_samples[i], codes_out + (size_t)i * 8 * cap, cap, &n_frames[i]);
+    })
+}
 int fs_codec_sample_rate(fs_codec_t* c) { return c ? c->impl->sample_rate() : -1; }
 int fs_codec_stream_begin(fs_codec_t* c) { FS_ARG(c, "null argument"); FS_TRY(c->impl->stream_begin()) }
 int fs_codec_stream_decode(fs_codec_t* c, const uint32_t* codes, int T, float* pcm_out) {

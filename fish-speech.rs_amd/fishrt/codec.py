@@ -73,22 +73,27 @@ class FireflyCodec:
     def stream_end(self):
         _ffi.check(_ffi.lib().fs_codec_stream_end(self._h))
 
-    def encode(self, pcm_data):
-        """codec.rs:73-94: f32 (1, 1, n) mono 44.1 kHz PCM (the samples are flattened, spectrogram.rs:33) -> u32 (1, 8, L)."""
+    def encode(self, pcm_data, lengths=None):
+        """codec.rs:73-94 / firefly.rs:36-39: f32 (b, 1, n) mono 44.1 kHz PCM -> u32 (b, 8, L).  Every clip is encoded on its own
+        (fishrt.h fs_codec_encode_batch; the reference's front-end would glue a batch into one signal, spectrogram.rs:33).  lengths: optional
+        per-clip sample counts <= n (ragged clips, zero-padded rows) -> list of (8, L_i) instead of one array."""
         if not isinstance(pcm_data, np.ndarray) or not pcm_data.flags["C_CONTIGUOUS"]:
             raise ValueError("Data must be a contiguous array")
-        if pcm_data.ndim != 3:
-            raise ValueError("pcm_data must be a 3-D array (1, 1, n)")
-        if pcm_data.shape[0] != 1 or pcm_data.shape[1] != 1:
-            # the reference flattens whatever it is given into ONE clip (spectrogram.rs:33 `flatten_all`) and returns (1, 8, L): a batch
-            # would come back as the codes of its clips glued together.  Refuse it instead of reproducing that silently.
-            raise ValueError("encode takes one mono clip (1, 1, n): the reference concatenates batched clips into one (spectrogram.rs:33); "
-                             "call encode once per clip")
-        pcm = pcm_data.astype(np.float32, copy=False).reshape(-1)
-        cap = pcm.size // 2048 + 4
-        codes = np.zeros((8, cap), np.uint32)
-        n = C.c_size_t(0)
-        _ffi.check(_ffi.lib().fs_codec_encode(self._h, pcm.ctypes.data_as(C.POINTER(C.c_float)), int(pcm.size),
-                                              codes.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_size_t(cap), C.byref(n)))
-        return codes[None, :, : n.value].copy()
+        if pcm_data.ndim != 3 or pcm_data.shape[1] != 1:
+            raise ValueError("pcm_data must be a 3-D array (b, 1, n)")
+        b, _, n_max = pcm_data.shape
+        pcm = np.ascontiguousarray(pcm_data.astype(np.float32, copy=False).reshape(b, n_max))
+        ns = np.array([n_max] * b if lengths is None else [int(v) for v in lengths], np.int32)
+        if ns.shape != (b,) or (ns <= 0).any() or (ns > n_max).any():
+            raise ValueError("lengths must hold one sample count in (0, n] per clip")
+        cap = n_max // 2048 + 4
+        codes = np.zeros((b, 8, cap), np.uint32)
+        nf = (C.c_size_t * b)()
+        _ffi.check(_ffi.lib().fs_codec_encode_batch(self._h, pcm.ctypes.data_as(C.POINTER(C.c_float)), int(b), C.c_size_t(n_max),
+                                                    ns.ctypes.data_as(C.POINTER(C.c_int)), codes.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                    C.c_size_t(cap), nf))
+        if lengths is not None:
+            return [codes[i, :, : nf[i]].copy() for i in range(b)]
+        assert len(set(nf[i] for i in range(b))) == 1
+        return codes[:, :, : nf[0]].copy()
 

@@ -254,6 +254,13 @@ int fs_codec_decode(fs_codec_t* c, const uint32_t* codes, int b, int T, float* p
  * -> FireflyEncoder::encode (codec/encoder.rs:38-42: ConvNeXt backbone, downsample x4, grouped FSQ).  codes_out: u32 [8, cap]
  * row-major, *n_frames = L = mel_frames / 4 codes per group.  (channel_div > 1 handles use a reduced backbone depth (1,1,2,1).) */
 int fs_codec_encode(fs_codec_t* c, const float* pcm, int n_samples, uint32_t* codes_out, size_t cap, size_t* n_frames);
+/* the (b, 1, samples) -> (b, 8, T) signature of FireflyCodec::encode (codec/firefly.rs:36-39, fish_speech_python/src/codec.rs:73-92) for
+ * b clips: pcm f32 [b, stride] row-major (clip i = its first n_samples[i] samples), codes_out u32 [b, 8, cap], n_frames[b].  Every clip is
+ * encoded ON ITS OWN (per-clip lengths, per-clip padding).  Deviation from the reference, on purpose: its front-end flattens whatever it is
+ * given into ONE signal (audio/spectrogram.rs:33 `flatten_all`), so a batch comes back as (1, 8, L) codes of the clips glued together;
+ * this entry point returns what the signature promises. */
+int fs_codec_encode_batch(fs_codec_t* c, const float* pcm, int b, size_t stride, const int* n_samples, uint32_t* codes_out, size_t cap,
+                          size_t* n_frames);
 /* Stateful streaming decode (no reference counterpart: the reference vocodes an utterance in one piece, server/lib/handlers/speech.rs:98-129).
  * Every convolution of the 1.4+ / 1.5 codec is causal (codec/utils/mod.rs:53-62,110-122), so the chunks of ONE code sequence can be decoded
  * one after the other with the convolutions' left context carried on the device: fs_codec_stream_begin, then fs_codec_stream_decode per

@@ -81,8 +81,23 @@ def test_gpu_encode_tiny_vs_oracle(otiny):
         c.encode(np.zeros((1, 1, 100), np.float32))
     with pytest.raises(ValueError):
         c.encode(np.zeros((1, 1, 5000), np.float32)[:, :, ::2])  # not contiguous
-    with pytest.raises(ValueError, match="one mono clip"):
-        c.encode(np.zeros((2, 1, 8192), np.float32))  # the reference would glue the two clips together (spectrogram.rs:33)
+    # (b, 1, n) -> (b, 8, L) (firefly.rs:36-39, codec.rs:73-92): every clip on its own -- the reference's front-end would glue the clips
+    # together (spectrogram.rs:33); batch rows equal the one-clip calls, ragged clips via `lengths`
+    clips = [_clip(512 * 37 + 11, 20 + i) for i in range(3)]
+    batch = np.stack(clips)[:, None, :]
+    gb = c.encode(np.ascontiguousarray(batch))
+    assert gb.shape[0] == 3 and gb.shape[1] == 8
+    for i, cl in enumerate(clips):
+        one = c.encode(cl[None, None])
+        assert np.array_equal(gb[i], one[0]), i
+        nbad, tot = _check_codes(gb[i:i + 1], otiny, cl)
+        assert nbad <= max(1, tot // 200)
+    lens = [512 * 37 + 11, 768 * 3, 9000]
+    rag = c.encode(np.ascontiguousarray(batch), lengths=lens)
+    for i, n in enumerate(lens):
+        assert np.array_equal(rag[i], c.encode(np.ascontiguousarray(clips[i][None, None, :n]))[0]), i
+    with pytest.raises(ValueError, match="lengths"):
+        c.encode(np.ascontiguousarray(batch), lengths=[1, 2])
     # decode accepts what encode produces (same handle)
     pcm = c.decode(np.ascontiguousarray(got))
     assert pcm.shape == (1, 1, 2048 * got.shape[2]) and np.isfinite(pcm).all()

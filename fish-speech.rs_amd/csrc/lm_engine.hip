@@ -1704,7 +1704,7 @@ class LM final : public LMBase {
         return A;
     }
     // the persistent fast decoder takes the slow-token decision in its prologue (no k_sample_slow node) whenever it runs
-    bool fold_slow_sampler() const { return use_persist_ && !legacy_ && n_audio_ <= 2048; }
+    bool fold_slow_sampler() const { return use_persist_ && n_audio_ <= 2048; }  // (Fish <= 1.4 too: the 2-way {pad, im_end} draw is taken in-launch)
     FastPersistArgs persist_args() {
         FastPersistArgs A = {};
         A.wpack = d_pack_.p;

@@ -187,10 +187,12 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
         rope_c[i] = A.cos_t[i];
         rope_s[i] = A.sin_t[i];
     }
-    const unsigned long long consumed0 = SAMPLED ? A.rng->consumed : 0ull;  // (a per-frame input: read before the first publish)
+    const unsigned long long consumed0 = (SAMPLED || cfg.legacy) ? A.rng->consumed : 0ull;  // (a per-frame input: read before the first publish)
     // this frame's StdRng words (slow draw + 8 codebook draws): ~2.4 us of dependent integer work, nine lanes of the last wave
     if (SAMPLED && tid >= PF_THREADS - 64 && tid < PF_THREADS - 64 + 9)
         s_words[tid - (PF_THREADS - 64)] = chacha12_word(A.rng->key, consumed0 + (unsigned)(tid - (PF_THREADS - 64)));
+    // Fish <= 1.4: the slow token is a 2-way {pad, im_end} draw whatever the temperature (sampling/mod.rs:8-26): the greedy kernel needs that one word
+    if (!SAMPLED && cfg.legacy && A.slow_logits && tid == PF_THREADS - 64) s_words[0] = chacha12_word(A.rng->key, A.rng->consumed);
     __syncthreads();
     uint32_t cur0 = s_misc[0];
     const bool have_prev = s_misc[1] != 0;
@@ -204,7 +206,28 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
     // logits over [im_end, V) (constrain_probs_to_audio, utils.rs:13-16) -> sample -> token = index + im_end (rescale_semantic_tokens,
     // utils.rs:45-46), single_batch.rs:102-144.  Every workgroup decides redundantly on the same logits (and the same StdRng word), so
     // the token -- needed for the <|im_end|> test here and for the next input's embedding at the end -- needs no edge.
-    if (A.slow_logits) {
+    if (A.slow_logits && cfg.legacy) {
+        // legacy_softmax_sample (sampling/mod.rs:8-26; single_batch.rs:104-124): P(pad) = softmax([pad, eos])[0]; u ~ U[0,1) = (next_u32 >> 8) * 2^-24
+        // (rand Standard<f32>), temperature ignored.  The reference draws from an unseeded thread_rng; the draw comes from the request's seeded
+        // StdRng stream here (k_sample_slow does the same on the per-node path).  Every workgroup decides redundantly on the same two logits
+        // and the same word.
+        const float pad = A.slow_logits[0], eosl = A.slow_logits[1], m = fmaxf(pad, eosl);
+        const float e_pad = expf(pad - m), e_eos = expf(eosl - m);
+        const float p_pad = e_pad / (e_pad + e_eos);
+        const float u = (float)(s_words[0] >> 8) * (1.0f / 16777216.0f);
+        const bool is_pad = u < p_pad || cfg.ignore_eos;
+        n_draws += 1;
+        if (b == 0) {
+            float* hid = A.hid_slot ? *A.hid_slot : nullptr;
+            if (hid) *reinterpret_cast<float2*>(hid + (size_t)A.state->frame * 1024 + 2 * tid) = *reinterpret_cast<const float2*>(A.xf + 2 * tid);
+            if (A.cap && A.state->frame < A.cap_frames && tid == 0) {  // (fs_lm_debug_capture: the two logits, the uniform draw, the pick)
+                float* cap = A.cap + (size_t)A.state->frame * 9 * 2048;
+                cap[0] = pad; cap[1] = eosl; cap[2] = u; cap[2047] = is_pad ? 0.f : 1.f;
+            }
+        }
+        cur0 = is_pad ? cfg.pad_id : cfg.im_end_id;
+        if (cur0 == cfg.im_end_id) done_in = 1;
+    } else if (A.slow_logits) {
         const int n = A.n_slow;
         float lv[4];
 #pragma unroll
@@ -677,7 +700,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
         st->have_prev = 1;
         st->pos += 1;
         st->frame = frame + 1;
-        if (SAMPLED) A.rng->consumed = consumed0 + (unsigned long long)n_draws;
+        if (SAMPLED || (cfg.legacy && A.slow_logits)) A.rng->consumed = consumed0 + (unsigned long long)n_draws;
         A.ctl[0] = epoch + 1;
     }
     // next slow input: embed([slow, c0..c7]) (dual_ar.rs:532-567): token row first, then the codebook rows in order

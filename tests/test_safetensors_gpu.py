@@ -137,9 +137,9 @@ def test_malformed_checkpoints_are_errors_not_crashes(tmp_path):
     fishrt.DualARTransformer(cfg, tok, 0, "f32").load_safetensors(path).close()
 
 
-def test_codec_checkpoint_equals_synthetic(tmp_path):
+def _codec_tensors(C=64, seed=1234):
+    """the tiny codec's tensors by the reference's names (channel_div 8), from the oracle's synthetic generator"""
     import math
-    C, seed = 64, 1234
     t = {}
 
     def put(name, shape, mean, std):
@@ -195,6 +195,12 @@ def test_codec_checkpoint_equals_synthetic(tmp_path):
     for g in range(8):
         put(f"quantizer.residual_fsq.rvqs.{g}.project_in.weight", (4, C // 8), 0.0, 1 / math.sqrt(C // 8))
         put(f"quantizer.residual_fsq.rvqs.{g}.project_in.bias", (4,), 0.0, 0.02)
+    return t
+
+
+def test_codec_checkpoint_equals_synthetic(tmp_path):
+    seed = 1234
+    t = _codec_tensors(64, seed)
     path = str(tmp_path / "firefly.safetensors")
     _save(t, path, False)
     a = fishrt.FireflyCodec(0, channel_div=8).load_safetensors(path)

@@ -134,6 +134,10 @@ int fs_lm_generate_multi(fs_lm_t* lm, const uint32_t* prompts, const int* lens, 
     FS_TRY(lm->impl->generate_multi(prompts, lens, n, max_new_tokens, samplings, seeds, flags, codes_out, cap, n_frames))
 }
 int fs_lm_debug_read_row(fs_lm_t* lm, int row, float* out, int n_frames) { FS_ARG(lm && out, "null argument"); FS_TRY(lm->impl->debug_read_row(row, out, n_frames)) }
+int fs_lm_debug_read_kv(fs_lm_t* lm, int slot, int layer, int t0, int n, float* k_out, float* v_out) {
+    FS_ARG(lm && k_out && v_out, "null argument");
+    FS_TRY(lm->impl->debug_read_kv(slot, layer, t0, n, k_out, v_out))
+}
 int fs_lm_weights_arena(fs_lm_t* lm, void** dev_ptr, size_t* bytes) {
     FS_ARG(lm && dev_ptr && bytes, "null argument");
     FS_TRY(lm->impl->weights_arena(dev_ptr, bytes))

@@ -297,6 +297,33 @@ class LM final : public LMBase {
         FS_HIP(hipStreamSynchronize(st_));
         FS_HIP(hipMemcpy(out, d_cap_.p, sizeof(float) * (size_t)n_frames * 9 * 2048, hipMemcpyDeviceToHost));
     }
+    // test hook (fs_lm_debug_read_kv): the cached K / V rows [t0, t0 + n) of slow layer `layer` of KV slot `slot`, as f32 [n][Hkv][Dh]
+    void debug_read_kv(int slot, int layer, int t0, int n, float* k_out, float* v_out) override {
+        use_device();
+        FS_REQUIRE(slot >= 0 && slot < B_ && layer >= 0 && layer < a_.n_layer, "bad KV slot / layer");
+        FS_REQUIRE(t0 >= 0 && n >= 0 && t0 + n <= (int)seq_pages_[slot].size() * KV_PAGE, "rows outside the slot's KV pages");
+        FS_HIP(hipStreamSynchronize(st_));
+        const int Hk = a_.n_local_heads, Dh = a_.head_dim;
+        std::vector<KT> pk(page_elems_), pv(page_elems_);
+        const KT* kpool = kv_pool_.as<KT>() + (size_t)layer * 2 * n_pages_ * page_elems_;
+        const KT* vpool = kpool + (size_t)n_pages_ * page_elems_;
+        int have = -1;
+        for (int t = t0; t < t0 + n; ++t) {
+            const int pg = seq_pages_[slot][t >> 6];
+            if (pg != have) {
+                FS_HIP(hipMemcpy(pk.data(), kpool + (size_t)pg * page_elems_, sizeof(KT) * page_elems_, hipMemcpyDeviceToHost));
+                FS_HIP(hipMemcpy(pv.data(), vpool + (size_t)pg * page_elems_, sizeof(KT) * page_elems_, hipMemcpyDeviceToHost));
+                have = pg;
+            }
+            for (int g = 0; g < Hk; ++g)
+                for (int d = 0; d < Dh; ++d) {
+                    const size_t src = ((size_t)g * KV_PAGE + (t & 63)) * Dh + d, dst = ((size_t)(t - t0) * Hk + g) * Dh + d;
+                    k_out[dst] = kv_f32(pk[src]); v_out[dst] = kv_f32(pv[src]);
+                }
+        }
+    }
+    static float kv_f32(float v) { return v; }
+    static float kv_f32(bf16_t v) { return bf16_to_f32_host(v); }
     void debug_read_row(int row, float* out, int n_frames) override {
         use_device();
         FS_REQUIRE(row >= 0 && row < PR_MAX_ROWS && d_rcap_.p, "no request-row capture (fs_lm_debug_capture, then fs_lm_generate_multi)");

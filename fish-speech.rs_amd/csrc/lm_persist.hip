@@ -396,6 +396,11 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
                         vc[(l * 8 + cb) * 64 + tid - 64] = f32_to_bf16_rne(__uint_as_float(vk.x)) | (f32_to_bf16_rne(__uint_as_float(vk.z)) << 16);
                     }
                     __syncthreads();
+                    // fs_lm_debug_capture: the K / V rows this pass appended (raw bf16 pairs: K [64], V [64] per layer) behind the pass's logits,
+                    // so that a test can make the oracle attend over exactly these rows (tests/test_kv_forced_gpu.py)
+                    if (A.cap && b == 0 && A.slow_logits && tid < 128 && A.state->frame < A.cap_frames)
+                        reinterpret_cast<uint32_t*>(A.cap + ((size_t)A.state->frame * 9 + 1 + cb) * 2048 + 1025)[l * 128 + tid] =
+                            tid < 64 ? kc[(l * 8 + cb) * 64 + tid] : vc[(l * 8 + cb) * 64 + tid - 64];
                     const int h = tid >> 5, g = h >> 3, p = (tid >> 2) & 7, qd = tid & 3;
                     {
                         const float scale = 0.125f;  // 1 / sqrt(64), applied to K (dual_ar.rs:260)

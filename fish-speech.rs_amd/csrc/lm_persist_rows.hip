@@ -970,6 +970,13 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                         }
                     }
                     __syncthreads();
+                    if (A.cap && b == 0 && tid < 128) {  // fs_lm_debug_capture: this pass's K / V rows behind its logits (see k_fast_persist)
+#pragma unroll 1
+                        for (int r = 0; r < R; ++r)
+                            if (((run >> r) & 1u) && A.state[r].frame < A.cap_frames)
+                                reinterpret_cast<uint32_t*>(A.cap + (((size_t)r * A.cap_frames + A.state[r].frame) * 9 + 1 + cb) * 2048 + 1025)[l * 128 + tid] =
+                                    tid < 64 ? kc[((r * PF_LAYERS + l) * 8 + cb) * 64 + tid] : vc[((r * PF_LAYERS + l) * 8 + cb) * 64 + tid - 64];
+                    }
                     const int h = tid >> 5, g = h >> 3, p = (tid >> 2) & 7, qd = tid & 3, j = tid & 31;
                     // rows in a REAL loop, two per iteration: unrolled over all rows the scheduler issues every row's LDS reads up front (~24 registers
                     // per row), one at a time each row is a ~1 us chain of dependent LDS / transcendental / cross-lane latencies

@@ -203,6 +203,14 @@ class DualARTransformer:
         _ffi.check(_ffi.lib().fs_lm_debug_read(self._h, out.ctypes.data_as(C.POINTER(C.c_float)), int(n_frames)))
         return out
 
+    def debug_read_kv(self, layer, t0, n, slot=0):
+        """test hook: cached K / V rows [t0, t0 + n) of one slow layer as f32 (n, n_local_heads, head_dim) each"""
+        sh = (int(n), self.cfg["n_local_heads"], self.cfg["head_dim"])
+        k, v = np.zeros(sh, np.float32), np.zeros(sh, np.float32)
+        _ffi.check(_ffi.lib().fs_lm_debug_read_kv(self._h, int(slot), int(layer), int(t0), int(n), k.ctypes.data_as(C.POINTER(C.c_float)),
+                                                  v.ctypes.data_as(C.POINTER(C.c_float))))
+        return k, v
+
     def debug_read_row(self, row, n_frames):
         """the capture of request `row` of the last generate_multi call"""
         out = np.zeros((int(n_frames), 9, 2048), np.float32)

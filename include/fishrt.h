@@ -95,6 +95,9 @@ int fs_selftest_sample_rows(int device_id, const float* logits, int B, int n, co
  * The parity tests replay these rows through the CPU sampler: same logits, same StdRng stream => same picks, token for token. */
 int fs_lm_debug_capture(fs_lm_t* lm, int n_frames);
 int fs_lm_debug_read(fs_lm_t* lm, float* out, int n_frames);
+/* test hook: the cached K / V rows [t0, t0 + n) of slow layer `layer` of KV slot `slot` (0 for batch-1 calls) as f32 [n][n_local_heads][head_dim]
+ * -- the parity tests hand the GPU's own cache entries to the CPU oracle (tests/test_kv_forced_gpu.py) */
+int fs_lm_debug_read_kv(fs_lm_t* lm, int slot, int layer, int t0, int n, float* k_out, float* v_out);
 /* the same record of request `row` of the last fs_lm_generate_multi call (every request row is captured) */
 int fs_lm_debug_read_row(fs_lm_t* lm, int row, float* out, int n_frames);
 

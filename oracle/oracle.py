@@ -65,6 +65,7 @@ def lib():
         L.orc_lm_fast_embeddings.restype = C.POINTER(C.c_float)
         L.orc_lm_freqs.restype = C.POINTER(C.c_float)
         L.orc_lm_tensor.restype = C.POINTER(C.c_float)
+        L.orc_lm_force_kv_diff.restype = C.c_float
         L.orc_reppen_create.restype = C.c_void_p
         L.orc_sampler_create.restype = C.c_void_p
         L.orc_sampler_sample.restype = C.c_uint32
@@ -158,6 +159,23 @@ class OracleLM:
 
     def kv_len(self):
         return lib().orc_lm_kv_len(self.h)
+
+    def force_kv(self, layer, k, v):
+        """test hook: the NEXT single-token step of `layer` (1000 + l: fast layer l) uses these K / V rows (Hkv, D) instead of its own;
+        force_kv_diff(layer) afterwards = how far its own rows were from them, in bf16 ulps"""
+        k = np.ascontiguousarray(k, np.float32).reshape(-1); v = np.ascontiguousarray(v, np.float32).reshape(-1)
+        if lib().orc_lm_force_kv(self.h, int(layer), _p(k, C.c_float), _p(v, C.c_float)) != 0:
+            raise RuntimeError("orc_lm_force_kv: bad layer")
+
+    def force_kv_diff(self, layer):
+        return float(lib().orc_lm_force_kv_diff(self.h, int(layer)))
+
+    def set_kv(self, layer, t0, k, v):
+        """test hook: overwrite cached K / V rows [t0, t0 + n) of slow layer `layer` (batch 1; 1000 + l: fast decoder layer l); k, v: f32 (n, Hkv, D)"""
+        k = np.ascontiguousarray(k, np.float32); v = np.ascontiguousarray(v, np.float32)
+        assert k.shape == v.shape and k.ndim == 3
+        if lib().orc_lm_set_kv(self.h, int(layer), int(t0), int(k.shape[0]), _p(k, C.c_float), _p(v, C.c_float)) != 0:
+            raise RuntimeError("orc_lm_set_kv: rows outside the cache")
 
     def fast_embeddings(self):
         n = self.cfg["codebook_size"] * self.cfg["dim"]

@@ -73,8 +73,44 @@ void orc_lm_clear_fast(void* p) { ((LM*)p)->clear_fast(); }
 void orc_lm_clear_slow(void* p) { ((LM*)p)->clear_slow(); }
 void orc_lm_clear_slow_until(void* p, int pos) { ((LM*)p)->clear_slow_until(pos); }
 int orc_lm_kv_len(void* p) { return ((LM*)p)->kv_len(); }
+// test hook: overwrite cached K / V rows [t0, t0 + n) of one slow layer (batch 1) with values computed elsewhere -- the parity tests feed the
+// oracle the GPU's own (bf16) cache entries so that K/V rounding-boundary flips stop compounding through the layers and only the
+// summation order of the CURRENT step separates the two (tests/test_kv_forced_gpu.py).  k, v: [n][Hkv][D]
+int orc_lm_set_kv(void* p, int layer, int t0, int n, const float* k, const float* v) {
+    LM* lm = (LM*)p;
+    const bool fast = layer >= 1000;  // layer 1000 + l: fast decoder layer l (its per-frame cache, dual_ar.rs:638-673)
+    if (fast) layer -= 1000;
+    if (layer < 0 || layer >= (int)(fast ? lm->fast_layers.size() : lm->layers.size())) return 1;
+    Block& b = fast ? lm->fast_layers[layer] : lm->layers[layer];
+    const int Hk = lm->a.n_local_heads, D = lm->a.head_dim, T = b.kv_len;
+    if (b.kv_b != 1 || t0 < 0 || n < 0 || t0 + n > T) return 1;
+    for (int t = 0; t < n; ++t)
+        for (int g = 0; g < Hk; ++g)
+            for (int d = 0; d < D; ++d) {
+                b.k[((size_t)g * T + t0 + t) * D + d] = k[((size_t)t * Hk + g) * D + d];
+                b.v[((size_t)g * T + t0 + t) * D + d] = v[((size_t)t * Hk + g) * D + d];
+            }
+    return 0;
+}
 const float* orc_lm_fast_embeddings(void* p) { return ((LM*)p)->fast_embeddings.data(); }
 const float* orc_lm_freqs(void* p, int sin) { return sin ? ((LM*)p)->sin_t.data() : ((LM*)p)->cos_t.data(); }
+// test hook: the next batch-1 single-token step of this layer (1000 + l: fast layer l) uses these K / V rows [Hkv][D] instead of its own
+int orc_lm_force_kv(void* p, int layer, const float* k, const float* v) {
+    LM* lm = (LM*)p;
+    const bool fast = layer >= 1000;
+    if (fast) layer -= 1000;
+    if (layer < 0 || layer >= (int)(fast ? lm->fast_layers.size() : lm->layers.size())) return 1;
+    Block& b = fast ? lm->fast_layers[layer] : lm->layers[layer];
+    const size_t n = (size_t)lm->a.n_local_heads * lm->a.head_dim;
+    b.force_k.assign(k, k + n); b.force_v.assign(v, v + n);
+    return 0;
+}
+float orc_lm_force_kv_diff(void* p, int layer) {
+    LM* lm = (LM*)p;
+    const bool fast = layer >= 1000;
+    if (fast) layer -= 1000;
+    return (fast ? lm->fast_layers.at(layer) : lm->layers.at(layer)).force_diff;
+}
 // tensor access for cross-checks
 const float* orc_lm_tensor(void* p, const char* name, int layer) {
     LM* lm = (LM*)p;

@@ -210,6 +210,20 @@ void LM::block_forward(Block& blk, float* x, int B, int L, int input_pos, int /*
         for (auto& f : kn) f = fsgen::round_bf16(f);
         for (auto& f : vn) f = fsgen::round_bf16(f);
     }
+    if (!blk.force_k.empty()) {  // test hook: see Block::force_k
+        if (B != 1 || L != 1 || blk.force_k.size() != kn.size()) throw std::runtime_error("orc_lm_force_kv: needs a batch-1 single-token step");
+        float worst = 0.f;
+        for (size_t i = 0; i < kn.size(); ++i) {
+            // bf16 ulp (8 significant bits) of the forced value, floored at 2^-17: below |x| ~ 1e-3 the f32 summation-order noise of the
+            // projection (~1e-6 absolute) is worth several ulps of the tiny value without being a rounding-boundary flip of anything that matters
+            const float uk = std::ldexp(1.f, std::max(std::ilogb(std::max(std::fabs(blk.force_k[i]), 1e-30f)) - 7, -17));
+            const float uv = std::ldexp(1.f, std::max(std::ilogb(std::max(std::fabs(blk.force_v[i]), 1e-30f)) - 7, -17));
+            worst = std::max(worst, std::max(std::fabs(kn[i] - blk.force_k[i]) / uk, std::fabs(vn[i] - blk.force_v[i]) / uv));
+        }
+        blk.force_diff = worst;
+        kn = blk.force_k; vn = blk.force_v;
+        blk.force_k.clear(); blk.force_v.clear();
+    }
     // Tensor::cat(&[prev, new], 2): full re-copy every call (:316-324)
     const int Tp = blk.kv_len, T = Tp + L;
     if (Tp > 0 && blk.kv_b != B) throw std::runtime_error("KV cache batch mismatch");

@@ -41,6 +41,10 @@ struct Block {
     // growing KV cache (dual_ar.rs:204,316-324), layout (B, Hkv, T, D)
     std::vector<float> k, v;
     int kv_len = 0, kv_b = 0;
+    // test hook (orc_lm_force_kv): one-shot replacement of the NEXT single-token step's own K / V row by rows computed elsewhere (the GPU
+    // kernel's bf16 entries); force_diff = largest |own - forced| of that step in units of the forced value's bf16 ulp
+    std::vector<float> force_k, force_v;
+    float force_diff = 0.f;
 };
 
 // fish_speech_core/lib/lm/sampling/rep_pen.rs:4-72 (SingleBatchedRepPenProcessor)

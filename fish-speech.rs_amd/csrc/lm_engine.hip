@@ -290,6 +290,9 @@ class LM final : public LMBase {
         for (auto& kv : graphs_) { (void)hipGraphExecDestroy(kv.second.first); (void)hipGraphExecDestroy(kv.second.second); }
         graphs_.clear();  // the captured launches carry the buffer pointer
         g_frame_ = g_step_ = nullptr;
+        for (auto& kv : batch_graphs_) if (kv.second) (void)hipGraphExecDestroy(kv.second);
+        batch_graphs_.clear();  // (the row-path step graphs include the capture kernels only while the hook is armed)
+        if (!n_frames) d_rcap_ = DevBuf();
     }
     void debug_read(float* out, int n_frames) override {
         use_device();
@@ -326,7 +329,7 @@ class LM final : public LMBase {
     static float kv_f32(bf16_t v) { return bf16_to_f32_host(v); }
     void debug_read_row(int row, float* out, int n_frames) override {
         use_device();
-        FS_REQUIRE(row >= 0 && row < PR_MAX_ROWS && d_rcap_.p, "no request-row capture (fs_lm_debug_capture, then fs_lm_generate_multi)");
+        FS_REQUIRE(row >= 0 && d_rcap_.p, "no row capture (fs_lm_debug_capture, then fs_lm_generate_multi / fs_lm_generate_batch / a session)");
         FS_REQUIRE(n_frames >= 0 && n_frames <= cap_frames_, "more frames than were captured");
         FS_REQUIRE(sizeof(float) * ((size_t)row + 1) * cap_frames_ * 9 * 2048 <= d_rcap_.n, "row beyond the captured rows");
         FS_HIP(hipStreamSynchronize(st_));
@@ -638,6 +641,7 @@ class LM final : public LMBase {
         clear_fast();
         ensure_prefill_buffers();
         ensure_batch_buffers();
+        ensure_rows_capture(B);
         SampleCfg cfg = base_cfg();
         cfg.temp = (float)s.temp; cfg.top_p = (float)s.top_p; cfg.top_p64 = s.top_p;
         cfg.top_k = (int)std::min<uint64_t>(s.top_k, 1u << 30);
@@ -770,6 +774,7 @@ class LM final : public LMBase {
         clear_fast();
         ensure_prefill_buffers();
         ensure_batch_buffers();
+        ensure_rows_capture(B_);
         SampleCfg cfg = base_cfg();
         cfg.temp = (float)s.temp; cfg.top_p = (float)s.top_p; cfg.top_p64 = s.top_p;
         cfg.top_k = (int)std::min<uint64_t>(s.top_k, 1u << 30);
@@ -1603,6 +1608,8 @@ class LM final : public LMBase {
         // block-parallel samplers (temp > 1e-7, top_k <= 256): the step's C + 1 StdRng words per row are derived up front
         const uint32_t* words = rows_par_ ? d_rwords_.as<uint32_t>() : nullptr;
         if (rows_par_) SampleKernels<WT>::rows_rng_words(d_rng_.as<RngState>(), B, C + 1, state(0), d_rwords_.as<uint32_t>(), st_);
+        const bool capt = cap_frames_ > 0 && d_rcap_.p && d_rcap_.n >= sizeof(float) * (size_t)B * cap_frames_ * 9 * 2048;  // (fs_lm_debug_capture)
+        if (capt) launch_cap_rows_logits(d_lrows_.as<float>(), ld_slow_, n_audio_, state(0), d_cfg_.as<SampleCfg>(), B, d_rcap_.as<float>(), cap_frames_, 0, st_);
         SampleKernels<WT>::sample_slow_rows(d_, d_lrows_.as<float>(), ld_slow_, n_audio_, d_cfg_.as<SampleCfg>(), d_rng_.as<RngState>(), B,
                                             C + 1, state(0), cs.X, d_xfrows_.as<float>(), st_, words);
         for (int cbi = 0; cbi < C; ++cbi) {
@@ -1621,10 +1628,20 @@ class LM final : public LMBase {
             }
             LmKernels<WT>::rows_finish(d_, B, cf, fast_norm_w_, st_);
             LmKernels<WT>::rows_head(d_, B, cf, fast_out_w_, kFp8 ? fast_out_s_ : nullptr, a_.codebook_size, d_lfast_.as<float>(), a_.codebook_size, st_);
+            if (capt) launch_cap_rows_logits(d_lfast_.as<float>(), a_.codebook_size, a_.codebook_size, state(0), d_cfg_.as<SampleCfg>(), B, d_rcap_.as<float>(),
+                                             cap_frames_, 1 + cbi, st_);
             SampleKernels<WT>::sample_fast_rows(d_, d_lfast_.as<float>(), cbi, C, a_.codebook_size, d_cfg_.as<SampleCfg>(),
                                                 d_rng_.as<RngState>(), B, state(0), fast_emb_, d_xfrows_.as<float>(), tok_emb_, cb_emb_,
                                                 cs.X, d_out_.as<uint32_t>(), out_cap_, st_, words);
         }
+        if (capt) launch_cap_rows_picks(state(0), d_cfg_.as<SampleCfg>(), B, d_rcap_.as<float>(), cap_frames_, C, st_);
+    }
+    // the capture record of a row-path call: [B][cap_frames][9][2048] (allocated when fs_lm_debug_capture is armed)
+    void ensure_rows_capture(int B) {
+        if (!cap_frames_) return;
+        FS_REQUIRE((size_t)B * cap_frames_ <= 4096, "decision capture on the row path: rows x frames limited to 4096 (302 MB)");
+        d_rcap_.alloc(sizeof(float) * (size_t)B * cap_frames_ * 9 * 2048);
+        FS_HIP(hipMemsetAsync(d_rcap_.p, 0, d_rcap_.n, st_));
     }
     hipGraphExec_t batch_graph(int B) {
         const int key = (sess_active_ ? 1 << 24 : 0) + (rows_par_ ? 1 << 25 : 0) + B * 1024 + nc_launch_;

@@ -212,7 +212,11 @@ bool rows_par_sampler_ok(double temp, uint64_t top_k, int n_slow, int cb_size);
 template <typename WT>
 void launch_gather_rows(const void* src, int dim, uint32_t r0, uint32_t r1, void* dst, hipStream_t st);
 void launch_advance(SeqState* state, hipStream_t st);  // pos++, step++ (sequential prefill step)
-void launch_advance_n(SeqState* state, int n, hipStream_t st);  // pos += n, step += n (chunked prefill)
+void launch_advance_n(SeqState* state, int n, hipStream_t st);
+// decision capture on the row path (static batch / sessions): cap[row][cap_frames][9][2048]
+void launch_cap_rows_logits(const float* logits, int ld, int n, const SeqState* states, const SampleCfg* cfg, int B, float* cap, int cap_frames, int decision,
+                            hipStream_t st);
+void launch_cap_rows_picks(const SeqState* states, const SampleCfg* cfg, int B, float* cap, int cap_frames, int n_cb, hipStream_t st);  // pos += n, step += n (chunked prefill)
 void launch_reppen_reset(RepPenState rp, int n_cb, int cb_size, hipStream_t st);
 
 // synthetic tensor fill (fs_synth.h): n_rows x n_cols, destination row = r * row_mul + row_off (W1/W3 interleave)

@@ -3201,6 +3201,36 @@ void LmKernels<WT>::rows_head(const ModelDims& d, int M, const RowsCtx& c, const
     }
 }
 
+// ---- decision capture on the row path (fs_lm_debug_capture for generate_static_batch / sessions): what every row's decision saw and picked,
+// in the layout of the request-row kernels' record: cap[row][cap_frames][9][2048], logits at [0, n), the pick at [2047] (slow) / [1024] (fast)
+__global__ __launch_bounds__(256) void k_cap_rows_logits(const float* __restrict__ logits, int ld, int n, const SeqState* __restrict__ states,
+                                                         const SampleCfg* __restrict__ cp, float* __restrict__ cap, int cap_frames, int decision) {
+    const int b = blockIdx.x, frame = states[b].frame;
+    if (frame >= cap_frames) return;
+    float* dst = cap + (((size_t)b * cap_frames + frame) * 9 + decision) * 2048;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        float v = logits[(size_t)b * ld + i];
+        if (decision == 0 && i == 0 && cp->ignore_eos) v = -INFINITY;  // (what the slow samplers do to <|im_end|> before they select)
+        dst[i] = v;
+    }
+}
+__global__ __launch_bounds__(64) void k_cap_rows_picks(const SeqState* __restrict__ states, const SampleCfg* __restrict__ cp, float* __restrict__ cap,
+                                                       int cap_frames, int n_cb) {
+    const int b = blockIdx.x, frame = states[b].frame - 1, t = threadIdx.x;  // (the last sampler of the frame advanced the counter)
+    if (frame < 0 || frame >= cap_frames || t > n_cb) return;
+    float* dst = cap + (((size_t)b * cap_frames + frame) * 9 + t) * 2048;
+    const uint32_t v = states[b].cur[t];
+    if (t == 0) dst[2047] = v == cp->im_end_id ? 0.f : (float)(v - cp->audio_base);
+    else dst[1024] = (float)v;
+}
+void launch_cap_rows_logits(const float* logits, int ld, int n, const SeqState* states, const SampleCfg* cfg, int B, float* cap, int cap_frames, int decision,
+                            hipStream_t st) {
+    hipLaunchKernelGGL(k_cap_rows_logits, dim3(B), dim3(256), 0, st, logits, ld, n, states, cfg, cap, cap_frames, decision);
+}
+void launch_cap_rows_picks(const SeqState* states, const SampleCfg* cfg, int B, float* cap, int cap_frames, int n_cb, hipStream_t st) {
+    hipLaunchKernelGGL(k_cap_rows_picks, dim3(B), dim3(64), 0, st, states, cfg, cap, cap_frames, n_cb);
+}
+
 void launch_advance_n(SeqState* state, int n, hipStream_t st) {
     hipLaunchKernelGGL(k_advance_n, dim3(1), dim3(1), 0, st, state, n);
     FS_LAUNCH_CHECK();

@@ -31,14 +31,20 @@ def _orc_rows(logits, temp, top_p, top_k, seed, call):
     return out.astype(np.int64)
 
 
-def _replay_sampler(caps, outs, F, kw, seed):
+def replay_batch_decisions(lm, B, F, kw, seed, outs, n_audio=N_AUDIO, cb_size=1024):
+    """for other test modules: read the row-path capture of the last generate_static_batch call (debug_capture(F) armed before it) and
+    check every decision of every row against the oracle batch sampler on the captured logits"""
+    return _replay_sampler([lm.debug_read_row(b, F) for b in range(B)], outs, F, kw, seed, n_audio, cb_size)
+
+
+def _replay_sampler(caps, outs, F, kw, seed, n_audio=N_AUDIO, cb_size=1024):
     """caps: [B][F][9][2048]; every decision of every row == the oracle batch sampler on the captured logits"""
     B = len(caps)
     cap = np.stack(caps)  # (B, F, 9, 2048)
     bad = 0
     for f in range(F):
         for d in range(9):
-            n = N_AUDIO if d == 0 else 1024
+            n = n_audio if d == 0 else cb_size
             exp = _orc_rows(cap[:, f, d, :n], kw["temp"], kw["top_p"], kw["top_k"], seed, f * 9 + d)
             got = cap[:, f, d, 2047 if d == 0 else 1024].astype(np.int64)
             bad += int((exp != got).sum())

@@ -197,7 +197,12 @@ def test_fp8_static_batch_mfma_rows_vs_oracle():
     prompts = [_tiny_prompt(L, seed=20 + i) for i, L in enumerate((5, 11, 8, 3, 7))]
     M = 40
     for sampling in (dict(temp=0.0, top_p=1.0, top_k=0), dict(temp=0.7, top_p=0.8, top_k=32)):
+        lm.debug_capture(M - 11 + 2)
         got = lm.generate_static_batch(prompts, M, seed=42, repetition_penalty=1.3, ignore_eos=True, **sampling)
+        from test_batch_capture_gpu import replay_batch_decisions  # every decision == the oracle batch sampler on the captured logits
+        replay_batch_decisions(lm, 5, M - 11 + 2, sampling, 42, got, n_audio=fcfg.TINY["vocab_size"] - fcfg.TINY_TOKENS["im_end_id"],
+                               cb_size=fcfg.TINY["codebook_size"])
+        lm.debug_capture(0)
         exp = o.generate_batch(prompts, M, seed=42, ignore_eos=True, **sampling)
         assert [g.shape for g in got] == [e.shape for e in exp] == [(8, M - 11 + 2)] * 5
         agree = [int(np.argmin((g == e).all(0))) if not (g == e).all() else g.shape[1] for g, e in zip(got, exp)]
@@ -210,7 +215,7 @@ def test_fp8_static_batch_mfma_rows_vs_oracle():
                     mf = float(min(m[f, b], m[f - 1, b])) if f > 0 else float(m[f, b])  # (the slow token of iteration f - 1 shows in frame f)
                     assert mf < 5e-3, f"fp8 row {b} left the oracle's stream at frame {f} on a margin of {mf:.2e}"
         else:
-            assert min(agree) >= 8, agree
+            assert min(agree) >= 8, agree  # (tripwire; the decision replay above is the check)
     lm.close()
 
 

@@ -318,7 +318,13 @@ def test_static_batch_mfma_rows_vs_oracle(sampling):
     o.set_kv_round_bf16(True)
     prompts = _batch_prompts(5, (5, 11, 8, 3, 7))
     M = 40
+    lm.debug_capture(M - 11 + 2)
     got = lm.generate_static_batch(prompts, M, seed=42, repetition_penalty=1.3, ignore_eos=True, **sampling)
+    # every decision of every row == the oracle batch sampler on the logits the decision saw (fs_lm_debug_capture on the row path): no
+    # near-tie / CDF-boundary excuse -- the comparison is on the GPU's own logits
+    from test_batch_capture_gpu import replay_batch_decisions
+    replay_batch_decisions(lm, 5, M - 11 + 2, sampling, 42, got, n_audio=fcfg.TINY["vocab_size"] - fcfg.TINY_TOKENS["im_end_id"], cb_size=fcfg.TINY["codebook_size"])
+    lm.debug_capture(0)
     exp = o.generate_batch(prompts, M, seed=42, ignore_eos=True, **sampling)
     assert [g.shape for g in got] == [e.shape for e in exp] == [(8, M - 11 + 2)] * 5
     agree = [int(np.argmin((g == e).all(0))) if not (g == e).all() else g.shape[1] for g, e in zip(got, exp)]
@@ -326,7 +332,7 @@ def test_static_batch_mfma_rows_vs_oracle(sampling):
     if sampling["temp"] == 0.0:
         _rows_leave_oracle_only_at_near_ties(got, exp, o, "B=5")
     else:
-        assert min(agree) >= 8, agree  # sampled: a CDF boundary within the bf16 logit noise of a draw moves the stream; a kernel bug shows at frame 0-1
+        assert min(agree) >= 8, agree  # tripwire next to the decision replay above: a CDF boundary within the bf16 logit noise of a draw moves the stream
     # EOS path: rows finish at different frames; dead rows are stepped but not recorded (static_batch.rs:160-173,328-331)
     got = lm.generate_static_batch(prompts, 150, seed=42, **sampling)
     exp = o.generate_batch(prompts, 150, seed=42, **sampling)
@@ -381,11 +387,18 @@ def test_static_batch_more_rows_than_one_mfma_panel():
     assert [g.shape for g in got] == [e.shape for e in exp]
     flips = _rows_leave_oracle_only_at_near_ties(got, exp, o, "B=40")
     print(f"B=40: {40 - flips}/40 rows identical to the oracle over {got[0].shape[1]} frames, {flips} left it at a near-tie")
-    # sampled: per-row child RNG streams are indexed by (call, row) with B = 40
+    # sampled: per-row child RNG streams are indexed by (call, row) with B = 40 -- every decision of the 40 rows replayed through the oracle
+    # batch sampler on the captured logits
+    Fr = got[0].shape[1]
+    lm.debug_capture(Fr)
     got = lm.generate_static_batch(prompts, M, seed=42, temp=0.7, top_p=0.8, top_k=32, ignore_eos=True)
+    from test_batch_capture_gpu import replay_batch_decisions
+    replay_batch_decisions(lm, 40, Fr, dict(temp=0.7, top_p=0.8, top_k=32), 42, got, n_audio=fcfg.TINY["vocab_size"] - fcfg.TINY_TOKENS["im_end_id"],
+                           cb_size=fcfg.TINY["codebook_size"])
+    lm.debug_capture(0)
     exp = o.generate_batch(prompts, M, seed=42, temp=0.7, top_p=0.8, top_k=32, ignore_eos=True)
     agree = [int(np.argmin((g == e).all(0))) if not (g == e).all() else g.shape[1] for g, e in zip(got, exp)]
-    assert min(agree) >= 4 and np.mean(agree) >= 8, agree
+    assert min(agree) >= 4 and np.mean(agree) >= 8, agree  # (tripwire; the replay above is the check)
     lm.close()
 
 

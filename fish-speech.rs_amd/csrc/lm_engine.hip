@@ -453,9 +453,29 @@ class LM final : public LMBase {
         // frame `it` runs at KV length T = n_cached + L + it: pick the graph captured for that attention chunk bucket
         // FS_GEN_TIME_KERNELS: the frame's two persistent launches one by one, a HIP event in front of / between / behind them
         const bool time_k = (flags & FS_GEN_TIME_KERNELS) && use_persist_ && use_pslow_ && fold_slow_sampler();
+        bool b1_rows_fast = false;
+        if constexpr (std::is_same<WT, bf16_t>::value) {
+            if (getenv("FISHRT_B1_ROWS_FAST") && use_persist_ && use_pslow_ && fold_slow_sampler() && !legacy_) {
+                ensure_rows(2);
+                b1_rows_fast = true;
+                const int big = 1 << 30;
+                FS_HIP(hipMemcpyAsync(d_rcfg_.p, &cfg, sizeof(cfg), hipMemcpyHostToDevice, st_));
+                FS_HIP(hipMemcpyAsync(d_rbudget_.p, &big, sizeof(int), hipMemcpyHostToDevice, st_));
+                FS_HIP(hipMemcpyAsync(d_rrng_.p, &rng, sizeof(rng), hipMemcpyHostToDevice, st_));
+                launch_reppen_reset(rows_rp(0), C, a_.codebook_size, st_);
+            }
+        }
         std::vector<hipEvent_t> kev;
         auto launch_frame = [&](long long it_) {
             set_bucket(n_cached + L + (int)it_);
+            if (b1_rows_fast) {  // experiment hook (FISHRT_B1_ROWS_FAST): the fast decoder of this batch-1 request on k_fast_rows<1>
+                launch_slow_persist(pslow_args(), st_);
+                RowsFastArgs F = rows_fast_args(0, 1);
+                F.slow_logits = d_logits_slow_.as<float>();
+                F.cap = nullptr;
+                launch_rows_fast(F, 1, persist_sampled_, st_);
+                return;
+            }
             if (time_k && it_ >= 1) {
                 for (int i = 0; i < 3; ++i) { hipEvent_t e; FS_HIP(hipEventCreate(&e)); kev.push_back(e); }
                 FS_HIP(hipEventRecord(kev[kev.size() - 3], st_));
@@ -774,12 +794,38 @@ class LM final : public LMBase {
         clear_fast();
         ensure_prefill_buffers();
         ensure_batch_buffers();
-        ensure_rows_capture(B_);
+        // FS_SESSION_ROWS: the slots run on the request-row persistent kernels (lm_persist_rows.hip) and keep BATCH-1 semantics -- every slot is
+        // its own generate_blocking (repetition penalty, its own LogitsProcessor stream seeded seed + its admission number) -- instead of the
+        // static-batch sampler's.  Needs max_batch <= 8, a bf16 Fish-1.5 handle and a sampler setting the in-launch decisions cover.
+        sess_rows_ = false;
+        if (flags & FS_SESSION_ROWS) {
+            const int tk = (int)std::min<uint64_t>(s.top_k, 1u << 30);
+            const bool ok = B_ >= 2 && B_ <= PR_MAX_ROWS && pslow_ok_ && persist_ok_ && !kFp8 && !legacy_ && n_audio_ <= 2048 &&
+                            (s.temp == 0.0 || fast_persist_samples((float)s.temp, tk, a_.codebook_size));
+            FS_REQUIRE(ok, "FS_SESSION_ROWS needs a bf16 Fish-1.5 handle with 2 <= max_batch <= 8 and greedy or top_k <= 256 sampling");
+            sess_plock_ = std::unique_lock<std::mutex>(persist_mutex(device_), std::try_to_lock);
+            FS_REQUIRE(sess_plock_.owns_lock(), "another call on this device holds the persistent kernels");
+            sess_R_ = B_ <= 2 ? 2 : (B_ <= 4 ? 4 : 8);
+            FS_REQUIRE(sess_R_ == B_, "FS_SESSION_ROWS needs max_batch 2, 4 or 8 (the row launches cover exactly that many slots; state slot max_batch is the prefill staging state)");
+            ensure_rows(sess_R_);
+            sess_rows_ = true;
+            sess_sampled_ = s.temp != 0.0;
+            sess_seed_ = seed;
+            sess_adds_ = 0;
+        }
+        ensure_rows_capture(sess_rows_ ? sess_R_ : B_);
         SampleCfg cfg = base_cfg();
         cfg.temp = (float)s.temp; cfg.top_p = (float)s.top_p; cfg.top_p64 = s.top_p;
         cfg.top_k = (int)std::min<uint64_t>(s.top_k, 1u << 30);
-        cfg.rep_pen = 1.0f; cfg.ignore_eos = (flags & FS_GEN_IGNORE_EOS) ? 1 : 0;
-        cfg.session = 1;
+        cfg.rep_pen = sess_rows_ ? s.repetition_penalty : 1.0f; cfg.ignore_eos = (flags & FS_GEN_IGNORE_EOS) ? 1 : 0;
+        cfg.session = sess_rows_ ? 0 : 1;
+        if (sess_rows_) {
+            std::vector<SampleCfg> cfgs(sess_R_, cfg);
+            FS_HIP(hipMemcpyAsync(d_rcfg_.p, cfgs.data(), sizeof(SampleCfg) * sess_R_, hipMemcpyHostToDevice, st_));
+            float* nullp = nullptr;
+            FS_HIP(hipMemcpyAsync(d_hid_slot_.p, &nullp, sizeof(nullp), hipMemcpyHostToDevice, st_));
+            FS_HIP(hipStreamSynchronize(st_));  // (cfgs is a local)
+        }
         rows_par_ = rows_par_sampler_ok(s.temp, s.top_k, n_audio_, a_.codebook_size) && !getenv("FISHRT_ROWS_SAMPLER_1024");
         FS_HIP(hipMemcpyAsync(d_cfg_.p, &cfg, sizeof(cfg), hipMemcpyHostToDevice, st_));
         RngState rng = {};
@@ -801,7 +847,7 @@ class LM final : public LMBase {
     }
     void park_slot(int b) {
         SeqState ss = {};
-        ss.done = 1; ss.frame = 1;
+        ss.done = sess_rows_ ? 2 : 1; ss.frame = 1;  // (rows mode: a terminated row is skipped by the row kernels altogether)
         sess_hs_[b] = ss;
         FS_HIP(hipMemcpyAsync(state(b), &sess_hs_[b], sizeof(SeqState), hipMemcpyHostToDevice, st_));
         FS_HIP(hipMemcpyAsync(d_page_table_.as<int>() + (size_t)b * max_pages_, &sess_scratch_, sizeof(int), hipMemcpyHostToDevice, st_));
@@ -835,7 +881,7 @@ class LM final : public LMBase {
         }
         alloc_pages(b, L + (int)n_iter - 1);
         PendingAdd pa;
-        pa.slot = b; pa.L = L; pa.n_iter = (int)n_iter;
+        pa.slot = b; pa.L = L; pa.n_iter = (int)n_iter; pa.order = sess_adds_++;
         pa.prompt.assign(prompt, prompt + (size_t)C1 * L);
         sess_queue_.push_back(std::move(pa));
         sess_left_[b] = -2;  // reserved: prefilling
@@ -950,6 +996,16 @@ class LM final : public LMBase {
             for (int r = 0; r < C1; ++r) ss.cur[r] = pa.prompt[(size_t)r * L + (L - 1)];
             sess_hs_[b] = ss;
             FS_HIP(hipMemcpyAsync(state(b), &sess_hs_[b], sizeof(SeqState), hipMemcpyHostToDevice, st_));
+            if (sess_rows_) {  // the slot becomes a live row: first-frame input, iteration budget, fresh repetition-penalty window and sampler stream
+                LmKernels<WT>::embed(d_, tok_emb_, cb_emb_, a_.num_codebooks, a_.codebook_size, d_cfg_.as<SampleCfg>(), nullptr, state(b), x(b), st_);
+                sess_budget_tmp_ = pa.n_iter;
+                FS_HIP(hipMemcpyAsync(d_rbudget_.as<int>() + b, &sess_budget_tmp_, sizeof(int), hipMemcpyHostToDevice, st_));
+                RngState rng = {};
+                seed_key(sess_seed_ + (uint64_t)pa.order, rng.key);
+                FS_HIP(hipMemcpyAsync(d_rrng_.as<RngState>() + b, &rng, sizeof(rng), hipMemcpyHostToDevice, st_));
+                launch_reppen_reset(rows_rp(b), a_.num_codebooks, a_.codebook_size, st_);
+                FS_HIP(hipStreamSynchronize(st_));  // (rng / budget are locals)
+            } else
             LmKernels<WT>::embed(d_, tok_emb_, cb_emb_, a_.num_codebooks, a_.codebook_size, d_cfg_.as<SampleCfg>(), nullptr, state(b),
                                  d_pfx_.as<float>() + (size_t)b * a_.dim, st_);
             sess_left_[b] = pa.n_iter;
@@ -997,6 +1053,18 @@ class LM final : public LMBase {
                 continue;
             }
             if (!live) break;
+            if (sess_rows_) {
+                use_persist_ = true; use_pslow_ = true; persist_sampled_ = sess_sampled_;
+                for (int i = 0; i < chunk; ++i) {
+                    set_bucket(longest + i + 1);
+                    launch_rows_slow(rows_slow_args(sess_R_), sess_R_, st_);
+                    for (int r0 = 0; r0 < B_; r0 += PR_FAST_ROWS) {
+                        const int left = std::min(PR_FAST_ROWS, sess_R_ - r0), Rf = left >= 4 ? 4 : (left >= 2 ? 2 : 1);
+                        launch_rows_fast(rows_fast_args(r0, Rf), Rf, sess_sampled_, st_);
+                    }
+                }
+                use_persist_ = use_pslow_ = false;
+            } else
             for (int i = 0; i < chunk; ++i) {
                 set_bucket(longest + i + 1);
                 FS_HIP(hipGraphLaunch(batch_graph(B_), st_));
@@ -1005,7 +1073,7 @@ class LM final : public LMBase {
             for (int b = 0; b < B_; ++b)
                 if (sess_left_[b] > 0 && !sess_hs_[b].done) {
                     sess_left_[b] -= chunk; sess_pos_[b] += chunk;
-                    if (sess_left_[b] == 0) {  // iteration budget spent: the slot is finished whatever it sampled
+                    if (sess_left_[b] == 0 && !sess_rows_) {  // iteration budget spent: the slot is finished whatever it sampled (rows mode: the kernels' own budget word terminates the row)
                         // Its last iteration left pos = L + n_iter - 1, one token PAST its page allocation (and == max_seq_len when the
                         // budget was clamped), and a frozen slot still rides the step graphs, whose QKV epilogue writes K/V at pos: park
                         // the write on the scratch page at position 0 (n_out and the codes stay) before the next replay can run.
@@ -1070,6 +1138,15 @@ class LM final : public LMBase {
         FS_HIP(hipStreamSynchronize(st_));
         sess_active_ = false;
         sess_released_frames_ = 0;
+        if (sess_rows_) {
+            uint32_t ctl[4];
+            for (DevBuf* cb : {&d_rctl_s_, &d_rctl_f_}) {
+                FS_HIP(hipMemcpy(ctl, cb->p, sizeof(ctl), hipMemcpyDeviceToHost));
+                if (ctl[1] || ctl[2]) FS_HIP(hipMemset((uint32_t*)cb->p + 1, 0, 8));
+            }
+            sess_rows_ = false;
+            if (sess_plock_.owns_lock()) sess_plock_.unlock();
+        }
     }
 
     void generate_batch_sequential(const uint32_t* prompts, const int* lens, int n, int max_new_tokens, const fs_sampling& s, uint64_t seed,
@@ -1414,7 +1491,7 @@ class LM final : public LMBase {
         // unconditionally and mask them afterwards, which needs finite (not uninitialised) contents
         kv_pool_.alloc((size_t)a_.n_layer * 2 * n_pages_ * page_elems_ * sizeof(KT));
         FS_HIP(hipMemset(kv_pool_.p, 0, kv_pool_.n));
-        d_page_table_.alloc(sizeof(int) * (size_t)(2 * B_ + 1) * max_pages_);  // + the staging rows of a session's joining requests (one group pass)
+        d_page_table_.alloc(sizeof(int) * (size_t)std::max(2 * B_ + 1, PR_MAX_ROWS) * max_pages_);  // + the staging rows of a session's joining requests (one group pass)
         FS_HIP(hipMemset(d_page_table_.p, 0, d_page_table_.n));
         for (int p = n_pages_ - 1; p >= 0; --p) free_pages_.push_back(p);
         seq_pages_.assign(B_, {});
@@ -1426,8 +1503,10 @@ class LM final : public LMBase {
         d_zero_table_.alloc(sizeof(int) * 4);
         FS_HIP(hipMemset(d_zero_table_.p, 0, d_zero_table_.n));
         // activations / state
-        d_x_.alloc(sizeof(float) * (size_t)B_ * a_.dim);
-        d_xf_.alloc(sizeof(float) * (size_t)B_ * a_.dim);
+        // (>= PR_MAX_ROWS rows / states: a request-row launch covers 2, 4 or 8 rows whatever max_batch is -- the padding rows are read, found terminated and skipped)
+        d_x_.alloc(sizeof(float) * (size_t)std::max(B_, PR_MAX_ROWS) * a_.dim);
+        d_xf_.alloc(sizeof(float) * (size_t)std::max(B_, PR_MAX_ROWS) * a_.dim);
+        FS_HIP(hipMemset(d_x_.p, 0, d_x_.n));
         d_q_.alloc(sizeof(float) * a_.dim);
         d_part_.alloc(sizeof(float) * (size_t)a_.n_head * n_chunks_ * (a_.head_dim + 2));
         FS_HIP(hipMemset(d_part_.p, 0, d_part_.n));
@@ -1436,7 +1515,7 @@ class LM final : public LMBase {
         d_logits_fast_.alloc(sizeof(float) * a_.codebook_size);
         d_hid_slot_.alloc(sizeof(float*));
         FS_HIP(hipMemset(d_hid_slot_.p, 0, sizeof(float*)));
-        d_state_.alloc(sizeof(SeqState) * (B_ + 1));  // + the staging state of a session's joining request
+        d_state_.alloc(sizeof(SeqState) * (std::max(B_, PR_MAX_ROWS) + 1));  // + the staging state of a session's joining request (index B_)
         FS_HIP(hipMemset(d_state_.p, 0, d_state_.n));
         d_cfg_.alloc(sizeof(SampleCfg));
         SampleCfg c = base_cfg();
@@ -1978,12 +2057,15 @@ class LM final : public LMBase {
     bool persist_ok_ = false, use_persist_ = false, pslow_ok_ = false, use_pslow_ = false, persist_sampled_ = false;
     int batch_rows_ = 0, batch_row_ = 0;  // generate_batch_sequential: batch sampler semantics for the row being generated
     // continuous-batching session: per-slot remaining iterations (-1 = empty), host copy of the slot states, scratch KV page of empty slots
-    bool sess_active_ = false;
+    bool sess_active_ = false, sess_rows_ = false, sess_sampled_ = false;  // sess_rows_: FS_SESSION_ROWS (slots on the request-row kernels)
+    int sess_R_ = 0, sess_adds_ = 0, sess_budget_tmp_ = 0;
+    uint64_t sess_seed_ = 0;
+    std::unique_lock<std::mutex> sess_plock_;
     std::vector<int> sess_left_, sess_pos_;
     std::vector<SeqState> sess_hs_;
     int sess_scratch_ = 0;
     uint64_t sess_released_frames_ = 0;
-    struct PendingAdd { int slot = -1, L = 0, n_iter = 0; std::vector<uint32_t> prompt; };
+    struct PendingAdd { int slot = -1, L = 0, n_iter = 0, order = 0; std::vector<uint32_t> prompt; };
     std::vector<uint32_t> sess_stage_prompts_;
     std::vector<int> sess_stage_rows_;
     std::vector<PendingAdd> sess_queue_, sess_flight_;  // joining requests: queued by session_add / prefill launched (flush_pending)

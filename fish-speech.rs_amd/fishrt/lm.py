@@ -185,9 +185,9 @@ class DualARTransformer:
         _ffi.check(_ffi.lib().fs_lm_weights_adopt(self._h))
         return self
 
-    def session(self, temp=0.7, top_p=0.9, top_k=50, seed=42, ignore_eos=False):
+    def session(self, temp=0.7, top_p=0.9, top_k=50, seed=42, ignore_eos=False, rows=False, repetition_penalty=1.2):
         """continuous batching over this handle's max_batch slots (fishrt.h: fs_lm_session_*): `with lm.session(...) as s:`"""
-        return Session(self, temp, top_p, top_k, seed, ignore_eos)
+        return Session(self, temp, top_p, top_k, seed, ignore_eos, rows, repetition_penalty)
 
     def last_stats(self):
         st = _ffi.GenStats()
@@ -232,10 +232,12 @@ class Session:
     step(n) runs up to n frames for all live slots and returns how many are still generating; poll(slot) -> (codes (C, n), done);
     release(slot) frees the slot.  A slot generates what a one-prompt generate_static_batch would (no repetition penalty)."""
 
-    def __init__(self, lm, temp, top_p, top_k, seed, ignore_eos):
+    def __init__(self, lm, temp, top_p, top_k, seed, ignore_eos, rows=False, repetition_penalty=1.2):
+        """rows=True: FS_SESSION_ROWS -- the slots run on the request-row persistent kernels with batch-1 semantics (repetition penalty, own
+        sampler stream per slot); max_batch <= 8"""
         self.lm, self._open = lm, False
-        s = _ffi.Sampling(float(temp), float(top_p), int(top_k), 1.0)
-        _ffi.check(_ffi.lib().fs_lm_session_begin(lm._h, C.byref(s), C.c_uint64(seed), 1 if ignore_eos else 0))
+        s = _ffi.Sampling(float(temp), float(top_p), int(top_k), float(repetition_penalty) if rows else 1.0)
+        _ffi.check(_ffi.lib().fs_lm_session_begin(lm._h, C.byref(s), C.c_uint64(seed), (1 if ignore_eos else 0) | (8 if rows else 0)))
         self._open = True
 
     def __enter__(self):

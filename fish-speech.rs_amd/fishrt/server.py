@@ -221,7 +221,19 @@ class Scheduler:
                     else:
                         if sess is None:
                             sa = self.s.default_sampling_args
-                            sess = lm.session(temp=sa.temp, top_p=sa.top_p, top_k=sa.top_k, seed=self.s.seed_source() & (2**64 - 1))
+                            seed = self.s.seed_source() & (2**64 - 1)
+                            # handles with 2 / 4 / 8 slots and the request-row kernels: the slots keep the batch-1 semantics of _single
+                            # (repetition penalty, one LogitsProcessor stream per job) while they share every decode launch (FS_SESSION_ROWS)
+                            rows = getattr(lm, "max_batch", 0) in (2, 4, 8) and hasattr(lm, "generate_multi") and (sa.temp == 0 or 0 < sa.top_k <= 256)
+                            try:
+                                sess = lm.session(temp=sa.temp, top_p=sa.top_p, top_k=sa.top_k, seed=seed, rows=True,
+                                                  repetition_penalty=sa.repetition_penalty) if rows else None
+                            except Exception:  # (f32 / fp8 / Fish <= 1.4 handles, or the device's persistent kernels are taken)
+                                sess = None
+                            if sess is None:
+                                sess = lm.session(temp=sa.temp, top_p=sa.top_p, top_k=sa.top_k, seed=seed)
+                            else:
+                                self.stats["row_sessions"] = self.stats.get("row_sessions", 0) + 1
                             self.cached_key = None
                         try:
                             slot = sess.add(held.full_prompt(), self.s.max_new_tokens)

@@ -208,7 +208,13 @@ int fs_lm_weights_adopt(fs_lm_t* lm);
  * ignored like static_batch.rs:204-206), 1 + max(0, max_new_tokens - L + 1) iterations (static_batch.rs:122), stopping early at
  * <|im_end|> or at max_seq_len.  With temp <= 1e-7 a slot's codes are independent of what the other slots do.
  * bf16 / fp8 handles with the Fish 1.5 token layout only; while a session is open the handle's other entry points fail. */
-int fs_lm_session_begin(fs_lm_t* lm, const fs_sampling* sampling, uint64_t seed, uint32_t flags /* FS_GEN_IGNORE_EOS */);
+/* FS_SESSION_ROWS (round 4): the slots run on the request-row persistent kernels (csrc/lm_persist_rows.hip, see fs_lm_generate_multi) and keep
+ * BATCH-1 semantics: a slot is its own generate_blocking call -- repetition penalty applied, LogitsProcessor sampling on its own StdRng stream
+ * seeded `seed + the slot's admission number`, 1 + max(0, max_new_tokens - L + 1) iterations -- while requests join and leave between
+ * frames; a decode frame costs one slow launch for all slots + one fast launch per 4 slots instead of the 373-node step.  bf16 Fish-1.5
+ * handles with 2 <= max_batch <= 8, greedy or 0 < top_k <= 256; the device's persistent kernels are held for the session's lifetime. */
+#define FS_SESSION_ROWS 8u
+int fs_lm_session_begin(fs_lm_t* lm, const fs_sampling* sampling, uint64_t seed, uint32_t flags /* FS_GEN_IGNORE_EOS | FS_SESSION_ROWS */);
 /* prompt u32 [C+1, L] row-major (copied); *slot = the slot taken, or -1 when all max_batch slots are busy or the KV page pool cannot hold
  * the request right now (not an error: retry after a release).  Returns once the
  * prefill is enqueued (one prefill in flight: a second add first waits for the previous one); the slot starts generating in a later step */

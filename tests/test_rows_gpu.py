@@ -259,3 +259,78 @@ def test_sampled_rows_every_decision_equals_the_oracle_sampler_on_the_same_logit
     other = lm8.generate_multi(prompts, mnt, repetition_penalty=rp, seeds=[s + 100 for s in seeds], ignore_eos=True, **kw)
     assert not all(np.array_equal(a, b) for a, b in zip(got, other))
     print(f"{kw}: {n} sampled rows x {F * 9} decisions identical to the oracle sampler on the captured logits")
+
+
+def test_rows_session_churn_every_request_is_its_own_generate_call():
+    """FS_SESSION_ROWS: continuous batching on the row kernels -- 9 requests through 4 slots (joins mid-flight, odd step sizes, slot reuse,
+    ragged budgets); every request == generate_blocking of the same prompt / budget on the same handle (greedy: identical, or parted at a
+    refereed near-tie)"""
+    rp = 1.2
+    lm = fishrt.DualARTransformer(fcfg.FISH_1_5, TOK, 0, "bf16", max_batch=4).load_synthetic(SEED)
+    rng = np.random.RandomState(11)
+    lens = [int(v) for v in rng.randint(10, 90, 9)]
+    frames = [int(v) for v in rng.randint(6, 40, 9)]
+    prompts = [_prompt(L, 400 + i) for i, L in enumerate(lens)]
+    budgets = [L + F - 2 for L, F in zip(lens, frames)]
+    results, pending, live = {}, list(range(9)), {}
+    with lm.session(temp=0.0, top_p=1.0, top_k=0, seed=5, ignore_eos=True, rows=True, repetition_penalty=rp) as s:
+        steps = 0
+        while pending or live:
+            while pending:
+                slot = s.add(prompts[pending[0]], budgets[pending[0]])
+                if slot is None:
+                    assert len(live) == 4
+                    break
+                live[slot] = pending.pop(0)
+            s.step(int(rng.randint(1, 9)))
+            steps += 1
+            for slot in list(live):
+                n, done = s.poll(slot, codes=False)
+                if done:
+                    results[live.pop(slot)] = s.poll(slot)[0]
+                    s.release(slot)
+        assert steps > 8
+        st = lm.last_stats()
+    parted = 0
+    for i in range(9):
+        lm.clear_slow_layer_caches()
+        ref = lm.generate_blocking(prompts[i], budgets[i], temp=0.0, top_p=1.0, top_k=0, repetition_penalty=rp, ignore_eos=True)
+        assert results[i].shape == ref.shape == (8, frames[i]), (i, results[i].shape, ref.shape)
+        if not np.array_equal(results[i], ref):
+            parted += 1
+            _referee(lm, prompts[i], budgets[i], results[i], ref, rp)
+    print(f"rows session: {9 - parted} of 9 requests identical to their own fs_lm_generate call, {parted} parted at a refereed near-tie; "
+          f"{st['frames']} frames in {st['decode_ms']:.1f} ms")
+    assert parted <= 5
+    lm.close()
+
+
+def test_rows_session_sampled_slots_every_decision():
+    """sampled slots: slot k (admission number k) draws from StdRng(seed + k): every captured decision == the oracle sampler"""
+    from test_persist_sampled_gpu import _oracle_picks
+    F, rp, seed = 24, 1.2, 77
+    kw = dict(temp=0.7, top_p=0.8, top_k=256)
+    lm = fishrt.DualARTransformer(fcfg.FISH_1_5, TOK, 0, "bf16", max_batch=4).load_synthetic(SEED)
+    lm.debug_capture(F)
+    prompts = [_prompt(18 + 11 * i, 600 + i) for i in range(4)]
+    outs = {}
+    with lm.session(seed=seed, ignore_eos=True, rows=True, repetition_penalty=rp, **kw) as s:
+        slots = []
+        for i, p in enumerate(prompts):  # one join per round: each request meets the others mid-flight
+            slots.append(s.add(p, p.shape[1] + F - 2))
+            s.step(3)
+        while s.step(8):
+            pass
+        for i, sl in enumerate(slots):
+            outs[i] = s.poll(sl)[0]
+    for i, sl in enumerate(slots):
+        cap = lm.debug_read_row(sl, F)
+        assert outs[i].shape == (8, F)
+        picks = np.concatenate([cap[:, :1, 2047], cap[:, 1:, 1024]], axis=1).astype(np.int64)
+        assert np.array_equal(picks[:, 1:].T, outs[i].astype(np.int64))
+        exp = _oracle_picks(cap, seed + i, kw["temp"], kw["top_p"], kw["top_k"])
+        bad = np.argwhere(picks != exp)
+        assert bad.size == 0, f"slot {sl}: {len(bad)} of {F * 9} decisions differ from the oracle sampler, first {bad[0]}"
+    lm.debug_capture(0)
+    lm.close()
+    print(f"rows session, sampled: 4 slots x {F * 9} decisions identical to the oracle sampler on the captured logits")

@@ -11,7 +11,10 @@ pids=()
 for f in lm_kernels.hip lm_persist.hip lm_persist_slow.hip lm_persist_rows.hip lm_engine.hip codec_kernels.hip codec_conv_bf3.hip codec_engine.hip fishrt_api.cpp; do
   o="$HERE/build/${f%.*}.o"
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ -n "$(find . -name '*.h' -newer "$o" -print -quit)" ] || [ "../../include/fishrt.h" -nt "$o" ]; then
-    ( /opt/rocm/bin/hipcc $FLAGS -x hip -c "$f" -o "$o" ) &
+    # (lm_persist_rows.hip: four unrolled layers x two row groups x R rows exceed clang's default budget for `#pragma unroll`; a loop it refuses to
+    # unroll indexes the resident weight-fragment array at run time, which moves the whole array to scratch)
+    EXTRA=""; [ "$f" = lm_persist_rows.hip ] && EXTRA="-mllvm -pragma-unroll-threshold=1000000"
+    ( /opt/rocm/bin/hipcc $FLAGS $EXTRA -x hip -c "$f" -o "$o" ) &
     pids+=($!)
   fi
 done

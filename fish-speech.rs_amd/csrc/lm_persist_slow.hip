@@ -38,6 +38,7 @@ namespace fs {
 namespace {
 
 #include "lm_persist_dev.h"
+#include "lm_persist_rows_dev.h"  // pr_sweep_att8: 16 x 16-byte sweep loads of one lane in flight (uniform bases in SGPRs)
 
 constexpr int PS_DROR8 = 0x128;  // DPP row_ror:8 -- lane l <- lane l ^ 8 inside a row of 16
 
@@ -451,6 +452,29 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
             // two passes over the slices would need the maxima first: keep {m, l, o} of up to 16 slices in registers (n_sl <= 16)
             float sm[16], sl_[16], so0[16], so1[16];
             pf_nap_before_sweep(A.naps[2]);
+            if (n_sl > 4) {
+                // 8 or 16 slices per head: 8 slices = 16 units per lane in ONE sweep (round 4; two dependent 8-unit sweeps cost a second memory-side
+                // round trip per layer: 0.8 us x 24 on every frame beyond 512 cached tokens)
+                const unsigned off_o = (unsigned)((h * n_sl * 66 + 2 * j) * 8), off_ml = (unsigned)((h * n_sl * 66 + 64) * 8);
+#pragma unroll
+                for (int rd = 0; rd < 2; ++rd) {
+                    if (8 * rd < n_sl) {
+                        const u64* sb[8];
+                        u32x4 vo[8], vm[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) sb[k] = eb + (size_t)(8 * rd + k) * 66;
+                        pr_sweep_att8(sb, off_o, off_ml, tag0 + e + 1, vo, vm, dead, A.ctl);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            so0[8 * rd + k] = __uint_as_float(vo[k].x); so1[8 * rd + k] = __uint_as_float(vo[k].z);
+                            sm[8 * rd + k] = __uint_as_float(vm[k].x); sl_[8 * rd + k] = __uint_as_float(vm[k].z);
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) { so0[8 * rd + k] = 0.f; so1[8 * rd + k] = 0.f; sm[8 * rd + k] = -1e30f; sl_[8 * rd + k] = 0.f; }
+                    }
+                }
+            } else
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int s0 = 4 * g4;  // compile-time: the slice arrays stay in registers

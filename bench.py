@@ -142,7 +142,8 @@ def dry_run(args, dist, rank, world):
                           "reason": "no HIP device visible: control path only (launch, shard, broadcast, all-gather); fishrt has no CPU path",
                           "requests": n_req, "requests_per_rank": [len(fanout.shard_requests(n_req, r, world)) for r in range(world)],
                           "collective_ranks": int(seen), "backend": "gloo" if dist is not None else None, "fan_in_ok": bool(ok),
-                          "batch_per_rank": B}), flush=True)
+                          "batch_per_rank": B, "config": args.config,
+                          "static_batches_per_rank": [(len(fanout.shard_requests(n_req, r, world)) + B - 1) // B for r in range(world)]}), flush=True)
     if dist is not None:
         dist.destroy_process_group()
     sys.exit(0 if ok else 1)
@@ -170,10 +171,12 @@ def run_config3(args, lm_factory, dist, rank, world, cfg, tok):
         codes = np.zeros((len(mine), 8, frames), np.uint32)
         nf = np.zeros(len(mine), np.int32)
         dec_s = pre_s = 0.0
+        lmaxes = []
         for b0 in range(0, len(mine), B):
             idx = mine[b0:b0 + B]
             ps = [np.ascontiguousarray(packed[i, :, : lens[i]]) for i in idx]
             Lmax = max(p.shape[1] for p in ps)
+            lmaxes.append(Lmax)
             outs = lm.generate_static_batch(ps, frames + Lmax - 2, temp=0.7, top_p=0.8, top_k=256, seed=42, ignore_eos=True)
             st = lm.last_stats()
             dec_s += st["decode_ms"] * 1e-3
@@ -181,7 +184,7 @@ def run_config3(args, lm_factory, dist, rank, world, cfg, tok):
             for k, o in enumerate(outs):
                 codes[b0 + k, :, : o.shape[1]] = o
                 nf[b0 + k] = o.shape[1]
-        return codes, nf, dec_s, pre_s
+        return codes, nf, dec_s, pre_s, float(np.mean(lmaxes))
 
     def barrier():
         fanout.barrier(dist)
@@ -192,7 +195,7 @@ def run_config3(args, lm_factory, dist, rank, world, cfg, tok):
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        codes, nf, dec_s, pre_s = one_job()
+        codes, nf, dec_s, pre_s, lmax_avg = one_job()
         ca, fa, seen = fanout.all_gather_codes(dist, codes, nf)  # the job's fan-in is part of the timed region
     barrier()
     dt = fanout.max_over_ranks(dist, time.perf_counter() - t0)
@@ -200,6 +203,8 @@ def run_config3(args, lm_factory, dist, rank, world, cfg, tok):
     frames_total = n_req * frames * args.steps
     n_batches = (len(mine) + B - 1) // B
     step_s = dec_s / (n_batches * (frames - 1))
+    # a static batch is left-padded to its longest prompt (static_batch.rs:68-111): every row's KV length is Lmax + the frames so far
+    bytes_step = frame_bytes(cfg, tok, 0) + B * 12288 * (lmax_avg + frames / 2)
     res = {
         "metric": "codec tokens/sec (frames/s; 1 frame = 1 slow + 8 codebook tokens = 2048 PCM samples), Fish-1.5 static batches of 32",
         "value": round(frames_total / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -214,9 +219,10 @@ def run_config3(args, lm_factory, dist, rank, world, cfg, tok):
         "rccl_ranks": int(seen), "frames_per_rank": [int(v) for v in fa.sum(axis=1)],
         "decode_step_us_rank0": round(step_s * 1e6, 1), "prefill_s_per_job_rank0": round(pre_s, 3),
         "roofline": {"bound": "hbm", "kernel": "static-batch decode step (one graph replay, B = 32 rows on the MFMA row path)",
-                     "achieved": round((frame_bytes(cfg, tok, 0) + B * 12288 * (float(lens.mean()) + frames / 2)) / step_s / 1e9, 2),
+                     "achieved": round(bytes_step / step_s / 1e9, 2),
                      "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                     "frac": round((frame_bytes(cfg, tok, 0) + B * 12288 * (float(lens.mean()) + frames / 2)) / step_s / HBM_PEAK, 4), "traffic": None},
+                     "frac": round(bytes_step / step_s / HBM_PEAK, 4), "algorithmic_bytes_per_step": int(bytes_step),
+                     **offline_batch_traffic("static_batch32")},
     }
     if rank == 0:
         print(json.dumps(res), flush=True)
@@ -405,6 +411,21 @@ def offline_traffic(kernels_per_frame):
     return {"traffic": None, "traffic_source": "no PMC summary for this path under profiles/ (tools/pmc_traffic.sh)"}
 
 
+def offline_batch_traffic(key):
+    """HBM bytes per decode step of the static batch of 32 (key "static_batch32") or per R-row persistent frame ("rows_R4", "rows_R8") from
+    the differenced PMC passes summarised in profiles/rNN_pmc_batch_traffic.json (tools/pmc_batch.sh); None when no tracked summary has it."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_batch_traffic.json")), reverse=True):
+        with open(path) as f:
+            t = json.load(f)
+        if key in t:
+            v = t[key]
+            return {"traffic": v.get("hbm_bytes_per_step", v.get("hbm_bytes_per_frame")),
+                    "traffic_algorithmic_bytes_same_window": v.get("algorithmic_bytes_per_step", v.get("algorithmic_bytes_per_frame")),
+                    "traffic_source": f"offline: profiles/{os.path.basename(path)}[{key}] ({v.get('command', '')}; commit {t.get('commit', '?')})"}
+    return {"traffic": None, "traffic_source": "no PMC summary for this path under profiles/ (tools/pmc_batch.sh)"}
+
+
 def continuous_vs_lockstep(lmb, prompts):
     """64 requests with ragged lengths (prompts U{64..384}, 64..256 frames each, fixed by ignore_eos) on a 32-row handle: lock-step static
     batches (two batches of 32, each as long as its longest row, generate/static_batch.rs:282-390) vs continuous batching (fs_lm_session_*:
@@ -481,8 +502,10 @@ def extras(cfg, tok):
                      "decode_frames_per_s": round(B / step_s, 1), "step_us": round(step_s * 1e6, 1),
                      "roofline_frac": round(bytes_step / step_s / HBM_PEAK, 4),
                      "frames_out": int(sum(o.shape[1] for o in outs)), "prefill_ms_all_rows": round(st["prefill_ms"], 1),
-                     "prefill_tokens_per_s": round(B * (Lmax - 1) / (st["prefill_ms"] * 1e-3), 0)}
+                     "prefill_tokens_per_s": round(B * (Lmax - 1) / (st["prefill_ms"] * 1e-3), 0),
+                     "algorithmic_bytes_per_step": int(bytes_step)}
         if name == "static_batch32":
+            out[name].update(offline_batch_traffic("static_batch32"))
             out["continuous_batching32"] = continuous_vs_lockstep(lmb, prompts_all[:64])
         lmb.close()
     codes = np.random.RandomState(1).randint(0, 1000, (1, 8, 256)).astype(np.uint32)
@@ -560,7 +583,8 @@ def extras(cfg, tok):
         key = f"R{R}" + ("" if kw["temp"] == 0.0 else "_sampled")
         rows[key] = {"frame_us": round(best, 1), "decode_frames_per_s": round(R * 1e6 / best, 1), "whole_job_frames_per_s": round(R * Fr / wall, 1),
                      "speedup_vs_one_request_at_a_time": round(R * one_us / best, 2), "launches_per_frame": int(stR["kernels_per_frame"]),
-                     "roofline_frac": round(bytes_frame / (best * 1e-6) / HBM_PEAK, 4),
+                     "roofline_frac": round(bytes_frame / (best * 1e-6) / HBM_PEAK, 4), "algorithmic_bytes_per_frame": int(bytes_frame),
+                     **(offline_batch_traffic(f"rows_R{R}") if kw["temp"] == 0.0 and R in (4, 8) else {}),
                      # (the R requests are the same request: identical rows; they part from the batch-1 kernels' tokens at the first bf16
                      # near-tie -- other summation order -- like the batch-1 persistent path parts from the per-node path)
                      "rows_identical_to_each_other": (bool(all(np.array_equal(o, outs[0]) for o in outs)) if kw["temp"] == 0.0 else None),

@@ -47,3 +47,21 @@ def test_bench_gpus2_self_launch_dry_run():
     env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     p2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env2)
     assert p2.returncode == 2 and "WORLD_SIZE=1" in p2.stderr
+
+
+def test_bench_gpus8_config3_dry_run():
+    """BASELINE.json configs[3] as the driver would launch it on a node (`--gpus 8 --config 3`): 256 requests -> 32 per rank = one static
+    batch of 32 per GPU; on a CPU box the 8 ranks run the control path (shard, prompt broadcast, code all-gather over gloo)."""
+    import json
+    import fishrt
+    if fishrt.lib().fs_device_count() > 0:
+        import pytest
+        pytest.skip("a GPU is visible: the real bench runs instead (covered by the driver)")
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--config", "3"], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    j = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j["dry_run"] is True and j["config"] == 3 and j["n_gpus"] == 8 and j["collective_ranks"] == 8 and j["fan_in_ok"]
+    assert j["requests_per_rank"] == [32] * 8 and j["static_batches_per_rank"] == [1] * 8 and j["batch_per_rank"] == 32

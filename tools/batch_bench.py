@@ -1,7 +1,7 @@
 """BASELINE.json configs[2]: Fish-1.5 bf16, B concurrent requests, top-p 0.8 / temp 0.7 / top-k 256, 256 frames, one MI355X."""
 import sys, time
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/fish-speech.rs_amd")
-import numpy as np, fishrt
+import numpy as np, torch, fishrt  # torch first: under rocprofv3 its HIP runtime must load before libfishrt
 from fishrt import config as fcfg
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 256

@@ -2,7 +2,6 @@
 # per-kernel time of the B = 32 static-batch decode step (rocprofv3 --kernel-trace --stats on tools/batch_bench.py 32 64)
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; O=$GRAFT_REPO_ROOT/gpurun_out
 export TMPDIR=/tmp; cd /tmp; rm -rf /tmp/profb
-sed -i 's/^import numpy as np, fishrt/import numpy as np, torch, fishrt/' $GRAFT_REPO_ROOT/tools/batch_bench.py
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profb -o b -- python $GRAFT_REPO_ROOT/tools/batch_bench.py ${1:-32} ${2:-64} > $O/prof_batch.log 2>&1
 F=$(find /tmp/profb -name "*kernel_stats.csv" | head -1)
 if [ -n "$F" ]; then cp $F $O/batch_kernel_stats.csv; python3 - $F <<'PY'

@@ -1300,7 +1300,17 @@ __global__ __launch_bounds__((AttnGeom<WT, DH>::NW * 64)) void k_attn_rows(const
                                                    int n_chunks_max = 0, int tpb = 1 << 30) {
     // hsplit > 1: the query heads of a kv group are spread over hsplit blocks of NREP heads each (small batches: more blocks,
     // less VALU work per wave; the K/V tiles are then read hsplit times, from L2)
-    const int g = blockIdx.x / hsplit, hb = (blockIdx.x % hsplit) * NREP, mrow = blockIdx.y;
+    int g = blockIdx.x / hsplit, hb = (blockIdx.x % hsplit) * NREP, mrow = blockIdx.y;
+    if (!PART && hsplit > 1) {
+        // XCD-aware placement: workgroups go round-robin over the 8 XCDs by linear id, and each XCD has its own L2 -- the hsplit blocks
+        // that share one (kv head, row) K/V stream must land on ONE XCD or the stream crosses the fabric hsplit times (PMC at B = 32:
+        // 711 MB per step for 162 MB of K/V with the plain mapping)
+        const int total = gridDim.x * gridDim.y, per_xcd = total / (8 * hsplit);
+        if (per_xcd * 8 * hsplit == total) {
+            const int lin = blockIdx.x + gridDim.x * blockIdx.y, k = lin >> 3, grp = (lin & 7) * per_xcd + k / hsplit;
+            g = grp % Hk; mrow = grp / Hk; hb = (k % hsplit) * NREP;
+        }
+    }
     const int GH = NREP * hsplit;  // query heads per kv head
     kv.page_table += (size_t)mrow * pt_stride;
     const float* q = q_all + (size_t)mrow * Hk * GH * DH;

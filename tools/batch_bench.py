@@ -5,6 +5,7 @@ import numpy as np, torch, fishrt  # torch first: under rocprofv3 its HIP runtim
 from fishrt import config as fcfg
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 lm = fishrt.DualARTransformer(fcfg.FISH_1_5, fcfg.FISH_1_5_TOKENS, 0, "bf16", max_batch=B).load_synthetic(0xF15E5EED)
 rng = np.random.RandomState(77)
 prompts = []
@@ -12,7 +13,7 @@ for L in rng.randint(64, 385, B):   # prompt lengths U{64..384} seed 77 (SURVEY.
     p = np.zeros((9, int(L)), np.uint32); p[0] = rng.randint(0, 100000, int(L)); prompts.append(p)
 Lmax = max(p.shape[1] for p in prompts)
 M = frames + Lmax - 2
-for rep in range(2):
+for rep in range(reps):
     t = time.perf_counter()
     outs = lm.generate_static_batch(prompts, M, temp=0.7, top_p=0.8, top_k=256, seed=42, ignore_eos=True)
     dt = time.perf_counter() - t

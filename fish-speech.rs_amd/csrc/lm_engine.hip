@@ -1925,6 +1925,7 @@ class LM final : public LMBase {
         A.ctl = d_rctl_f_.as<uint32_t>();
         A.prof = getenv("FISHRT_PERSIST_PROF") ? reinterpret_cast<unsigned long long*>(d_rctl_f_.as<uint32_t>() + 16) : nullptr;
         set_naps(A.naps, "FISHRT_NAPS_ROWS_FAST", kNapsRowsFast);
+        A.nap_draw = getenv("FISHRT_NAP_ROWS_DRAW") ? atoi(getenv("FISHRT_NAP_ROWS_DRAW")) : 16;  // flat between 0 and 48 (1075 us per sampled 4-row frame), 1088 at 96, 1111 at 200
         return A;
     }
     // the batch-1 fast kernel on row i of a multi-request call (FISHRT_ROWS_FAST_SINGLE: reference composition for the row fast kernel)

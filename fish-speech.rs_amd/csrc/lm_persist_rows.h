@@ -74,6 +74,7 @@ struct RowsFastArgs {
     unsigned long long* prof;
     uint32_t* ctl;
     int naps[6];
+    int nap_draw;               // sampled instantiation: nap in front of the decision-edge sweep (a draw takes ~7 us on the drawing workgroups)
 };
 
 size_t rows_slow_edge_bytes(int R);

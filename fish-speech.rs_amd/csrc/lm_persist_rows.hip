@@ -773,6 +773,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
 
     // ---- the slow-token decision of every live row (constrain_probs_to_audio utils.rs:13-16, rescale_semantic_tokens :45-46,
     // single_batch.rs:102-144), redundantly on every workgroup
+    bool dead = false;
     unsigned run = 0;  // rows whose fast decoder runs: live and not terminated by <|im_end|> this frame (single_batch.rs:153-156)
     int n_draws[R];
 #pragma unroll
@@ -792,16 +793,16 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
             if (A.cap && b == 0 && lv_r && A.state[r].frame < A.cap_frames)
                 *reinterpret_cast<float4*>(A.cap + ((size_t)r * A.cap_frames + A.state[r].frame) * 9 * 2048 + 4 * tid) = make_float4(lv[0], lv[1], lv[2], lv[3]);
             if (SAMPLED) {
-                int idx = 0;
-                if (lv_r) {
+                // one draw costs ~7 us on a whole workgroup: row r's is taken by workgroups 8r .. 8r+7 only (one per edge replica) and
+                // handed to everybody through a two-granule decision edge {index | consumed << 16} -- R draws side by side instead of
+                // one after the other on every workgroup
+                if (lv_r && (b >> 3) == r) {
                     int used = 0;
                     const int* cf = s_ring + r * RR + 168 + 16;
-                    __syncthreads();  // (the sampler's scratch: nobody still reads the previous row's)
-                    idx = bsample<PF_THREADS, 4>(lv, n, cf[8], (float)(1.0 / (double)__int_as_float(cf[6])), __int_as_float(cf[7]),
-                                                 (uint32_t)s_ring[r * RR + 168 + 32], &used, samp);
-                    n_draws[r] += used;
+                    const int idx = bsample<PF_THREADS, 4>(lv, n, cf[8], (float)(1.0 / (double)__int_as_float(cf[6])), __int_as_float(cf[7]),
+                                                           (uint32_t)s_ring[r * RR + 168 + 32], &used, samp);
+                    if (tid < 2) pub(0u, b & 7, r, tid, epoch * 256u + 1u, __uint_as_float((uint32_t)idx | ((uint32_t)used << 16)));
                 }
-                if (tid == 0) amax[(r * 8) * 2 + 1] = __int_as_float(idx);
             } else {
             float bv = lv[0];
             int bi = 4 * tid;
@@ -813,11 +814,21 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
             if (lane == 0) { amax[(r * 8 + wave) * 2] = wm; amax[(r * 8 + wave) * 2 + 1] = __int_as_float(ci); }
             }
         }
+        u32x4 dv[R];
+        if (SAMPLED) {
+            const int first_l = __builtin_ctz(live);
+            const u64* bs[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) bs[r] = ebase(0u, rep, ((live >> r) & 1u) ? r : first_l);
+            pf_nap_before_sweep(A.nap_draw);
+            pr_sweep_rows<R>(bs, 0u, epoch * 256u + 1u, dv, dead, A.ctl);
+        }
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            float gv = amax[(r * 8) * 2];
-            int idx = __float_as_int(amax[(r * 8) * 2 + 1]);
+            float gv = SAMPLED ? 0.f : amax[(r * 8) * 2];
+            int idx = SAMPLED ? (int)(dv[r].x & 0xFFFFu) : __float_as_int(amax[(r * 8) * 2 + 1]);
+            if (SAMPLED && ((live >> r) & 1u)) n_draws[r] += (int)(dv[r].x >> 16);
             if (!SAMPLED) {
 #pragma unroll
             for (int w = 1; w < 8; ++w) {
@@ -839,7 +850,6 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
     run = __builtin_amdgcn_readfirstlane(run);
     if (!run && b != 0) return;
 
-    bool dead = false;
     unsigned long long tk[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = A.prof ? wall_clock64() : 0;
 #define PF_TICK(k) do { if (A.prof) { const unsigned long long n_ = wall_clock64(); tk[k] += n_ - t_last; t_last = n_; } } while (0)
     if (run) {
@@ -878,7 +888,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
 #pragma unroll
             for (int u2 = 0; u2 < 8; ++u2) asm volatile("" : "+v"(w13v[l][u2]));
         PF_TICK(0);
-        unsigned e = 0;
+        unsigned e = SAMPLED ? 1u : 0u;  // (edge 0: the slow-token draws)
         const unsigned tag0 = epoch * 256u;
         int par = 0;
         auto sweep_x = [&](unsigned ee, u32x4 (&v)[R]) {
@@ -1260,17 +1270,15 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                         if (A.cap && b == 0 && on && A.state[r].frame < A.cap_frames)
                             *reinterpret_cast<float2*>(A.cap + (((size_t)r * A.cap_frames + A.state[r].frame) * 9 + 1 + cb) * 2048 + 2 * tid) = make_float2(lv0, lv1);
                         if (SAMPLED) {
-                            int gi = 0;
-                            if (on) {
+                            if (on && (b >> 3) == r) {  // this workgroup draws for row r (see the slow-token draws)
                                 int used = 0;
                                 const int* cf = ring + 168 + 16;
                                 const float lvv[2] = {lv0, lv1};
-                                __syncthreads();  // (the sampler's scratch aliases the staging tiles: every wave is past this pass's last S3 / previous row)
-                                gi = bsample<PF_THREADS, 2>(lvv, 1024, cf[8], (float)(1.0 / (double)__int_as_float(cf[6])), __int_as_float(cf[7]),
-                                                            (uint32_t)ring[168 + 32 + n_draws[r]], &used, samp);
-                                n_draws[r] += used;
+                                __syncthreads();  // (the sampler's scratch aliases the staging tiles: every wave is past this pass's last S3)
+                                const int gi = bsample<PF_THREADS, 2>(lvv, 1024, cf[8], (float)(1.0 / (double)__int_as_float(cf[6])), __int_as_float(cf[7]),
+                                                                      (uint32_t)ring[168 + 32 + n_draws[r]], &used, samp);
+                                if (tid < 2) pub(e, b & 7, r, tid, tag0 + e + 1, __uint_as_float((uint32_t)gi | ((uint32_t)used << 16)));
                             }
-                            if (tid == 0) amax[((par * R + r) * 8) * 2 + 1] = __int_as_float(gi);
                         } else {
                         float bv = lv0;
                         int bi = 2 * tid;
@@ -1281,12 +1289,22 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                         }
                     }
                 }
+                u32x4 dv[R];
+                if (SAMPLED) {
+                    const u64* bs[R];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) bs[r] = ebase(e, rep, ((run >> r) & 1u) ? r : first);
+                    pf_nap_before_sweep(A.nap_draw);
+                    pr_sweep_rows<R>(bs, 0u, tag0 + e + 1, dv, dead, A.ctl);
+                    ++e;
+                }
                 __syncthreads();
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const bool on = (run >> r) & 1u;
-                    float gv = amax[((par * R + r) * 8) * 2];
-                    int gi = __float_as_int(amax[((par * R + r) * 8) * 2 + 1]);
+                    float gv = SAMPLED ? 0.f : amax[((par * R + r) * 8) * 2];
+                    int gi = SAMPLED ? (int)(dv[r].x & 0xFFFFu) : __float_as_int(amax[((par * R + r) * 8) * 2 + 1]);
+                    if (SAMPLED && on) n_draws[r] += (int)(dv[r].x >> 16);
                     if (!SAMPLED) {
 #pragma unroll
                     for (int w = 1; w < 8; ++w) {

@@ -1335,8 +1335,8 @@ class LM final : public LMBase {
                     R, pr[1] * f, pr[2] * f, pr[8] * f, pr[3] * f, pr[9] * f, pr[10] * f, pr[11] * f, pr[4] * f, pr[12] * f, pr[13] * f, pr[5] * f, pr[6] * f);
             FS_HIP(hipMemcpy(pr, d_rctl_f_.as<uint32_t>() + 16, sizeof(pr), hipMemcpyDeviceToHost));
             FS_HIP(hipMemset(d_rctl_f_.as<uint32_t>() + 16, 0, sizeof(pr)));
-            fprintf(stderr, "rows fast prof (us/frame summed over the fast launches, workgroup 0; wait+work): preload %.1f  S1 %.1f+%.1f  S2 %.1f+%.1f  S3 %.1f+%.1f  S4 %.1f+%.1f  head %.1f+%.1f  decision %.1f+%.1f  tail %.1f\n",
-                    pr[0] * f, pr[9] * f, pr[1] * f, pr[10] * f, pr[2] * f, pr[11] * f, (pr[3] + pr[8]) * f, pr[12] * f, pr[4] * f, pr[13] * f, pr[5] * f, pr[14] * f, pr[6] * f, pr[7] * f);
+            fprintf(stderr, "rows fast prof (us/frame summed over the fast launches, workgroup 0; wait+work): preload %.1f  S1 %.1f+%.1f  S2 %.1f+%.1f  S3 %.1f+%.1f  S4 %.1f+%.1f  head %.1f+%.1f  decision %.1f+%.1f (rows' logits -> argmax / draw %.1f, pick -> next input %.1f)  tail %.1f\n",
+                    pr[0] * f, pr[9] * f, pr[1] * f, pr[10] * f, pr[2] * f, pr[11] * f, (pr[3] + pr[8]) * f, pr[12] * f, pr[4] * f, pr[13] * f, pr[5] * f, pr[14] * f, (pr[6] + pr[15]) * f, pr[15] * f, pr[6] * f, pr[7] * f);
         }
         for (DevBuf* cb : {&d_rctl_s_, &d_rctl_f_, &d_ctl_}) {
             uint32_t ctl[4] = {0, 0, 0, 0};

@@ -848,7 +848,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
         __syncthreads();
     }
     run = __builtin_amdgcn_readfirstlane(run);
-    if (!run && b != 0) return;
+    if (!run && b >= R) return;  // (the end-of-frame rows are kept by workgroups 0 .. R-1)
 
     unsigned long long tk[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = A.prof ? wall_clock64() : 0;
 #define PF_TICK(k) do { if (A.prof) { const unsigned long long n_ = wall_clock64(); tk[k] += n_ - t_last; t_last = n_; } } while (0)
@@ -1259,7 +1259,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                             if (i0 == dropped && m0 == pen) m0 = 1.0f;
                             if (i1 == last) m1 = pen;
                             if (i1 == dropped && m1 == pen) m1 = 1.0f;
-                            if (b == 0 && on) {
+                            if (b == r && on) {  // (row r's window state is kept by workgroup r: four rows' guarded stores on one workgroup sat on every decision's critical path)
                                 float* mk = A.rp_mask + ((size_t)r * 8 + cb) * 1024;
                                 if (m0 != o0) mk[i0] = m0;
                                 if (m1 != o1) mk[i1] = m1;
@@ -1289,6 +1289,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                         }
                     }
                 }
+                PF_TICK(15);
                 u32x4 dv[R];
                 if (SAMPLED) {
                     const u64* bs[R];
@@ -1299,6 +1300,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                     ++e;
                 }
                 __syncthreads();
+                uint32_t codes[R];
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const bool on = (run >> r) & 1u;
@@ -1313,32 +1315,45 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                         if (v2 > gv || (v2 == gv && i2 > gi)) { gv = v2; gi = i2; }
                     }
                     }
-                    const uint32_t code = (uint32_t)max(gi, 0);
+                    codes[r] = (uint32_t)max(gi, 0);
+                }
+                // hidden_states = fast_embeddings(code) (single_batch.rs:181-183): the next pass's S1 reads it back (same lane).  All rows' table
+                // rows are requested before anything else touches memory: inside the row loop each request waited behind the previous row's
+                // guarded stores (3.3 us per decision at 4 rows)
+                uint32_t ew[R];
+                if (cb != 7) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) ew[r] = reinterpret_cast<const uint32_t*>(A.fast_emb)[codes[r] * 512u + (unsigned)tid];
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const bool on = (run >> r) & 1u;
                     if (A.cap && b == 0 && tid == 0 && on && A.state[r].frame < A.cap_frames)
-                        A.cap[(((size_t)r * A.cap_frames + A.state[r].frame) * 9 + 1 + cb) * 2048 + 1024] = (float)code;
-                    if (tid == 0) s_ring[r * RR + 168 + 4 + cb] = (int)code;
-                    if (cb != 7) {  // hidden_states = fast_embeddings(code) (single_batch.rs:181-183): the next pass's S1 reads it back (same lane)
-                        const uint32_t ew = reinterpret_cast<const uint32_t*>(A.fast_emb)[(size_t)code * 512 + tid];
-                        *reinterpret_cast<float2*>(qs + r * 1024 + 2 * tid) = make_float2(bf_lo(ew), bf_hi(ew));
-                    }
+                        A.cap[(((size_t)r * A.cap_frames + A.state[r].frame) * 9 + 1 + cb) * 2048 + 1024] = (float)codes[r];
+                    if (tid == 0) s_ring[r * RR + 168 + 4 + cb] = (int)codes[r];
+                }
+                if (cb != 7) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) *reinterpret_cast<float2*>(qs + r * 1024 + 2 * tid) = make_float2(bf_lo(ew[r]), bf_hi(ew[r]));
                 }
                 par ^= 1;
                 PF_TICK(6);
             }
         }
     }
-    if (b != 0) return;
+    if (b >= R) return;
     int* n_draws_l = reinterpret_cast<int*>(amax);  // (dead: every decision is taken)
     __syncthreads();
     if (tid == 0) {
 #pragma unroll
         for (int r = 0; r < R; ++r) n_draws_l[r] = n_draws[r];
     }
-    // ---- end of frame, workgroup 0 only, row by row (single_batch.rs:185-210 + generate_blocking :250,264-266)
+    // ---- end of frame: row r on workgroup r (single_batch.rs:185-210 + generate_blocking :250,264-266); every workgroup holds the same
+    // per-row decisions in LDS, so the rows' state updates and next-input gathers run side by side instead of row by row on workgroup 0
     __syncthreads();
-#pragma unroll 1
-    for (int r = 0; r < R; ++r) {
-        if (!((live >> r) & 1u)) continue;
+    {
+        const int r = b;
+        if ((live >> r) & 1u) {
         const bool eos = !((run >> r) & 1u);
         SeqState* st = A.state + r;
         const int* misc = s_ring + r * RR + 168;
@@ -1379,7 +1394,9 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
             }
             *reinterpret_cast<float2*>(A.x + (size_t)r * 1024 + 2 * tid) = make_float2(e0, e1);
         }
+        }
     }
+    if (b != 0) return;
     if (tid == 0) A.ctl[0] = epoch + 1;
     PF_TICK(7);
     if (A.prof && tid == 0) for (int k = 0; k < 16; ++k) A.prof[k] += tk[k];

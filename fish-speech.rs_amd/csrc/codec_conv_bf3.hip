@@ -120,7 +120,10 @@ __device__ unsigned long long g_c3prof[8];
 // stream (and for one-shot decoding), else the last PP slots of the same tensor in the previous chunk, kept in a per-tensor context
 //   ctx[part][C/8][PP][8]
 // `ci` = the context to copy in (null: zeros); producers also copy the last PP slots they write into `co` (null: not streaming).
-struct PlaneCtx { const uint16_t* ci; uint16_t* co; };
+// ParallelBlock mean folded into a residual conv (hifi_gan.rs:114-117): when `mean_a` is set, the residual epilogue's value c = res + conv
+// (the third ResBlock's output) becomes ((mean_a + mean_b) + c) / 3 -- the same f32 operations in the same order as k_mean3_planes / k_mean3 --
+// before it is stored / split, so the third block's f32 output and the mean kernel's three reads never touch memory.
+struct PlaneCtx { const uint16_t* ci; uint16_t* co; const float* mean_a = nullptr; const float* mean_b = nullptr; };
 template <bool F16>
 __device__ __forceinline__ void c3_zero_pad(uint16_t* pb, int CG, int T, int g_first, int n_groups, int tid, int nthreads, const uint16_t* ci = nullptr) {
     constexpr int NP = F16 ? 1 : 2;
@@ -197,8 +200,11 @@ __global__ void k_mean3_planes(const float* __restrict__ a, const float* __restr
 template <bool F16, int NT, int E, bool PS1>
 __device__ __forceinline__ void c3_epilogue_k(const f32x16 (&acc)[NT], int ob, int tbase, int h, int c, int Cout, int T, int ps,
                                               const float* __restrict__ bias, const float* __restrict__ res, const float* __restrict__ gamma,
-                                              float* __restrict__ y, uint16_t* __restrict__ ypb, int post_silu, uint16_t* __restrict__ yco = nullptr) {
+                                              float* __restrict__ y, uint16_t* __restrict__ ypb, int post_silu, uint16_t* __restrict__ yco = nullptr,
+                                              const float* __restrict__ m0 = nullptr, const float* __restrict__ m1 = nullptr) {
     constexpr bool RES = E == CODEC_EPI_RES || E == CODEC_EPI_GAMMA_RES;
+    const bool mean3 = E == CODEC_EPI_RES && m0 != nullptr;  // (uniform: a kernel argument)
+    const float third = (float)(1.0 / 3.0);
     const int CGo = Cout >> 3;
     float bv[16], gv[16];
 #pragma unroll
@@ -213,12 +219,16 @@ __device__ __forceinline__ void c3_epilogue_k(const f32x16 (&acc)[NT], int ob, i
     for (int j = 0; j < NT; ++j) {
         const int t = tbase + j * 32 + c, tc = min(t, T - 1);
         uint32_t oi[16];
-        float rv[16];
+        float rv[16], ma[16], mb[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int o = min(ob + (r >> 2) * 8 + h * 4 + (r & 3), Cout - 1), oc = PS1 ? o : o / ps;
             oi[r] = PS1 ? (uint32_t)o * (uint32_t)T + (uint32_t)tc : ((uint32_t)oc * (uint32_t)T + (uint32_t)tc) * (uint32_t)ps + (uint32_t)(o % ps);  // (polyphase rows: see k_conv1d)
             if (RES) rv[r] = res[oi[r]];
+        }
+        if (E == CODEC_EPI_RES && mean3) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { ma[r] = m0[oi[r]]; mb[r] = m1[oi[r]]; }
         }
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
@@ -229,7 +239,7 @@ __device__ __forceinline__ void c3_epilogue_k(const f32x16 (&acc)[NT], int ob, i
                 float v = acc[j][r] + bv[r];
                 if (E == CODEC_EPI_GELU) v = c3_gelu(v);
                 else if (E == CODEC_EPI_GAMMA_RES) v = rv[r] + gv[r] * v;
-                else if (E == CODEC_EPI_RES) v = rv[r] + v;
+                else if (E == CODEC_EPI_RES) { v = rv[r] + v; if (mean3) v = ((ma[r] + mb[r]) + v) * third; }
                 else if (E == CODEC_EPI_TANH) v = tanhf(v);
                 if (y && o < Cout && t < T) y[oi[r]] = v;
                 v4[rr] = v;
@@ -238,7 +248,8 @@ __device__ __forceinline__ void c3_epilogue_k(const f32x16 (&acc)[NT], int ob, i
             if (ypb && ob8 < Cout && t < T) {
                 uint32_t hi[4], lo[4];
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) c3_split<F16>(post_silu ? c3_silu_fast(v4[rr]) : v4[rr], hi[rr], lo[rr]);
+                for (int rr = 0; rr < 4; ++rr)  // (the folded mean keeps k_mean3_planes' IEEE-division SiLU: bit-identical planes)
+                    c3_split<F16>(post_silu ? (mean3 ? c3_silu(v4[rr]) : c3_silu_fast(v4[rr])) : v4[rr], hi[rr], lo[rr]);
                 uint16_t* d = ypb + ((size_t)(ob8 >> 3) * (PP + T) + PP + t) * 8 + h * 4;
                 *reinterpret_cast<uint2*>(d) = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
                 if constexpr (!F16)
@@ -260,13 +271,14 @@ template <bool F16, int NT, int EPI = -1, bool PS1 = false>
 __device__ __forceinline__ void c3_epilogue(const f32x16 (&acc)[NT], int ob, int tbase, int h, int c, int Cout, int T, int ps,
                                             const float* __restrict__ bias, int epi, const float* __restrict__ res,
                                             const float* __restrict__ gamma, float* __restrict__ y, uint16_t* __restrict__ ypb,
-                                            int post_silu, uint16_t* __restrict__ yco = nullptr) {
+                                            int post_silu, uint16_t* __restrict__ yco = nullptr, const float* __restrict__ m0 = nullptr,
+                                            const float* __restrict__ m1 = nullptr) {
     if constexpr (EPI >= 0) {
-        c3_epilogue_k<F16, NT, EPI, PS1>(acc, ob, tbase, h, c, Cout, T, ps, bias, res, gamma, y, ypb, post_silu, yco);
+        c3_epilogue_k<F16, NT, EPI, PS1>(acc, ob, tbase, h, c, Cout, T, ps, bias, res, gamma, y, ypb, post_silu, yco, m0, m1);
     } else {
         if (epi == CODEC_EPI_GELU) c3_epilogue_k<F16, NT, CODEC_EPI_GELU, false>(acc, ob, tbase, h, c, Cout, T, ps, bias, res, gamma, y, ypb, post_silu, yco);
         else if (epi == CODEC_EPI_GAMMA_RES) c3_epilogue_k<F16, NT, CODEC_EPI_GAMMA_RES, false>(acc, ob, tbase, h, c, Cout, T, ps, bias, res, gamma, y, ypb, post_silu, yco);
-        else if (epi == CODEC_EPI_RES) c3_epilogue_k<F16, NT, CODEC_EPI_RES, false>(acc, ob, tbase, h, c, Cout, T, ps, bias, res, gamma, y, ypb, post_silu, yco);
+        else if (epi == CODEC_EPI_RES) c3_epilogue_k<F16, NT, CODEC_EPI_RES, false>(acc, ob, tbase, h, c, Cout, T, ps, bias, res, gamma, y, ypb, post_silu, yco, m0, m1);
         else if (epi == CODEC_EPI_TANH) c3_epilogue_k<F16, NT, CODEC_EPI_TANH, false>(acc, ob, tbase, h, c, Cout, T, ps, bias, res, gamma, y, ypb, post_silu, yco);
         else c3_epilogue_k<F16, NT, CODEC_EPI_NONE, false>(acc, ob, tbase, h, c, Cout, T, ps, bias, res, gamma, y, ypb, post_silu, yco);
     }
@@ -500,7 +512,8 @@ __global__ __launch_bounds__(256, F16 ? 3 : 2) void k_conv1d_bf3p(const uint16_t
     uint16_t* ypb = yp ? yp + (size_t)blockIdx.z * NPART * (Cout >> 3) * row * 8 : nullptr;
     if (ypb && t0 == 0) c3_zero_pad<F16>(ypb, Cout >> 3, T, o0 >> 3, OT / 8, tid, 256, pc.ci);
     c3_epilogue<F16, NT, EPI, PS1>(acc, o0 + ob, t0 + tb, h, c, Cout, T, ps, bias, epi, res ? res + boff_out : nullptr, gamma,
-                              y ? y + boff_out : nullptr, ypb, post_silu, ypb ? pc.co : nullptr);
+                              y ? y + boff_out : nullptr, ypb, post_silu, ypb ? pc.co : nullptr, pc.mean_a ? pc.mean_a + boff_out : nullptr,
+                              pc.mean_a ? pc.mean_b + boff_out : nullptr);
     C3_TICK(5);
 #ifdef FS_C3_PROF
     if (threadIdx.x == 0)
@@ -568,7 +581,8 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void k_conv1d_bf3t(const uint
         int Tl = T;  // opaque per tile: keeps the epilogue's ~100 row addresses from being hoisted out of the tile loop (200+ VGPRs)
         asm volatile("" : "+s"(Tl));
         c3_epilogue<F16, NT, EPI, PS1>(acc, o0, t0, h, c, Cout, Tl, ps, bias, epi, res ? res + boff_out : nullptr, gamma, y ? y + boff_out : nullptr,
-                                  ypb, post_silu, ypb ? pc.co : nullptr);
+                                  ypb, post_silu, ypb ? pc.co : nullptr, pc.mean_a ? pc.mean_a + boff_out : nullptr,
+                                  pc.mean_a ? pc.mean_b + boff_out : nullptr);
     }
 }
 
@@ -595,9 +609,11 @@ bool codec_conv1d_bf3_ok(int Cin, int Cout, int K, int dil) { return Cin >= 16 &
 template <bool F16>
 static void conv1d_bf3_impl(const float* x, const uint16_t* xp, int B, int Cin, int T, const uint16_t* wp, const float* bias, int Cout, int K,
                             int dil, bool pre_silu, int epi, const float* res, const float* gamma, float* y, uint16_t* yp, bool post_silu, int ps,
-                            hipStream_t st, const uint16_t* ctx_in, uint16_t* ctx_out) {
+                            hipStream_t st, const uint16_t* ctx_in, uint16_t* ctx_out, const float* mean_a, const float* mean_b) {
     constexpr int NPL = F16 ? 2 : 4;
-    const PlaneCtx pc{ctx_in, ctx_out};
+    const PlaneCtx pc{ctx_in, ctx_out, mean_a, mean_b};
+    FS_REQUIRE((mean_a != nullptr) == (mean_b != nullptr) && (!mean_a || (xp && epi == CODEC_EPI_RES && ps == 1)),
+               "the folded ParallelBlock mean needs both partners and a plane-input residual conv");
     FS_REQUIRE((!ctx_in && !ctx_out) || (yp && B == 1 && T >= PP), "streaming contexts need a plane output, one item and >= 64 samples per chunk");
     FS_REQUIRE(codec_conv1d_bf3_ok(Cin, Cout, K, dil), "conv shape outside the bf16x3 kernel's range");
     FS_REQUIRE((x != nullptr) != (xp != nullptr), "exactly one of the f32 input and the plane input");
@@ -737,9 +753,9 @@ static void conv1d_bf3_impl(const float* x, const uint16_t* xp, int B, int Cin, 
 
 void codec_conv1d_bf3(const float* x, const uint16_t* xp, int B, int Cin, int T, const uint16_t* wp, bool f16, const float* bias, int Cout, int K,
                       int dil, bool pre_silu, int epi, const float* res, const float* gamma, float* y, uint16_t* yp, bool post_silu, int ps,
-                      hipStream_t st, const uint16_t* ctx_in, uint16_t* ctx_out) {
-    if (f16) conv1d_bf3_impl<true>(x, xp, B, Cin, T, wp, bias, Cout, K, dil, pre_silu, epi, res, gamma, y, yp, post_silu, ps, st, ctx_in, ctx_out);
-    else conv1d_bf3_impl<false>(x, xp, B, Cin, T, wp, bias, Cout, K, dil, pre_silu, epi, res, gamma, y, yp, post_silu, ps, st, ctx_in, ctx_out);
+                      hipStream_t st, const uint16_t* ctx_in, uint16_t* ctx_out, const float* mean_a, const float* mean_b) {
+    if (f16) conv1d_bf3_impl<true>(x, xp, B, Cin, T, wp, bias, Cout, K, dil, pre_silu, epi, res, gamma, y, yp, post_silu, ps, st, ctx_in, ctx_out, mean_a, mean_b);
+    else conv1d_bf3_impl<false>(x, xp, B, Cin, T, wp, bias, Cout, K, dil, pre_silu, epi, res, gamma, y, yp, post_silu, ps, st, ctx_in, ctx_out, mean_a, mean_b);
 }
 
 void codec_act_split(const float* x, int B, int C, int T, bool silu, uint16_t* planes, bool f16, hipStream_t st, const uint16_t* ctx_in,

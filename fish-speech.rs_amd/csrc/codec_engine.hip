@@ -227,11 +227,26 @@ class Codec final : public CodecBase {
                         const PC pa = pctx(), pb2 = m < 2 ? pctx() : PC{nullptr, nullptr};
                         codec_conv1d_planes(nullptr, curp, B, ch, Tc, conv(res_[s][j][0][m]), dils[m], true, CODEC_EPI_NONE, nullptr, nullptr,
                                             nullptr, t2p, true, st_, pa.ci, pa.co);
+                        if (j == 2 && m == 2 && fold_mean_) {
+                            // the ParallelBlock mean (hifi_gan.rs:114-117) inside the epilogue of the last residual conv: ((acc0 + acc1) + this
+                            // block's output) / 3 goes straight to the next stage's input planes (or, after the last stage, to conv_post's f32
+                            // input) -- the third block's f32 output and the mean kernel's three plane-sized reads never touch memory
+                            if (stage_planes(s + 1)) {
+                                const PC pm = pctx();
+                                codec_conv1d_planes(nullptr, t2p, B, ch, Tc, conv(res_[s][j][1][m]), dils[m], true, CODEC_EPI_RES, cur, nullptr, nullptr,
+                                                    xp, true, st_, pm.ci, pm.co, acc0, acc1);
+                            } else {
+                                codec_conv1d_planes(nullptr, t2p, B, ch, Tc, conv(res_[s][j][1][m]), dils[m], true, CODEC_EPI_RES, cur, nullptr, x,
+                                                    nullptr, true, st_, nullptr, nullptr, acc0, acc1);
+                            }
+                            break;
+                        }
                         codec_conv1d_planes(nullptr, t2p, B, ch, Tc, conv(res_[s][j][1][m]), dils[m], true, CODEC_EPI_RES, cur, nullptr, accs[j],
                                             m < 2 ? accp : nullptr, true, st_, pb2.ci, pb2.co);
                         cur = accs[j]; curp = accp;
                     }
                 }
+                if (fold_mean_) continue;
                 if (stage_planes(s + 1)) {
                     const PC pm = pctx();
                     codec_mean3_planes(acc0, acc1, acc2, B, ch, Tc, true, xp, f16_, st_, pm.ci, pm.co);
@@ -523,6 +538,7 @@ class Codec final : public CodecBase {
     DBuf sctx_p_[2], sctx_f_[2];            // streaming contexts (plane tensors / f32 conv inputs), ping-pong per chunk
     int stream_chunk_ = -1, stream_prec_ = 0;  // -1: no stream open
     std::vector<size_t> packed_off_, packed16_off_;
+    bool fold_mean_ = getenv("FISHRT_VOC_NO_FOLD_MEAN") == nullptr;  // ParallelBlock mean inside the last residual conv's epilogue (A/B switch)
     bool f16_ = true;   // with bf3_: the plane data flow carries single f16 operands (mode 2) instead of bf16 hi / lo pairs (mode 1)
     bool bf3_ = true, use_bf3_now_ = false;  // decode precision mode (fs_codec_set_precision); the encoder always runs exact f32
     int proj_w_ = 0, proj_b_ = 0, up_conv_[2] = {0, 0}, conv_pre_ = 0, conv_post_ = 0, ups_[5] = {0, 0, 0, 0, 0};

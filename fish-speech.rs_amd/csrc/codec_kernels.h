@@ -42,7 +42,10 @@ bool codec_conv1d_bf3_ok(int Cin, int Cout, int K, int dil);
 // output: f32 `y` and / or planes `yp` = split(post_silu ? silu(v) : v) (plain convs only)
 void codec_conv1d_bf3(const float* x, const uint16_t* xp, int B, int Cin, int T, const uint16_t* wp, bool f16, const float* bias, int Cout, int K,
                       int dil, bool pre_silu, int epi, const float* res, const float* gamma, float* y, uint16_t* yp, bool post_silu, int ps,
-                      hipStream_t st, const uint16_t* ctx_in = nullptr, uint16_t* ctx_out = nullptr);
+                      hipStream_t st, const uint16_t* ctx_in = nullptr, uint16_t* ctx_out = nullptr, const float* mean_a = nullptr,
+                      const float* mean_b = nullptr);
+// mean_a / mean_b (plane-input residual convs only): the ParallelBlock mean folded into the epilogue -- the stored / split value is
+// ((mean_a + mean_b) + (res + conv)) / 3, bit-identical to k_mean3_planes / k_mean3 on the three ResBlock outputs.
 // Streaming (fs_codec_stream_*): `ctx_in` = the left context of the plane tensor being written ([parts][C/8][CODEC_PLANE_PAD][8], the last
 // CODEC_PLANE_PAD slots of the same tensor in the previous chunk; null = zeros, i.e. the start of a signal), `ctx_out` receives this
 // chunk's last CODEC_PLANE_PAD slots.  B == 1 and T >= CODEC_PLANE_PAD.
@@ -53,7 +56,7 @@ void codec_mean3_planes(const float* a, const float* b, const float* c, int B, i
 // conv / transposed conv of the plane data flow (decode path, bf16x3 mode): see codec_conv1d_bf3
 void codec_conv1d_planes(const float* x, const uint16_t* xp, int B, int Cin, int T, const ConvW& w, int dil, bool pre_silu, int epi,
                          const float* res, const float* gamma, float* y, uint16_t* yp, bool post_silu, hipStream_t st,
-                         const uint16_t* ctx_in = nullptr, uint16_t* ctx_out = nullptr);
+                         const uint16_t* ctx_in = nullptr, uint16_t* ctx_out = nullptr, const float* mean_a = nullptr, const float* mean_b = nullptr);
 void codec_tconv1d_planes(const uint16_t* xp, int B, int Cin, int Tin, const ConvW& w, int stride, float* y, hipStream_t st);
 // ---- encoder side (FireflyCodec::encode)
 void codec_stft_mag(const float* pcm, int n, int n_fft, int hop, int n_frames, float* lin /*[n_fft/2+1][frames]*/, hipStream_t st);

@@ -476,9 +476,10 @@ void codec_tconv1d(const float* x, int B, int Cin, int Tin, const ConvW& w, int 
 
 void codec_conv1d_planes(const float* x, const uint16_t* xp, int B, int Cin, int T, const ConvW& w, int dil, bool pre_silu, int epi,
                          const float* res, const float* gamma, float* y, uint16_t* yp, bool post_silu, hipStream_t st,
-                         const uint16_t* ctx_in, uint16_t* ctx_out) {
+                         const uint16_t* ctx_in, uint16_t* ctx_out, const float* mean_a, const float* mean_b) {
     FS_REQUIRE(w.wp, "the plane data flow needs packed bf16x3 weights");
-    codec_conv1d_bf3(x, xp, B, Cin, T, w.wp, w.f16, w.b, w.cout, w.k, dil, pre_silu, epi, res, gamma, y, yp, post_silu, 1, st, ctx_in, ctx_out);
+    codec_conv1d_bf3(x, xp, B, Cin, T, w.wp, w.f16, w.b, w.cout, w.k, dil, pre_silu, epi, res, gamma, y, yp, post_silu, 1, st, ctx_in, ctx_out, mean_a,
+                     mean_b);
 }
 
 void codec_tconv1d_planes(const uint16_t* xp, int B, int Cin, int Tin, const ConvW& w, int stride, float* y, hipStream_t st) {

@@ -1294,7 +1294,8 @@ class LM final : public LMBase {
             launch_rows_slow(S, R, st_);
             if (rows_fast) {
                 for (int r0 = 0; r0 < n; r0 += PR_FAST_ROWS) {
-                    const int Rf = std::min(PR_FAST_ROWS, R - r0) >= 4 ? 4 : (std::min(PR_FAST_ROWS, R - r0) >= 2 ? 2 : 1);
+                    // the last group takes the smallest instantiation that holds its requests (n = 5: 4 + 1 rows, n = 6: 4 + 2)
+                    const int left = std::min(PR_FAST_ROWS, n - r0), Rf = left >= 3 ? 4 : left;
                     launch_rows_fast(rows_fast_args(r0, Rf), Rf, rows_sampled, st_);
                 }
             } else {

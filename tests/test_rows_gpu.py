@@ -133,7 +133,7 @@ def _referee(lm, p, mnt, a, b, rp, ignore_eos=True):
     return f, c, gap
 
 
-@pytest.mark.parametrize("n", [2, 3, 4, 5, 8])
+@pytest.mark.parametrize("n", [2, 3, 4, 5, 6, 8])
 def test_rows_match_their_own_generate_call_or_part_at_a_near_tie(lm8, n):
     F, rp = 48, 1.2
     lens = [24 + 37 * i for i in range(n)]

@@ -1055,11 +1055,17 @@ class LM final : public LMBase {
             if (!live) break;
             if (sess_rows_) {
                 use_persist_ = true; use_pslow_ = true; persist_sampled_ = sess_sampled_;
+                // the launch group covers slots [0, top): the smallest instantiations that hold the highest live slot (an 8-slot session with two
+                // live requests in slots 0, 1 pays the 2-row frame, 0.84 ms, not the 8-row one, 1.67 ms); slots are handed out lowest-first
+                int top = 0;
+                for (int b = 0; b < B_; ++b)
+                    if (sess_left_[b] > 0 && !sess_hs_[b].done) top = b + 1;
+                const int Rs = std::min(sess_R_, top <= 2 ? 2 : (top <= 4 ? 4 : 8));
                 for (int i = 0; i < chunk; ++i) {
                     set_bucket(longest + i + 1);
-                    launch_rows_slow(rows_slow_args(sess_R_), sess_R_, st_);
-                    for (int r0 = 0; r0 < B_; r0 += PR_FAST_ROWS) {
-                        const int left = std::min(PR_FAST_ROWS, sess_R_ - r0), Rf = left >= 4 ? 4 : (left >= 2 ? 2 : 1);
+                    launch_rows_slow(rows_slow_args(Rs), Rs, st_);
+                    for (int r0 = 0; r0 < top; r0 += PR_FAST_ROWS) {
+                        const int left = std::min(PR_FAST_ROWS, top - r0), Rf = left >= 3 ? 4 : left;
                         launch_rows_fast(rows_fast_args(r0, Rf), Rf, sess_sampled_, st_);
                     }
                 }

@@ -1907,6 +1907,7 @@ class LM final : public LMBase {
         A.kv_pool = kv_pool_.p; A.layer_half = (size_t)n_pages_ * page_elems_;
         A.page_table = d_page_table_.as<int>(); A.pt_stride = max_pages_;
         A.n_sl = std::max(1, std::min(nc_launch_, 16 / R));
+        if (const char* c = getenv("FISHRT_ROWS_NSL_MAX")) A.n_sl = std::max(1, std::min(A.n_sl, atoi(c)));  // experiment: fewer, longer attention slices
         A.edges = d_redges_s_.as<unsigned long long>();
         A.ctl = d_rctl_s_.as<uint32_t>();
         A.prof = getenv("FISHRT_PERSIST_PROF") ? reinterpret_cast<unsigned long long*>(d_rctl_s_.as<uint32_t>() + 16) : nullptr;

@@ -98,24 +98,27 @@ __device__ __forceinline__ int bs_wave_scan(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
     return v;
 }
-// 32 consecutive floats of an LDS array with eight independent 16-byte reads; entries >= n read as +0.0 (x + 0.0f == x for the
+// CH (32 | 16) consecutive floats of an LDS array with CH / 4 independent 16-byte reads; entries >= n read as +0.0 (x + 0.0f == x for the
 // non-negative sums taken here)
-__device__ __forceinline__ void bs_fetch32(const float* a, int j, int n, float (&v)[32]) {
+template <int CH>
+__device__ __forceinline__ void bs_fetch(const float* a, int j, int n, float (&v)[CH]) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < CH / 4; ++q) {
         const float4 t = *reinterpret_cast<const float4*>(a + j + 4 * q);
         v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
     }
-    if (j + 32 > n) {
+    if (j + CH > n) {
 #pragma unroll
-        for (int e = 0; e < 32; ++e) if (j + e >= n) v[e] = 0.f;
+        for (int e = 0; e < CH; ++e) if (j + e >= n) v[e] = 0.f;
     }
 }
 
 // lv: this thread's EPT logits (already penalised / masked), candidates tid * EPT + s; entries at or beyond n are ignored.
 // word: the StdRng output word this draw would consume.  Returns the picked candidate index on every thread; *consumed = 1 iff the
 // draw consumed `word` (rand's WeightedIndex needs a positive total).
-template <int NT, int EPT>
+// CH: chunk of the three sequential f32 chains (32: fewest loop trips; 16: 16 registers less at their peak -- the persistent fast decoder calls
+// with its weights resident in all but ~20 registers, and every spilled value is a scratch round trip per decision)
+template <int NT, int EPT, int CH = 32>
 __device__ int bsample(const float (&lv)[EPT], int n, int kk, float inv_t, float top_p, uint32_t word, int* consumed, BSampLds& S,
                        bool batch = false, double top_p64 = 0.0) {  // batch: BatchedLogitsProcessor's f64 comparison (sampling/mod.rs:68)
     static_assert(NT % 64 == 0 && NT >= BS_MAXK + 64 && NT * EPT <= 2048, "block shape");
@@ -266,14 +269,14 @@ __device__ int bsample(const float (&lv)[EPT], int n, int kk, float inv_t, float
     // ---- D: ascending-index sum (wave 0) || ranks by counting (threads 64 .. 64 + kk)
     if (wv == 0) {
         float cum = 0.f;
-        for (int j = 0; j < kk; j += 32) {
-            float v[32];
-            bs_fetch32(S.kp, j, kk, v);
+        for (int j = 0; j < kk; j += CH) {
+            float v[CH];
+            bs_fetch<CH>(S.kp, j, kk, v);
 #pragma unroll
-            for (int e = 0; e < 32; ++e) { cum += v[e]; v[e] = cum; }
+            for (int e = 0; e < CH; ++e) { cum += v[e]; v[e] = cum; }
             if (lane == 0) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(S.cumk + j + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+                for (int q = 0; q < CH / 4; ++q) *reinterpret_cast<float4*>(S.cumk + j + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
             }
         }
         if (lane == 0) S.misc[6] = __float_as_int(cum);
@@ -315,13 +318,13 @@ __device__ int bsample(const float (&lv)[EPT], int n, int kk, float inv_t, float
         if (wv == 0) {
             float cum = 0.f;
             int first = -1;
-            for (int j = 0; j < kk && first < 0; j += 32) {
-                float v[32];
-                bs_fetch32(S.sp, j, kk, v);
+            for (int j = 0; j < kk && first < 0; j += CH) {
+                float v[CH];
+                bs_fetch<CH>(S.sp, j, kk, v);
 #pragma unroll
-                for (int e = 0; e < 32; ++e) { cum += v[e]; v[e] = cum; }
+                for (int e = 0; e < CH; ++e) { cum += v[e]; v[e] = cum; }
 #pragma unroll
-                for (int e = 31; e >= 0; --e) if (j + e < kk && v[e] >= top_p) first = j + e;
+                for (int e = CH - 1; e >= 0; --e) if (j + e < kk && v[e] >= top_p) first = j + e;
             }
             if (lane == 0) S.misc[2] = first < 0 ? kk : first + 1;
         }
@@ -343,14 +346,14 @@ __device__ int bsample(const float (&lv)[EPT], int n, int kk, float inv_t, float
             for (int s = 0; s < 4; ++s)
                 if (lane * 4 + s < kk && ws[s] != 0.f) { S.sp[p2] = ws[s]; S.rnk[p2] = lane * 4 + s; ++p2; }
             float cum = 0.f;  // (one wave: its LDS operations stay in order)
-            for (int j = 0; j < m; j += 32) {
-                float v[32];
-                bs_fetch32(S.sp, j, m, v);
+            for (int j = 0; j < m; j += CH) {
+                float v[CH];
+                bs_fetch<CH>(S.sp, j, m, v);
 #pragma unroll
-                for (int e = 0; e < 32; ++e) { cum += v[e]; v[e] = cum; }
+                for (int e = 0; e < CH; ++e) { cum += v[e]; v[e] = cum; }
                 if (lane == 0) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(S.cumk + j + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+                    for (int q = 0; q < CH / 4; ++q) *reinterpret_cast<float4*>(S.cumk + j + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
                 }
             }
             if (lane == 0) { S.misc[5] = m; S.misc[6] = __float_as_int(cum); }

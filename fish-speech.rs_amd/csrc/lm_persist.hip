@@ -245,7 +245,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
         int idx;
         if (SAMPLED) {
             int used = 0;
-            idx = bsample<PF_THREADS, 4>(lv, n, cfg.top_k, (float)(1.0 / (double)cfg.temp), cfg.top_p, s_words[0], &used, samp);
+            idx = bsample<PF_THREADS, 4, 8>(lv, n, cfg.top_k, (float)(1.0 / (double)cfg.temp), cfg.top_p, s_words[0], &used, samp);
             n_draws += used;
         } else {  // host ArgMax rule: the LAST maximal index (per thread ascending, then value / index maxima)
             float bv = lv[0];
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
                     int used = 0;
                     __syncthreads();  // (the scratch aliases this stage's own LDS: nobody is still reading the previous decision's)
                     const float lvv[2] = {lv0, lv1};
-                    gi = bsample<PF_THREADS, 2>(lvv, 1024, cfg.top_k, (float)(1.0 / (double)cfg.temp), cfg.top_p, s_words[n_draws], &used, samp);
+                    gi = bsample<PF_THREADS, 2, 8>(lvv, 1024, cfg.top_k, (float)(1.0 / (double)cfg.temp), cfg.top_p, s_words[n_draws], &used, samp);
                     n_draws += used;
                     PF_TICK(6);
                 } else {

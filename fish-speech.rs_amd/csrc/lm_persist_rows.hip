@@ -799,7 +799,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                 if (lv_r && (b >> 3) == r) {
                     int used = 0;
                     const int* cf = s_ring + r * RR + 168 + 16;
-                    const int idx = bsample<PF_THREADS, 4>(lv, n, cf[8], (float)(1.0 / (double)__int_as_float(cf[6])), __int_as_float(cf[7]),
+                    const int idx = bsample<PF_THREADS, 4, 8>(lv, n, cf[8], (float)(1.0 / (double)__int_as_float(cf[6])), __int_as_float(cf[7]),
                                                            (uint32_t)s_ring[r * RR + 168 + 32], &used, samp);
                     if (tid < 2) pub(0u, b & 7, r, tid, epoch * 256u + 1u, __uint_as_float((uint32_t)idx | ((uint32_t)used << 16)));
                 }
@@ -1275,7 +1275,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                                 const int* cf = ring + 168 + 16;
                                 const float lvv[2] = {lv0, lv1};
                                 __syncthreads();  // (the sampler's scratch aliases the staging tiles: every wave is past this pass's last S3)
-                                const int gi = bsample<PF_THREADS, 2>(lvv, 1024, cf[8], (float)(1.0 / (double)__int_as_float(cf[6])), __int_as_float(cf[7]),
+                                const int gi = bsample<PF_THREADS, 2, 8>(lvv, 1024, cf[8], (float)(1.0 / (double)__int_as_float(cf[6])), __int_as_float(cf[7]),
                                                                       (uint32_t)ring[168 + 32 + n_draws[r]], &used, samp);
                                 if (tid < 2) pub(e, b & 7, r, tid, tag0 + e + 1, __uint_as_float((uint32_t)gi | ((uint32_t)used << 16)));
                             }

@@ -9,7 +9,7 @@ p = bench.default_voice_prompt(fcfg.FISH_1_5_TOKENS)
 M = 256 + p.shape[1] - 2
 for name, kw in (("greedy", dict(temp=0.0, top_p=1.0, top_k=0)), ("temp0.7 top_p0.8 top_k256", dict(temp=0.7, top_p=0.8, top_k=256)),
                  ("temp0.7 top_p0.9 top_k50", dict(temp=0.7, top_p=0.9, top_k=50)),
-                 ("temp0.05 top_p0.8 top_k256 (peaked rows)", dict(temp=0.05, top_p=0.8, top_k=256)), ("temp0.7 top_p0.8 top_k0", dict(temp=0.7, top_p=0.8, top_k=0))):
+                 ("temp0.05 top_p0.8 top_k256 (sharper rows)", dict(temp=0.05, top_p=0.8, top_k=256)), ("temp0.02 top_p0.8 top_k256 (peaked rows)", dict(temp=0.02, top_p=0.8, top_k=256)), ("temp0.7 top_p0.8 top_k0", dict(temp=0.7, top_p=0.8, top_k=0))):
     for _ in range(2):
         lm.clear_slow_layer_caches()
         out = lm.generate_blocking(p, M, repetition_penalty=1.2, seed=1, ignore_eos=True, **kw)

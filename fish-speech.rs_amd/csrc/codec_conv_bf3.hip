@@ -586,6 +586,120 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void k_conv1d_bf3t(const uint
     }
 }
 
+
+// ---- one ResBlock pair of the thin late stages in ONE kernel (f16 mode): x' = x + conv2(silu(conv1(silu(x)))), both convs dilated by `dil`
+// (hifi_gan.rs:74-85).  The intermediate never touches memory: a wave computes conv1 on its NTO output tiles PLUS the NH tiles to their left
+// (the causal halo of conv2, recomputed by the left neighbour's wave as well), activates / rounds it exactly as the plane-writing epilogue would
+// (bias, c3_silu_fast, f16), parks it in its own LDS scratch in B-operand order, and runs conv2 from there; the epilogue is the residual
+// epilogue of the separate kernel (f32 residual stream in / out, next conv's planes, streaming context, folded ParallelBlock mean).  Same
+// products in the same order as the two separate kernels: bit-identical output.  Per pair the planes of the intermediate (one write + one
+// read of C x T x 2 bytes) and one launch disappear: 8 -> 6 plane-passes of HBM traffic on convs that are bandwidth-bound.
+// Positions in front of the signal (t < 0) take the intermediate's streaming context (or zeros); the wave that owns t in [T - PP, T) saves it.
+template <int K, int NIB, int NTO, int NH, int NW>
+__global__ __launch_bounds__(NW * 64) void k_respair_f16t(const uint16_t* __restrict__ xp, int T, const uint16_t* __restrict__ w1p, const uint16_t* __restrict__ w2p,
+                                                   int Cp, const float* __restrict__ b1, const float* __restrict__ b2, int dil, const float* __restrict__ res,
+                                                   float* __restrict__ y, uint16_t* __restrict__ yp, int nwt, PlaneCtx pc, const uint16_t* __restrict__ mci,
+                                                   uint16_t* __restrict__ mco) {
+    constexpr int C = 16 * NIB, CG = 2 * NIB, NT1 = NTO + NH, HS = NT1 * 32, WCH = NIB * K * 2 * 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32x4* ws1 = reinterpret_cast<u32x4*>(smem_raw);  // [NIB][K][2][32]
+    u32x4* ws2 = ws1 + WCH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    u32x4* hs = ws2 + WCH + (size_t)wave * CG * HS;   // this wave's intermediate: [CG][HS] slots of 8 channels
+    const int h = lane >> 5, c = lane & 31;
+    const int halo = (K - 1) * dil;
+    const size_t row = (size_t)(PP + T);
+    for (int e = tid; e < WCH; e += NW * 64) {
+        const int kp = e >> 5, o = e & 31;
+        ws1[e] = *reinterpret_cast<const u32x4*>(w1p + ((size_t)kp * Cp + o) * 8);
+        ws2[e] = *reinterpret_cast<const u32x4*>(w2p + ((size_t)kp * Cp + o) * 8);
+    }
+    __syncthreads();
+    const u32x4* xpb = reinterpret_cast<const u32x4*>(xp) + (size_t)blockIdx.z * CG * row;
+    const size_t boff = (size_t)blockIdx.z * C * T;
+    uint16_t* ypb = yp ? yp + (size_t)blockIdx.z * CG * row * 8 : nullptr;
+    if (ypb && blockIdx.x == 0) c3_zero_pad<true>(ypb, CG, T, 0, CG, tid, NW * 64, pc.ci);
+    float bv1[4 * CG > 16 ? 16 : 4 * CG];
+#pragma unroll
+    for (int r = 0; r < 4 * CG; ++r) bv1[r] = b1[(r >> 2) * 8 + h * 4 + (r & 3)];
+    for (int wt = blockIdx.x * NW + wave; wt < nwt; wt += gridDim.x * NW) {
+        const int t0 = wt * (32 * NTO), s0 = t0 - 32 * NH;
+        // ---- conv1 on [s0, t0 + 32 NTO)
+        {
+            f32x16 acc[NT1];
+#pragma unroll
+            for (int j = 0; j < NT1; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+            // slot index of (tile j, step i) in a plane row, clamped at the row's first slot (only the first tiles of a signal reach in front of
+            // it, and what they compute there is replaced by the context below)
+            const int base = PP + s0 + c - halo;
+            auto bsrc = [&](int i, int j) {
+                const int idx = max(base + 32 * j + (i % K) * dil, 0);
+                return xpb[(size_t)(2 * (i / K) + h) * row + idx];
+            };
+            u32x4 bh[NT1], nb[NT1];
+#pragma unroll
+            for (int j = 0; j < NT1; ++j) bh[j] = bsrc(0, j);
+#pragma unroll 2
+            for (int i = 0; i < NIB * K; ++i) {
+                if (i + 1 < NIB * K) {
+#pragma unroll
+                    for (int j = 0; j < NT1; ++j) nb[j] = bsrc(i + 1, j);
+                }
+                const u32x4 a = ws1[(i * 2 + h) * 32 + c];
+#pragma unroll
+                for (int j = 0; j < NT1; ++j) acc[j] = c3_mma<true>(a, a, bh[j], bh[j], acc[j]);
+#pragma unroll
+                for (int j = 0; j < NT1; ++j) bh[j] = nb[j];
+            }
+            // ---- bias, SiLU, f16 -> this wave's scratch (B-operand slots), exactly what the plane-writing epilogue stores
+#pragma unroll
+            for (int j = 0; j < NT1; ++j) {
+                const int s = s0 + 32 * j + c;
+#pragma unroll
+                for (int q4 = 0; q4 < CG; ++q4) {
+                    uint32_t hi[4], lo_;
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) c3_split<true>(c3_silu_fast(acc[j][q4 * 4 + rr] + bv1[q4 * 4 + rr]), hi[rr], lo_);
+                    uint2 v = make_uint2(hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16));
+                    if (s < 0) {  // in front of the signal: the previous chunk's last PP slots, or zeros
+                        v = make_uint2(0u, 0u);
+                        if (mci && s >= -PP) v = *reinterpret_cast<const uint2*>(mci + ((size_t)q4 * PP + (PP + s)) * 8 + h * 4);
+                    }
+                    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(hs + (size_t)q4 * HS + 32 * j + c) + h * 4) = v;
+                    if (mco && j >= NH && s >= T - PP && s < T)
+                        *reinterpret_cast<uint2*>(mco + ((size_t)q4 * PP + (s - (T - PP))) * 8 + h * 4) = v;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (one wave: its LDS operations complete in order; nothing to synchronise with)
+        __builtin_amdgcn_wave_barrier();
+        // ---- conv2 from the scratch
+        f32x16 acc2[NTO];
+#pragma unroll
+        for (int j = 0; j < NTO; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
+        const u32x4* hb = hs + (32 * NH - halo) + c;
+#pragma unroll 2
+        for (int i = 0; i < NIB * K; ++i) {
+            const u32x4 a = ws2[(i * 2 + h) * 32 + c];
+            const u32x4* hsrc = hb + (size_t)(2 * (i / K) + h) * HS + (i % K) * dil;
+            u32x4 bb[NTO];
+#pragma unroll
+            for (int j = 0; j < NTO; ++j) bb[j] = hsrc[32 * j];
+#pragma unroll
+            for (int j = 0; j < NTO; ++j) acc2[j] = c3_mma<true>(a, a, bb[j], bb[j], acc2[j]);
+        }
+        __builtin_amdgcn_wave_barrier();  // the next tile's conv1 overwrites the scratch
+        int Tl = T;
+        asm volatile("" : "+s"(Tl));
+        c3_epilogue<true, NTO, CODEC_EPI_RES, true>(acc2, 0, t0, h, c, C, Tl, 1, b2, CODEC_EPI_RES, res + boff, nullptr, y ? y + boff : nullptr, ypb, 1,
+                                                  ypb ? pc.co : nullptr, pc.mean_a ? pc.mean_a + boff : nullptr, pc.mean_a ? pc.mean_b + boff : nullptr);
+    }
+}
+
 }  // namespace
 
 size_t codec_pack_bf3_elems(int Cin, int K, int Cout, bool f16) {
@@ -756,6 +870,43 @@ void codec_conv1d_bf3(const float* x, const uint16_t* xp, int B, int Cin, int T,
                       hipStream_t st, const uint16_t* ctx_in, uint16_t* ctx_out, const float* mean_a, const float* mean_b) {
     if (f16) conv1d_bf3_impl<true>(x, xp, B, Cin, T, wp, bias, Cout, K, dil, pre_silu, epi, res, gamma, y, yp, post_silu, ps, st, ctx_in, ctx_out, mean_a, mean_b);
     else conv1d_bf3_impl<false>(x, xp, B, Cin, T, wp, bias, Cout, K, dil, pre_silu, epi, res, gamma, y, yp, post_silu, ps, st, ctx_in, ctx_out, mean_a, mean_b);
+}
+
+bool codec_respair_ok(int C, int K, int dil, bool f16) {
+    return f16 && (C == 16 || C == 32) && (K == 3 || K == 7 || K == 11) && (K - 1) * dil <= CODEC_PLANE_PAD && !getenv("FISHRT_VOC_NO_PAIR_FUSION");
+}
+
+void codec_respair_f16(const uint16_t* xp, int B, int C, int T, const uint16_t* w1p, const float* b1, const uint16_t* w2p, const float* b2, int K, int dil,
+                       const float* res, float* y, uint16_t* yp, hipStream_t st, const uint16_t* mid_ctx_in, uint16_t* mid_ctx_out, const uint16_t* ctx_in,
+                       uint16_t* ctx_out, const float* mean_a, const float* mean_b) {
+    FS_REQUIRE(codec_respair_ok(C, K, dil, true), "ResBlock pair outside the fused kernel's range");
+    FS_REQUIRE(res && (y || yp), "the fused ResBlock pair needs the residual input and an output");
+    FS_REQUIRE((mean_a != nullptr) == (mean_b != nullptr), "the folded ParallelBlock mean needs both partners");
+    FS_REQUIRE((!mid_ctx_in && !mid_ctx_out && !ctx_in && !ctx_out) || (B == 1 && T >= PP), "streaming contexts need one item and >= 64 samples per chunk");
+    const PlaneCtx pc{ctx_in, ctx_out, mean_a, mean_b};
+    const int Cp = 64, halo = (K - 1) * dil, nib = C / 16;
+    constexpr int NTO = 4;
+    const int nwt = (T + 32 * NTO - 1) / (32 * NTO);
+    auto go = [&](auto kern, int NW, int NH) {
+        const size_t smem = 16 * ((size_t)2 * nib * K * 2 * 32 + (size_t)NW * 2 * nib * (NTO + NH) * 32);
+        FS_REQUIRE(smem <= 160 * 1024, "fused ResBlock pair does not fit LDS");
+        if (smem > 64 * 1024) {
+            static thread_local std::set<const void*> raised;
+            if (raised.insert((const void*)kern).second) FS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        }
+        const int per_cu = std::max(1, (int)((150 * 1024) / smem));
+        const int gx = std::max(1, std::min((nwt + NW - 1) / NW, 256 * per_cu / std::max(1, B)));
+        hipLaunchKernelGGL(kern, dim3(gx, 1, B), dim3(NW * 64), smem, st, xp, T, w1p, w2p, Cp, b1, b2, dil, res, y, yp, nwt, pc, mid_ctx_in, mid_ctx_out);
+    };
+#define FS_PAIR(KK, NIBv, NWv)                                                    \
+    do {                                                                          \
+        if (halo <= 32) go(k_respair_f16t<KK, NIBv, NTO, 1, NWv>, NWv, 1);        \
+        else go(k_respair_f16t<KK, NIBv, NTO, 2, NWv>, NWv, 2);                   \
+    } while (0)
+    if (nib == 1) { if (K == 3) FS_PAIR(3, 1, 4); else if (K == 7) FS_PAIR(7, 1, 4); else FS_PAIR(11, 1, 4); }
+    else { if (K == 3) FS_PAIR(3, 2, 8); else if (K == 7) FS_PAIR(7, 2, 8); else FS_PAIR(11, 2, 8); }
+#undef FS_PAIR
+    FS_HIP(hipGetLastError());
 }
 
 void codec_act_split(const float* x, int B, int C, int T, bool silu, uint16_t* planes, bool f16, hipStream_t st, const uint16_t* ctx_in,

@@ -225,6 +225,27 @@ class Codec final : public CodecBase {
                     const uint16_t* curp = t1p;
                     for (int m = 0; m < 3; ++m) {
                         const PC pa = pctx(), pb2 = m < 2 ? pctx() : PC{nullptr, nullptr};
+                        const ConvW w1 = conv(res_[s][j][0][m]), w2 = conv(res_[s][j][1][m]);
+                        if (w1.f16 && w2.f16 && w1.k == w2.k && codec_respair_ok(ch, w1.k, dils[m], true)) {
+                            // thin stages, f16 mode: the pair in ONE kernel (the intermediate stays in LDS).  Its output planes go to the buffer the
+                            // pair does not read (other waves still read the input planes' halo): t1p -> accp -> t2p
+                            uint16_t* outp = curp == accp ? t2p : accp;
+                            if (j == 2 && m == 2 && fold_mean_) {
+                                if (stage_planes(s + 1)) {
+                                    const PC pm = pctx();
+                                    codec_respair_f16(curp, B, ch, Tc, w1.wp, w1.b, w2.wp, w2.b, w1.k, dils[m], cur, nullptr, xp, st_, pa.ci, pa.co, pm.ci, pm.co,
+                                                      acc0, acc1);
+                                } else {
+                                    codec_respair_f16(curp, B, ch, Tc, w1.wp, w1.b, w2.wp, w2.b, w1.k, dils[m], cur, x, nullptr, st_, pa.ci, pa.co, nullptr, nullptr,
+                                                      acc0, acc1);
+                                }
+                                break;
+                            }
+                            codec_respair_f16(curp, B, ch, Tc, w1.wp, w1.b, w2.wp, w2.b, w1.k, dils[m], cur, accs[j], m < 2 ? outp : nullptr, st_, pa.ci, pa.co,
+                                              pb2.ci, pb2.co);
+                            cur = accs[j]; curp = outp;
+                            continue;
+                        }
                         codec_conv1d_planes(nullptr, curp, B, ch, Tc, conv(res_[s][j][0][m]), dils[m], true, CODEC_EPI_NONE, nullptr, nullptr,
                                             nullptr, t2p, true, st_, pa.ci, pa.co);
                         if (j == 2 && m == 2 && fold_mean_) {

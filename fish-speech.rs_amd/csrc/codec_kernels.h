@@ -58,6 +58,13 @@ void codec_conv1d_planes(const float* x, const uint16_t* xp, int B, int Cin, int
                          const float* res, const float* gamma, float* y, uint16_t* yp, bool post_silu, hipStream_t st,
                          const uint16_t* ctx_in = nullptr, uint16_t* ctx_out = nullptr, const float* mean_a = nullptr, const float* mean_b = nullptr);
 void codec_tconv1d_planes(const uint16_t* xp, int B, int Cin, int Tin, const ConvW& w, int stride, float* y, hipStream_t st);
+// one ResBlock pair x' = x + conv2(silu(conv1(silu(x)))) of a thin stage (C = 16 | 32, f16 mode) in one kernel: the intermediate stays in LDS
+// (codec_conv_bf3.hip: k_respair_f16t).  xp = planes of silu(x), res = x (f32); outputs as codec_conv1d_bf3's residual conv.  mid_ctx_*: the
+// streaming context of the INTERMEDIATE's planes (the tensor that is no longer written), ctx_*: of the output planes.
+bool codec_respair_ok(int C, int K, int dil, bool f16);
+void codec_respair_f16(const uint16_t* xp, int B, int C, int T, const uint16_t* w1p, const float* b1, const uint16_t* w2p, const float* b2, int K, int dil,
+                       const float* res, float* y, uint16_t* yp, hipStream_t st, const uint16_t* mid_ctx_in = nullptr, uint16_t* mid_ctx_out = nullptr,
+                       const uint16_t* ctx_in = nullptr, uint16_t* ctx_out = nullptr, const float* mean_a = nullptr, const float* mean_b = nullptr);
 // ---- encoder side (FireflyCodec::encode)
 void codec_stft_mag(const float* pcm, int n, int n_fft, int hop, int n_frames, float* lin /*[n_fft/2+1][frames]*/, hipStream_t st);
 void codec_mel_log(const float* lin, const float* fb /*[nf][n_mels]*/, int nf, int n_mels, int F, float* mel /*[n_mels][F]*/, hipStream_t st);

@@ -903,8 +903,12 @@ void codec_respair_f16(const uint16_t* xp, int B, int C, int T, const uint16_t* 
         if (halo <= 32) go(k_respair_f16t<KK, NIBv, NTO, 1, NWv>, NWv, 1);        \
         else go(k_respair_f16t<KK, NIBv, NTO, 2, NWv>, NWv, 2);                   \
     } while (0)
-    if (nib == 1) { if (K == 3) FS_PAIR(3, 1, 4); else if (K == 7) FS_PAIR(7, 1, 4); else FS_PAIR(11, 1, 4); }
-    else { if (K == 3) FS_PAIR(3, 2, 8); else if (K == 7) FS_PAIR(7, 2, 8); else FS_PAIR(11, 2, 8); }
+    // waves per block (the two weight sets are shared by a block's waves; every wave owns 2 nib x 6 KB of scratch): tuning knobs
+    static const int nw1 = getenv("FISHRT_PAIR_NW1") ? atoi(getenv("FISHRT_PAIR_NW1")) : 4, nw2 = getenv("FISHRT_PAIR_NW2") ? atoi(getenv("FISHRT_PAIR_NW2")) : 8;
+#define FS_PAIRK(NIBv, NWv) do { if (K == 3) FS_PAIR(3, NIBv, NWv); else if (K == 7) FS_PAIR(7, NIBv, NWv); else FS_PAIR(11, NIBv, NWv); } while (0)
+    if (nib == 1) { if (nw1 == 8) FS_PAIRK(1, 8); else FS_PAIRK(1, 4); }
+    else { if (nw2 == 4) FS_PAIRK(2, 4); else FS_PAIRK(2, 8); }
+#undef FS_PAIRK
 #undef FS_PAIR
     FS_HIP(hipGetLastError());
 }

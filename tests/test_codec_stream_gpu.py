@@ -60,3 +60,33 @@ def test_stream_errors():
     with pytest.raises(RuntimeError, match="plane data flow"):
         tiny.stream_begin()
     tiny.close()
+
+
+def test_fused_vocoder_kernels_are_bit_identical_to_the_separate_ones(monkeypatch):
+    """f16 mode: the thin stages' ResBlock pairs run as ONE kernel (intermediate in LDS, halo recomputed) and the ParallelBlock mean sits in the
+    last residual conv's epilogue.  Both are the same f32 / f16 operations in the same order as the separate kernels, so the PCM must be
+    identical bit for bit -- one-shot at lengths that are not multiples of the 128-sample tile, and streamed in uneven chunks (the
+    intermediate's streaming context is carried although the intermediate itself is never written)."""
+    codes = np.random.RandomState(3).randint(0, 1000, (1, 8, 83)).astype(np.uint32)
+    pcm = {}
+    for name, env in (("fused", {}), ("no_pair", {"FISHRT_VOC_NO_PAIR_FUSION": "1"}), ("no_mean", {"FISHRT_VOC_NO_FOLD_MEAN": "1"}),
+                      ("neither", {"FISHRT_VOC_NO_PAIR_FUSION": "1", "FISHRT_VOC_NO_FOLD_MEAN": "1"})):
+        for k in ("FISHRT_VOC_NO_PAIR_FUSION", "FISHRT_VOC_NO_FOLD_MEAN"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = fishrt.FireflyCodec(0, precision="f16").load_synthetic(0xC0DEC)  # (the mean switch is read when the handle is created)
+        one = c.decode(codes)
+        parts = []
+        c.stream_begin()
+        for a, b in ((0, 17), (17, 40), (40, 83)):
+            parts.append(c.stream_decode(np.ascontiguousarray(codes[0, :, a:b])))
+        c.stream_end()
+        assert np.array_equal(np.concatenate(parts), one[0, 0]), name
+        for T in (16, 31):
+            pcm[(name, T)] = c.decode(np.ascontiguousarray(codes[:, :, :T]))
+        pcm[(name, 83)] = one
+        c.close()
+    for T in (16, 31, 83):
+        for name in ("no_pair", "no_mean", "neither"):
+            assert np.array_equal(pcm[("fused", T)], pcm[(name, T)]), (name, T)

@@ -4,7 +4,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.OrderedDict()
 for r in rows:
     n = r["Kernel_Name"]
-    if not any(s in n for s in ("conv1d", "act_split", "tconv", "dwconv", "mean3", "stft", "mel", "layernorm", "fsq")):
+    if not any(s in n for s in ("conv1d", "respair", "act_split", "tconv", "dwconv", "mean3", "stft", "mel", "layernorm", "fsq")):
         continue
     short = n.replace("(anonymous namespace)::", "").split("(")[0].replace("void fs::", "").replace("fs::", "")
     key = (short, r.get("Grid_Size_X") or r.get("Grid_Size"), r.get("Grid_Size_Y"))

@@ -860,6 +860,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
         // row pairs (Wqkv 5 + Wo 4 per layer, 4 head rows): streamed one stage ahead from the dword-major image (L2-resident, 80 KB per CU)
         const uint32_t* rpi = A.rowpairs + (size_t)b * 40 * PF_THREADS;
         uint32_t wq5[5], wo4[4], wh4[4];
+        uint2 wo8[4];  // R >= 2: Wo row pairs of the lane's FOUR attention dims (half-block attention, see S2)
 #pragma unroll
         for (int i = 0; i < 5; ++i) wq5[i] = rpi[(unsigned)(i * PF_THREADS + tid)];
         u32x4 w13v[PF_LAYERS][8];
@@ -914,7 +915,10 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                         PF_TICK(9);
                     }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) wo4[i] = rpi[(unsigned)((9 * l + 5 + i) * PF_THREADS + tid)];  // next stage's row pairs
+                    for (int i = 0; i < 4; ++i) {  // next stage's row pairs
+                        if constexpr (R == 1) wo4[i] = rpi[(unsigned)((9 * l + 5 + i) * PF_THREADS + tid)];
+                        else wo8[i] = *reinterpret_cast<const uint2*>(rpi + (unsigned)((9 * l + 5 + i) * PF_THREADS + 2 * (tid & 255)));
+                    }
                     // all rows' partial sums through halving trees of at most 16 values (two rows each: 32 live accumulators cost registers
                     // the resident W13 fragments need)
                     constexpr int RG = R < 2 ? R : 2;
@@ -987,69 +991,136 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                                 reinterpret_cast<uint32_t*>(A.cap + (((size_t)r * A.cap_frames + A.state[r].frame) * 9 + 1 + cb) * 2048 + 1025)[l * 128 + tid] =
                                     tid < 64 ? kc[((r * PF_LAYERS + l) * 8 + cb) * 64 + tid] : vc[((r * PF_LAYERS + l) * 8 + cb) * 64 + tid - 64];
                     }
-                    const int h = tid >> 5, g = h >> 3, p = (tid >> 2) & 7, qd = tid & 3, j = tid & 31;
-                    // rows in a REAL loop, two per iteration: unrolled over all rows the scheduler issues every row's LDS reads up front (~24 registers
-                    // per row), one at a time each row is a ~1 us chain of dependent LDS / transcendental / cross-lane latencies
-                    constexpr int RI = R < 2 ? R : 2;
+                    if constexpr (R == 1) {
+                        const int h = tid >> 5, g = h >> 3, p = (tid >> 2) & 7, qd = tid & 3, j = tid & 31;
+                        // rows in a REAL loop, two per iteration: unrolled over all rows the scheduler issues every row's LDS reads up front (~24 registers
+                        // per row), one at a time each row is a ~1 us chain of dependent LDS / transcendental / cross-lane latencies
+                        constexpr int RI = R < 2 ? R : 2;
 #pragma unroll 1
-                    for (int r0 = 0; r0 < R; r0 += RI) {
-                        float accs[RI];
+                        for (int r0 = 0; r0 < R; r0 += RI) {
+                            float accs[RI];
 #pragma unroll
-                        for (int i2 = 0; i2 < RI; ++i2) {
-                            const int r = r0 + i2;
+                            for (int i2 = 0; i2 < RI; ++i2) {
+                                const int r = r0 + i2;
+                                const float4* qp = reinterpret_cast<const float4*>(qs + r * 1024 + h * 64 + qd * 16);
+                                const u32x4* kp = reinterpret_cast<const u32x4*>(kc + ((r * PF_LAYERS + l) * 8 + p) * 64 + g * 32 + qd * 8);
+                                float acc = 0.f;
+#pragma unroll
+                                for (int i = 0; i < 2; ++i) {
+                                    const u32x4 kw = kp[i];
+                                    const float4 q0 = qp[2 * i], q1 = qp[2 * i + 1];
+                                    acc = fmaf(q0.x, bf_lo(kw.x), acc); acc = fmaf(q0.y, bf_hi(kw.x), acc);
+                                    acc = fmaf(q0.z, bf_lo(kw.y), acc); acc = fmaf(q0.w, bf_hi(kw.y), acc);
+                                    acc = fmaf(q1.x, bf_lo(kw.z), acc); acc = fmaf(q1.y, bf_hi(kw.z), acc);
+                                    acc = fmaf(q1.z, bf_lo(kw.w), acc); acc = fmaf(q1.w, bf_hi(kw.w), acc);
+                                }
+                                acc += pf_dpp<PF_XOR1>(acc);
+                                acc += pf_dpp<PF_XOR2>(acc);
+                                accs[i2] = acc * 0.125f;  // 1 / sqrt(64) on K (dual_ar.rs:260): a power of two, exact wherever it is applied
+                            }
+#pragma unroll
+                            for (int i2 = 0; i2 < RI; ++i2) if (qd == 0) sc[(r0 + i2) * 128 + h * 8 + p] = accs[i2];
+                            __builtin_amdgcn_wave_barrier();
+                            float a[4 * RI];
+#pragma unroll
+                            for (int i2 = 0; i2 < RI; ++i2) {
+                                const int r = r0 + i2;
+                                float mn = -1e30f;
+#pragma unroll
+                                for (int t = 0; t < 8; ++t) if (t < T) mn = fmaxf(mn, sc[r * 128 + h * 8 + t]);
+                                float Ls = 0.f, O0 = 0.f, O1 = 0.f;
+#pragma unroll
+                                for (int t = 0; t < 8; ++t)
+                                    if (t < T) {
+                                        const float pr = __expf(sc[r * 128 + h * 8 + t] - mn);
+                                        Ls += pr;
+                                        const uint32_t vw = vc[((r * PF_LAYERS + l) * 8 + t) * 64 + g * 32 + j];
+                                        O0 = fmaf(pr, bf_lo(vw), O0);
+                                        O1 = fmaf(pr, bf_hi(vw), O1);
+                                    }
+                                const float inv = 1.f / Ls;
+                                const float at0 = O0 * inv, at1 = O1 * inv;
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) a[4 * i2 + i] = pf_dot2(wo4[i], at0, at1, 0.f);
+                            }
+                            const float tot = pf_reduce<4 * RI>(a, lane);
+                            constexpr int SH = RI == 2 ? 3 : 4;
+                            if ((lane & ((1 << SH) - 1)) == 0) red[(par * 8 + wave) * R * FRW + (r0 + ((lane >> SH) >> 2)) * FRW + ((lane >> SH) & 3)] = tot;
+                        }
+                    } else {
+                        // R >= 2: the two HALVES of the block (4 waves each) attend for different rows at the same time -- rows {0, 1} / {2, 3} at
+                        // R = 4, row 0 / row 1 at R = 2 -- instead of the whole block taking one row pair after the other: a row pair is a ~1.6 us
+                        // chain of dependent LDS / transcendental / cross-lane latencies, not work.  A lane covers head h, positions pp and pp + 4,
+                        // 16 of the head's 64 dims in the score phase, and FOUR output dims (two Wo row-pair dwords) in the value phase.
+                        constexpr int RH = R / 2;
+                        const int half = tid >> 8, tq = tid & 255;
+                        const int h = tq >> 4, g = h >> 3, pp = (tq >> 2) & 3, qd = tq & 3, jj = tq & 15;
+                        float sa[RH], sb[RH];
+#pragma unroll
+                        for (int i2 = 0; i2 < RH; ++i2) {
+                            const int r = half * RH + i2;
                             const float4* qp = reinterpret_cast<const float4*>(qs + r * 1024 + h * 64 + qd * 16);
-                            const u32x4* kp = reinterpret_cast<const u32x4*>(kc + ((r * PF_LAYERS + l) * 8 + p) * 64 + g * 32 + qd * 8);
-                            float acc = 0.f;
+                            const u32x4* ka = reinterpret_cast<const u32x4*>(kc + ((r * PF_LAYERS + l) * 8 + pp) * 64 + g * 32 + qd * 8);
+                            const u32x4* kb = ka + 64;  // position pp + 4
+                            float acc = 0.f, acd = 0.f;
 #pragma unroll
                             for (int i = 0; i < 2; ++i) {
-                                const u32x4 kw = kp[i];
+                                const u32x4 kw = ka[i], kx = kb[i];
                                 const float4 q0 = qp[2 * i], q1 = qp[2 * i + 1];
                                 acc = fmaf(q0.x, bf_lo(kw.x), acc); acc = fmaf(q0.y, bf_hi(kw.x), acc);
                                 acc = fmaf(q0.z, bf_lo(kw.y), acc); acc = fmaf(q0.w, bf_hi(kw.y), acc);
                                 acc = fmaf(q1.x, bf_lo(kw.z), acc); acc = fmaf(q1.y, bf_hi(kw.z), acc);
                                 acc = fmaf(q1.z, bf_lo(kw.w), acc); acc = fmaf(q1.w, bf_hi(kw.w), acc);
+                                acd = fmaf(q0.x, bf_lo(kx.x), acd); acd = fmaf(q0.y, bf_hi(kx.x), acd);
+                                acd = fmaf(q0.z, bf_lo(kx.y), acd); acd = fmaf(q0.w, bf_hi(kx.y), acd);
+                                acd = fmaf(q1.x, bf_lo(kx.z), acd); acd = fmaf(q1.y, bf_hi(kx.z), acd);
+                                acd = fmaf(q1.z, bf_lo(kx.w), acd); acd = fmaf(q1.w, bf_hi(kx.w), acd);
                             }
-                            acc += pf_dpp<PF_XOR1>(acc);
-                            acc += pf_dpp<PF_XOR2>(acc);
-                            accs[i2] = acc * 0.125f;  // 1 / sqrt(64) on K (dual_ar.rs:260): a power of two, exact wherever it is applied
+                            acc += pf_dpp<PF_XOR1>(acc); acd += pf_dpp<PF_XOR1>(acd);
+                            acc += pf_dpp<PF_XOR2>(acc); acd += pf_dpp<PF_XOR2>(acd);
+                            sa[i2] = acc * 0.125f; sb[i2] = acd * 0.125f;  // 1 / sqrt(64) on K (dual_ar.rs:260): a power of two, exact wherever it is applied
                         }
 #pragma unroll
-                        for (int i2 = 0; i2 < RI; ++i2) if (qd == 0) sc[(r0 + i2) * 128 + h * 8 + p] = accs[i2];
-                        __builtin_amdgcn_wave_barrier();
-                        float a[4 * RI];
+                        for (int i2 = 0; i2 < RH; ++i2)
+                            if (qd == 0) { sc[(half * RH + i2) * 128 + h * 8 + pp] = sa[i2]; sc[(half * RH + i2) * 128 + h * 8 + pp + 4] = sb[i2]; }
+                        __builtin_amdgcn_wave_barrier();  // (a wave holds four whole heads in both phases)
+                        float a[4 * RH];
 #pragma unroll
-                        for (int i2 = 0; i2 < RI; ++i2) {
-                            const int r = r0 + i2;
+                        for (int i2 = 0; i2 < RH; ++i2) {
+                            const int r = half * RH + i2;
                             float mn = -1e30f;
 #pragma unroll
                             for (int t = 0; t < 8; ++t) if (t < T) mn = fmaxf(mn, sc[r * 128 + h * 8 + t]);
-                            float Ls = 0.f, O0 = 0.f, O1 = 0.f;
+                            float Ls = 0.f, O0 = 0.f, O1 = 0.f, O2 = 0.f, O3 = 0.f;
 #pragma unroll
                             for (int t = 0; t < 8; ++t)
                                 if (t < T) {
                                     const float pr = __expf(sc[r * 128 + h * 8 + t] - mn);
                                     Ls += pr;
-                                    const uint32_t vw = vc[((r * PF_LAYERS + l) * 8 + t) * 64 + g * 32 + j];
-                                    O0 = fmaf(pr, bf_lo(vw), O0);
-                                    O1 = fmaf(pr, bf_hi(vw), O1);
+                                    const uint2 vw = *reinterpret_cast<const uint2*>(vc + ((r * PF_LAYERS + l) * 8 + t) * 64 + g * 32 + 2 * jj);
+                                    O0 = fmaf(pr, bf_lo(vw.x), O0); O1 = fmaf(pr, bf_hi(vw.x), O1);
+                                    O2 = fmaf(pr, bf_lo(vw.y), O2); O3 = fmaf(pr, bf_hi(vw.y), O3);
                                 }
                             const float inv = 1.f / Ls;
-                            const float at0 = O0 * inv, at1 = O1 * inv;
+                            const float at0 = O0 * inv, at1 = O1 * inv, at2 = O2 * inv, at3 = O3 * inv;
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) a[4 * i2 + i] = pf_dot2(wo4[i], at0, at1, 0.f);
+                            for (int i = 0; i < 4; ++i) a[4 * i2 + i] = pf_dot2(wo8[i].y, at2, at3, pf_dot2(wo8[i].x, at0, at1, 0.f));
                         }
-                        const float tot = pf_reduce<4 * RI>(a, lane);
-                        constexpr int SH = RI == 2 ? 3 : 4;
-                        if ((lane & ((1 << SH) - 1)) == 0) red[(par * 8 + wave) * R * FRW + (r0 + ((lane >> SH) >> 2)) * FRW + ((lane >> SH) & 3)] = tot;
+                        const float tot = pf_reduce<4 * RH>(a, lane);
+                        constexpr int SH = RH == 2 ? 3 : 4;
+                        if ((lane & ((1 << SH) - 1)) == 0) red[(par * 8 + wave) * R * FRW + (half * RH + ((lane >> SH) >> 2)) * FRW + ((lane >> SH) & 3)] = tot;
                     }
                     __syncthreads();
                     for (int idx = tid; idx < 4 * R * PF_REPL; idx += PF_THREADS) {
                         const int m = idx & 3, r = (idx >> 2) % R, rr = idx / (4 * R);
                         if ((run >> r) & 1u) {
-                            const float* rp = red + (par * 8) * R * FRW + r * FRW;
+                            // (R >= 2: the row's Wo partials sit in the four waves of its half of the block)
+                            constexpr int NWR = R == 1 ? 8 : 4;
+                            const int w0 = R == 1 ? 0 : 4 * (r / (R / 2 > 0 ? R / 2 : 1));
+                            const float* rp = red + (par * 8 + w0) * R * FRW + r * FRW;
                             float t = rp[m];
 #pragma unroll
-                            for (int w = 1; w < 8; ++w) t += rp[w * R * FRW + m];
+                            for (int w = 1; w < NWR; ++w) t += rp[w * R * FRW + m];
                             pub(e, rr, r, 4 * b + m, tag0 + e + 1, xr[r * 4 + m] + t);
                         }
                     }

@@ -1897,7 +1897,7 @@ class LM final : public LMBase {
         rp.ring = d_rrp_ring_.as<int>() + (size_t)i * ncb * 17; rp.ring_meta = d_rrp_meta_.as<int>() + (size_t)i * ncb * 2;
         return rp;
     }
-    static constexpr int kNapsRowsSlow[6] = {24, 4, 8, 40, 24, 28}, kNapsRowsFast[6] = {16, 16, 16, 0, 20, 20};  // tools/tune_naps_rows.py at R = 4 (999 -> 989 us per frame)
+    static constexpr int kNapsRowsSlow[6] = {28, 4, 8, 40, 24, 28}, kNapsRowsFast[6] = {20, 16, 16, 16, 20, 20};  // tools/tune_naps_rows.py at R = 4 (945 -> 933 us per frame; re-tuned after the half-block S2)
     RowsSlowArgs rows_slow_args(int R) {
         RowsSlowArgs A = {};
         A.wimg = d_rimg_.p; A.himg = d_rhimg_.p; A.norms = d_snorms_.as<float>();

@@ -376,63 +376,56 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
                 // ================= S2: gather qkv -> RoPE, KV append, attention over T <= 8 tokens -> Wo rows + residual -> publish 4
                 {
                     tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
-                    u32x4 vq, vk;
+                    // Attention of one head on the 32 lanes of a half-wave, q / k / v of the NEW token straight from the edge (every lane loads its
+                    // head's two q dims and the matching two dims of its kv head: three units per lane) and the earlier positions' K / V from LDS,
+                    // requested before the sweep.  Scores are 32-lane sums left in every lane (permlane16_swap + DPP), softmax and the value sum
+                    // run in registers: no q round trip through LDS, no block barrier in front of the attention, no score table -- the stage was a
+                    // chain of LDS round trips and barriers, not arithmetic.  Heads 0 and 8 append the token's K / V rows for the later passes.
+                    const int h = tid >> 5, g = h >> 3, j = tid & 31;
+                    uint32_t kw[7];
+#pragma unroll
+                    for (int t = 0; t < 7; ++t) kw[t] = kc[(l * 8 + t) * 64 + g * 32 + j];  // (positions >= cb: stale words, not used)
+                    u32x4 vq, vk, vv;
                     const u64* eb = my_edges + (size_t)(e & 3) * PF_REPL * PF_EDGE_CAP;
                     pf_nap_before_sweep(A.naps[1]);
-                    if (tid < 128) pf_sweep2(eb, tid, 512 + tid, tag0 + e + 1, vq, vk, dead, A.ctl);
-                    else pf_sweep1(eb, tid, tag0 + e + 1, vq, dead, A.ctl);
+                    pf_sweep3(eb, tid, 512 + g * 32 + j, 576 + g * 32 + j, tag0 + e + 1, vq, vk, vv, dead, A.ctl);
                     ++e;
                     PF_TICK(10);
-                    const int j = tid & 31;
                     const float c = rope_c[cb * 32 + j], s = rope_s[cb * 32 + j];
-                    {   // q pair (dual_ar.rs:246-247)
-                        const float qa = __uint_as_float(vq.x), qb = __uint_as_float(vq.z);
-                        *reinterpret_cast<float2*>(qs + 2 * tid) = make_float2(qa * c - qb * s, qa * s + qb * c);
-                    }
-                    if (tid < 64) {   // k pair of kv head tid / 32: RoPE, bf16 (the cache dtype)
-                        const float ka = __uint_as_float(vk.x), kb = __uint_as_float(vk.z);
-                        kc[(l * 8 + cb) * 64 + tid] = f32_to_bf16_rne(ka * c - kb * s) | (f32_to_bf16_rne(ka * s + kb * c) << 16);
-                    } else if (tid < 128) {
-                        vc[(l * 8 + cb) * 64 + tid - 64] = f32_to_bf16_rne(__uint_as_float(vk.x)) | (f32_to_bf16_rne(__uint_as_float(vk.z)) << 16);
-                    }
-                    __syncthreads();
-                    // fs_lm_debug_capture: the K / V rows this pass appended (raw bf16 pairs: K [64], V [64] per layer) behind the pass's logits,
-                    // so that a test can make the oracle attend over exactly these rows (tests/test_kv_forced_gpu.py)
-                    if (A.cap && b == 0 && A.slow_logits && tid < 128 && A.state->frame < A.cap_frames)
-                        reinterpret_cast<uint32_t*>(A.cap + ((size_t)A.state->frame * 9 + 1 + cb) * 2048 + 1025)[l * 128 + tid] =
-                            tid < 64 ? kc[(l * 8 + cb) * 64 + tid] : vc[(l * 8 + cb) * 64 + tid - 64];
-                    const int h = tid >> 5, g = h >> 3, p = (tid >> 2) & 7, qd = tid & 3;
-                    {
-                        const float scale = 0.125f;  // 1 / sqrt(64), applied to K (dual_ar.rs:260)
-                        const float4* qp = reinterpret_cast<const float4*>(qs + h * 64 + qd * 16);
-                        const u32x4* kp = reinterpret_cast<const u32x4*>(kc + (l * 8 + p) * 64 + g * 32 + qd * 8);
-                        float acc = 0.f;
-#pragma unroll
-                        for (int i = 0; i < 2; ++i) {
-                            const u32x4 kw = kp[i];
-                            const float4 q0 = qp[2 * i], q1 = qp[2 * i + 1];
-                            acc = fmaf(q0.x, bf_lo(kw.x) * scale, acc); acc = fmaf(q0.y, bf_hi(kw.x) * scale, acc);
-                            acc = fmaf(q0.z, bf_lo(kw.y) * scale, acc); acc = fmaf(q0.w, bf_hi(kw.y) * scale, acc);
-                            acc = fmaf(q1.x, bf_lo(kw.z) * scale, acc); acc = fmaf(q1.y, bf_hi(kw.z) * scale, acc);
-                            acc = fmaf(q1.z, bf_lo(kw.w) * scale, acc); acc = fmaf(q1.w, bf_hi(kw.w) * scale, acc);
+                    // q pair (dual_ar.rs:246-247), 1 / sqrt(64) folded in (a power of two: exact; the reference scales K, dual_ar.rs:260)
+                    const float qa = __uint_as_float(vq.x), qb = __uint_as_float(vq.z);
+                    const float q0 = (qa * c - qb * s) * 0.125f, q1 = (qa * s + qb * c) * 0.125f;
+                    const float ka = __uint_as_float(vk.x), kb = __uint_as_float(vk.z);
+                    const uint32_t knew = f32_to_bf16_rne(ka * c - kb * s) | (f32_to_bf16_rne(ka * s + kb * c) << 16);  // bf16: the cache dtype
+                    const uint32_t vnew = f32_to_bf16_rne(__uint_as_float(vv.x)) | (f32_to_bf16_rne(__uint_as_float(vv.z)) << 16);
+                    if ((h & 7) == 0) {
+                        kc[(l * 8 + cb) * 64 + g * 32 + j] = knew;
+                        vc[(l * 8 + cb) * 64 + g * 32 + j] = vnew;
+                        // fs_lm_debug_capture: the K / V rows this pass appended (raw bf16 pairs: K [64], V [64] per layer) behind the pass's logits,
+                        // so that a test can make the oracle attend over exactly these rows (tests/test_kv_forced_gpu.py)
+                        if (A.cap && b == 0 && A.slow_logits && A.state->frame < A.cap_frames) {
+                            uint32_t* cw = reinterpret_cast<uint32_t*>(A.cap + ((size_t)A.state->frame * 9 + 1 + cb) * 2048 + 1025) + l * 128 + g * 32 + j;
+                            cw[0] = knew; cw[64] = vnew;
                         }
-                        acc += pf_dpp<PF_XOR1>(acc);
-                        acc += pf_dpp<PF_XOR2>(acc);
-                        if (qd == 0) sc[h * 8 + p] = acc;
                     }
-                    __builtin_amdgcn_wave_barrier();  // both heads of a wave are scored and consumed by that wave (LDS ops of a wave are in order)
                     float at0, at1;
                     {
+                        float scr[8];
                         float mn = -1e30f;
 #pragma unroll
-                        for (int t = 0; t < 8; ++t) if (t < T) mn = fmaxf(mn, sc[h * 8 + t]);
+                        for (int t = 0; t < 8; ++t)
+                            if (t < T) {
+                                const uint32_t kk = (t == cb || t == 7) ? knew : kw[t < 7 ? t : 0];
+                                scr[t] = pf_allsum32(fmaf(q1, bf_hi(kk), q0 * bf_lo(kk)));
+                                mn = fmaxf(mn, scr[t]);
+                            }
                         float L = 0.f, O0 = 0.f, O1 = 0.f;
 #pragma unroll
                         for (int t = 0; t < 8; ++t)
                             if (t < T) {
-                                const float pr = __expf(sc[h * 8 + t] - mn);
+                                const float pr = __expf(scr[t] - mn);
                                 L += pr;
-                                const uint32_t vw = vc[(l * 8 + t) * 64 + g * 32 + j];
+                                const uint32_t vw = (t == cb) ? vnew : vc[(l * 8 + t) * 64 + g * 32 + j];
                                 O0 = fmaf(pr, bf_lo(vw), O0);
                                 O1 = fmaf(pr, bf_hi(vw), O1);
                             }

@@ -160,6 +160,23 @@ __device__ __forceinline__ void pf_sweep2(const u64* base, int unit0, int unit1,
         if (spins > PF_SPIN_MAX) { dead = true; atomicAdd(ctl + 1, 1u); return; }
     }
 }
+__device__ __forceinline__ void pf_sweep3(const u64* base, int unit0, int unit1, int unit2, unsigned tag, u32x4& v0, u32x4& v1, u32x4& v2, bool& dead,
+                                          uint32_t* ctl) {
+    const u64 *p0 = base + 2 * (size_t)unit0, *p1 = base + 2 * (size_t)unit1, *p2 = base + 2 * (size_t)unit2;
+    for (unsigned spins = 0;; ++spins) {
+        asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %4, off sc1\n\tglobal_load_dwordx4 %2, %5, off sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(v0), "=&v"(v1), "=&v"(v2) : "v"(p0), "v"(p1), "v"(p2) : "memory");
+        if ((pf_tags_ok(v0, tag) && pf_tags_ok(v1, tag) && pf_tags_ok(v2, tag)) || dead) return;
+        if (spins > PF_SPIN_MAX) { dead = true; atomicAdd(ctl + 1, 1u); return; }
+    }
+}
+// sum over the 32 lanes of a half-wave, left in every one of them (lane ^ 16 through v_permlane16_swap, then the 16-lane row by DPP)
+__device__ __forceinline__ float pf_allsum32(float x) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    float t = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    t += pf_dpp<PF_MIRROR>(t); t += pf_dpp<PF_HALF_MIRROR>(t); t += pf_dpp<PF_XOR2>(t); t += pf_dpp<PF_XOR1>(t);
+    return t;
+}
 __device__ __forceinline__ void pf_sweep4(const u64* base, int tid, unsigned tag, u32x4 (&v)[4], bool& dead, uint32_t* ctl) {
     const u64 *p0 = base + 2 * (size_t)tid, *p1 = p0 + 2 * PF_THREADS, *p2 = p1 + 2 * PF_THREADS, *p3 = p2 + 2 * PF_THREADS;
     for (unsigned spins = 0;; ++spins) {

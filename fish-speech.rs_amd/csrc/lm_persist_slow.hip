@@ -343,8 +343,12 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
             }
             ++e;
             __syncthreads();
-            // running {m, l, o[d]} of the slice, owned by threads d < 64 (o) -- every thread tracks m and l redundantly
-            float run_m = -1e30f, run_l = 0.f, run_o = 0.f;
+            // Every WAVE keeps its own running {m, l, o} over the tiles (flash-decoding inside the workgroup): the wave maximum is uniform by DPP /
+            // readlane, a lane accumulates p * v for its own tokens and 8-dim slice and p for its token (lanes with du == 0), and nothing crosses
+            // lanes or waves until the tiles are done -- one cross-lane sum, ONE block barrier, a merge of the 8 wave partials by the 66 publishing
+            // threads.  (Before: a block-wide maximum, a partial table and a running-state merge PER TILE: three barriers and two LDS round
+            // trips per tile + two more around the publish staging; the stage was barriers, not arithmetic.)
+            float run_m = -1e30f, run_l = 0.f, ro[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             const int du = tid & 7;
             float qv[8];
             {
@@ -381,28 +385,32 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
                 m = fmaxf(m, pf_dpp<PF_XOR1>(m)); m = fmaxf(m, pf_dpp<PF_XOR2>(m)); m = fmaxf(m, pf_dpp<PF_HALF_MIRROR>(m)); m = fmaxf(m, pf_dpp<PF_MIRROR>(m));
                 m = fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 15)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 31))),
                           fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 47)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 63))));
-                if (lane == 0) wmax[wave] = m;
-                __syncthreads();
-                float mt = wmax[0];
+                const float mn = fmaxf(run_m, m), ca = __expf(run_m - mn);  // (wave-uniform)
+                run_l *= ca;
 #pragma unroll
-                for (int w = 1; w < 8; ++w) mt = fmaxf(mt, wmax[w]);
-                // p = exp(s - m_tile); partial l (one lane per token) and o (this lane's 8 dims), summed over the tokens of the wave
-                float o9[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int i = 0; i < 8; ++i) ro[i] *= ca;
 #pragma unroll
                 for (int u = 0; u < 3; ++u) {
-                    const float p = valid[u] ? __expf(sc[u] - mt) : 0.f;
-                    if (du == 0) o9[8] += p;
+                    const float p = valid[u] ? __expf(sc[u] - mn) : 0.f;
+                    if (du == 0) run_l += p;
                     if (u < 2) {
                         const u32x4 vv = vreg[u];
-                        o9[0] = fmaf(p, bf_lo(vv.x), o9[0]); o9[1] = fmaf(p, bf_hi(vv.x), o9[1]); o9[2] = fmaf(p, bf_lo(vv.y), o9[2]); o9[3] = fmaf(p, bf_hi(vv.y), o9[3]);
-                        o9[4] = fmaf(p, bf_lo(vv.z), o9[4]); o9[5] = fmaf(p, bf_hi(vv.z), o9[5]); o9[6] = fmaf(p, bf_lo(vv.w), o9[6]); o9[7] = fmaf(p, bf_hi(vv.w), o9[7]);
+                        ro[0] = fmaf(p, bf_lo(vv.x), ro[0]); ro[1] = fmaf(p, bf_hi(vv.x), ro[1]); ro[2] = fmaf(p, bf_lo(vv.y), ro[2]); ro[3] = fmaf(p, bf_hi(vv.y), ro[3]);
+                        ro[4] = fmaf(p, bf_lo(vv.z), ro[4]); ro[5] = fmaf(p, bf_hi(vv.z), ro[5]); ro[6] = fmaf(p, bf_lo(vv.w), ro[6]); ro[7] = fmaf(p, bf_hi(vv.w), ro[7]);
                     } else {
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) o9[i] = fmaf(p, vnew[du * 8 + i], o9[i]);
+                        for (int i = 0; i < 8; ++i) ro[i] = fmaf(p, vnew[du * 8 + i], ro[i]);
                     }
                 }
+                run_m = mn;
+            }
+            {   // the wave's partial: sum over its 8 token lanes that share a dim slice (lane ^ 8, ^ 16, ^ 32)
+                float o9[9];
 #pragma unroll
-                for (int i = 0; i < 9; ++i) {  // sum over the 8 tokens of the wave that share this lane's dim slice (lane ^ 8, ^ 16, ^ 32)
+                for (int i = 0; i < 8; ++i) o9[i] = ro[i];
+                o9[8] = run_l;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) {
                     float t = o9[i];
                     t += pf_dpp<PS_DROR8>(t);
                     const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(t), __float_as_uint(t), false, false);
@@ -413,30 +421,24 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
                 if (lane < 8) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) part[wave * 72 + lane * 8 + i] = o9[i];
-                    if (lane == 0) part[wave * 72 + 64] = o9[8];
+                    if (lane == 0) { part[wave * 72 + 64] = o9[8]; wmax[wave] = run_m; }
                 }
-                __syncthreads();
-                {   // merge the tile into the running state (flash-decoding rescale)
-                    float lt = part[64], ot = tid < 64 ? part[tid] : 0.f;
-#pragma unroll
-                    for (int w = 1; w < 8; ++w) { lt += part[w * 72 + 64]; if (tid < 64) ot += part[w * 72 + tid]; }
-                    const float mn = fmaxf(run_m, mt);
-                    const float ca = __expf(run_m - mn), cb2 = __expf(mt - mn);
-                    run_l = run_l * ca + lt * cb2;
-                    run_o = run_o * ca + ot * cb2;
-                    run_m = mn;
-                }
-                __syncthreads();  // part / wmax are rewritten by the next tile
             }
-            // publish {o[64], m, l}
-            const int base = (ah * n_sl + as) * 66;
-            // stage the 66 values in LDS so that 528 (value, replica) stores can be spread over the workgroup
-            if (tid < 64) part[tid] = run_o;
-            if (tid == 64) { part[64] = run_m; part[65] = run_l; }
             __syncthreads();
-            for (int idx = tid; idx < 66 * PF_REPL; idx += PF_THREADS) {
-                const int jj = idx % 66, rr = idx / 66;
-                pub(e, rr, base + jj, tag0 + e + 1, part[jj]);
+            // merge the 8 wave partials (flash-decoding rescale) and publish {o[64], m, l}: 66 threads x 8 replicas
+            if (tid < 66) {
+                float M = wmax[0];
+#pragma unroll
+                for (int w = 1; w < 8; ++w) M = fmaxf(M, wmax[w]);
+                float val = 0.f;
+                if (tid == 64) val = M;
+                else {
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) val = fmaf(part[w * 72 + (tid < 64 ? tid : 64)], __expf(wmax[w] - M), val);
+                }
+                const int base = (ah * n_sl + as) * 66;
+#pragma unroll
+                for (int rr = 0; rr < PF_REPL; ++rr) pub(e, rr, base + tid, tag0 + e + 1, val);
             }
             __syncthreads();
             PS_TICK(2);

@@ -273,7 +273,8 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
             }
             ++e;
             __syncthreads();
-            float run_m = -1e30f, run_l = 0.f, run_o = 0.f;
+            // every WAVE keeps its own running {m, l, o} over the tiles; one cross-lane sum and ONE block barrier at the end (see k_slow_persist S2)
+            float run_m = -1e30f, run_l = 0.f, ro[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             const int du = tid & 7;
             float qv[8];
             {
@@ -310,26 +311,31 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
                 m = fmaxf(m, pf_dpp<PF_XOR1>(m)); m = fmaxf(m, pf_dpp<PF_XOR2>(m)); m = fmaxf(m, pf_dpp<PF_HALF_MIRROR>(m)); m = fmaxf(m, pf_dpp<PF_MIRROR>(m));
                 m = fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 15)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 31))),
                           fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 47)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 63))));
-                if (lane == 0) wmax[wave] = m;
-                __syncthreads();
-                float mt = wmax[0];
+                const float mn = fmaxf(run_m, m), ca = __expf(run_m - mn);  // (wave-uniform)
+                run_l *= ca;
 #pragma unroll
-                for (int w = 1; w < 8; ++w) mt = fmaxf(mt, wmax[w]);
-                float o9[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int i = 0; i < 8; ++i) ro[i] *= ca;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     if (u == 2 && !g3) continue;
-                    const float p = valid[u] ? __expf(sc[u] - mt) : 0.f;
-                    if (du == 0) o9[8] += p;
+                    const float p = valid[u] ? __expf(sc[u] - mn) : 0.f;
+                    if (du == 0) run_l += p;
                     if (u < 3) {
                         const u32x4 vv = vreg[u];
-                        o9[0] = fmaf(p, bf_lo(vv.x), o9[0]); o9[1] = fmaf(p, bf_hi(vv.x), o9[1]); o9[2] = fmaf(p, bf_lo(vv.y), o9[2]); o9[3] = fmaf(p, bf_hi(vv.y), o9[3]);
-                        o9[4] = fmaf(p, bf_lo(vv.z), o9[4]); o9[5] = fmaf(p, bf_hi(vv.z), o9[5]); o9[6] = fmaf(p, bf_lo(vv.w), o9[6]); o9[7] = fmaf(p, bf_hi(vv.w), o9[7]);
+                        ro[0] = fmaf(p, bf_lo(vv.x), ro[0]); ro[1] = fmaf(p, bf_hi(vv.x), ro[1]); ro[2] = fmaf(p, bf_lo(vv.y), ro[2]); ro[3] = fmaf(p, bf_hi(vv.y), ro[3]);
+                        ro[4] = fmaf(p, bf_lo(vv.z), ro[4]); ro[5] = fmaf(p, bf_hi(vv.z), ro[5]); ro[6] = fmaf(p, bf_lo(vv.w), ro[6]); ro[7] = fmaf(p, bf_hi(vv.w), ro[7]);
                     } else {
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) o9[i] = fmaf(p, vnew[du * 8 + i], o9[i]);
+                        for (int i = 0; i < 8; ++i) ro[i] = fmaf(p, vnew[du * 8 + i], ro[i]);
                     }
                 }
+                run_m = mn;
+            }
+            {
+                float o9[9];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o9[i] = ro[i];
+                o9[8] = run_l;
 #pragma unroll
                 for (int i = 0; i < 9; ++i) {
                     float t = o9[i];
@@ -342,30 +348,24 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
                 if (lane < 8) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) part[wave * 72 + lane * 8 + i] = o9[i];
-                    if (lane == 0) part[wave * 72 + 64] = o9[8];
+                    if (lane == 0) { part[wave * 72 + 64] = o9[8]; wmax[wave] = run_m; }
                 }
-                __syncthreads();
-                {
-                    float lt = part[64], ot = tid < 64 ? part[tid] : 0.f;
+            }
+            __syncthreads();
+            if (tid < 66) {  // merge the 8 wave partials (flash-decoding rescale) and publish {o[64], m, l}: 66 threads x 8 replicas
+                float M = wmax[0];
 #pragma unroll
-                    for (int w = 1; w < 8; ++w) { lt += part[w * 72 + 64]; if (tid < 64) ot += part[w * 72 + tid]; }
-                    const float mn = fmaxf(run_m, mt);
-                    const float ca = __expf(run_m - mn), cb2 = __expf(mt - mn);
-                    run_l = run_l * ca + lt * cb2;
-                    run_o = run_o * ca + ot * cb2;
-                    run_m = mn;
+                for (int w = 1; w < 8; ++w) M = fmaxf(M, wmax[w]);
+                float val = 0.f;
+                if (tid == 64) val = M;
+                else {
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) val = fmaf(part[w * 72 + (tid < 64 ? tid : 64)], __expf(wmax[w] - M), val);
                 }
-                __syncthreads();
+                const int base = (ah * n_sl + as) * 66;
+#pragma unroll
+                for (int rr = 0; rr < PF_REPL; ++rr) pub(e, rr, ar, base + tid, tag0 + e + 1, val);
             }
-            const int base = (ah * n_sl + as) * 66;
-            if (tid < 64) part[tid] = run_o;
-            if (tid == 64) { part[64] = run_m; part[65] = run_l; }
-            __syncthreads();
-            for (int idx = tid; idx < 66 * PF_REPL; idx += PF_THREADS) {
-                const int jj = idx % 66, rr = idx / 66;
-                pub(e, rr, ar, base + jj, tag0 + e + 1, part[jj]);
-            }
-            __syncthreads();
             PS_TICK(2);
         } else {
             ++e;

@@ -1827,7 +1827,8 @@ class LM final : public LMBase {
         A.kv_pool = kv_pool_.p; A.layer_half = (size_t)n_pages_ * page_elems_;
         A.page_table = d_page_table_.as<int>();
         A.n_sl = std::min(nc_launch_, 16);
-        if (const char* c = getenv("FISHRT_NSL_MAX")) A.n_sl = std::max(1, std::min(A.n_sl, atoi(c)));  // (debug knob)
+        if (const char* c = getenv("FISHRT_NSL_MAX")) A.n_sl = std::max(1, std::min(A.n_sl, atoi(c)));  // (debug knobs)
+        if (const char* c = getenv("FISHRT_NSL_MIN")) A.n_sl = std::min(16, std::max(A.n_sl, atoi(c)));
         // (measured, round 3: half / a quarter as many slices -> S2 +44 / +115 us per frame, S3 only -10 / -12)
         A.edges = d_sedges_.as<unsigned long long>();
         A.ctl = d_sctl_.as<uint32_t>();

@@ -73,10 +73,13 @@ def _replay_gap(lm, p, a, b, rep_pen):
     lm.clear_slow_layer_caches()
     cur, pos, prev = p, 0, None
     rps = [_RepPen(1024, rep_pen) for _ in range(8)]
+    slow_margin = []
     for it in range(f + 1):
         lg, hg = lm.forward_generate(cur, pos)
         s = lg[0, im_end:].copy()
         s[0] = -np.inf  # ignore_eos
+        srt = np.sort(s[np.isfinite(s)])
+        slow_margin.append(float(srt[-1] - srt[-2]))
         frame = [_argmax_last(s) + im_end]
         lm.clear_fast_layer_caches()
         x = hg
@@ -85,7 +88,11 @@ def _replay_gap(lm, p, a, b, rep_pen):
             if prev is not None:
                 fg = rps[ci].apply(fg, prev[ci + 1])
             if it == f and ci == cbd:
-                return f, cbd, float(abs(fg[a[ci, f]] - fg[b[ci, f]])), float(np.sort(fg)[-1] - np.sort(fg)[-2])
+                gap = float(abs(fg[a[ci, f]] - fg[b[ci, f]]))
+                # the codes do not carry the slow token: the paths may have parted at the SLOW decision of frame f or f - 1 (whose eight codes
+                # can still coincide): a near-tie of the slow logits there is that parting
+                gap = min([gap] + slow_margin[-2:])
+                return f, cbd, gap, float(np.sort(fg)[-1] - np.sort(fg)[-2])
             assert _argmax_last(fg) == a[ci, it], f"replay lost path A at frame {it} codebook {ci}"
             frame.append(int(a[ci, it]))
             x = lm.fast_embeddings([int(a[ci, it])])

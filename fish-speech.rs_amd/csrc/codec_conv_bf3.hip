@@ -816,7 +816,11 @@ static void conv1d_bf3_impl(const float* x, const uint16_t* xp, int B, int Cin, 
             // f16 mode (half the LDS per channel block): 2 blocks per stage, still 3 thread blocks per CU -- 2.555 -> 2.470 ms per 256 frames,
             // bit-identical PCM; 4 blocks per stage (1..2 thread blocks per CU): 2.71 ms
             static const char* cfgn = getenv("FISHRT_BF3P_NIBS");
-            const int want = cfgn ? atoi(cfgn) : 2;
+            // (four blocks per stage where the grid has at most two thread blocks per CU anyway -- the 256-channel stage at 256 frames: the LDS
+            // they cost takes no occupancy away there)
+            static const char* cfg4 = getenv("FISHRT_BF3P_NIBS4_BLOCKS");
+            const long long blocks_tt = (long long)((T + TT - 1) / TT) * ((Cout + 31) / 32) * B;
+            const int want = cfgn ? atoi(cfgn) : ((blocks_tt <= (cfg4 ? atoll(cfg4) : 512) && nib % 4 == 0) ? 4 : 2);
             const int nibs = (F16 && want > 0 && nib % want == 0) ? want : 1;
 #define FS_WIDEN(TTv, NB)                                                                                \
     do {                                                                                                 \

@@ -1761,7 +1761,7 @@ class LM final : public LMBase {
 
     // naps before the first sweep of each stage kind (64-clock units; tuned on MI355X, profiles/r03_poll_naps.txt); the environment
     // variables ("a,b,c,d,e,f") override them for tuning runs
-    static constexpr int kNapsFast[6] = {16, 16, 20, 20, 20, 12}, kNapsSlow[6] = {24, 0, 8, 40, 32, 12};
+    static constexpr int kNapsFast[6] = {16, 20, 16, 20, 16, 12}, kNapsSlow[6] = {24, 4, 8, 40, 32, 12};  // (re-tuned after the S2 restructurings of round 4: -1 us)
     // the same coordinate descent on the in-launch-sampler instantiation of k_fast_persist (680 -> 662 us per sampled frame) and on the
     // e4m3 image of k_slow_persist (595 -> 585 us per fp8 frame): their stage arithmetic differs, so the edges complete at other times
     static constexpr int kNapsFastSampled[6] = {12, 12, 12, 20, 16, 16}, kNapsSlowFp8[6] = {20, 0, 32, 24, 28, 12};

@@ -133,6 +133,10 @@ int fs_lm_generate_multi(fs_lm_t* lm, const uint32_t* prompts, const int* lens, 
     FS_ARG(lm && prompts && lens && max_new_tokens && samplings && seeds && codes_out && n_frames, "null argument");
     FS_TRY(lm->impl->generate_multi(prompts, lens, n, max_new_tokens, samplings, seeds, flags, codes_out, cap, n_frames))
 }
+int fs_lm_rows_supported(fs_lm_t* lm, int n, const fs_sampling* samplings, int* supported) {
+    FS_ARG(lm && samplings && supported && n >= 1, "bad argument");
+    FS_TRY(*supported = lm->impl->rows_supported(n, samplings) ? 1 : 0)
+}
 int fs_lm_debug_read_row(fs_lm_t* lm, int row, float* out, int n_frames) { FS_ARG(lm && out, "null argument"); FS_TRY(lm->impl->debug_read_row(row, out, n_frames)) }
 int fs_lm_debug_read_kv(fs_lm_t* lm, int slot, int layer, int t0, int n, float* k_out, float* v_out) {
     FS_ARG(lm && k_out && v_out, "null argument");

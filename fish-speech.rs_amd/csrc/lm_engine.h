@@ -33,6 +33,7 @@ class LMBase {
     // R concurrent batch-1 requests (fishrt.h: fs_lm_generate_multi)
     virtual void generate_multi(const uint32_t* prompts, const int* lens, int n, const int* max_new_tokens, const fs_sampling* samplings,
                                 const uint64_t* seeds, uint32_t flags, uint32_t* codes_out, size_t cap, size_t* n_frames) = 0;
+    virtual bool rows_supported(int n, const fs_sampling* samplings) = 0;
     // continuous batching over the static-batch step (fishrt.h: fs_lm_session_*)
     virtual void session_begin(const fs_sampling& s, uint64_t seed, uint32_t flags) = 0;
     virtual int session_add(const uint32_t* prompt, int L, int max_new_tokens) = 0;

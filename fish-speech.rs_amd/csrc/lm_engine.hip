@@ -798,15 +798,24 @@ class LM final : public LMBase {
         // its own generate_blocking (repetition penalty, its own LogitsProcessor stream seeded seed + its admission number) -- instead of the
         // static-batch sampler's.  Needs max_batch <= 8, a bf16 Fish-1.5 handle and a sampler setting the in-launch decisions cover.
         sess_rows_ = false;
+        std::unique_lock<std::mutex> rows_lock;
+        struct RowsGuard {  // anything thrown below leaves the handle out of row mode (the local lock releases itself)
+            bool& flag; bool armed = true;
+            ~RowsGuard() { if (armed) flag = false; }
+        } rows_guard{sess_rows_};
         if (flags & FS_SESSION_ROWS) {
             const int tk = (int)std::min<uint64_t>(s.top_k, 1u << 30);
             const bool ok = B_ >= 2 && B_ <= PR_MAX_ROWS && pslow_ok_ && persist_ok_ && !kFp8 && !legacy_ && n_audio_ <= 2048 &&
                             (s.temp == 0.0 || fast_persist_samples((float)s.temp, tk, a_.codebook_size));
             FS_REQUIRE(ok, "FS_SESSION_ROWS needs a bf16 Fish-1.5 handle with 2 <= max_batch <= 8 and greedy or top_k <= 256 sampling");
-            sess_plock_ = std::unique_lock<std::mutex>(persist_mutex(device_), std::try_to_lock);
-            FS_REQUIRE(sess_plock_.owns_lock(), "another call on this device holds the persistent kernels");
-            sess_R_ = B_ <= 2 ? 2 : (B_ <= 4 ? 4 : 8);
-            FS_REQUIRE(sess_R_ == B_, "FS_SESSION_ROWS needs max_batch 2, 4 or 8 (the row launches cover exactly that many slots; state slot max_batch is the prefill staging state)");
+            FS_REQUIRE(B_ == 2 || B_ == 4 || B_ == 8, "FS_SESSION_ROWS needs max_batch 2, 4 or 8 (the row launches cover exactly that many slots; state slot max_batch is the prefill staging state)");
+            FS_REQUIRE(rows_kv_span_ok(B_), "FS_SESSION_ROWS: max_seq_len too long for the row kernels' attention slices at this slot count");
+            FS_REQUIRE(!free_pages_.empty(), "KV page pool exhausted");
+            // the device's persistent-kernel lock is held in a LOCAL until nothing below can throw any more (a throw after taking it used to
+            // leave sess_plock_ owning the mutex with sess_active_ false: session_end returned early and the device was locked out for good)
+            rows_lock = std::unique_lock<std::mutex>(persist_mutex(device_), std::try_to_lock);
+            FS_REQUIRE(rows_lock.owns_lock(), "another call on this device holds the persistent kernels");
+            sess_R_ = B_;
             ensure_rows(sess_R_);
             sess_rows_ = true;
             sess_sampled_ = s.temp != 0.0;
@@ -843,6 +852,8 @@ class LM final : public LMBase {
         FS_HIP(hipMemsetAsync(d_pfx_.p, 0, sizeof(float) * (size_t)B_ * a_.dim, st_));
         FS_HIP(hipStreamSynchronize(st_));
         stats_ = {};
+        rows_guard.armed = false;
+        if (sess_rows_) sess_plock_ = std::move(rows_lock);
         sess_active_ = true;
     }
     void park_slot(int b) {
@@ -1054,6 +1065,7 @@ class LM final : public LMBase {
             }
             if (!live) break;
             if (sess_rows_) {
+                PersistFlagsGuard flags_guard{*this};
                 use_persist_ = true; use_pslow_ = true; persist_sampled_ = sess_sampled_;
                 // the launch group covers slots [0, top): the smallest instantiations that hold the highest live slot (an 8-slot session with two
                 // live requests in slots 0, 1 pays the 2-row frame, 0.84 ms, not the 8-row one, 1.67 ms); slots are handed out lowest-first
@@ -1069,7 +1081,6 @@ class LM final : public LMBase {
                         launch_rows_fast(rows_fast_args(r0, Rf), Rf, sess_sampled_, st_);
                     }
                 }
-                use_persist_ = use_pslow_ = false;
             } else
             for (int i = 0; i < chunk; ++i) {
                 set_bucket(longest + i + 1);
@@ -1092,6 +1103,9 @@ class LM final : public LMBase {
             // (a slot that sampled <|im_end|> inside the chunk froze itself on the device; the host learns it below)
             FS_HIP(hipMemcpyAsync(sess_hs_.data(), state(0), sizeof(SeqState) * B_, hipMemcpyDeviceToHost, st_));
             FS_HIP(hipStreamSynchronize(st_));
+            // a spin timeout inside the chunk (the joining prefill shares the CUs the persistent launches need co-resident) means the slots'
+            // codes are garbage: raise instead of handing them out; the caller ends the session (the handle is off the row path afterwards)
+            if (sess_rows_) rows_check_ctl(/*include_b1_fast=*/false);
         }
         FS_HIP(hipEventRecord(ev_[2], st_));
         FS_HIP(hipEventSynchronize(ev_[2]));
@@ -1151,8 +1165,8 @@ class LM final : public LMBase {
                 if (ctl[1] || ctl[2]) FS_HIP(hipMemset((uint32_t*)cb->p + 1, 0, 8));
             }
             sess_rows_ = false;
-            if (sess_plock_.owns_lock()) sess_plock_.unlock();
         }
+        if (sess_plock_.owns_lock()) sess_plock_.unlock();
     }
 
     void generate_batch_sequential(const uint32_t* prompts, const int* lens, int n, int max_new_tokens, const fs_sampling& s, uint64_t seed,
@@ -1205,16 +1219,8 @@ class LM final : public LMBase {
             size_t off = 0;
             for (int i = 0; i < n; ++i) { FS_REQUIRE(lens[i] >= 1, "empty prompt"); FS_REQUIRE(max_new_tokens[i] >= 0, "negative max_new_tokens"); poff[i] = off; off += (size_t)C1 * lens[i]; }
         }
-        bool rows_ok = n >= 2 && n <= PR_MAX_ROWS && n <= B_ && pslow_ok_ && persist_ok_ && !kFp8 && !legacy_ && n_audio_ <= 2048 &&
-                       !(flags & FS_GEN_NO_PERSIST) && !getenv("FISHRT_NO_ROWS");
-        // one instantiation per launch: every request greedy, or every request within the in-launch sampler (temp > 0, 0 < top_k <= 256)
-        bool rows_sampled = samplings[0].temp != 0.0;
-        for (int i = 0; i < n && rows_ok; ++i) {
-            const fs_sampling& s = samplings[i];
-            const int tk = (int)std::min<uint64_t>(s.top_k, 1u << 30);
-            if ((s.temp != 0.0) != rows_sampled) rows_ok = false;
-            if (rows_sampled && !fast_persist_samples((float)s.temp, tk, a_.codebook_size)) rows_ok = false;
-        }
+        bool rows_ok = rows_supported(n, samplings) && !(flags & FS_GEN_NO_PERSIST);
+        const bool rows_sampled = samplings[0].temp != 0.0;
         std::unique_lock<std::mutex> plock;
         if (rows_ok) { plock = std::unique_lock<std::mutex>(persist_mutex(device_), std::try_to_lock); rows_ok = plock.owns_lock(); }
         if (!rows_ok) {
@@ -1262,7 +1268,8 @@ class LM final : public LMBase {
         FS_HIP(hipMemcpyAsync(d_rbudget_.p, budget.data(), sizeof(int) * R, hipMemcpyHostToDevice, st_));
         float* nullp = nullptr;
         FS_HIP(hipMemcpyAsync(d_hid_slot_.p, &nullp, sizeof(nullp), hipMemcpyHostToDevice, st_));
-        if (cap_frames_) { d_rcap_.alloc(sizeof(float) * (size_t)R * cap_frames_ * 9 * 2048); FS_HIP(hipMemsetAsync(d_rcap_.p, 0, d_rcap_.n, st_)); }
+        ensure_rows_capture(R);
+        PersistFlagsGuard flags_guard{*this};
         stats_ = {};
         FS_HIP(hipEventRecord(ev_[0], st_));
         for (int i = 0; i < R; ++i) {
@@ -1345,14 +1352,7 @@ class LM final : public LMBase {
             fprintf(stderr, "rows fast prof (us/frame summed over the fast launches, workgroup 0; wait+work): preload %.1f  S1 %.1f+%.1f  S2 %.1f+%.1f  S3 %.1f+%.1f  S4 %.1f+%.1f  head %.1f+%.1f  decision %.1f+%.1f (rows' logits -> argmax / draw %.1f, pick -> next input %.1f)  tail %.1f\n",
                     pr[0] * f, pr[9] * f, pr[1] * f, pr[10] * f, pr[2] * f, pr[11] * f, (pr[3] + pr[8]) * f, pr[12] * f, pr[4] * f, pr[13] * f, pr[5] * f, pr[14] * f, (pr[6] + pr[15]) * f, pr[15] * f, pr[6] * f, pr[7] * f);
         }
-        for (DevBuf* cb : {&d_rctl_s_, &d_rctl_f_, &d_ctl_}) {
-            uint32_t ctl[4] = {0, 0, 0, 0};
-            FS_HIP(hipMemcpy(ctl, cb->p, sizeof(ctl), hipMemcpyDeviceToHost));
-            if (ctl[1] || ctl[2]) {
-                FS_HIP(hipMemset((uint32_t*)cb->p + 1, 0, 8));
-                throw Error("request-row persistent kernels: a grid-wide wait timed out (are all 256 CUs available to this process?)");
-            }
-        }
+        rows_check_ctl(/*include_b1_fast=*/!rows_fast);
         std::vector<uint32_t> tmp((size_t)n * C * out_cap_);
         FS_HIP(hipMemcpy(tmp.data(), d_out_.p, sizeof(uint32_t) * tmp.size(), hipMemcpyDeviceToHost));
         uint64_t total = 0;
@@ -1368,8 +1368,56 @@ class LM final : public LMBase {
         stats_.frames = total;
     }
 
+    // fs_lm_rows_supported: would fs_lm_generate_multi serve these n requests on the request-row kernels (one persistent launch group per
+    // frame) rather than one after the other?  Says nothing about whether another call holds the device's persistent kernels right now.
+    bool rows_supported(int n, const fs_sampling* samplings) override {
+        bool ok = n >= 2 && n <= PR_MAX_ROWS && n <= B_ && loaded_ && pslow_ok_ && persist_ok_ && !kFp8 && !legacy_ && n_audio_ <= 2048 &&
+                  !getenv("FISHRT_NO_ROWS") && rows_kv_span_ok(n <= 2 ? 2 : (n <= 4 ? 4 : 8));
+        // one instantiation per launch: every request greedy, or every request within the in-launch sampler (temp > 0, 0 < top_k <= 256)
+        const bool sampled = ok && samplings[0].temp != 0.0;
+        for (int i = 0; i < n && ok; ++i) {
+            const fs_sampling& s = samplings[i];
+            const int tk = (int)std::min<uint64_t>(s.top_k, 1u << 30);
+            if ((s.temp != 0.0) != sampled) ok = false;
+            if (sampled && !fast_persist_samples((float)s.temp, tk, a_.codebook_size)) ok = false;
+        }
+        return ok;
+    }
+
   private:
     void use_device() { FS_HIP(hipSetDevice(device_)); }
+
+    // k_slow_rows stages the page ids of ONE attention slice in 160 LDS slots (lm_persist_rows.hip `s_pages`): a slice is at most
+    // ceil(max_seq_len / (16 / R)) tokens (fewer slices only while the cache is shorter than that many 128-token chunks)
+    bool rows_kv_span_ok(int R) const {
+        const int nslm = std::max(1, 16 / std::max(1, R));
+        return ((a_.max_seq_len + nslm - 1) / nslm) / KV_PAGE + 2 <= 160;
+    }
+    // the request-row kernels' control words: [1] = a grid-wide wait hit its spin bound, [2] = launched with a sampler configuration the
+    // instantiation was not built for.  Either way the codes of this call are garbage: reset the words, take the handle off the
+    // persistent kernels for its next calls (like generate() does) and raise.
+    void rows_check_ctl(bool include_b1_fast) {
+        bool timeout = false, bad_cfg = false;
+        for (DevBuf* cb : {&d_rctl_s_, &d_rctl_f_, include_b1_fast ? &d_ctl_ : (DevBuf*)nullptr}) {
+            if (!cb || !cb->p) continue;
+            uint32_t ctl[4] = {0, 0, 0, 0};
+            FS_HIP(hipMemcpy(ctl, cb->p, sizeof(ctl), hipMemcpyDeviceToHost));
+            if (ctl[1] || ctl[2]) FS_HIP(hipMemset((uint32_t*)cb->p + 1, 0, 8));
+            timeout |= ctl[1] != 0; bad_cfg |= ctl[2] != 0;
+        }
+        if (timeout) {
+            pslow_ok_ = persist_ok_ = false;
+            throw Error("request-row persistent kernels: a grid-wide wait timed out (are all 256 CUs available to this process?); "
+                        "the handle falls back to per-node launches for its next calls");
+        }
+        if (bad_cfg) throw Error("request-row persistent kernels launched with a sampling configuration they were not built for");
+    }
+    // use_persist_ / use_pslow_ / persist_sampled_ select graphs and sampler folding for generate(); a row-path call sets them for its own
+    // launches and must leave them cleared however it ends
+    struct PersistFlagsGuard {
+        LM& lm;
+        ~PersistFlagsGuard() { lm.use_persist_ = lm.use_pslow_ = false; }
+    };
     void require_loaded() { FS_REQUIRE(loaded_, "weights not loaded: call fs_lm_load_safetensors or fs_lm_load_synthetic first"); }
 
     SampleCfg base_cfg() const {

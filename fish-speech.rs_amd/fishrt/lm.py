@@ -175,6 +175,15 @@ class DualARTransformer:
                                                    out.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_size_t(cap), nf))
         return [out[i, :, : nf[i]].copy() for i in range(n)]
 
+    def rows_supported(self, n, temp=0.0, top_p=1.0, top_k=0, repetition_penalty=1.2):
+        """fishrt.h fs_lm_rows_supported: would generate_multi serve n requests with these settings on the request-row kernels?"""
+        per = lambda v: list(v) if isinstance(v, (list, tuple, np.ndarray)) else [v] * n
+        temps, tps, tks, rps = per(temp), per(top_p), per(top_k), per(repetition_penalty)
+        ss = (_ffi.Sampling * n)(*[_ffi.Sampling(float(temps[i]), float(tps[i]), int(tks[i]), float(rps[i])) for i in range(n)])
+        ok = C.c_int(0)
+        _ffi.check(_ffi.lib().fs_lm_rows_supported(self._h, int(n), ss, C.byref(ok)))
+        return bool(ok.value)
+
     def weights_arena(self):
         """(device pointer, bytes) of the handle's weight arena (fishrt.h: fs_lm_weights_arena) -- for fanout.broadcast_weights"""
         ptr, n = C.c_void_p(), C.c_size_t(0)

@@ -224,7 +224,8 @@ class Scheduler:
                             seed = self.s.seed_source() & (2**64 - 1)
                             # handles with 2 / 4 / 8 slots and the request-row kernels: the slots keep the batch-1 semantics of _single
                             # (repetition penalty, one LogitsProcessor stream per job) while they share every decode launch (FS_SESSION_ROWS)
-                            rows = getattr(lm, "max_batch", 0) in (2, 4, 8) and hasattr(lm, "generate_multi") and (sa.temp == 0 or 0 < sa.top_k <= 256)
+                            rows = (getattr(lm, "max_batch", 0) in (2, 4, 8) and hasattr(lm, "rows_supported")
+                                    and lm.rows_supported(lm.max_batch, **sa.kw()))
                             try:
                                 sess = lm.session(temp=sa.temp, top_p=sa.top_p, top_k=sa.top_k, seed=seed, rows=True,
                                                   repetition_penalty=sa.repetition_penalty) if rows else None
@@ -328,7 +329,10 @@ class Scheduler:
         self.stats["batches"] += 1
         self.stats["batched_rows"] += len(jobs)
         kw = sa.kw()
-        if 2 <= len(jobs) <= 8 and len(jobs) <= getattr(lm, "max_batch", 0) and hasattr(lm, "generate_multi"):
+        # (only where the C side really takes the row kernels: on any other handle / sampler setting fs_lm_generate_multi would run the jobs
+        # one after the other -- N times the latency of ONE lock-step generate_static_batch, which streams the weights once per step)
+        if (2 <= len(jobs) <= 8 and len(jobs) <= getattr(lm, "max_batch", 0) and hasattr(lm, "generate_multi")
+                and hasattr(lm, "rows_supported") and lm.rows_supported(len(jobs), **kw)):
             # request rows (fishrt.h fs_lm_generate_multi): every job keeps the batch-1 semantics of _single -- its own repetition-penalty
             # window and sampler stream -- while one persistent launch serves all of them
             self.stats["row_batches"] = self.stats.get("row_batches", 0) + 1

@@ -191,6 +191,13 @@ int fs_lm_generate_multi(fs_lm_t* lm, const uint32_t* prompts, const int* lens, 
                          const fs_sampling* samplings, const uint64_t* seeds, uint32_t flags, uint32_t* codes_out, size_t cap,
                          size_t* n_frames);
 
+/* Capability query for schedulers (fishrt/server.py): *supported = 1 when fs_lm_generate_multi would serve these n requests with these
+ * sampler settings on the request-row kernels (one persistent launch group per frame), 0 when it would run them one after the other
+ * through fs_lm_generate (handle dtype / token layout / n / sampler mix outside the row kernels) -- in which case a lock-step
+ * fs_lm_generate_batch streams the weights once per step for all of them and is the better multi-request path.  Static property of the
+ * handle and the settings: it does not look at whether another call currently holds the device's persistent kernels. */
+int fs_lm_rows_supported(fs_lm_t* lm, int n, const fs_sampling* samplings, int* supported);
+
 /* ---- replica start-up (no reference counterpart: the reference has no distributed layer).  The handle's device
  * weight arena -- every checkpoint tensor in the handle's storage type, laid out by its tensor plan -- is a pure function of (model args,
  * token config, dtype, checkpoint), so N replicas need ONE checkpoint read: rank 0 loads, fs_lm_weights_arena() gives every rank the

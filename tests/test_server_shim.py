@@ -282,6 +282,7 @@ def test_lock_step_variant_runs_small_batches_as_request_rows():
         finally:
             lm.lock.release()
     lm.generate_multi = generate_multi
+    lm.rows_supported = lambda n, **kw: True
     c = _client(state)
     results = _fire(c, 6)
     assert all(r.status_code == 200 for r in results.values())
@@ -289,6 +290,26 @@ def test_lock_step_variant_runs_small_batches_as_request_rows():
     assert multi and "batch" not in [k[0] for k in lm.calls]
     assert all("repetition_penalty" in k[3] and len(set(k[2])) == len(k[2]) == len(k[1]) for k in multi)
     assert state.scheduler.stats.get("row_batches", 0) == len(multi)
+    state.scheduler.close()
+
+
+def test_lock_step_variant_keeps_the_static_batch_where_the_row_kernels_do_not_apply():
+    """fs_lm_rows_supported == 0 (fp8 / f32 / Fish <= 1.4 handle, sampler outside the in-launch sampler): generate_multi would run the jobs
+    one after the other, so the scheduler must keep ONE lock-step generate_static_batch and must not count a row batch"""
+    state, lm = _state(max_batch=8, continuous=False, slow=0.02, auto_batch=True)
+    lm.max_batch = 8
+    asked = []
+
+    def generate_multi(prompts, max_new_tokens, seeds=None, **kw):
+        raise AssertionError("generate_multi taken on a handle that cannot run request rows")
+    lm.generate_multi = generate_multi
+    lm.rows_supported = lambda n, **kw: asked.append((n, dict(kw))) or False
+    c = _client(state)
+    results = _fire(c, 6)
+    assert all(r.status_code == 200 for r in results.values())
+    assert asked and all(2 <= n <= 8 and "temp" in kw and "top_k" in kw for n, kw in asked)
+    assert "batch" in [k[0] for k in lm.calls] and "multi" not in [k[0] for k in lm.calls]
+    assert state.scheduler.stats.get("row_batches", 0) == 0
     state.scheduler.close()
 
 

@@ -18,6 +18,11 @@
 #include <type_traits>
 #include <vector>
 
+#include <fcntl.h>
+#include <sys/file.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include "fs_common.h"
 #include "fs_synth.h"
 #include "lm_kernels.h"
@@ -70,12 +75,53 @@ void seed_key(uint64_t state, uint32_t* key) {
 }
 
 
-// The persistent fast-decoder kernel needs all of its 256 workgroups co-resident; two such launches from two handles of one GPU
-// could each hold half of the CUs and wait for the other half forever (until their spin limits).  One generate call at a time may
-// use it per device; a concurrent call on another handle takes the per-node graph instead.
-std::mutex& persist_mutex(int device) {
-    static std::mutex m[64];
+// The persistent kernels need all of their 256 workgroups co-resident; two such launches on one GPU -- from two handles of one process
+// OR from two processes -- could each hold half of the CUs and wait for the other half forever (until their spin limits).  One call at a
+// time may use them per PHYSICAL device: an in-process mutex (threads) plus an advisory flock() on a per-device file keyed by the PCI bus
+// id (processes; the kernel drops the lock when its holder dies).  A call that does not get the lock takes the per-node graphs instead;
+// FISHRT_PERSIST_WAIT=1 makes it wait for the holder (two ranks sharing one GPU in a rehearsal: both deterministic, one after the other).
+class PersistLock {
+  public:
+    void bind(int device) {
+        std::call_once(once_, [&] {
+            char bus[64] = {0};
+            if (hipDeviceGetPCIBusId(bus, sizeof(bus), device) != hipSuccess) snprintf(bus, sizeof(bus), "dev%d", device);
+            for (char* c = bus; *c; ++c) if (*c == ':' || *c == '/') *c = '_';
+            for (const char* dir : {"/dev/shm", "/tmp"}) {
+                const std::string path = std::string(dir) + "/fishrt-persist-" + bus + ".lock";
+                fd_ = open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+                if (fd_ >= 0) { (void)fchmod(fd_, 0666); break; }
+            }  // (no writable directory: the lock stays process-local)
+        });
+    }
+    bool try_lock() {
+        if (!m_.try_lock()) return false;
+        if (fd_ >= 0 && flock(fd_, LOCK_EX | LOCK_NB) != 0) { m_.unlock(); return false; }
+        return true;
+    }
+    void lock() {
+        m_.lock();
+        if (fd_ >= 0) while (flock(fd_, LOCK_EX) != 0 && errno == EINTR) {}
+    }
+    void unlock() {
+        if (fd_ >= 0) (void)flock(fd_, LOCK_UN);
+        m_.unlock();
+    }
+
+  private:
+    std::mutex m_;
+    std::once_flag once_;
+    int fd_ = -1;
+};
+PersistLock& persist_mutex(int device) {
+    static PersistLock m[64];
+    m[device & 63].bind(device);
     return m[device & 63];
+}
+// try (default) or wait (FISHRT_PERSIST_WAIT) for the device's persistent kernels
+std::unique_lock<PersistLock> acquire_persist(int device) {
+    if (getenv("FISHRT_PERSIST_WAIT")) return std::unique_lock<PersistLock>(persist_mutex(device));
+    return std::unique_lock<PersistLock>(persist_mutex(device), std::try_to_lock);
 }
 
 constexpr int kRows = 256;     // static-batch generator: max sequences per step (32-row MFMA panels; <= kPartRows)
@@ -419,10 +465,10 @@ class LM final : public LMBase {
         FS_HIP(hipMemcpyAsync(d_cfg_.p, &cfg, sizeof(cfg), hipMemcpyHostToDevice, st_));
         // greedy decoding on a Fish-geometry bf16 handle: the 8 fast-decoder passes of a frame run as ONE persistent launch
         // (lm_persist.hip) instead of 144 graph nodes, if no other handle of this GPU is using it right now
-        std::unique_lock<std::mutex> plock;
+        std::unique_lock<PersistLock> plock;
         use_persist_ = use_pslow_ = false;
         if ((persist_ok_ || pslow_ok_) && !(flags & FS_GEN_NO_PERSIST)) {
-            plock = std::unique_lock<std::mutex>(persist_mutex(device_), std::try_to_lock);
+            plock = acquire_persist(device_);
             // the fast kernel decides in-launch: greedily (host ArgMax rule), or with the block-parallel top-k / top-p sampler when top_k <= 256
             persist_sampled_ = cfg.temp != 0.f;
             use_persist_ = plock.owns_lock() && persist_ok_ && batch_rows_ == 0 &&
@@ -581,12 +627,13 @@ class LM final : public LMBase {
         }
         if (use_pslow_) {
             if (getenv("FISHRT_PERSIST_PROF")) {
-                unsigned long long pr[8];
+                unsigned long long pr[16];
                 FS_HIP(hipMemcpy(pr, d_sctl_.as<uint32_t>() + 16, sizeof(pr), hipMemcpyDeviceToHost));
                 FS_HIP(hipMemset(d_sctl_.as<uint32_t>() + 16, 0, sizeof(pr)));
                 const double f = 0.01 / std::max<double>(1.0, (double)stats_.graph_launches - (double)L + 1);
-                fprintf(stderr, "slow persist prof (us/frame, workgroup 0): S1 %.1f  S2 %.1f  S3 %.1f  S4 %.1f  S5 %.1f  head %.1f\n", pr[1] * f, pr[2] * f, pr[3] * f,
-                        pr[4] * f, pr[5] * f, pr[6] * f);
+                fprintf(stderr, "slow persist prof (us/frame, workgroup %d; wait+work): S1 %.1f+%.1f  S2 %.1f+%.1f  S3 %.1f+%.1f  S4 %.1f+%.1f  S5 %.1f+%.1f  head %.1f+%.1f\n",
+                        getenv("FISHRT_PERSIST_PROF_WG") ? atoi(getenv("FISHRT_PERSIST_PROF_WG")) : 0, pr[9] * f, pr[1] * f, pr[10] * f, pr[2] * f, pr[11] * f, pr[3] * f,
+                        pr[12] * f, pr[4] * f, pr[13] * f, pr[5] * f, pr[14] * f, pr[6] * f);
             }
             uint32_t ctl[4] = {0, 0, 0, 0};
             FS_HIP(hipMemcpy(ctl, d_sctl_.p, sizeof(ctl), hipMemcpyDeviceToHost));
@@ -798,7 +845,7 @@ class LM final : public LMBase {
         // its own generate_blocking (repetition penalty, its own LogitsProcessor stream seeded seed + its admission number) -- instead of the
         // static-batch sampler's.  Needs max_batch <= 8, a bf16 Fish-1.5 handle and a sampler setting the in-launch decisions cover.
         sess_rows_ = false;
-        std::unique_lock<std::mutex> rows_lock;
+        std::unique_lock<PersistLock> rows_lock;
         struct RowsGuard {  // anything thrown below leaves the handle out of row mode (the local lock releases itself)
             bool& flag; bool armed = true;
             ~RowsGuard() { if (armed) flag = false; }
@@ -813,7 +860,7 @@ class LM final : public LMBase {
             FS_REQUIRE(!free_pages_.empty(), "KV page pool exhausted");
             // the device's persistent-kernel lock is held in a LOCAL until nothing below can throw any more (a throw after taking it used to
             // leave sess_plock_ owning the mutex with sess_active_ false: session_end returned early and the device was locked out for good)
-            rows_lock = std::unique_lock<std::mutex>(persist_mutex(device_), std::try_to_lock);
+            rows_lock = acquire_persist(device_);
             FS_REQUIRE(rows_lock.owns_lock(), "another call on this device holds the persistent kernels");
             sess_R_ = B_;
             ensure_rows(sess_R_);
@@ -1221,8 +1268,8 @@ class LM final : public LMBase {
         }
         bool rows_ok = rows_supported(n, samplings) && !(flags & FS_GEN_NO_PERSIST);
         const bool rows_sampled = samplings[0].temp != 0.0;
-        std::unique_lock<std::mutex> plock;
-        if (rows_ok) { plock = std::unique_lock<std::mutex>(persist_mutex(device_), std::try_to_lock); rows_ok = plock.owns_lock(); }
+        std::unique_lock<PersistLock> plock;
+        if (rows_ok) { plock = acquire_persist(device_); rows_ok = plock.owns_lock(); }
         if (!rows_ok) {
             if (plock.owns_lock()) plock.unlock();
             double pf = 0, dc = 0; uint64_t fr = 0, pt = 0, gl = 0;
@@ -1882,6 +1929,7 @@ class LM final : public LMBase {
         A.ctl = d_sctl_.as<uint32_t>();
         A.prof = getenv("FISHRT_PERSIST_PROF") ? reinterpret_cast<unsigned long long*>(d_sctl_.as<uint32_t>() + 16) : nullptr;
         set_naps(A.naps, "FISHRT_NAPS_SLOW", kFp8 ? kNapsSlowFp8 : kNapsSlow);
+        A.prof_wg = getenv("FISHRT_PERSIST_PROF_WG") ? atoi(getenv("FISHRT_PERSIST_PROF_WG")) : 0;
         return A;
     }
     // the persistent fast decoder takes the slow-token decision in its prologue (no k_sample_slow node) whenever it runs
@@ -2120,7 +2168,7 @@ class LM final : public LMBase {
     bool sess_active_ = false, sess_rows_ = false, sess_sampled_ = false;  // sess_rows_: FS_SESSION_ROWS (slots on the request-row kernels)
     int sess_R_ = 0, sess_adds_ = 0, sess_budget_tmp_ = 0;
     uint64_t sess_seed_ = 0;
-    std::unique_lock<std::mutex> sess_plock_;
+    std::unique_lock<PersistLock> sess_plock_;
     std::vector<int> sess_left_, sess_pos_;
     std::vector<SeqState> sess_hs_;
     int sess_scratch_ = 0;

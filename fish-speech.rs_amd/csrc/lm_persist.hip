@@ -362,13 +362,17 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
                     const float r8 = pf_reduce<8>(a8, lane);
                     if ((lane & 7) == 0) red[(par * 8 + wave) * PF_RED + (lane >> 3)] = r8;
                     __syncthreads();
-                    if (tid < 5 * PF_REPL) {
-                        const int r = tid % 5, rr = tid / 5;
-                        float t = red[(par * 8) * PF_RED + r], tot = red[(par * 8) * PF_RED + 5];
-#pragma unroll
-                        for (int w = 1; w < 8; ++w) { t += red[(par * 8 + w) * PF_RED + r]; tot += red[(par * 8 + w) * PF_RED + 5]; }
-                        if (fp8) t *= s_scl[48 * l + r];
-                        pf_publish(edges, e, rr, 5 * b + r, tag0 + e + 1, t * pf_rms_inv(tot, A.eps));
+                    if (wave == 0) {  // publishing wave (pf_sum_rows): lane (row r, lane row k) -> replicas k, k + 4
+                        const int r = min(lane & 15, 5), k = lane >> 4;
+                        const float* rp = red + (par * 8 + k) * PF_RED;
+                        float t = pf_sum_rows(rp[r] + rp[4 * PF_RED + r]);
+                        const float tot = pf_sum_rows(rp[5] + rp[4 * PF_RED + 5]);
+                        if (fp8) t *= s_scl[48 * l + min(r, 4)];
+                        if ((lane & 15) < 5) {
+                            const float val = t * pf_rms_inv(tot, A.eps);
+                            pf_publish(edges, e, k, 5 * b + r, tag0 + e + 1, val);
+                            pf_publish(edges, e, k + 4, 5 * b + r, tag0 + e + 1, val);
+                        }
                     }
                     par ^= 1;
                     PF_TICK(1);
@@ -438,15 +442,17 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
                     const float r4 = pf_reduce<4>(a4, lane);
                     if ((lane & 15) == 0) red[(par * 8 + wave) * PF_RED + (lane >> 4)] = r4;
                     float xres = 0.f;
-                    if (tid < 4 * PF_REPL) xres = xr[tid & 3];
+                    if (tid < 64) xres = xr[min(tid & 15, 3)];
                     __syncthreads();
-                    if (tid < 4 * PF_REPL) {
-                        const int r = tid & 3, rr = tid >> 2;
-                        float t = red[(par * 8) * PF_RED + r];
-#pragma unroll
-                        for (int w = 1; w < 8; ++w) t += red[(par * 8 + w) * PF_RED + r];
+                    if (wave == 0) {
+                        const int r = min(lane & 15, 3), k = lane >> 4;
+                        const float* rp = red + (par * 8 + k) * PF_RED;
+                        float t = pf_sum_rows(rp[r] + rp[4 * PF_RED + r]);
                         if (fp8) t *= s_scl[48 * l + 8 + r];
-                        pf_publish(edges, e, rr, 4 * b + r, tag0 + e + 1, xres + t);
+                        if ((lane & 15) < 4) {
+                            pf_publish(edges, e, k, 4 * b + r, tag0 + e + 1, xres + t);
+                            pf_publish(edges, e, k + 4, 4 * b + r, tag0 + e + 1, xres + t);
+                        }
                     }
                     par ^= 1;
                     PF_TICK(2);
@@ -508,18 +514,18 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
                     PF_TICK(8);
                     __syncthreads();
                     PF_TICK(15);
-                    if (tid < 16 * PF_REPL) {
-                        const int jj = tid & 15, rr = tid >> 4;
-                        float ga = red[(par * 8) * PF_RED + 2 * jj], gb = red[(par * 8) * PF_RED + 2 * jj + 1], tot = red[(par * 8) * PF_RED + 32];
-#pragma unroll
-                        for (int w = 1; w < 8; ++w) {
-                            ga += red[(par * 8 + w) * PF_RED + 2 * jj]; gb += red[(par * 8 + w) * PF_RED + 2 * jj + 1];
-                            tot += red[(par * 8 + w) * PF_RED + 32];
-                        }
+                    if (wave == 0) {
+                        const int jj = lane & 15, k = lane >> 4;
+                        const float* rp = red + (par * 8 + k) * PF_RED;
+                        const float2 g2 = *reinterpret_cast<const float2*>(rp + 2 * jj), h2 = *reinterpret_cast<const float2*>(rp + 4 * PF_RED + 2 * jj);
+                        float ga = pf_sum_rows(g2.x + h2.x), gb = pf_sum_rows(g2.y + h2.y);
+                        const float tot = pf_sum_rows(rp[32] + rp[4 * PF_RED + 32]);
                         const float dni = pf_rms_inv(tot, A.eps);
                         if (fp8) { ga *= s_scl[48 * l + 12 + 2 * jj]; gb *= s_scl[48 * l + 12 + 2 * jj + 1]; }
                         ga *= dni; gb *= dni;
-                        pf_publish(edges, e, rr, 16 * b + jj, tag0 + e + 1, pf_silu(ga) * gb);  // candle silu = x / (1 + exp(-x))
+                        const float act = pf_silu(ga) * gb;  // candle silu = x / (1 + exp(-x))
+                        pf_publish(edges, e, k, 16 * b + jj, tag0 + e + 1, act);
+                        pf_publish(edges, e, k + 4, 16 * b + jj, tag0 + e + 1, act);
                     }
                     par ^= 1;
                     PF_TICK(3);
@@ -545,15 +551,17 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
                     const float r4 = pf_reduce<4>(a4, lane);
                     if ((lane & 15) == 0) red[(par * 8 + wave) * PF_RED + (lane >> 4)] = r4;
                     float xres = 0.f;
-                    if (tid < 4 * PF_REPL) xres = xr[tid & 3];
+                    if (tid < 64) xres = xr[min(tid & 15, 3)];
                     __syncthreads();
-                    if (tid < 4 * PF_REPL) {
-                        const int r = tid & 3, rr = tid >> 2;
-                        float t = red[(par * 8) * PF_RED + r];
-#pragma unroll
-                        for (int w = 1; w < 8; ++w) t += red[(par * 8 + w) * PF_RED + r];
+                    if (wave == 0) {
+                        const int r = min(lane & 15, 3), k = lane >> 4;
+                        const float* rp = red + (par * 8 + k) * PF_RED;
+                        float t = pf_sum_rows(rp[r] + rp[4 * PF_RED + r]);
                         if (fp8) t *= s_scl[48 * l + 44 + r];
-                        pf_publish(edges, e, rr, 4 * b + r, tag0 + e + 1, xres + t);
+                        if ((lane & 15) < 4) {
+                            pf_publish(edges, e, k, 4 * b + r, tag0 + e + 1, xres + t);
+                            pf_publish(edges, e, k + 4, 4 * b + r, tag0 + e + 1, xres + t);
+                        }
                     }
                     par ^= 1;
                     PF_TICK(4);
@@ -578,13 +586,17 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
                 const float r8 = pf_reduce<8>(a8, lane);
                 if ((lane & 7) == 0) red[(par * 8 + wave) * PF_RED + (lane >> 3)] = r8;
                 __syncthreads();
-                if (tid < 4 * PF_REPL) {
-                    const int r = tid & 3, rr = tid >> 2;
-                    float t = red[(par * 8) * PF_RED + r], tot = red[(par * 8) * PF_RED + 4];
-#pragma unroll
-                    for (int w = 1; w < 8; ++w) { t += red[(par * 8 + w) * PF_RED + r]; tot += red[(par * 8 + w) * PF_RED + 4]; }
+                if (wave == 0) {
+                    const int r = min(lane & 15, 3), k = lane >> 4;
+                    const float* rp = red + (par * 8 + k) * PF_RED;
+                    float t = pf_sum_rows(rp[r] + rp[4 * PF_RED + r]);
+                    const float tot = pf_sum_rows(rp[4] + rp[4 * PF_RED + 4]);
                     if (fp8) t *= s_scl[192 + r];
-                    pf_publish(edges, e, rr, 4 * b + r, tag0 + e + 1, t * pf_rms_inv(tot, A.eps));
+                    if ((lane & 15) < 4) {
+                        const float val = t * pf_rms_inv(tot, A.eps);
+                        pf_publish(edges, e, k, 4 * b + r, tag0 + e + 1, val);
+                        pf_publish(edges, e, k + 4, 4 * b + r, tag0 + e + 1, val);
+                    }
                 }
                 par ^= 1;
                     PF_TICK(5);

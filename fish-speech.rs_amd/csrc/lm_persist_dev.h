@@ -127,6 +127,20 @@ __device__ __forceinline__ float pf_wave_sum(float v) {
     return __uint_as_float(r2[0]) + __uint_as_float(r2[1]);
 }
 
+// Sum over the four 16-lane rows of a wave (lanes l, l ^ 16, l ^ 32, l ^ 48), left in all four with identical bits (both levels add the same
+// two operands on either side).  The publishing wave of a stage uses it to add the 8 wave partials behind the stage's block barrier: lane
+// (value r = lane & 15, row k = lane >> 4) adds partials k and k + 4 from LDS, the rows meet through two v_permlane swaps, and row k stores
+// edge replicas k and k + 4 -- r consecutive granules per replica and store instruction, as before.  The chain behind the barrier is 2 LDS
+// reads + 3 adds + 2 swaps instead of 8-24 dependent LDS reads + adds on a lone wave (round 5: a stage's epilogue measured ~0.35 us of
+// dependent issue latency; an 8-lanes-per-value DPP variant shortened it as well but scattered the write-through stores over 8 replicas per
+// value and the NEXT stage's wait grew by more than the epilogue lost, profiles/r05_stage_profile.txt).
+__device__ __forceinline__ float pf_sum_rows(float x) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    const float t = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    const auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+    return __uint_as_float(r2[0]) + __uint_as_float(r2[1]);
+}
+
 // value barrier: what is derived from the result is not loop-invariant, so per-lane addresses / predicates are recomputed per stage
 // (a few VALU ops) instead of being hoisted out of the pass loop into ~150 extra live registers
 __device__ __forceinline__ int pf_opaque(int v) { asm volatile("" : "+v"(v)); return v; }

@@ -29,6 +29,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "fs_common.h"
@@ -250,9 +251,31 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
     bool dead = false;
     unsigned e = 0;
     int par = 0;
-    unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = A.prof ? wall_clock64() : 0;
+    unsigned long long tk[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = A.prof ? wall_clock64() : 0;  // [1..6] work of S1..S5 / head, [9..14] the wait (nap + sweep) in front of it
 #define PS_TICK(k) do { if (A.prof) { const unsigned long long n_ = wall_clock64(); tk[k] += n_ - t_last; t_last = n_; } } while (0)
 
+    // tile 0 of this workgroup's slice is the same rows of every layer's pool: its element offsets are computed ONCE (the per-layer request
+    // used to redo two LDS page lookups + 64-bit address arithmetic per lane inside S1, on the critical path of the qkv edge: an attention
+    // workgroup published 0.65 us later than the others, profiles/r05_stage_profile.txt)
+    uint32_t kv_off0[2] = {0u, 0u};
+    if (att && n_tok > 0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + PF_THREADS * u;
+            const int t = min(t0 + (i >> 3), max(t1 - 1, t0));
+            const int pg = s_pages[(t >> 6) - (t0 >> 6)];
+            kv_off0[u] = (uint32_t)(((pg * 2 + ag) * KV_PAGE + (t & 63)) * 64 + (i & 7) * 8);
+        }
+    }
+    auto load_kv_tile0 = [&](int l) {
+        const uint16_t* kpool = reinterpret_cast<const uint16_t*>(A.kv_pool) + (size_t)l * 2 * A.layer_half;
+        const uint16_t* vpool = kpool + A.layer_half;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            kreg[u] = *reinterpret_cast<const u32x4*>(kpool + kv_off0[u]);
+            vreg[u] = *reinterpret_cast<const u32x4*>(vpool + kv_off0[u]);
+        }
+    };
     auto load_kv_tile = [&](int l, int tile) {  // 128 tokens x 64 dims of K and V of kv head ag: lane unit i = tid + 512 u -> token i >> 3, 16-B slice i & 7
         const uint16_t* kpool = reinterpret_cast<const uint16_t*>(A.kv_pool) + (size_t)l * 2 * A.layer_half;
         const uint16_t* vpool = kpool + A.layer_half;
@@ -280,14 +303,15 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
                 pf_sweep1(my_edges + (size_t)(e & 3) * ering, tid, tag0 + e + 1, v, dead, A.ctl);
                 x0 = __uint_as_float(v.x); x1 = __uint_as_float(v.z);
                 ++e;
+                PS_TICK(9);
             }
-            if (att && n_tok > 0) load_kv_tile(l, 0);  // this layer's first K/V tile, under the qkv stage
+            if (att && n_tok > 0) load_kv_tile0(l);  // this layer's first K/V tile, under the qkv stage
             *reinterpret_cast<float2*>(xs + 2 * tid) = make_float2(x0, x1);
             const float xn0 = x0 * nw.x, xn1 = x1 * nw.y;
             float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             float rsc = 1.f;
             if constexpr (FP8) {
-                if (tid < 5 * PF_REPL) rsc = scl[(size_t)l * scl_layer + SC_QKV + tid % 5];
+                if (tid < 64) rsc = scl[(size_t)l * scl_layer + SC_QKV + min(tid & 15, 4)];
                 pf_dot2x2_fp8(wq4f.x, xn0, xn1, a8[0], a8[1]); pf_dot2x2_fp8(wq4f.y, xn0, xn1, a8[2], a8[3]);
                 pf_dot2x2_fp8(wq1, xn0, xn1, a8[4], a8[6]);  // (the odd half of this dword is zero)
                 a8[6] = 0.f;
@@ -300,13 +324,17 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
             const float r8 = pf_reduce<8>(a8, lane);
             if ((lane & 7) == 0) red[(par * 8 + wave) * PS_RED + (lane >> 3)] = r8;
             __syncthreads();
-            if (tid < 5 * PF_REPL) {
-                const int r = tid % 5, rr = tid / 5;
-                float t = red[(par * 8) * PS_RED + r], tot = red[(par * 8) * PS_RED + 5];
-#pragma unroll
-                for (int w = 1; w < 8; ++w) { t += red[(par * 8 + w) * PS_RED + r]; tot += red[(par * 8 + w) * PS_RED + 5]; }
+            if (wave == 0) {  // publishing wave (pf_sum_rows): lane (row r, lane row k) -> replicas k, k + 4
+                const int r = min(lane & 15, 5), k = lane >> 4;
+                const float* rp = red + (par * 8 + k) * PS_RED;
+                float t = pf_sum_rows(rp[r] + rp[4 * PS_RED + r]);
+                const float tot = pf_sum_rows(rp[5] + rp[4 * PS_RED + 5]);
                 if constexpr (FP8) t *= rsc;
-                pub(e, rr, 5 * b + r, tag0 + e + 1, t * pf_rms_inv(tot, A.eps));
+                if ((lane & 15) < 5) {
+                    const float val = t * pf_rms_inv(tot, A.eps);
+                    pub(e, k, 5 * b + r, tag0 + e + 1, val);
+                    pub(e, k + 4, 5 * b + r, tag0 + e + 1, val);
+                }
             }
             par ^= 1;
             PS_TICK(1);
@@ -343,6 +371,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
             }
             ++e;
             __syncthreads();
+            PS_TICK(10);
             // Every WAVE keeps its own running {m, l, o} over the tiles (flash-decoding inside the workgroup): the wave maximum is uniform by DPP /
             // readlane, a lane accumulates p * v for its own tokens and 8-dim slice and p for its token (lanes with du == 0), and nothing crosses
             // lanes or waves until the tiles are done -- one cross-lane sum, ONE block barrier, a merge of the 8 wave partials by the 66 publishing
@@ -425,7 +454,8 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
                 }
             }
             __syncthreads();
-            // merge the 8 wave partials (flash-decoding rescale) and publish {o[64], m, l}: 66 threads x 8 replicas
+            // merge the 8 wave partials (flash-decoding rescale) and publish {o[64], m, l}: 66 threads x 8 replicas (every store instruction
+            // writes 64 consecutive granules of one replica; one granule per lane over 8 replicas per value measured +1.3 us on S3's wait)
             if (tid < 66) {
                 float M = wmax[0];
 #pragma unroll
@@ -502,9 +532,10 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
                 }
             }
             ++e;
+            PS_TICK(11);
             float rsc = 1.f;
             if constexpr (FP8) {
-                if (tid < 4 * PF_REPL) rsc = scl[(size_t)l * scl_layer + SC_WO + (tid & 3)];
+                if (tid < 64) rsc = scl[(size_t)l * scl_layer + SC_WO + min(tid & 15, 3)];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) w13f[c] = reinterpret_cast<const u32x4*>(wl + I8_W13)[c * PF_THREADS + tid];  // next stage's weights (32 KB per CU)
             } else {
@@ -512,18 +543,30 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
 #pragma unroll
                 for (int c = 1; c < 8; ++c) w13[c] = reinterpret_cast<const u32x4*>(wl + IM_W13)[c * PF_THREADS + tid];
             }
+            // flash-decoding combine of the head's slices, one instantiation per slice count (a runtime bound kept all 16 slots alive: 32
+            // predicated v_exp per lane whatever n_sl was)
+            auto merge = [&](auto NC) {
+                constexpr int NS = decltype(NC)::value;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) if (s < n_sl) mn = fmaxf(mn, sm[s]);
+                for (int s = 0; s < NS; ++s) mn = fmaxf(mn, sm[s]);
+                float ex[NS];
 #pragma unroll
-            for (int s = 0; s < 16; ++s) if (s < n_sl) L += sl_[s] * __expf(sm[s] - mn);
-            const float inv = 1.f / L;
+                for (int s = 0; s < NS; ++s) { ex[s] = __expf(sm[s] - mn); L += sl_[s] * ex[s]; }
+                const float inv = 1.f / L;
 #pragma unroll
-            for (int s = 0; s < 16; ++s)
-                if (s < n_sl) {
-                    const float wj = __expf(sm[s] - mn) * inv;
+                for (int s = 0; s < NS; ++s) {
+                    const float wj = ex[s] * inv;
                     at0 = fmaf(wj, so0[s], at0);
                     at1 = fmaf(wj, so1[s], at1);
                 }
+            };
+            switch (n_sl) {
+                case 1: merge(std::integral_constant<int, 1>{}); break;
+                case 2: merge(std::integral_constant<int, 2>{}); break;
+                case 4: merge(std::integral_constant<int, 4>{}); break;
+                case 8: merge(std::integral_constant<int, 8>{}); break;
+                default: merge(std::integral_constant<int, 16>{}); break;
+            }
             float a4[4] = {0.f, 0.f, 0.f, 0.f};
             if constexpr (FP8) {
                 pf_dot2x2_fp8(wo4f.x, at0, at1, a4[0], a4[1]); pf_dot2x2_fp8(wo4f.y, at0, at1, a4[2], a4[3]);
@@ -534,15 +577,17 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
             const float r4 = pf_reduce<4>(a4, lane);
             if ((lane & 15) == 0) red[(par * 8 + wave) * PS_RED + (lane >> 4)] = r4;
             float xres = 0.f;
-            if (tid < 4 * PF_REPL) xres = xs[4 * b + (tid & 3)];
+            if (tid < 64) xres = xs[4 * b + min(tid & 15, 3)];
             __syncthreads();
-            if (tid < 4 * PF_REPL) {
-                const int r = tid & 3, rr = tid >> 2;
-                float t = red[(par * 8) * PS_RED + r];
-#pragma unroll
-                for (int w = 1; w < 8; ++w) t += red[(par * 8 + w) * PS_RED + r];
+            if (wave == 0) {
+                const int r = min(lane & 15, 3), k = lane >> 4;
+                const float* rp = red + (par * 8 + k) * PS_RED;
+                float t = pf_sum_rows(rp[r] + rp[4 * PS_RED + r]);
                 if constexpr (FP8) t *= rsc;
-                pub(e, rr, 4 * b + r, tag0 + e + 1, xres + t);
+                if ((lane & 15) < 4) {
+                    pub(e, k, 4 * b + r, tag0 + e + 1, xres + t);
+                    pub(e, k + 4, 4 * b + r, tag0 + e + 1, xres + t);
+                }
             }
             par ^= 1;
             PS_TICK(3);
@@ -555,9 +600,10 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
             pf_nap_before_sweep(A.naps[3]);
             pf_sweep1(my_edges + (size_t)(e & 3) * ering, tid, tag0 + e + 1, v, dead, A.ctl);
             ++e;
+            PS_TICK(12);
             float rsa = 1.f, rsb = 1.f;
             if constexpr (FP8) {
-                if (tid < 16 * PF_REPL) { rsa = scl[(size_t)l * scl_layer + SC_W13 + 2 * (tid & 15)]; rsb = scl[(size_t)l * scl_layer + SC_W13 + 2 * (tid & 15) + 1]; }
+                if (tid < 64) { rsa = scl[(size_t)l * scl_layer + SC_W13 + 2 * (tid & 15)]; rsb = scl[(size_t)l * scl_layer + SC_W13 + 2 * (tid & 15) + 1]; }
                 w2f[0] = reinterpret_cast<const u32x4*>(wl + I8_W2)[tid]; w2f[1] = reinterpret_cast<const u32x4*>(wl + I8_W2)[PF_THREADS + tid];  // next stage's weights
             } else {
 #pragma unroll
@@ -590,18 +636,18 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
                 if ((lane & 3) == 0) red[(par * 8 + wave) * PS_RED + half * 16 + (lane >> 2)] = r16;
             }
             __syncthreads();
-            if (tid < 16 * PF_REPL) {
-                const int jj = tid & 15, rr = tid >> 4;
-                float ga = red[(par * 8) * PS_RED + 2 * jj], gb = red[(par * 8) * PS_RED + 2 * jj + 1], tot = red[(par * 8) * PS_RED + 32];
-#pragma unroll
-                for (int w = 1; w < 8; ++w) {
-                    ga += red[(par * 8 + w) * PS_RED + 2 * jj]; gb += red[(par * 8 + w) * PS_RED + 2 * jj + 1];
-                    tot += red[(par * 8 + w) * PS_RED + 32];
-                }
+            if (wave == 0) {
+                const int jj = lane & 15, k = lane >> 4;
+                const float* rp = red + (par * 8 + k) * PS_RED;
+                const float2 g2 = *reinterpret_cast<const float2*>(rp + 2 * jj), h2 = *reinterpret_cast<const float2*>(rp + 4 * PS_RED + 2 * jj);
+                float ga = pf_sum_rows(g2.x + h2.x), gb = pf_sum_rows(g2.y + h2.y);
+                const float tot = pf_sum_rows(rp[32] + rp[4 * PS_RED + 32]);
                 const float dni = pf_rms_inv(tot, A.eps);
                 if constexpr (FP8) { ga *= rsa; gb *= rsb; }
                 ga *= dni; gb *= dni;
-                pub(e, rr, 16 * b + jj, tag0 + e + 1, pf_silu(ga) * gb);
+                const float act = pf_silu(ga) * gb;
+                pub(e, k, 16 * b + jj, tag0 + e + 1, act);
+                pub(e, k + 4, 16 * b + jj, tag0 + e + 1, act);
             }
             par ^= 1;
             PS_TICK(4);
@@ -613,8 +659,9 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
             pf_nap_before_sweep(A.naps[4]);
             pf_sweep4(my_edges + (size_t)(e & 3) * ering, tid, tag0 + e + 1, v, dead, A.ctl);
             ++e;
+            PS_TICK(13);
             float rsc = 1.f;
-            if constexpr (FP8) { if (tid < 4 * PF_REPL) rsc = scl[(size_t)l * scl_layer + SC_W2 + (tid & 3)]; }
+            if constexpr (FP8) { if (tid < 64) rsc = scl[(size_t)l * scl_layer + SC_W2 + min(tid & 15, 3)]; }
             if (l + 1 < A.n_layer) {  // next layer's Wqkv rows
                 if constexpr (FP8) {
                     wq4f = reinterpret_cast<const u32x2*>(wl + layer_img + I8_QKV4)[tid];
@@ -644,15 +691,17 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
             const float r4 = pf_reduce<4>(a4, lane);
             if ((lane & 15) == 0) red[(par * 8 + wave) * PS_RED + (lane >> 4)] = r4;
             float xres = 0.f;
-            if (tid < 4 * PF_REPL) xres = xs[4 * b + (tid & 3)];
+            if (tid < 64) xres = xs[4 * b + min(tid & 15, 3)];
             __syncthreads();
-            if (tid < 4 * PF_REPL) {
-                const int r = tid & 3, rr = tid >> 2;
-                float t = red[(par * 8) * PS_RED + r];
-#pragma unroll
-                for (int w = 1; w < 8; ++w) t += red[(par * 8 + w) * PS_RED + r];
+            if (wave == 0) {
+                const int r = min(lane & 15, 3), k = lane >> 4;
+                const float* rp = red + (par * 8 + k) * PS_RED;
+                float t = pf_sum_rows(rp[r] + rp[4 * PS_RED + r]);
                 if constexpr (FP8) t *= rsc;
-                pub(e, rr, 4 * b + r, tag0 + e + 1, xres + t);
+                if ((lane & 15) < 4) {
+                    pub(e, k, 4 * b + r, tag0 + e + 1, xres + t);
+                    pub(e, k + 4, 4 * b + r, tag0 + e + 1, xres + t);
+                }
             }
             par ^= 1;
             PS_TICK(5);
@@ -665,11 +714,12 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
         const u32x4* hp = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(A.hpack) + (size_t)b * (FP8 ? PS_HEAD_IMAGE_FP8 : PS_HEAD_IMAGE));
         const u32x4 h0 = hp[tid], h1 = FP8 ? u32x4{0, 0, 0, 0} : hp[PF_THREADS + tid];
         float rsc = 1.f;
-        if constexpr (FP8) { if (tid < 8) rsc = A.hscales[8 * b + tid]; }
+        if constexpr (FP8) { if (tid < 64) rsc = A.hscales[8 * b + min(tid & 15, 7)]; }
         u32x4 v;
         pf_nap_before_sweep(A.naps[5]);
         pf_sweep1(my_edges + (size_t)(e & 3) * ering, tid, tag0 + e + 1, v, dead, A.ctl);
         ++e;
+        PS_TICK(14);
         x0 = __uint_as_float(v.x); x1 = __uint_as_float(v.z);
         if (b == 0) *reinterpret_cast<float2*>(A.x + 2 * tid) = make_float2(x0, x1);
         const float xn0 = x0 * nw.x, xn1 = x1 * nw.y;
@@ -686,19 +736,18 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
         if ((lane & 7) == 0) red[(par * 8 + wave) * PS_RED + (lane >> 3)] = r8;
         if (lane == 0) red[(par * 8 + wave) * PS_RED + 8] = ssw;
         __syncthreads();
-        if (tid < 8 && 8 * b + tid < A.n_head_rows) {
-            float t = red[(par * 8) * PS_RED + tid], tot = red[(par * 8) * PS_RED + 8];
-#pragma unroll
-            for (int w = 1; w < 8; ++w) { t += red[(par * 8 + w) * PS_RED + tid]; tot += red[(par * 8 + w) * PS_RED + 8]; }
+        if (wave == 0) {
+            const int r = min(lane & 15, 7), k = lane >> 4;
+            const float* rp = red + (par * 8 + k) * PS_RED;
+            float t = pf_sum_rows(rp[r] + rp[4 * PS_RED + r]);
+            const float tot = pf_sum_rows(rp[8] + rp[4 * PS_RED + 8]);
             if constexpr (FP8) t *= rsc;
-            A.logits[8 * b + tid] = t * pf_rms_inv(tot, A.eps);
+            if (lane < 8 && 8 * b + r < A.n_head_rows) A.logits[8 * b + r] = t * pf_rms_inv(tot, A.eps);
         }
         PS_TICK(6);
     }
-    if (b == 0 && tid == 0) {
-        A.ctl[0] = epoch + 1;
-        if (A.prof) for (int k = 0; k < 8; ++k) A.prof[k] += tk[k];
-    }
+    if (b == 0 && tid == 0) A.ctl[0] = epoch + 1;
+    if (A.prof && b == A.prof_wg && tid == 0) for (int k = 0; k < 16; ++k) A.prof[k] += tk[k];
 #undef PS_TICK
 }
 

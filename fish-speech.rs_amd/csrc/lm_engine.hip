@@ -1856,7 +1856,7 @@ class LM final : public LMBase {
 
     // naps before the first sweep of each stage kind (64-clock units; tuned on MI355X, profiles/r03_poll_naps.txt); the environment
     // variables ("a,b,c,d,e,f") override them for tuning runs
-    static constexpr int kNapsFast[6] = {16, 20, 16, 20, 16, 12}, kNapsSlow[6] = {24, 4, 8, 40, 32, 12};  // (re-tuned after the S2 restructurings of round 4: -1 us)
+    static constexpr int kNapsFast[6] = {12, 16, 16, 20, 12, 16}, kNapsSlow[6] = {20, 12, 2, 32, 32, 12};  // (re-tuned in round 5 behind the publishing-wave epilogues and the early W13 request: 558.8 -> 551.1 us on the tuner's workload)
     // the same coordinate descent on the in-launch-sampler instantiation of k_fast_persist (680 -> 662 us per sampled frame) and on the
     // e4m3 image of k_slow_persist (595 -> 585 us per fp8 frame): their stage arithmetic differs, so the edges complete at other times
     static constexpr int kNapsFastSampled[6] = {12, 12, 12, 20, 16, 16}, kNapsSlowFp8[6] = {20, 0, 32, 24, 28, 12};
@@ -1930,6 +1930,7 @@ class LM final : public LMBase {
         A.prof = getenv("FISHRT_PERSIST_PROF") ? reinterpret_cast<unsigned long long*>(d_sctl_.as<uint32_t>() + 16) : nullptr;
         set_naps(A.naps, "FISHRT_NAPS_SLOW", kFp8 ? kNapsSlowFp8 : kNapsSlow);
         A.prof_wg = getenv("FISHRT_PERSIST_PROF_WG") ? atoi(getenv("FISHRT_PERSIST_PROF_WG")) : 0;
+        A.l2_touch = getenv("FISHRT_SLOW_NO_EARLY13") ? 0 : 1;
         return A;
     }
     // the persistent fast decoder takes the slow-token decision in its prologue (no k_sample_slow node) whenever it runs

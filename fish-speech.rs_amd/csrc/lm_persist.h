@@ -88,6 +88,7 @@ struct SlowPersistArgs {
     uint32_t* ctl;          // [0] epoch, [1] timeouts
     int naps[6];            // 64-clock naps before the first sweep of S1 / S2 / S3 / S4 / S5 / head
     int prof_wg;            // the workgroup whose stage timers go to `prof` (FISHRT_PERSIST_PROF_WG; default 0 = an attention workgroup)
+    int l2_touch;           // 1: workgroups without an attention item request a layer's W13 slice behind S1's publish instead of in S3 (FISHRT_SLOW_NO_EARLY13=1 switches it off)
 };
 size_t slow_persist_pack_bytes(int n_layer, bool fp8 = false);
 size_t slow_persist_scale_floats(int n_layer);

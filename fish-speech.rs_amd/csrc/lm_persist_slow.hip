@@ -98,6 +98,13 @@ __device__ __forceinline__ void pf_sweep8u(const u64* base, const int (&unit)[8]
     }
 }
 
+// A 16-byte load the compiler's s_waitcnt bookkeeping does not see: dst is valid after the next sweep (every sweep statement ends in
+// s_waitcnt vmcnt(0)).  Used where the ISSUE POINT of a prefetch depends on the workgroup's role: as ordinary loads in two branches they
+// made every later wait for an older load a vmcnt(0) (the pass cannot count loads of a branch not taken) and cost what the early issue gained.
+__device__ __forceinline__ void ps_load16_unseen(u32x4& dst, const unsigned char* base, unsigned voff) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base));
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ weight images
@@ -251,6 +258,23 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
     bool dead = false;
     unsigned e = 0;
     int par = 0;
+    // W13 (needed by S4) is 56 % of a layer's bytes.  Requested one stage ahead by all 256 workgroups it is a 16.8 MB burst with ~2.4 us to
+    // arrive (7 TB/s): S4's sweep, behind it in a wave's return order, completed when the burst did -- S4 waited 2.2 us against 0.9 us for
+    // S1 (profiles/r05_stage_profile.txt).  The workgroups WITHOUT an attention item have no sweep and no K/V tile between S1's publish and
+    // S3, so they ask for their W13 slice right behind S1's publish, three stages ahead, while HBM is idle; the attention workgroups
+    // (64 or 128 of 256) keep asking in S3 and share a burst a quarter to a half the size.  (FISHRT_SLOW_NO_EARLY13=1: everybody in S3.)
+    // (measured and rejected on top of it, profiles/r05_stage_profile.txt: W2 riding with W13; the attention workgroups asking behind their S2
+    // publish; W2 through the same unseen loads at its old place in S4 -- each 5 .. 30 us per frame worse)
+    const bool early13 = A.l2_touch && !att;
+    auto request_w13 = [&](const unsigned char* wl_) {  // the W13 slice of this layer -> registers, valid after the next sweep
+        if constexpr (FP8) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ps_load16_unseen(w13f[c], wl_ + I8_W13 + (size_t)c * PF_THREADS * 16, (unsigned)tid_k * 16u);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) ps_load16_unseen(w13[c], wl_ + IM_W13 + (size_t)c * PF_THREADS * 16, (unsigned)tid_k * 16u);
+        }
+    };
     unsigned long long tk[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = A.prof ? wall_clock64() : 0;  // [1..6] work of S1..S5 / head, [9..14] the wait (nap + sweep) in front of it
 #define PS_TICK(k) do { if (A.prof) { const unsigned long long n_ = wall_clock64(); tk[k] += n_ - t_last; t_last = n_; } } while (0)
 
@@ -336,6 +360,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
                     pub(e, k + 4, 5 * b + r, tag0 + e + 1, val);
                 }
             }
+            if (early13) request_w13(wl);  // (nothing of this wave is in flight here: the stage's own weights and norm vector have been consumed)
             par ^= 1;
             PS_TICK(1);
         }
@@ -536,12 +561,11 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
             float rsc = 1.f;
             if constexpr (FP8) {
                 if (tid < 64) rsc = scl[(size_t)l * scl_layer + SC_WO + min(tid & 15, 3)];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) w13f[c] = reinterpret_cast<const u32x4*>(wl + I8_W13)[c * PF_THREADS + tid];  // next stage's weights (32 KB per CU)
+                asm volatile("" : "+v"(wo4f));  // (in flight since S2: the compiler's wait for it lands HERE, where the sweep's vmcnt(0) has already satisfied it, not behind the unseen loads)
+                if (!early13) request_w13(wl);  // next stage's weights (32 KB per CU)
             } else {
-                w13[0] = reinterpret_cast<const u32x4*>(wl + IM_W13)[tid];  // next stage's weights (64 KB per CU), behind the sweep
-#pragma unroll
-                for (int c = 1; c < 8; ++c) w13[c] = reinterpret_cast<const u32x4*>(wl + IM_W13)[c * PF_THREADS + tid];
+                asm volatile("" : "+v"(wo4));  // (see the fp8 branch)
+                if (!early13) request_w13(wl);  // next stage's weights (64 KB per CU), behind the sweep (workgroups without an attention item asked for them in S1)
             }
             // flash-decoding combine of the head's slices, one instantiation per slice count (a runtime bound kept all 16 slots alive: 32
             // predicated v_exp per lane whatever n_sl was)

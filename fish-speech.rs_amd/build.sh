@@ -18,6 +18,13 @@ for f in lm_kernels.hip lm_persist.hip lm_persist_slow.hip lm_persist_rows.hip l
     pids+=($!)
   fi
 done
+# the range-counting twin of the vocoder's f16 conversion kernels (csrc/codec_conv_bf3.hip compiled again with -DFS_C3_CHECK into fs::c3chk:
+# fs_codec_set_range_check); same source, second object
+o="$HERE/build/codec_conv_bf3_chk.o"
+if [ ! -f "$o" ] || [ codec_conv_bf3.hip -nt "$o" ] || [ -n "$(find . -name '*.h' -newer "$o" -print -quit)" ]; then
+  ( /opt/rocm/bin/hipcc $FLAGS -DFS_C3_CHECK -x hip -c codec_conv_bf3.hip -o "$o" ) &
+  pids+=($!)
+fi
 for p in "${pids[@]}"; do wait "$p"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "$HERE"/build/*.o -o "$HERE/libfishrt.so"
 echo "built $HERE/libfishrt.so"

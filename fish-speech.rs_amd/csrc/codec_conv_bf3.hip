@@ -33,6 +33,38 @@
 
 namespace fs {
 
+// Range-checked twin (f16 precision mode only): this file is compiled a second time with -DFS_C3_CHECK into namespace
+// fs::c3chk.  There every f32 -> f16 operand conversion (weights at pack time, activations in the producers' epilogues) counts operands that
+// SATURATE (|x| > 65504) or are FLUSHED to zero (0 < |x| < 2^-24) in a device counter.  The unchecked build's launchers forward to the twin
+// while codec_range_check(true) is set (fs_codec_set_range_check): the default kernels pay nothing for the diagnostic.
+#ifdef FS_C3_CHECK
+namespace c3chk {
+#else
+namespace c3chk {
+size_t codec_pack_bf3_elems(int Cin, int K, int Cout, bool f16);
+void codec_pack_bf3(const float* relaid, uint16_t* dst, int Cin, int K, int Cout, bool f16, hipStream_t st);
+void codec_conv1d_bf3(const float* x, const uint16_t* xp, int B, int Cin, int T, const uint16_t* wp, bool f16, const float* bias, int Cout, int K,
+                      int dil, bool pre_silu, int epi, const float* res, const float* gamma, float* y, uint16_t* yp, bool post_silu, int ps,
+                      hipStream_t st, const uint16_t* ctx_in, uint16_t* ctx_out, const float* mean_a, const float* mean_b);
+void codec_respair_f16(const uint16_t* xp, int B, int C, int T, const uint16_t* w1p, const float* b1, const uint16_t* w2p, const float* b2, int K, int dil,
+                       const float* res, float* y, uint16_t* yp, hipStream_t st, const uint16_t* mid_ctx_in, uint16_t* mid_ctx_out,
+                       const uint16_t* ctx_in, uint16_t* ctx_out, const float* mean_a, const float* mean_b);
+void codec_act_split(const float* x, int B, int C, int T, bool silu, uint16_t* planes, bool f16, hipStream_t st, const uint16_t* ctx_in, uint16_t* ctx_out);
+void codec_mean3_planes(const float* a, const float* b, const float* c, int B, int C, int T, bool silu, uint16_t* planes, bool f16, hipStream_t st,
+                        const uint16_t* ctx_in, uint16_t* ctx_out);
+void codec_range_reset(hipStream_t st);
+void codec_range_read(unsigned long long* out2, hipStream_t st);
+}  // namespace c3chk
+static bool g_c3_checked = false;
+void codec_range_check(bool on) { g_c3_checked = on; }
+void codec_range_reset(hipStream_t st) { c3chk::codec_range_reset(st); }
+void codec_range_read(unsigned long long* out2, hipStream_t st) { c3chk::codec_range_read(out2, st); }
+#endif
+
+#ifdef FS_C3_CHECK
+__device__ unsigned long long g_c3_range[2];  // [0] operands beyond +-65504 (saturated), [1] non-zero operands below 2^-24 (flushed to zero)
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -47,7 +79,14 @@ __device__ __forceinline__ uint32_t c3_bf16(float f) {  // round to nearest even
     uint32_t u = __float_as_uint(f);
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
-__device__ __forceinline__ uint32_t c3_f16(float f) {  // round to nearest even, saturating (|f| > 65504 does not occur in the vocoder)
+// round to nearest even, saturating.  |f| > 65504 does not occur with N(0, 1 / fan_in) synthetic convs; whether it does with a weight-normed
+// checkpoint is what the range-checked twin (FS_C3_CHECK, see the top of the file) counts.
+__device__ __forceinline__ uint32_t c3_f16(float f) {
+#ifdef FS_C3_CHECK
+    const float a = fabsf(f);
+    if (a > 65504.f) atomicAdd(&g_c3_range[0], 1ull);
+    else if (a != 0.f && a < 5.9604645e-8f) atomicAdd(&g_c3_range[1], 1ull);
+#endif
     return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)__builtin_amdgcn_fmed3f(f, -65504.f, 65504.f));
 }
 // F16 = false: v = hi + lo in bf16 ("bf16x3"); F16 = true: one f16 value ("f16": `lo` is not used by any caller)
@@ -708,6 +747,9 @@ size_t codec_pack_bf3_elems(int Cin, int K, int Cout, bool f16) {
 }
 
 void codec_pack_bf3(const float* relaid, uint16_t* dst, int Cin, int K, int Cout, bool f16, hipStream_t st) {
+#ifndef FS_C3_CHECK
+    if (g_c3_checked) return c3chk::codec_pack_bf3(relaid, dst, Cin, K, Cout, f16, st);
+#endif
     const int Cp = (Cout + 63) / 64 * 64;
     const size_t n = codec_pack_bf3_elems(Cin, K, Cout, f16);
     const dim3 grid((unsigned)std::min<size_t>((n + 255) / 256, 4096));
@@ -872,6 +914,9 @@ static void conv1d_bf3_impl(const float* x, const uint16_t* xp, int B, int Cin, 
 void codec_conv1d_bf3(const float* x, const uint16_t* xp, int B, int Cin, int T, const uint16_t* wp, bool f16, const float* bias, int Cout, int K,
                       int dil, bool pre_silu, int epi, const float* res, const float* gamma, float* y, uint16_t* yp, bool post_silu, int ps,
                       hipStream_t st, const uint16_t* ctx_in, uint16_t* ctx_out, const float* mean_a, const float* mean_b) {
+#ifndef FS_C3_CHECK
+    if (g_c3_checked) return c3chk::codec_conv1d_bf3(x, xp, B, Cin, T, wp, f16, bias, Cout, K, dil, pre_silu, epi, res, gamma, y, yp, post_silu, ps, st, ctx_in, ctx_out, mean_a, mean_b);
+#endif
     if (f16) conv1d_bf3_impl<true>(x, xp, B, Cin, T, wp, bias, Cout, K, dil, pre_silu, epi, res, gamma, y, yp, post_silu, ps, st, ctx_in, ctx_out, mean_a, mean_b);
     else conv1d_bf3_impl<false>(x, xp, B, Cin, T, wp, bias, Cout, K, dil, pre_silu, epi, res, gamma, y, yp, post_silu, ps, st, ctx_in, ctx_out, mean_a, mean_b);
 }
@@ -883,6 +928,9 @@ bool codec_respair_ok(int C, int K, int dil, bool f16) {
 void codec_respair_f16(const uint16_t* xp, int B, int C, int T, const uint16_t* w1p, const float* b1, const uint16_t* w2p, const float* b2, int K, int dil,
                        const float* res, float* y, uint16_t* yp, hipStream_t st, const uint16_t* mid_ctx_in, uint16_t* mid_ctx_out, const uint16_t* ctx_in,
                        uint16_t* ctx_out, const float* mean_a, const float* mean_b) {
+#ifndef FS_C3_CHECK
+    if (g_c3_checked) return c3chk::codec_respair_f16(xp, B, C, T, w1p, b1, w2p, b2, K, dil, res, y, yp, st, mid_ctx_in, mid_ctx_out, ctx_in, ctx_out, mean_a, mean_b);
+#endif
     FS_REQUIRE(codec_respair_ok(C, K, dil, true), "ResBlock pair outside the fused kernel's range");
     FS_REQUIRE(res && (y || yp), "the fused ResBlock pair needs the residual input and an output");
     FS_REQUIRE((mean_a != nullptr) == (mean_b != nullptr), "the folded ParallelBlock mean needs both partners");
@@ -919,6 +967,9 @@ void codec_respair_f16(const uint16_t* xp, int B, int C, int T, const uint16_t* 
 
 void codec_act_split(const float* x, int B, int C, int T, bool silu, uint16_t* planes, bool f16, hipStream_t st, const uint16_t* ctx_in,
                      uint16_t* ctx_out) {
+#ifndef FS_C3_CHECK
+    if (g_c3_checked) return c3chk::codec_act_split(x, B, C, T, silu, planes, f16, st, ctx_in, ctx_out);
+#endif
     FS_REQUIRE(C % 8 == 0, "activation planes need a multiple of 8 channels");
     FS_REQUIRE((!ctx_in && !ctx_out) || (B == 1 && T >= PP), "streaming contexts need one item and >= 64 samples per chunk");
     const dim3 grid((T + 255) / 256, C / 8, B);
@@ -930,6 +981,9 @@ void codec_act_split(const float* x, int B, int C, int T, bool silu, uint16_t* p
 
 void codec_mean3_planes(const float* a, const float* b, const float* c, int B, int C, int T, bool silu, uint16_t* planes, bool f16,
                         hipStream_t st, const uint16_t* ctx_in, uint16_t* ctx_out) {
+#ifndef FS_C3_CHECK
+    if (g_c3_checked) return c3chk::codec_mean3_planes(a, b, c, B, C, T, silu, planes, f16, st, ctx_in, ctx_out);
+#endif
     FS_REQUIRE(C % 8 == 0, "activation planes need a multiple of 8 channels");
     FS_REQUIRE((!ctx_in && !ctx_out) || (B == 1 && T >= PP), "streaming contexts need one item and >= 64 samples per chunk");
     const dim3 grid((T + 255) / 256, C / 8, B);
@@ -938,5 +992,20 @@ void codec_mean3_planes(const float* a, const float* b, const float* c, int B, i
     else hipLaunchKernelGGL(k_mean3_planes<false>, grid, dim3(256), 0, st, a, b, c, C, T, silu ? 1 : 0, planes, pc);
     FS_HIP(hipGetLastError());
 }
+
+#ifdef FS_C3_CHECK
+void codec_range_reset(hipStream_t st) {
+    void* p = nullptr;
+    FS_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(g_c3_range)));
+    FS_HIP(hipMemsetAsync(p, 0, 16, st));
+}
+void codec_range_read(unsigned long long* out2, hipStream_t st) {
+    void* p = nullptr;
+    FS_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(g_c3_range)));
+    FS_HIP(hipMemcpyAsync(out2, p, 16, hipMemcpyDeviceToHost, st));
+    FS_HIP(hipStreamSynchronize(st));
+}
+}  // namespace c3chk
+#endif
 
 }  // namespace fs

@@ -20,6 +20,8 @@ class CodecBase {
     virtual int sample_rate() = 0;
     virtual void set_precision(int mode) = 0;  // 0 = f32 (exact f32 products), 1 = bf16x3, 2 = f16 (default); decode only
     virtual int precision() = 0;
+    virtual void set_range_check(bool on) = 0;      // fs_codec_set_range_check
+    virtual void range_stats(uint64_t* out5, double* last_rms) = 0;   // fs_codec_range_stats
 };
 
 CodecBase* make_codec(int device, int channel_div);

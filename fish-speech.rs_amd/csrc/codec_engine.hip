@@ -94,7 +94,71 @@ class Codec final : public CodecBase {
     }
     int precision() override { return f16_ ? 2 : (bf3_ ? 1 : 0); }
 
-    void decode(const uint32_t* codes, int B, int T, float* pcm_out) override { decode_impl(codes, B, T, pcm_out, false); }
+    // ---- f16 range guard (no reference counterpart: the reference runs the codec in f32, server/lib/utils/load.rs:161-164).  The f16 mode
+    // rounds every matrix operand to f16 once: |x| > 65504 saturates, 0 < |x| < 2^-24 becomes zero, and its error is RELATIVE (2^-11) while
+    // the acceptance bound on the PCM is absolute.  None of this bites with the synthetic N(0, 1 / fan_in) convs at the test signal's level; a
+    // weight-normed checkpoint, or loud material, is a different distribution.  With the check on, decode() in f16 mode
+    //   * runs the range-counting kernel twins (csrc/codec_conv_bf3.hip, FS_C3_CHECK): operands saturated / flushed to zero, for the
+    //     activations of the call and (once, when the check is switched on) the f16 weight images;
+    //   * decodes the same codes in bf16x3 mode as well (f32 exponent range, 2^-17 relative) and measures the RMS difference of the two PCMs;
+    //   * returns the bf16x3 PCM when an operand saturated or the difference exceeds kGuardRms (half the 1e-4 acceptance bound), else the
+    //     f16 PCM.  Flushed operands alone are reported, not acted on: SiLU tails put a few hundred activations per decode below 2^-24 with
+    //     any weights, at an absolute error below 6e-8 each.
+    // Streamed chunks are counted, not compared (their left context lives in the f16 planes).  ~3x the cost of a plain call: a validation
+    // tool for a new checkpoint, not a serving mode.
+    static constexpr double kGuardRms = 5e-5;
+    void set_range_check(bool on) override {
+        FS_HIP(hipSetDevice(device_));
+        range_check_ = on;
+        if (!on || !loaded_) return;
+        scan_weight_range();
+    }
+    void range_stats(uint64_t* out5, double* last_rms) override {
+        out5[0] = range_act_[0]; out5[1] = range_act_[1]; out5[2] = range_w_[0]; out5[3] = range_w_[1]; out5[4] = range_fallbacks_;
+        if (last_rms) *last_rms = range_last_rms_;
+    }
+    void scan_weight_range() {  // pack the f16 weight images again through the counting twin (same bytes)
+        if (!packed16_.p) return;
+        codec_range_check(true);
+        codec_range_reset(st_);
+        for (size_t i = 0; i < convs_.size(); ++i) {
+            const ConvSpec& cs = convs_[i];
+            const int K = cs.transposed ? cs.k / cs.stride : cs.k, Cout = cs.transposed ? cs.cout * cs.stride : cs.cout;
+            codec_pack_bf3(relaid_.f() + relaid_off_[i], packed16_.u16() + packed16_off_[i], cs.cin_g, K, Cout, true, st_);
+        }
+        codec_range_check(false);
+        unsigned long long r[2] = {0, 0};
+        codec_range_read(r, st_);
+        range_w_[0] = r[0]; range_w_[1] = r[1];
+    }
+
+    void decode(const uint32_t* codes, int B, int T, float* pcm_out) override {
+        if (!(range_check_ && bf3_ && f16_)) { decode_impl(codes, B, T, pcm_out, false); return; }
+        FS_HIP(hipSetDevice(device_));
+        codec_range_check(true);
+        codec_range_reset(st_);
+        try { decode_impl(codes, B, T, pcm_out, false); } catch (...) { codec_range_check(false); throw; }
+        codec_range_check(false);
+        unsigned long long r[2] = {0, 0};
+        codec_range_read(r, st_);
+        range_act_[0] += r[0]; range_act_[1] += r[1];
+        std::vector<float> wide((size_t)B * T * 2048);  // 4 x 8 x 8 x 2 x 2 x 2 samples per frame (the upsample rates are fixed: config.rs:196-202)
+        f16_ = false;
+        try { decode_impl(codes, B, T, wide.data(), false); } catch (...) { f16_ = true; throw; }
+        f16_ = true;
+        double ss = 0.0;
+        bool finite = true;
+        for (size_t i = 0; i < wide.size(); ++i) {
+            const double d = (double)pcm_out[i] - (double)wide[i];
+            ss += d * d;
+            finite &= std::isfinite(pcm_out[i]);
+        }
+        range_last_rms_ = std::sqrt(ss / (double)wide.size());
+        if (r[0] || range_w_[0] || !finite || !(range_last_rms_ <= kGuardRms)) {  // this call's PCM comes from the bf16x3 mode
+            ++range_fallbacks_;
+            std::memcpy(pcm_out, wide.data(), wide.size() * sizeof(float));
+        }
+    }
 
     // ---- stateful streaming (no reference counterpart; the reference vocodes an utterance in one piece, server/lib/handlers/speech.rs:98-129).
     // Every conv of the 1.4+/1.5 codec is causal, so chunk i of a stream needs, per conv input, only the last `halo` samples of chunk i-1:
@@ -121,7 +185,15 @@ class Codec final : public CodecBase {
         FS_REQUIRE(stream_chunk_ >= 0, "fs_codec_stream_begin first");
         FS_REQUIRE(precision() == stream_prec_, "the precision mode changed inside a stream");
         FS_REQUIRE(T >= kStreamMinFrames, "a streamed chunk needs >= 16 frames (64 samples at the vocoder's lowest rate)");
-        decode_impl(codes, 1, T, pcm_out, true);
+        const bool chk = range_check_ && bf3_ && f16_;
+        if (chk) { codec_range_check(true); codec_range_reset(st_); }
+        try { decode_impl(codes, 1, T, pcm_out, true); } catch (...) { codec_range_check(false); throw; }
+        if (chk) {
+            codec_range_check(false);
+            unsigned long long r[2] = {0, 0};
+            codec_range_read(r, st_);
+            range_act_[0] += r[0]; range_act_[1] += r[1];
+        }
         ++stream_chunk_;
     }
     void stream_end() override { stream_chunk_ = -1; }
@@ -560,6 +632,9 @@ class Codec final : public CodecBase {
     int stream_chunk_ = -1, stream_prec_ = 0;  // -1: no stream open
     std::vector<size_t> packed_off_, packed16_off_;
     bool fold_mean_ = getenv("FISHRT_VOC_NO_FOLD_MEAN") == nullptr;  // ParallelBlock mean inside the last residual conv's epilogue (A/B switch)
+    bool range_check_ = false;              // fs_codec_set_range_check
+    uint64_t range_act_[2] = {0, 0}, range_w_[2] = {0, 0}, range_fallbacks_ = 0;
+    double range_last_rms_ = 0.0;            // RMS difference of the f16 and bf16x3 PCMs of the last checked decode call
     bool f16_ = true;   // with bf3_: the plane data flow carries single f16 operands (mode 2) instead of bf16 hi / lo pairs (mode 1)
     bool bf3_ = true, use_bf3_now_ = false;  // decode precision mode (fs_codec_set_precision); the encoder always runs exact f32
     int proj_w_ = 0, proj_b_ = 0, up_conv_[2] = {0, 0}, conv_pre_ = 0, conv_post_ = 0, ups_[5] = {0, 0, 0, 0, 0};

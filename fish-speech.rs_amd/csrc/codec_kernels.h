@@ -65,6 +65,11 @@ bool codec_respair_ok(int C, int K, int dil, bool f16);
 void codec_respair_f16(const uint16_t* xp, int B, int C, int T, const uint16_t* w1p, const float* b1, const uint16_t* w2p, const float* b2, int K, int dil,
                        const float* res, float* y, uint16_t* yp, hipStream_t st, const uint16_t* mid_ctx_in = nullptr, uint16_t* mid_ctx_out = nullptr,
                        const uint16_t* ctx_in = nullptr, uint16_t* ctx_out = nullptr, const float* mean_a = nullptr, const float* mean_b = nullptr);
+// f16 range diagnostic (fs_codec_set_range_check): while on, the launchers above run the range-checked twin of codec_conv_bf3.hip, whose
+// f32 -> f16 conversions count saturated (|x| > 65504) and flushed (0 < |x| < 2^-24) operands; reset / read the two device counters
+void codec_range_check(bool on);
+void codec_range_reset(hipStream_t st);
+void codec_range_read(unsigned long long* out2, hipStream_t st);
 // ---- encoder side (FireflyCodec::encode)
 void codec_stft_mag(const float* pcm, int n, int n_fft, int hop, int n_frames, float* lin /*[n_fft/2+1][frames]*/, hipStream_t st);
 void codec_mel_log(const float* lin, const float* fb /*[nf][n_mels]*/, int nf, int n_mels, int F, float* mel /*[n_mels][F]*/, hipStream_t st);

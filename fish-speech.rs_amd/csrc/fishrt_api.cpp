@@ -128,6 +128,15 @@ int fs_lm_generate_batch(fs_lm_t* lm, const uint32_t* prompts, const int* lens, 
     FS_ARG(lm && prompts && lens && sampling && codes_out && n_frames, "null argument");
     FS_TRY(lm->impl->generate_batch(prompts, lens, n, max_new_tokens, *sampling, seed, flags, codes_out, cap, n_frames))
 }
+int fs_lm_generate_static_batch(fs_lm_t* lm, const uint32_t* prompts, const int* lens, int n, int max_new_tokens, int audio_only,
+                                const fs_sampling* sampling, uint64_t seed, uint32_t flags, uint32_t* codes_out, size_t cap, size_t* n_frames,
+                                uint8_t* is_audio_out) {
+    FS_ARG(lm && prompts && lens && sampling && codes_out && n_frames, "null argument");
+    FS_ARG(audio_only != 0, "generate_static_batch(audio_only = false) is not implemented: the reference then samples the slow token over the FULL "
+                            "vocabulary, never terminates a row and keeps the slow-token row in its outputs (static_batch.rs:132-141,156-173,361-364); "
+                            "its server always passes true (server/lib/handlers/speech.rs:80-86)");
+    FS_TRY(lm->impl->generate_batch(prompts, lens, n, max_new_tokens, *sampling, seed, flags, codes_out, cap, n_frames, is_audio_out))
+}
 int fs_lm_generate_multi(fs_lm_t* lm, const uint32_t* prompts, const int* lens, int n, const int* max_new_tokens, const fs_sampling* samplings,
                          const uint64_t* seeds, uint32_t flags, uint32_t* codes_out, size_t cap, size_t* n_frames) {
     FS_ARG(lm && prompts && lens && max_new_tokens && samplings && seeds && codes_out && n_frames, "null argument");
@@ -206,5 +215,10 @@ int fs_codec_stream_decode(fs_codec_t* c, const uint32_t* codes, int T, float* p
 int fs_codec_stream_end(fs_codec_t* c) { FS_ARG(c, "null argument"); FS_TRY(c->impl->stream_end()) }
 int fs_codec_set_precision(fs_codec_t* c, int mode) { FS_ARG(c, "null argument"); FS_TRY(c->impl->set_precision(mode)) }
 int fs_codec_precision(fs_codec_t* c) { return c ? c->impl->precision() : -1; }
+int fs_codec_set_range_check(fs_codec_t* c, int on) { FS_ARG(c, "null argument"); FS_TRY(c->impl->set_range_check(on != 0)) }
+int fs_codec_range_stats(fs_codec_t* c, uint64_t* out5, double* last_pcm_rms_diff) {
+    FS_ARG(c && out5, "null argument");
+    FS_TRY(c->impl->range_stats(out5, last_pcm_rms_diff))
+}
 
 }  // extern "C"

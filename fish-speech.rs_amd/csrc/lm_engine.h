@@ -27,9 +27,10 @@ class LMBase {
     virtual void generate(const uint32_t* prompt, int L, int max_new_tokens, const fs_sampling& s, uint64_t seed,
                           uint32_t flags, uint32_t* codes_out, size_t cap, size_t* n_frames, fs_frame_cb cb,
                           void* cb_user, float* hidden_out = nullptr, size_t hidden_cap = 0, size_t* n_hidden = nullptr) = 0;
+    // is_audio (nullable): u8 [n][cap], BatchPosition::is_audio of every returned position (generate_static_batch's second return value)
     virtual void generate_batch(const uint32_t* prompts, const int* lens, int n, int max_new_tokens,
                                 const fs_sampling& s, uint64_t seed, uint32_t flags, uint32_t* codes_out, size_t cap,
-                                size_t* n_frames) = 0;
+                                size_t* n_frames, uint8_t* is_audio = nullptr) = 0;
     // R concurrent batch-1 requests (fishrt.h: fs_lm_generate_multi)
     virtual void generate_multi(const uint32_t* prompts, const int* lens, int n, const int* max_new_tokens, const fs_sampling* samplings,
                                 const uint64_t* seeds, uint32_t flags, uint32_t* codes_out, size_t cap, size_t* n_frames) = 0;

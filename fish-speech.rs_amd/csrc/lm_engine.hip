@@ -677,21 +677,21 @@ class LM final : public LMBase {
     // greedy decoding).  The left padding with <|im_end|>/0 IS applied because the reference never masks it (dual_ar.rs:589-615);
     // repetition penalty is a no-op in the reference's batch path for Fish models (static_batch.rs:204-206 => mask stays 1).
     void generate_batch(const uint32_t* prompts, const int* lens, int n, int max_new_tokens, const fs_sampling& s, uint64_t seed,
-                        uint32_t flags, uint32_t* codes_out, size_t cap, size_t* n_frames) override {
+                        uint32_t flags, uint32_t* codes_out, size_t cap, size_t* n_frames, uint8_t* is_audio) override {
         FS_REQUIRE(n >= 1, "Must have at least one prompt");  // static_batch.rs:69-71
         FS_REQUIRE(!sess_active_, "the handle is in session mode (fs_lm_session_end first)");
         if (LmKernels<WT>::has_mfma_prefill() && n <= kRows && n <= B_ && a_.dim % 128 == 0 && a_.intermediate_size % 128 == 0 &&
             a_.num_codebooks <= 8 && !legacy_) {
-            generate_batch_rows(prompts, lens, n, max_new_tokens, s, seed, flags, codes_out, cap, n_frames);
+            generate_batch_rows(prompts, lens, n, max_new_tokens, s, seed, flags, codes_out, cap, n_frames, is_audio);
             return;
         }
-        generate_batch_sequential(prompts, lens, n, max_new_tokens, s, seed, flags, codes_out, cap, n_frames);
+        generate_batch_sequential(prompts, lens, n, max_new_tokens, s, seed, flags, codes_out, cap, n_frames, is_audio);
     }
 
     // generate_static_batch on the MFMA row path: the B sequences are the rows of every GEMM (weights streamed once per
     // step for the whole batch), per-row paged KV, per-row on-device sampling, one captured graph per (B, chunk bucket).
     void generate_batch_rows(const uint32_t* prompts, const int* lens, int n, int max_new_tokens, const fs_sampling& s, uint64_t seed,
-                             uint32_t flags, uint32_t* codes_out, size_t cap, size_t* n_frames) {
+                             uint32_t flags, uint32_t* codes_out, size_t cap, size_t* n_frames, uint8_t* is_audio) {
         use_device();
         require_loaded();
         const int C = a_.num_codebooks, C1 = C + 1, B = n;
@@ -821,6 +821,10 @@ class LM final : public LMBase {
             n_frames[b] = nb;
             total += nb;
             seq_len_[b] = hs[b].pos;
+            // BatchPosition::is_audio (static_batch.rs:229): the first position is returned unconditionally and is not audio when its slow token
+            // was <|im_end|> (the row samplers mark that in `step`); every later returned position belongs to a live row, i.e. is a semantic token
+            if (is_audio)
+                for (size_t f = 0; f < nb; ++f) is_audio[(size_t)b * cap + f] = (f == 0 && hs[b].step == -1) ? 0 : 1;
         }
         stats_.frames = total;
     }
@@ -1217,7 +1221,7 @@ class LM final : public LMBase {
     }
 
     void generate_batch_sequential(const uint32_t* prompts, const int* lens, int n, int max_new_tokens, const fs_sampling& s, uint64_t seed,
-                                   uint32_t flags, uint32_t* codes_out, size_t cap, size_t* n_frames) {
+                                   uint32_t flags, uint32_t* codes_out, size_t cap, size_t* n_frames, uint8_t* is_audio) {
         if (legacy_) throw Error("generate_static_batch samples the slow token over the full vocabulary for Fish <= 1.4 (static_batch.rs:132-141); not implemented");
         const int C1 = a_.num_codebooks + 1;
         int Lmax = 0;
@@ -1243,6 +1247,11 @@ class LM final : public LMBase {
                          nullptr, nullptr, nullptr, 0, nullptr);
             } catch (...) { batch_rows_ = 0; batch_row_ = 0; throw; }
             batch_rows_ = 0; batch_row_ = 0;
+            if (is_audio) {  // (one iteration executed and its slow token was <|im_end|>: the unconditional first position is not audio)
+                const SeqState* hs = reinterpret_cast<const SeqState*>(h_pin_);
+                const bool first_not_audio = hs->frame == 1 && hs->cur[0] == t_.im_end_id;
+                for (size_t f = 0; f < n_frames[i]; ++f) is_audio[(size_t)i * cap + f] = (f == 0 && first_not_audio) ? 0 : 1;
+            }
         }
     }
 
@@ -1859,7 +1868,7 @@ class LM final : public LMBase {
     static constexpr int kNapsFast[6] = {12, 16, 16, 20, 12, 16}, kNapsSlow[6] = {20, 12, 2, 32, 32, 12};  // (re-tuned in round 5 behind the publishing-wave epilogues and the early W13 request: 558.8 -> 551.1 us on the tuner's workload)
     // the same coordinate descent on the in-launch-sampler instantiation of k_fast_persist (680 -> 662 us per sampled frame) and on the
     // e4m3 image of k_slow_persist (595 -> 585 us per fp8 frame): their stage arithmetic differs, so the edges complete at other times
-    static constexpr int kNapsFastSampled[6] = {12, 12, 12, 20, 16, 16}, kNapsSlowFp8[6] = {20, 0, 32, 24, 28, 12};
+    static constexpr int kNapsFastSampled[6] = {12, 16, 12, 16, 12, 16}, kNapsSlowFp8[6] = {20, 4, 28, 24, 24, 0};  // (round 5 re-tune: profiles/r05_tune_naps.txt)
     static void set_naps(int (&naps)[6], const char* env, const int (&dflt)[6]) {
         for (int i = 0; i < 6; ++i) naps[i] = dflt[i];
         if (const char* v = getenv(env)) {

@@ -829,6 +829,11 @@ __global__ __launch_bounds__(256) void k_prep(float* __restrict__ X, int D, cons
     const int m = blockIdx.x;
     float* xm = X + (size_t)m * D;
     float ss = 0.f;
+    // D <= 1024 (every row-path model here): a thread's one float4 stays in registers between the two phases -- the second phase used to
+    // read the row back from memory behind the block barrier, one more dependent L2 round trip in a node that is nothing but latency
+    const bool one = D <= 1024;
+    float4 keep = make_float4(0.f, 0.f, 0.f, 0.f), wkeep = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (one && norm_w && threadIdx.x * 4 < D) wkeep = *reinterpret_cast<const float4*>(norm_w + threadIdx.x * 4);  // (requested with the row, not behind the barrier)
     for (int e = threadIdx.x * 4; e < D; e += 1024) {
         float4 v = *reinterpret_cast<const float4*>(xm + e);
         for (int sI = 0; sI < S; ++sI) {
@@ -837,6 +842,7 @@ __global__ __launch_bounds__(256) void k_prep(float* __restrict__ X, int D, cons
         }
         if (S > 0) *reinterpret_cast<float4*>(xm + e) = v;
         ss = fmaf(v.x, v.x, ss); ss = fmaf(v.y, v.y, ss); ss = fmaf(v.z, v.z, ss); ss = fmaf(v.w, v.w, ss);
+        keep = v;
     }
     if (!Ohi) return;
     float d = 1.f;
@@ -847,10 +853,10 @@ __global__ __launch_bounds__(256) void k_prep(float* __restrict__ X, int D, cons
         d = sqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)D + eps);
     }
     for (int e = threadIdx.x * 4; e < D; e += 1024) {
-        const float4 v = *reinterpret_cast<const float4*>(xm + e);  // own earlier write (same thread)
+        const float4 v = one ? keep : *reinterpret_cast<const float4*>(xm + e);  // (else: own earlier write, same thread)
         float a[4] = {v.x, v.y, v.z, v.w};
         if (norm_w) {
-            const float4 w = *reinterpret_cast<const float4*>(norm_w + e);
+            const float4 w = one ? wkeep : *reinterpret_cast<const float4*>(norm_w + e);
             a[0] = (a[0] / d) * w.x; a[1] = (a[1] / d) * w.y; a[2] = (a[2] / d) * w.z; a[3] = (a[3] / d) * w.w;
         }
         bf16_t hi[4], lo[4];
@@ -2539,6 +2545,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_fast_rows(const float
         const bool frozen = c.session != 0 && st->done != 0 && frame > 0;
         if (!frozen) {
             if (frame == 0 || !st->done) {  // first position unconditionally, then only while the row is active
+                if (frame == 0 && cur[0] < c.sem_lo) st->step = -1;  // BatchPosition::is_audio of the first position (static_batch.rs:229): `step` is free during decode
                 const int o = st->n_out;
                 uint32_t* oc = out_codes + (size_t)b * n_cb * out_cap;
                 if (o < out_cap)
@@ -2629,6 +2636,7 @@ __global__ __launch_bounds__(PAR_THREADS) void k_sample_fast_rows_par(const floa
         const bool frozen = c.session != 0 && st->done != 0 && frame > 0;
         if (!frozen) {
             if (frame == 0 || !st->done) {
+                if (frame == 0 && cur[0] < c.sem_lo) st->step = -1;  // (see k_sample_fast_rows)
                 const int o = st->n_out;
                 uint32_t* oc = out_codes + (size_t)b * n_cb * out_cap;
                 if (o < out_cap)

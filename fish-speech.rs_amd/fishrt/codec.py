@@ -50,6 +50,17 @@ class FireflyCodec:
                                               pcm.ctypes.data_as(C.POINTER(C.c_float))))
         return pcm
 
+    # ---- f16 range guard (fishrt.h fs_codec_set_range_check / fs_codec_range_stats): diagnostic for validating a new checkpoint
+    def set_range_check(self, on=True):
+        _ffi.check(_ffi.lib().fs_codec_set_range_check(self._h, 1 if on else 0))
+        return self
+
+    def range_stats(self):
+        out, rms = (C.c_uint64 * 5)(), C.c_double(0.0)
+        _ffi.check(_ffi.lib().fs_codec_range_stats(self._h, out, C.byref(rms)))
+        return dict(act_saturated=int(out[0]), act_flushed=int(out[1]), weights_saturated=int(out[2]), weights_flushed=int(out[3]),
+                    fallbacks=int(out[4]), last_pcm_rms_diff=float(rms.value))
+
     # ---- stateful streaming (fishrt.h fs_codec_stream_*): chunks of ONE code sequence, left context kept on the device
     STREAM_MIN_FRAMES = 16
 

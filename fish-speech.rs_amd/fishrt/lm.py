@@ -136,8 +136,11 @@ class DualARTransformer:
         return out[:, : n.value].copy(), (hid[: nh.value].reshape(nh.value, 1, D).copy() if collect_hidden_states else None)
 
     def generate_static_batch(self, prompts, max_new_tokens, temp=0.7, top_p=0.9, top_k=50, repetition_penalty=1.2,
-                              seed=42, ignore_eos=False):
-        """generate/static_batch.rs:282-390 (audio_only).  prompts: list of u32 (C+1, L_i) -> list of (C, n_i)."""
+                              seed=42, ignore_eos=False, audio_only=True, return_is_audio=False):
+        """generate/static_batch.rs:282-390.  prompts: list of u32 (C+1, L_i) -> list of (C, n_i); return_is_audio=True: the reference's full
+        return value (codes, is_audio) with is_audio a list of bool arrays (n_i,) -- through fs_lm_generate_static_batch."""
+        if return_is_audio or not audio_only:
+            return self._generate_static_batch_full(prompts, max_new_tokens, temp, top_p, top_k, repetition_penalty, seed, ignore_eos, audio_only)
         Cb = self.cfg["num_codebooks"]
         ps = [_u32(p) for p in prompts]
         lens = np.array([p.shape[1] for p in ps], np.int32)
@@ -151,6 +154,22 @@ class DualARTransformer:
                                                    C.byref(s), C.c_uint64(seed), 1 if ignore_eos else 0,
                                                    out.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_size_t(cap), nf))
         return [out[i, :, : nf[i]].copy() for i in range(len(ps))]
+
+    def _generate_static_batch_full(self, prompts, max_new_tokens, temp, top_p, top_k, repetition_penalty, seed, ignore_eos, audio_only):
+        Cb = self.cfg["num_codebooks"]
+        ps = [_u32(p) for p in prompts]
+        lens = np.array([p.shape[1] for p in ps], np.int32)
+        flat = np.concatenate([p.reshape(-1) for p in ps])
+        cap = max(1, max_new_tokens - int(lens.max()) + 2) + 1
+        out = np.zeros((len(ps), Cb, cap), np.uint32)
+        isa = np.zeros((len(ps), cap), np.uint8)
+        nf = (C.c_size_t * len(ps))()
+        s = _ffi.Sampling(float(temp), float(top_p), int(top_k), float(repetition_penalty))
+        _ffi.check(_ffi.lib().fs_lm_generate_static_batch(self._h, flat.ctypes.data_as(C.POINTER(C.c_uint32)), lens.ctypes.data_as(C.POINTER(C.c_int)),
+                                                          len(ps), int(max_new_tokens), 1 if audio_only else 0, C.byref(s), C.c_uint64(seed),
+                                                          1 if ignore_eos else 0, out.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_size_t(cap), nf,
+                                                          isa.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return [out[i, :, : nf[i]].copy() for i in range(len(ps))], [isa[i, : nf[i]].astype(bool) for i in range(len(ps))]
 
     def generate_multi(self, prompts, max_new_tokens, temp=0.0, top_p=1.0, top_k=0, repetition_penalty=1.2, seeds=None,
                        ignore_eos=False, persistent=True):

@@ -175,6 +175,16 @@ int fs_lm_generate_batch(fs_lm_t* lm, const uint32_t* prompts, const int* lens, 
                          const fs_sampling* sampling, uint64_t seed, uint32_t flags, uint32_t* codes_out, size_t cap,
                          size_t* n_frames);
 
+/* The same call with generate_static_batch's full signature (generate/static_batch.rs:282-390): `audio_only` as an argument and the second
+ * return value, `Vec<Vec<bool>>` of BatchPosition::is_audio (:229: slow token >= semantic_start), as is_audio_out u8 [n, cap] (nullable;
+ * is_audio_out[i * cap + f] for f < n_frames[i]).  With audio_only = 1 every returned position is audio except a row's FIRST position when its
+ * slow token was <|im_end|> (the first position is returned unconditionally, :305-316, with zero codes, :230-233).  audio_only = 0 -- slow
+ * token sampled over the full vocabulary, rows never terminate, outputs keep the slow-token row (:132-141,156-173,361-364) -- is NOT
+ * implemented and returns an error; the reference's server always passes true (server/lib/handlers/speech.rs:80-86). */
+int fs_lm_generate_static_batch(fs_lm_t* lm, const uint32_t* prompts, const int* lens, int n, int max_new_tokens, int audio_only,
+                                const fs_sampling* sampling, uint64_t seed, uint32_t flags, uint32_t* codes_out, size_t cap,
+                                size_t* n_frames, uint8_t* is_audio_out);
+
 /* R concurrent batch-1 requests on ONE device (round 4; the reference's only multi-request generator is the lock-step static batch,
  * generate/static_batch.rs:117-274, which changes the sampler semantics; its server serialises requests behind one mutex,
  * server/lib/state.rs:12-29).  Request i IS generate_blocking(prompt_i, max_new_tokens[i], samplings[i]) with sampler seed seeds[i] on a
@@ -297,6 +307,18 @@ int fs_codec_sample_rate(fs_codec_t* c);
  * mode 0 = exact f32 products on the f32 matrix cores (4e-8 of the oracle, ~4.5x the time of mode 2).  The encoder always uses mode 0. */
 int fs_codec_set_precision(fs_codec_t* c, int mode);
 int fs_codec_precision(fs_codec_t* c);
+/* Range guard of mode 2 (validation tool, off by default; no reference counterpart).  f16 operands saturate beyond +-65504, vanish below
+ * 2^-24, and carry a RELATIVE error (2^-11) against an absolute acceptance bound; synthetic N(0, 1 / fan_in) convs at the test signal's level
+ * are far from all three, a weight-normed HiFi-GAN checkpoint or loud material has not been seen by this code.  With the check on,
+ * fs_codec_decode in mode 2 (a) runs range-counting twins of the conversion kernels, (b) decodes the same codes in mode 1 (bf16x3: f32
+ * exponent range, 2^-17 relative) too and takes the RMS difference of the two PCMs, and (c) returns the mode-1 PCM when an activation or
+ * weight operand saturated or that difference exceeds 5e-5 (half the 1e-4 bound), else the mode-2 PCM.
+ * fs_codec_range_stats: out5 = {activation operands saturated, flushed to zero (cumulative since the check was switched on), f16 weights
+ * saturated, flushed (of the loaded checkpoint), decode calls answered from mode 1}; *last_pcm_rms_diff (nullable) = the RMS difference
+ * of the last checked call.  Flushed operands are reported, not acted on (SiLU tails put a few hundred activations per decode below 2^-24
+ * with any weights, < 6e-8 absolute each).  Streamed chunks (fs_codec_stream_decode) are counted only.  ~3x the cost of a plain call. */
+int fs_codec_set_range_check(fs_codec_t* c, int on);
+int fs_codec_range_stats(fs_codec_t* c, uint64_t* out5, double* last_pcm_rms_diff);
 
 #ifdef __cplusplus
 }

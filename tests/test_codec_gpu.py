@@ -179,3 +179,70 @@ def test_overlapped_lm_vocoder_pipeline(tiny):
     ref_pcm = tiny.decode(np.ascontiguousarray(ref_codes[None]))[0, 0]
     assert pcm.shape == ref_pcm.shape and np.array_equal(pcm, ref_pcm)
     assert synth.stats["frames"] == 76
+
+
+def test_f16_range_guard_counts_and_falls_back(tmp_path):
+    """fs_codec_set_range_check: the f16 mode saturates beyond +-65504, loses operands below 2^-24 and has a relative
+    error against an absolute bound.  With the check on, decode() counts out-of-range operands in the f32 -> f16 conversions (range-counting
+    kernel twins), decodes in bf16x3 mode as well, and answers from bf16x3 when an operand saturated or the two PCMs are more than 5e-5 RMS
+    apart.  Four checkpoints from the synthetic generator (tiny topology): as is; conv_pre and ups.0 x 1e3 (activations saturate); conv_post x 40 (loud
+    output: the relative error crosses the absolute bound); one ResBlock conv x 1e-10 (weights flush to zero: reported, harmless)."""
+    import test_safetensors_gpu as tsf
+    codes = np.random.RandomState(3).randint(0, 1000, (1, 8, 12)).astype(np.uint32)
+
+    def codec_from(t, precision="f16"):
+        path = str(tmp_path / "c.safetensors")
+        tsf._save(t, path, False)
+        return fishrt.FireflyCodec(0, channel_div=8, precision=precision).load_safetensors(path)
+
+    def variant(**scale):
+        t = {k: v.copy() for k, v in base.items()}
+        for k, f in scale.items():
+            t[k.replace("__", ".")] *= np.float32(f)
+        return t
+
+    base = tsf._codec_tensors(64, 1234)
+    # (a) in range: nothing saturates, no fall-back, and the checked kernels produce the unchecked kernels' PCM bit for bit
+    c = codec_from(base)
+    ref = c.decode(codes)
+    c.set_range_check(True)
+    got = c.decode(codes)
+    st = c.range_stats()
+    assert st["act_saturated"] == 0 and st["weights_saturated"] == 0 and st["weights_flushed"] == 0 and st["fallbacks"] == 0, st
+    assert st["act_flushed"] < 100 and 0 < st["last_pcm_rms_diff"] < 4e-5, st  # (SiLU tails; the f16-vs-bf16x3 distance of an ordinary signal)
+    assert np.array_equal(got, ref)
+    c.set_range_check(False)
+    assert np.array_equal(c.decode(codes), ref)
+    c.close()
+    # (b) activations beyond 65504 (two convs x 1000 each; the weights themselves stay far inside the range): counted, answered from bf16x3
+    # (== a bf16x3 handle's PCM); the unguarded f16 PCM is something else
+    t = variant(head__conv_pre__conv__weight=1e3, head__ups__0__conv__weight=1e3)
+    c = codec_from(t)
+    unguarded = c.decode(codes)
+    c.set_range_check(True)
+    got = c.decode(codes)
+    st = c.range_stats()
+    assert st["act_saturated"] > 0 and st["fallbacks"] == 1 and st["weights_saturated"] == 0, st
+    c3 = codec_from(t, "bf16x3")
+    exp = c3.decode(codes)
+    assert np.isfinite(got).all() and np.array_equal(got, exp) and not np.array_equal(unguarded, exp)
+    c.decode(codes)
+    assert c.range_stats()["fallbacks"] == 2
+    c.close(); c3.close()
+    # (c) loud output (pre-tanh x 40): nothing saturates, but f16's relative error is now > 5e-5 absolute -> bf16x3 answers
+    t = variant(head__conv_post__conv__weight=40.0)
+    c = codec_from(t).set_range_check(True)
+    got = c.decode(codes)
+    st = c.range_stats()
+    assert st["act_saturated"] == 0 and st["last_pcm_rms_diff"] > 5e-5 and st["fallbacks"] == 1, st
+    c3 = codec_from(t, "bf16x3")
+    assert np.array_equal(got, c3.decode(codes)) and float(np.sqrt(np.mean(got.astype(np.float64) ** 2))) > 0.2
+    c.close(); c3.close()
+    # (d) weights below 2^-24: found when the check is switched on, reported, and (absolute error < 6e-8 each) not a reason to fall back
+    c = codec_from(variant(head__resblocks__1__blocks__0__convs1__0__conv__weight=1e-10)).set_range_check(True)
+    st = c.range_stats()
+    assert st["weights_flushed"] > 0 and st["weights_saturated"] == 0, st
+    c.decode(codes)
+    st = c.range_stats()
+    assert st["fallbacks"] == 0 and st["last_pcm_rms_diff"] < 4e-5, st
+    c.close()

@@ -237,6 +237,43 @@ def test_rows_eos_semantics_match_the_single_request_path(lm_eos, group):
     assert same_short >= n_req // 2
 
 
+def test_static_batch_full_signature_audio_only_and_is_audio(lm_eos):
+    """fs_lm_generate_static_batch = generate_static_batch(model, prompts, max_new_tokens, audio_only, sampling) -> (codes, is_audio)
+    (static_batch.rs:282-390): the codes against the oracle's restatement on the EOS-heavy checkpoint (rows die at different frames, several
+    at the very first position), is_audio per returned position (:229,305-338), and audio_only = false as an explicit error"""
+    import test_safetensors_gpu as tsf
+    o = orc.OracleLM({**EOS_CFG, **EOS_TOK}).load_synthetic(tsf.SEED, bf16=True)
+    w = o.tensor("output", (EOS_CFG["vocab_size"], EOS_CFG["dim"]))  # (a view of the oracle's own matrix: the same <|im_end|> boost as the fixture's)
+    w[EOS_TOK["im_end_id"]] *= np.float32(EOS_BOOST)
+    w[EOS_TOK["im_end_id"]] = (w[EOS_TOK["im_end_id"]].view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)
+    o.set_kv_round_bf16(True)
+    M, first_dead, later_dead = 30, 0, 0
+    for g0 in range(0, 16, 8):
+        prompts = [_eos_prompt(14, 5000 + g0 + i) for i in range(8)]
+        got, isa = lm_eos.generate_static_batch(prompts, 14 + M, temp=0.0, top_p=1.0, top_k=0, return_is_audio=True)
+        exp = o.generate_batch(prompts, 14 + M, temp=0.0)
+        mg = o.last_batch_margins  # [iteration, row]: smallest top-2 margin of the row's 9 decisions
+        for b, (g, e) in enumerate(zip(got, exp)):  # (rows of different lengths included: a flipped <|im_end|> decision moves where a row ends)
+            n = min(g.shape[1], e.shape[1])
+            neq = (g[:, :n] != e[:, :n]).any(0)
+            if g.shape == e.shape and not neq.any():
+                continue
+            f = int(np.argmax(neq)) if neq.any() else n
+            near = float(min(mg[min(f, mg.shape[0] - 1), b], mg[max(f - 1, 0), b]))
+            assert near < NEAR_TIE, f"row {g0 + b} leaves the oracle's stream at frame {f} on a margin of {near:.2e}"
+        for c, a in zip(got, isa):
+            assert a.shape == (c.shape[1],) and a.dtype == bool and a[1:].all()
+            if c[:, 0].any():
+                assert a[0]
+            else:  # zero codes in the unconditional first position: its slow token was <|im_end|> (static_batch.rs:229-233)
+                assert not a[0] and c.shape[1] == 1
+                first_dead += 1
+            later_dead += 1 < c.shape[1] < M + 2
+    assert first_dead >= 1 and later_dead >= 4, (first_dead, later_dead)  # (28 % per slow decision on this checkpoint: pinned prompts, both cases present)
+    with pytest.raises(RuntimeError, match="audio_only = false.*not implemented"):
+        lm_eos.generate_static_batch([_eos_prompt(14, 1)], 20, audio_only=False)
+
+
 def test_sequential_fallback_is_the_single_request_path(lm8):
     """requests outside the row kernels (sampler settings the in-launch sampler does not cover, n == 1) run one after the other through
     fs_lm_generate: identical tokens, per-request seeds"""

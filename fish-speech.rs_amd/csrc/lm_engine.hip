@@ -856,9 +856,9 @@ class LM final : public LMBase {
         } rows_guard{sess_rows_};
         if (flags & FS_SESSION_ROWS) {
             const int tk = (int)std::min<uint64_t>(s.top_k, 1u << 30);
-            const bool ok = B_ >= 2 && B_ <= PR_MAX_ROWS && pslow_ok_ && persist_ok_ && !kFp8 && !legacy_ && n_audio_ <= 2048 &&
+            const bool ok = B_ >= 2 && B_ <= PR_MAX_ROWS && pslow_ok_ && persist_ok_ && !legacy_ && n_audio_ <= 2048 &&
                             (s.temp == 0.0 || fast_persist_samples((float)s.temp, tk, a_.codebook_size));
-            FS_REQUIRE(ok, "FS_SESSION_ROWS needs a bf16 Fish-1.5 handle with 2 <= max_batch <= 8 and greedy or top_k <= 256 sampling");
+            FS_REQUIRE(ok, "FS_SESSION_ROWS needs a bf16 / fp8 Fish-1.5 handle with 2 <= max_batch <= 8 and greedy or top_k <= 256 sampling");
             FS_REQUIRE(B_ == 2 || B_ == 4 || B_ == 8, "FS_SESSION_ROWS needs max_batch 2, 4 or 8 (the row launches cover exactly that many slots; state slot max_batch is the prefill staging state)");
             FS_REQUIRE(rows_kv_span_ok(B_), "FS_SESSION_ROWS: max_seq_len too long for the row kernels' attention slices at this slot count");
             FS_REQUIRE(!free_pages_.empty(), "KV page pool exhausted");
@@ -1427,7 +1427,7 @@ class LM final : public LMBase {
     // fs_lm_rows_supported: would fs_lm_generate_multi serve these n requests on the request-row kernels (one persistent launch group per
     // frame) rather than one after the other?  Says nothing about whether another call holds the device's persistent kernels right now.
     bool rows_supported(int n, const fs_sampling* samplings) override {
-        bool ok = n >= 2 && n <= PR_MAX_ROWS && n <= B_ && loaded_ && pslow_ok_ && persist_ok_ && !kFp8 && !legacy_ && n_audio_ <= 2048 &&
+        bool ok = n >= 2 && n <= PR_MAX_ROWS && n <= B_ && loaded_ && pslow_ok_ && persist_ok_ && n_audio_ <= 2048 &&
                   !getenv("FISHRT_NO_ROWS") && rows_kv_span_ok(n <= 2 ? 2 : (n <= 4 ? 4 : 8));
         // one instantiation per launch: every request greedy, or every request within the in-launch sampler (temp > 0, 0 < top_k <= 256)
         const bool sampled = ok && samplings[0].temp != 0.0;
@@ -1969,11 +1969,12 @@ class LM final : public LMBase {
 
     // ---- request rows (lm_persist_rows.hip): MFMA weight images, row edge buffers, per-row sampler / repetition-penalty state
     void ensure_rows(int R) {
-        if constexpr (std::is_same<WT, bf16_t>::value) {
+        if constexpr (std::is_same<WT, bf16_t>::value || kFp8) {
             if (!d_rimg_.p) {
-                d_rimg_.alloc(slow_persist_pack_bytes(a_.n_layer, false));
+                d_rimg_.alloc(slow_persist_pack_bytes(a_.n_layer, false));  // (FS_FP8 too: the row images hold the e4m3 weights widened to bf16)
                 d_rhimg_.alloc((size_t)PF_BLOCKS * PS_HEAD_IMAGE);
-                launch_rows_pack(slow_.data(), a_.n_layer, slow_head_w(), n_audio_, d_rimg_.p, d_rhimg_.p, st_);
+                if constexpr (kFp8) launch_rows_pack_fp8(slow_.data(), a_.n_layer, slow_head_w(), n_audio_, d_rimg_.p, d_rhimg_.p, st_);
+                else launch_rows_pack(slow_.data(), a_.n_layer, slow_head_w(), n_audio_, d_rimg_.p, d_rhimg_.p, st_);
                 d_rpairs_.alloc((size_t)PF_BLOCKS * 40 * PF_THREADS * 4);
                 launch_rows_pack_rowpairs(d_pack_.p, d_rpairs_.p, st_);
                 d_redges_s_.alloc(rows_slow_edge_bytes(PR_MAX_ROWS));
@@ -1996,7 +1997,7 @@ class LM final : public LMBase {
             }
             (void)R;
         } else {
-            throw Error("request rows need a bf16 handle");
+            throw Error("request rows need a bf16 or fp8 handle");
         }
     }
     RepPenState rows_rp(int i) {
@@ -2010,6 +2011,8 @@ class LM final : public LMBase {
     RowsSlowArgs rows_slow_args(int R) {
         RowsSlowArgs A = {};
         A.wimg = d_rimg_.p; A.himg = d_rhimg_.p; A.norms = d_snorms_.as<float>();
+        A.scales = d_sscl_.p ? d_sscl_.as<float>() : nullptr;  // FS_FP8: the slow persistent kernel's scale tables (same row -> workgroup mapping)
+        A.hscales = d_sscl_.p ? d_sscl_.as<float>() + (size_t)a_.n_layer * PF_BLOCKS * 48 : nullptr;
         A.n_layer = a_.n_layer; A.n_head_rows = n_audio_;
         A.cos_t = d_cos_.as<float>(); A.sin_t = d_sin_.as<float>(); A.eps = d_.eps;
         A.x = x(0); A.logits = d_rlogits_.as<float>(); A.state = state(0);
@@ -2027,6 +2030,7 @@ class LM final : public LMBase {
         RowsFastArgs A = {};
         (void)Rf;
         A.wpack = d_pack_.p; A.rowpairs = d_rpairs_.as<uint32_t>();
+        A.scales = d_fscl_.p ? d_fscl_.as<float>() : nullptr;
         for (int l = 0; l < PF_LAYERS; ++l) { A.norms[2 * l] = fast_[l].attn_norm; A.norms[2 * l + 1] = fast_[l].ffn_norm; }
         A.norms[2 * PF_LAYERS] = fast_norm_w_;
         A.fast_emb = fast_emb_; A.tok_emb = tok_emb_; A.cb_emb = cb_emb_;

@@ -27,6 +27,8 @@ struct RowsSlowArgs {
     const void* wimg;       // [n_layer][PF_BLOCKS][PS_LAYER_IMAGE]: MFMA A-fragment images (launch_rows_pack)
     const void* himg;       // [PF_BLOCKS][PS_HEAD_IMAGE]: head rows [8b, 8b+8) as A fragments
     const float* norms;     // [2 * n_layer + 1][1024]
+    const float* scales;    // FS_FP8 handles: the slow persistent kernel's row scales [n_layer][PF_BLOCKS][48] (the images hold the e4m3 weights widened to bf16); null: bf16 handle
+    const float* hscales;   // FS_FP8: head row scales [PF_BLOCKS][8]
     int n_layer, n_head_rows;
     const float* cos_t;
     const float* sin_t;
@@ -48,6 +50,7 @@ struct RowsSlowArgs {
 struct RowsFastArgs {
     const void* wpack;          // the batch-1 fast image (launch_fast_persist_pack): W13 fragments stay in registers; W2 is streamed from it
     const uint32_t* rowpairs;   // [PF_BLOCKS][40][512]: the image's row-pair dwords, dword-major (launch_rows_pack_rowpairs), streamed
+    const float* scales;        // FS_FP8 handles: row scales of the (bf16-widened) fast image [PF_BLOCKS][PF_SCL] (FastPersistArgs::scales); null: bf16 handle
     const float* norms[2 * PF_LAYERS + 1];
     const void* fast_emb;
     const void* tok_emb;
@@ -81,6 +84,7 @@ size_t rows_slow_edge_bytes(int R);
 size_t rows_fast_edge_bytes(int R);
 // re-lays the slow blocks + the audio-range head into MFMA A-fragment images (device to device, once per weight load)
 void launch_rows_pack(const LayerW* layers, int n_layer, const void* head_w, int n_head_rows, void* wimg, void* himg, hipStream_t st);
+void launch_rows_pack_fp8(const LayerW* layers, int n_layer, const void* head_w, int n_head_rows, void* wimg, void* himg, hipStream_t st);  // FS_FP8 matrices -> the same (bf16) images
 void launch_rows_pack_rowpairs(const void* fast_pack, void* out /*PF_BLOCKS * 40 * 512 * 4 bytes*/, hipStream_t st);
 void launch_rows_slow(const RowsSlowArgs& a, int R, hipStream_t st);   // R in {2, 4, 8}
 void launch_rows_fast(const RowsFastArgs& a, int R, bool sampled, hipStream_t st);   // R in {1, 2, 4}; sampled: every row temp > 0, 0 < top_k <= 256

@@ -38,6 +38,10 @@ constexpr size_t IR_QKV = 0, IR_WO = 10240, IR_W13 = 18432, IR_W2 = 83968;
 static_assert(IR_W2 + 32768 == PS_LAYER_IMAGE, "image layout");
 
 constexpr int RW = 36;  // row partials per (wave, request row): up to 32 weight rows + the sum of squares
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// FS_FP8 row scales: the tables of the slow / fast persistent kernels (lm_persist_slow.hip PS_SC layout: per (layer, workgroup) 48 floats,
+// Wqkv 5 at [0], Wo 4 at [8], W13 32 at [12], W2 4 at [44]; lm_persist.h PF_SCL: 48 per fast layer + the 4 head rows at [192])
+constexpr int PRS = 48, PRS_QKV = 0, PRS_WO = 8, PRS_W13 = 12, PRS_W2 = 44;
 
 template <int R>
 struct SlowLds {
@@ -84,6 +88,44 @@ __global__ __launch_bounds__(PF_THREADS) void k_pr_pack_head(const u32x4* __rest
     for (int j = 0; j < 4; ++j) {
         const int row = 8 * b + m, ku = 16 * wave + 4 * j + q4;
         reinterpret_cast<u32x4*>(image + (size_t)b * PS_HEAD_IMAGE)[((wave * 4 + j) * 4 + q4) * 8 + m] = row < n_rows ? W[(size_t)row * 128 + ku] : u32x4{0, 0, 0, 0};
+    }
+}
+
+// FS_FP8 handles: the same A-fragment images from the e4m3 byte matrices, WIDENED to bf16 (exact: e4m3 is a subset of bf16) -- the row
+// kernels are bound by their stage chain, not by bytes, so the images keep the bf16 layout and the kernels stay one
+// instantiation; the per-row scales of the quantiser (the slow persistent kernel's own scale tables) multiply the K-summed row results in
+// the publishing lanes, as in k_slow_persist<true>.
+__device__ __forceinline__ u32x4 pr_widen8(uint2 q) {  // 8 e4m3 bytes -> 8 bf16
+    const f32x2_t a = __builtin_amdgcn_cvt_pk_f32_fp8(q.x, false), b2 = __builtin_amdgcn_cvt_pk_f32_fp8(q.x, true);
+    const f32x2_t c = __builtin_amdgcn_cvt_pk_f32_fp8(q.y, false), d = __builtin_amdgcn_cvt_pk_f32_fp8(q.y, true);
+    auto pk = [](float lo, float hi) { return (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xFFFF0000u); };
+    return u32x4{pk(a.x, a.y), pk(b2.x, b2.y), pk(c.x, c.y), pk(d.x, d.y)};
+}
+__global__ __launch_bounds__(PF_THREADS) void k_pr_pack_layer_fp8(LayerW w, unsigned char* __restrict__ image /*[PF_BLOCKS][PS_LAYER_IMAGE]*/) {
+    const int b = blockIdx.x, t = threadIdx.x, wave = t >> 6, lane = t & 63, m = lane & 15, q4 = lane >> 4;
+    unsigned char* im = image + (size_t)b * PS_LAYER_IMAGE;
+    const uint2* Wq = reinterpret_cast<const uint2*>(w.wqkv);   // row-major e4m3: 128 x 8 B per 1024-wide row
+    const uint2* Wo = reinterpret_cast<const uint2*>(w.wo);
+    const uint2* W13 = reinterpret_cast<const uint2*>(w.w13);
+    const uint2* W2 = reinterpret_cast<const uint2*>(w.w2);     // 512 x 8 B per 4096-wide row
+    for (int j = 0; j < 4; ++j) {
+        const int ku = 16 * wave + 4 * j + q4;
+        if (m < 5) reinterpret_cast<u32x4*>(im + IR_QKV)[((wave * 4 + j) * 4 + q4) * 5 + m] = pr_widen8(Wq[(size_t)(5 * b + m) * 128 + ku]);
+        if (m < 4) reinterpret_cast<u32x4*>(im + IR_WO)[((wave * 4 + j) * 4 + q4) * 4 + m] = pr_widen8(Wo[(size_t)(4 * b + m) * 128 + ku]);
+        for (int tile = 0; tile < 2; ++tile)
+            reinterpret_cast<u32x4*>(im + IR_W13)[((tile * 8 + wave) * 4 + j) * 64 + lane] = pr_widen8(W13[(size_t)(32 * b + 16 * tile + m) * 128 + ku]);
+    }
+    for (int j = 0; j < 16; ++j) {
+        const int ku = 128 * (j >> 2) + 16 * wave + 4 * (j & 3) + q4;
+        if (m < 4) reinterpret_cast<u32x4*>(im + IR_W2)[((wave * 16 + j) * 4 + q4) * 4 + m] = pr_widen8(W2[(size_t)(4 * b + m) * 512 + ku]);
+    }
+}
+__global__ __launch_bounds__(PF_THREADS) void k_pr_pack_head_fp8(const uint2* __restrict__ W, int n_rows, unsigned char* __restrict__ image) {
+    const int b = blockIdx.x, t = threadIdx.x, wave = t >> 6, lane = t & 63, m = lane & 15, q4 = lane >> 4;
+    if (m >= 8) return;
+    for (int j = 0; j < 4; ++j) {
+        const int row = 8 * b + m, ku = 16 * wave + 4 * j + q4;
+        reinterpret_cast<u32x4*>(image + (size_t)b * PS_HEAD_IMAGE)[((wave * 4 + j) * 4 + q4) * 8 + m] = row < n_rows ? pr_widen8(W[(size_t)row * 128 + ku]) : u32x4{0, 0, 0, 0};
     }
 }
 
@@ -152,6 +194,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
 
     const unsigned char* wimg = reinterpret_cast<const unsigned char*>(A.wimg) + (size_t)b * PS_LAYER_IMAGE;
     const size_t layer_img = (size_t)PF_BLOCKS * PS_LAYER_IMAGE;
+    const float* const scl0 = A.scales ? A.scales + (size_t)b * PRS : nullptr;  // FS_FP8: this workgroup's row scales, layer l at + l * PF_BLOCKS * PRS
     const u32x4 zero4 = u32x4{0, 0, 0, 0};
     u32x4 wq[4], wo[4], w13[8], w2[16];
     {
@@ -194,6 +237,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
 #pragma unroll 1
     for (int l = 0; l < A.n_layer; ++l) {
         const unsigned char* wl = wimg + (size_t)l * layer_img;
+        const float* const scl = scl0 ? scl0 + (size_t)l * PF_BLOCKS * PRS : nullptr;
         // ================= S1: (gather x) -> RMSNorm folded -> Wqkv rows [5b, 5b+5) of every row
         {
             tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
@@ -232,6 +276,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
                     float t = rp[m], tot = rp[32];
 #pragma unroll
                     for (int w = 1; w < 8; ++w) { t += rp[w * R * RW + m]; tot += rp[w * R * RW + 32]; }
+                    if (scl) t *= scl[PRS_QKV + m];
                     pub(e, rr, r, 5 * b + m, tag0 + e + 1, t * pf_rms_inv(tot, A.eps));
                 }
             }
@@ -444,6 +489,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
                     float t = rp[m];
 #pragma unroll
                     for (int w = 1; w < 8; ++w) t += rp[w * R * RW + m];
+                    if (scl) t *= scl[PRS_WO + m];
                     pub(e, rr, r, 4 * b + m, tag0 + e + 1, xr[r * 4 + m] + t);
                 }
             }
@@ -492,6 +538,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
 #pragma unroll
                     for (int w = 1; w < 8; ++w) { ga += rp[w * R * RW + 2 * jj]; gb += rp[w * R * RW + 2 * jj + 1]; tot += rp[w * R * RW + 32]; }
                     const float dni = pf_rms_inv(tot, A.eps);
+                    if (scl) { ga *= scl[PRS_W13 + 2 * jj]; gb *= scl[PRS_W13 + 2 * jj + 1]; }
                     ga *= dni; gb *= dni;
                     pub(e, rr, r, 16 * b + jj, tag0 + e + 1, pf_silu(ga) * gb);
                 }
@@ -547,6 +594,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
                     float t = rp[m];
 #pragma unroll
                     for (int w = 1; w < 8; ++w) t += rp[w * R * RW + m];
+                    if (scl) t *= scl[PRS_W2 + m];
                     pub(e, rr, r, 4 * b + m, tag0 + e + 1, xr[r * 4 + m] + t);
                 }
             }
@@ -594,6 +642,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
                 float t = rp[m], tot = rp[32];
 #pragma unroll
                 for (int w = 1; w < 8; ++w) { t += rp[w * R * RW + m]; tot += rp[w * R * RW + 32]; }
+                if (A.hscales) t *= A.hscales[8 * b + m];
                 A.logits[(size_t)r * PR_LD + 8 * b + m] = t * pf_rms_inv(tot, A.eps);
             }
         }
@@ -754,6 +803,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
         misc[16] = __float_as_int(c.rep_pen); misc[17] = c.ignore_eos; misc[18] = (int)c.im_end_id; misc[19] = (int)c.audio_base;
         misc[20] = (int)c.sem_lo; misc[21] = (int)c.sem_hi;
         misc[22] = __float_as_int(c.temp); misc[23] = __float_as_int(c.top_p); misc[24] = c.top_k;
+        misc[25] = c.legacy; misc[26] = (int)c.pad_id;
         const bool ok = SAMPLED ? (c.temp > 0.f && c.top_k > 0 && c.top_k <= BS_MAXK) : c.temp == 0.f;
         if (!ok && b == 0 && A.state[tid].done == 0) atomicAdd(A.ctl + 2, 1u);  // the host picks the instantiation by the sampling configuration
     }
@@ -761,6 +811,10 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
         const int k = tid - (PF_THREADS - 64), r = k / 9, i = k % 9;
         s_ring[r * RR + 168 + 32 + i] = (int)chacha12_word(A.rng[r].key, A.rng[r].consumed + (unsigned)i);
     }
+    // Fish <= 1.4 (SampleCfg::legacy, one token layout per handle): the slow token is a 2-way {pad, <|im_end|>} draw whatever the temperature
+    // (sampling/mod.rs:8-26; single_batch.rs:104-124) -- the greedy instantiation needs that one StdRng word per row too
+    if (!SAMPLED && tid >= PF_THREADS - 64 && tid < PF_THREADS - 64 + R && A.cfg[tid - (PF_THREADS - 64)].legacy)
+        s_ring[(tid - (PF_THREADS - 64)) * RR + 168 + 32] = (int)chacha12_word(A.rng[tid - (PF_THREADS - 64)].key, A.rng[tid - (PF_THREADS - 64)].consumed);
     if (tid == 64) s_ring[168 + 3] = (int)A.ctl[0];
     if (tid >= 256) { const int i = tid - 256; rope_c[i] = A.cos_t[i]; rope_s[i] = A.sin_t[i]; }
     __syncthreads();
@@ -770,6 +824,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
     for (int r = 0; r < R; ++r) { if (s_ring[r * RR + 168 + 2] == 0) live |= 1u << r; if (s_ring[r * RR + 168 + 1] != 0) hp |= 1u << r; }
     live = __builtin_amdgcn_readfirstlane(live); hp = __builtin_amdgcn_readfirstlane(hp);  // (read from LDS: uniform by construction)
     if (!live) return;
+    const bool legacy = __builtin_amdgcn_readfirstlane(s_ring[168 + 25]) != 0;
 
     // ---- the slow-token decision of every live row (constrain_probs_to_audio utils.rs:13-16, rescale_semantic_tokens :45-46,
     // single_batch.rs:102-144), redundantly on every workgroup
@@ -780,9 +835,28 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
     for (int r = 0; r < R; ++r) n_draws[r] = 0;
     {
         const int n = A.n_slow;
+        int leg_idx[R];  // legacy draw of row r: 1 = pad, 0 = <|im_end|>
+#pragma unroll
+        for (int r = 0; r < R; ++r) leg_idx[r] = 0;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const bool lv_r = (live >> r) & 1u;
+            if (legacy) {
+                // legacy_softmax_sample (sampling/mod.rs:8-26): P(pad) = softmax([pad, eos])[0]; u ~ U[0, 1) = (next_u32 >> 8) * 2^-24 from the row's own
+                // seeded StdRng stream (the reference: unseeded thread_rng), temperature ignored -- redundantly on every workgroup, as k_fast_persist
+                const float pad = A.slow_logits[(size_t)r * PR_LD], eosl = A.slow_logits[(size_t)r * PR_LD + 1], m = fmaxf(pad, eosl);
+                const float e_pad = expf(pad - m), e_eos = expf(eosl - m);
+                const float p_pad = e_pad / (e_pad + e_eos);
+                const float u = (float)((uint32_t)s_ring[r * RR + 168 + 32] >> 8) * (1.0f / 16777216.0f);
+                const bool is_pad = u < p_pad || s_ring[r * RR + 168 + 17] != 0;
+                leg_idx[r] = is_pad ? 1 : 0;
+                if (lv_r) n_draws[r] += 1;
+                if (A.cap && b == 0 && tid == 0 && lv_r && A.state[r].frame < A.cap_frames) {  // (the record of k_fast_persist: the two logits, the uniform draw, the pick)
+                    float* cp = A.cap + ((size_t)r * A.cap_frames + A.state[r].frame) * 9 * 2048;
+                    cp[0] = pad; cp[1] = eosl; cp[2] = u; cp[2047] = is_pad ? 0.f : 1.f;
+                }
+                continue;
+            }
             float lv[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -815,7 +889,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
             }
         }
         u32x4 dv[R];
-        if (SAMPLED) {
+        if (SAMPLED && !legacy) {
             const int first_l = __builtin_ctz(live);
             const u64* bs[R];
 #pragma unroll
@@ -826,10 +900,10 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            float gv = SAMPLED ? 0.f : amax[(r * 8) * 2];
-            int idx = SAMPLED ? (int)(dv[r].x & 0xFFFFu) : __float_as_int(amax[(r * 8) * 2 + 1]);
-            if (SAMPLED && ((live >> r) & 1u)) n_draws[r] += (int)(dv[r].x >> 16);
-            if (!SAMPLED) {
+            float gv = (SAMPLED || legacy) ? 0.f : amax[(r * 8) * 2];
+            int idx = legacy ? 0 : (SAMPLED ? (int)(dv[r].x & 0xFFFFu) : __float_as_int(amax[(r * 8) * 2 + 1]));
+            if (SAMPLED && !legacy && ((live >> r) & 1u)) n_draws[r] += (int)(dv[r].x >> 16);
+            if (!SAMPLED && !legacy) {
 #pragma unroll
             for (int w = 1; w < 8; ++w) {
                 const float v2 = amax[(r * 8 + w) * 2];
@@ -838,10 +912,11 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
             }
             }
             const bool lv_r = (live >> r) & 1u;
-            if (A.cap && b == 0 && tid == 0 && lv_r && A.state[r].frame < A.cap_frames)
+            if (!legacy && A.cap && b == 0 && tid == 0 && lv_r && A.state[r].frame < A.cap_frames)
                 A.cap[((size_t)r * A.cap_frames + A.state[r].frame) * 9 * 2048 + 2047] = (float)idx;
             const int* cf = s_ring + r * RR + 168 + 16;
-            const uint32_t c0 = idx > 0 ? (uint32_t)cf[3] + (uint32_t)idx : (uint32_t)cf[2];  // audio_tok()
+            const uint32_t c0 = legacy ? (leg_idx[r] ? (uint32_t)cf[10] : (uint32_t)cf[2])
+                                       : (idx > 0 ? (uint32_t)cf[3] + (uint32_t)idx : (uint32_t)cf[2]);  // audio_tok()
             if (lv_r && c0 != (uint32_t)cf[2]) run |= 1u << r;
             if (tid == 0) s_ring[r * RR + 168 + 0] = (int)c0;
         }
@@ -859,6 +934,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
         const u32x4* wp = reinterpret_cast<const u32x4*>(A.wpack) + (size_t)b * PF_CHUNKS * PF_THREADS;
         // row pairs (Wqkv 5 + Wo 4 per layer, 4 head rows): streamed one stage ahead from the dword-major image (L2-resident, 80 KB per CU)
         const uint32_t* rpi = A.rowpairs + (size_t)b * 40 * PF_THREADS;
+        const float* const fscl = A.scales ? A.scales + (size_t)b * PF_SCL : nullptr;  // FS_FP8: row scales of the bf16-widened image (48 per layer + head at [192])
         uint32_t wq5[5], wo4[4], wh4[4];
         uint2 wo8[4];  // R >= 2: Wo row pairs of the lane's FOUR attention dims (half-block attention, see S2)
 #pragma unroll
@@ -950,6 +1026,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                             float t = rp[m], ss = rp[5];
 #pragma unroll
                             for (int w = 1; w < 8; ++w) { t += rp[w * R * FRW + m]; ss += rp[w * R * FRW + 5]; }
+                            if (fscl) t *= fscl[PRS * l + PRS_QKV + m];
                             pub(e, rr, r, 5 * b + m, tag0 + e + 1, t * pf_rms_inv(ss, A.eps));
                         }
                     }
@@ -1121,6 +1198,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                             float t = rp[m];
 #pragma unroll
                             for (int w = 1; w < NWR; ++w) t += rp[w * R * FRW + m];
+                            if (fscl) t *= fscl[PRS * l + PRS_WO + m];
                             pub(e, rr, r, 4 * b + m, tag0 + e + 1, xr[r * 4 + m] + t);
                         }
                     }
@@ -1168,6 +1246,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
 #pragma unroll
                             for (int w = 1; w < 8; ++w) { ga += rp[w * R * FRW + 2 * jj]; gb += rp[w * R * FRW + 2 * jj + 1]; ss += rp[w * R * FRW + 32]; }
                             const float dni = pf_rms_inv(ss, A.eps);
+                            if (fscl) { ga *= fscl[PRS * l + PRS_W13 + 2 * jj]; gb *= fscl[PRS * l + PRS_W13 + 2 * jj + 1]; }
                             ga *= dni; gb *= dni;
                             pub(e, rr, r, 16 * b + jj, tag0 + e + 1, pf_silu(ga) * gb);
                         }
@@ -1244,6 +1323,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                             float t = rp[m];
 #pragma unroll
                             for (int w = 1; w < 8; ++w) t += rp[w * R * FRW + m];
+                            if (fscl) t *= fscl[PRS * l + PRS_W2 + m];
                             pub(e, rr, r, 4 * b + m, tag0 + e + 1, xr[r * 4 + m] + t);
                         }
                     }
@@ -1288,6 +1368,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                         float t = rp[m], ss = rp[4];
 #pragma unroll
                         for (int w = 1; w < 8; ++w) { t += rp[w * R * FRW + m]; ss += rp[w * R * FRW + 4]; }
+                        if (fscl) t *= fscl[4 * PRS + m];
                         pub(e, rr, r, 4 * b + m, tag0 + e + 1, t * pf_rms_inv(ss, A.eps));
                     }
                 }
@@ -1447,7 +1528,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
             st->pos += 1;
             st->frame = fr + 1;
             if (eos || fr + 1 >= A.budget[r]) st->done = 2;
-            if (SAMPLED) A.rng[r].consumed += (unsigned long long)n_draws_l[r];
+            if (SAMPLED || legacy) A.rng[r].consumed += (unsigned long long)n_draws_l[r];
         }
         // next slow input: embed([slow, c0..c7]) (dual_ar.rs:532-567)
         {
@@ -1482,6 +1563,15 @@ void launch_rows_pack(const LayerW* layers, int n_layer, const void* head_w, int
         hipLaunchKernelGGL(k_pr_pack_layer, dim3(PF_BLOCKS), dim3(PF_THREADS), 0, st, layers[l],
                            reinterpret_cast<unsigned char*>(wimg) + (size_t)l * PF_BLOCKS * PS_LAYER_IMAGE);
     hipLaunchKernelGGL(k_pr_pack_head, dim3(PF_BLOCKS), dim3(PF_THREADS), 0, st, reinterpret_cast<const u32x4*>(head_w), n_head_rows,
+                       reinterpret_cast<unsigned char*>(himg));
+    FS_HIP(hipGetLastError());
+}
+
+void launch_rows_pack_fp8(const LayerW* layers, int n_layer, const void* head_w, int n_head_rows, void* wimg, void* himg, hipStream_t st) {
+    for (int l = 0; l < n_layer; ++l)
+        hipLaunchKernelGGL(k_pr_pack_layer_fp8, dim3(PF_BLOCKS), dim3(PF_THREADS), 0, st, layers[l],
+                           reinterpret_cast<unsigned char*>(wimg) + (size_t)l * PF_BLOCKS * PS_LAYER_IMAGE);
+    hipLaunchKernelGGL(k_pr_pack_head_fp8, dim3(PF_BLOCKS), dim3(PF_THREADS), 0, st, reinterpret_cast<const uint2*>(head_w), n_head_rows,
                        reinterpret_cast<unsigned char*>(himg));
     FS_HIP(hipGetLastError());
 }

@@ -164,19 +164,20 @@ def test_fp8_persistent_kernels_kv_forced_fp8_oracle(sampling):
 ROW_LENS = [40, 130, 77, 250, 61, 199, 33, 160]
 
 
-@pytest.mark.parametrize("n,sampling", [(2, GREEDY), (4, GREEDY), (5, GREEDY), (6, GREEDY), (8, GREEDY), (4, SAMPLED), (5, SAMPLED)],
-                         ids=["R2", "R4", "R5", "R6", "R8", "R4-sampled", "R5-sampled"])
-def test_row_kernels_kv_forced_oracle(n, sampling):
+@pytest.mark.parametrize("n,sampling,dtype", [(2, GREEDY, "bf16"), (4, GREEDY, "bf16"), (5, GREEDY, "bf16"), (6, GREEDY, "bf16"), (8, GREEDY, "bf16"),
+                                              (4, SAMPLED, "bf16"), (5, SAMPLED, "bf16"), (4, GREEDY, "fp8"), (5, SAMPLED, "fp8")],
+                         ids=["R2", "R4", "R5", "R6", "R8", "R4-sampled", "R5-sampled", "R4-fp8", "R5-fp8-sampled"])
+def test_row_kernels_kv_forced_oracle(n, sampling, dtype):
     """every instantiation of the request-row kernels (k_slow_rows<2|4|8>, k_fast_rows<1|2|4, greedy|sampled>) against the ORACLE, each row
     teacher-forced on its own tokens and its own cached K/V"""
     F, rp = 40 if n <= 5 else 32, 1.2
     lens = ROW_LENS[:n]
     prompts = [_prompt(L, 900 + i) for i, L in enumerate(lens)]
-    lm = fishrt.DualARTransformer(fcfg.FISH_1_5, TOK, 0, "bf16", max_batch=8 if n > 4 else n).load_synthetic(SEED)
+    lm = fishrt.DualARTransformer(fcfg.FISH_1_5, TOK, 0, dtype, max_batch=8 if n > 4 else n).load_synthetic(SEED)
     lm.debug_capture(F)
     got = lm.generate_multi(prompts, [L + F - 2 for L in lens], repetition_penalty=rp, ignore_eos=True, seeds=[100 + i for i in range(n)], **sampling)
     assert lm.last_stats()["kernels_per_frame"] == 1 + (n + 3) // 4
-    o = orc.OracleLM(orc.FISH15).load_synthetic(SEED, bf16=True)
+    o = orc.OracleLM(orc.FISH15).load_synthetic(SEED, bf16=(dtype == "bf16"), fp8=(dtype == "fp8"))
     o.set_kv_round_bf16(True)
     R, worst = (2 if n <= 2 else 4 if n <= 4 else 8), [0.0, 0.0]
     for i in range(n):
@@ -184,7 +185,7 @@ def test_row_kernels_kv_forced_oracle(n, sampling):
         cap = lm.debug_read_row(i, F)
         ws, w0, wf = _kv_forced_replay(o, lm, i, prompts[i], cap, got[i], rp, fcfg.FISH_1_5["n_layer"])
         left = min(4, n - 4 * (i // 4))
-        _report(f"k_slow_rows<{R}> / k_fast_rows<{4 if left >= 3 else left}, {'sampled' if sampling is SAMPLED else 'greedy'}>: n {n} row {i} (L {lens[i]}), "
+        _report(f"k_slow_rows<{R}> / k_fast_rows<{4 if left >= 3 else left}, {'sampled' if sampling is SAMPLED else 'greedy'}>{' [fp8 handle]' if dtype == 'fp8' else ''}: n {n} row {i} (L {lens[i]}), "
                 f"{F} frames: max |dlogit| slow {ws:.2e} (frame 0: {w0:.2e}), fast {wf:.2e}; own K/V rows within {_kv_units[-1]:.1f} units")
         assert ws < SLOW_TOL and wf < FAST_TOL and w0 < 1e-2, (i, ws, w0, wf)
         worst = [max(worst[0], ws), max(worst[1], wf)]

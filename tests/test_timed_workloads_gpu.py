@@ -115,6 +115,45 @@ def test_full_size_vocoder_64_frames_vs_oracle():
         assert pcm.shape == ref.shape == (2048 * 64,) and r < tol and sig > 1e-3
 
 
+def _fp8_replay(o, cfg_name, cfg, tok, p, cap, codes, F, rp, greedy=True):
+    """the fp8-mode oracle teacher-forced on one request's tokens: max |dlogit| of the slow / fast decisions against the capture record"""
+    o.clear_slow()
+    rps = [_RepPen(1024, rp) for _ in range(8)]
+    femb = o.fast_embeddings()
+    im_end, n_audio = tok["im_end_id"], cfg["vocab_size"] - tok["im_end_id"]
+    cur, pos, prev, worst = p, 0, None, [0.0, 0.0]
+    for f in range(F):
+        lg, hd = o.forward_generate(cur, pos, full_head=(cfg_name == "fish14"))
+        if cfg_name == "fish15":
+            s = lg[0, im_end:].copy()
+            d = float(np.abs(s[1:] - cap[f, 0, 1:n_audio]).max())
+            worst[0] = max(worst[0], d)
+            assert d < BF16_TOL, ("slow logits", f, d)
+            slow = int(cap[f, 0, 2047]) + im_end
+            assert not greedy or slow == _argmax_last(np.concatenate([[-np.inf], cap[f, 0, 1:n_audio]])) + im_end
+        else:
+            slow = tok["pad_id"]  # ignore_eos: the legacy 2-way draw always yields the <|semantic|> / pad token (single_batch.rs:104-124)
+            two = np.array([lg[0, tok["pad_id"]], lg[0, im_end]])  # the in-launch decision saw {pad, im_end} logits, drew u, picked pad
+            d = float(np.abs(two - cap[f, 0, :2]).max())
+            worst[0] = max(worst[0], d)
+            assert d < BF16_TOL and 0.0 <= cap[f, 0, 2] < 1.0 and cap[f, 0, 2047] == 0.0, ("legacy slow decision", f, d)
+        o.clear_fast()
+        x = hd[0]
+        for c in range(8):
+            fg = o.forward_generate_fast(x, c)[0]
+            if prev is not None:
+                fg = rps[c].apply(fg, int(prev[c + 1]))
+            d = float(np.abs(fg - cap[f, 1 + c, :1024]).max())  # (both token layouts: the capture hook lives in the folded prologue path)
+            worst[1] = max(worst[1], d)
+            assert d < BF16_TOL, ("fast logits", f, c, d)
+            assert int(cap[f, 1 + c, 1024]) == codes[c, f] and (not greedy or _argmax_last(cap[f, 1 + c, :1024]) == codes[c, f]), (f, c)
+            x = femb[int(codes[c, f])]
+        frame = np.array([slow] + [int(v) for v in codes[:, f]], np.uint32)
+        pos += cur.shape[1]
+        prev, cur = frame, frame.reshape(9, 1)
+    return worst
+
+
 @pytest.mark.parametrize("cfg_name", ["fish15", "fish14"])
 def test_fp8_persistent_path_every_decision_vs_fp8_oracle(cfg_name):
     """FS_FP8 handles take the persistent kernels too (e4m3 weight images for the slow kernel, bf16-widened e4m3 + row scales for the
@@ -136,37 +175,36 @@ def test_fp8_persistent_path_every_decision_vs_fp8_oracle(cfg_name):
     lm.close()
     o = orc.OracleLM(ocfg).load_synthetic(SEED, fp8=True)
     o.set_kv_round_bf16(True)
-    rps = [_RepPen(1024, rp) for _ in range(8)]
-    femb = o.fast_embeddings()
-    im_end, n_audio = tok["im_end_id"], cfg["vocab_size"] - tok["im_end_id"]
-    cur, pos, prev, worst = p, 0, None, [0.0, 0.0]
-    for f in range(F):
-        lg, hd = o.forward_generate(cur, pos, full_head=(cfg_name == "fish14"))
-        if cfg_name == "fish15":
-            s = lg[0, im_end:].copy()
-            d = float(np.abs(s[1:] - cap[f, 0, 1:n_audio]).max())
-            worst[0] = max(worst[0], d)
-            assert d < BF16_TOL, ("slow logits", f, d)
-            slow = int(cap[f, 0, 2047]) + im_end
-            assert slow == _argmax_last(np.concatenate([[-np.inf], cap[f, 0, 1:n_audio]])) + im_end
-        else:
-            slow = tok["pad_id"]  # ignore_eos: the legacy 2-way draw always yields the <|semantic|> / pad token (single_batch.rs:104-124)
-            two = np.array([lg[0, tok["pad_id"]], lg[0, im_end]])  # the in-launch decision saw {pad, im_end} logits, drew u, picked pad
-            d = float(np.abs(two - cap[f, 0, :2]).max())
-            worst[0] = max(worst[0], d)
-            assert d < BF16_TOL and 0.0 <= cap[f, 0, 2] < 1.0 and cap[f, 0, 2047] == 0.0, ("legacy slow decision", f, d)
-        o.clear_fast()
-        x = hd[0]
-        for c in range(8):
-            fg = o.forward_generate_fast(x, c)[0]
-            if prev is not None:
-                fg = rps[c].apply(fg, int(prev[c + 1]))
-            d = float(np.abs(fg - cap[f, 1 + c, :1024]).max())  # (both token layouts: the capture hook lives in the folded prologue path)
-            worst[1] = max(worst[1], d)
-            assert d < BF16_TOL, ("fast logits", f, c, d)
-            assert _argmax_last(cap[f, 1 + c, :1024]) == codes[c, f], (f, c)
-            x = femb[int(codes[c, f])]
-        frame = np.array([slow] + [int(v) for v in codes[:, f]], np.uint32)
-        pos += cur.shape[1]
-        prev, cur = frame, frame.reshape(9, 1)
+    worst = _fp8_replay(o, cfg_name, cfg, tok, p, cap, codes, F, rp)
     print(f"fp8 persistent path [{cfg_name}], {F} frames: max |dlogit| vs the fp8-mode oracle: slow {worst[0]:.2e}, fast {worst[1]:.2e}")
+
+
+@pytest.mark.parametrize("cfg_name,sampled", [("fish14", False), ("fish15", False), ("fish14", True)], ids=["fish14-greedy", "fish15-greedy", "fish14-sampled"])
+def test_fp8_request_rows_every_decision_vs_fp8_oracle(cfg_name, sampled):
+    """round 5: FS_FP8 and Fish <= 1.4 handles take the request-row kernels too (fs_lm_generate_multi: the e4m3 weights widened to bf16 in the
+    MFMA images, the quantiser's row scales in the publishing lanes; the legacy 2-way slow draw per row inside k_fast_rows).  4 concurrent
+    BASELINE configs[4]-style requests: one slow + one fast launch per frame, every decision of every row against the fp8-mode oracle
+    teacher-forced on the row's own tokens (sampled rows: the logits every draw saw; the draws themselves are replayed through the oracle
+    sampler in tests/test_rows_gpu.py on the bf16 handle -- the sampler code is the same)."""
+    F, rp, n = 32, 1.2, 4
+    cfg, tok = (fcfg.FISH_1_5, TOK) if cfg_name == "fish15" else (fcfg.FISH_1_4, fcfg.FISH_1_4_TOKENS)
+    lens = [60, 141, 33, 97]
+    prompts = []
+    for i, L in enumerate(lens):
+        q = np.zeros((9, L), np.uint32)
+        q[0] = np.random.RandomState(40 + i).randint(6, min(tok["im_end_id"] if cfg_name == "fish15" else cfg["vocab_size"], cfg["vocab_size"]), L)
+        prompts.append(q)
+    kw = dict(temp=0.7, top_p=0.8, top_k=256) if sampled else dict(temp=0.0, top_p=1.0, top_k=0)
+    lm = fishrt.DualARTransformer(cfg, tok, 0, "fp8", max_batch=4).load_synthetic(SEED)
+    assert lm.rows_supported(n, **kw)
+    lm.debug_capture(F)
+    got = lm.generate_multi(prompts, [L + F - 2 for L in lens], repetition_penalty=rp, seeds=[70 + i for i in range(n)], ignore_eos=True, **kw)
+    assert lm.last_stats()["kernels_per_frame"] == 2, "the request-row kernels were not taken"
+    caps = [lm.debug_read_row(i, F) for i in range(n)]
+    lm.close()
+    o = orc.OracleLM(dict(cfg, **tok)).load_synthetic(SEED, fp8=True)
+    o.set_kv_round_bf16(True)
+    for i in range(n):
+        assert got[i].shape == (8, F)
+        worst = _fp8_replay(o, cfg_name, cfg, tok, prompts[i], caps[i], got[i], F, rp, greedy=not sampled)
+        print(f"fp8 request rows [{cfg_name}{', sampled' if sampled else ''}] row {i} (L {lens[i]}): max |dlogit| vs the fp8-mode oracle: slow {worst[0]:.2e}, fast {worst[1]:.2e}")

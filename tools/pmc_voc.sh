@@ -17,7 +17,7 @@ for i in range(3):
     for f in glob.glob(f"/tmp/pv_{i}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void fs::", "")
-            if "conv1d" in k or "mean3" in k or "act_split" in k or "dwconv" in k:
+            if "conv1d" in k or "respair" in k or "mean3" in k or "act_split" in k or "dwconv" in k:
                 key = (k, int(r.get("Grid_Size", "0")))
                 acc[key][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[key][r["Counter_Name"]] += 1
 print(f"# tools/pmc_voc.sh (VOC_PREC={sys.argv[1]}): three separate passes of rocprofv3 --pmc <set> --kernel-trace -- python tools/vocoder_time.py 256 {sys.argv[1]}")

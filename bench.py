@@ -594,6 +594,19 @@ def extras(cfg, tok):
                      "rows_identical_to_each_other": (bool(all(np.array_equal(o, outs[0]) for o in outs)) if kw["temp"] == 0.0 else None),
                      "frames_identical_to_the_batch1_call": (int(np.argmax((outs[0] != ref1).any(0))) if kw["temp"] == 0.0 and (outs[0] != ref1).any() else
                                                              (Fr if kw["temp"] == 0.0 else None))}
+    # round 5: the same on an FS_FP8 handle (e4m3 weights widened into the row kernels' MFMA images, quantiser row scales in the publishing lanes)
+    lm4f = fishrt.DualARTransformer(cfg, tok, 0, "fp8", max_batch=4).load_synthetic(SEED)
+    bestf, outsf = 1e9, None
+    for _ in range(2):
+        outsf = lm4f.generate_multi([tokp] * 4, Fr + Lp - 2, temp=0.0, top_p=1.0, top_k=0, repetition_penalty=1.2, seeds=[1, 2, 3, 4], ignore_eos=True)
+        stf = lm4f.last_stats()
+        bestf = min(bestf, stf["decode_ms"] * 1e3 / (Fr - 1))
+    assert all(o.shape == (8, Fr) for o in outsf) and stf["kernels_per_frame"] == 2
+    lm4f.close()
+    bytes_f = frame_bytes(cfg, tok, 0, 1) + 4 * 12288 * (Lp + Fr / 2.0)
+    rows["R4_fp8"] = {"frame_us": round(bestf, 1), "decode_frames_per_s": round(4 * 1e6 / bestf, 1), "launches_per_frame": 2,
+                      "roofline_frac": round(bytes_f / (bestf * 1e-6) / HBM_PEAK, 4), "algorithmic_bytes_per_frame": int(bytes_f),
+                      "note": "fp8 weight STORAGE (0.64 GB per replica); the row images stream the widened bf16 values, so the frame costs what the bf16 rows cost"}
     # continuous batching on the row kernels (FS_SESSION_ROWS): 24 ragged sampled requests through 8 slots vs one request at a time on the
     # batch-1 persistent kernels (what the reference's mutex-serialised server does, server/lib/state.rs:12-29) -- same handle, same requests
     rngc = np.random.RandomState(5)

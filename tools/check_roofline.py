@@ -72,7 +72,7 @@ if ex:
     for key, v in pr.items():
         if key[0] == "R" and "frame_us" in v:
             R = int(key[1])
-            bs = bench.frame_bytes(cfg, tok, 0) + R * 12288 * (Lp + 256 / 2.0)
+            bs = bench.frame_bytes(cfg, tok, 0, 1 if key.endswith("_fp8") else 2) + R * 12288 * (Lp + 256 / 2.0)
             check(f"extras.persistent_rows.{key}.roofline_frac", v["roofline_frac"], bs / (v["frame_us"] * 1e-6) / bench.HBM_PEAK, 2e-3)
             check(f"extras.persistent_rows.{key}.decode_frames_per_s", v["decode_frames_per_s"], R * 1e6 / v["frame_us"], 2e-3)
     for key in ("batch1_sampled", "batch1_fp8"):

@@ -22,5 +22,5 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
     done
   done
 done
-python3 $GRAFT_REPO_ROOT/tools/pmc_batch.py /tmp $O/pmc_batch_traffic.json $GRAFT_REPO_ROOT/profiles/r04_pmc_batch_traffic.json
+python3 $GRAFT_REPO_ROOT/tools/pmc_batch.py /tmp $O/pmc_batch_traffic.json $GRAFT_REPO_ROOT/profiles/${PMC_BATCH_PREV:-r04_pmc_batch_traffic.json}
 cat $O/pmc_batch_traffic.json

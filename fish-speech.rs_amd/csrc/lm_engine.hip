@@ -1939,7 +1939,7 @@ class LM final : public LMBase {
         A.prof = getenv("FISHRT_PERSIST_PROF") ? reinterpret_cast<unsigned long long*>(d_sctl_.as<uint32_t>() + 16) : nullptr;
         set_naps(A.naps, "FISHRT_NAPS_SLOW", kFp8 ? kNapsSlowFp8 : kNapsSlow);
         A.prof_wg = getenv("FISHRT_PERSIST_PROF_WG") ? atoi(getenv("FISHRT_PERSIST_PROF_WG")) : 0;
-        A.l2_touch = getenv("FISHRT_SLOW_NO_EARLY13") ? 0 : 1;
+        A.l2_touch = getenv("FISHRT_SLOW_EARLY") ? atoi(getenv("FISHRT_SLOW_EARLY")) : 1;  // k_slow_persist early_mode bits
         return A;
     }
     // the persistent fast decoder takes the slow-token decision in its prologue (no k_sample_slow node) whenever it runs

@@ -268,6 +268,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
             for (int c = 0; c < NCT; ++c) acc[0][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             pr_mfma_seg<1, NCT>(wq, 4, 0, reinterpret_cast<const u32x4*>(xt), n, q4, acc);
             pr_extract<1, NCT, RPC, 5, RW>(acc, redw, n, q4);
+            const float psc = scl ? scl[PRS_QKV + tid % 5] : 1.f;  // (FS_FP8 row scale of this lane's first publish: requested in front of the barrier, not in the chain behind it)
             __syncthreads();
             for (int idx = tid; idx < 5 * R * PF_REPL; idx += PF_THREADS) {
                 const int m = idx % 5, r = (idx / 5) % R, rr = idx / (5 * R);
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
                     float t = rp[m], tot = rp[32];
 #pragma unroll
                     for (int w = 1; w < 8; ++w) { t += rp[w * R * RW + m]; tot += rp[w * R * RW + 32]; }
-                    if (scl) t *= scl[PRS_QKV + m];
+                    if (scl) t *= idx == tid ? psc : scl[PRS_QKV + m];
                     pub(e, rr, r, 5 * b + m, tag0 + e + 1, t * pf_rms_inv(tot, A.eps));
                 }
             }
@@ -481,6 +482,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
             for (int c = 0; c < NCT; ++c) acc[0][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             pr_mfma_seg<1, NCT>(wo, 4, 0, reinterpret_cast<const u32x4*>(xt), n, q4, acc);
             pr_extract<1, NCT, RPC, 4, RW>(acc, redw, n, q4);
+            const float psc = scl ? scl[PRS_WO + (tid & 3)] : 1.f;
             __syncthreads();
             for (int idx = tid; idx < 4 * R * PF_REPL; idx += PF_THREADS) {
                 const int m = idx & 3, r = (idx >> 2) % R, rr = idx / (4 * R);
@@ -489,7 +491,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
                     float t = rp[m];
 #pragma unroll
                     for (int w = 1; w < 8; ++w) t += rp[w * R * RW + m];
-                    if (scl) t *= scl[PRS_WO + m];
+                    if (scl) t *= psc;  // (m == tid & 3 in every iteration: the stride is a multiple of 4)
                     pub(e, rr, r, 4 * b + m, tag0 + e + 1, xr[r * 4 + m] + t);
                 }
             }
@@ -527,6 +529,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
             for (int c = 0; c < NCT; ++c) { acc[0][c] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[1][c] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
             pr_mfma_seg<2, NCT>(w13, 4, 0, reinterpret_cast<const u32x4*>(xt), n, q4, acc);
             pr_extract<2, NCT, RPC, 32, RW>(acc, redw, n, q4);
+            const float psa = scl ? scl[PRS_W13 + 2 * (tid & 15)] : 1.f, psb = scl ? scl[PRS_W13 + 2 * (tid & 15) + 1] : 1.f;
             PS_TICK(10);
             __syncthreads();
             PS_TICK(11);
@@ -538,7 +541,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
 #pragma unroll
                     for (int w = 1; w < 8; ++w) { ga += rp[w * R * RW + 2 * jj]; gb += rp[w * R * RW + 2 * jj + 1]; tot += rp[w * R * RW + 32]; }
                     const float dni = pf_rms_inv(tot, A.eps);
-                    if (scl) { ga *= scl[PRS_W13 + 2 * jj]; gb *= scl[PRS_W13 + 2 * jj + 1]; }
+                    if (scl) { ga *= psa; gb *= psb; }  // (jj == tid & 15 in every iteration)
                     ga *= dni; gb *= dni;
                     pub(e, rr, r, 16 * b + jj, tag0 + e + 1, pf_silu(ga) * gb);
                 }
@@ -585,6 +588,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
             ++e;
             PS_TICK(12);
             pr_extract<1, NCT, RPC, 4, RW>(acc, redw, n, q4);
+            const float psc = scl ? scl[PRS_W2 + (tid & 3)] : 1.f;
             __syncthreads();
             PS_TICK(13);
             for (int idx = tid; idx < 4 * R * PF_REPL; idx += PF_THREADS) {
@@ -594,7 +598,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
                     float t = rp[m];
 #pragma unroll
                     for (int w = 1; w < 8; ++w) t += rp[w * R * RW + m];
-                    if (scl) t *= scl[PRS_W2 + m];
+                    if (scl) t *= psc;
                     pub(e, rr, r, 4 * b + m, tag0 + e + 1, xr[r * 4 + m] + t);
                 }
             }
@@ -634,6 +638,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
         for (int c = 0; c < NCT; ++c) acc[0][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         pr_mfma_seg<1, NCT>(hd, 4, 0, reinterpret_cast<const u32x4*>(xt), n, q4, acc);
         pr_extract<1, NCT, RPC, 8, RW>(acc, redw, n, q4);
+        const float phs = A.hscales ? A.hscales[8 * b + (tid & 7)] : 1.f;
         __syncthreads();
         if (tid < 8 * R) {
             const int m = tid & 7, r = tid >> 3;
@@ -642,7 +647,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
                 float t = rp[m], tot = rp[32];
 #pragma unroll
                 for (int w = 1; w < 8; ++w) { t += rp[w * R * RW + m]; tot += rp[w * R * RW + 32]; }
-                if (A.hscales) t *= A.hscales[8 * b + m];
+                if (A.hscales) t *= phs;
                 A.logits[(size_t)r * PR_LD + 8 * b + m] = t * pf_rms_inv(tot, A.eps);
             }
         }
@@ -1018,6 +1023,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                         constexpr int SH = RG == 2 ? 2 : 3;  // value index = lane >> SH
                         if ((lane & ((1 << SH) - 1)) == 0) red[(par * 8 + wave) * R * FRW + (r0 + ((lane >> SH) >> 3)) * FRW + ((lane >> SH) & 7)] = tot;
                     }
+                    const float psc = fscl ? fscl[PRS * l + PRS_QKV + tid % 5] : 1.f;
                     __syncthreads();
                     for (int idx = tid; idx < 5 * R * PF_REPL; idx += PF_THREADS) {
                         const int m = idx % 5, r = (idx / 5) % R, rr = idx / (5 * R);
@@ -1026,7 +1032,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                             float t = rp[m], ss = rp[5];
 #pragma unroll
                             for (int w = 1; w < 8; ++w) { t += rp[w * R * FRW + m]; ss += rp[w * R * FRW + 5]; }
-                            if (fscl) t *= fscl[PRS * l + PRS_QKV + m];
+                            if (fscl) t *= idx == tid ? psc : fscl[PRS * l + PRS_QKV + m];
                             pub(e, rr, r, 5 * b + m, tag0 + e + 1, t * pf_rms_inv(ss, A.eps));
                         }
                     }
@@ -1187,6 +1193,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                         constexpr int SH = RH == 2 ? 3 : 4;
                         if ((lane & ((1 << SH) - 1)) == 0) red[(par * 8 + wave) * R * FRW + (half * RH + ((lane >> SH) >> 2)) * FRW + ((lane >> SH) & 3)] = tot;
                     }
+                    const float pso = fscl ? fscl[PRS * l + PRS_WO + (tid & 3)] : 1.f;  // (FS_FP8 row scales: requested in front of the barrier)
                     __syncthreads();
                     for (int idx = tid; idx < 4 * R * PF_REPL; idx += PF_THREADS) {
                         const int m = idx & 3, r = (idx >> 2) % R, rr = idx / (4 * R);
@@ -1198,7 +1205,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                             float t = rp[m];
 #pragma unroll
                             for (int w = 1; w < NWR; ++w) t += rp[w * R * FRW + m];
-                            if (fscl) t *= fscl[PRS * l + PRS_WO + m];
+                            if (fscl) t *= pso;
                             pub(e, rr, r, 4 * b + m, tag0 + e + 1, xr[r * 4 + m] + t);
                         }
                     }
@@ -1236,6 +1243,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                     // needs from memory: a wave's loads return in order
 #pragma unroll
                     for (int q = 0; q < 4; ++q) w2r[q] = wp[(unsigned)((PF_REG_CHUNKS + 4 * l + q) * PF_THREADS + tid)];
+                    const float psa = fscl ? fscl[PRS * l + PRS_W13 + 2 * (tid & 15)] : 1.f, psb = fscl ? fscl[PRS * l + PRS_W13 + 2 * (tid & 15) + 1] : 1.f;
                     PF_TICK(8);
                     __syncthreads();
                     for (int idx = tid; idx < 16 * R * PF_REPL; idx += PF_THREADS) {
@@ -1246,7 +1254,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
 #pragma unroll
                             for (int w = 1; w < 8; ++w) { ga += rp[w * R * FRW + 2 * jj]; gb += rp[w * R * FRW + 2 * jj + 1]; ss += rp[w * R * FRW + 32]; }
                             const float dni = pf_rms_inv(ss, A.eps);
-                            if (fscl) { ga *= fscl[PRS * l + PRS_W13 + 2 * jj]; gb *= fscl[PRS * l + PRS_W13 + 2 * jj + 1]; }
+                            if (fscl) { ga *= psa; gb *= psb; }
                             ga *= dni; gb *= dni;
                             pub(e, rr, r, 16 * b + jj, tag0 + e + 1, pf_silu(ga) * gb);
                         }
@@ -1314,6 +1322,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) wh4[i] = rpi[(unsigned)((9 * PF_LAYERS + i) * PF_THREADS + tid)];
                     }
+                    const float ps2 = fscl ? fscl[PRS * l + PRS_W2 + (tid & 3)] : 1.f;
                     PF_TICK(12);
                     __syncthreads();
                     for (int idx = tid; idx < 4 * R * PF_REPL; idx += PF_THREADS) {
@@ -1323,7 +1332,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                             float t = rp[m];
 #pragma unroll
                             for (int w = 1; w < 8; ++w) t += rp[w * R * FRW + m];
-                            if (fscl) t *= fscl[PRS * l + PRS_W2 + m];
+                            if (fscl) t *= ps2;
                             pub(e, rr, r, 4 * b + m, tag0 + e + 1, xr[r * 4 + m] + t);
                         }
                     }
@@ -1360,6 +1369,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                     constexpr int SH = RG == 2 ? 2 : 3;
                     if ((lane & ((1 << SH) - 1)) == 0) red[(par * 8 + wave) * R * FRW + (r0 + ((lane >> SH) >> 3)) * FRW + ((lane >> SH) & 7)] = tot;
                 }
+                const float psh = fscl ? fscl[4 * PRS + (tid & 3)] : 1.f;
                 __syncthreads();
                 for (int idx = tid; idx < 4 * R * PF_REPL; idx += PF_THREADS) {
                     const int m = idx & 3, r = (idx >> 2) % R, rr = idx / (4 * R);
@@ -1368,7 +1378,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                         float t = rp[m], ss = rp[4];
 #pragma unroll
                         for (int w = 1; w < 8; ++w) { t += rp[w * R * FRW + m]; ss += rp[w * R * FRW + 4]; }
-                        if (fscl) t *= fscl[4 * PRS + m];
+                        if (fscl) t *= psh;
                         pub(e, rr, r, 4 * b + m, tag0 + e + 1, t * pf_rms_inv(ss, A.eps));
                     }
                 }

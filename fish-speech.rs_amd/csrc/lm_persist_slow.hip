@@ -263,9 +263,16 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
     // S1 (profiles/r05_stage_profile.txt).  The workgroups WITHOUT an attention item have no sweep and no K/V tile between S1's publish and
     // S3, so they ask for their W13 slice right behind S1's publish, three stages ahead, while HBM is idle; the attention workgroups
     // (64 or 128 of 256) keep asking in S3 and share a burst a quarter to a half the size.  (FISHRT_SLOW_NO_EARLY13=1: everybody in S3.)
-    // (measured and rejected on top of it, profiles/r05_stage_profile.txt: W2 riding with W13; the attention workgroups asking behind their S2
-    // publish; W2 through the same unseen loads at its old place in S4 -- each 5 .. 30 us per frame worse)
-    const bool early13 = A.l2_touch && !att;
+    // Rule for every unseen request below: the compiler counts only the loads it knows, so its wait for a KNOWN load that is still in flight
+    // (Wo, the norm vector, the next Wqkv rows, the K/V tile) must be made to land BEFORE the unseen loads are issued -- each such value is
+    // pinned (empty asm) right behind the sweep that has already completed it; a wait left behind the unseen loads becomes a wait for them.
+    // bit 0: workgroups without an attention item request W13 behind S1's publish
+    // bit 1: they request W2 (needed by S5, 28 % of the bytes) there as well; the attention workgroups request W2 in S4 as before
+    // bit 2: attention workgroups whose slice is ONE K/V tile: waves 2..7 request W13 behind S1's publish too (the K/V tile through unseen loads with
+    //        an explicit s_waitcnt in S2), waves 0 / 1 -- which sweep q / k / v in S2 -- behind that sweep
+    const int early_mode = A.l2_touch;
+    const bool early13 = (early_mode & 1) && !att, early2 = (early_mode & 2) && !att;
+    const bool att_early = (early_mode & 4) && att && n_tiles <= 1;
     auto request_w13 = [&](const unsigned char* wl_) {  // the W13 slice of this layer -> registers, valid after the next sweep
         if constexpr (FP8) {
 #pragma unroll
@@ -273,6 +280,14 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
         } else {
 #pragma unroll
             for (int c = 0; c < 8; ++c) ps_load16_unseen(w13[c], wl_ + IM_W13 + (size_t)c * PF_THREADS * 16, (unsigned)tid_k * 16u);
+        }
+    };
+    auto request_w2 = [&](const unsigned char* wl_) {
+        if constexpr (FP8) {
+            ps_load16_unseen(w2f[0], wl_ + I8_W2, (unsigned)tid_k * 16u); ps_load16_unseen(w2f[1], wl_ + I8_W2 + PF_THREADS * 16, (unsigned)tid_k * 16u);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ps_load16_unseen(w2r[q], wl_ + IM_W2 + (size_t)q * PF_THREADS * 16, (unsigned)tid_k * 16u);
         }
     };
     unsigned long long tk[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = A.prof ? wall_clock64() : 0;  // [1..6] work of S1..S5 / head, [9..14] the wait (nap + sweep) in front of it
@@ -321,6 +336,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
         {
             tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
             const float2 nw = *reinterpret_cast<const float2*>(A.norms + (size_t)(2 * l) * 1024 + 2 * tid);
+            float2 nw_pin = nw;
             if (l > 0) {
                 u32x4 v;
                 pf_nap_before_sweep(A.naps[0]);
@@ -329,9 +345,20 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
                 ++e;
                 PS_TICK(9);
             }
-            if (att && n_tok > 0) load_kv_tile0(l);  // this layer's first K/V tile, under the qkv stage
+            if (att_early) {  // (see early_mode bit 2) the K/V tile through unseen loads: pin what the compiler still has in flight first
+                float nwx = nw.x, nwy = nw.y;
+                asm volatile("" : "+v"(nwx), "+v"(nwy));
+                if constexpr (FP8) asm volatile("" : "+v"(wq4f), "+v"(wq1)); else asm volatile("" : "+v"(wq4), "+v"(wq1));
+                nw_pin = make_float2(nwx, nwy);
+                if (n_tok > 0) {
+                    const unsigned char* kp = reinterpret_cast<const unsigned char*>(A.kv_pool) + (size_t)l * 2 * A.layer_half * 2;
+                    const unsigned char* vp = kp + A.layer_half * 2;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) { ps_load16_unseen(kreg[u], kp, kv_off0[u] * 2u); ps_load16_unseen(vreg[u], vp, kv_off0[u] * 2u); }
+                }
+            } else if (att && n_tok > 0) load_kv_tile0(l);  // this layer's first K/V tile, under the qkv stage
             *reinterpret_cast<float2*>(xs + 2 * tid) = make_float2(x0, x1);
-            const float xn0 = x0 * nw.x, xn1 = x1 * nw.y;
+            const float xn0 = x0 * nw_pin.x, xn1 = x1 * nw_pin.y;
             float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             float rsc = 1.f;
             if constexpr (FP8) {
@@ -360,7 +387,8 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
                     pub(e, k + 4, 5 * b + r, tag0 + e + 1, val);
                 }
             }
-            if (early13) request_w13(wl);  // (nothing of this wave is in flight here: the stage's own weights and norm vector have been consumed)
+            if (early13 || (att_early && wave >= 2)) request_w13(wl);  // (nothing the compiler knows of is in flight here: the stage's own weights and norm vector have been consumed)
+            if (early2) request_w2(wl);
             par ^= 1;
             PS_TICK(1);
         }
@@ -395,7 +423,12 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
                 }
             }
             ++e;
+            if (att_early && wave < 2) request_w13(wl);
             __syncthreads();
+            if (att_early) {  // the tile's four loads are older than this wave's W13 request (8 / 4 loads) and Wo (1 / 1): let those stay in flight
+                if constexpr (FP8) asm volatile("s_waitcnt vmcnt(5)" : "+v"(kreg[0]), "+v"(kreg[1]), "+v"(vreg[0]), "+v"(vreg[1]));
+                else asm volatile("s_waitcnt vmcnt(9)" : "+v"(kreg[0]), "+v"(kreg[1]), "+v"(vreg[0]), "+v"(vreg[1]));
+            }
             PS_TICK(10);
             // Every WAVE keeps its own running {m, l, o} over the tiles (flash-decoding inside the workgroup): the wave maximum is uniform by DPP /
             // readlane, a lane accumulates p * v for its own tokens and 8-dim slice and p for its token (lanes with du == 0), and nothing crosses
@@ -505,6 +538,8 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
             tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
             const int h = tid >> 5, j = tid & 31;
             const u64* eb = my_edges + (size_t)(e & 3) * ering;
+            float rsc = 1.f;  // fp8 row scale of the publishing lanes: requested in FRONT of the sweep and pinned behind it (see the unseen-request rule)
+            if constexpr (FP8) { if (tid < 64) rsc = scl[(size_t)l * scl_layer + SC_WO + min(tid & 15, 3)]; }
             float mn = -1e30f, L = 0.f, at0 = 0.f, at1 = 0.f;
             // two passes over the slices would need the maxima first: keep {m, l, o} of up to 16 slices in registers (n_sl <= 16)
             float sm[16], sl_[16], so0[16], so1[16];
@@ -558,14 +593,13 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
             }
             ++e;
             PS_TICK(11);
-            float rsc = 1.f;
             if constexpr (FP8) {
-                if (tid < 64) rsc = scl[(size_t)l * scl_layer + SC_WO + min(tid & 15, 3)];
+                asm volatile("" : "+v"(rsc));
                 asm volatile("" : "+v"(wo4f));  // (in flight since S2: the compiler's wait for it lands HERE, where the sweep's vmcnt(0) has already satisfied it, not behind the unseen loads)
-                if (!early13) request_w13(wl);  // next stage's weights (32 KB per CU)
+                if (!early13 && !att_early) request_w13(wl);  // next stage's weights (32 KB per CU)
             } else {
                 asm volatile("" : "+v"(wo4));  // (see the fp8 branch)
-                if (!early13) request_w13(wl);  // next stage's weights (64 KB per CU), behind the sweep (workgroups without an attention item asked for them in S1)
+                if (!early13 && !att_early) request_w13(wl);  // next stage's weights (64 KB per CU), behind the sweep (workgroups without an attention item asked for them in S1)
             }
             // flash-decoding combine of the head's slices, one instantiation per slice count (a runtime bound kept all 16 slots alive: 32
             // predicated v_exp per lane whatever n_sl was)
@@ -620,22 +654,22 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
         {
             tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
             const float2 nw = *reinterpret_cast<const float2*>(A.norms + (size_t)(2 * l + 1) * 1024 + 2 * tid);
+            float rsa = 1.f, rsb = 1.f;
+            if constexpr (FP8) {
+                if (tid < 64) { rsa = scl[(size_t)l * scl_layer + SC_W13 + 2 * (tid & 15)]; rsb = scl[(size_t)l * scl_layer + SC_W13 + 2 * (tid & 15) + 1]; }
+            }
             u32x4 v;
             pf_nap_before_sweep(A.naps[3]);
             pf_sweep1(my_edges + (size_t)(e & 3) * ering, tid, tag0 + e + 1, v, dead, A.ctl);
             ++e;
             PS_TICK(12);
-            float rsa = 1.f, rsb = 1.f;
-            if constexpr (FP8) {
-                if (tid < 64) { rsa = scl[(size_t)l * scl_layer + SC_W13 + 2 * (tid & 15)]; rsb = scl[(size_t)l * scl_layer + SC_W13 + 2 * (tid & 15) + 1]; }
-                w2f[0] = reinterpret_cast<const u32x4*>(wl + I8_W2)[tid]; w2f[1] = reinterpret_cast<const u32x4*>(wl + I8_W2)[PF_THREADS + tid];  // next stage's weights
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) w2r[q] = reinterpret_cast<const u32x4*>(wl + IM_W2)[q * PF_THREADS + tid];  // next stage's weights
-            }
+            float nwx = nw.x, nwy = nw.y;
+            asm volatile("" : "+v"(nwx), "+v"(nwy));  // (in flight since the top of the stage: its wait lands here, behind the sweep that completed it)
+            if constexpr (FP8) asm volatile("" : "+v"(rsa), "+v"(rsb));
+            if (!early2) request_w2(wl);  // next stage's weights (workgroups without an attention item asked for them in S1)
             x0 = __uint_as_float(v.x); x1 = __uint_as_float(v.z);
             *reinterpret_cast<float2*>(xs + 2 * tid) = make_float2(x0, x1);
-            const float xn0 = x0 * nw.x, xn1 = x1 * nw.y;
+            const float xn0 = x0 * nwx, xn1 = x1 * nwy;
             const float ssw = pf_wave_sum(fmaf(x1, x1, fmaf(x0, x0, 0.f)));
             if (lane == 0) red[(par * 8 + wave) * PS_RED + 32] = ssw;
 #pragma unroll

@@ -1975,6 +1975,13 @@ class LM final : public LMBase {
                 d_rhimg_.alloc((size_t)PF_BLOCKS * PS_HEAD_IMAGE);
                 if constexpr (kFp8) launch_rows_pack_fp8(slow_.data(), a_.n_layer, slow_head_w(), n_audio_, d_rimg_.p, d_rhimg_.p, st_);
                 else launch_rows_pack(slow_.data(), a_.n_layer, slow_head_w(), n_audio_, d_rimg_.p, d_rhimg_.p, st_);
+                if constexpr (!kFp8) {  // bf16 handles: the row kernels multiply every K-summed row result by a table entry unconditionally -- ones
+                    const size_t n1 = (size_t)a_.n_layer * PF_BLOCKS * 48 + (size_t)PF_BLOCKS * 8 + (size_t)PF_BLOCKS * PF_SCL;
+                    std::vector<float> ones(n1, 1.0f);
+                    d_rones_.alloc(n1 * sizeof(float));
+                    FS_HIP(hipMemcpyAsync(d_rones_.p, ones.data(), n1 * sizeof(float), hipMemcpyHostToDevice, st_));
+                    FS_HIP(hipStreamSynchronize(st_));
+                }
                 d_rpairs_.alloc((size_t)PF_BLOCKS * 40 * PF_THREADS * 4);
                 launch_rows_pack_rowpairs(d_pack_.p, d_rpairs_.p, st_);
                 d_redges_s_.alloc(rows_slow_edge_bytes(PR_MAX_ROWS));
@@ -2011,8 +2018,9 @@ class LM final : public LMBase {
     RowsSlowArgs rows_slow_args(int R) {
         RowsSlowArgs A = {};
         A.wimg = d_rimg_.p; A.himg = d_rhimg_.p; A.norms = d_snorms_.as<float>();
-        A.scales = d_sscl_.p ? d_sscl_.as<float>() : nullptr;  // FS_FP8: the slow persistent kernel's scale tables (same row -> workgroup mapping)
-        A.hscales = d_sscl_.p ? d_sscl_.as<float>() + (size_t)a_.n_layer * PF_BLOCKS * 48 : nullptr;
+        const float* sc0 = kFp8 ? d_sscl_.as<float>() : d_rones_.as<float>();  // FS_FP8: the slow persistent kernel's scale tables (same row -> workgroup mapping); bf16: ones
+        A.scales = sc0;
+        A.hscales = sc0 + (size_t)a_.n_layer * PF_BLOCKS * 48;
         A.n_layer = a_.n_layer; A.n_head_rows = n_audio_;
         A.cos_t = d_cos_.as<float>(); A.sin_t = d_sin_.as<float>(); A.eps = d_.eps;
         A.x = x(0); A.logits = d_rlogits_.as<float>(); A.state = state(0);
@@ -2030,7 +2038,7 @@ class LM final : public LMBase {
         RowsFastArgs A = {};
         (void)Rf;
         A.wpack = d_pack_.p; A.rowpairs = d_rpairs_.as<uint32_t>();
-        A.scales = d_fscl_.p ? d_fscl_.as<float>() : nullptr;
+        A.scales = kFp8 ? d_fscl_.as<float>() : d_rones_.as<float>() + (size_t)a_.n_layer * PF_BLOCKS * 48 + (size_t)PF_BLOCKS * 8;
         for (int l = 0; l < PF_LAYERS; ++l) { A.norms[2 * l] = fast_[l].attn_norm; A.norms[2 * l + 1] = fast_[l].ffn_norm; }
         A.norms[2 * PF_LAYERS] = fast_norm_w_;
         A.fast_emb = fast_emb_; A.tok_emb = tok_emb_; A.cb_emb = cb_emb_;
@@ -2205,7 +2213,7 @@ class LM final : public LMBase {
     std::map<int, hipGraphExec_t> batch_graphs_;
     RepPenState rp_ = {};
     DevBuf d_rimg_, d_rhimg_, d_redges_s_, d_redges_f_, d_rctl_s_, d_rctl_f_, d_rlogits_, d_rcfg_, d_rrng_, d_rbudget_;  // request rows (lm_persist_rows.hip)
-    DevBuf d_rrp_mask_, d_rrp_seen_, d_rrp_ring_, d_rrp_meta_, d_rcap_, d_rpairs_;
+    DevBuf d_rrp_mask_, d_rrp_seen_, d_rrp_ring_, d_rrp_meta_, d_rcap_, d_rpairs_, d_rones_;
     void* h_pin_ = nullptr;
     hipGraphExec_t g_frame_ = nullptr, g_step_ = nullptr;
     hipEvent_t ev_[3] = {nullptr, nullptr, nullptr};

@@ -27,8 +27,8 @@ struct RowsSlowArgs {
     const void* wimg;       // [n_layer][PF_BLOCKS][PS_LAYER_IMAGE]: MFMA A-fragment images (launch_rows_pack)
     const void* himg;       // [PF_BLOCKS][PS_HEAD_IMAGE]: head rows [8b, 8b+8) as A fragments
     const float* norms;     // [2 * n_layer + 1][1024]
-    const float* scales;    // FS_FP8 handles: the slow persistent kernel's row scales [n_layer][PF_BLOCKS][48] (the images hold the e4m3 weights widened to bf16); null: bf16 handle
-    const float* hscales;   // FS_FP8: head row scales [PF_BLOCKS][8]
+    const float* scales;    // row scales [n_layer][PF_BLOCKS][48]: FS_FP8 handles: the slow persistent kernel's (the images hold the e4m3 weights widened to bf16); bf16 handles: ones
+    const float* hscales;   // head row scales [PF_BLOCKS][8] (FS_FP8: the quantiser's; bf16: ones)
     int n_layer, n_head_rows;
     const float* cos_t;
     const float* sin_t;
@@ -50,7 +50,7 @@ struct RowsSlowArgs {
 struct RowsFastArgs {
     const void* wpack;          // the batch-1 fast image (launch_fast_persist_pack): W13 fragments stay in registers; W2 is streamed from it
     const uint32_t* rowpairs;   // [PF_BLOCKS][40][512]: the image's row-pair dwords, dword-major (launch_rows_pack_rowpairs), streamed
-    const float* scales;        // FS_FP8 handles: row scales of the (bf16-widened) fast image [PF_BLOCKS][PF_SCL] (FastPersistArgs::scales); null: bf16 handle
+    const float* scales;        // row scales of the fast image [PF_BLOCKS][PF_SCL]: FS_FP8 handles: FastPersistArgs::scales (bf16-widened e4m3 image); bf16 handles: ones
     const float* norms[2 * PF_LAYERS + 1];
     const void* fast_emb;
     const void* tok_emb;

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
 
     const unsigned char* wimg = reinterpret_cast<const unsigned char*>(A.wimg) + (size_t)b * PS_LAYER_IMAGE;
     const size_t layer_img = (size_t)PF_BLOCKS * PS_LAYER_IMAGE;
-    const float* const scl0 = A.scales ? A.scales + (size_t)b * PRS : nullptr;  // FS_FP8: this workgroup's row scales, layer l at + l * PF_BLOCKS * PRS
+    const float* const scl0 = A.scales + (size_t)b * PRS;  // this workgroup's row scales (FS_FP8: the quantiser's; bf16 handles: a table of ones -- an unconditional load the compiler can count, where a load behind `if (scales)` made later waits vmcnt(0): +65 us per 4-row frame), layer l at + l * PF_BLOCKS * PRS
     const u32x4 zero4 = u32x4{0, 0, 0, 0};
     u32x4 wq[4], wo[4], w13[8], w2[16];
     {
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
 #pragma unroll 1
     for (int l = 0; l < A.n_layer; ++l) {
         const unsigned char* wl = wimg + (size_t)l * layer_img;
-        const float* const scl = scl0 ? scl0 + (size_t)l * PF_BLOCKS * PRS : nullptr;
+        const float* const scl = scl0 + (size_t)l * PF_BLOCKS * PRS;
         // ================= S1: (gather x) -> RMSNorm folded -> Wqkv rows [5b, 5b+5) of every row
         {
             tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
@@ -245,6 +245,10 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
             uint32_t* xt = reinterpret_cast<uint32_t*>(smem + L::XB + wave * NCT * 4096);
             float* redw = red + (par * 8 + wave) * R * RW;
             const float2 nw = *reinterpret_cast<const float2*>(A.norms + (size_t)(2 * l) * 1024 + 2 * tid);
+            // (row scale of this lane's publish: requested IN FRONT of the stage's sweep and pinned behind it.  vmcnt retires in order, so a
+            // scale requested later waits for every prefetch in front of it -- the K/V tile here, the next stage's weights elsewhere: +85 us
+            // per 4-row frame when it was loaded next to its use)
+            float psc = scl[PRS_QKV + tid % 5];
             if (l > 0) {
                 u32x4 v[R];
                 pf_nap_before_sweep(A.naps[0]);
@@ -253,6 +257,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
                 for (int r = 0; r < R; ++r) { x0[r] = __uint_as_float(v[r].x); x1[r] = __uint_as_float(v[r].z); }
                 ++e;
             }
+            asm volatile("" : "+v"(psc));
             if (att && n_tok > 0) load_kv_tile(l, 0);
 #pragma unroll
             for (int r = 0; r < R; ++r) {  // (unguarded: an inactive row's inputs alias an active row's, nothing of it is published, and
@@ -268,7 +273,6 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
             for (int c = 0; c < NCT; ++c) acc[0][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             pr_mfma_seg<1, NCT>(wq, 4, 0, reinterpret_cast<const u32x4*>(xt), n, q4, acc);
             pr_extract<1, NCT, RPC, 5, RW>(acc, redw, n, q4);
-            const float psc = scl ? scl[PRS_QKV + tid % 5] : 1.f;  // (FS_FP8 row scale of this lane's first publish: requested in front of the barrier, not in the chain behind it)
             __syncthreads();
             for (int idx = tid; idx < 5 * R * PF_REPL; idx += PF_THREADS) {
                 const int m = idx % 5, r = (idx / 5) % R, rr = idx / (5 * R);
@@ -277,7 +281,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
                     float t = rp[m], tot = rp[32];
 #pragma unroll
                     for (int w = 1; w < 8; ++w) { t += rp[w * R * RW + m]; tot += rp[w * R * RW + 32]; }
-                    if (scl) t *= idx == tid ? psc : scl[PRS_QKV + m];
+                    t *= idx == tid ? psc : scl[PRS_QKV + m];  // (5 R PF_REPL <= 512 for R <= 12: one iteration)
                     pub(e, rr, r, 5 * b + m, tag0 + e + 1, t * pf_rms_inv(tot, A.eps));
                 }
             }
@@ -427,6 +431,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
 #pragma unroll
             for (int r = 0; r < R; ++r) { mM[r] = -1e30f; mL[r] = 0.f; mO0[r] = 0.f; mO1[r] = 0.f; }
             const unsigned off_o = (unsigned)((h * n_sl * 66 + 2 * j) * 8), off_ml = (unsigned)((h * n_sl * 66 + 64) * 8);
+            float psc = scl[PRS_WO + (tid & 3)];
             pf_nap_before_sweep(A.naps[2]);
 #pragma unroll
             for (int round = 0; round < 2; ++round) {
@@ -464,6 +469,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
             }
             ++e;
             PS_TICK(8);
+            asm volatile("" : "+v"(psc));
             {   // next stage's weights (64 KB per CU), behind the sweep
                 const u32x4* wp = reinterpret_cast<const u32x4*>(wl + IR_W13);
 #pragma unroll
@@ -482,7 +488,6 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
             for (int c = 0; c < NCT; ++c) acc[0][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             pr_mfma_seg<1, NCT>(wo, 4, 0, reinterpret_cast<const u32x4*>(xt), n, q4, acc);
             pr_extract<1, NCT, RPC, 4, RW>(acc, redw, n, q4);
-            const float psc = scl ? scl[PRS_WO + (tid & 3)] : 1.f;
             __syncthreads();
             for (int idx = tid; idx < 4 * R * PF_REPL; idx += PF_THREADS) {
                 const int m = idx & 3, r = (idx >> 2) % R, rr = idx / (4 * R);
@@ -491,7 +496,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
                     float t = rp[m];
 #pragma unroll
                     for (int w = 1; w < 8; ++w) t += rp[w * R * RW + m];
-                    if (scl) t *= psc;  // (m == tid & 3 in every iteration: the stride is a multiple of 4)
+                    t *= psc;  // (m == tid & 3 in every iteration: the stride is a multiple of 4)
                     pub(e, rr, r, 4 * b + m, tag0 + e + 1, xr[r * 4 + m] + t);
                 }
             }
@@ -505,11 +510,13 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
             uint32_t* xt = reinterpret_cast<uint32_t*>(smem + L::XB + wave * NCT * 4096);
             float* redw = red + (par * 8 + wave) * R * RW;
             const float2 nw = *reinterpret_cast<const float2*>(A.norms + (size_t)(2 * l + 1) * 1024 + 2 * tid);
+            float psa = scl[PRS_W13 + 2 * (tid & 15)], psb = scl[PRS_W13 + 2 * (tid & 15) + 1];
             u32x4 v[R];
             pf_nap_before_sweep(A.naps[3]);
             sweep_x(e, v);
             ++e;
             PS_TICK(9);
+            asm volatile("" : "+v"(psa), "+v"(psb));
             {   // next stage's weights
                 const int m = min(lane & 15, 3);
 #pragma unroll
@@ -529,7 +536,6 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
             for (int c = 0; c < NCT; ++c) { acc[0][c] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[1][c] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
             pr_mfma_seg<2, NCT>(w13, 4, 0, reinterpret_cast<const u32x4*>(xt), n, q4, acc);
             pr_extract<2, NCT, RPC, 32, RW>(acc, redw, n, q4);
-            const float psa = scl ? scl[PRS_W13 + 2 * (tid & 15)] : 1.f, psb = scl ? scl[PRS_W13 + 2 * (tid & 15) + 1] : 1.f;
             PS_TICK(10);
             __syncthreads();
             PS_TICK(11);
@@ -541,7 +547,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
 #pragma unroll
                     for (int w = 1; w < 8; ++w) { ga += rp[w * R * RW + 2 * jj]; gb += rp[w * R * RW + 2 * jj + 1]; tot += rp[w * R * RW + 32]; }
                     const float dni = pf_rms_inv(tot, A.eps);
-                    if (scl) { ga *= psa; gb *= psb; }  // (jj == tid & 15 in every iteration)
+                    ga *= psa; gb *= psb;  // (jj == tid & 15 in every iteration)
                     ga *= dni; gb *= dni;
                     pub(e, rr, r, 16 * b + jj, tag0 + e + 1, pf_silu(ga) * gb);
                 }
@@ -561,6 +567,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
             unsigned offs[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) offs[q] = (unsigned)(tid + PF_THREADS * q) * 16u;
+            float psc = scl[PRS_W2 + (tid & 3)];
             pf_nap_before_sweep(A.naps[4]);
 #pragma unroll
             for (int c = 0; c < NCT; ++c) {
@@ -569,6 +576,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
 #pragma unroll
                 for (int i = 0; i < RPC; ++i) bs[i] = ebase(e, rep, ((act >> (c * RPC + i)) & 1u) ? c * RPC + i : first);
                 pr_sweep_seg4<RPC>(bs, offs, tag0 + e + 1, v, dead, A.ctl);
+                if (c == 0) asm volatile("" : "+v"(psc));
                 if (c == NCT - 1 && l + 1 < A.n_layer) {  // next layer's Wqkv rows
                     const int m = min(lane & 15, 4);
 #pragma unroll
@@ -588,7 +596,6 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
             ++e;
             PS_TICK(12);
             pr_extract<1, NCT, RPC, 4, RW>(acc, redw, n, q4);
-            const float psc = scl ? scl[PRS_W2 + (tid & 3)] : 1.f;
             __syncthreads();
             PS_TICK(13);
             for (int idx = tid; idx < 4 * R * PF_REPL; idx += PF_THREADS) {
@@ -598,7 +605,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
                     float t = rp[m];
 #pragma unroll
                     for (int w = 1; w < 8; ++w) t += rp[w * R * RW + m];
-                    if (scl) t *= psc;
+                    t *= psc;
                     pub(e, rr, r, 4 * b + m, tag0 + e + 1, xr[r * 4 + m] + t);
                 }
             }
@@ -620,6 +627,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) hd[jj] = hp[((wave * 4 + jj) * 4 + q4) * 8 + m];
         }
+        const float phs = A.hscales[8 * b + (tid & 7)];
         u32x4 v[R];
         pf_nap_before_sweep(A.naps[5]);
         sweep_x(e, v);
@@ -638,7 +646,6 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
         for (int c = 0; c < NCT; ++c) acc[0][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         pr_mfma_seg<1, NCT>(hd, 4, 0, reinterpret_cast<const u32x4*>(xt), n, q4, acc);
         pr_extract<1, NCT, RPC, 8, RW>(acc, redw, n, q4);
-        const float phs = A.hscales ? A.hscales[8 * b + (tid & 7)] : 1.f;
         __syncthreads();
         if (tid < 8 * R) {
             const int m = tid & 7, r = tid >> 3;
@@ -647,7 +654,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
                 float t = rp[m], tot = rp[32];
 #pragma unroll
                 for (int w = 1; w < 8; ++w) { t += rp[w * R * RW + m]; tot += rp[w * R * RW + 32]; }
-                if (A.hscales) t *= phs;
+                t *= phs;
                 A.logits[(size_t)r * PR_LD + 8 * b + m] = t * pf_rms_inv(tot, A.eps);
             }
         }
@@ -693,7 +700,9 @@ struct FastLds {
     static constexpr int RING = ROPE + 2 * 8 * 32 * 4;           // per row: ring [8][17], meta [8][2], prev [16], misc [16], cfg [16], StdRng words [16]
     static constexpr int RING_ROW = 8 * 17 + 16 + 16 + 16 + 16 + 16;
     static constexpr int MB = RING + R * RING_ROW * 4;           // [R][512] repetition-penalty mask bits of each lane's two candidates
-    static constexpr int END = MB + R * 512 * 4;
+    static constexpr int SCL = MB + R * 512 * 4;                 // float [PF_SCL] this workgroup's row scales (an LDS read in the publish chain: a global one
+                                                                 // retires behind every prefetch in front of it)
+    static constexpr int END = SCL + ((PF_SCL * 4 + 15) & ~15);
     static constexpr int BYTES = END < 96 * 1024 ? 96 * 1024 : END;
     static_assert(END <= 160 * 1024, "LDS budget");
     static_assert(sizeof(BSampLds) <= 8 * 4096, "the sampler's scratch aliases the staging tiles (dead during a decision)");
@@ -775,6 +784,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
     float* rope_s = rope_c + 8 * 32;
     int* s_ring = reinterpret_cast<int*>(smem + L::RING);  // per row: [0,136) ring, [136,152) meta, [152,168) prev, [168,184) misc, [184,192) cfg
     uint32_t* s_mb = reinterpret_cast<uint32_t*>(smem + L::MB);
+    float* fscl = reinterpret_cast<float*>(smem + L::SCL);
     BSampLds& samp = *reinterpret_cast<BSampLds*>(smem + L::XB);
     constexpr int RR = L::RING_ROW;
     // misc: [0] slow token, [1] have_prev, [2] done, [3] epoch (row 0), [4..11] codes of this frame
@@ -939,7 +949,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
         const u32x4* wp = reinterpret_cast<const u32x4*>(A.wpack) + (size_t)b * PF_CHUNKS * PF_THREADS;
         // row pairs (Wqkv 5 + Wo 4 per layer, 4 head rows): streamed one stage ahead from the dword-major image (L2-resident, 80 KB per CU)
         const uint32_t* rpi = A.rowpairs + (size_t)b * 40 * PF_THREADS;
-        const float* const fscl = A.scales ? A.scales + (size_t)b * PF_SCL : nullptr;  // FS_FP8: row scales of the bf16-widened image (48 per layer + head at [192])
+        if (tid < PF_SCL) fscl[tid] = A.scales[(size_t)b * PF_SCL + tid];  // row scales of the image (FS_FP8: the quantiser's; bf16: ones), 48 per layer + head at [192]
         uint32_t wq5[5], wo4[4], wh4[4];
         uint2 wo8[4];  // R >= 2: Wo row pairs of the lane's FOUR attention dims (half-block attention, see S2)
 #pragma unroll
@@ -1023,7 +1033,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                         constexpr int SH = RG == 2 ? 2 : 3;  // value index = lane >> SH
                         if ((lane & ((1 << SH) - 1)) == 0) red[(par * 8 + wave) * R * FRW + (r0 + ((lane >> SH) >> 3)) * FRW + ((lane >> SH) & 7)] = tot;
                     }
-                    const float psc = fscl ? fscl[PRS * l + PRS_QKV + tid % 5] : 1.f;
+                    const float psc = fscl[PRS * l + PRS_QKV + tid % 5];
                     __syncthreads();
                     for (int idx = tid; idx < 5 * R * PF_REPL; idx += PF_THREADS) {
                         const int m = idx % 5, r = (idx / 5) % R, rr = idx / (5 * R);
@@ -1032,7 +1042,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                             float t = rp[m], ss = rp[5];
 #pragma unroll
                             for (int w = 1; w < 8; ++w) { t += rp[w * R * FRW + m]; ss += rp[w * R * FRW + 5]; }
-                            if (fscl) t *= idx == tid ? psc : fscl[PRS * l + PRS_QKV + m];
+                            t *= idx == tid ? psc : fscl[PRS * l + PRS_QKV + m];
                             pub(e, rr, r, 5 * b + m, tag0 + e + 1, t * pf_rms_inv(ss, A.eps));
                         }
                     }
@@ -1193,7 +1203,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                         constexpr int SH = RH == 2 ? 3 : 4;
                         if ((lane & ((1 << SH) - 1)) == 0) red[(par * 8 + wave) * R * FRW + (half * RH + ((lane >> SH) >> 2)) * FRW + ((lane >> SH) & 3)] = tot;
                     }
-                    const float pso = fscl ? fscl[PRS * l + PRS_WO + (tid & 3)] : 1.f;  // (FS_FP8 row scales: requested in front of the barrier)
+                    const float pso = fscl[PRS * l + PRS_WO + (tid & 3)];  // (row scales: requested in front of the barrier)
                     __syncthreads();
                     for (int idx = tid; idx < 4 * R * PF_REPL; idx += PF_THREADS) {
                         const int m = idx & 3, r = (idx >> 2) % R, rr = idx / (4 * R);
@@ -1205,7 +1215,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                             float t = rp[m];
 #pragma unroll
                             for (int w = 1; w < NWR; ++w) t += rp[w * R * FRW + m];
-                            if (fscl) t *= pso;
+                            t *= pso;
                             pub(e, rr, r, 4 * b + m, tag0 + e + 1, xr[r * 4 + m] + t);
                         }
                     }
@@ -1243,7 +1253,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                     // needs from memory: a wave's loads return in order
 #pragma unroll
                     for (int q = 0; q < 4; ++q) w2r[q] = wp[(unsigned)((PF_REG_CHUNKS + 4 * l + q) * PF_THREADS + tid)];
-                    const float psa = fscl ? fscl[PRS * l + PRS_W13 + 2 * (tid & 15)] : 1.f, psb = fscl ? fscl[PRS * l + PRS_W13 + 2 * (tid & 15) + 1] : 1.f;
+                    const float psa = fscl[PRS * l + PRS_W13 + 2 * (tid & 15)], psb = fscl[PRS * l + PRS_W13 + 2 * (tid & 15) + 1];
                     PF_TICK(8);
                     __syncthreads();
                     for (int idx = tid; idx < 16 * R * PF_REPL; idx += PF_THREADS) {
@@ -1254,7 +1264,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
 #pragma unroll
                             for (int w = 1; w < 8; ++w) { ga += rp[w * R * FRW + 2 * jj]; gb += rp[w * R * FRW + 2 * jj + 1]; ss += rp[w * R * FRW + 32]; }
                             const float dni = pf_rms_inv(ss, A.eps);
-                            if (fscl) { ga *= psa; gb *= psb; }
+                            ga *= psa; gb *= psb;
                             ga *= dni; gb *= dni;
                             pub(e, rr, r, 16 * b + jj, tag0 + e + 1, pf_silu(ga) * gb);
                         }
@@ -1322,7 +1332,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) wh4[i] = rpi[(unsigned)((9 * PF_LAYERS + i) * PF_THREADS + tid)];
                     }
-                    const float ps2 = fscl ? fscl[PRS * l + PRS_W2 + (tid & 3)] : 1.f;
+                    const float ps2 = fscl[PRS * l + PRS_W2 + (tid & 3)];
                     PF_TICK(12);
                     __syncthreads();
                     for (int idx = tid; idx < 4 * R * PF_REPL; idx += PF_THREADS) {
@@ -1332,7 +1342,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                             float t = rp[m];
 #pragma unroll
                             for (int w = 1; w < 8; ++w) t += rp[w * R * FRW + m];
-                            if (fscl) t *= ps2;
+                            t *= ps2;
                             pub(e, rr, r, 4 * b + m, tag0 + e + 1, xr[r * 4 + m] + t);
                         }
                     }
@@ -1369,7 +1379,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                     constexpr int SH = RG == 2 ? 2 : 3;
                     if ((lane & ((1 << SH) - 1)) == 0) red[(par * 8 + wave) * R * FRW + (r0 + ((lane >> SH) >> 3)) * FRW + ((lane >> SH) & 7)] = tot;
                 }
-                const float psh = fscl ? fscl[4 * PRS + (tid & 3)] : 1.f;
+                const float psh = fscl[4 * PRS + (tid & 3)];
                 __syncthreads();
                 for (int idx = tid; idx < 4 * R * PF_REPL; idx += PF_THREADS) {
                     const int m = idx & 3, r = (idx >> 2) % R, rr = idx / (4 * R);
@@ -1378,7 +1388,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                         float t = rp[m], ss = rp[4];
 #pragma unroll
                         for (int w = 1; w < 8; ++w) { t += rp[w * R * FRW + m]; ss += rp[w * R * FRW + 4]; }
-                        if (fscl) t *= psh;
+                        t *= psh;
                         pub(e, rr, r, 4 * b + m, tag0 + e + 1, t * pf_rms_inv(ss, A.eps));
                     }
                 }

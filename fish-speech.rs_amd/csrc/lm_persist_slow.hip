@@ -266,13 +266,14 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
     // Rule for every unseen request below: the compiler counts only the loads it knows, so its wait for a KNOWN load that is still in flight
     // (Wo, the norm vector, the next Wqkv rows, the K/V tile) must be made to land BEFORE the unseen loads are issued -- each such value is
     // pinned (empty asm) right behind the sweep that has already completed it; a wait left behind the unseen loads becomes a wait for them.
-    // bit 0: workgroups without an attention item request W13 behind S1's publish
-    // bit 1: they request W2 (needed by S5, 28 % of the bytes) there as well; the attention workgroups request W2 in S4 as before
-    // bit 2: attention workgroups whose slice is ONE K/V tile: waves 2..7 request W13 behind S1's publish too (the K/V tile through unseen loads with
-    //        an explicit s_waitcnt in S2), waves 0 / 1 -- which sweep q / k / v in S2 -- behind that sweep
+    // bit 0 (default): workgroups without an attention item request W13 behind S1's publish
+    // bit 1: they request W2 (needed by S5, 28 % of the bytes) there as well (measured: 549.5 vs 549.0 us -- no gain, off)
+    // Measured and removed: the attention workgroups whose slice is one K/V tile requesting W13 behind S1's publish as well (waves 2..7; waves
+    // 0 / 1 behind their q / k / v sweep in S2; the K/V tile through unseen loads with an explicit s_waitcnt vmcnt(9) in S2): 576-582 us against
+    // 549, and the greedy tokens stopped being reproducible run to run -- an attention workgroup's S2 is the critical path of the layer, and
+    // anything queued in front of its K/V tile costs more than the burst it removes from S3.
     const int early_mode = A.l2_touch;
     const bool early13 = (early_mode & 1) && !att, early2 = (early_mode & 2) && !att;
-    const bool att_early = (early_mode & 4) && att && n_tiles <= 1;
     auto request_w13 = [&](const unsigned char* wl_) {  // the W13 slice of this layer -> registers, valid after the next sweep
         if constexpr (FP8) {
 #pragma unroll
@@ -336,7 +337,6 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
         {
             tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
             const float2 nw = *reinterpret_cast<const float2*>(A.norms + (size_t)(2 * l) * 1024 + 2 * tid);
-            float2 nw_pin = nw;
             if (l > 0) {
                 u32x4 v;
                 pf_nap_before_sweep(A.naps[0]);
@@ -345,20 +345,9 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
                 ++e;
                 PS_TICK(9);
             }
-            if (att_early) {  // (see early_mode bit 2) the K/V tile through unseen loads: pin what the compiler still has in flight first
-                float nwx = nw.x, nwy = nw.y;
-                asm volatile("" : "+v"(nwx), "+v"(nwy));
-                if constexpr (FP8) asm volatile("" : "+v"(wq4f), "+v"(wq1)); else asm volatile("" : "+v"(wq4), "+v"(wq1));
-                nw_pin = make_float2(nwx, nwy);
-                if (n_tok > 0) {
-                    const unsigned char* kp = reinterpret_cast<const unsigned char*>(A.kv_pool) + (size_t)l * 2 * A.layer_half * 2;
-                    const unsigned char* vp = kp + A.layer_half * 2;
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) { ps_load16_unseen(kreg[u], kp, kv_off0[u] * 2u); ps_load16_unseen(vreg[u], vp, kv_off0[u] * 2u); }
-                }
-            } else if (att && n_tok > 0) load_kv_tile0(l);  // this layer's first K/V tile, under the qkv stage
+            if (att && n_tok > 0) load_kv_tile0(l);  // this layer's first K/V tile, under the qkv stage
             *reinterpret_cast<float2*>(xs + 2 * tid) = make_float2(x0, x1);
-            const float xn0 = x0 * nw_pin.x, xn1 = x1 * nw_pin.y;
+            const float xn0 = x0 * nw.x, xn1 = x1 * nw.y;
             float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             float rsc = 1.f;
             if constexpr (FP8) {
@@ -387,7 +376,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
                     pub(e, k + 4, 5 * b + r, tag0 + e + 1, val);
                 }
             }
-            if (early13 || (att_early && wave >= 2)) request_w13(wl);  // (nothing the compiler knows of is in flight here: the stage's own weights and norm vector have been consumed)
+            if (early13) request_w13(wl);  // (nothing the compiler knows of is in flight here: the stage's own weights and norm vector have been consumed)
             if (early2) request_w2(wl);
             par ^= 1;
             PS_TICK(1);
@@ -423,12 +412,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
                 }
             }
             ++e;
-            if (att_early && wave < 2) request_w13(wl);
             __syncthreads();
-            if (att_early) {  // the tile's four loads are older than this wave's W13 request (8 / 4 loads) and Wo (1 / 1): let those stay in flight
-                if constexpr (FP8) asm volatile("s_waitcnt vmcnt(5)" : "+v"(kreg[0]), "+v"(kreg[1]), "+v"(vreg[0]), "+v"(vreg[1]));
-                else asm volatile("s_waitcnt vmcnt(9)" : "+v"(kreg[0]), "+v"(kreg[1]), "+v"(vreg[0]), "+v"(vreg[1]));
-            }
             PS_TICK(10);
             // Every WAVE keeps its own running {m, l, o} over the tiles (flash-decoding inside the workgroup): the wave maximum is uniform by DPP /
             // readlane, a lane accumulates p * v for its own tokens and 8-dim slice and p for its token (lanes with du == 0), and nothing crosses
@@ -596,10 +580,10 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
             if constexpr (FP8) {
                 asm volatile("" : "+v"(rsc));
                 asm volatile("" : "+v"(wo4f));  // (in flight since S2: the compiler's wait for it lands HERE, where the sweep's vmcnt(0) has already satisfied it, not behind the unseen loads)
-                if (!early13 && !att_early) request_w13(wl);  // next stage's weights (32 KB per CU)
+                if (!early13) request_w13(wl);  // next stage's weights (32 KB per CU)
             } else {
                 asm volatile("" : "+v"(wo4));  // (see the fp8 branch)
-                if (!early13 && !att_early) request_w13(wl);  // next stage's weights (64 KB per CU), behind the sweep (workgroups without an attention item asked for them in S1)
+                if (!early13) request_w13(wl);  // next stage's weights (64 KB per CU), behind the sweep (workgroups without an attention item asked for them in S1)
             }
             // flash-decoding combine of the head's slices, one instantiation per slice count (a runtime bound kept all 16 slots alive: 32
             // predicated v_exp per lane whatever n_sl was)

@@ -190,7 +190,10 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
         const float2 x2 = *reinterpret_cast<const float2*>(A.x + (size_t)r * 1024 + 2 * tid);
         x0[r] = x2.x; x1[r] = x2.y;
     }
+    // row ar's rotary pair of lane j = tid & 31, the same in all layers (see k_slow_persist)
+    float rope_c = A.cos_t[(size_t)rpos * 32 + (tid & 31)], rope_s = A.sin_t[(size_t)rpos * 32 + (tid & 31)];
     __syncthreads();
+    asm volatile("" : "+v"(rope_c), "+v"(rope_s));
 
     const unsigned char* wimg = reinterpret_cast<const unsigned char*>(A.wimg) + (size_t)b * PS_LAYER_IMAGE;
     const size_t layer_img = (size_t)PF_BLOCKS * PS_LAYER_IMAGE;
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_rows(RowsSlowArgs A) {
                 pf_sweep1(eb, unit, tag0 + e + 1, v, dead, A.ctl);
                 const float a0 = __uint_as_float(v.x), a1 = __uint_as_float(v.z);
                 const int j = tid & 31;
-                const float c = A.cos_t[(size_t)rpos * 32 + j], s = A.sin_t[(size_t)rpos * 32 + j];
+                const float c = rope_c, s = rope_s;
                 if (tid < 32) {
                     *reinterpret_cast<float2*>(qs + 2 * j) = make_float2((a0 * c - a1 * s) * 0.125f, (a0 * s + a1 * c) * 0.125f);
                 } else if (tid < 64) {

@@ -234,7 +234,11 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
     const int page_new = A.page_table[pos >> 6];
     float2 x2 = *reinterpret_cast<const float2*>(A.x + 2 * tid);
     float x0 = x2.x, x1 = x2.y;
+    // this token's rotary pair of lane j = tid & 31: the same in all layers.  (Loaded behind S2's sweep in every layer it was a memory round
+    // trip in the attention workgroups' critical chain, 24 times per frame.)
+    float rope_c = A.cos_t[(size_t)rpos * 32 + (tid & 31)], rope_s = A.sin_t[(size_t)rpos * 32 + (tid & 31)];
     __syncthreads();
+    asm volatile("" : "+v"(rope_c), "+v"(rope_s));
 
     constexpr size_t LIMG = FP8 ? PS_LAYER_IMAGE_FP8 : PS_LAYER_IMAGE;
     const unsigned char* wimg = reinterpret_cast<const unsigned char*>(A.wpack) + (size_t)b * LIMG;
@@ -394,7 +398,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
                 pf_sweep1(eb, unit, tag0 + e + 1, v, dead, A.ctl);
                 const float a0 = __uint_as_float(v.x), a1 = __uint_as_float(v.z);
                 const int j = tid & 31;
-                const float c = A.cos_t[(size_t)rpos * 32 + j], s = A.sin_t[(size_t)rpos * 32 + j];
+                const float c = rope_c, s = rope_s;
                 if (tid < 32) {  // rope_i, then the 1/sqrt(64) of the scores folded into q (a power of two: exact)
                     *reinterpret_cast<float2*>(qs + 2 * j) = make_float2((a0 * c - a1 * s) * 0.125f, (a0 * s + a1 * c) * 0.125f);
                 } else if (tid < 64) {

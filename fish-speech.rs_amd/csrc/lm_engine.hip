@@ -804,6 +804,7 @@ class LM final : public LMBase {
         }
         FS_HIP(hipEventRecord(ev_[2], st_));
         const bool done_all = all_done();
+        check_rows_xchg();
         float ms01 = 0, ms12 = 0;
         FS_HIP(hipEventElapsedTime(&ms01, ev_[0], ev_[1]));
         FS_HIP(hipEventElapsedTime(&ms12, ev_[1], ev_[2]));
@@ -1157,6 +1158,7 @@ class LM final : public LMBase {
             // a spin timeout inside the chunk (the joining prefill shares the CUs the persistent launches need co-resident) means the slots'
             // codes are garbage: raise instead of handing them out; the caller ends the session (the handle is off the row path afterwards)
             if (sess_rows_) rows_check_ctl(/*include_b1_fast=*/false);
+            else check_rows_xchg();
         }
         FS_HIP(hipEventRecord(ev_[2], st_));
         FS_HIP(hipEventSynchronize(ev_[2]));
@@ -1770,6 +1772,17 @@ class LM final : public LMBase {
         FS_HIP(hipMemsetAsync(d_pfa_.p, 0, d_pfa_.n, st_));
         FS_HIP(hipMemsetAsync(d_pfc_.p, 0, d_pfc_.n, st_));
     }
+    // the in-launch split-K sums of the folded decode steps give up after ~0.1 s of polling (a tile's blocks were not co-resident): loud failure
+    void check_rows_xchg() {
+        if (!d_epoch_.p) return;
+        uint32_t e[2] = {0, 0};
+        FS_HIP(hipMemcpy(e, d_epoch_.p, sizeof(e), hipMemcpyDeviceToHost));
+        if (e[1] != 0) {
+            const uint32_t z = 0;
+            FS_HIP(hipMemcpy(d_epoch_.as<uint32_t>() + 1, &z, sizeof(z), hipMemcpyHostToDevice));
+            throw Error("static-batch decode: " + std::to_string(e[1]) + " split-K exchange waits timed out (FISHRT_ROWS_NO_FOLD=1 selects the slab path)");
+        }
+    }
     void ensure_batch_buffers() {
         if (d_xfrows_.p) return;
         ld_slow_ = ((n_audio_ + 63) / 64) * 64;
@@ -1783,6 +1796,12 @@ class LM final : public LMBase {
         std::vector<int> tb(B_);
         for (int i = 0; i < B_; ++i) tb[i] = i;
         d_rwords_.alloc(sizeof(uint32_t) * 16 * kRows);
+        // folded decode steps (k_gemm_down): exchange units of the in-launch split-K sums + {step epoch, timeouts}
+        d_xchg_.alloc(rows_xchg_bytes(a_.dim));
+        FS_HIP(hipMemset(d_xchg_.p, 0, d_xchg_.n));
+        d_epoch_.alloc(sizeof(uint32_t) * 2);
+        const uint32_t e0[2] = {1u, 0u};
+        FS_HIP(hipMemcpy(d_epoch_.p, e0, sizeof(e0), hipMemcpyHostToDevice));
         d_fast_table_.alloc(sizeof(int) * B_);
         FS_HIP(hipMemcpy(d_fast_table_.p, tb.data(), sizeof(int) * B_, hipMemcpyHostToDevice));
     }
@@ -1792,16 +1811,23 @@ class LM final : public LMBase {
         // lock-step static batch: every row at state(0)->pos (left-padded prompts); session: row m is its own sequence at state(m)->pos
         RowsCtx cs = rows_ctx(state(0), /*pos_step=*/sess_active_ ? -1 : 0, /*pt_stride=*/max_pages_);
         cs.nc_launch = nc_launch_;
-        for (int l = 0; l < a_.n_layer; ++l) LmKernels<WT>::rows_layer(d_, B, cs, slow_[l], slow_kv(l, 0), l == 0, st_);
-        LmKernels<WT>::rows_finish(d_, B, cs, norm_w_, st_);
-        LmKernels<WT>::rows_head(d_, B, cs, slow_head_w(), slow_head_s(), n_audio_, d_lrows_.as<float>(), ld_slow_, st_);
+        // decode steps of <= 32 rows: the down projections close every layer themselves (in-launch split-K sums: no slabs, no k_prep nodes but the first)
+        cs.xchg = d_xchg_.p; cs.epoch = d_epoch_.as<uint32_t>();
+        const bool fold = LmKernels<WT>::rows_fold_ok(d_, B, cs) && a_.n_layer <= 64 && a_.n_fast_layer <= 8 && C <= 32;
+        cs.fold = fold;
+        for (int l = 0; l < a_.n_layer; ++l, cs.node_id = (uint32_t)l)
+            LmKernels<WT>::rows_layer(d_, B, cs, slow_[l], slow_kv(l, 0), l == 0, st_, fold ? (l + 1 < a_.n_layer ? slow_[l + 1].attn_norm : norm_w_) : nullptr);
+        if (!fold) LmKernels<WT>::rows_finish(d_, B, cs, norm_w_, st_);
+        LmKernels<WT>::rows_head(d_, B, cs, slow_head_w(), slow_head_s(), n_audio_, d_lrows_.as<float>(), ld_slow_, st_, fold);
         // block-parallel samplers (temp > 1e-7, top_k <= 256): the step's C + 1 StdRng words per row are derived up front
         const uint32_t* words = rows_par_ ? d_rwords_.as<uint32_t>() : nullptr;
         if (rows_par_) SampleKernels<WT>::rows_rng_words(d_rng_.as<RngState>(), B, C + 1, state(0), d_rwords_.as<uint32_t>(), st_);
         const bool capt = cap_frames_ > 0 && d_rcap_.p && d_rcap_.n >= sizeof(float) * (size_t)B * cap_frames_ * 9 * 2048;  // (fs_lm_debug_capture)
         if (capt) launch_cap_rows_logits(d_lrows_.as<float>(), ld_slow_, n_audio_, state(0), d_cfg_.as<SampleCfg>(), B, d_rcap_.as<float>(), cap_frames_, 0, st_);
+        // folded steps: the sampler that writes a fast-decoder input row also leaves its first layer's normalised GEMM input (no k_prep node)
+        const float* prep_g = fold && a_.dim <= 1024 ? fast_[0].attn_norm : nullptr;
         SampleKernels<WT>::sample_slow_rows(d_, d_lrows_.as<float>(), ld_slow_, n_audio_, d_cfg_.as<SampleCfg>(), d_rng_.as<RngState>(), B,
-                                            C + 1, state(0), cs.X, d_xfrows_.as<float>(), st_, words);
+                                            C + 1, state(0), cs.X, d_xfrows_.as<float>(), st_, words, prep_g, cs.A, fold ? d_epoch_.as<uint32_t>() : nullptr);
         for (int cbi = 0; cbi < C; ++cbi) {
             RowsCtx cf = cs;
             cf.X = d_xfrows_.as<float>();
@@ -1810,19 +1836,22 @@ class LM final : public LMBase {
             cf.pt_stride = 1;
             cf.nc_launch = 1;
             cf.small_attn = a_.num_codebooks <= 8;
+            cf.first_prepped = prep_g != nullptr;
+            cf.identity_pages = true;  // d_fast_table_[i] == i
             for (int l = 0; l < a_.n_fast_layer; ++l) {
                 KVView kv;
                 KT* base = fast_pool_.as<KT>() + ((size_t)l * 2 * B_) * page_elems_;
                 kv.k = base; kv.v = base + (size_t)B_ * page_elems_; kv.page_table = d_fast_table_.as<int>();
-                LmKernels<WT>::rows_layer(d_, B, cf, fast_[l], kv, l == 0, st_);
+                cf.node_id = 64u + (uint32_t)cbi * 8u + (uint32_t)l;
+                LmKernels<WT>::rows_layer(d_, B, cf, fast_[l], kv, l == 0, st_, fold ? (l + 1 < a_.n_fast_layer ? fast_[l + 1].attn_norm : fast_norm_w_) : nullptr);
             }
-            LmKernels<WT>::rows_finish(d_, B, cf, fast_norm_w_, st_);
-            LmKernels<WT>::rows_head(d_, B, cf, fast_out_w_, kFp8 ? fast_out_s_ : nullptr, a_.codebook_size, d_lfast_.as<float>(), a_.codebook_size, st_);
+            if (!fold) LmKernels<WT>::rows_finish(d_, B, cf, fast_norm_w_, st_);
+            LmKernels<WT>::rows_head(d_, B, cf, fast_out_w_, kFp8 ? fast_out_s_ : nullptr, a_.codebook_size, d_lfast_.as<float>(), a_.codebook_size, st_, fold);
             if (capt) launch_cap_rows_logits(d_lfast_.as<float>(), a_.codebook_size, a_.codebook_size, state(0), d_cfg_.as<SampleCfg>(), B, d_rcap_.as<float>(),
                                              cap_frames_, 1 + cbi, st_);
             SampleKernels<WT>::sample_fast_rows(d_, d_lfast_.as<float>(), cbi, C, a_.codebook_size, d_cfg_.as<SampleCfg>(),
                                                 d_rng_.as<RngState>(), B, state(0), fast_emb_, d_xfrows_.as<float>(), tok_emb_, cb_emb_,
-                                                cs.X, d_out_.as<uint32_t>(), out_cap_, st_, words);
+                                                cs.X, d_out_.as<uint32_t>(), out_cap_, st_, words, prep_g, cs.A);
         }
         if (capt) launch_cap_rows_picks(state(0), d_cfg_.as<SampleCfg>(), B, d_rcap_.as<float>(), cap_frames_, C, st_);
     }
@@ -2207,6 +2236,7 @@ class LM final : public LMBase {
     DevBuf d_pfx_, d_pfq_, d_pfslab_, d_pfa_, d_pfa2_, d_pfss_, d_pfc_, d_pfpart_;  // MFMA row-path activations (kRowsCap rows)
     DevBuf d_bprompt_;  // static batch: all left-padded prompts [B][C + 1][Lmax] (group prefill)
     DevBuf d_xfrows_, d_lrows_, d_lfast_, d_fast_state_, d_fast_table_, d_rwords_;  // static-batch generator
+    DevBuf d_xchg_, d_epoch_;  // folded decode steps: split-K exchange units, {step epoch, timeouts}
     bool rows_par_ = false;  // this batch / session samples with the block-parallel row samplers
     int ld_slow_ = 0, down_split_ = 4;
     bool batch_warm_ = false;

@@ -68,6 +68,7 @@ struct ModelDims {
 };
 
 struct SampleCfg;
+size_t rows_xchg_bytes(int dim);
 
 // Buffers + row mapping of the MFMA row path (prefill / batched decode).  All activation buffers hold Mcap rows (a multiple
 // of 32: the GEMMs read whole 32-row panels, so rows >= M must exist and hold finite values).
@@ -93,6 +94,12 @@ struct RowsCtx {
     bool no_flash = false;       // micro-benchmark / test hook: keep the chunked row attention for prefill passes
     bool chunked_attn = false;   // micro-benchmark / test hook: keep k_attn_decode + k_attn_combine for rows-are-sequences passes
     bool small_attn = false;     // every row attends over <= 8 tokens of ONE page (fast decoder): fused attention node
+    void* xchg = nullptr;        // fold: exchange units of the layer-closing down projection (rows_xchg_bytes(dim), zero-initialised, used by nothing else)
+    uint32_t* epoch = nullptr;   // fold: [0] = step epoch (>= 1; bumped once per step by the slow-token sampler node), [1] = exchange timeouts
+    uint32_t node_id = 0;        // fold: unique per rows_layer call of a step (< 4096)
+    bool identity_pages = false; // small_attn: page_table[m * pt_stride] == m for every row (the batched fast decoder's one-page-per-row table)
+    bool first_prepped = false;  // fold: the first layer's normalised input fragments are already in A (written by the sampler that produced the row)
+    bool fold = false;           // decode step with the un-split down projection (see rows_layer's next_norm)
     unsigned stage_mask = 0xFFu;  // micro-benchmark hook: bit i enables stage i of rows_layer (prep, qkv, attn, combine, wo, prep, w13, w2)
 };
 
@@ -133,11 +140,16 @@ struct LmKernels {
     // one transformer block over M <= Mcap activation rows (X updated in place up to the down-projection, whose split-K
     // slabs are folded in by the NEXT rows_layer / rows_finish):
     //   x += slabs | rmsnorm+Wqkv+rope+KV append | attention over the paged cache | Wo + residual | rmsnorm+W13+SwiGLU | W2 slabs
-    static void rows_layer(const ModelDims& d, int M, const RowsCtx& c, const LayerW& w, KVView kv, bool first, hipStream_t st);
+    // c.fold (decode steps of <= 32 rows, rows_fold_ok): next_norm = the norm weight of whoever consumes this layer's output (the next
+    // layer's attention_norm, or the final norm in front of the head) -- the down projection runs un-split and closes the layer itself
+    // (no slabs, no k_prep node; rows_finish is then not called and rows_head takes rms = true)
+    static void rows_layer(const ModelDims& d, int M, const RowsCtx& c, const LayerW& w, KVView kv, bool first, hipStream_t st,
+                           const float* next_norm = nullptr);
+    static bool rows_fold_ok(const ModelDims& d, int M, const RowsCtx& c);
     static void rows_finish(const ModelDims& d, int M, const RowsCtx& c, const float* norm_w, hipStream_t st);
     static void rows_warmup();
     static void rows_head(const ModelDims& d, int M, const RowsCtx& c, const void* W, const float* wscale, int n_rows, float* logits, int ld,
-                          hipStream_t st);
+                          hipStream_t st, bool rms = false);
     // fast_embeddings gather: out[i] = fast_emb[ids[i]]
     static void fast_embed(const ModelDims& d, const void* fast_emb, const uint32_t* ids, int n, float* out,
                            hipStream_t st);
@@ -199,10 +211,14 @@ struct SampleKernels {
     // words != null: the block-parallel sampler (512 threads per row) with this step's pre-derived StdRng words (rows_rng_words);
     // requires temp > 1e-7, 0 < top_k <= 256 < candidates (rows_par_sampler_ok)
     static void sample_slow_rows(const ModelDims& d, const float* logits, int ld, int n, const SampleCfg* c, const RngState* master, int B,
-                                 int calls_per_frame, SeqState* states, const float* X, float* XF, hipStream_t st, const uint32_t* words = nullptr);
+                                 int calls_per_frame, SeqState* states, const float* X, float* XF, hipStream_t st, const uint32_t* words = nullptr,
+                                 const float* prep_g = nullptr, uint16_t* prep_A = nullptr, uint32_t* epoch = nullptr);
+    // prep_g != null (both samplers): the block also leaves RMSNorm(XF row; prep_g) as fragment-major hi/lo GEMM input in prep_A -- what the
+    // k_prep node in front of the fast decoder's first layer would produce (RowsCtx::first_prepped)
     static void sample_fast_rows(const ModelDims& d, const float* logits, int cb, int n_cb, int cb_size, const SampleCfg* c,
                                  const RngState* master, int B, SeqState* states, const void* fast_emb, float* XF, const void* tok_emb,
-                                 const void* cb_emb, float* X, uint32_t* out_codes, int out_cap, hipStream_t st, const uint32_t* words = nullptr);
+                                 const void* cb_emb, float* X, uint32_t* out_codes, int out_cap, hipStream_t st, const uint32_t* words = nullptr,
+                                 const float* prep_g = nullptr, uint16_t* prep_A = nullptr);
     // words[b * 16 + call] = the StdRng word of sample() call `call` of this step for row b (child stream of master u64 number (frame * calls + call) * B + b)
     static void rows_rng_words(const RngState* master, int B, int calls_per_frame, const SeqState* states, uint32_t* words, hipStream_t st);
 };

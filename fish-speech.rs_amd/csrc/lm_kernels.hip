@@ -787,7 +787,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 constexpr int PF_M = 32;    // activation rows per pass
 
-enum { EPI_STORE = 0, EPI_RESIDUAL = 1, EPI_SWIGLU = 2, EPI_QKV = 3, EPI_RESIDUAL_NORM = 4, EPI_SWIGLU_RMS = 5 };
+enum { EPI_STORE = 0, EPI_RESIDUAL = 1, EPI_SWIGLU = 2, EPI_QKV = 3, EPI_RESIDUAL_NORM = 4, EPI_SWIGLU_RMS = 5, EPI_QKV_RMS = 6, EPI_STORE_RMS = 7 };
+// epilogues that divide the K-summed accumulators by the row's rms (the producer left split(x * g) and sum-of-squares partials: NormAux)
+__host__ __device__ constexpr bool epi_rms(int e) { return e == EPI_SWIGLU_RMS || e == EPI_QKV_RMS || e == EPI_STORE_RMS; }
 // RMSNorm folded into the GEMMs around it (saves the k_prep node between Wo and W13): the Wo GEMM's epilogue writes the new
 // residual stream, the UN-normalised GEMM input split(x * g) and one sum-of-squares partial per (block, row); the W13 GEMM's
 // epilogue divides its accumulators by rms[m] = sqrt(sum_b partial[m][b] / D + eps) (a per-row scalar commutes with the GEMM).
@@ -870,6 +872,34 @@ __global__ __launch_bounds__(256) void k_prep(float* __restrict__ X, int D, cons
     }
 }
 
+// k_prep's RMSNorm + hi/lo split of ONE row by the block that has just written it (the batched samplers: the row is the fast decoder's
+// next input, so its first layer needs no k_prep node in a folded decode step).  Threads 0..255 take one float4 each (D <= 1024) and the sums
+// meet in k_prep's order: the fragments are bit-identical to what the node would have produced.
+struct PrepOut { const float* g; float eps; bf16_t* A; uint32_t* epoch; };   // g == nullptr: disabled; epoch != nullptr (slow-token sampler): the step epoch of k_gemm_down's tags is bumped here, once per step
+__device__ __forceinline__ void block_prep_row(const float* __restrict__ xm, int D, const PrepOut& po, int m, float* red4) {
+    __syncthreads();  // the row's stores by the other threads of this block
+    const int e = threadIdx.x * 4;
+    const bool act = threadIdx.x < 256 && e < D;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f), w = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (act) { v = *reinterpret_cast<const float4*>(xm + e); w = *reinterpret_cast<const float4*>(po.g + e); }
+    float ss = 0.f;
+    ss = fmaf(v.x, v.x, ss); ss = fmaf(v.y, v.y, ss); ss = fmaf(v.z, v.z, ss); ss = fmaf(v.w, v.w, ss);
+    ss = wave_sum(ss);
+    if (threadIdx.x < 256 && (threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (!act) return;
+    const float d = sqrtf(((red4[0] + red4[1]) + (red4[2] + red4[3])) / (float)D + po.eps);
+    float a[4] = {(v.x / d) * w.x, (v.y / d) * w.y, (v.z / d) * w.z, (v.w / d) * w.w};
+    bf16_t hi[4], lo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split_bf16(a[i], hi[i], lo[i]);
+    uint2 ph, pl;
+    ph.x = hi[0] | ((uint32_t)hi[1] << 16); ph.y = hi[2] | ((uint32_t)hi[3] << 16);
+    pl.x = lo[0] | ((uint32_t)lo[1] << 16); pl.y = lo[2] | ((uint32_t)lo[3] << 16);
+    *reinterpret_cast<uint2*>(po.A + frag_off(m, e, 0, D)) = ph;
+    *reinterpret_cast<uint2*>(po.A + frag_off(m, e, 1, D)) = pl;
+}
+
 // Epilogue of the row-path GEMMs for one (row pair r/r+1, activation row m): a, b are the K-summed (and fp8-scaled) dot products.
 // Thread mapping contract: the ROWS / 2 threads of one m are adjacent lanes (RESIDUAL_NORM's sum of squares meets by shuffles).
 struct GemmEpi {
@@ -879,28 +909,34 @@ struct GemmEpi {
     int pos0, rope_off, N;
     const SeqState* states = nullptr;  // pos_step < 0: row m reads its own position (session slots)
 };
+// values the epilogue needs from memory that do not depend on the GEMM: requested at kernel entry by k_gemm3 (one slot per thread, first
+// panel) so that they arrive under the weight stream instead of starting a dependent L2 round trip behind the K loop
+struct EpiPre { float2 o; float2 g; float cs, sn; };
 template <int EPI, int ROWS>
-__device__ __forceinline__ void gemm_epilogue(float a, float b, int r, int m, int ml, int pr, const GemmEpi& g, const float* s_rms) {
+__device__ __forceinline__ void gemm_epilogue(float a, float b, int r, int m, int ml, int pr, const GemmEpi& g, const float* s_rms,
+                                              const EpiPre* pre = nullptr) {
     float* const Y = g.Y; const int ldy = g.ldy, ldo = g.ldo, N = g.N, H = g.H, Hk = g.Hk, Dh = g.Dh, pos0 = g.pos0, rope_off = g.rope_off;
     const size_t slab_stride = g.slab_stride;
     bf16_t* const Of = g.Of;
     const float *cos_t = g.cos_t, *sin_t = g.sin_t;
     const KVView& kv = g.kv; const RowMap& rm = g.rm; const NormAux& na = g.na;
-    if (EPI == EPI_STORE) {  // split-K slab blockIdx.y
+    if (EPI == EPI_QKV_RMS || EPI == EPI_STORE_RMS) { const float dn = s_rms[ml]; a /= dn; b /= dn; }  // (a per-row scalar commutes with the GEMM)
+    if (EPI == EPI_STORE || EPI == EPI_STORE_RMS) {  // split-K slab blockIdx.y
         float* yp = Y + (size_t)blockIdx.y * slab_stride + (size_t)m * ldy + r;
         yp[0] = a;
         if (r + 1 < N) yp[1] = b;
     } else if (EPI == EPI_RESIDUAL) {
         float2* yp = reinterpret_cast<float2*>(Y + (size_t)m * ldy + r);
-        const float2 o = *yp;
+        const float2 o = pre ? pre->o : *yp;
         *yp = make_float2(o.x + a, o.y + b);
     } else if (EPI == EPI_RESIDUAL_NORM) {  // the ROWS/2 threads of one m are adjacent lanes (8, 16 or 32 of them)
         float2* yp = reinterpret_cast<float2*>(Y + (size_t)m * ldy + r);
-        const float2 o = *yp;
+        const float2 o = pre ? pre->o : *yp;
         const float v0 = o.x + a, v1 = o.y + b;
         *yp = make_float2(v0, v1);
         bf16_t h0, l0, h1, l1;
-        split_bf16(v0 * na.g[r], h0, l0); split_bf16(v1 * na.g[r + 1], h1, l1);
+        const float2 gw = pre ? pre->g : make_float2(na.g[r], na.g[r + 1]);
+        split_bf16(v0 * gw.x, h0, l0); split_bf16(v1 * gw.y, h1, l1);
         *reinterpret_cast<uint32_t*>(na.A2 + frag_off(m, r, 0, na.D)) = h0 | ((uint32_t)h1 << 16);
         *reinterpret_cast<uint32_t*>(na.A2 + frag_off(m, r, 1, na.D)) = l0 | ((uint32_t)l1 << 16);
         float ssq = group_sum<(ROWS / 2 >= 16 ? 16 : ROWS / 2)>(fmaf(v0, v0, v1 * v1));
@@ -928,7 +964,7 @@ __device__ __forceinline__ void gemm_epilogue(float a, float b, int r, int m, in
         const int qdim = H * Dh, kdim = Hk * Dh, half = Dh / 2;
         if (r < qdim + kdim) {
             const int j = (r % Dh) / 2;
-            const float cs = cos_t[(size_t)rpos * half + j], sn = sin_t[(size_t)rpos * half + j];
+            const float cs = pre ? pre->cs : cos_t[(size_t)rpos * half + j], sn = pre ? pre->sn : sin_t[(size_t)rpos * half + j];
             const float o0 = a * cs - b * sn, o1 = a * sn + b * cs;
             if (r < qdim) { *reinterpret_cast<float2*>(Y + (size_t)m * ldy + r) = make_float2(o0, o1); }
             else {
@@ -981,7 +1017,7 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* __restrict__ Xf, in
     const int n0 = blockIdx.x * ROWS;
     const int kbeg = ((int)blockIdx.y * 4 + kq) * NKS * 32 + (lane >> 4) * 8;  // this lane's first k of every 32-wide step (weights)
     int pos0 = 0, rope_off = 0;
-    if (EPI == EPI_QKV) { pos0 = state->pos; rope_off = state->rope_off; }  // requested up front: the epilogue must not start a dependent chain
+    if (EPI == EPI_QKV || EPI == EPI_QKV_RMS) { pos0 = state->pos; rope_off = state->rope_off; }  // requested up front: the epilogue must not start a dependent chain
     const GemmEpi ge{Y, ldy, slab_stride, Of, ldo, cos_t, sin_t, kv, H, Hk, Dh, rm, na, pos0, rope_off, N, state};
     u32x4 wf[RT][NKS];
 #pragma unroll
@@ -1000,11 +1036,21 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* __restrict__ Xf, in
             for (int ks = 0; ks < NKS; ++ks) wf[rt][ks] = ld_stream(reinterpret_cast<const u32x4*>(wp + ks * 32));
         }
     }
+    // one epilogue slot per thread (RT == 1): what that slot reads from memory is requested now, behind the weight stream (first panel)
+    constexpr bool PRE_RES = RT == 1 && (EPI == EPI_RESIDUAL || EPI == EPI_RESIDUAL_NORM), PRE_QKV = RT == 1 && (EPI == EPI_QKV || EPI == EPI_QKV_RMS);
+    EpiPre pre{make_float2(0.f, 0.f), make_float2(1.f, 1.f), 1.f, 0.f};
+    const int pre_r = n0 + 2 * ((int)threadIdx.x % (ROWS / 2)), pre_m = (int)blockIdx.z * PF_M + (int)threadIdx.x / (ROWS / 2);
+    bool use_pre = PRE_RES;
+    if (PRE_RES && pre_r < N && pre_m < M) {
+        pre.o = *reinterpret_cast<const float2*>(Y + (size_t)pre_m * ldy + pre_r);
+        if (EPI == EPI_RESIDUAL_NORM) pre.g = *reinterpret_cast<const float2*>(na.g + pre_r);
+    }
+    if (PRE_QKV) use_pre = rm.pos_step == 0 && rm.seq_rows == 0;  // lock-step decode rows: every row at state->pos (block-uniform)
     // row panels are spread over blockIdx.z (prefill: many panels -> more blocks; the weight tile is then re-read from L2)
     bool first_panel = true;
     for (int mp = (int)blockIdx.z * PF_M; mp < M; mp += (int)gridDim.z * PF_M) {
         float ss8 = 0.f;
-        if (EPI == EPI_SWIGLU_RMS) {  // this panel's 32 row norms: thread (m = tid/8, j = tid%8) sums every 8th block's partial, then 8 lanes meet
+        if (epi_rms(EPI)) {  // this panel's 32 row norms: thread (m = tid/8, j = tid%8) sums every 8th block's partial, then 8 lanes meet
             const float* sp = na.ss + (size_t)(mp + (threadIdx.x >> 3)) * na.nblk + (threadIdx.x & 7);
             for (int q8 = 0; q8 < na.nblk; q8 += 8) ss8 += sp[q8];
         }
@@ -1019,6 +1065,10 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* __restrict__ Xf, in
                 xf[ks][2] = *reinterpret_cast<const u32x4*>(xp + ks * 2048 + 512);    // hi, rows 16..31
                 xf[ks][3] = *reinterpret_cast<const u32x4*>(xp + ks * 2048 + 1536);   // lo, rows 16..31
             }
+        }
+        if (PRE_QKV && first_panel && use_pre && pre_r < (H + Hk) * Dh) {  // (waits for the scalar position load; the operand loads are already out)
+            const int j = (pre_r % Dh) / 2;
+            pre.cs = cos_t[(size_t)(pos0 + rope_off) * (Dh / 2) + j]; pre.sn = sin_t[(size_t)(pos0 + rope_off) * (Dh / 2) + j];
         }
         FS_ISSUE_FENCE();  // every operand load of the panel is in flight before the first MFMA waits (the scheduler would
                            // otherwise meter them out a dozen at a time, one memory round trip per batch)
@@ -1036,7 +1086,7 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* __restrict__ Xf, in
             }
         if (!first_panel) __syncthreads();  // the previous panel's epilogue has read `red` (and s_rms)
         first_panel = false;
-        if (EPI == EPI_SWIGLU_RMS) {
+        if (epi_rms(EPI)) {
             const float tot = group_sum<8>(ss8);
             if ((threadIdx.x & 7) == 0) s_rms[threadIdx.x >> 3] = sqrtf(tot / (float)na.D + na.eps);
         }
@@ -1060,9 +1110,120 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* __restrict__ Xf, in
             float b = (red[0][2 * pr + 1][ml] + red[1][2 * pr + 1][ml]) + (red[2][2 * pr + 1][ml] + red[3][2 * pr + 1][ml]);
             if (r >= N || m >= M) continue;
             if (FP8) { a *= wscale[r]; b *= wscale[min(r + 1, N - 1)]; }
-            gemm_epilogue<EPI, ROWS>(a, b, r, m, ml, pr, ge, s_rms);
+            gemm_epilogue<EPI, ROWS>(a, b, r, m, ml, pr, ge, s_rms, (PRE_RES || PRE_QKV) && use_pre && mp == (int)blockIdx.z * PF_M ? &pre : nullptr);
         }
     }
+}
+
+// ---- down projection of a decode step (M <= 32 rows) that closes the layer itself: split-K over gridDim.y blocks per 16-row weight tile
+// as before (every CU streams a 32 KB weight tile: the K depth of 4096 needs all of them), but the K partials meet INSIDE the launch
+// instead of in slabs + a k_prep node: thread (row pair pr, activation row ml) of block y publishes its two partial sums as one 16-byte
+// unit {a, tag, b, tag} (relaxed agent-scope write-through store, each 8-byte half self-validating -- the edge protocol of the persistent
+// decode kernels, lm_persist_dev.h) unless block y owns row ml; wave y of block y owns rows [y * 32 / ksplit, (y + 1) * 32 / ksplit):
+// it sweeps the other blocks' units of its slots (sc1 loads, retried until both tags match), adds the partials in block order and runs the
+// epilogue -- x += sum (residual stream), split(x * g_next) in fragment-major order for the next GEMM and one sum-of-squares partial per
+// (tile, row); the next GEMM divides its accumulators by the row's rms (EPI_QKV_RMS / EPI_STORE_RMS).  One of six graph nodes per layer
+// (~5 us each at 32 rows whatever they do) becomes a ~1 us in-launch hand-off among the <= 4 blocks of a tile, which share an XCD
+// (linear block id = tile + gridDim.x * y, gridDim.x % 8 == 0).  tag = step epoch * 4096 + node id: a unit is rewritten by every node
+// that uses the buffer, so a stale unit always carries the tag of the previous node or step.
+// Measured and rejected first (round 5): the same layer-closing epilogue on an UN-split block (16 weight rows x 16 activation rows x the
+// whole depth, 128 blocks): 9.0 us per node against 5.0 + 5.1 for the split GEMM + k_prep -- 384 KB of operands through ONE CU's vector
+// memory path at one wave per SIMD is ~55 GB/s per CU.
+constexpr unsigned DOWN_SPIN_MAX = 1u << 17;
+template <int NKS, bool FP8>
+__global__ __launch_bounds__(256) void k_gemm_down(const bf16_t* __restrict__ Xf, int M, int K, const void* __restrict__ Wv,
+                                                   const float* __restrict__ wscale, int N, float* __restrict__ Y, int ldy, NormAux na,
+                                                   u32x4* __restrict__ xchg, uint32_t* __restrict__ epoch, uint32_t node_id) {
+    __shared__ float red[4][16][33];
+    const int lane = threadIdx.x & 63, kq = threadIdx.x >> 6;
+    const int n0 = blockIdx.x * 16, y = blockIdx.y, ksplit = gridDim.y, rows_per = PF_M / ksplit;
+    const unsigned tag = epoch[0] * 4096u + node_id;
+    const int pr = threadIdx.x & 7, ml = threadIdx.x >> 3;   // epilogue slot: rows (r, r + 1) of activation row ml
+    const int r = n0 + 2 * pr;
+    const bool owner = ml / rows_per == y;                  // == (kq == y) for ksplit == 4; wave-uniform for every ksplit
+    float2 xo = make_float2(0.f, 0.f), gw = make_float2(1.f, 1.f), sc = make_float2(1.f, 1.f);
+    const int kbeg = (y * 4 + kq) * NKS * 32 + (lane >> 4) * 8;
+    u32x4 wf[NKS];
+    {
+        const size_t woff = (size_t)(n0 + (lane & 15)) * K + kbeg;
+        if (FP8) {
+            const uint8_t* wp = reinterpret_cast<const uint8_t*>(Wv) + woff;
+            u32x2 raw[NKS];
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) raw[ks] = ld_stream(reinterpret_cast<const u32x2*>(wp + ks * 32));
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) wf[ks] = fp8x8_to_bf16x8(raw[ks]);
+        } else {
+            const bf16_t* wp = reinterpret_cast<const bf16_t*>(Wv) + woff;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) wf[ks] = ld_stream(reinterpret_cast<const u32x4*>(wp + ks * 32));
+        }
+    }
+    const bf16_t* xp = Xf + (size_t)((y * 4 + kq) * NKS) * 2048 + lane * 8;
+    u32x4 xf[NKS][4];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        xf[ks][0] = *reinterpret_cast<const u32x4*>(xp + ks * 2048);          // hi, rows 0..15
+        xf[ks][1] = *reinterpret_cast<const u32x4*>(xp + ks * 2048 + 1024);   // lo, rows 0..15
+        xf[ks][2] = *reinterpret_cast<const u32x4*>(xp + ks * 2048 + 512);    // hi, rows 16..31
+        xf[ks][3] = *reinterpret_cast<const u32x4*>(xp + ks * 2048 + 1536);   // lo, rows 16..31
+    }
+    if (owner) {  // what the epilogue reads from memory does not depend on the GEMM: requested behind the operands
+        if (ml < M) xo = *reinterpret_cast<const float2*>(Y + (size_t)ml * ldy + r);
+        gw = *reinterpret_cast<const float2*>(na.g + r);
+    }
+    if (FP8) sc = *reinterpret_cast<const float2*>(wscale + r);
+    FS_ISSUE_FENCE();
+    f32x4v acc[2] = {f32x4v{0.f, 0.f, 0.f, 0.f}, f32x4v{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const bf16x8 af = __builtin_bit_cast(bf16x8, wf[ks]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j >> 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, xf[ks][j]), acc[j >> 1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {  // lane holds C[row = (lane>>4)*4 + i][m = mt*16 + (lane&15)]
+        const f32x4v c = acc[mt];
+        float* rp = &red[kq][(lane >> 4) * 4][mt * 16 + (lane & 15)];
+        rp[0] = c.x; rp[33] = c.y; rp[66] = c.z; rp[99] = c.w;
+    }
+    __syncthreads();
+    float a = (red[0][2 * pr][ml] + red[1][2 * pr][ml]) + (red[2][2 * pr][ml] + red[3][2 * pr][ml]);
+    float b = (red[0][2 * pr + 1][ml] + red[1][2 * pr + 1][ml]) + (red[2][2 * pr + 1][ml] + red[3][2 * pr + 1][ml]);
+    if (FP8) { a *= sc.x; b *= sc.y; }
+    // unit of (tile, source block, row, pair)
+    u32x4* const units = xchg + ((size_t)blockIdx.x * ksplit * PF_M + ml) * 8 + pr;
+    if (!owner) {
+        const u32x4 u = {__float_as_uint(a), tag, __float_as_uint(b), tag};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(units + (size_t)y * PF_M * 8), "v"(u) : "memory");
+        return;
+    }
+    float s0 = 0.f, s1 = 0.f;
+    bool dead = false;
+    for (int ys = 0; ys < ksplit; ++ys) {  // partials in block order (the own one from registers)
+        float pa = a, pb = b;
+        if (ys != y) {
+            const u32x4* p = units + (size_t)ys * PF_M * 8;
+            u32x4 v;
+            for (unsigned spins = 0;; ++spins) {
+                asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+                if ((v.y == tag && v.w == tag) || dead) break;
+                if (spins > DOWN_SPIN_MAX) { dead = true; atomicAdd(epoch + 1, 1u); break; }  // (reported: rows_xchg_timeouts)
+            }
+            pa = __uint_as_float(v.x); pb = __uint_as_float(v.z);
+        }
+        s0 += pa; s1 += pb;
+    }
+    const float v0 = xo.x + s0, v1 = xo.y + s1;
+    const bool live = ml < M;
+    const float ssq = group_sum<8>(live ? fmaf(v0, v0, v1 * v1) : 0.f);
+    if (!live) return;
+    *reinterpret_cast<float2*>(Y + (size_t)ml * ldy + r) = make_float2(v0, v1);
+    bf16_t h0, l0, h1, l1;
+    split_bf16(v0 * gw.x, h0, l0); split_bf16(v1 * gw.y, h1, l1);
+    *reinterpret_cast<uint32_t*>(na.A2 + frag_off(ml, r, 0, na.D)) = h0 | ((uint32_t)h1 << 16);
+    *reinterpret_cast<uint32_t*>(na.A2 + frag_off(ml, r, 1, na.D)) = l0 | ((uint32_t)l1 << 16);
+    if (pr == 0) na.ss[(size_t)ml * na.nblk + blockIdx.x] = ssq;
 }
 
 // ---- large-M variant (M >= GB_MIN_M rows: prefill passes, group prefill, big static batches) ---------------------------------
@@ -1099,7 +1260,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_big(const bf16_t* __restrict__ 
     int mp = (int)blockIdx.z * PF_M;
     if (mp >= M) return;
     int pos0 = 0, rope_off = 0;
-    if (EPI == EPI_QKV) { pos0 = state->pos; rope_off = state->rope_off; }
+    if (EPI == EPI_QKV || EPI == EPI_QKV_RMS) { pos0 = state->pos; rope_off = state->rope_off; }
     const GemmEpi ge{Y, ldy, slab_stride, Of, ldo, cos_t, sin_t, kv, H, Hk, Dh, rm, na, pos0, rope_off, N, state};
     const int ksw = (int)blockIdx.y * 32 + kh * NKS;  // this wave's first 32-deep k-step
     u32x4 wf[2][NKS];
@@ -1139,7 +1300,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_big(const bf16_t* __restrict__ 
     for (; mp < M; mp += mstep) {
         const int mp_next = mp + mstep;
         float ss8 = 0.f;
-        if (EPI == EPI_SWIGLU_RMS) {
+        if (epi_rms(EPI)) {
             const float* sp = na.ss + (size_t)(mp + (tid >> 3)) * na.nblk + (tid & 7);
             for (int q8 = 0; q8 < na.nblk; q8 += 8) ss8 += sp[q8];
         }
@@ -1177,7 +1338,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_big(const bf16_t* __restrict__ 
                         float* rp = &red[kh][rg * 32 + t * 16 + (lane >> 4) * 4][mt * 16 + (lane & 15)];
                         rp[0] = cc.x; rp[33] = cc.y; rp[66] = cc.z; rp[99] = cc.w;
                     }
-                if (EPI == EPI_SWIGLU_RMS) {
+                if (epi_rms(EPI)) {
                     const float tot = group_sum<8>(ss8);
                     if ((tid & 7) == 0) s_rms[tid >> 3] = sqrtf(tot / (float)na.D + na.eps);
                 }
@@ -1237,17 +1398,30 @@ __global__ __launch_bounds__(256) void k_attn_combine(const float* __restrict__ 
 // there is.  The row's page is page_table[m * pt_stride] (single page), its length state->pos + 1 + m * pos_step <= 8.
 template <int DH>
 __global__ __launch_bounds__(256) void k_attn_small_rows(const float* __restrict__ q_all, KVView kv, const SeqState* __restrict__ state,
-                                                         int H, int Hk, int pos_step, int pt_stride, bf16_t* __restrict__ Ohi) {
+                                                         int H, int Hk, int pos_step, int pt_stride, bf16_t* __restrict__ Ohi, int identity_pages) {
     __shared__ float sc[32 * 8];
     const int m = blockIdx.x, tid = threadIdx.x;
-    const int T = row_pos(state, m, pos_step) + 1;
-    const int page = kv.page_table[(size_t)m * pt_stride];
+    // identity_pages: row m's only page IS page m (the batched fast decoder's table) -- one dependent L2 round trip less in a node that is
+    // nothing but a chain of them
+    const int page = identity_pages ? m : kv.page_table[(size_t)m * pt_stride];
     const int n_rep = H / Hk;
     const float* q = q_all + (size_t)m * H * DH;
     const bf16_t* kb = reinterpret_cast<const bf16_t*>(kv.k) + (size_t)page * Hk * KV_PAGE * DH;
     const bf16_t* vb = reinterpret_cast<const bf16_t*>(kv.v) + (size_t)page * Hk * KV_PAGE * DH;
     const float scale = 1.0f / sqrtf((float)DH);
     constexpr int QD = DH / 2;
+    // the V values of this thread's first (head, 4 dims) output item are requested with the K rows, not behind the score barrier (all 8
+    // token slots of the page exist; slots >= T hold stale finite bf16 and are masked by t < T below)
+    uint2 vpre[8];
+    {
+        const int e4 = tid * 4;
+        if (e4 < H * DH) {
+            const int h = e4 / DH, dd = e4 % DH;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) vpre[t] = *reinterpret_cast<const uint2*>(vb + ((size_t)(h / n_rep) * KV_PAGE + t) * DH + dd);
+        }
+    }
+    const int T = row_pos(state, m, pos_step) + 1;
     for (int e1 = tid >> 1; e1 < H * 8; e1 += 128) {
         const int h = e1 >> 3, t = e1 & 7, sl = tid & 1;
         const bf16_t* kp = kb + ((size_t)(h / n_rep) * KV_PAGE + t) * DH + sl * QD;
@@ -1266,6 +1440,7 @@ __global__ __launch_bounds__(256) void k_attn_small_rows(const float* __restrict
     __syncthreads();
     for (int e4 = tid * 4; e4 < H * DH; e4 += 1024) {
         const int h = e4 / DH, dd = e4 % DH;
+        const bool firstit = e4 == tid * 4;
         float mx = -1e30f;
 #pragma unroll
         for (int t = 0; t < 8; ++t) if (t < T) mx = fmaxf(mx, sc[h * 8 + t]);
@@ -1275,7 +1450,7 @@ __global__ __launch_bounds__(256) void k_attn_small_rows(const float* __restrict
             if (t < T) {
                 const float p = __expf(sc[h * 8 + t] - mx);
                 L += p;
-                const uint2 vv = *reinterpret_cast<const uint2*>(vb + ((size_t)(h / n_rep) * KV_PAGE + t) * DH + dd);
+                const uint2 vv = firstit ? vpre[t] : *reinterpret_cast<const uint2*>(vb + ((size_t)(h / n_rep) * KV_PAGE + t) * DH + dd);
                 O[0] = fmaf(p, bf16_bits_to_f32((bf16_t)(vv.x & 0xFFFFu)), O[0]); O[1] = fmaf(p, bf16_bits_to_f32((bf16_t)(vv.x >> 16)), O[1]);
                 O[2] = fmaf(p, bf16_bits_to_f32((bf16_t)(vv.y & 0xFFFFu)), O[2]); O[3] = fmaf(p, bf16_bits_to_f32((bf16_t)(vv.y >> 16)), O[3]);
             }
@@ -2474,7 +2649,8 @@ template <typename WT>
 __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_slow_rows(const float* __restrict__ logits, int ld, int n,
                                                                      const SampleCfg* __restrict__ cp, const RngState* __restrict__ master,
                                                                      int B, int calls_per_frame, SeqState* __restrict__ states,
-                                                                     const float* __restrict__ X, float* __restrict__ XF, int dim) {
+                                                                     const float* __restrict__ X, float* __restrict__ XF, int dim, PrepOut po) {
+    __shared__ float red4[4];
     __shared__ __attribute__((aligned(16))) float lg[SAMPLE_MAXN];
     __shared__ __attribute__((aligned(16))) float sp[SAMPLE_MAXN];
     __shared__ __attribute__((aligned(16))) int si[SAMPLE_MAXN];
@@ -2499,6 +2675,8 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_slow_rows(const float
         st->cur[0] = tok;
         if (tok == c.im_end_id) st->done = 1;  // batch_item_is_dead |= newly dead (:160-173)
     }
+    if (po.epoch && b == 0 && tid == 0) po.epoch[0] += 1;
+    if (po.g) block_prep_row(XF + (size_t)b * dim, dim, po, b, red4);
 }
 
 template <typename WT>
@@ -2507,7 +2685,8 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_fast_rows(const float
                                                                      int B, SeqState* __restrict__ states, const WT* __restrict__ fast_emb,
                                                                      float* __restrict__ XF, const WT* __restrict__ tok_emb,
                                                                      const WT* __restrict__ cb_emb, float* __restrict__ X, int dim,
-                                                                     uint32_t* __restrict__ out_codes, int out_cap) {
+                                                                     uint32_t* __restrict__ out_codes, int out_cap, PrepOut po) {
+    __shared__ float red4[4];
     __shared__ __attribute__((aligned(16))) float lg[SAMPLE_MAXN];
     __shared__ __attribute__((aligned(16))) float sp[SAMPLE_MAXN];
     __shared__ __attribute__((aligned(16))) int si[SAMPLE_MAXN];
@@ -2526,6 +2705,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_sample_fast_rows(const float
     if (tid == 0) st->cur[cb + 1] = (uint32_t)code;
     if (cb != n_cb - 1) {
         for (int d = tid; d < dim; d += SAMPLE_THREADS) XF[(size_t)b * dim + d] = WTr<WT>::to_f32(fast_emb[(size_t)code * dim + d]);
+        if (po.g) block_prep_row(XF + (size_t)b * dim, dim, po, b, red4);
         return;
     }
     // ---- end of frame (static_batch.rs:224-267 + generate_static_batch :305-338)
@@ -2578,7 +2758,8 @@ constexpr int PAR_THREADS = 512;
 template <typename WT>
 __global__ __launch_bounds__(PAR_THREADS) void k_sample_slow_rows_par(const float* __restrict__ logits, int ld, int n, const SampleCfg* __restrict__ cp,
                                                                        const uint32_t* __restrict__ words, SeqState* __restrict__ states,
-                                                                       const float* __restrict__ X, float* __restrict__ XF, int dim) {
+                                                                       const float* __restrict__ X, float* __restrict__ XF, int dim, PrepOut po) {
+    __shared__ float red4[4];
     __shared__ BSampLds S;
     const int tid = threadIdx.x, b = blockIdx.x;
     SeqState* st = states + b;
@@ -2598,13 +2779,16 @@ __global__ __launch_bounds__(PAR_THREADS) void k_sample_slow_rows_par(const floa
         st->cur[0] = tok;
         if (tok == c.im_end_id) st->done = 1;  // batch_item_is_dead |= newly dead (:160-173)
     }
+    if (po.epoch && b == 0 && tid == 0) po.epoch[0] += 1;
+    if (po.g) block_prep_row(XF + (size_t)b * dim, dim, po, b, red4);
 }
 template <typename WT>
 __global__ __launch_bounds__(PAR_THREADS) void k_sample_fast_rows_par(const float* __restrict__ logits, int cb, int n_cb, int cb_size,
                                                                        const SampleCfg* __restrict__ cp, const uint32_t* __restrict__ words, SeqState* __restrict__ states,
                                                                        const WT* __restrict__ fast_emb, float* __restrict__ XF, const WT* __restrict__ tok_emb,
                                                                        const WT* __restrict__ cb_emb, float* __restrict__ X, int dim,
-                                                                       uint32_t* __restrict__ out_codes, int out_cap) {
+                                                                       uint32_t* __restrict__ out_codes, int out_cap, PrepOut po) {
+    __shared__ float red4[4];
     __shared__ BSampLds S;
     const int tid = threadIdx.x, b = blockIdx.x, n = cb_size;
     SeqState* st = states + b;
@@ -2618,6 +2802,7 @@ __global__ __launch_bounds__(PAR_THREADS) void k_sample_fast_rows_par(const floa
     if (tid == 0) st->cur[cb + 1] = (uint32_t)code;
     if (cb != n_cb - 1) {
         for (int d = tid; d < dim; d += PAR_THREADS) XF[(size_t)b * dim + d] = WTr<WT>::to_f32(fast_emb[(size_t)code * dim + d]);
+        if (po.g) block_prep_row(XF + (size_t)b * dim, dim, po, b, red4);
         return;
     }
     // ---- end of frame (static_batch.rs:224-267 + generate_static_batch :305-338): as k_sample_fast_rows
@@ -2934,32 +3119,37 @@ bool rows_par_sampler_ok(double temp, uint64_t top_k, int n_slow, int cb_size) {
 }
 template <typename WT>
 void SampleKernels<WT>::sample_slow_rows(const ModelDims& d, const float* logits, int ld, int n, const SampleCfg* c, const RngState* master,
-                                         int B, int calls_per_frame, SeqState* states, const float* X, float* XF, hipStream_t st, const uint32_t* words) {
+                                         int B, int calls_per_frame, SeqState* states, const float* X, float* XF, hipStream_t st, const uint32_t* words,
+                                         const float* prep_g, uint16_t* prep_A, uint32_t* epoch) {
     FS_REQUIRE(n <= SAMPLE_MAXN, "audio-range vocabulary larger than the sampler capacity");
+    FS_REQUIRE(!prep_g || (d.dim <= 1024 && d.dim % 4 == 0), "sampler-side RMSNorm of the next input row: dim <= 1024");
+    const PrepOut po{prep_g, d.eps, prep_A, epoch};
     if (words) {
-        hipLaunchKernelGGL((k_sample_slow_rows_par<KVT<WT>>), dim3(B), dim3(PAR_THREADS), 0, st, logits, ld, n, c, words, states, X, XF, d.dim);
+        hipLaunchKernelGGL((k_sample_slow_rows_par<KVT<WT>>), dim3(B), dim3(PAR_THREADS), 0, st, logits, ld, n, c, words, states, X, XF, d.dim, po);
         FS_LAUNCH_CHECK();
         return;
     }
     hipLaunchKernelGGL((k_sample_slow_rows<KVT<WT>>), dim3(B), dim3(SAMPLE_THREADS), 0, st, logits, ld, n, c, master, B, calls_per_frame, states,
-                       X, XF, d.dim);
+                       X, XF, d.dim, po);
     FS_LAUNCH_CHECK();
 }
 template <typename WT>
 void SampleKernels<WT>::sample_fast_rows(const ModelDims& d, const float* logits, int cb, int n_cb, int cb_size, const SampleCfg* c,
                                          const RngState* master, int B, SeqState* states, const void* fast_emb, float* XF,
                                          const void* tok_emb, const void* cb_emb, float* X, uint32_t* out_codes, int out_cap,
-                                         hipStream_t st, const uint32_t* words) {
+                                         hipStream_t st, const uint32_t* words, const float* prep_g, uint16_t* prep_A) {
     FS_REQUIRE(cb_size <= SAMPLE_MAXN, "codebook larger than the sampler capacity");
+    FS_REQUIRE(!prep_g || (d.dim <= 1024 && d.dim % 4 == 0), "sampler-side RMSNorm of the next input row: dim <= 1024");
+    const PrepOut po{prep_g, d.eps, prep_A, nullptr};
     if (words) {
         hipLaunchKernelGGL((k_sample_fast_rows_par<KVT<WT>>), dim3(B), dim3(PAR_THREADS), 0, st, logits, cb, n_cb, cb_size, c, words, states,
                            reinterpret_cast<const KVT<WT>*>(fast_emb), XF, reinterpret_cast<const KVT<WT>*>(tok_emb), reinterpret_cast<const KVT<WT>*>(cb_emb), X, d.dim,
-                           out_codes, out_cap);
+                           out_codes, out_cap, po);
         FS_LAUNCH_CHECK();
         return;
     }
     hipLaunchKernelGGL((k_sample_fast_rows<KVT<WT>>), dim3(B), dim3(SAMPLE_THREADS), 0, st, logits, cb, n_cb, cb_size, c, master, B, states,
-                       (const KVT<WT>*)fast_emb, XF, (const KVT<WT>*)tok_emb, (const KVT<WT>*)cb_emb, X, d.dim, out_codes, out_cap);
+                       (const KVT<WT>*)fast_emb, XF, (const KVT<WT>*)tok_emb, (const KVT<WT>*)cb_emb, X, d.dim, out_codes, out_cap, po);
     FS_LAUNCH_CHECK();
 }
 
@@ -3093,8 +3283,40 @@ static void launch_gemm3(int N, int ksplit, int rt, hipStream_t st, const bf16_t
 #undef FS_GEMM_CASE
 }
 
+// layer-closing down projection of a decode step (k_gemm_down): M <= 32 rows, depth = NKS * 128 * ksplit
+static bool gemm_down_ok(int M, int N, int K) { return M <= PF_M && N % 128 == 0 && (K == 4096 || K == 1024 || K == 256); }
+size_t rows_xchg_bytes(int dim) { return (size_t)(dim / 16) * 4 * PF_M * 8 * 16; }
+static void launch_gemm_down(hipStream_t st, const bf16_t* Xf, int M, int K, const void* W, const float* wscale, int N, float* Y, int ldy, NormAux na,
+                             void* xchg, uint32_t* epoch, uint32_t node_id) {
+    FS_REQUIRE(xchg && epoch, "folded decode step without an exchange buffer");
+    const int nks = K == 4096 ? 8 : (K == 1024 ? 2 : 1), ksplit = K / (nks * 128);   // 4, 4 (mid-size tests), 2 (tiny tests)
+    const dim3 grid(N / 16, ksplit);
+#define FS_DOWN_CASE(nk)                                                                                                              \
+    do {                                                                                                                              \
+        if (wscale) hipLaunchKernelGGL((k_gemm_down<nk, true>), grid, dim3(256), 0, st, Xf, M, K, W, wscale, N, Y, ldy, na, (u32x4*)xchg, epoch, node_id);  \
+        else hipLaunchKernelGGL((k_gemm_down<nk, false>), grid, dim3(256), 0, st, Xf, M, K, W, wscale, N, Y, ldy, na, (u32x4*)xchg, epoch, node_id);        \
+    } while (0)
+    switch (nks) {
+        case 8: FS_DOWN_CASE(8); break;
+        case 2: FS_DOWN_CASE(2); break;
+        default: FS_DOWN_CASE(1); break;
+    }
+#undef FS_DOWN_CASE
+}
+// FISHRT_ROWS_NO_FOLD=1: A/B hook -- decode steps keep the split-K slabs + k_prep nodes
+static bool rows_fold_enabled() {
+    static const bool v = [] { const char* e = std::getenv("FISHRT_ROWS_NO_FOLD"); return !(e && std::atoi(e) != 0); }();
+    return v;
+}
 template <typename WT>
-void LmKernels<WT>::rows_layer(const ModelDims& d, int M, const RowsCtx& c, const LayerW& w, KVView kv, bool first, hipStream_t st) {
+bool LmKernels<WT>::rows_fold_ok(const ModelDims& d, int M, const RowsCtx& c) {
+    if constexpr (std::is_same<WT, float>::value) return false;
+    return rows_fold_enabled() && c.A2 != nullptr && c.ss != nullptr && c.xchg != nullptr && c.epoch != nullptr && gemm_down_ok(M, d.dim, d.inter) &&
+           !gemm_big_ok(M, d.dim, d.dim, 1) && c.stage_mask == 0xFFu;
+}
+
+template <typename WT>
+void LmKernels<WT>::rows_layer(const ModelDims& d, int M, const RowsCtx& c, const LayerW& w, KVView kv, bool first, hipStream_t st, const float* next_norm) {
     if constexpr (std::is_same<WT, float>::value) {
         throw Error("the MFMA row path needs bf16 or fp8 weights");
     } else {
@@ -3112,10 +3334,19 @@ void LmKernels<WT>::rows_layer(const ModelDims& d, int M, const RowsCtx& c, cons
         KVView nokv = {};
         const size_t slab = (size_t)c.Mcap * d.dim;
         const int DOWN_SPLIT = c.down_split;
+        // decode steps (c.fold): the previous layer's un-split down projection (k_gemm_down) closed the residual stream and left
+        // split(x * attention_norm) + sum-of-squares partials in c.A / c.ss: no k_prep node, Wqkv divides by the row's rms instead
+        const bool fold = c.fold && next_norm != nullptr;
+        if (fold) FS_REQUIRE(rows_fold_ok(d, M, c), "folded decode step on a shape the un-split down projection does not take");
+        const int nblk_d = d.dim / 16;
         // (1) x += previous layer's down-proj slabs ; RMSNorm(attention_norm) -> hi/lo
-        if (c.stage_mask & 1u) hipLaunchKernelGGL(k_prep, dim3(M), dim3(256), 0, st, c.X, d.dim, c.P, first ? 0 : DOWN_SPLIT, slab, w.attn_norm, d.eps, c.A);
+        if (fold && (!first || c.first_prepped)) {}   // (first_prepped: the sampler that wrote the input row left its normalised fragments in c.A)
+        else if (c.stage_mask & 1u) hipLaunchKernelGGL(k_prep, dim3(M), dim3(256), 0, st, c.X, d.dim, c.P, first ? 0 : DOWN_SPLIT, slab, w.attn_norm, d.eps, c.A);
         // (2) Wqkv + rope + KV scatter
-        if (c.stage_mask & 2u) launch_gemm3<EPI_QKV>(qkv_rows, 1, rt_qkv, st, c.A, M, d.dim, w.wqkv, w.s_qkv, c.Q, d.dim, 0, nullptr, 0,
+        if (fold && !first)
+            launch_gemm3<EPI_QKV_RMS>(qkv_rows, 1, rt_qkv, st, c.A, M, d.dim, w.wqkv, w.s_qkv, c.Q, d.dim, 0, nullptr, 0,
+                                      c.cos_t, c.sin_t, c.state, kv, d.H, d.Hk, d.Dh, rm, NormAux{nullptr, c.ss, nullptr, nblk_d, d.dim, d.eps});
+        else if (c.stage_mask & 2u) launch_gemm3<EPI_QKV>(qkv_rows, 1, rt_qkv, st, c.A, M, d.dim, w.wqkv, w.s_qkv, c.Q, d.dim, 0, nullptr, 0,
                               c.cos_t, c.sin_t, c.state, kv, d.H, d.Hk, d.Dh, rm);
         // (3) attention over each row's KV prefix + chunk combine -> hi/lo
         if (c.seq_rows > 0) {
@@ -3130,9 +3361,9 @@ void LmKernels<WT>::rows_layer(const ModelDims& d, int M, const RowsCtx& c, cons
         } else if (c.small_attn && (c.stage_mask & 4u) && d.H <= 32 && (d.Dh == 64 || d.Dh == 32)) {
             // fast decoder: <= 8 tokens in one page -> one node instead of two
             if (d.Dh == 64)
-                hipLaunchKernelGGL((k_attn_small_rows<64>), dim3(M), dim3(256), 0, st, c.Q, kv, c.state, d.H, d.Hk, c.pos_step, c.pt_stride, c.A);
+                hipLaunchKernelGGL((k_attn_small_rows<64>), dim3(M), dim3(256), 0, st, c.Q, kv, c.state, d.H, d.Hk, c.pos_step, c.pt_stride, c.A, (int)c.identity_pages);
             else
-                hipLaunchKernelGGL((k_attn_small_rows<32>), dim3(M), dim3(256), 0, st, c.Q, kv, c.state, d.H, d.Hk, c.pos_step, c.pt_stride, c.A);
+                hipLaunchKernelGGL((k_attn_small_rows<32>), dim3(M), dim3(256), 0, st, c.Q, kv, c.state, d.H, d.Hk, c.pos_step, c.pt_stride, c.A, (int)c.identity_pages);
         } else if (c.pos_step <= 0 && !c.chunked_attn && ((d.Dh == 64 && (d.n_rep == 8 || d.n_rep == 2)) || (d.Dh == 32 && d.n_rep == 2))) {
             // static-batch decode: one fused node per layer (whole KV prefix per (kv head, row) block)
             // few rows: split the 8 query heads of a kv group over two blocks (64 -> 128 blocks at 32 rows)
@@ -3185,7 +3416,9 @@ void LmKernels<WT>::rows_layer(const ModelDims& d, int M, const RowsCtx& c, cons
             if (c.stage_mask & 64u) launch_gemm3<EPI_SWIGLU>(2 * d.inter, 1, rt_13, st, c.A, M, d.dim, w.w13, w.s_13, nullptr, 0, 0, c.C, d.inter,
                                      nullptr, nullptr, nullptr, nokv, 0, 0, 0, none);
         }
-        if (c.stage_mask & 128u) launch_gemm3<EPI_STORE>(d.dim, DOWN_SPLIT, rt_2, st, c.C, M, d.inter, w.w2, w.s_2, c.P, d.dim, slab, nullptr, 0, nullptr, nullptr,
+        if (fold)  // x += W2 . act ; split(x * next_norm) -> c.A ; sum-of-squares partials -> c.ss  (the attention output in c.A and Wo's partials are consumed)
+            launch_gemm_down(st, c.C, M, d.inter, w.w2, w.s_2, d.dim, c.X, d.dim, NormAux{next_norm, c.ss, c.A, nblk_d, d.dim, d.eps}, c.xchg, c.epoch, c.node_id);
+        else if (c.stage_mask & 128u) launch_gemm3<EPI_STORE>(d.dim, DOWN_SPLIT, rt_2, st, c.C, M, d.inter, w.w2, w.s_2, c.P, d.dim, slab, nullptr, 0, nullptr, nullptr,
                                 nullptr, nokv, 0, 0, 0, none);
         FS_LAUNCH_CHECK();
     }
@@ -3206,13 +3439,17 @@ void LmKernels<WT>::rows_finish(const ModelDims& d, int M, const RowsCtx& c, con
 // head GEMM of the MFMA row path: logits[m][0..n_rows) = W[n_rows, dim] . (hi + lo)[m]  (input = rows_finish(norm_w) output)
 template <typename WT>
 void LmKernels<WT>::rows_head(const ModelDims& d, int M, const RowsCtx& c, const void* W, const float* wscale, int n_rows, float* logits, int ld,
-                              hipStream_t st) {
+                              hipStream_t st, bool rms) {
     if constexpr (std::is_same<WT, float>::value) {
         throw Error("the MFMA row path needs bf16 or fp8 weights");
     } else {
         FS_REQUIRE(ld >= n_rows, "logits row stride must cover n_rows");
         KVView nokv = {};
         // EPI_STORE with one K range writes slab 0 == the logits matrix itself (row stride ld)
+        if (rms)  // folded decode step: c.A holds split(x * norm_w), c.ss the sum-of-squares partials of the last down projection
+            launch_gemm3<EPI_STORE_RMS>(n_rows, 1, 1, st, c.A, M, d.dim, W, wscale, logits, ld, 0, nullptr, 0, nullptr, nullptr, nullptr, nokv, 0, 0,
+                                        0, RowMap{0, 0}, NormAux{nullptr, c.ss, nullptr, d.dim / 16, d.dim, d.eps});
+        else
         launch_gemm3<EPI_STORE>(n_rows, 1, 1, st, c.A, M, d.dim, W, wscale, logits, ld, 0, nullptr, 0, nullptr, nullptr, nullptr, nokv, 0, 0,
                                 0, RowMap{0, 0});
         FS_LAUNCH_CHECK();
@@ -3293,7 +3530,7 @@ void debug_sample_rows(int device, const float* logits, int B, int n, double tem
         (void)hipFree(d_out);
     } else {
     hipLaunchKernelGGL((k_sample_slow_rows<bf16_t>), dim3(B), dim3(SAMPLE_THREADS), 0, nullptr, d_logits, n, n, d_cfg, d_rng, B, 1, d_st,
-                       (const float*)nullptr, (float*)nullptr, 0);
+                       (const float*)nullptr, (float*)nullptr, 0, PrepOut{nullptr, 0.f, nullptr, nullptr});
     FS_LAUNCH_CHECK();
     FS_HIP(hipDeviceSynchronize());
     FS_HIP(hipMemcpy(hs.data(), d_st, sizeof(SeqState) * B, hipMemcpyDeviceToHost));

@@ -1838,6 +1838,7 @@ class LM final : public LMBase {
             cf.small_attn = a_.num_codebooks <= 8;
             cf.first_prepped = prep_g != nullptr;
             cf.identity_pages = true;  // d_fast_table_[i] == i
+            cf.attn_t1 = cbi == 0;     // d_fast_state_[0].pos == 0
             for (int l = 0; l < a_.n_fast_layer; ++l) {
                 KVView kv;
                 KT* base = fast_pool_.as<KT>() + ((size_t)l * 2 * B_) * page_elems_;

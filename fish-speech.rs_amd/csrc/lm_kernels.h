@@ -97,6 +97,7 @@ struct RowsCtx {
     void* xchg = nullptr;        // fold: exchange units of the layer-closing down projection (rows_xchg_bytes(dim), zero-initialised, used by nothing else)
     uint32_t* epoch = nullptr;   // fold: [0] = step epoch (>= 1; bumped once per step by the slow-token sampler node), [1] = exchange timeouts
     uint32_t node_id = 0;        // fold: unique per rows_layer call of a step (< 4096)
+    bool attn_t1 = false;        // fold + small_attn: every row sits at position 0 of an empty cache (first codebook pass): no attention node
     bool identity_pages = false; // small_attn: page_table[m * pt_stride] == m for every row (the batched fast decoder's one-page-per-row table)
     bool first_prepped = false;  // fold: the first layer's normalised input fragments are already in A (written by the sampler that produced the row)
     bool fold = false;           // decode step with the un-split down projection (see rows_layer's next_norm)

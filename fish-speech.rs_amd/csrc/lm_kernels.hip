@@ -908,6 +908,9 @@ struct GemmEpi {
     KVView kv; int H, Hk, Dh; RowMap rm; NormAux na;
     int pos0, rope_off, N;
     const SeqState* states = nullptr;  // pos_step < 0: row m reads its own position (session slots)
+    bf16_t* o1 = nullptr;              // EPI_QKV*: every row sits at position 0 of an empty cache (the fast decoder's first pass): attention over one
+                                       // token is the identity on V, so the V rows also leave the attention output (hi = the cached bf16 value, lo = 0:
+                                       // exactly what the attention node computes for T = 1) in fragment-major order and that node is not launched
 };
 // values the epilogue needs from memory that do not depend on the GEMM: requested at kernel entry by k_gemm3 (one slot per thread, first
 // panel) so that they arrive under the weight stream instead of starting a dependent L2 round trip behind the K loop
@@ -975,7 +978,16 @@ __device__ __forceinline__ void gemm_epilogue(float a, float b, int r, int m, in
         } else {
             const int rv = r - qdim - kdim;
             bf16_t* dst = kv_addr<bf16_t>(kv.v, ptab, pos, rv / Dh, Hk, Dh) + rv % Dh;
-            *reinterpret_cast<uint32_t*>(dst) = WTr<bf16_t>::from_f32(a) | ((uint32_t)WTr<bf16_t>::from_f32(b) << 16);
+            const uint32_t vb2 = WTr<bf16_t>::from_f32(a) | ((uint32_t)WTr<bf16_t>::from_f32(b) << 16);
+            *reinterpret_cast<uint32_t*>(dst) = vb2;
+            if (g.o1) {
+                const int n_rep = H / Hk, gk = rv / Dh, dd = rv % Dh;
+                for (int hh = 0; hh < n_rep; ++hh) {
+                    const int e = (gk * n_rep + hh) * Dh + dd;
+                    *reinterpret_cast<uint32_t*>(g.o1 + frag_off(m, e, 0, qdim)) = vb2;
+                    *reinterpret_cast<uint32_t*>(g.o1 + frag_off(m, e, 1, qdim)) = 0u;
+                }
+            }
         }
     }
 }
@@ -1018,7 +1030,8 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* __restrict__ Xf, in
     const int kbeg = ((int)blockIdx.y * 4 + kq) * NKS * 32 + (lane >> 4) * 8;  // this lane's first k of every 32-wide step (weights)
     int pos0 = 0, rope_off = 0;
     if (EPI == EPI_QKV || EPI == EPI_QKV_RMS) { pos0 = state->pos; rope_off = state->rope_off; }  // requested up front: the epilogue must not start a dependent chain
-    const GemmEpi ge{Y, ldy, slab_stride, Of, ldo, cos_t, sin_t, kv, H, Hk, Dh, rm, na, pos0, rope_off, N, state};
+    const GemmEpi ge{Y, ldy, slab_stride, Of, ldo, cos_t, sin_t, kv, H, Hk, Dh, rm, na, pos0, rope_off, N, state,
+                     (EPI == EPI_QKV || EPI == EPI_QKV_RMS) ? Of : nullptr};  // (Of of a QKV launch: GemmEpi::o1)
     u32x4 wf[RT][NKS];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -1115,6 +1128,7 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* __restrict__ Xf, in
     }
 }
 
+constexpr unsigned DOWN_SPIN_MAX = 1u << 17;  // polls of an in-launch exchange unit before a thread gives up (~0.1 s; reported through epoch[1])
 // ---- down projection of a decode step (M <= 32 rows) that closes the layer itself: split-K over gridDim.y blocks per 16-row weight tile
 // as before (every CU streams a 32 KB weight tile: the K depth of 4096 needs all of them), but the K partials meet INSIDE the launch
 // instead of in slabs + a k_prep node: thread (row pair pr, activation row ml) of block y publishes its two partial sums as one 16-byte
@@ -1129,7 +1143,6 @@ __global__ __launch_bounds__(256) void k_gemm3(const bf16_t* __restrict__ Xf, in
 // Measured and rejected first (round 5): the same layer-closing epilogue on an UN-split block (16 weight rows x 16 activation rows x the
 // whole depth, 128 blocks): 9.0 us per node against 5.0 + 5.1 for the split GEMM + k_prep -- 384 KB of operands through ONE CU's vector
 // memory path at one wave per SIMD is ~55 GB/s per CU.
-constexpr unsigned DOWN_SPIN_MAX = 1u << 17;
 template <int NKS, bool FP8>
 __global__ __launch_bounds__(256) void k_gemm_down(const bf16_t* __restrict__ Xf, int M, int K, const void* __restrict__ Wv,
                                                    const float* __restrict__ wscale, int N, float* __restrict__ Y, int ldy, NormAux na,
@@ -1198,22 +1211,36 @@ __global__ __launch_bounds__(256) void k_gemm_down(const bf16_t* __restrict__ Xf
         asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(units + (size_t)y * PF_M * 8), "v"(u) : "memory");
         return;
     }
-    float s0 = 0.f, s1 = 0.f;
-    bool dead = false;
-    for (int ys = 0; ys < ksplit; ++ys) {  // partials in block order (the own one from registers)
-        float pa = a, pb = b;
-        if (ys != y) {
-            const u32x4* p = units + (size_t)ys * PF_M * 8;
-            u32x4 v;
-            for (unsigned spins = 0;; ++spins) {
-                asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-                if ((v.y == tag && v.w == tag) || dead) break;
-                if (spins > DOWN_SPIN_MAX) { dead = true; atomicAdd(epoch + 1, 1u); break; }  // (reported: rows_xchg_timeouts)
+    // the other blocks' units of this slot: all requests in flight together, retried (only the missing ones) until both tags of each match
+    u32x4 pv[4];
+    {
+        bool ok[4];
+#pragma unroll
+        for (int ys = 0; ys < 4; ++ys) { ok[ys] = ys >= ksplit || ys == y; pv[ys] = u32x4{0u, 0u, 0u, 0u}; }
+        for (unsigned spins = 0;; ++spins) {
+#pragma unroll
+            for (int ys = 0; ys < 4; ++ys)
+                if (!ok[ys]) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(pv[ys]) : "v"(units + (size_t)ys * PF_M * 8) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            bool all = true;
+#pragma unroll
+            for (int ys = 0; ys < 4; ++ys) {
+                // (the asm outputs above are only written when the load was issued; keep the compiler from assuming otherwise)
+                asm volatile("" : "+v"(pv[ys]));
+                if (!ok[ys]) ok[ys] = pv[ys].y == tag && pv[ys].w == tag;
+                all = all && ok[ys];
             }
-            pa = __uint_as_float(v.x); pb = __uint_as_float(v.z);
+            if (all) break;
+            if (spins > DOWN_SPIN_MAX) { atomicAdd(epoch + 1, 1u); break; }  // (reported: check_rows_xchg)
         }
-        s0 += pa; s1 += pb;
     }
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int ys = 0; ys < 4; ++ys)  // partials in block order (the own one from registers)
+        if (ys < ksplit) {
+            s0 += ys == y ? a : __uint_as_float(pv[ys].x);
+            s1 += ys == y ? b : __uint_as_float(pv[ys].z);
+        }
     const float v0 = xo.x + s0, v1 = xo.y + s1;
     const bool live = ml < M;
     const float ssq = group_sum<8>(live ? fmaf(v0, v0, v1 * v1) : 0.f);
@@ -3343,13 +3370,22 @@ void LmKernels<WT>::rows_layer(const ModelDims& d, int M, const RowsCtx& c, cons
         if (fold && (!first || c.first_prepped)) {}   // (first_prepped: the sampler that wrote the input row left its normalised fragments in c.A)
         else if (c.stage_mask & 1u) hipLaunchKernelGGL(k_prep, dim3(M), dim3(256), 0, st, c.X, d.dim, c.P, first ? 0 : DOWN_SPLIT, slab, w.attn_norm, d.eps, c.A);
         // (2) Wqkv + rope + KV scatter
+        // c.attn_t1 (fold, small_attn; every row at position 0 of an empty cache): the Wqkv epilogue leaves the attention output itself
+        // (GemmEpi::o1) in c.C -- free until this layer's W13 -- and the attention node is not launched
+        const bool t1 = fold && c.attn_t1 && c.small_attn && !gemm_big_ok(M, qkv_rows, d.dim, 1);
+        bf16_t* const o1 = t1 ? c.C : nullptr;
+        // (Measured and rejected, round 5: Wqkv + the row attention of the later passes in ONE launch -- the GEMM blocks publish q / k / v as
+        // tagged units, block m then attends for row m, bit-identical results: 10.1-10.4 us per node against 5.7 + 5.6 for the two nodes under
+        // rocprofv3, 1856-1877 vs 1825-1833 us per step -- a consumer that waits for units from all 80 blocks on all 8 XCDs pays the slowest
+        // block's finish + cross-XCD visibility, unlike k_gemm_down's four same-XCD partners; profiles/r05_rows_fold.txt)
         if (fold && !first)
-            launch_gemm3<EPI_QKV_RMS>(qkv_rows, 1, rt_qkv, st, c.A, M, d.dim, w.wqkv, w.s_qkv, c.Q, d.dim, 0, nullptr, 0,
+            launch_gemm3<EPI_QKV_RMS>(qkv_rows, 1, rt_qkv, st, c.A, M, d.dim, w.wqkv, w.s_qkv, c.Q, d.dim, 0, o1, 0,
                                       c.cos_t, c.sin_t, c.state, kv, d.H, d.Hk, d.Dh, rm, NormAux{nullptr, c.ss, nullptr, nblk_d, d.dim, d.eps});
-        else if (c.stage_mask & 2u) launch_gemm3<EPI_QKV>(qkv_rows, 1, rt_qkv, st, c.A, M, d.dim, w.wqkv, w.s_qkv, c.Q, d.dim, 0, nullptr, 0,
+        else if (c.stage_mask & 2u) launch_gemm3<EPI_QKV>(qkv_rows, 1, rt_qkv, st, c.A, M, d.dim, w.wqkv, w.s_qkv, c.Q, d.dim, 0, o1, 0,
                               c.cos_t, c.sin_t, c.state, kv, d.H, d.Hk, d.Dh, rm);
         // (3) attention over each row's KV prefix + chunk combine -> hi/lo
-        if (c.seq_rows > 0) {
+        if (t1) {}
+        else if (c.seq_rows > 0) {
             // group prefill: M = n_seq * seq_rows rows, every sequence starts at state->pos; flash attention per sequence
             FS_REQUIRE(d.Dh == 64 && M % c.seq_rows == 0 && !c.no_flash, "group prefill needs head_dim 64 and whole sequences");
             if (c.stage_mask & 4u)
@@ -3403,7 +3439,7 @@ void LmKernels<WT>::rows_layer(const ModelDims& d, int M, const RowsCtx& c, cons
         NormAux na{w.ffn_norm, c.ss, c.A2, nblk_o, d.dim, d.eps};
         if (!(c.stage_mask & 16u)) {}
         else if (fuse_norm)
-            launch_gemm3<EPI_RESIDUAL_NORM>(d.dim, 1, rt_o, st, c.A, M, d.dim, w.wo, w.s_o, c.X, d.dim, 0, nullptr, 0, nullptr, nullptr,
+            launch_gemm3<EPI_RESIDUAL_NORM>(d.dim, 1, rt_o, st, t1 ? c.C : c.A, M, d.dim, w.wo, w.s_o, c.X, d.dim, 0, nullptr, 0, nullptr, nullptr,
                                             nullptr, nokv, 0, 0, 0, none, na);
         else launch_gemm3<EPI_RESIDUAL>(d.dim, 1, rt_o, st, c.A, M, d.dim, w.wo, w.s_o, c.X, d.dim, 0, nullptr, 0,
                                    nullptr, nullptr, nullptr, nokv, 0, 0, 0, none);

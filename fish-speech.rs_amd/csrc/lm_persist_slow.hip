@@ -56,6 +56,13 @@ static_assert(I8_W2 + 2 * 8192 == PS_LAYER_IMAGE_FP8, "fp8 image layout");
 constexpr int PS_SC = 48, SC_QKV = 0, SC_WO = 8, SC_W13 = 12, SC_W2 = 44;
 
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 ps_bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float ps_f32x4_t __attribute__((ext_vector_type(4)));
+// FISHRT_SLOW_S4_VALU=1: A/B hook -- the bf16 image keeps the row-pair layout of W13 and S4 runs on the VALU (the round-4 stage)
+static bool slow_s4_mfma() {
+    static const bool v = [] { const char* e = std::getenv("FISHRT_SLOW_S4_VALU"); return !(e && std::atoi(e) != 0); }();
+    return v;
+}
 // two rows' (2 t, 2 t + 1) pairs in one dword: acc_even += row_even . c, acc_odd += row_odd . c
 __device__ __forceinline__ void pf_dot2x2_fp8(uint32_t w, float c0, float c1, float& acc_even, float& acc_odd) {
     const f32x2_t a = __builtin_amdgcn_cvt_pk_f32_fp8(w, false), b2 = __builtin_amdgcn_cvt_pk_f32_fp8(w, true);
@@ -73,7 +80,8 @@ constexpr int S_VN = S_KN + 256;              // new token's v (bf16-rounded) f3
 constexpr int S_PART = S_VN + 256;            // [8 waves][72]: o[64], l
 constexpr int S_WMAX = S_PART + 8 * 72 * 4;   // [8] wave maxima + [1] block max
 constexpr int S_PAGES = S_WMAX + 64;          // page ids of this workgroup's token slice, int [160]
-constexpr int S_END = S_PAGES + 160 * 4;
+constexpr int S_XB = S_PAGES + 160 * 4;       // S4 on the matrix cores: x . g split into three bf16 arrays [3][1024] + one 16-byte zero slot per wave
+constexpr int S_END = S_XB + 3 * 2048 + 8 * 16;
 constexpr int PS_LDS = 96 * 1024;             // requested size: > half of the CU's LDS, so the 256 workgroups sit on 256 different CUs
 static_assert(S_END <= PS_LDS, "LDS budget");
 
@@ -108,7 +116,10 @@ __device__ __forceinline__ void ps_load16_unseen(u32x4& dst, const unsigned char
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ weight images
-__global__ __launch_bounds__(PF_THREADS) void k_ps_pack_layer(LayerW w, unsigned char* __restrict__ image /*[PF_BLOCKS][PS_LAYER_IMAGE]*/) {
+// w13_frag: the W13 region holds the workgroup's 32 rows as MFMA A fragments (v_mfma_f32_16x16x32_bf16) -- chunk u: row tile u / 4 (rows
+// 32 b + 16 (u / 4) + (lane & 15)), k-step u % 4 of the wave's K slice: elements 128 wave + 32 (u % 4) + 8 (lane >> 4) .. + 8 (the layout of
+// the fast decoder's resident W13, lm_persist.hip) -- instead of row pairs [chunk c: rows 4 c .. 4 c + 3][lane t: elements 2 t, 2 t + 1]
+__global__ __launch_bounds__(PF_THREADS) void k_ps_pack_layer(LayerW w, unsigned char* __restrict__ image /*[PF_BLOCKS][PS_LAYER_IMAGE]*/, int w13_frag) {
     const int b = blockIdx.x, t = threadIdx.x;
     unsigned char* im = image + (size_t)b * PS_LAYER_IMAGE;
     const uint32_t* Wq = reinterpret_cast<const uint32_t*>(w.wqkv);
@@ -122,7 +133,13 @@ __global__ __launch_bounds__(PF_THREADS) void k_ps_pack_layer(LayerW w, unsigned
     for (int r = 0; r < 4; ++r) v[r] = Wo[(size_t)(4 * b + r) * 512 + t];
     reinterpret_cast<u32x4*>(im + IM_WO)[t] = v;
     for (int c = 0; c < 8; ++c) {
-        for (int r = 0; r < 4; ++r) v[r] = W13[(size_t)(32 * b + 4 * c + r) * 512 + t];
+        if (w13_frag) {
+            const int rt = c >> 2, j = c & 3, wv = t >> 6, ln = t & 63;
+            const size_t row = (size_t)(32 * b + 16 * rt + (ln & 15));
+            for (int k = 0; k < 4; ++k) v[k] = W13[row * 512 + (size_t)(64 * wv + 16 * j + 4 * (ln >> 4) + k)];
+        } else {
+            for (int r = 0; r < 4; ++r) v[r] = W13[(size_t)(32 * b + 4 * c + r) * 512 + t];
+        }
         reinterpret_cast<u32x4*>(im + IM_W13)[c * PF_THREADS + t] = v;
     }
     for (int q = 0; q < 4; ++q) {
@@ -277,6 +294,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
     // 549, and the greedy tokens stopped being reproducible run to run -- an attention workgroup's S2 is the critical path of the layer, and
     // anything queued in front of its K/V tile costs more than the burst it removes from S3.
     const int early_mode = A.l2_touch;
+    const bool s4_mfma = (early_mode & 4) != 0;  // (bf16 images only; wave-uniform)
     const bool early13 = (early_mode & 1) && !att, early2 = (early_mode & 2) && !att;
     auto request_w13 = [&](const unsigned char* wl_) {  // the W13 slice of this layer -> registers, valid after the next sweep
         if constexpr (FP8) {
@@ -660,26 +678,66 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
             const float xn0 = x0 * nwx, xn1 = x1 * nwy;
             const float ssw = pf_wave_sum(fmaf(x1, x1, fmaf(x0, x0, 0.f)));
             if (lane == 0) red[(par * 8 + wave) * PS_RED + 32] = ssw;
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                float a16[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                if constexpr (FP8) {
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) {  // rows 16 half + 8 c ..
-                        const u32x4 w = w13f[half * 2 + c];
-                        pf_dot2x2_fp8(w.x, xn0, xn1, a16[8 * c], a16[8 * c + 1]); pf_dot2x2_fp8(w.y, xn0, xn1, a16[8 * c + 2], a16[8 * c + 3]);
-                        pf_dot2x2_fp8(w.z, xn0, xn1, a16[8 * c + 4], a16[8 * c + 5]); pf_dot2x2_fp8(w.w, xn0, xn1, a16[8 * c + 6], a16[8 * c + 7]);
-                    }
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const u32x4 w = w13[half * 4 + c];
-                        a16[4 * c] = pf_dot2(w.x, xn0, xn1, 0.f); a16[4 * c + 1] = pf_dot2(w.y, xn0, xn1, 0.f);
-                        a16[4 * c + 2] = pf_dot2(w.z, xn0, xn1, 0.f); a16[4 * c + 3] = pf_dot2(w.w, xn0, xn1, 0.f);
-                    }
+            if (!FP8 && s4_mfma) {
+                // The 32 x 1024 GEMV on the matrix cores (as S3 of k_fast_persist, lm_persist.hip): x . g is split into three bf16 terms
+                // (truncation: hi + mid + lo == the f32 value exactly) that become columns 0 / 1 / 2 of the B operand; a wave multiplies its
+                // 128-deep K slice of the two 16-row tiles (8 x v_mfma_f32_16x16x32_bf16, A = the streamed fragments) and the K reduction
+                // happens inside the instruction: 24 VALU operations per lane instead of 128 unpack / FMA + two 16-value halving trees.
+                uint32_t* xb = reinterpret_cast<uint32_t*>(smem + S_XB);
+                uint32_t pk[3];
+                {
+                    const uint32_t h0 = __float_as_uint(xn0) & 0xFFFF0000u, h1 = __float_as_uint(xn1) & 0xFFFF0000u;
+                    const float r0 = xn0 - __uint_as_float(h0), r1 = xn1 - __uint_as_float(h1);
+                    const uint32_t m0 = __float_as_uint(r0) & 0xFFFF0000u, m1 = __float_as_uint(r1) & 0xFFFF0000u;
+                    const uint32_t l0 = __float_as_uint(r0 - __uint_as_float(m0)), l1 = __float_as_uint(r1 - __uint_as_float(m1));
+                    pk[0] = (h0 >> 16) | h1; pk[1] = (m0 >> 16) | m1; pk[2] = (l0 >> 16) | (l1 & 0xFFFF0000u);
                 }
-                const float r16 = pf_reduce<16>(a16, lane);
-                if ((lane & 3) == 0) red[(par * 8 + wave) * PS_RED + half * 16 + (lane >> 2)] = r16;
+                // a wave's K slice [128 wave, +128) is exactly what its own 64 lanes swept: the LDS round trip is a transpose inside the wave
+                xb[tid] = pk[0]; xb[512 + tid] = pk[1]; xb[1024 + tid] = pk[2];
+                if (lane < 4) xb[1536 + 4 * wave + lane] = 0u;
+                __builtin_amdgcn_wave_barrier();
+                const int n = lane & 15, q4 = lane >> 4;
+                const u32x4* xbv = reinterpret_cast<const u32x4*>(smem + S_XB);
+                const int zslot = 384 + wave;
+                const int src = n < 3 ? n * 128 + 16 * wave + q4 : zslot;
+                ps_f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const ps_bf16x8_t bv = __builtin_bit_cast(ps_bf16x8_t, xbv[n < 3 ? src + 4 * j : zslot]);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(ps_bf16x8_t, w13[j]), bv, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(ps_bf16x8_t, w13[4 + j]), bv, acc1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {  // columns 0 + 1 + 2 (row_shl: lane i reads lane i + 1 / i + 2 of its row of 16)
+                    acc0[r] += pf_dpp<0x101>(acc0[r]) + pf_dpp<0x102>(acc0[r]);
+                    acc1[r] += pf_dpp<0x101>(acc1[r]) + pf_dpp<0x102>(acc1[r]);
+                }
+                if (n == 0) {  // D[row 4 q4 + r][column 0]
+                    *reinterpret_cast<float4*>(red + (par * 8 + wave) * PS_RED + 4 * q4) = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
+                    *reinterpret_cast<float4*>(red + (par * 8 + wave) * PS_RED + 16 + 4 * q4) = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
+                }
+            } else {
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    float a16[16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    if constexpr (FP8) {
+    #pragma unroll
+                        for (int c = 0; c < 2; ++c) {  // rows 16 half + 8 c ..
+                            const u32x4 w = w13f[half * 2 + c];
+                            pf_dot2x2_fp8(w.x, xn0, xn1, a16[8 * c], a16[8 * c + 1]); pf_dot2x2_fp8(w.y, xn0, xn1, a16[8 * c + 2], a16[8 * c + 3]);
+                            pf_dot2x2_fp8(w.z, xn0, xn1, a16[8 * c + 4], a16[8 * c + 5]); pf_dot2x2_fp8(w.w, xn0, xn1, a16[8 * c + 6], a16[8 * c + 7]);
+                        }
+                    } else {
+    #pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const u32x4 w = w13[half * 4 + c];
+                            a16[4 * c] = pf_dot2(w.x, xn0, xn1, 0.f); a16[4 * c + 1] = pf_dot2(w.y, xn0, xn1, 0.f);
+                            a16[4 * c + 2] = pf_dot2(w.z, xn0, xn1, 0.f); a16[4 * c + 3] = pf_dot2(w.w, xn0, xn1, 0.f);
+                        }
+                    }
+                    const float r16 = pf_reduce<16>(a16, lane);
+                    if ((lane & 3) == 0) red[(par * 8 + wave) * PS_RED + half * 16 + (lane >> 2)] = r16;
+                }
             }
             __syncthreads();
             if (wave == 0) {
@@ -806,7 +864,7 @@ void launch_slow_persist_pack(const LayerW* layers, int n_layer, const void* hea
                               void* wpack, void* hpack, float* norms_flat, hipStream_t st) {
     for (int l = 0; l < n_layer; ++l)
         hipLaunchKernelGGL(k_ps_pack_layer, dim3(PF_BLOCKS), dim3(PF_THREADS), 0, st, layers[l],
-                           reinterpret_cast<unsigned char*>(wpack) + (size_t)l * PF_BLOCKS * PS_LAYER_IMAGE);
+                           reinterpret_cast<unsigned char*>(wpack) + (size_t)l * PF_BLOCKS * PS_LAYER_IMAGE, slow_s4_mfma() ? 1 : 0);
     hipLaunchKernelGGL(k_ps_pack_head, dim3(PF_BLOCKS), dim3(PF_THREADS), 0, st, reinterpret_cast<const uint32_t*>(head_w), n_head_rows,
                        reinterpret_cast<unsigned char*>(hpack));
     for (int i = 0; i < 2 * n_layer + 1; ++i)
@@ -835,7 +893,11 @@ void launch_slow_persist(const SlowPersistArgs& a, hipStream_t st) {
         attr_set = true;
     }
     if (a.scales) hipLaunchKernelGGL(k_slow_persist<true>, dim3(PF_BLOCKS), dim3(PF_THREADS), PS_LDS, st, a);
-    else hipLaunchKernelGGL(k_slow_persist<false>, dim3(PF_BLOCKS), dim3(PF_THREADS), PS_LDS, st, a);
+    else {
+        SlowPersistArgs b2 = a;
+        if (slow_s4_mfma()) b2.l2_touch |= 4;  // bit 2: the bf16 image carries W13 as MFMA fragments (launch_slow_persist_pack)
+        hipLaunchKernelGGL(k_slow_persist<false>, dim3(PF_BLOCKS), dim3(PF_THREADS), PS_LDS, st, b2);
+    }
     FS_HIP(hipGetLastError());
 }
 

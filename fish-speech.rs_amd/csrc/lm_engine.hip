@@ -1895,7 +1895,7 @@ class LM final : public LMBase {
 
     // naps before the first sweep of each stage kind (64-clock units; tuned on MI355X, profiles/r03_poll_naps.txt); the environment
     // variables ("a,b,c,d,e,f") override them for tuning runs
-    static constexpr int kNapsFast[6] = {16, 16, 16, 16, 12, 16}, kNapsSlow[6] = {20, 12, 2, 32, 32, 12};  // (re-tuned in round 5 behind the publishing-wave epilogues and the early W13 request: 558.8 -> 551.1 us on the tuner's workload; again at the end of the round: 543.1 -> 542.2)
+    static constexpr int kNapsFast[6] = {16, 16, 16, 16, 12, 16}, kNapsSlow[6] = {24, 16, 2, 32, 36, 12};  // (re-tuned in round 5 behind the publishing-wave epilogues and the early W13 request: 558.8 -> 551.1 us on the tuner's workload; again at the end of the round: 543.1 -> 542.2, and behind the matrix-core S4 of the slow kernel: 541.9 -> 540.3)
     // the same coordinate descent on the in-launch-sampler instantiation of k_fast_persist (680 -> 662 us per sampled frame) and on the
     // e4m3 image of k_slow_persist (595 -> 585 us per fp8 frame): their stage arithmetic differs, so the edges complete at other times
     static constexpr int kNapsFastSampled[6] = {12, 16, 12, 16, 12, 16}, kNapsSlowFp8[6] = {20, 4, 28, 24, 24, 0};  // (round 5 re-tune: profiles/r05_tune_naps.txt)

@@ -651,7 +651,7 @@ def extras(cfg, tok):
         rows["vs_static_batch32"] = {"thirty_two_requests_as_4_launch_groups_of_8_us": round(4 * rows["R8"]["frame_us"], 1),
                                      "static_batch32_step_us": out["static_batch32"]["step_us"],
                                      "note": "the stage chain of the row kernels is latency-bound per launch group, so 32 rows as 4 x R = 8 cost 4 chains: the "
-                                             "MFMA row path (one chain of 373 nodes for all 32 rows) stays the B = 32 path; the row kernels are the 2..8-request path"}
+                                             "MFMA row path (one chain of ~300 nodes for all 32 rows) stays the B = 32 path; the row kernels are the 2..8-request path"}
     out["persistent_rows"] = rows
     # N independent batch-1 request streams on this ONE GPU (own handle, HIP stream and host thread each; no lock-step batching):
     # the frame is a chain of dependent graph nodes whose launch gaps leave the chip idle, so independent chains interleave

@@ -89,7 +89,7 @@ if len(sys.argv) > 5 and ex:
     print(f"   B = 32 decode step, rocprofv3 kernel time differenced over {steps} steps (KV window Lmax + 32..96): {tot:.1f} us of kernels per step")
     for k, v in sorted(per.items(), key=lambda kv: -kv[1])[:12]:
         print(f"      {v:8.1f} us/step  {k.replace('void fs::', '')[:110]}")
-    # 373 dispatches per step: the profiler's per-dispatch timestamping adds 0.3-0.9 us to every node's duration (box to box: the sum came out
+    # ~300 dispatches per step (373 before round 5's folded step): the profiler's per-dispatch timestamping adds 0.3-0.9 us to every node's duration (box to box: the sum came out
     # 7 % and 17 % above the un-profiled HIP-event step time in two runs), so this is a sanity band, not a timing claim -- the step time of
     # record is the HIP-event one; what the table above is for is the SPLIT of the step over its kernels
     check("extras.static_batch32.step_us (HIP events) vs rocprofv3 kernel time per step (profiler-inflated; 25 % sanity band)", ex["static_batch32"]["step_us"], tot, 0.25)

@@ -3354,7 +3354,8 @@ void LmKernels<WT>::rows_layer(const ModelDims& d, int M, const RowsCtx& c, cons
         // 16-row-tiles per wave: 1 everywhere, 2 for the wide W13 (halves the L2 re-reads of the activation fragments).  64-row
         // blocks (rt = 4) were measured for prefill-sized passes and are SLOWER (W13 at 384 rows: 33 -> 41 us): the lost
         // occupancy costs more than the saved fragment traffic.
-        const int rt_qkv = 1, rt_o = 1, rt_13 = 2, rt_2 = 1;
+        static const int rt13_env = [] { const char* e = std::getenv("FISHRT_RT13"); return e ? std::atoi(e) : 0; }();  // experiment hook (1, 2 or 4)
+        const int rt_qkv = 1, rt_o = 1, rt_13 = (rt13_env == 1 || rt13_env == 2 || rt13_env == 4) ? rt13_env : 2, rt_2 = 1;
         const int nblk_o = gemm_big_ok(M, d.dim, d.dim, 1) ? d.dim / GB_ROWS : d.dim / (16 * rt_o);  // blocks of the Wo GEMM (sum-of-squares partials)
         const RowMap rm{c.pos_step, c.pt_stride, c.seq_rows};
         const RowMap none{0, 0, 0};

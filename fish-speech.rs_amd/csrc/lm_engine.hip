@@ -1960,7 +1960,12 @@ class LM final : public LMBase {
         A.x = x(0); A.logits = d_logits_slow_.as<float>(); A.state = state(0);
         A.kv_pool = kv_pool_.p; A.layer_half = (size_t)n_pages_ * page_elems_;
         A.page_table = d_page_table_.as<int>();
-        A.n_sl = std::min(nc_launch_, 16);
+        // Token slices per query head.  8 slices = 128 attention workgroups: the other 128 have no attention item and request their W13 slice
+        // three stages ahead (k_slow_persist early_mode bit 0), and S3 merges 8 partials per head.  16 slices halve S2's tokens per slice but give
+        // every workgroup an item (W13 arrives as one burst again: S4 waits 31 -> 47-49 us per frame) and double S3's sweep: measured per frame
+        // at 8 / 16 slices (profiles/r05_kv_slices.txt): KV 1100 568 / 588 us, 2100 587 / 612, 3100 605 / 611, 4100 624 / 629, 6000 646 / 632
+        // (fp8: 1100 576 / 583, 2100 594 / 602, 4100 631 / 620) -- 16 only beyond 4096 cached tokens.
+        A.n_sl = std::min(nc_launch_, nc_launch_ > 32 ? 16 : 8);
         if (const char* c = getenv("FISHRT_NSL_MAX")) A.n_sl = std::max(1, std::min(A.n_sl, atoi(c)));  // (debug knobs)
         if (const char* c = getenv("FISHRT_NSL_MIN")) A.n_sl = std::min(16, std::max(A.n_sl, atoi(c)));
         // (measured, round 3: half / a quarter as many slices -> S2 +44 / +115 us per frame, S3 only -10 / -12)

@@ -1146,7 +1146,7 @@ constexpr unsigned DOWN_SPIN_MAX = 1u << 17;  // polls of an in-launch exchange 
 template <int NKS, bool FP8>
 __global__ __launch_bounds__(256) void k_gemm_down(const bf16_t* __restrict__ Xf, int M, int K, const void* __restrict__ Wv,
                                                    const float* __restrict__ wscale, int N, float* __restrict__ Y, int ldy, NormAux na,
-                                                   u32x4* __restrict__ xchg, uint32_t* __restrict__ epoch, uint32_t node_id) {
+                                                   u32x4* __restrict__ xchg, uint32_t* __restrict__ epoch, uint32_t node_id, int nap) {
     __shared__ float red[4][16][33];
     const int lane = threadIdx.x & 63, kq = threadIdx.x >> 6;
     const int n0 = blockIdx.x * 16, y = blockIdx.y, ksplit = gridDim.y, rows_per = PF_M / ksplit;
@@ -1211,7 +1211,11 @@ __global__ __launch_bounds__(256) void k_gemm_down(const bf16_t* __restrict__ Xf
         asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(units + (size_t)y * PF_M * 8), "v"(u) : "memory");
         return;
     }
-    // the other blocks' units of this slot: all requests in flight together, retried (only the missing ones) until both tags of each match
+    // the other blocks' units of this slot: all requests in flight together, retried (only the missing ones) until both tags of each match.
+    // The partners finish their K quarter when this block does and their stores take ~1 us to become visible: polling from the first instant
+    // only re-reads units that cannot be there yet (memory-side traffic in front of the stores everybody waits for), so the sweep starts
+    // `nap` x 64 clocks later (as the persistent kernels' pre-sweep naps)
+    for (int i = 0; i < nap; ++i) __builtin_amdgcn_s_sleep(1);
     u32x4 pv[4];
     {
         bool ok[4];
@@ -3317,11 +3321,12 @@ static void launch_gemm_down(hipStream_t st, const bf16_t* Xf, int M, int K, con
                              void* xchg, uint32_t* epoch, uint32_t node_id) {
     FS_REQUIRE(xchg && epoch, "folded decode step without an exchange buffer");
     const int nks = K == 4096 ? 8 : (K == 1024 ? 2 : 1), ksplit = K / (nks * 128);   // 4, 4 (mid-size tests), 2 (tiny tests)
+    static const int nap = [] { const char* e = std::getenv("FISHRT_DOWN_NAP"); return e ? std::atoi(e) : 8; }();  // 64-clock units before the first sweep (0 / 8 / 16 / 24 / 40: 1820 / 1813 / 1820 / 1853 / 1890 us per B = 32 step)
     const dim3 grid(N / 16, ksplit);
 #define FS_DOWN_CASE(nk)                                                                                                              \
     do {                                                                                                                              \
-        if (wscale) hipLaunchKernelGGL((k_gemm_down<nk, true>), grid, dim3(256), 0, st, Xf, M, K, W, wscale, N, Y, ldy, na, (u32x4*)xchg, epoch, node_id);  \
-        else hipLaunchKernelGGL((k_gemm_down<nk, false>), grid, dim3(256), 0, st, Xf, M, K, W, wscale, N, Y, ldy, na, (u32x4*)xchg, epoch, node_id);        \
+        if (wscale) hipLaunchKernelGGL((k_gemm_down<nk, true>), grid, dim3(256), 0, st, Xf, M, K, W, wscale, N, Y, ldy, na, (u32x4*)xchg, epoch, node_id, nap);  \
+        else hipLaunchKernelGGL((k_gemm_down<nk, false>), grid, dim3(256), 0, st, Xf, M, K, W, wscale, N, Y, ldy, na, (u32x4*)xchg, epoch, node_id, nap);        \
     } while (0)
     switch (nks) {
         case 8: FS_DOWN_CASE(8); break;

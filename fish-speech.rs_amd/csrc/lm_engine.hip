@@ -1968,6 +1968,7 @@ class LM final : public LMBase {
         A.n_sl = std::min(nc_launch_, nc_launch_ > 32 ? 16 : 8);
         if (const char* c = getenv("FISHRT_NSL_MAX")) A.n_sl = std::max(1, std::min(A.n_sl, atoi(c)));  // (debug knobs)
         if (const char* c = getenv("FISHRT_NSL_MIN")) A.n_sl = std::min(16, std::max(A.n_sl, atoi(c)));
+        while (A.n_sl & (A.n_sl - 1)) A.n_sl &= A.n_sl - 1;  // the kernel's item mapping needs a power of two (10 / 12 slices: grid-wait timeouts)
         // (measured, round 3: half / a quarter as many slices -> S2 +44 / +115 us per frame, S3 only -10 / -12)
         A.edges = d_sedges_.as<unsigned long long>();
         A.ctl = d_sctl_.as<uint32_t>();

@@ -172,6 +172,7 @@ class LM final : public LMBase {
         (void)hipSetDevice(device_);
         (void)hipStreamSynchronize(st_);
         for (auto& kvp : batch_graphs_) if (kvp.second) (void)hipGraphExecDestroy(kvp.second);
+        for (auto& kvp : multi_graphs_) if (kvp.second) (void)hipGraphExecDestroy(kvp.second);
         for (auto& kvp : graphs_) {
             if (kvp.second.first) (void)hipGraphExecDestroy(kvp.second.first);
             if (kvp.second.second) (void)hipGraphExecDestroy(kvp.second.second);
@@ -335,6 +336,8 @@ class LM final : public LMBase {
         else d_cap_ = DevBuf();
         for (auto& kv : graphs_) { (void)hipGraphExecDestroy(kv.second.first); (void)hipGraphExecDestroy(kv.second.second); }
         graphs_.clear();  // the captured launches carry the buffer pointer
+        for (auto& kv : multi_graphs_) if (kv.second) (void)hipGraphExecDestroy(kv.second);
+        multi_graphs_.clear();
         g_frame_ = g_step_ = nullptr;
         for (auto& kv : batch_graphs_) if (kv.second) (void)hipGraphExecDestroy(kv.second);
         batch_graphs_.clear();  // (the row-path step graphs include the capture kernels only while the hook is armed)
@@ -512,6 +515,7 @@ class LM final : public LMBase {
             }
         }
         std::vector<hipEvent_t> kev;
+        const bool multi_ok = use_persist_ && use_pslow_ && fold_slow_sampler() && !time_k && !b1_rows_fast;
         auto launch_frame = [&](long long it_) {
             set_bucket(n_cached + L + (int)it_);
             if (b1_rows_fast) {  // experiment hook (FISHRT_B1_ROWS_FAST): the fast decoder of this batch-1 request on k_fast_rows<1>
@@ -553,7 +557,23 @@ class LM final : public LMBase {
         struct Batch { long long first, end; int slot; };
         auto enqueue_batch = [&](int sl) {
             Batch b{it, std::min<long long>(n_iter, it + CHUNK), sl};
-            for (; it < b.end; ++it) { launch_frame(it); stats_.graph_launches += 1; }
+            while (it < b.end) {
+                // several frames per graph launch where the batch has them and they share an attention chunk bucket (multi_frame_graph)
+                const int nf = frames_per_graph();
+                if (multi_ok && nf == 0) {
+                    set_bucket(n_cached + L + (int)it);
+                    launch_slow_persist(pslow_args(), st_);
+                    launch_fast_persist(persist_args(), persist_sampled_, st_);
+                    ++it; stats_.graph_launches += 1;
+                } else if (multi_ok && nf > 1 && b.end - it >= nf && chunk_bucket(n_cached + L + (int)it) == chunk_bucket(n_cached + L + (int)it + nf - 1)) {
+                    set_bucket(n_cached + L + (int)it);
+                    use_graphs_for_bucket();  // (keeps the single-frame graph of the bucket current as well)
+                    FS_HIP(hipGraphLaunch(multi_frame_graph(), st_));
+                    it += nf; stats_.graph_launches += (uint64_t)nf;
+                } else {
+                    launch_frame(it); ++it; stats_.graph_launches += 1;
+                }
+            }
             FS_HIP(hipMemcpyAsync(slot_state(sl), state(0), sizeof(SeqState), hipMemcpyDeviceToHost, st_));
             if (cb)  // columns [first, end) of every codebook row (frame index == iteration index until <|im_end|>)
                 FS_HIP(hipMemcpy2DAsync(slot_codes(sl), sizeof(uint32_t) * CHUNK, d_out_.as<uint32_t>() + b.first, sizeof(uint32_t) * out_cap_,
@@ -618,22 +638,26 @@ class LM final : public LMBase {
             for (hipEvent_t e : kev) (void)hipEventDestroy(e);
         }
         if (use_persist_ && getenv("FISHRT_PERSIST_PROF")) {
-            unsigned long long pr[16];
+            unsigned long long pr[24];
             FS_HIP(hipMemcpy(pr, d_ctl_.as<uint32_t>() + 16, sizeof(pr), hipMemcpyDeviceToHost));
             FS_HIP(hipMemset(d_ctl_.as<uint32_t>() + 16, 0, sizeof(pr)));
             const double f = 0.01 / std::max<double>(1.0, (double)stats_.graph_launches - (double)L + 1);  // us per frame
             fprintf(stderr, "persist prof (us/frame, workgroup 0; wait+work): preload %.1f  S1 %.1f+%.1f  S2 %.1f+%.1f  S3 %.1f+%.1f  S4 %.1f+%.1f  head %.1f+%.1f  decision %.1f+%.1f  tail %.1f | S3 split: gemv+reduce %.1f barrier %.1f epilogue %.1f\n",
                     pr[0] * f, pr[9] * f, pr[1] * f, pr[10] * f, pr[2] * f, pr[11] * f, pr[3] * f, pr[12] * f, pr[4] * f, pr[13] * f, pr[5] * f, pr[14] * f, pr[6] * f, pr[7] * f, pr[8] * f, pr[15] * f, pr[3] * f);
+            fprintf(stderr, "persist boundaries (us/frame, workgroup 0): slow kernel's finish -> fast kernel's entry %.2f (%llu frames)  entry -> first stage timer (state, slow-token decision) %.2f  last timer -> finish %.2f\n",
+                    pr[20] ? pr[17] * 0.01 / (double)pr[20] : 0.0, pr[20], pr[18] * f, pr[19] * f);
         }
         if (use_pslow_) {
             if (getenv("FISHRT_PERSIST_PROF")) {
-                unsigned long long pr[16];
+                unsigned long long pr[24];
                 FS_HIP(hipMemcpy(pr, d_sctl_.as<uint32_t>() + 16, sizeof(pr), hipMemcpyDeviceToHost));
                 FS_HIP(hipMemset(d_sctl_.as<uint32_t>() + 16, 0, sizeof(pr)));
                 const double f = 0.01 / std::max<double>(1.0, (double)stats_.graph_launches - (double)L + 1);
                 fprintf(stderr, "slow persist prof (us/frame, workgroup %d; wait+work): S1 %.1f+%.1f  S2 %.1f+%.1f  S3 %.1f+%.1f  S4 %.1f+%.1f  S5 %.1f+%.1f  head %.1f+%.1f\n",
                         getenv("FISHRT_PERSIST_PROF_WG") ? atoi(getenv("FISHRT_PERSIST_PROF_WG")) : 0, pr[9] * f, pr[1] * f, pr[10] * f, pr[2] * f, pr[11] * f, pr[3] * f,
                         pr[12] * f, pr[4] * f, pr[13] * f, pr[5] * f, pr[14] * f, pr[6] * f);
+                fprintf(stderr, "slow persist boundaries (us/frame): fast kernel's finish -> slow kernel's entry %.2f (%llu frames)  entry -> first stage timer (state, first loads) %.2f  last timer -> finish %.2f\n",
+                        pr[20] ? pr[17] * 0.01 / (double)pr[20] : 0.0, pr[20], pr[18] * f, pr[19] * f);
             }
             uint32_t ctl[4] = {0, 0, 0, 0};
             FS_HIP(hipMemcpy(ctl, d_sctl_.p, sizeof(ctl), hipMemcpyDeviceToHost));
@@ -1380,6 +1404,8 @@ class LM final : public LMBase {
         launch_frame(0);
         FS_HIP(hipEventRecord(ev_[1], st_));
         long long it = 1;
+        // (direct launches: 8 frames of these launches in ONE graph were measured at 940.9 vs 937.6 us per 4-row frame, 1575.5 vs 1576.7 at R = 8 --
+        // back-to-back launches on a stream already pay what a graph edge does; the 7 us the batch-1 loop saved belong to hipGraphLaunch)
         while (it < max_iter) {
             const long long end = std::min<long long>(max_iter, it + 32);
             for (; it < end; ++it) launch_frame(it);
@@ -1920,7 +1946,7 @@ class LM final : public LMBase {
                 d_pack_.alloc(fast_persist_pack_bytes());
                 d_edges_.alloc(fast_persist_edge_bytes());
                 FS_HIP(hipMemset(d_edges_.p, 0, d_edges_.n));
-                d_ctl_.alloc(256);
+                d_ctl_.alloc(320);
                 FS_HIP(hipMemset(d_ctl_.p, 0, d_ctl_.n));
                 if (FP8) d_fscl_.alloc(sizeof(float) * (size_t)PF_BLOCKS * PF_SCL);
             }
@@ -1937,7 +1963,7 @@ class LM final : public LMBase {
                 d_snorms_.alloc(sizeof(float) * (size_t)(2 * a_.n_layer + 1) * a_.dim);
                 d_sedges_.alloc(slow_persist_edge_bytes());
                 FS_HIP(hipMemset(d_sedges_.p, 0, d_sedges_.n));
-                d_sctl_.alloc(256);
+                d_sctl_.alloc(320);
                 FS_HIP(hipMemset(d_sctl_.p, 0, d_sctl_.n));
             }
             std::vector<const float*> np;
@@ -1973,6 +1999,7 @@ class LM final : public LMBase {
         A.edges = d_sedges_.as<unsigned long long>();
         A.ctl = d_sctl_.as<uint32_t>();
         A.prof = getenv("FISHRT_PERSIST_PROF") ? reinterpret_cast<unsigned long long*>(d_sctl_.as<uint32_t>() + 16) : nullptr;
+        A.peer_stamps = (A.prof && d_ctl_.p) ? reinterpret_cast<const unsigned long long*>(d_ctl_.as<uint32_t>() + 16) + 16 : nullptr;
         set_naps(A.naps, "FISHRT_NAPS_SLOW", kFp8 ? kNapsSlowFp8 : kNapsSlow);
         A.prof_wg = getenv("FISHRT_PERSIST_PROF_WG") ? atoi(getenv("FISHRT_PERSIST_PROF_WG")) : 0;
         A.l2_touch = getenv("FISHRT_SLOW_EARLY") ? atoi(getenv("FISHRT_SLOW_EARLY")) : 1;  // k_slow_persist early_mode bits
@@ -1998,6 +2025,7 @@ class LM final : public LMBase {
         A.edges = d_edges_.as<unsigned long long>();
         A.ctl = d_ctl_.as<uint32_t>();
         A.prof = getenv("FISHRT_PERSIST_PROF") ? reinterpret_cast<unsigned long long*>(d_ctl_.as<uint32_t>() + 16) : nullptr;
+        A.peer_stamps = (A.prof && d_sctl_.p) ? reinterpret_cast<const unsigned long long*>(d_sctl_.as<uint32_t>() + 16) + 16 : nullptr;
         set_naps(A.naps, "FISHRT_NAPS_FAST", persist_sampled_ ? kNapsFastSampled : kNapsFast);
         return A;
     }
@@ -2208,6 +2236,32 @@ class LM final : public LMBase {
     // KV
     int max_pages_ = 0, n_pages_ = 0, out_cap_ = 0, n_chunks_ = 0, nc_launch_ = 1;
     std::map<int, std::pair<hipGraphExec_t, hipGraphExec_t>> graphs_;  // attention chunk bucket -> (frame, prefill-step) graphs
+    std::map<int, hipGraphExec_t> multi_graphs_;                       // same key -> kFramesPerGraph frames of the two persistent launches in ONE graph
+    // Measured with the launch-boundary stamps of FISHRT_PERSIST_PROF (s_memrealtime, one clock for all kernels): the slow kernel's finish ->
+    // the fast kernel's entry inside a graph is 1.9 us, the fast kernel's finish -> the NEXT graph launch's slow kernel 7.2-7.3 us.  A graph
+    // that holds several frames pays the 1.9 us edge between them (the kernels read positions / epochs from device memory, so a frame's two
+    // launches are the same nodes every time; frames past <|im_end|> are no-ops on the device as in the per-frame replay).
+    static int frames_per_graph() {
+        static const int v = [] { const char* e = getenv("FISHRT_FRAMES_PER_GRAPH"); const int n = e ? atoi(e) : 8; return n < 0 ? 1 : (n > 32 ? 32 : n); }();  // 0: no graph, the two launches of every frame directly (experiment)
+        return v;
+    }
+    hipGraphExec_t multi_frame_graph() {  // for the bucket currently in nc_launch_; the persistent 2-launch frame only
+        const int key = nc_launch_ * 8 + (persist_sampled_ ? 4 : 0);
+        auto it = multi_graphs_.find(key);
+        if (it != multi_graphs_.end()) return it->second;
+        hipGraph_t g = nullptr;
+        hipGraphExec_t ge = nullptr;
+        FS_HIP(hipStreamBeginCapture(st_, hipStreamCaptureModeThreadLocal));
+        for (int f = 0; f < frames_per_graph(); ++f) {
+            launch_slow_persist(pslow_args(), st_);
+            launch_fast_persist(persist_args(), persist_sampled_, st_);
+        }
+        FS_HIP(hipStreamEndCapture(st_, &g));
+        FS_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        FS_HIP(hipGraphDestroy(g));
+        multi_graphs_[key] = ge;
+        return ge;
+    }
     size_t page_elems_ = 0;
     DevBuf kv_pool_, fast_pool_, d_page_table_, d_zero_table_;
     std::vector<int> free_pages_, seq_len_, fast_len_;

@@ -54,7 +54,8 @@ struct FastPersistArgs {
     uint32_t* out_codes;
     int out_cap;
     unsigned long long* edges;  // [PF_RING][PF_REPL][PF_EDGE_CAP] granules (zeroed once at allocation)
-    unsigned long long* prof;   // null, or [16]: workgroup 0 accumulates 10 ns ticks per stage kind (FISHRT_PERSIST_PROF=1)
+    unsigned long long* prof;   // null, or [16 + 8]: workgroup 0 accumulates 10 ns ticks per stage kind (FISHRT_PERSIST_PROF=1); [16..]: launch-boundary stamps
+    const unsigned long long* peer_stamps;  // prof only: the slow kernel's stamp area (its [0] = the absolute time its timed workgroup finished)
     uint32_t* ctl;              // [0] launch counter (tag epoch), [1] spin-timeout count (host checks it), [2] launches whose sampling configuration does not match the instantiation
     int naps[6];                // 64-clock naps before the first sweep of S1 / S2 / S3 / S4 / head / decision (lm_persist_dev.h pf_nap_before_sweep)
 };
@@ -84,7 +85,8 @@ struct SlowPersistArgs {
     const int* page_table;
     int n_sl;               // token slices per head of the attention stage (1, 2, 4, 8 or 16)
     unsigned long long* edges;  // [PF_RING][PF_REPL][PS_EDGE_CAP]
-    unsigned long long* prof;
+    unsigned long long* prof;   // null, or [16 + 8] (see FastPersistArgs)
+    const unsigned long long* peer_stamps;  // prof only: the fast kernel's stamp area
     uint32_t* ctl;          // [0] epoch, [1] timeouts
     int naps[6];            // 64-clock naps before the first sweep of S1 / S2 / S3 / S4 / S5 / head
     int prof_wg;            // the workgroup whose stage timers go to `prof` (FISHRT_PERSIST_PROF_WG; default 0 = an attention workgroup)

@@ -147,6 +147,9 @@ __global__ void k_pf_pack_scales(LayerW w0, LayerW w1, LayerW w2, LayerW w3, con
 template <bool SAMPLED>
 __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // launch-boundary stamps (FISHRT_PERSIST_PROF; s_memrealtime is one clock for all kernels): prof[16] = when this launch's workgroup 0 finished,
+    // [17] += entry - the slow kernel's finish, [18] += entry -> first stage timer (per-frame state + the slow-token decision), [19] += last timer -> finish
+    const unsigned long long t_entry = A.prof ? wall_clock64() : 0;
     u32x4* w2s = reinterpret_cast<u32x4*>(smem + L_W2);
     uint32_t* kc = reinterpret_cast<uint32_t*>(smem + L_KC);
     uint32_t* vc = reinterpret_cast<uint32_t*>(smem + L_VC);
@@ -284,6 +287,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
     bool dead = false;
     float x0 = 0.f, x1 = 0.f;
     unsigned long long tk[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = A.prof ? wall_clock64() : 0;
+    const unsigned long long t_timers = t_last;
 #define PF_TICK(k) do { if (A.prof) { const unsigned long long n_ = wall_clock64(); tk[k] += n_ - t_last; t_last = n_; } } while (0)
     if (!eos) {
         // ---- resident weights: 42 register chunks + 16 LDS chunks per lane
@@ -730,7 +734,14 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
         *reinterpret_cast<float2*>(A.x + 2 * tid) = make_float2(e0, e1);
     }
     PF_TICK(7);
-    if (A.prof && tid == 0) for (int k = 0; k < 16; ++k) A.prof[k] += tk[k];
+    if (A.prof && tid == 0) {
+        for (int k = 0; k < 16; ++k) A.prof[k] += tk[k];
+        const unsigned long long t_end = wall_clock64(), peer_end = A.peer_stamps ? A.peer_stamps[0] : 0;
+        if (peer_end && t_entry > peer_end && t_entry - peer_end < 20000) { A.prof[17] += t_entry - peer_end; A.prof[20] += 1; }
+        A.prof[18] += t_timers - t_entry;
+        A.prof[19] += t_end - t_last;
+        A.prof[16] = t_end;
+    }
 #undef PF_TICK
 }
 

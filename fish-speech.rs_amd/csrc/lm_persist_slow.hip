@@ -210,6 +210,7 @@ __global__ void k_ps_copy_norm(const float* __restrict__ src, float* __restrict_
 template <bool FP8>
 __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned long long t_entry = A.prof ? wall_clock64() : 0;  // launch-boundary stamps: see k_fast_persist
     float* xs = reinterpret_cast<float*>(smem + S_XS);
     float* red = reinterpret_cast<float*>(smem + S_RED);
     float* qs = reinterpret_cast<float*>(smem + S_QS);
@@ -314,6 +315,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
         }
     };
     unsigned long long tk[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = A.prof ? wall_clock64() : 0;  // [1..6] work of S1..S5 / head, [9..14] the wait (nap + sweep) in front of it
+    const unsigned long long t_timers = t_last;
 #define PS_TICK(k) do { if (A.prof) { const unsigned long long n_ = wall_clock64(); tk[k] += n_ - t_last; t_last = n_; } } while (0)
 
     // tile 0 of this workgroup's slice is the same rows of every layer's pool: its element offsets are computed ONCE (the per-layer request
@@ -851,7 +853,14 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
         PS_TICK(6);
     }
     if (b == 0 && tid == 0) A.ctl[0] = epoch + 1;
-    if (A.prof && b == A.prof_wg && tid == 0) for (int k = 0; k < 16; ++k) A.prof[k] += tk[k];
+    if (A.prof && b == A.prof_wg && tid == 0) {
+        for (int k = 0; k < 16; ++k) A.prof[k] += tk[k];
+        const unsigned long long t_end = wall_clock64(), peer_end = A.peer_stamps ? A.peer_stamps[0] : 0;
+        if (peer_end && t_entry > peer_end && t_entry - peer_end < 20000) { A.prof[17] += t_entry - peer_end; A.prof[20] += 1; }  // (the first frame of a request follows the prefill)
+        A.prof[18] += t_timers - t_entry;
+        A.prof[19] += t_end - t_last;
+        A.prof[16] = t_end;
+    }
 #undef PS_TICK
 }
 

@@ -52,7 +52,7 @@ for name, nb, nbm in (("k_slow_persist", b_slow, b_slow), ("k_fast_persist", b_f
     check(f"{name} frac", k["frac"], nb / (k["avg_us"] * 1e-6) / bench.HBM_PEAK, 2e-3)
     check(f"{name} frac_min", k["frac_min"], nbm / (k["avg_us"] * 1e-6) / bench.HBM_PEAK, 2e-3)
 ssum = sum(r["kernels"][n]["avg_us"] for n in r["kernels"])
-print(f"   sum of the two kernels {ssum:.1f} us vs frame {r['frame_us']:.1f} us (the difference = the two launch boundaries of a replay)")
+print(f"   sum of the two kernels {ssum:.1f} us vs frame {r['frame_us']:.1f} us (per-kernel figures: direct launches with a HIP event in front of / between / behind them; frame: the event-free replay of 8-frame graphs)")
 ok &= ssum <= r["frame_us"] * 1.02
 if len(sys.argv) > 3:
     pmc = json.load(open(sys.argv[3]))

@@ -12,7 +12,7 @@ configs[3] instead (256 requests sharded i mod N, static batches of 32 per GPU, 
 ranks exercise the control path only (dry run, value null): libfishrt has no CPU path.
 
 Extra objects on the JSON line:
-  roofline     -- HBM roofline of the decode FRAME (one hipGraph replay = the unit of the hot loop: the two persistent launches
+  roofline     -- HBM roofline of the decode FRAME (the unit of the hot loop, replayed from hipGraphs of 8 frames: the two persistent launches
                   k_slow_persist + k_fast_persist; 266 kernels with --no-persistent):
                   achieved = B_frame(T_avg) / t_frame, t_frame from HIP events recorded on the engine's own stream
                   (fs_lm_last_stats); B_frame is SURVEY.md §8(d)'s algorithmic-bytes formula; frac_min prices the same time against
@@ -375,7 +375,7 @@ def main():
                    "parallelism": f"replicas x{world} (no data-path collective; codes all-gathered over RCCL after the run)"},
         "rtf": round((frames_total / FRAME_RATE) / dt, 2), "rccl_ranks": int(seen), "weight_broadcast": wbcast, "frames_per_rank": [int(v) for v in fa.sum(axis=1) * args.steps],
         "decode_frames_per_s_per_gpu": round(1.0 / t_frame, 2), "prefill_ms": round(pre_ms, 3),
-        "roofline": {"bound": "hbm", "kernel": (f"decode frame = one hipGraph replay of {kpf} kernels: " +
+        "roofline": {"bound": "hbm", "kernel": (f"decode frame = {kpf} kernels of a hipGraph replay (8 frames per graph launch on the persistent path): " +
                                                ("k_slow_persist (24 slow blocks + head) then k_fast_persist (slow-token decision, 8 codebook passes, 8 decisions)" if kpf == 2 else
                                                 "24 slow blocks x 5 + head + sample, then 8 x (4 fast blocks x 4 + head + sample)")
                                                + "; HIP-event timed on the engine stream"),

@@ -190,3 +190,60 @@ def test_row_kernels_kv_forced_oracle(n, sampling, dtype):
         assert ws < SLOW_TOL and wf < FAST_TOL and w0 < 1e-2, (i, ws, w0, wf)
         worst = [max(worst[0], ws), max(worst[1], wf)]
     lm.close()
+
+
+def _kv_forced_batch_row(o, lm, row, padded, cap, codes, n_layer):
+    """static-batch row (left-padded prompt, no repetition penalty): max |dlogit| of the SLOW logits over frames >= 1 with the oracle attending
+    over the rows the GPU cached for this row (the row path's captures carry no fast-decoder K/V, so the fast logits stay with the bf16
+    protocol of tests/test_batch_capture_gpu.py), and for frame 0 (oracle's own prefill rows)"""
+    F, L = codes.shape[1], padded.shape[1]
+    gk = [lm.debug_read_kv(l, 0, L + F - 1, slot=row) for l in range(n_layer)]
+    slow_tok = cap[:F, 0, 2047].astype(np.int64) + IM_END
+    o.clear_slow()
+    cur, pos, ws, w0, units = padded, 0, 0.0, 0.0, 0.0
+    for f in range(F):
+        if f > 0:
+            for l in range(n_layer):
+                o.force_kv(l, gk[l][0][pos], gk[l][1][pos])
+        lg, _ = o.forward_generate(cur, pos, full_head=False)
+        n = cur.shape[1]
+        if f > 0:
+            units = max([units] + [o.force_kv_diff(l) for l in range(n_layer)])
+        for l in range(n_layer):
+            o.set_kv(l, pos, gk[l][0][pos:pos + n], gk[l][1][pos:pos + n])
+        d = float(np.abs(lg[0, IM_END:][1:] - cap[f, 0, 1:N_AUDIO]).max())
+        if f == 0:
+            w0 = d
+        else:
+            ws = max(ws, d)
+        pos += n
+        cur = np.array([slow_tok[f]] + [int(v) for v in codes[:, f]], np.uint32).reshape(9, 1)
+    assert units <= 16.0, f"a slow-layer K/V entry the row path cached is {units:.2f} units (bf16 ulp, floored at 2^-17) from the oracle's"
+    return ws, w0, units
+
+
+@pytest.mark.parametrize("B,dtype", [(32, "bf16"), (12, "fp8")], ids=["B32", "B12-fp8"])
+def test_static_batch_step_kv_forced_oracle(B, dtype):
+    """the folded static-batch decode step (round 5: Wqkv with the rms epilogue, k_attn_rows, Wo, W13, k_gemm_down with the in-launch split-K
+    sums, head with the rms epilogue; B <= 16 takes the half-panel GEMMs) against the ORACLE at the tolerance of the persistent kernels:
+    rows of a BASELINE configs[2]-shaped batch, each teacher-forced on its own sampled tokens and its own cached K/V rows"""
+    F = 10
+    kw = dict(temp=0.7, top_p=0.8, top_k=256)
+    prompts = bench.config2_prompts(TOK, B)
+    lens = [p.shape[1] for p in prompts]
+    Lmax = max(lens)
+    lm = fishrt.DualARTransformer(fcfg.FISH_1_5, TOK, 0, dtype, max_batch=B).load_synthetic(SEED)
+    lm.debug_capture(F)
+    outs = lm.generate_static_batch(prompts, F + Lmax - 2, seed=9, ignore_eos=True, **kw)
+    o = orc.OracleLM(orc.FISH15).load_synthetic(SEED, bf16=(dtype == "bf16"), fp8=(dtype == "fp8"))
+    o.set_kv_round_bf16(True)
+    for b in (0, B // 2 - 1, B - 1):
+        padded = np.zeros((9, Lmax), np.uint32)
+        padded[0, : Lmax - lens[b]] = IM_END
+        padded[:, Lmax - lens[b]:] = prompts[b]
+        ws, w0, units = _kv_forced_batch_row(o, lm, b, padded, lm.debug_read_row(b, F), outs[b], fcfg.FISH_1_5["n_layer"])
+        _report(f"static-batch step (folded, B {B}, {dtype}): row {b} (L {lens[b]} left-padded to {Lmax}), {F} frames: max |dlogit| slow {ws:.2e} "
+                f"(frame 0, own K/V: {w0:.2e}); own K/V rows within {units:.1f} units")
+        assert ws < SLOW_TOL and w0 < 1e-2, (b, ws, w0)
+    lm.debug_capture(0)
+    lm.close()

@@ -75,6 +75,7 @@ int fs_selftest_sample_rows(int device_id, const float* logits, int B, int n, co
     FS_TRY(fs::debug_sample_rows(device_id, logits, B, n, s->temp, s->top_p, s->top_k, seed, call_index, out))
 }
 
+int fs_lm_selftest(fs_lm_t* lm, const char* what) { FS_ARG(lm && what, "null argument"); FS_TRY(lm->impl->selftest(what)) }
 int fs_lm_debug_capture(fs_lm_t* lm, int n_frames) { FS_ARG(lm, "null argument"); FS_TRY(lm->impl->debug_capture(n_frames)) }
 int fs_lm_debug_read(fs_lm_t* lm, float* out, int n_frames) { FS_ARG(lm && out, "null argument"); FS_TRY(lm->impl->debug_read(out, n_frames)) }
 

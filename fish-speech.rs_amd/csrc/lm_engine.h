@@ -46,6 +46,7 @@ class LMBase {
     virtual void debug_read(float* out, int n_frames) = 0;
     virtual void debug_read_row(int row, float* out, int n_frames) = 0;
     virtual void debug_read_kv(int slot, int layer, int t0, int n, float* k_out, float* v_out) = 0;
+    virtual void selftest(const char* what) = 0;  // fishrt.h: fs_lm_selftest
     virtual fs_gen_stats last_stats() = 0;
     virtual void* stream() = 0;
     // measurement hook: average duration (us) of ONE launch of decode kernel `kind` (0 qkv, 1 attention, 2 wo, 3 ffn_up, 4 ffn_down) as a

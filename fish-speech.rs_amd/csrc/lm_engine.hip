@@ -339,8 +339,7 @@ class LM final : public LMBase {
         for (auto& kv : multi_graphs_) if (kv.second) (void)hipGraphExecDestroy(kv.second);
         multi_graphs_.clear();
         g_frame_ = g_step_ = nullptr;
-        for (auto& kv : batch_graphs_) if (kv.second) (void)hipGraphExecDestroy(kv.second);
-        batch_graphs_.clear();  // (the row-path step graphs include the capture kernels only while the hook is armed)
+        drop_batch_graphs();  // (the row-path step graphs include the capture kernels only while the hook is armed)
         if (!n_frames) d_rcap_ = DevBuf();
     }
     void debug_read(float* out, int n_frames) override {
@@ -386,6 +385,60 @@ class LM final : public LMBase {
     }
     fs_gen_stats last_stats() override { return stats_; }
     void* stream() override { return (void*)st_; }
+
+    // fs_lm_selftest("persist"): the persistent decode kernels of THIS binary against the per-node kernels, on the loaded
+    // weights.  k_slow_persist requests weight slices through loads the compiler's wait-count pass does not see (lm_persist_slow.hip:
+    // ps_load16_unseen) and k_fast_persist keeps 168 pinned weight registers per lane -- both depend on how hipcc allocates registers, so a
+    // toolchain or flag change must be caught by running, not by reading.  Protocol: a 12-position prompt, 4 greedy frames on the
+    // persistent path with the decision capture armed; then ONE teacher-forced per-node step (forward_generate at the position of frame 1,
+    // fed frame 0's picks; forward_generate_fast on its hidden state) and a comparison of frame 1's captured logits -- the first slow
+    // step k_slow_persist computed, the first codebook pass of k_fast_persist behind it -- with the per-node logits.  Both paths share the
+    // prefill's K/V rows and differ in summation order only, so the bound is loose for rounding and tight for a wrong weight register:
+    // 2e-2 x max(1, max |logit|).
+    void selftest(const char* what) override {
+        use_device();
+        require_loaded();
+        FS_REQUIRE(what && std::string(what) == "persist", "unknown handle self-test (known: \"persist\")");
+        FS_REQUIRE(!sess_active_, "the handle is in session mode (fs_lm_session_end first)");
+        FS_REQUIRE(cap_frames_ == 0, "decision capture is armed (fs_lm_debug_capture(lm, 0) first)");
+        if (!persist_ok_ || !pslow_ok_) throw Error("self-test \"persist\": this handle has no persistent kernels (dtype / geometry / device)");
+        const int C = a_.num_codebooks, C1 = C + 1, L = 12;
+        const SampleCfg cfg = base_cfg();
+        std::vector<uint32_t> prompt((size_t)C1 * L, 0u);
+        const uint32_t n_text = std::max<uint32_t>(1u, std::min<uint32_t>(cfg.im_end_id, 1000u));
+        for (int i = 0; i < L; ++i) prompt[i] = (uint32_t)((7919ull * (uint64_t)(i + 1) + 13ull) % n_text);
+        clear_slow();
+        debug_capture(2);
+        struct Restore { LM* lm; ~Restore() { try { lm->debug_capture(0); lm->clear_slow(); lm->clear_fast(); } catch (...) {} } } restore{this};
+        fs_sampling sa = {};
+        sa.temp = 0.0; sa.top_p = 1.0; sa.top_k = 0; sa.repetition_penalty = 1.0f;
+        std::vector<uint32_t> codes((size_t)C * 8, 0u);
+        size_t nf = 0;
+        generate(prompt.data(), L, L + 2, sa, 1, FS_GEN_IGNORE_EOS, codes.data(), 8, &nf, nullptr, nullptr, nullptr, 0, nullptr);
+        if (stats_.kernels_per_frame != 2)
+            throw Error("self-test \"persist\": the call did not take the persistent kernels (another handle of this GPU holds them?)");
+        std::vector<float> cap((size_t)2 * 9 * 2048);
+        debug_read(cap.data(), 2);
+        std::vector<uint32_t> in(C1);
+        in[0] = legacy_ ? cfg.pad_id : audio_tok(cfg, (int)cap[2047]);
+        for (int c = 0; c < C; ++c) in[1 + c] = (uint32_t)cap[(size_t)(1 + c) * 2048 + 1024];
+        clear_slow_until(L);
+        std::vector<float> lg(a_.vocab_size), hid(a_.dim), lf(a_.codebook_size);
+        forward_generate(in.data(), 1, 1, L, lg.data(), hid.data());
+        clear_fast();
+        forward_generate_fast(hid.data(), 1, 0, lf.data());
+        const float* c_slow = cap.data() + (size_t)(9 + 0) * 2048;
+        const float* c_fast = cap.data() + (size_t)(9 + 1) * 2048;
+        float worst = 0.f, scale = 1.f;
+        auto cmp = [&](float ref, float got) { scale = std::max(scale, std::fabs(ref)); worst = std::max(worst, std::fabs(ref - got)); };
+        if (legacy_) { cmp(lg[cfg.pad_id], c_slow[0]); cmp(lg[cfg.im_end_id], c_slow[1]); }
+        else for (int i = 1; i < n_audio_; ++i) cmp(lg[audio_tok(cfg, i)], c_slow[i]);  // (index 0 = <|im_end|>: masked to -inf under FS_GEN_IGNORE_EOS)
+        const float worst_slow = worst;
+        for (int i = 0; i < a_.codebook_size; ++i) cmp(lf[i], c_fast[i]);
+        if (!(worst <= 2e-2f * scale))
+            throw Error("self-test \"persist\": persistent kernels disagree with the per-node kernels (max |dlogit| slow " + std::to_string(worst_slow) +
+                        ", all " + std::to_string(worst) + " at logit scale " + std::to_string(scale) + "): rebuild with the pinned toolchain or run with FISHRT_NO_PERSIST=1");
+    }
 
     float bench_kernel(int kind, int kv_len, int reps) override {
         use_device();
@@ -1806,7 +1859,12 @@ class LM final : public LMBase {
         if (e[1] != 0) {
             const uint32_t z = 0;
             FS_HIP(hipMemcpy(d_epoch_.as<uint32_t>() + 1, &z, sizeof(z), hipMemcpyHostToDevice));
-            throw Error("static-batch decode: " + std::to_string(e[1]) + " split-K exchange waits timed out (FISHRT_ROWS_NO_FOLD=1 selects the slab path)");
+            // this call's tokens are garbage (reported), but the handle recovers: the folded step is off from now on and the captured step
+            // graphs are dropped, so the next call runs the slab + k_prep step instead of timing out again
+            fold_off_ = true;
+            drop_batch_graphs();
+            throw Error("static-batch decode: " + std::to_string(e[1]) + " split-K exchange waits timed out (a down projection's blocks were not co-resident); "
+                        "this handle falls back to the slab path for its next calls");
         }
     }
     void ensure_batch_buffers() {
@@ -1839,7 +1897,7 @@ class LM final : public LMBase {
         cs.nc_launch = nc_launch_;
         // decode steps of <= 32 rows: the down projections close every layer themselves (in-launch split-K sums: no slabs, no k_prep nodes but the first)
         cs.xchg = d_xchg_.p; cs.epoch = d_epoch_.as<uint32_t>();
-        const bool fold = LmKernels<WT>::rows_fold_ok(d_, B, cs) && a_.n_layer <= 64 && a_.n_fast_layer <= 8 && C <= 32;
+        const bool fold = !fold_off_ && LmKernels<WT>::rows_fold_ok(d_, B, cs) && a_.n_layer <= 64 && a_.n_fast_layer <= 8 && C <= 32;
         cs.fold = fold;
         for (int l = 0; l < a_.n_layer; ++l, cs.node_id = (uint32_t)l)
             LmKernels<WT>::rows_layer(d_, B, cs, slow_[l], slow_kv(l, 0), l == 0, st_, fold ? (l + 1 < a_.n_layer ? slow_[l + 1].attn_norm : norm_w_) : nullptr);
@@ -1889,10 +1947,19 @@ class LM final : public LMBase {
         d_rcap_.alloc(sizeof(float) * (size_t)B * cap_frames_ * 9 * 2048);
         FS_HIP(hipMemsetAsync(d_rcap_.p, 0, d_rcap_.n, st_));
     }
+    void drop_batch_graphs() {
+        for (auto& kv : batch_graphs_) if (kv.second) (void)hipGraphExecDestroy(kv.second);
+        batch_graphs_.clear();
+    }
     hipGraphExec_t batch_graph(int B) {
         const int key = (sess_active_ ? 1 << 24 : 0) + (rows_par_ ? 1 << 25 : 0) + B * 1024 + nc_launch_;
         auto it = batch_graphs_.find(key);
         if (it != batch_graphs_.end()) return it->second;
+        {   // the co-residency query of the folded step (rows_fold_ok -> occupancy API) is answered once, OUTSIDE stream capture
+            RowsCtx cs = rows_ctx(state(0), 0, max_pages_);
+            cs.xchg = d_xchg_.p; cs.epoch = d_epoch_.as<uint32_t>();
+            (void)LmKernels<WT>::rows_fold_ok(d_, B, cs);
+        }
         hipGraph_t g = nullptr;
         hipGraphExec_t ge = nullptr;
         // warm every kernel once outside capture (function attributes are set lazily on first launch)
@@ -1951,6 +2018,11 @@ class LM final : public LMBase {
                 if (FP8) d_fscl_.alloc(sizeof(float) * (size_t)PF_BLOCKS * PF_SCL);
             }
             launch_fast_persist_pack(fast_.data(), fast_out_w_, d_pack_.p, st_, FP8, fast_out_s_, d_fscl_.as<float>());
+            // layer-0 qkv table of the codebook passes 1..7 (lm_persist.hip: 7 of a frame's 137 stages become three loads per lane)
+            if (!getenv("FISHRT_FAST_NO_QKV0")) {
+                if (!d_qkv0_.p) d_qkv0_.alloc(fast_persist_qkv0_bytes());
+                launch_fast_persist_qkv0_table(d_pack_.p, FP8 ? d_fscl_.as<float>() : nullptr, fast_[0].attn_norm, fast_emb_, d_.eps, d_qkv0_.as<float>(), st_);
+            }
             FS_HIP(hipStreamSynchronize(st_));
             persist_ok_ = true;
             // slow transformer: same geometry, the audio-range head must fit 8 rows per workgroup
@@ -2014,6 +2086,7 @@ class LM final : public LMBase {
         for (int l = 0; l < PF_LAYERS; ++l) { A.norms[2 * l] = fast_[l].attn_norm; A.norms[2 * l + 1] = fast_[l].ffn_norm; }
         A.norms[2 * PF_LAYERS] = fast_norm_w_;
         A.fast_emb = fast_emb_; A.tok_emb = tok_emb_; A.cb_emb = cb_emb_;
+        A.qkv0_tbl = d_qkv0_.p ? d_qkv0_.as<float>() : nullptr;
         A.cos_t = d_cos_.as<float>(); A.sin_t = d_sin_.as<float>();
         A.eps = d_.eps;
         const bool fold = fold_slow_sampler();
@@ -2269,7 +2342,7 @@ class LM final : public LMBase {
     // activations / state
     DevBuf d_x_, d_xf_, d_q_, d_part_, d_act_, d_logits_slow_, d_logits_fast_, d_state_, d_cfg_, d_rng_, d_prompt_, d_out_;
     DevBuf d_rp_mask_, d_rp_seen_, d_rp_ring_, d_rp_meta_;
-    DevBuf d_pack_, d_edges_, d_ctl_;  // persistent fast decoder
+    DevBuf d_pack_, d_edges_, d_ctl_, d_qkv0_;  // persistent fast decoder (+ the layer-0 qkv table of the codebook passes 1..7)
     DevBuf d_fscl_, d_sscl_;           // FS_FP8 handles: row scales of the persistent kernels' images
     DevBuf d_cap_;                     // fs_lm_debug_capture
     int cap_frames_ = 0;
@@ -2300,6 +2373,7 @@ class LM final : public LMBase {
     DevBuf d_xchg_, d_epoch_;  // folded decode steps: split-K exchange units, {step epoch, timeouts}
     bool rows_par_ = false;  // this batch / session samples with the block-parallel row samplers
     int ld_slow_ = 0, down_split_ = 4;
+    bool fold_off_ = false;  // set after a reported exchange timeout of the folded decode step: the handle keeps the slab path from then on
     bool batch_warm_ = false;
     std::map<int, hipGraphExec_t> batch_graphs_;
     RepPenState rp_ = {};

@@ -3340,11 +3340,40 @@ static bool rows_fold_enabled() {
     static const bool v = [] { const char* e = std::getenv("FISHRT_ROWS_NO_FOLD"); return !(e && std::atoi(e) != 0); }();
     return v;
 }
+// k_gemm_down's owner waves spin on units published by the other K-quarter blocks of the SAME launch: every block of the grid must be
+// resident at once.  The grid is dispatched y = 0 first; on a device (or partition: CPX, a masked-off part) where
+// occupancy x CUs < N / 16 x ksplit the owners of resident tiles would wait for blocks that cannot be scheduled.  Checked once per
+// (device, instantiation) with the runtime's occupancy query; such devices keep the slab + k_prep step.
+template <int NKS, bool FP8>
+static bool gemm_down_resident_inst(int blocks) {
+    static int cached_dev = -1, cached_cap = 0;
+    int dev = 0;
+    FS_HIP(hipGetDevice(&dev));
+    if (dev != cached_dev) {
+        int per_cu = 0;
+        hipDeviceProp_t prop;
+        FS_HIP(hipGetDeviceProperties(&prop, dev));
+        FS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k_gemm_down<NKS, FP8>), 256, 0));
+        cached_cap = per_cu * prop.multiProcessorCount;
+        cached_dev = dev;
+    }
+    if (const char* e = std::getenv("FISHRT_DOWN_FAKE_CAPACITY")) return std::atoi(e) >= blocks;  // (test hook: pretend a smaller device)
+    return cached_cap >= blocks;
+}
+static bool gemm_down_resident(int N, int K, bool fp8) {
+    const int nks = K == 4096 ? 8 : (K == 1024 ? 2 : 1), ksplit = K / (nks * 128), blocks = (N / 16) * ksplit;
+    switch (nks) {
+        case 8: return fp8 ? gemm_down_resident_inst<8, true>(blocks) : gemm_down_resident_inst<8, false>(blocks);
+        case 2: return fp8 ? gemm_down_resident_inst<2, true>(blocks) : gemm_down_resident_inst<2, false>(blocks);
+        default: return fp8 ? gemm_down_resident_inst<1, true>(blocks) : gemm_down_resident_inst<1, false>(blocks);
+    }
+}
 template <typename WT>
 bool LmKernels<WT>::rows_fold_ok(const ModelDims& d, int M, const RowsCtx& c) {
     if constexpr (std::is_same<WT, float>::value) return false;
-    return rows_fold_enabled() && c.A2 != nullptr && c.ss != nullptr && c.xchg != nullptr && c.epoch != nullptr && gemm_down_ok(M, d.dim, d.inter) &&
-           !gemm_big_ok(M, d.dim, d.dim, 1) && c.stage_mask == 0xFFu;
+    else
+        return rows_fold_enabled() && c.A2 != nullptr && c.ss != nullptr && c.xchg != nullptr && c.epoch != nullptr && gemm_down_ok(M, d.dim, d.inter) &&
+               !gemm_big_ok(M, d.dim, d.dim, 1) && c.stage_mask == 0xFFu && gemm_down_resident(d.dim, d.inter, std::is_same<WT, fp8_t>::value);
 }
 
 template <typename WT>

@@ -35,6 +35,7 @@ struct FastPersistArgs {
     const float* scales;        // null, or [PF_BLOCKS][PF_SCL]: FS_FP8 handle -- the image holds the e4m3 weights widened to bf16, these are their row scales
     const float* norms[2 * PF_LAYERS + 1];  // attention_norm l, ffn_norm l (l = 0..3), fast_norm: f32 [1024]
     const void* fast_emb;       // bf16 [1024][1024]
+    const float* qkv0_tbl;      // null, or f32 [1024][1280]: what S1 of fast layer 0 publishes for input fast_embeddings[code] (launch_fast_persist_qkv0_table)
     const void* tok_emb;        // bf16 [V][1024]
     const void* cb_emb;         // bf16 [8 * 1024][1024]
     const float* cos_t;         // [max_seq_len][32] (rows 0..7 used: RoPE position = codebook index, dual_ar.rs:651-655)
@@ -108,6 +109,10 @@ size_t fast_persist_edge_bytes();
 // re-lays the four fast blocks' matrices + fast_output into the per-lane image (device to device, once per weight load)
 void launch_fast_persist_pack(const LayerW* fast, const void* head_w, void* pack, hipStream_t st, bool fp8 = false, const float* head_s = nullptr,
                               float* scales = nullptr);
+// layer-0 qkv table of the codebook passes 1..7 (built from the packed image with stage S1's own arithmetic; scales: FS_FP8 row scales or null)
+size_t fast_persist_qkv0_bytes();
+void launch_fast_persist_qkv0_table(const void* pack, const float* scales, const float* norm0, const void* fast_emb, float eps, float* tbl,
+                                    hipStream_t st);
 void launch_fast_persist(const FastPersistArgs& a, bool sampled, hipStream_t st);
 // true when the in-launch sampler covers this configuration (0 < top_k <= 256 candidates kept, sampling/mod.rs:51-132); temp == 0 is the greedy kernel
 bool fast_persist_samples(float temp, int top_k, int cb_size);

@@ -139,6 +139,47 @@ __global__ void k_pf_pack_scales(LayerW w0, LayerW w1, LayerW w2, LayerW w3, con
     out[(size_t)b * PF_SCL + t] = sc;
 }
 
+// ------------------------------------------------------------------------------------------------ layer-0 qkv table (round 6)
+// Codebook passes 1..7 feed the fast decoder fast_embeddings[code] (single_batch.rs:181-183), so the first fast layer's
+// attention_norm + Wqkv of those passes is a pure function of the 1024 code ids: tbl[code][1280] = what stage S1 of layer 0 would publish
+// (pre-RoPE q | k | v; the position's rotation is applied by the consumer as before).  Built once per weight load FROM THE PACKED IMAGE
+// with S1's own instruction sequence (same per-lane products, same halving tree, same wave-partial order, same v_rsq), so a table entry
+// carries the bits the stage would have published.  The frame kernel then reads 3 float2 per lane behind the decision instead of
+// computing, publishing and sweeping an edge: 7 of the 137 stages of a frame disappear.
+__global__ __launch_bounds__(PF_THREADS) void k_pf_qkv0_table(const void* __restrict__ wpack, const float* __restrict__ scales,
+                                                              const float* __restrict__ norm0, const void* __restrict__ fast_emb, float eps,
+                                                              float* __restrict__ tbl) {
+    __shared__ float red[2 * 8 * PF_RED];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32x4* wp = reinterpret_cast<const u32x4*>(wpack) + (size_t)b * PF_CHUNKS * PF_THREADS + tid;
+    const u32x4 c0 = wp[0], c1 = wp[PF_THREADS];
+    const uint32_t wl[5] = {c0.x, c0.y, c0.z, c0.w, c1.x};  // layer 0: dwords 0..4 = Wqkv rows 5b .. 5b+4, elements (2 tid, 2 tid + 1)
+    const float2 nw = *reinterpret_cast<const float2*>(norm0 + 2 * tid);
+    int par = 0;
+    for (int code = blockIdx.y; code < 1024; code += gridDim.y) {
+        const uint32_t ew = reinterpret_cast<const uint32_t*>(fast_emb)[(size_t)code * 512 + tid];
+        const float x0 = bf_lo(ew), x1 = bf_hi(ew);
+        const float xn0 = x0 * nw.x, xn1 = x1 * nw.y;
+        float a8[8];
+#pragma unroll
+        for (int r = 0; r < 5; ++r) a8[r] = pf_dot2(wl[r], xn0, xn1, 0.f);
+        a8[5] = fmaf(x1, x1, fmaf(x0, x0, 0.f));
+        a8[6] = 0.f; a8[7] = 0.f;
+        const float r8 = pf_reduce<8>(a8, lane);
+        if ((lane & 7) == 0) red[(par * 8 + wave) * PF_RED + (lane >> 3)] = r8;
+        __syncthreads();
+        if (wave == 0) {
+            const int r = min(lane & 15, 5), k = lane >> 4;
+            const float* rp = red + (par * 8 + k) * PF_RED;
+            float t = pf_sum_rows(rp[r] + rp[4 * PF_RED + r]);
+            const float tot = pf_sum_rows(rp[5] + rp[4 * PF_RED + 5]);
+            if (scales) t *= scales[(size_t)b * PF_SCL + min(r, 4)];
+            if (lane < 5) tbl[(size_t)code * 1280 + 5 * b + r] = t * pf_rms_inv(tot, eps);
+        }
+        par ^= 1;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ the frame kernel
 // SAMPLED: temp > 0 with 0 < top_k <= 256 (the server default, server/lib/utils/load.rs:116-125): the decision is the block-parallel
 // top-k / top-p / WeightedIndex sampler of lm_bsample_dev.h, run redundantly by every workgroup on the same logits and the same StdRng
@@ -336,6 +377,8 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
         unsigned e = 0;                       // edge counter of this launch
         const unsigned tag0 = epoch * 256u;   // tag of edge e = tag0 + e + 1
         int par = 0;                          // parity of the double-buffered LDS partials
+        float2 tq = make_float2(0.f, 0.f), tk2 = tq, tv2 = tq;  // qkv table entries of the code picked by the previous decision (this lane's S2 units)
+        float xres_tbl = 0.f;
 #pragma unroll 1
         for (int cb = 0; cb < 8; ++cb) {
             const int T = cb + 1;
@@ -343,7 +386,10 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
             for (int l = 0; l < PF_LAYERS; ++l) {
                 const uint32_t* wl = wr + 9 * l;
                 // ================= S1: (gather x) -> RMSNorm -> Wqkv rows -> publish 5 values
-                {
+                // (layer 0 of the passes 1..7 with the qkv table: the stage does not exist -- S2 takes q / k / v of the new token from the table row
+                // of the code the previous decision picked)
+                const bool from_tbl = l == 0 && cb > 0 && A.qkv0_tbl != nullptr;
+                if (!from_tbl) {
                     tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
                     const float2 nw = norm_w(2 * l, tid);
                     if (l > 0) {
@@ -394,10 +440,16 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
 #pragma unroll
                     for (int t = 0; t < 7; ++t) kw[t] = kc[(l * 8 + t) * 64 + g * 32 + j];  // (positions >= cb: stale words, not used)
                     u32x4 vq, vk, vv;
-                    const u64* eb = my_edges + (size_t)(e & 3) * PF_REPL * PF_EDGE_CAP;
-                    pf_nap_before_sweep(A.naps[1]);
-                    pf_sweep3(eb, tid, 512 + g * 32 + j, 576 + g * 32 + j, tag0 + e + 1, vq, vk, vv, dead, A.ctl);
-                    ++e;
+                    if (from_tbl) {
+                        vq.x = __float_as_uint(tq.x); vq.z = __float_as_uint(tq.y);
+                        vk.x = __float_as_uint(tk2.x); vk.z = __float_as_uint(tk2.y);
+                        vv.x = __float_as_uint(tv2.x); vv.z = __float_as_uint(tv2.y);
+                    } else {
+                        const u64* eb = my_edges + (size_t)(e & 3) * PF_REPL * PF_EDGE_CAP;
+                        pf_nap_before_sweep(A.naps[1]);
+                        pf_sweep3(eb, tid, 512 + g * 32 + j, 576 + g * 32 + j, tag0 + e + 1, vq, vk, vv, dead, A.ctl);
+                        ++e;
+                    }
                     PF_TICK(10);
                     const float c = rope_c[cb * 32 + j], s = rope_s[cb * 32 + j];
                     // q pair (dual_ar.rs:246-247), 1 / sqrt(64) folded in (a power of two: exact; the reference scales K, dual_ar.rs:260)
@@ -446,7 +498,8 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
                     const float r4 = pf_reduce<4>(a4, lane);
                     if ((lane & 15) == 0) red[(par * 8 + wave) * PF_RED + (lane >> 4)] = r4;
                     float xres = 0.f;
-                    if (tid < 64) xres = xr[min(tid & 15, 3)];
+                    if (from_tbl) xres = xres_tbl;  // (this workgroup's four residual elements = fast_embeddings[code][4b ..], requested behind the decision)
+                    else if (tid < 64) xres = xr[min(tid & 15, 3)];
                     __syncthreads();
                     if (wave == 0) {
                         const int r = min(lane & 15, 3), k = lane >> 4;
@@ -683,8 +736,18 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_persist(FastPersistArgs A) 
                     if (b == 0) A.state->cur[cb + 1] = code;
                 }
                 if (cb != 7) {  // hidden_states = fast_embeddings(code) (single_batch.rs:181-183)
-                    const uint32_t ew = reinterpret_cast<const uint32_t*>(A.fast_emb)[(size_t)code * 512 + tid];
-                    x0 = bf_lo(ew); x1 = bf_hi(ew);
+                    if (A.qkv0_tbl) {
+                        const int h2 = tid >> 5, g2 = h2 >> 3, j2 = tid & 31;  // (S2's lane geometry: head, kv group, dim pair)
+                        const float* row = A.qkv0_tbl + (size_t)code * 1280;
+                        tq = *reinterpret_cast<const float2*>(row + 2 * tid);
+                        tk2 = *reinterpret_cast<const float2*>(row + 1024 + g2 * 64 + 2 * j2);
+                        tv2 = *reinterpret_cast<const float2*>(row + 1152 + g2 * 64 + 2 * j2);
+                        const uint32_t hw = reinterpret_cast<const uint16_t*>(A.fast_emb)[(size_t)code * 1024 + 4 * b + min(tid & 15, 3)];
+                        xres_tbl = __uint_as_float(hw << 16);
+                    } else {
+                        const uint32_t ew = reinterpret_cast<const uint32_t*>(A.fast_emb)[(size_t)code * 512 + tid];
+                        x0 = bf_lo(ew); x1 = bf_hi(ew);
+                    }
                 }
             }
         }
@@ -785,6 +848,13 @@ void launch_fast_persist_pack(const LayerW* fast, const void* head_w, void* pack
         hipLaunchKernelGGL(k_pf_pack<false>, dim3(PF_BLOCKS, PF_CHUNKS), dim3(PF_THREADS), 0, st, fast[0], fast[1], fast[2], fast[3], head_w,
                            reinterpret_cast<u32x4*>(pack));
     }
+    FS_HIP(hipGetLastError());
+}
+
+size_t fast_persist_qkv0_bytes() { return (size_t)1024 * 1280 * sizeof(float); }
+void launch_fast_persist_qkv0_table(const void* pack, const float* scales, const float* norm0, const void* fast_emb, float eps, float* tbl,
+                                    hipStream_t st) {
+    hipLaunchKernelGGL(k_pf_qkv0_table, dim3(PF_BLOCKS, 32), dim3(PF_THREADS), 0, st, pack, scales, norm0, fast_emb, eps, tbl);
     FS_HIP(hipGetLastError());
 }
 

@@ -674,6 +674,17 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
             float nwx = nw.x, nwy = nw.y;
             asm volatile("" : "+v"(nwx), "+v"(nwy));  // (in flight since the top of the stage: its wait lands here, behind the sweep that completed it)
             if constexpr (FP8) asm volatile("" : "+v"(rsa), "+v"(rsb));
+            // The W13 slice was requested through unseen loads (S1 or S3) and has landed with this sweep's vmcnt(0).  Re-define the registers
+            // HERE for the compiler: whatever it derives from them is ordered behind this point, and a value it might have carried
+            // in another register across the request is dead.  (What this cannot rule out -- a copy or spill of the destination registers
+            // BETWEEN request and landing -- is what fs_lm_selftest("persist") runs for after a toolchain change.)
+            if constexpr (FP8) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(w13f[c]));
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) asm volatile("" : "+v"(w13[c]));
+            }
             if (!early2) request_w2(wl);  // next stage's weights (workgroups without an attention item asked for them in S1)
             x0 = __uint_as_float(v.x); x1 = __uint_as_float(v.z);
             *reinterpret_cast<float2*>(xs + 2 * tid) = make_float2(x0, x1);
@@ -766,6 +777,11 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
             pf_sweep4(my_edges + (size_t)(e & 3) * ering, tid, tag0 + e + 1, v, dead, A.ctl);
             ++e;
             PS_TICK(13);
+            if constexpr (FP8) { asm volatile("" : "+v"(w2f[0]), "+v"(w2f[1])); }  // (W2: requested through unseen loads, landed with this sweep -- see S4)
+            else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(w2r[q]));
+            }
             float rsc = 1.f;
             if constexpr (FP8) { if (tid < 64) rsc = scl[(size_t)l * scl_layer + SC_W2 + min(tid & 15, 3)]; }
             if (l + 1 < A.n_layer) {  // next layer's Wqkv rows

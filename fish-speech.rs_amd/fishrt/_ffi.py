@@ -38,7 +38,7 @@ SYMBOLS = ["fs_last_error", "fs_version", "fs_device_count", "fs_lm_create", "fs
            "fs_lm_curr_kv_size", "fs_lm_generate", "fs_lm_generate_with_hidden", "fs_lm_generate_batch", "fs_lm_generate_static_batch", "fs_lm_generate_multi", "fs_lm_rows_supported", "fs_lm_debug_read_row", "fs_lm_debug_read_kv", "fs_lm_last_stats", "fs_lm_stream", "fs_lm_bench_kernel",
            "fs_lm_weights_arena", "fs_lm_weights_adopt", "fs_lm_session_begin", "fs_lm_session_add", "fs_lm_session_step", "fs_lm_session_poll", "fs_lm_session_release", "fs_lm_session_end",
            "fs_codec_create", "fs_codec_destroy", "fs_codec_load_safetensors", "fs_codec_load_synthetic",
-           "fs_codec_decode", "fs_codec_encode", "fs_codec_encode_batch", "fs_codec_sample_rate", "fs_codec_set_precision", "fs_codec_precision", "fs_codec_set_range_check", "fs_codec_range_stats", "fs_codec_stream_begin", "fs_codec_stream_decode", "fs_codec_stream_end", "fs_fp8_quantize_rows", "fs_fp8_decode_table", "fs_selftest", "fs_selftest_sample_rows", "fs_lm_debug_capture", "fs_lm_debug_read"]
+           "fs_codec_decode", "fs_codec_encode", "fs_codec_encode_batch", "fs_codec_sample_rate", "fs_codec_set_precision", "fs_codec_precision", "fs_codec_set_range_check", "fs_codec_range_stats", "fs_codec_stream_begin", "fs_codec_stream_decode", "fs_codec_stream_end", "fs_fp8_quantize_rows", "fs_fp8_decode_table", "fs_selftest", "fs_lm_selftest", "fs_selftest_sample_rows", "fs_lm_debug_capture", "fs_lm_debug_read"]
 
 _lib = None
 

@@ -222,6 +222,10 @@ class DualARTransformer:
         _ffi.check(_ffi.lib().fs_lm_last_stats(self._h, C.byref(st)))
         return {k: getattr(st, k) for k, _ in _ffi.GenStats._fields_}
 
+    def selftest(self, what="persist"):
+        """fs_lm_selftest: the persistent decode kernels of this build against the per-node kernels on the loaded weights (raises on a mismatch)"""
+        _ffi.check(_ffi.lib().fs_lm_selftest(self._h, what.encode()))
+
     def debug_capture(self, n_frames):
         """test hook: record what the 9 decisions of each of the first n_frames iterations saw and picked (persistent path only)"""
         _ffi.check(_ffi.lib().fs_lm_debug_capture(self._h, int(n_frames)))

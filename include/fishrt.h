@@ -87,6 +87,13 @@ int fs_selftest(int device_id, const char* what);
 int fs_selftest_sample_rows(int device_id, const float* logits, int B, int n, const fs_sampling* s, uint64_t seed, int call_index,
                             uint32_t* out);
 
+/* Self-test of a LOADED handle, by name.  "persist": the persistent decode kernels of this binary (csrc/lm_persist.hip, lm_persist_slow.hip:
+ * pinned weight registers, loads issued outside the compiler's wait-count bookkeeping) against the per-node kernels on the handle's own
+ * weights -- 4 greedy frames on the persistent path with the decision capture armed, then one teacher-forced per-node step
+ * (fs_lm_forward_generate / _fast) compared with the captured logits of the first k_slow_persist step and the first k_fast_persist pass
+ * (bound 2e-2 x max(1, max |logit|): loose for summation order, tight for a wrong weight register).  A deployment runs it once after a
+ * toolchain change; 0 = passed, the message names the remedy otherwise.  Clears the handle's KV caches.  No reference counterpart. */
+int fs_lm_selftest(fs_lm_t* lm, const char* what);
 /* Decision capture of the persistent batch-1 decode path (diagnostics / parity tests; no reference counterpart).  After
  * fs_lm_debug_capture(lm, n) every fs_lm_generate call that takes the persistent fast decoder records, for its first n generator
  * iterations, what each of the 9 decisions of a frame saw and chose: fs_lm_debug_read copies f32 [n][9][2048]; row 0 = the slow

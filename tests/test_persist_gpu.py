@@ -107,6 +107,26 @@ def test_reduction_trees_selftest():
     assert _ffi.lib().fs_selftest(0, b"no-such-test") != 0
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp8"])
+def test_handle_selftest_persist(dtype):
+    """fs_lm_selftest("persist"): the persistent kernels of this binary against the per-node kernels on the handle's own weights --
+    what a deployment runs after a toolchain change (unseen loads / pinned weight registers depend on hipcc's register allocation)."""
+    lm = fishrt.DualARTransformer(fcfg.FISH_1_5, fcfg.FISH_1_5_TOKENS, 0, dtype).load_synthetic(0xF15E5EED)
+    lm.selftest("persist")
+    assert lm.curr_kv_size() == 0  # the handle is handed back with empty caches
+    assert _ffi.lib().fs_lm_selftest(lm._h, b"no-such-test") != 0
+    # the handle still generates, on the persistent path, after the self-test
+    p = _text_prompt(16, 1234)
+    out = lm.generate_blocking(p, 16 + 6, repetition_penalty=1.2, persistent=True, **GREEDY)
+    assert out.shape == (8, 8) and lm.last_stats()["kernels_per_frame"] == 2
+
+
+def test_handle_selftest_persist_legacy_fp8():
+    """the same on a Fish-1.4-shaped fp8 handle (configs[4]: 2-way {pad, im_end} slow decision inside k_fast_persist)"""
+    lm = fishrt.DualARTransformer(fcfg.FISH_1_4, fcfg.FISH_1_4_TOKENS, 0, "fp8").load_synthetic(0xF15E5EED)
+    lm.selftest("persist")
+
+
 @pytest.mark.parametrize("rep_pen", [1.0, 1.2])
 def test_persistent_equals_per_node_path(lm15, rep_pen):
     # KV lengths 16..4300: attention stage with 1, 2, 4, 16 token slices per head, one to three 128-token tiles per workgroup

@@ -50,3 +50,16 @@ def test_folded_step_is_deterministic_and_agrees_with_the_slab_path(tmp_path, cf
     pa, pc = a["cap"][:, 0, 0, 2047], c["cap"][:, 0, 0, 2047]
     if a["greedy"]:
         assert np.array_equal(pa[clear], pc[clear])
+
+
+def test_fold_is_gated_on_co_residency(tmp_path):
+    """k_gemm_down's owner waves wait for units from the other blocks of the SAME launch, so the folded step is only taken where
+    the occupancy query says the whole grid is resident.  FISHRT_DOWN_FAKE_CAPACITY pretends a device that holds 100 blocks (the Fish-1.5
+    grid has 256): the step must fall back to the slab path -- bit for bit what FISHRT_ROWS_NO_FOLD=1 computes -- instead of spinning."""
+    a, _ = _run(tmp_path, "small_dev", "fish15", "bf16", 8, 3, {"FISHRT_DOWN_FAKE_CAPACITY": "100"})
+    b, _ = _run(tmp_path, "nofold", "fish15", "bf16", 8, 3, {"FISHRT_ROWS_NO_FOLD": "1"})
+    c, _ = _run(tmp_path, "big_dev", "fish15", "bf16", 8, 3, {"FISHRT_DOWN_FAKE_CAPACITY": "256"})
+    d, _ = _run(tmp_path, "fold", "fish15", "bf16", 8, 3, {})
+    assert np.array_equal(a["codes"], b["codes"]) and np.array_equal(a["cap"], b["cap"])
+    assert np.array_equal(c["codes"], d["codes"]) and np.array_equal(c["cap"], d["cap"])
+    assert not np.array_equal(a["cap"], d["cap"])  # (the two steps sum the down projection in different orders)

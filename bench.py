@@ -141,7 +141,7 @@ def dry_run(args, dist, rank, world):
         print(json.dumps({"metric": "codec tokens/sec (frames/s)", "value": None, "unit": "frames/s", "n_gpus": world, "dry_run": True,
                           "reason": "no HIP device visible: control path only (launch, shard, broadcast, all-gather); fishrt has no CPU path",
                           "requests": n_req, "requests_per_rank": [len(fanout.shard_requests(n_req, r, world)) for r in range(world)],
-                          "collective_ranks": int(seen), "backend": "gloo" if dist is not None else None, "fan_in_ok": bool(ok),
+                          "collective_ranks": int(seen), "backend": fanout.backend_name(dist), "fan_in_ok": bool(ok),
                           "batch_per_rank": B, "config": args.config,
                           "static_batches_per_rank": [(len(fanout.shard_requests(n_req, r, world)) + B - 1) // B for r in range(world)]}), flush=True)
     if dist is not None:
@@ -216,7 +216,7 @@ def run_config3(args, lm_factory, dist, rank, world, cfg, tok):
                    "requests": n_req, "batch_per_gpu": B, "frames_per_request": frames,
                    "parallelism": f"request shards x{world}; prompt broadcast + code all-gather over RCCL, no per-token collective"},
         "rtf": round((frames_total / FRAME_RATE) / dt, 2),
-        "rccl_ranks": int(seen), "frames_per_rank": [int(v) for v in fa.sum(axis=1)],
+        "rccl_ranks": int(seen), "fanout_backend": fanout.backend_name(dist), "frames_per_rank": [int(v) for v in fa.sum(axis=1)],
         "decode_step_us_rank0": round(step_s * 1e6, 1), "prefill_s_per_job_rank0": round(pre_s, 3),
         "roofline": {"bound": "hbm", "kernel": "static-batch decode step (one graph replay, B = 32 rows on the MFMA row path)",
                      "achieved": round(bytes_step / step_s / 1e9, 2),
@@ -258,8 +258,12 @@ def main():
     if "FISHRT_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["FISHRT_BENCH_DEVICE"])
         torch.cuda.set_device(local_rank)
-    backend = os.environ.get("FISHRT_BENCH_BACKEND", "nccl") if have_gpu else "gloo"
-    dist = fanout.init(backend if world > 1 else None)  # nccl == RCCL: control plane + request fan-out only
+    backend = os.environ.get("FISHRT_BENCH_BACKEND", "rccl") if have_gpu else "gloo"
+    # rccl: the fs_comm_* C entry points of libfishrt.so on librccl directly (request fan-out + the job's clock; no torch process group)
+    dist = fanout.init(backend if world > 1 else None, device=local_rank)
+    if world == 1 and have_gpu and os.environ.get("FISHRT_BENCH_COMM1"):  # test hook: the whole fan-out through a ONE-rank RCCL communicator
+        from fishrt.comm import RcclComm
+        dist = RcclComm.from_env(device=local_rank)
     if not have_gpu:
         dry_run(args, dist, rank, world)
 
@@ -287,7 +291,8 @@ def main():
         dtb = time.perf_counter() - t0
         if ok_all:
             wbcast = {"bytes": int(nbytes), "ms": round(dtb * 1e3, 1), "GBps_per_receiver": round(nbytes / dtb / 1e9, 1),
-                      "how": "fs_lm_weights_arena -> torch.distributed.broadcast (RCCL) in 256 MB pieces -> fs_lm_weights_adopt"}
+                      "how": "fs_comm_broadcast_weights: arena -> ncclBroadcast in 256 MB pieces -> fs_lm_weights_adopt" if fanout.backend_name(dist).startswith("rccl")
+                             else "fs_lm_weights_arena -> torch.distributed.broadcast (gloo rehearsal) -> fs_lm_weights_adopt"}
         else:  # the replicas do not depend on it: every rank materialises the (deterministic) weights itself -- ALL of them
             wbcast = {"error": err or "another rank failed", "how": "fallback: every rank ran fs_lm_load_synthetic"}
             if rank != 0:
@@ -373,7 +378,7 @@ def main():
                                "one request per step per GPU (prefill included in the timed region)",
                    "prompt_positions": L, "frames_per_request": args.frames, "requests_per_step": world,
                    "parallelism": f"replicas x{world} (no data-path collective; codes all-gathered over RCCL after the run)"},
-        "rtf": round((frames_total / FRAME_RATE) / dt, 2), "rccl_ranks": int(seen), "weight_broadcast": wbcast, "frames_per_rank": [int(v) for v in fa.sum(axis=1) * args.steps],
+        "rtf": round((frames_total / FRAME_RATE) / dt, 2), "rccl_ranks": int(seen), "fanout_backend": fanout.backend_name(dist), "weight_broadcast": wbcast, "frames_per_rank": [int(v) for v in fa.sum(axis=1) * args.steps],
         "decode_frames_per_s_per_gpu": round(1.0 / t_frame, 2), "prefill_ms": round(pre_ms, 3),
         "roofline": {"bound": "hbm", "kernel": (f"decode frame = {kpf} kernels of a hipGraph replay (8 frames per graph launch on the persistent path): " +
                                                ("k_slow_persist (24 slow blocks + head) then k_fast_persist (slow-token decision, 8 codebook passes, 8 decisions)" if kpf == 2 else

@@ -8,7 +8,7 @@ mkdir -p "$HERE/build"
 # the top of every graph node: -1.3% on the 266-node decode frame, measured with tools/ubench_lm)
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -ffp-contract=on -mllvm -amdgpu-kernarg-preload-count=16"
 pids=()
-for f in lm_kernels.hip lm_persist.hip lm_persist_slow.hip lm_persist_rows.hip lm_engine.hip codec_kernels.hip codec_conv_bf3.hip codec_engine.hip fishrt_api.cpp; do
+for f in lm_kernels.hip lm_persist.hip lm_persist_slow.hip lm_persist_rows.hip lm_engine.hip codec_kernels.hip codec_conv_bf3.hip codec_engine.hip fs_comm.cpp fishrt_api.cpp; do
   o="$HERE/build/${f%.*}.o"
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ -n "$(find . -name '*.h' -newer "$o" -print -quit)" ] || [ "../../include/fishrt.h" -nt "$o" ]; then
     # (lm_persist_rows.hip: four unrolled layers x two row groups x R rows exceed clang's default budget for `#pragma unroll`; a loop it refuses to

@@ -5,6 +5,7 @@
 
 #include "../../include/fishrt.h"
 #include "codec_engine.h"
+#include "fs_comm.h"
 #include "fs_common.h"
 #include "lm_engine.h"
 #include "lm_kernels.h"
@@ -18,6 +19,7 @@ static thread_local std::string g_err;
 
 struct fs_lm { fs::LMBase* impl; };
 struct fs_codec { fs::CodecBase* impl; };
+struct fs_comm { fs::Comm* impl; };
 
 #define FS_TRY(body)                                                          \
     try { body; return FS_OK; }                                               \
@@ -73,6 +75,46 @@ int fs_selftest(int device_id, const char* what) {
 int fs_selftest_sample_rows(int device_id, const float* logits, int B, int n, const fs_sampling* s, uint64_t seed, int call_index, uint32_t* out) {
     FS_ARG(logits && s && out, "null argument");
     FS_TRY(fs::debug_sample_rows(device_id, logits, B, n, s->temp, s->top_p, s->top_k, seed, call_index, out))
+}
+
+// ---- replica fan-out over RCCL (fs_comm.h)
+int fs_comm_unique_id(uint8_t id_out[FS_COMM_ID_BYTES]) { FS_ARG(id_out, "null argument"); FS_TRY(fs::Comm::unique_id(id_out)) }
+int fs_comm_create(const uint8_t id[FS_COMM_ID_BYTES], int rank, int world, int device_id, fs_comm_t** out) {
+    FS_ARG(id && out, "null argument");
+    FS_TRY({ *out = nullptr; fs::Comm* c = new fs::Comm(id, rank, world, device_id); *out = new fs_comm{c}; })
+}
+void fs_comm_destroy(fs_comm_t* c) {
+    if (!c) return;
+    delete c->impl;
+    delete c;
+}
+int fs_comm_rank(fs_comm_t* c) { if (!c) { g_err = "null argument"; return -1; } return c->impl->rank(); }
+int fs_comm_world(fs_comm_t* c) { if (!c) { g_err = "null argument"; return -1; } return c->impl->world(); }
+int fs_comm_barrier(fs_comm_t* c) { FS_ARG(c, "null argument"); FS_TRY(c->impl->barrier()) }
+int fs_comm_all_reduce_f64(fs_comm_t* c, double* vals, int n, int op) { FS_ARG(c && vals, "null argument"); FS_TRY(c->impl->all_reduce_f64(vals, n, op)) }
+int fs_comm_broadcast_weights(fs_comm_t* c, fs_lm_t* lm, int src, size_t* bytes_moved) {
+    FS_ARG(c && lm, "null argument");
+    FS_TRY({ const size_t n = c->impl->broadcast_weights(lm->impl, src); if (bytes_moved) *bytes_moved = n; })
+}
+int fs_comm_broadcast_prompt_dims(fs_comm_t* c, int64_t dims[3], int src) {
+    FS_ARG(c && dims, "null argument");
+    FS_TRY(c->impl->broadcast_host(dims, 3 * sizeof(int64_t), src))
+}
+int fs_comm_broadcast_prompts(fs_comm_t* c, uint32_t* packed, int32_t* lens, const int64_t dims[3], int src) {
+    FS_ARG(c && packed && lens && dims, "null argument");
+    FS_ARG(dims[0] >= 0 && dims[1] >= 1 && dims[2] >= 0 && dims[0] <= (1 << 20) && dims[1] <= 64 && dims[2] <= (1 << 20), "bad prompt batch shape");
+    FS_TRY({
+        c->impl->broadcast_host(packed, (size_t)dims[0] * (size_t)dims[1] * (size_t)dims[2] * sizeof(uint32_t), src);
+        c->impl->broadcast_host(lens, (size_t)dims[0] * sizeof(int32_t), src);
+    })
+}
+int fs_comm_all_gather_codes(fs_comm_t* c, const uint32_t* codes, const int32_t* n_frames, int B, int C, int N, uint32_t* codes_all, int32_t* n_frames_all) {
+    FS_ARG(c && codes && n_frames && codes_all && n_frames_all, "null argument");
+    FS_ARG(B >= 1 && C >= 1 && N >= 0, "bad code array shape");
+    FS_TRY({
+        c->impl->all_gather_host(codes, codes_all, (size_t)B * (size_t)C * (size_t)N * sizeof(uint32_t));
+        c->impl->all_gather_host(n_frames, n_frames_all, (size_t)B * sizeof(int32_t));
+    })
 }
 
 int fs_lm_selftest(fs_lm_t* lm, const char* what) { FS_ARG(lm && what, "null argument"); FS_TRY(lm->impl->selftest(what)) }

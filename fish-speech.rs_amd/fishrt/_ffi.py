@@ -36,7 +36,8 @@ SYMBOLS = ["fs_last_error", "fs_version", "fs_device_count", "fs_lm_create", "fs
            "fs_lm_load_synthetic", "fs_lm_forward_generate", "fs_lm_forward_generate_fast", "fs_lm_fast_embed",
            "fs_lm_clear_fast_layer_caches", "fs_lm_clear_slow_layer_caches", "fs_lm_clear_slow_caches_until",
            "fs_lm_curr_kv_size", "fs_lm_generate", "fs_lm_generate_with_hidden", "fs_lm_generate_batch", "fs_lm_generate_static_batch", "fs_lm_generate_multi", "fs_lm_rows_supported", "fs_lm_debug_read_row", "fs_lm_debug_read_kv", "fs_lm_last_stats", "fs_lm_stream", "fs_lm_bench_kernel",
-           "fs_lm_weights_arena", "fs_lm_weights_adopt", "fs_lm_session_begin", "fs_lm_session_add", "fs_lm_session_step", "fs_lm_session_poll", "fs_lm_session_release", "fs_lm_session_end",
+           "fs_lm_weights_arena", "fs_lm_weights_adopt", "fs_comm_unique_id", "fs_comm_create", "fs_comm_destroy", "fs_comm_rank", "fs_comm_world", "fs_comm_barrier",
+           "fs_comm_all_reduce_f64", "fs_comm_broadcast_weights", "fs_comm_broadcast_prompt_dims", "fs_comm_broadcast_prompts", "fs_comm_all_gather_codes", "fs_lm_session_begin", "fs_lm_session_add", "fs_lm_session_step", "fs_lm_session_poll", "fs_lm_session_release", "fs_lm_session_end",
            "fs_codec_create", "fs_codec_destroy", "fs_codec_load_safetensors", "fs_codec_load_synthetic",
            "fs_codec_decode", "fs_codec_encode", "fs_codec_encode_batch", "fs_codec_sample_rate", "fs_codec_set_precision", "fs_codec_precision", "fs_codec_set_range_check", "fs_codec_range_stats", "fs_codec_stream_begin", "fs_codec_stream_decode", "fs_codec_stream_end", "fs_fp8_quantize_rows", "fs_fp8_decode_table", "fs_selftest", "fs_lm_selftest", "fs_selftest_sample_rows", "fs_lm_debug_capture", "fs_lm_debug_read"]
 
@@ -55,6 +56,8 @@ def lib():
         L.fs_lm_stream.restype = C.c_void_p
         L.fs_lm_destroy.restype = None
         L.fs_codec_destroy.restype = None
+        L.fs_comm_destroy.restype = None
+        L.fs_comm_destroy.argtypes = [C.c_void_p]
         L.fs_lm_destroy.argtypes = [C.c_void_p]
         L.fs_codec_destroy.argtypes = [C.c_void_p]
         _lib = L

@@ -1,9 +1,21 @@
 """Multi-GPU request fan-out: the reference has no distributed layer, requests are independent
 sequences, so the only multi-GPU mode is REPLICAS -- one process per GPU, each with its own fishrt handle; request i goes
-to rank i mod world.  torch.distributed (backend "nccl" == RCCL on ROCm, "gloo" in CPU tests) is used only for control:
-barrier, max-reduce of the timed region, the start-up weight broadcast, the prompt broadcast and the fan-in of the (KB-sized)
-code arrays.  Nothing on the per-token path crosses GPUs."""
+to rank i mod world.  Nothing on the per-token path crosses GPUs; what does cross is the start-up weight broadcast, the prompt
+broadcast, the fan-in of the (KB-sized) code arrays, and the barrier / max-reduce of the timed region.
+
+Two carriers, one function set (every function takes the `dist` object init() returned, or None at world 1):
+ * fishrt.comm.RcclComm -- the fs_comm_* C entry points of libfishrt.so on librccl DIRECTLY (ncclBroadcast / ncclAllGather /
+   ncclAllReduce over xGMI): the GPU path, and what a Rust host binds.  torch is used only for the launcher's key-value store that carries
+   the 128-byte communicator id; no torch process group exists.
+ * the torch.distributed module with the gloo backend -- CPU tests (world 2 without a GPU) and the one-GPU rehearsal of N > 1
+   (RCCL refuses two ranks on one device)."""
 import os
+
+from .comm import RcclComm, MAX, MIN, SUM
+
+
+def _is_rccl(dist):
+    return isinstance(dist, RcclComm)
 
 
 def env_rank():
@@ -15,21 +27,26 @@ def shard_requests(n_requests, rank, world):
     return list(range(rank, n_requests, world))
 
 
-def init(backend=None):
-    """Initialise torch.distributed from the torchrun environment; returns the module (or None when world == 1)."""
+def init(backend=None, device=None):
+    """world 1 -> None.  backend "nccl" / "rccl" (default when a HIP device is visible) -> an RcclComm created from the torchrun environment
+    (fs_comm_create on device LOCAL_RANK, or `device`); "gloo" -> the initialised torch.distributed module."""
     rank, local_rank, world = env_rank()
     if world == 1:
         return None
-    import torch
-    import torch.distributed as dist
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
-    if backend == "nccl":
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
-    else:
-        dist.init_process_group(backend)
+        from . import _ffi
+        backend = "rccl" if _ffi.lib().fs_device_count() > 0 else "gloo"
+    if backend in ("nccl", "rccl"):
+        return RcclComm.from_env(device=local_rank if device is None else device)
+    import torch.distributed as dist
+    dist.init_process_group(backend)
     return dist
+
+
+def backend_name(dist):
+    if dist is None:
+        return None
+    return "rccl (fs_comm_* C ABI on librccl)" if _is_rccl(dist) else dist.get_backend()
 
 
 def barrier(dist):
@@ -37,43 +54,55 @@ def barrier(dist):
         dist.barrier()
 
 
-def max_over_ranks(dist, value):
-    """MAX-reduce a python float over all ranks (the timed region of the whole job is the slowest rank's)."""
+def _reduce(dist, value, op):
     if dist is None:
         return float(value)
+    if _is_rccl(dist):
+        return float(dist.all_reduce([float(value)], op)[0])
     import torch
-    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    t = torch.tensor([float(value)], dtype=torch.float64)
+    dist.all_reduce(t, op={MAX: dist.ReduceOp.MAX, MIN: dist.ReduceOp.MIN, SUM: dist.ReduceOp.SUM}[op])
     return float(t.item())
+
+
+def max_over_ranks(dist, value):
+    """MAX-reduce a python float over all ranks (the timed region of the whole job is the slowest rank's)."""
+    return _reduce(dist, value, MAX)
 
 
 def min_over_ranks(dist, value):
     """MIN-reduce a python number over all ranks (e.g. a success flag: 1 only if every rank succeeded)."""
-    if dist is None:
-        return float(value)
-    import torch
-    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MIN)
-    return float(t.item())
+    return _reduce(dist, value, MIN)
 
 
 def sum_over_ranks(dist, value):
-    if dist is None:
-        return float(value)
-    import torch
-    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return float(t.item())
+    return _reduce(dist, value, SUM)
 
 
 def gather_results(dist, n_requests, local_results):
     """Fan-in: `local_results` maps request index -> numpy codes (C, n_i) for this rank's shard.  Rank 0 gets the full
-    list ordered by request index (others get None)."""
+    list ordered by request index (others get None).  (RCCL carrier: padded to the longest result and all-gathered.)"""
     if dist is None:
         return [local_results[i] for i in range(n_requests)]
+    if _is_rccl(dist):
+        import numpy as np
+        per = (n_requests + dist.world - 1) // dist.world
+        C = next(iter(local_results.values())).shape[0] if local_results else 1
+        nmax = int(max_over_ranks(dist, max([v.shape[1] for v in local_results.values()], default=0)))
+        C = int(max_over_ranks(dist, C))
+        codes = np.zeros((per, C, nmax), np.uint32)
+        nf = np.full(per, -1, np.int32)
+        for k, i in enumerate(shard_requests(n_requests, dist.rank, dist.world)):
+            codes[k, :, : local_results[i].shape[1]] = local_results[i]
+            nf[k] = local_results[i].shape[1]
+        ca, fa, _ = dist.all_gather_codes(codes, nf)
+        if dist.rank != 0:
+            return None
+        out = [None] * n_requests
+        for r in range(dist.world):
+            for k, i in enumerate(shard_requests(n_requests, r, dist.world)):
+                out[i] = ca[r, k, :, : fa[r, k]].copy()
+        return out
     out = [None] * dist.get_world_size() if dist.get_rank() == 0 else None
     dist.gather_object(local_results, out, dst=0)
     if dist.get_rank() != 0:
@@ -85,7 +114,7 @@ def gather_results(dist, n_requests, local_results):
 
 
 def _dev(dist):
-    return "cuda" if dist.get_backend() == "nccl" else "cpu"
+    return "cpu"  # (the torch carrier is gloo: host tensors; device arenas are staged through _DeviceBytes below)
 
 
 class _DeviceBytes:
@@ -102,11 +131,13 @@ def broadcast_weights(dist, lm, src=0, chunk_bytes=256 << 20):
     weights_host() -> numpy u8).  Returns the bytes moved."""
     if dist is None:
         return 0
+    if _is_rccl(dist):
+        return dist.broadcast_weights(lm, src)
     import torch
     me = dist.get_rank()
     if hasattr(lm, "weights_host"):  # host-memory double (gloo tests)
         t = torch.from_numpy(lm.weights_host())
-    else:
+    else:  # gloo with real handles (the one-GPU rehearsal): the arena as a CUDA tensor, gloo stages it through the host
         ptr, n = lm.weights_arena()
         t = torch.as_tensor(_DeviceBytes(ptr, n), device="cuda")
     n = int(t.numel())
@@ -130,6 +161,8 @@ def broadcast_prompts(dist, packed=None, lens=None, src=0):
     import numpy as np
     if dist is None:
         return np.ascontiguousarray(packed, np.uint32), np.asarray(lens, np.int32)
+    if _is_rccl(dist):
+        return dist.broadcast_prompts(packed, lens, src)
     import torch
     dev, me = _dev(dist), dist.get_rank()
     shape = torch.tensor(list(packed.shape) if me == src else [0, 0, 0], dtype=torch.int64, device=dev)
@@ -155,6 +188,8 @@ def all_gather_codes(dist, codes, n_frames):
     n_frames = np.ascontiguousarray(n_frames, np.int32)
     if dist is None:
         return codes[None], n_frames[None], 1
+    if _is_rccl(dist):
+        return dist.all_gather_codes(codes, n_frames)
     import torch
     dev, world = _dev(dist), dist.get_world_size()
     c = torch.from_numpy(codes.view(np.int32)).to(dev)

@@ -223,6 +223,41 @@ int fs_lm_rows_supported(fs_lm_t* lm, int n, const fs_sampling* samplings, int* 
 int fs_lm_weights_arena(fs_lm_t* lm, void** dev_ptr, size_t* bytes);
 int fs_lm_weights_adopt(fs_lm_t* lm);
 
+/* ---- replica fan-out over RCCL / xGMI (BASELINE.json north_star: "batch-sharded across the 8 GPUs of one node with
+ * RCCL over xGMI only for multi-request fan-out").  No reference counterpart: the reference serves one model behind one mutex
+ * (server/lib/state.rs:12-29) and has no distributed layer.  One process per GPU; each holds its own fs_lm_t (full replica) and ONE
+ * communicator.  Request i goes to rank i mod world; nothing on the per-token path crosses GPUs, so these are all the collectives there
+ * are: (1) the weight arena from the rank that read the checkpoint (ncclBroadcast in 256 MB pieces, then fs_lm_weights_adopt on the
+ * receivers), (2) the packed prompt batch, (3) the end-of-run fan-in of the code arrays (ncclAllGather), plus a barrier and small f64
+ * reductions for the job's clock and frame counters (ncclAllReduce).  librccl is bound with dlopen at the first call: single-GPU hosts
+ * never load it.  Host buffers are caller-owned, as everywhere in this header; calls block until the collective has completed.
+ *   bring-up: rank 0 calls fs_comm_unique_id and ships the 128 bytes to the other ranks over the host's own channel (environment,
+ *   file, TCP store); every rank then calls fs_comm_create(id, rank, world, device) -- collective, like ncclCommInitRank. */
+#define FS_COMM_ID_BYTES 128
+typedef struct fs_comm fs_comm_t;
+int fs_comm_unique_id(uint8_t id_out[FS_COMM_ID_BYTES]);
+int fs_comm_create(const uint8_t id[FS_COMM_ID_BYTES], int rank, int world, int device_id, fs_comm_t** out);
+void fs_comm_destroy(fs_comm_t* comm);
+int fs_comm_rank(fs_comm_t* comm);   /* -1 on a null handle */
+int fs_comm_world(fs_comm_t* comm);
+/* every rank enters; returns when all have (an all-reduce of a rank count + the stream sync behind it) */
+int fs_comm_barrier(fs_comm_t* comm);
+/* in place on a host array of n <= 4096 doubles; op: 0 sum, 1 max, 2 min (the job's wall time is the MAX over ranks, its frames the SUM) */
+int fs_comm_all_reduce_f64(fs_comm_t* comm, double* vals, int n, int op);
+/* (1) `lm` on rank `src` is loaded; on every other rank it was created with the same model args / token config / dtype and is NOT loaded:
+ * after the call every rank's handle is ready (receivers ran fs_lm_weights_adopt).  Arena sizes are compared across ranks first; a
+ * mismatch is an error on EVERY rank before a byte moves.  *bytes_moved (nullable) = the arena size. */
+int fs_comm_broadcast_weights(fs_comm_t* comm, fs_lm_t* lm, int src, size_t* bytes_moved);
+/* (2) the packed prompt batch: dims = {n_requests, num_codebooks + 1, Lmax}; packed u32 [n_requests][C+1][Lmax] (rows left-aligned,
+ * zero-padded), lens i32 [n_requests].  Receivers first learn the shape (fs_comm_broadcast_prompt_dims fills dims from rank src), size
+ * their buffers, then every rank calls fs_comm_broadcast_prompts with the same dims. */
+int fs_comm_broadcast_prompt_dims(fs_comm_t* comm, int64_t dims[3], int src);
+int fs_comm_broadcast_prompts(fs_comm_t* comm, uint32_t* packed, int32_t* lens, const int64_t dims[3], int src);
+/* (3) fan-in: this rank's codes u32 [B][C][N] (its requests, padded to N frames) and n_frames i32 [B] -> on EVERY rank
+ * codes_all u32 [world][B][C][N] and n_frames_all i32 [world][B].  B, C, N must be the same on every rank (pad the last shard). */
+int fs_comm_all_gather_codes(fs_comm_t* comm, const uint32_t* codes, const int32_t* n_frames, int B, int C, int N, uint32_t* codes_all,
+                             int32_t* n_frames_all);
+
 /* ---- continuous batching (no reference counterpart: the reference server serialises requests behind one mutex, server/lib/state.rs:12-29,
  * or runs lock-step batches, generate/static_batch.rs:282-390; SURVEY.md section 8 f-4 asks for a scheduler that replaces the mutex).
  * A session turns the max_batch rows of the static-batch decode step into independent request SLOTS: a request's prompt is prefilled on

@@ -64,7 +64,7 @@ struct alignas(16) BSampLds {  // LDS scratch of one call (7.9 KB)
     double wsum[16];
     float wmax[16];
     int wcnt[2][16];
-    int misc[16];  // 0 bin, 1 above, 2 cut, 3 first, 4 last, 5 n_surv, 6 sum bits, 7 chosen bits, 8 any
+    int misc[16];  // 0 bin, 1 above, 2 cut, 3 first, 4 last, 5 n_surv, 6 sum bits, 7 chosen bits, 8 fast-tail result, 9 candidates in the selected bin, 10 / 11 their max / min pattern
 };
 
 #ifdef BS_PROF
@@ -98,6 +98,16 @@ __device__ __forceinline__ int bs_wave_scan(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
     return v;
 }
+// the same for f32 (a fixed tree: used where the summation order is free)
+__device__ __forceinline__ float bs_wave_scan_f(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false));
+    return v;
+}
 // CH (32 | 16) consecutive floats of an LDS array with CH / 4 independent 16-byte reads; entries >= n read as +0.0 (x + 0.0f == x for the
 // non-negative sums taken here)
 template <int CH>
@@ -123,7 +133,12 @@ __device__ int bsample(const float (&lv)[EPT], int n, int kk, float inv_t, float
                        bool batch = false, double top_p64 = 0.0) {  // batch: BatchedLogitsProcessor's f64 comparison (sampling/mod.rs:68)
     static_assert(NT % 64 == 0 && NT >= BS_MAXK + 64 && NT * EPT <= 2048, "block shape");
     constexpr int W = NT / 64;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // (opaque: inside a persistent kernel's pass loop every per-lane LDS address of this function is loop-invariant; hoisted, the ~25 of them
+    // outlive the loop next to 168 resident weight registers and were SPILLED -- a scratch load + vmcnt(0) in front of each LDS access, ~2 us
+    // per call on the decision's critical path.  Re-deriving them from an opaque thread id costs a few VALU operations per use instead.)
+    int tid_o = threadIdx.x;
+    asm volatile("" : "+v"(tid_o));
+    const int tid = tid_o, lane = tid & 63, wv = tid >> 6;
     const int base = tid * EPT;
     BS_TS(0);
     // ---- A: softmax
@@ -184,6 +199,7 @@ __device__ int bsample(const float (&lv)[EPT], int n, int kk, float inv_t, float
     // ---- B: T = the kk-th largest pattern (#{u > T} < kk <= #{u >= T}); slots past n count as zeros, exactly as in the one-wave version
     uint32_t prefix = 0u;
     int krem = kk;
+    bool done_early = false;
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = pass == 0 ? 22 : (pass == 1 ? 14 : (pass == 2 ? 6 : 0)), bits = pass == 3 ? 6 : 8;
@@ -200,7 +216,7 @@ __device__ int bsample(const float (&lv)[EPT], int n, int kk, float inv_t, float
             int above = __builtin_amdgcn_readlane(incl, 63) - incl;  // candidates in bins of higher lanes
 #pragma unroll
             for (int j = 3; j >= 0; --j) {  // exactly one (lane, j) holds the krem-th candidate from the top
-                if (above < krem && krem <= above + h4[j]) { S.misc[0] = lane * 4 + j; S.misc[1] = above; }
+                if (above < krem && krem <= above + h4[j]) { S.misc[0] = lane * 4 + j; S.misc[1] = above; S.misc[9] = h4[j]; S.misc[10] = 0; S.misc[11] = 0x7FFFFFFF; }
                 above += h4[j];
             }
         } else if (wv == 1) {
@@ -209,7 +225,19 @@ __device__ int bsample(const float (&lv)[EPT], int n, int kk, float inv_t, float
         __syncthreads();
         prefix = (prefix << bits) | (uint32_t)S.misc[0];
         krem -= S.misc[1];
+        // round 6: one or two candidates left in the selected bin (the usual state after two passes: ~170 candidates of a flat row over 256
+        // bins) -- their owners post the patterns themselves (LDS max / min) and the remaining passes, two barriers each, are skipped
+        if (pass < 3 && S.misc[9] <= 2) {
+#pragma unroll
+            for (int s = 0; s < EPT; ++s)
+                if ((u[s] >> shift) == prefix) { atomicMax(&S.misc[10], (int)u[s]); atomicMin(&S.misc[11], (int)u[s]); }
+            __syncthreads();
+            prefix = (uint32_t)(krem == 1 ? S.misc[10] : S.misc[11]);  // the krem-th largest of the bin's one or two patterns
+            done_early = true;
+            break;
+        }
     }
+    (void)done_early;  // (S.misc[9..11] are next written behind the barriers of the next call's softmax)
     const uint32_t T = prefix;
     BS_TS(2);
     // ---- C: keep p > T and the first kk - #{p > T} ties in index order (thread-major, then slot)
@@ -266,6 +294,124 @@ __device__ int bsample(const float (&lv)[EPT], int n, int kk, float inv_t, float
     for (int w = 0; w < W; ++w) approx += S.wmax[w];
     const bool maybe_topp = top_p > 0.f && top_p < approx * 1.0001f;
     BS_TS(3);
+    // ---- fast tail (round 6): the three sequential f32 chains below (ascending-index sum, descending top-p walk, cumulative weights of the
+    // survivors) are the reference's own sums and their rounding is part of the result -- but only through two COMPARISONS: "has the running
+    // sum reached top_p" and "does the cumulative weight exceed the draw".  Any summation order of n <= 256 non-negative f32 terms lies within
+    // gamma_255 = 255 * 2^-24 / (1 - 255 * 2^-24) < 1.53e-5 (relative) of the exact sum, so two orders differ by < 3.05e-5 of it.  Wave 0
+    // therefore takes the sums as PARALLEL prefix scans (4 entries per lane + a DPP wave scan, ~100 instructions instead of a 150-256-step
+    // dependent chain) and accepts a comparison only where every prefix sum stays at least 6.2e-5 x total (top-p walk) / 1.3e-4 x total
+    // (draw: the threshold itself, u * scale(total), inherits the total's error) away from the threshold; otherwise -- a few per cent of
+    // the calls on flat rows -- the call falls through to the exact chains below, unchanged.  Same picks, token for token
+    // (tests/test_sampler_gpu.py, tests/test_persist_sampled_gpu.py); flat rows 11.5 -> ~5 us per call (profiles/r06_ubench_bsample.txt).
+    {
+        const double tp = batch ? top_p64 : (double)top_p;
+        const bool cut_sure = tp > 0.0 && tp < (double)approx * 0.9999, nocut_sure = !(tp > 0.0) || tp >= (double)approx * 1.0001;
+        if (cut_sure || nocut_sure) {  // (uniform over the block)
+            if (cut_sure) {
+                // descending-order ranks by counting, two threads per entry where the block has them (each counts one half of the entries)
+                constexpr int TPE = NT >= 2 * BS_MAXK ? 2 : 1;
+                const int kk8 = (kk + 7) & ~7, half = TPE == 2 ? (((kk8 >> 1) + 7) & ~7) : kk8;
+                const int part = TPE == 2 ? (tid >> 8) : 0, j = TPE == 2 ? (tid & (BS_MAXK - 1)) : tid;
+                int* part_rnk = reinterpret_cast<int*>(S.cumk);  // (cumk is not needed before the exact tail, which rewrites it)
+                int myr = 0;
+                const int pj = __float_as_int(S.kp[min(j, kk - 1)]);
+                if (tid < TPE * BS_MAXK && j < ((kk + 63) & ~63)) {
+                    const int lo = part == 0 ? 0 : half, hi = (TPE == 2 && part == 0) ? half : kk8;
+                    const int jb = __builtin_amdgcn_readfirstlane(j & ~63), pjm1 = pj - 1;
+                    int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+                    auto count8 = [&](int i, auto thr) {
+                        const float4 a = *reinterpret_cast<const float4*>(S.kp + i), b4 = *reinterpret_cast<const float4*>(S.kp + i + 4);
+                        r0 += __float_as_int(a.x) > thr(i) ? 1 : 0; r1 += __float_as_int(a.y) > thr(i + 1) ? 1 : 0;
+                        r2 += __float_as_int(a.z) > thr(i + 2) ? 1 : 0; r3 += __float_as_int(a.w) > thr(i + 3) ? 1 : 0;
+                        r0 += __float_as_int(b4.x) > thr(i + 4) ? 1 : 0; r1 += __float_as_int(b4.y) > thr(i + 5) ? 1 : 0;
+                        r2 += __float_as_int(b4.z) > thr(i + 6) ? 1 : 0; r3 += __float_as_int(b4.w) > thr(i + 7) ? 1 : 0;
+                    };
+                    const int lo_end = min(max(jb, lo), hi), mid_end = min(max(jb + 64, lo), hi);
+                    for (int i = lo; i < lo_end; i += 8) count8(i, [&](int) { return pjm1; });
+                    for (int i = lo_end; i < mid_end; i += 8) count8(i, [&](int ii) { return ii < j ? pjm1 : pj; });
+                    for (int i = mid_end; i < hi; i += 8) count8(i, [&](int) { return pj; });
+                    myr = (r0 + r1) + (r2 + r3);
+                    if (part == 1) part_rnk[j] = myr;
+                }
+                __syncthreads();
+                if (tid < kk) {
+                    const int r = myr + (TPE == 2 ? part_rnk[tid] : 0);
+                    S.rnk[tid] = r;
+                    S.sp[r] = __int_as_float(pj);
+                }
+                __syncthreads();
+            }
+            if (wv == 0) {
+                const int i0 = 4 * lane;
+                bool amb = false;
+                int cut = kk;
+                if (cut_sure) {  // first rank whose inclusive running sum (descending order) has reached top_p
+                    const float4 s4 = *reinterpret_cast<const float4*>(S.sp + i0);
+                    const float c0 = i0 < kk ? s4.x : 0.f, c1 = c0 + (i0 + 1 < kk ? s4.y : 0.f), c2 = c1 + (i0 + 2 < kk ? s4.z : 0.f), c3 = c2 + (i0 + 3 < kk ? s4.w : 0.f);
+                    const float off = bs_wave_scan_f(c3) - c3, eps = 6.2e-5f * approx;
+                    const float d[4] = {off + c0, off + c1, off + c2, off + c3};
+                    int below = 0;
+                    bool near = false;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (i0 + e < kk) { below += d[e] < top_p ? 1 : 0; near |= fabsf(d[e] - top_p) < eps; }
+                    below = bs_wave_scan(below);
+                    const int q = __builtin_amdgcn_readlane(below, 63);  // == the first rank whose sum is >= top_p (kk: none)
+                    amb = __ballot(near) != 0ull;
+                    cut = q < kk ? q + 1 : kk;
+                }
+                // cumulative weights of the survivors in index order (a cut entry weighs zero and moves no sum) and the draw over them
+                const float4 k4 = *reinterpret_cast<const float4*>(S.kp + i0);
+                float w[4] = {k4.x, k4.y, k4.z, k4.w};
+                if (cut_sure) {
+                    const int4 r4 = *reinterpret_cast<const int4*>(S.rnk + i0);
+                    if (r4.x >= cut) w[0] = 0.f;
+                    if (r4.y >= cut) w[1] = 0.f;
+                    if (r4.z >= cut) w[2] = 0.f;
+                    if (r4.w >= cut) w[3] = 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (i0 + e >= kk) w[e] = 0.f;
+                const float c0 = w[0], c1 = c0 + w[1], c2 = c1 + w[2], c3 = c2 + w[3];
+                const float incl = bs_wave_scan_f(c3), off = incl - c3;
+                const float total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63));
+                const float d[4] = {off + c0, off + c1, off + c2, off + c3};
+                int tok = -1;
+                if (!(total > 0.f)) amb = true;  // (all-zero weights: the exact tail knows the reference's answer)
+                else {
+                    // WeightedIndex::sample -- UniformFloat<f32>::sample_single over [0, total), as in F below
+                    const float max_rand = __uint_as_float((0xFFFFFFFFu >> 9) | (127u << 23)) - 1.0f;
+                    float scale = total;
+                    while (scale * max_rand + 0.f >= total) scale = __uint_as_float(__float_as_uint(scale) - 1u);
+                    const float chosen = (__uint_as_float((word >> 9) | (127u << 23)) - 1.0f) * scale + 0.f, eps2 = 1.3e-4f * total;
+                    int first = 4;
+                    bool near = false;
+#pragma unroll
+                    for (int e = 3; e >= 0; --e) {
+                        if (w[e] != 0.f && d[e] > chosen) first = e;
+                        near |= fabsf(d[e] - chosen) < eps2;
+                    }
+                    amb |= __ballot(near && i0 < kk) != 0ull;
+                    const unsigned long long m_hit = __ballot(first < 4);
+                    if (m_hit == 0ull) amb = true;
+                    else {
+                        const int src = __builtin_ctzll(m_hit);
+                        const int jsel = 4 * src + __builtin_amdgcn_readlane(first, src);
+                        tok = S.ki[jsel];
+                    }
+                }
+                if (lane == 0) S.misc[8] = amb ? -1 : tok;
+            }
+            __syncthreads();
+            const int fast = S.misc[8];
+            __syncthreads();  // (the scratch may be re-used by the caller; the exact tail below re-uses it too)
+            if (fast >= 0) {
+                BS_TS(4); BS_TS(5); BS_TS(6);
+                *consumed = 1;
+                return fast;
+            }
+        }
+    }
     // ---- D: ascending-index sum (wave 0) || ranks by counting (threads 64 .. 64 + kk)
     if (wv == 0) {
         float cum = 0.f;

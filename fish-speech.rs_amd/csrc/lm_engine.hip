@@ -13,6 +13,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <condition_variable>
 #include <map>
 #include <mutex>
 #include <type_traits>
@@ -87,29 +89,66 @@ class PersistLock {
             char bus[64] = {0};
             if (hipDeviceGetPCIBusId(bus, sizeof(bus), device) != hipSuccess) snprintf(bus, sizeof(bus), "dev%d", device);
             for (char* c = bus; *c; ++c) if (*c == ':' || *c == '/') *c = '_';
+            // The file must be visible to EVERY process that can reach the GPU (another user's process holding half the CUs is exactly the
+            // case the lock exists for), so it lives in a shared directory.  ADVICE r5: never follow a planted symlink (O_NOFOLLOW), accept
+            // only a regular file, and leave its mode alone unless this process created it (fchmod fails for a non-owner anyway).
             for (const char* dir : {"/dev/shm", "/tmp"}) {
                 const std::string path = std::string(dir) + "/fishrt-persist-" + bus + ".lock";
-                fd_ = open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0666);
-                if (fd_ >= 0) { (void)fchmod(fd_, 0666); break; }
-            }  // (no writable directory: the lock stays process-local)
+                int fd = open(path.c_str(), O_RDWR | O_CLOEXEC | O_NOFOLLOW);
+                if (fd < 0 && errno == ENOENT) {
+                    fd = open(path.c_str(), O_CREAT | O_EXCL | O_RDWR | O_CLOEXEC | O_NOFOLLOW, 0666);
+                    if (fd >= 0) (void)fchmod(fd, 0666);
+                    else if (errno == EEXIST) fd = open(path.c_str(), O_RDWR | O_CLOEXEC | O_NOFOLLOW);  // (lost the creation race)
+                }
+                if (fd < 0) continue;
+                struct stat st;
+                if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { close(fd); continue; }
+                fd_ = fd;
+                break;
+            }  // (no usable file: the lock stays process-local)
         });
     }
     bool try_lock() {
-        if (!m_.try_lock()) return false;
-        if (fd_ >= 0 && flock(fd_, LOCK_EX | LOCK_NB) != 0) { m_.unlock(); return false; }
+        {
+            std::lock_guard<std::mutex> g(mm_);
+            if (held_) return false;
+            held_ = true;
+        }
+        if (fd_ >= 0 && flock(fd_, LOCK_EX | LOCK_NB) != 0) { release_local(); return false; }
         return true;
     }
-    void lock() {
-        m_.lock();
-        if (fd_ >= 0) while (flock(fd_, LOCK_EX) != 0 && errno == EINTR) {}
+    // FISHRT_PERSIST_WAIT: wait for the holder -- but not forever (anybody can hold an advisory lock on a shared file): the wait
+    // is bounded (the variable's value in seconds; 1 = the default of 600), after which the caller runs on the per-node graphs like a
+    // caller that never waited.  Returns whether the lock was taken.
+    bool lock_for(double seconds) {
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(seconds);
+        {
+            std::unique_lock<std::mutex> g(mm_);
+            if (!cv_.wait_until(g, deadline, [&] { return !held_; })) return false;
+            held_ = true;
+        }
+        if (fd_ < 0) return true;
+        for (;;) {
+            if (flock(fd_, LOCK_EX | LOCK_NB) == 0) return true;
+            if (std::chrono::steady_clock::now() >= deadline) { release_local(); return false; }
+            usleep(500);
+        }
     }
+    void lock() { (void)lock_for(600.0); }
+    // (a binary semaphore, not a std::mutex: a row session takes it in session_begin and gives it back in session_end, possibly on another thread)
     void unlock() {
         if (fd_ >= 0) (void)flock(fd_, LOCK_UN);
-        m_.unlock();
+        release_local();
     }
 
   private:
-    std::mutex m_;
+    void release_local() {
+        { std::lock_guard<std::mutex> g(mm_); held_ = false; }
+        cv_.notify_one();
+    }
+    std::mutex mm_;
+    std::condition_variable cv_;
+    bool held_ = false;
     std::once_flag once_;
     int fd_ = -1;
 };
@@ -118,10 +157,15 @@ PersistLock& persist_mutex(int device) {
     m[device & 63].bind(device);
     return m[device & 63];
 }
-// try (default) or wait (FISHRT_PERSIST_WAIT) for the device's persistent kernels
+// try (default) or wait (FISHRT_PERSIST_WAIT = seconds; 1 = 600 s) for the device's persistent kernels
 std::unique_lock<PersistLock> acquire_persist(int device) {
-    if (getenv("FISHRT_PERSIST_WAIT")) return std::unique_lock<PersistLock>(persist_mutex(device));
-    return std::unique_lock<PersistLock>(persist_mutex(device), std::try_to_lock);
+    PersistLock& pl = persist_mutex(device);
+    if (const char* w = getenv("FISHRT_PERSIST_WAIT")) {
+        const double secs = atof(w) > 1.0 ? atof(w) : 600.0;
+        if (pl.lock_for(secs)) return std::unique_lock<PersistLock>(pl, std::adopt_lock);
+        return std::unique_lock<PersistLock>(pl, std::defer_lock);
+    }
+    return std::unique_lock<PersistLock>(pl, std::try_to_lock);
 }
 
 constexpr int kRows = 256;     // static-batch generator: max sequences per step (32-row MFMA panels; <= kPartRows)
@@ -933,12 +977,8 @@ class LM final : public LMBase {
             ~RowsGuard() { if (armed) flag = false; }
         } rows_guard{sess_rows_};
         if (flags & FS_SESSION_ROWS) {
-            const int tk = (int)std::min<uint64_t>(s.top_k, 1u << 30);
-            const bool ok = B_ >= 2 && B_ <= PR_MAX_ROWS && pslow_ok_ && persist_ok_ && !legacy_ && n_audio_ <= 2048 &&
-                            (s.temp == 0.0 || fast_persist_samples((float)s.temp, tk, a_.codebook_size));
-            FS_REQUIRE(ok, "FS_SESSION_ROWS needs a bf16 / fp8 Fish-1.5 handle with 2 <= max_batch <= 8 and greedy or top_k <= 256 sampling");
-            FS_REQUIRE(B_ == 2 || B_ == 4 || B_ == 8, "FS_SESSION_ROWS needs max_batch 2, 4 or 8 (the row launches cover exactly that many slots; state slot max_batch is the prefill staging state)");
-            FS_REQUIRE(rows_kv_span_ok(B_), "FS_SESSION_ROWS: max_seq_len too long for the row kernels' attention slices at this slot count");
+            const char* why = nullptr;
+            if (!rows_predicate(B_, &s, 1, /*for_session=*/true, &why)) throw Error(std::string("FS_SESSION_ROWS needs ") + why);
             FS_REQUIRE(!free_pages_.empty(), "KV page pool exhausted");
             // the device's persistent-kernel lock is held in a LOCAL until nothing below can throw any more (a throw after taking it used to
             // leave sess_plock_ owning the mutex with sess_active_ false: session_end returned early and the device was locked out for good)
@@ -1507,19 +1547,31 @@ class LM final : public LMBase {
 
     // fs_lm_rows_supported: would fs_lm_generate_multi serve these n requests on the request-row kernels (one persistent launch group per
     // frame) rather than one after the other?  Says nothing about whether another call holds the device's persistent kernels right now.
-    bool rows_supported(int n, const fs_sampling* samplings) override {
-        bool ok = n >= 2 && n <= PR_MAX_ROWS && n <= B_ && loaded_ && pslow_ok_ && persist_ok_ && n_audio_ <= 2048 &&
-                  !getenv("FISHRT_NO_ROWS") && rows_kv_span_ok(n <= 2 ? 2 : (n <= 4 ? 4 : 8));
-        // one instantiation per launch: every request greedy, or every request within the in-launch sampler (temp > 0, 0 < top_k <= 256)
-        const bool sampled = ok && samplings[0].temp != 0.0;
-        for (int i = 0; i < n && ok; ++i) {
-            const fs_sampling& s = samplings[i];
-            const int tk = (int)std::min<uint64_t>(s.top_k, 1u << 30);
-            if ((s.temp != 0.0) != sampled) ok = false;
-            if (sampled && !fast_persist_samples((float)s.temp, tk, a_.codebook_size)) ok = false;
+    // ONE predicate for "these requests run on the request-row kernels" (the capability query, fs_lm_generate_multi and
+    // fs_lm_session_begin(FS_SESSION_ROWS) used to carry three hand-written copies that had drifted apart).  ns = 1: one sampler setting for
+    // all n rows (sessions); ns = n: one per request.  for_session: a row session's slots additionally need the Fish 1.5 token layout (the
+    // legacy 2-way slow draw is per-call state of generate_multi, not of a slot) and exactly 2, 4 or 8 slots.  why (nullable): what failed.
+    bool rows_predicate(int n, const fs_sampling* ss, int ns, bool for_session, const char** why = nullptr) const {
+        const char* w = nullptr;
+        if (!(n >= 2 && n <= PR_MAX_ROWS && n <= B_)) w = "2 <= requests <= min(8, max_batch)";
+        else if (!(loaded_ && pslow_ok_ && persist_ok_ && n_audio_ <= 2048)) w = "a loaded bf16 / fp8 handle with the Fish geometry on a 256-CU device";
+        else if (getenv("FISHRT_NO_ROWS")) w = "FISHRT_NO_ROWS is set";
+        else if (!rows_kv_span_ok(n <= 2 ? 2 : (n <= 4 ? 4 : 8))) w = "max_seq_len too long for the row kernels' attention slices at this row count";
+        else if (for_session && legacy_) w = "row SESSIONS need the Fish 1.5 token layout (fs_lm_generate_multi serves Fish <= 1.4 handles)";
+        else if (for_session && !(n == 2 || n == 4 || n == 8)) w = "row sessions need max_batch 2, 4 or 8";
+        else {
+            // one instantiation per launch: every request greedy, or every request within the in-launch sampler (temp > 0, 0 < top_k <= 256)
+            const bool sampled = ss[0].temp != 0.0;
+            for (int i = 0; i < ns && !w; ++i) {
+                const int tk = (int)std::min<uint64_t>(ss[i].top_k, 1u << 30);
+                if ((ss[i].temp != 0.0) != sampled) w = "every request greedy or every request sampled";
+                else if (sampled && !fast_persist_samples((float)ss[i].temp, tk, a_.codebook_size)) w = "sampled requests with 0 < top_k <= 256";
+            }
         }
-        return ok;
+        if (why) *why = w;
+        return w == nullptr;
     }
+    bool rows_supported(int n, const fs_sampling* samplings) override { return rows_predicate(n, samplings, n, /*for_session=*/false); }
 
   private:
     void use_device() { FS_HIP(hipSetDevice(device_)); }

@@ -255,6 +255,13 @@ class OracleCodec:
         _chk(lib().orc_codec_load_synthetic(self.h, C.c_uint64(seed)))
         return self
 
+    def set_tensors(self, tensors):
+        """override decode-side tensors (name -> array, the checkpoint's names) of a codec sized by load_synthetic"""
+        for name, v in tensors.items():
+            a = np.ascontiguousarray(v, np.float32)
+            _chk(lib().orc_codec_set_tensor(self.h, name.encode(), _p(a, C.c_float), C.c_uint64(a.size)))
+        return self
+
     @property
     def hop(self):
         return lib().orc_codec_hop(self.h)

@@ -230,6 +230,7 @@ void* orc_codec_create(int tiny) {
 }
 void orc_codec_destroy(void* c) { delete (Codec*)c; }
 int orc_codec_load_synthetic(void* c, uint64_t seed) { GUARD(((Codec*)c)->load_synthetic(seed)) }
+int orc_codec_set_tensor(void* c, const char* name, const float* data, uint64_t n) { GUARD(((Codec*)c)->set_tensor(name, data, (size_t)n)) }
 int orc_codec_hop(void* c) { return ((Codec*)c)->hop(); }
 void orc_codec_fsq_code(void* c, uint32_t idx, float* code4) { ((Codec*)c)->fsq_code(idx, code4); }
 // pcm_out: (hop*T).  If stage_out != null, stage `stage_idx` (0 = quantizer output, 1..2 upsample, 3 conv_pre,

@@ -134,6 +134,47 @@ static void fill_conv(Conv& c, int cout, int cin_per_group, int k, bool transpos
     fsgen::fill(c.b.data(), cout, name + ".conv.bias", seed, 0.f, 0.02, false);
 }
 
+// decode side only (what a "hard checkpoint" test overrides): name -> the vector load_synthetic sized
+void Codec::set_tensor(const std::string& name, const float* data, size_t n) {
+    std::vector<float>* dst = nullptr;
+    auto conv = [&](Conv& c, const std::string& prefix) {
+        if (name == prefix + ".conv.weight") dst = &c.w;
+        else if (name == prefix + ".conv.bias") dst = &c.b;
+    };
+    for (int g = 0; g < n_groups && !dst; ++g) {
+        const std::string p = "quantizer.residual_fsq.rvqs." + std::to_string(g) + ".project_out";
+        if (name == p + ".weight") dst = &proj_w[g];
+        else if (name == p + ".bias") dst = &proj_b[g];
+    }
+    for (size_t i = 0; i < up_conv.size() && !dst; ++i) {
+        const std::string p = "quantizer.upsample." + std::to_string(i);
+        conv(up_conv[i], p + ".0");
+        ConvNeXt& b = up_block[i];
+        conv(b.dwconv, p + ".1.dwconv");
+        if (name == p + ".1.norm.weight") dst = &b.norm_w;
+        else if (name == p + ".1.norm.bias") dst = &b.norm_b;
+        else if (name == p + ".1.pwconv1.weight") dst = &b.pw1_w;
+        else if (name == p + ".1.pwconv1.bias") dst = &b.pw1_b;
+        else if (name == p + ".1.pwconv2.weight") dst = &b.pw2_w;
+        else if (name == p + ".1.pwconv2.bias") dst = &b.pw2_b;
+        else if (name == p + ".1.gamma") dst = &b.gamma;
+    }
+    if (!dst) conv(conv_pre, "head.conv_pre");
+    if (!dst) conv(conv_post, "head.conv_post");
+    for (size_t i = 0; i < ups.size() && !dst; ++i) {
+        conv(ups[i], "head.ups." + std::to_string(i));
+        for (size_t j = 0; j < res[i].size() && !dst; ++j)
+            for (size_t m = 0; m < res[i][j].c1.size() && !dst; ++m) {
+                const std::string q = "head.resblocks." + std::to_string(i) + ".blocks." + std::to_string(j);
+                conv(res[i][j].c1[m], q + ".convs1." + std::to_string(m));
+                if (!dst) conv(res[i][j].c2[m], q + ".convs2." + std::to_string(m));
+            }
+    }
+    if (!dst) throw std::runtime_error("oracle codec: unknown decode-side tensor " + name);
+    if (dst->size() != n) throw std::runtime_error("oracle codec: " + name + " has " + std::to_string(dst->size()) + " elements, got " + std::to_string(n));
+    std::copy(data, data + n, dst->begin());
+}
+
 void Codec::load_synthetic(uint64_t seed) {
     const int dg = input_dim / n_groups;
     proj_w.resize(n_groups); proj_b.resize(n_groups);

@@ -55,6 +55,9 @@ struct Codec {
     void init_fish15();
     void init_tiny();
     void load_synthetic(uint64_t seed);
+    // decode-side tensor by its checkpoint name (the reference's VarBuilder paths: quantizer.rs:69-94, hifi_gan.rs:128-205, codec/utils/mod.rs:28-40);
+    // the codec must have been sized by load_synthetic first; throws on an unknown name or a size mismatch
+    void set_tensor(const std::string& name, const float* data, size_t n);
     void fsq_code(uint32_t idx, float* code4) const;
     int hop() const { int h = 1; for (int d : downsample) h *= d; for (int r : up_rates) h *= r; return h; }
     std::vector<float> decode(const uint32_t* codes, int T, std::vector<std::vector<float>>* stages = nullptr) const;

@@ -246,3 +246,65 @@ def test_f16_range_guard_counts_and_falls_back(tmp_path):
     st = c.range_stats()
     assert st["fallbacks"] == 0 and st["last_pcm_rms_diff"] < 4e-5, st
     c.close()
+
+
+def test_hard_checkpoint_weight_norm_scales_vs_f32_oracle(tmp_path):
+    """the vocoder's f16 operand mode has only seen N(0, 1 / fan_in) weights.  A real Firefly checkpoint is weight-normed and
+    "must be pre-merged" (codec/utils/mod.rs:28-40): after merging g / ||v|| every output channel carries its own gain.  This builds that kind
+    of checkpoint: per-output-channel gains log-uniform in [0.05, 20] on the first conv of every ResBlock pair and on conv_pre (weights AND
+    biases), the inverse gain on the matching input channel of the conv that consumes it (so the network's function stays in range while its
+    intermediate planes span 400 x in scale, channel by channel), biases of size 0.2, and code indices at the extremes 0 / 999 among random
+    ones.  Contract: with the range guard on, decode() answers within 1e-4 RMS of the f32 oracle -- from the f16 mode, or from the bf16x3 mode
+    it falls back to (server/lib/utils/load.rs:161-164 runs the codec in f32; the bound is the north star's)."""
+    import test_safetensors_gpu as tsf
+    rng = np.random.RandomState(11)
+    t = {k: v.copy() for k, v in tsf._codec_tensors(64, 1234).items()}
+    gains = lambda n: np.exp(rng.uniform(np.log(0.05), np.log(20.0), n)).astype(np.float32)
+    for k in list(t):
+        if k.endswith(".bias") and k.startswith("head."):
+            t[k] = (t[k] * 10.0).astype(np.float32)  # std 0.02 -> 0.2
+    n_pairs = 0
+    for s_ in range(5):
+        for j in range(3):
+            for m in range(3):
+                q = f"head.resblocks.{s_}.blocks.{j}"
+                w1, b1, w2 = q + f".convs1.{m}.conv.weight", q + f".convs1.{m}.conv.bias", q + f".convs2.{m}.conv.weight"
+                g = gains(t[w1].shape[0])
+                t[w1] = t[w1] * g[:, None, None]            # Conv1d [out, in, k]: output channel gains
+                t[b1] = t[b1] * g
+                t[w2] = t[w2] / g[None, :, None]            # the consumer's input channels
+                n_pairs += 1
+    g = gains(t["head.conv_pre.conv.weight"].shape[0])
+    t["head.conv_pre.conv.weight"] *= g[:, None, None]
+    t["head.conv_pre.conv.bias"] *= g
+    t["head.ups.0.conv.weight"] /= g[:, None, None]          # ConvTranspose1d [in, out, k]
+    assert n_pairs == 45
+    codes = rng.randint(0, 1000, (1, 8, 16)).astype(np.uint32)
+    codes[0, :, 0] = 0; codes[0, :, 5] = 999; codes[0, ::2, 9] = 0; codes[0, 1::2, 9] = 999
+    ref = orc.OracleCodec(tiny=True).load_synthetic(1234).set_tensors({k: v for k, v in t.items() if k.startswith(("head.", "quantizer.upsample", "quantizer.residual_fsq")) and "project_in" not in k}).decode(codes[0])
+    sig = float(np.sqrt(np.mean(ref.astype(np.float64) ** 2)))
+    path = str(tmp_path / "hard.safetensors")
+    tsf._save(t, path, False)
+    rms = lambda a: float(np.sqrt(np.mean((a.astype(np.float64) - ref) ** 2)))
+    c32 = fishrt.FireflyCodec(0, channel_div=8, precision="f32").load_safetensors(path)
+    e32 = rms(c32.decode(codes)[0, 0])
+    c32.close()
+    c = fishrt.FireflyCodec(0, channel_div=8, precision="f16").load_safetensors(path)
+    e16_unguarded = rms(c.decode(codes)[0, 0])
+    c.set_range_check(True)
+    got = c.decode(codes)[0, 0]
+    st = c.range_stats()
+    c.close()
+    c3 = fishrt.FireflyCodec(0, channel_div=8, precision="bf16x3").load_safetensors(path)
+    e3 = rms(c3.decode(codes)[0, 0])
+    c3.close()
+    print(f"hard checkpoint: signal rms {sig:.3f}; rms error vs the f32 oracle: f32 mode {e32:.2e}, bf16x3 {e3:.2e}, f16 unguarded {e16_unguarded:.2e}, "
+          f"guarded answer {rms(got):.2e} (fallbacks {st['fallbacks']}, act_saturated {st['act_saturated']}, act_flushed {st['act_flushed']}, "
+          f"weights_saturated {st['weights_saturated']}, weights_flushed {st['weights_flushed']}, f16-vs-bf16x3 {st['last_pcm_rms_diff']:.2e})")
+    assert np.isfinite(got).all() and e32 < 2e-6 and e3 < 2.5e-5
+    assert rms(got) < 1e-4, "the guarded decode left the 1e-4 RMS bound on a weight-norm-scaled checkpoint"
+    # which mode answered is data; that the guard's rule was followed is the check: a fall-back answer IS the bf16x3 PCM
+    if st["fallbacks"]:
+        assert abs(rms(got) - e3) < 1e-9
+    else:
+        assert st["act_saturated"] == 0 and st["last_pcm_rms_diff"] <= 5e-5

@@ -51,7 +51,11 @@ def _oracle_picks(cap, seed, temp, top_p, top_k):
 
 
 @pytest.mark.parametrize("kw", [dict(temp=0.7, top_p=0.8, top_k=256), dict(temp=0.7, top_p=0.9, top_k=50), dict(temp=1.0, top_p=0.3, top_k=256),
-                                dict(temp=1.3, top_p=1.0, top_k=200), dict(temp=0.0, top_p=1.0, top_k=0)])
+                                dict(temp=1.3, top_p=1.0, top_k=200), dict(temp=0.0, top_p=1.0, top_k=0),
+                                # PEAKED rows: the synthetic weights give flat logits; a trained head does not.  The sampler sees
+                                # logits / temp, so temp = 0.7 / 8 IS "output heads scaled x 8 at the server's temp 0.7" (a power-of-two scale is exact),
+                                # and temp 0.02 is the regime where the largest probability alone exceeds top_p (one-weight shortcut) on most rows
+                                dict(temp=0.0875, top_p=0.8, top_k=256), dict(temp=0.02, top_p=0.8, top_k=256), dict(temp=0.05, top_p=0.95, top_k=40)])
 @pytest.mark.parametrize("rep_pen", [1.0, 1.2])
 def test_in_launch_decisions_equal_the_oracle_sampler_on_the_same_logits(lm15, kw, rep_pen):
     F, seed = 40, 1234

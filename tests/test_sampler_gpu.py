@@ -69,6 +69,33 @@ def test_static_batch_sampler_rows_token_exact(n, temp, top_p, top_k, impl):
     print(f"n={n} temp={temp} top_p={top_p} top_k={top_k}: {agree}/{total} rows identical")
 
 
+def test_fast_tail_guards_token_exact_in_volume():
+    """Round 6: the block-parallel sampler takes its three cumulative sums as PARALLEL prefix scans and accepts a threshold comparison only
+    where the scan stays a guard band (6.2e-5 / 1.3e-4 x total: twice the worst-case distance between two summation orders of 256 terms) away
+    from the threshold; inside the band the call falls through to the reference's sequential chains (lm_bsample_dev.h, "fast tail").  On flat
+    rows a few per cent of the draws land in the band, so BOTH tails -- and the boundary between them -- are exercised here in volume:
+    12 800 rows per setting, every pick identical to the oracle's sequential sampler."""
+    old = os.environ.get("FISHRT_SAMPLER_IMPL")
+    os.environ["FISHRT_SAMPLER_IMPL"] = "par512"
+    try:
+        rs = np.random.RandomState(99)
+        for temp, top_p, top_k, n in ((0.7, 0.8, 256, 1024), (0.7, 0.5, 256, 2037), (1.0, 0.9, 128, 1024), (0.9, 0.97, 256, 1024), (0.7, 0.999, 256, 1024)):
+            bad = total = 0
+            for call in range(25):
+                for scale in (1.0, 2.5):
+                    logits = np.ascontiguousarray((rs.randn(256, n) * scale).astype(np.float32))
+                    g, o = _gpu_rows(logits, temp, top_p, top_k, 7, call), _orc_rows(logits, temp, top_p, top_k, 7, call)
+                    bad += int((g != o).sum())
+                    total += 256
+            print(f"temp={temp} top_p={top_p} top_k={top_k} n={n}: {total - bad}/{total} rows identical")
+            assert bad == 0
+    finally:
+        if old is None:
+            os.environ.pop("FISHRT_SAMPLER_IMPL", None)
+        else:
+            os.environ["FISHRT_SAMPLER_IMPL"] = old
+
+
 def test_batch_path_compares_top_p_in_f64(impl):
     """sampling/mod.rs:68: `top_p >= sum_p as f64` with top_p kept as f64 -- for a top_p a hair below the f32 sum of the kept probabilities
     the f64 rule takes the top-p branch where an f32 comparison (top_p rounds up to the sum) would draw from all k.  A sweep of top_p values

@@ -1975,6 +1975,9 @@ class LM final : public LMBase {
             cf.first_prepped = prep_g != nullptr;
             cf.identity_pages = true;  // d_fast_table_[i] == i
             cf.attn_t1 = cbi == 0;     // d_fast_state_[0].pos == 0
+            // passes 1..: the first fast layer's q / k / v come from the qkv table (row = the code the previous pass picked): no Wqkv node
+            const bool tbl = fold && cbi > 0 && d_qkv0_.p && !getenv("FISHRT_ROWS_NO_QKV0") && a_.codebook_size == 1024;
+            if (tbl) { cf.qkv0_tbl = d_qkv0_.as<float>(); cf.row_states = state(0); cf.code_slot = cbi; }
             for (int l = 0; l < a_.n_fast_layer; ++l) {
                 KVView kv;
                 KT* base = fast_pool_.as<KT>() + ((size_t)l * 2 * B_) * page_elems_;
@@ -1988,7 +1991,9 @@ class LM final : public LMBase {
                                              cap_frames_, 1 + cbi, st_);
             SampleKernels<WT>::sample_fast_rows(d_, d_lfast_.as<float>(), cbi, C, a_.codebook_size, d_cfg_.as<SampleCfg>(),
                                                 d_rng_.as<RngState>(), B, state(0), fast_emb_, d_xfrows_.as<float>(), tok_emb_, cb_emb_,
-                                                cs.X, d_out_.as<uint32_t>(), out_cap_, st_, words, prep_g, cs.A);
+                                                cs.X, d_out_.as<uint32_t>(), out_cap_, st_, words,
+                                                // (with the qkv table the next pass's first layer needs no normalised GEMM input from this sampler)
+                                                (fold && d_qkv0_.p && !getenv("FISHRT_ROWS_NO_QKV0") && a_.codebook_size == 1024) ? nullptr : prep_g, cs.A);
         }
         if (capt) launch_cap_rows_picks(state(0), d_cfg_.as<SampleCfg>(), B, d_rcap_.as<float>(), cap_frames_, C, st_);
     }

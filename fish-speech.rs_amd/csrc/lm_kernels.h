@@ -101,6 +101,9 @@ struct RowsCtx {
     bool identity_pages = false; // small_attn: page_table[m * pt_stride] == m for every row (the batched fast decoder's one-page-per-row table)
     bool first_prepped = false;  // fold: the first layer's normalised input fragments are already in A (written by the sampler that produced the row)
     bool fold = false;           // decode step with the un-split down projection (see rows_layer's next_norm)
+    const float* qkv0_tbl = nullptr;         // fold + small_attn, first layer of a codebook pass >= 1: [codebook_size][(H + 2 Hk) Dh] f32 qkv table (lm_persist.hip) -- no Wqkv node
+    const SeqState* row_states = nullptr;    // ... the rows' generator states: row m's previous code = row_states[m].cur[code_slot]
+    int code_slot = 0;
     unsigned stage_mask = 0xFFu;  // micro-benchmark hook: bit i enables stage i of rows_layer (prep, qkv, attn, combine, wo, prep, w13, w2)
 };
 

@@ -1497,6 +1497,117 @@ __global__ __launch_bounds__(256) void k_attn_small_rows(const float* __restrict
     }
 }
 
+// k_attn_small_rows for the FIRST fast layer of the codebook passes 1.. (round 6): that layer's input row is fast_embeddings[code] of the code the
+// previous pass's sampler picked (static_batch.rs:236-241 / single_batch.rs:181-183), so attention_norm + Wqkv of it is row `code` of the qkv
+// table the persistent fast decoder builds at load time (lm_persist.hip k_pf_qkv0_table: 1024 x 1280 f32, pre-RoPE).  The node takes q / k / v of
+// the new token from that row instead of from a Wqkv GEMM node in front of it (7 nodes of a step disappear): RoPE at the pass's position, K / V
+// appended to the row's page exactly as the GEMM epilogue would (bf16, EPI_QKV), and the new position's K / V used from LDS in their cached
+// (bf16-rounded) form.  code = row_states[m].cur[code_slot] (written by the sampler node in front of this one).
+template <int DH>
+__global__ __launch_bounds__(256) void k_attn_small_rows_tbl(const float* __restrict__ tbl, const SeqState* __restrict__ row_states, int code_slot, KVView kv,
+                                                             const SeqState* __restrict__ state, int H, int Hk, int pos_step, int pt_stride,
+                                                             const float* __restrict__ cos_t, const float* __restrict__ sin_t, bf16_t* __restrict__ Ohi,
+                                                             int identity_pages) {
+    __shared__ float sc[32 * 8];
+    __shared__ __attribute__((aligned(16))) float qS[32 * DH];
+    __shared__ __attribute__((aligned(16))) float knS[4 * DH], vnS[4 * DH];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const int page = identity_pages ? m : kv.page_table[(size_t)m * pt_stride];
+    const int n_rep = H / Hk;
+    bf16_t* kb = reinterpret_cast<bf16_t*>(kv.k) + (size_t)page * Hk * KV_PAGE * DH;
+    bf16_t* vb = reinterpret_cast<bf16_t*>(kv.v) + (size_t)page * Hk * KV_PAGE * DH;
+    const float scale = 1.0f / sqrtf((float)DH);
+    constexpr int QD = DH / 2;
+    uint2 vpre[8];  // (as k_attn_small_rows: requested up front; the slot of the new position is stale here and replaced below)
+    {
+        const int e4 = tid * 4;
+        if (e4 < H * DH) {
+            const int h = e4 / DH, dd = e4 % DH;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) vpre[t] = *reinterpret_cast<const uint2*>(vb + ((size_t)(h / n_rep) * KV_PAGE + t) * DH + dd);
+        }
+    }
+    const int pos = row_pos(state, m, pos_step), T = pos + 1;
+    const int rpos = pos + (pos_step < 0 ? state[m].rope_off : state->rope_off);
+    const uint32_t code = row_states[m].cur[code_slot];
+    const int qdim = H * DH, kdim = Hk * DH;
+    const float* row = tbl + (size_t)code * (qdim + 2 * kdim);
+    for (int i = tid; i < (qdim + 2 * kdim) / 2; i += 256) {
+        const int r = 2 * i;
+        const float2 ab = *reinterpret_cast<const float2*>(row + r);
+        if (r < qdim + kdim) {  // rope_i (dual_ar.rs:246-247)
+            const int j = (r % DH) / 2;
+            const float cs = cos_t[(size_t)rpos * QD + j], sn = sin_t[(size_t)rpos * QD + j];
+            const float o0 = ab.x * cs - ab.y * sn, o1 = ab.x * sn + ab.y * cs;
+            if (r < qdim) { qS[r] = o0; qS[r + 1] = o1; }
+            else {
+                const int rk = r - qdim;
+                const bf16_t b0 = WTr<bf16_t>::from_f32(o0), b1 = WTr<bf16_t>::from_f32(o1);
+                *reinterpret_cast<uint32_t*>(kb + ((size_t)(rk / DH) * KV_PAGE + pos) * DH + rk % DH) = b0 | ((uint32_t)b1 << 16);
+                knS[rk] = bf16_bits_to_f32(b0); knS[rk + 1] = bf16_bits_to_f32(b1);
+            }
+        } else {
+            const int rv = r - qdim - kdim;
+            const bf16_t b0 = WTr<bf16_t>::from_f32(ab.x), b1 = WTr<bf16_t>::from_f32(ab.y);
+            *reinterpret_cast<uint32_t*>(vb + ((size_t)(rv / DH) * KV_PAGE + pos) * DH + rv % DH) = b0 | ((uint32_t)b1 << 16);
+            vnS[rv] = bf16_bits_to_f32(b0); vnS[rv + 1] = bf16_bits_to_f32(b1);
+        }
+    }
+    __syncthreads();
+    for (int e1 = tid >> 1; e1 < H * 8; e1 += 128) {
+        const int h = e1 >> 3, t = e1 & 7, sl = tid & 1;
+        const bf16_t* kp = kb + ((size_t)(h / n_rep) * KV_PAGE + t) * DH + sl * QD;
+        const float* kn = knS + (h / n_rep) * DH + sl * QD;
+        const float* qp = qS + h * DH + sl * QD;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < QD; i += 8) {
+            float kf[8];
+            WTr<bf16_t>::unpack(*reinterpret_cast<const u32x4*>(kp + i), kf);
+            if (t == pos) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) kf[j] = kn[i + j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc = fmaf(qp[i + j], kf[j] * scale, acc);  // q . (k^T * scale)  (dual_ar.rs:260)
+        }
+        acc += dpp_mov<DPP_XOR1>(acc);
+        if (sl == 0) sc[e1] = acc;
+    }
+    __syncthreads();
+    for (int e4 = tid * 4; e4 < H * DH; e4 += 1024) {
+        const int h = e4 / DH, dd = e4 % DH;
+        const bool firstit = e4 == tid * 4;
+        float mx = -1e30f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) if (t < T) mx = fmaxf(mx, sc[h * 8 + t]);
+        float L = 0.f, O[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            if (t < T) {
+                const float p = __expf(sc[h * 8 + t] - mx);
+                L += p;
+                if (t == pos) {
+                    const float* vn = vnS + (h / n_rep) * DH + dd;
+                    O[0] = fmaf(p, vn[0], O[0]); O[1] = fmaf(p, vn[1], O[1]); O[2] = fmaf(p, vn[2], O[2]); O[3] = fmaf(p, vn[3], O[3]);
+                } else {
+                    const uint2 vv = firstit ? vpre[t] : *reinterpret_cast<const uint2*>(vb + ((size_t)(h / n_rep) * KV_PAGE + t) * DH + dd);
+                    O[0] = fmaf(p, bf16_bits_to_f32((bf16_t)(vv.x & 0xFFFFu)), O[0]); O[1] = fmaf(p, bf16_bits_to_f32((bf16_t)(vv.x >> 16)), O[1]);
+                    O[2] = fmaf(p, bf16_bits_to_f32((bf16_t)(vv.y & 0xFFFFu)), O[2]); O[3] = fmaf(p, bf16_bits_to_f32((bf16_t)(vv.y >> 16)), O[3]);
+                }
+            }
+        const float inv = 1.f / L;
+        bf16_t hi[4], lo[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) split_bf16(O[i] * inv, hi[i], lo[i]);
+        uint2 ph, pl;
+        ph.x = hi[0] | ((uint32_t)hi[1] << 16); ph.y = hi[2] | ((uint32_t)hi[3] << 16);
+        pl.x = lo[0] | ((uint32_t)lo[1] << 16); pl.y = lo[2] | ((uint32_t)lo[3] << 16);
+        *reinterpret_cast<uint2*>(Ohi + frag_off(m, e4, 0, H * DH)) = ph;
+        *reinterpret_cast<uint2*>(Ohi + frag_off(m, e4, 1, H * DH)) = pl;
+    }
+}
+
 // Static-batch decode attention in ONE node: block = (kv head g, activation row m) walks the row's whole KV prefix chunk by
 // chunk (same wave / lane-group geometry as k_attn_decode; the next chunk's K/V tiles are in flight while the current one is
 // scored), every lane group keeps a running (max, sum, o) (online softmax), the waves meet once in LDS and the normalised result
@@ -3402,7 +3513,11 @@ void LmKernels<WT>::rows_layer(const ModelDims& d, int M, const RowsCtx& c, cons
         if (fold) FS_REQUIRE(rows_fold_ok(d, M, c), "folded decode step on a shape the un-split down projection does not take");
         const int nblk_d = d.dim / 16;
         // (1) x += previous layer's down-proj slabs ; RMSNorm(attention_norm) -> hi/lo
-        if (fold && (!first || c.first_prepped)) {}   // (first_prepped: the sampler that wrote the input row left its normalised fragments in c.A)
+        // c.qkv0_tbl (fold, small_attn, first layer of a codebook pass >= 1): q / k / v of the new token are a row of the qkv table -- no k_prep, no Wqkv
+        // GEMM; the attention node reads the table itself (k_attn_small_rows_tbl)
+        const bool tbl0 = fold && first && c.qkv0_tbl != nullptr && c.small_attn && !c.attn_t1 && d.Dh == 64 && d.H <= 32 && d.Hk <= 4 && (c.stage_mask & 4u);
+        if (tbl0) {}
+        else if (fold && (!first || c.first_prepped)) {}   // (first_prepped: the sampler that wrote the input row left its normalised fragments in c.A)
         else if (c.stage_mask & 1u) hipLaunchKernelGGL(k_prep, dim3(M), dim3(256), 0, st, c.X, d.dim, c.P, first ? 0 : DOWN_SPLIT, slab, w.attn_norm, d.eps, c.A);
         // (2) Wqkv + rope + KV scatter
         // c.attn_t1 (fold, small_attn; every row at position 0 of an empty cache): the Wqkv epilogue leaves the attention output itself
@@ -3413,13 +3528,17 @@ void LmKernels<WT>::rows_layer(const ModelDims& d, int M, const RowsCtx& c, cons
         // tagged units, block m then attends for row m, bit-identical results: 10.1-10.4 us per node against 5.7 + 5.6 for the two nodes under
         // rocprofv3, 1856-1877 vs 1825-1833 us per step -- a consumer that waits for units from all 80 blocks on all 8 XCDs pays the slowest
         // block's finish + cross-XCD visibility, unlike k_gemm_down's four same-XCD partners; profiles/r05_rows_fold.txt)
-        if (fold && !first)
+        if (tbl0) {}
+        else if (fold && !first)
             launch_gemm3<EPI_QKV_RMS>(qkv_rows, 1, rt_qkv, st, c.A, M, d.dim, w.wqkv, w.s_qkv, c.Q, d.dim, 0, o1, 0,
                                       c.cos_t, c.sin_t, c.state, kv, d.H, d.Hk, d.Dh, rm, NormAux{nullptr, c.ss, nullptr, nblk_d, d.dim, d.eps});
         else if (c.stage_mask & 2u) launch_gemm3<EPI_QKV>(qkv_rows, 1, rt_qkv, st, c.A, M, d.dim, w.wqkv, w.s_qkv, c.Q, d.dim, 0, o1, 0,
                               c.cos_t, c.sin_t, c.state, kv, d.H, d.Hk, d.Dh, rm);
         // (3) attention over each row's KV prefix + chunk combine -> hi/lo
         if (t1) {}
+        else if (tbl0)
+            hipLaunchKernelGGL((k_attn_small_rows_tbl<64>), dim3(M), dim3(256), 0, st, c.qkv0_tbl, c.row_states, c.code_slot, kv, c.state, d.H, d.Hk, c.pos_step,
+                               c.pt_stride, c.cos_t, c.sin_t, c.A, (int)c.identity_pages);
         else if (c.seq_rows > 0) {
             // group prefill: M = n_seq * seq_rows rows, every sequence starts at state->pos; flash attention per sequence
             FS_REQUIRE(d.Dh == 64 && M % c.seq_rows == 0 && !c.no_flash, "group prefill needs head_dim 64 and whole sequences");

@@ -2236,6 +2236,7 @@ class LM final : public LMBase {
         for (int l = 0; l < PF_LAYERS; ++l) { A.norms[2 * l] = fast_[l].attn_norm; A.norms[2 * l + 1] = fast_[l].ffn_norm; }
         A.norms[2 * PF_LAYERS] = fast_norm_w_;
         A.fast_emb = fast_emb_; A.tok_emb = tok_emb_; A.cb_emb = cb_emb_;
+        A.qkv0_tbl = (d_qkv0_.p && !getenv("FISHRT_ROWS_FAST_NO_QKV0")) ? d_qkv0_.as<float>() : nullptr;
         A.cos_t = d_cos_.as<float>(); A.sin_t = d_sin_.as<float>(); A.eps = d_.eps;
         A.xf = x(r0); A.x = x(r0);
         A.slow_logits = d_rlogits_.as<float>() + (size_t)r0 * PR_LD; A.n_slow = n_audio_;

@@ -53,6 +53,7 @@ struct RowsFastArgs {
     const float* scales;        // row scales of the fast image [PF_BLOCKS][PF_SCL]: FS_FP8 handles: FastPersistArgs::scales (bf16-widened e4m3 image); bf16 handles: ones
     const float* norms[2 * PF_LAYERS + 1];
     const void* fast_emb;
+    const float* qkv0_tbl;      // null, or the batch-1 fast decoder's layer-0 qkv table f32 [1024][1280] (lm_persist.h): codebook passes 1..7 skip layer 0's S1
     const void* tok_emb;
     const void* cb_emb;
     const float* cos_t;

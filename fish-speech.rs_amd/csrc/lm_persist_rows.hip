@@ -992,13 +992,28 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
             for (int r = 0; r < R; ++r) bs[r] = ebase(ee, rep, ((run >> r) & 1u) ? r : first);
             pr_sweep_rows<R>(bs, (unsigned)tid * 16u, tag0 + ee + 1, v, dead, A.ctl);
         };
+        uint32_t pcode[R];  // the code every row picked in the previous pass (uniform)
+#pragma unroll
+        for (int r = 0; r < R; ++r) pcode[r] = 0u;
 #pragma unroll 1
         for (int cb = 0; cb < 8; ++cb) {
             const int T = cb + 1;
 #pragma unroll
             for (int l = 0; l < PF_LAYERS; ++l) {
                 // ================= S1: (gather x) -> RMSNorm folded -> Wqkv rows of every row
-                {
+                // (round 6: layer 0 of the passes 1..7 with the qkv table -- the input row is fast_embeddings[code], so what this stage would publish
+                // is row `code` of the table built at load time (lm_persist.hip k_pf_qkv0_table); S2 reads it, the stage and its edge do not exist)
+                // (not in the sampled 4-row instantiation: at 256 registers the extra live values cost it 40 spilled W13 fragment registers, +25 us per frame)
+                constexpr bool TBL_OK = !(SAMPLED && R == 4);
+                const bool from_tbl = TBL_OK && l == 0 && cb > 0 && A.qkv0_tbl != nullptr;
+                if (from_tbl) {
+                    tid = pf_opaque(tid_k);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {  // next stage's row pairs
+                        if constexpr (R == 1) wo4[i] = rpi[(unsigned)((9 * l + 5 + i) * PF_THREADS + tid)];
+                        else wo8[i] = *reinterpret_cast<const uint2*>(rpi + (unsigned)((9 * l + 5 + i) * PF_THREADS + 2 * (tid & 255)));
+                    }
+                } else {
                     tid = pf_opaque(tid_k); lane = tid & 63; wave = tid >> 6;
                     const float2 nw = reinterpret_cast<const float2*>(A.norms[2 * l])[(unsigned)tid];
                     u32x4 v[R];
@@ -1060,10 +1075,25 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                         const u64* bs[R];
 #pragma unroll
                         for (int r = 0; r < R; ++r) bs[r] = ebase(e, rep, ((run >> r) & 1u) ? r : first);
-                        pf_nap_before_sweep(A.naps[1]);
-                        if (tid < 128) pr_sweep_rows2<R>(bs, (unsigned)tid * 16u, (unsigned)(512 + tid) * 16u, tag0 + e + 1, vq, vk, dead, A.ctl);
-                        else pr_sweep_rows<R>(bs, (unsigned)tid * 16u, tag0 + e + 1, vq, dead, A.ctl);
-                        ++e;
+                        if (from_tbl) {
+#pragma unroll
+                            for (int r = 0; r < R; ++r) {
+                                // (uniform base + 32-bit index, like every streamed image of this kernel)
+                                const float2* t2 = reinterpret_cast<const float2*>(A.qkv0_tbl);
+                                const unsigned ro = pcode[r] * 640u + (unsigned)tid;
+                                const float2 q2 = t2[ro];
+                                vq[r].x = __float_as_uint(q2.x); vq[r].z = __float_as_uint(q2.y);
+                                if (tid < 128) {  // k pairs 1024 + 2 tid (tid < 64), v pairs 1152 + 2 (tid - 64): the units 512 + tid of the qkv edge
+                                    const float2 k2 = t2[ro + 512u];
+                                    vk[r].x = __float_as_uint(k2.x); vk[r].z = __float_as_uint(k2.y);
+                                }
+                            }
+                        } else {
+                            pf_nap_before_sweep(A.naps[1]);
+                            if (tid < 128) pr_sweep_rows2<R>(bs, (unsigned)tid * 16u, (unsigned)(512 + tid) * 16u, tag0 + e + 1, vq, vk, dead, A.ctl);
+                            else pr_sweep_rows<R>(bs, (unsigned)tid * 16u, tag0 + e + 1, vq, dead, A.ctl);
+                            ++e;
+                        }
                         PF_TICK(10);
                         const int j = tid & 31;
                         const float c = rope_c[cb * 32 + j], s = rope_s[cb * 32 + j];
@@ -1496,9 +1526,18 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                 // rows are requested before anything else touches memory: inside the row loop each request waited behind the previous row's
                 // guarded stores (3.3 us per decision at 4 rows)
                 uint32_t ew[R];
+                const bool next_tbl = !(SAMPLED && R == 4) && A.qkv0_tbl != nullptr;
                 if (cb != 7) {
+                    if (next_tbl) {  // the next pass's first layer reads the qkv table; of the embedding row only this workgroup's 4 residual elements are needed
 #pragma unroll
-                    for (int r = 0; r < R; ++r) ew[r] = reinterpret_cast<const uint32_t*>(A.fast_emb)[codes[r] * 512u + (unsigned)tid];
+                        for (int r = 0; r < R; ++r) {
+                            pcode[r] = (uint32_t)__builtin_amdgcn_readfirstlane((int)codes[r]);
+                            ew[r] = (uint32_t)reinterpret_cast<const uint16_t*>(A.fast_emb)[codes[r] * 1024u + (unsigned)(4 * b + (tid & 3))];
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < R; ++r) ew[r] = reinterpret_cast<const uint32_t*>(A.fast_emb)[codes[r] * 512u + (unsigned)tid];
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
@@ -1508,8 +1547,15 @@ __global__ __launch_bounds__(PF_THREADS) void k_fast_rows(RowsFastArgs A) {
                     if (tid == 0) s_ring[r * RR + 168 + 4 + cb] = (int)codes[r];
                 }
                 if (cb != 7) {
+                    if (next_tbl) {  // (read behind S2's block barrier; the last reader of xr -- layer 3's S4 epilogue -- is two barriers back)
+                        if (tid < 4) {
 #pragma unroll
-                    for (int r = 0; r < R; ++r) *reinterpret_cast<float2*>(qs + r * 1024 + 2 * tid) = make_float2(bf_lo(ew[r]), bf_hi(ew[r]));
+                            for (int r = 0; r < R; ++r) xr[r * 4 + tid] = __uint_as_float(ew[r] << 16);
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < R; ++r) *reinterpret_cast<float2*>(qs + r * 1024 + 2 * tid) = make_float2(bf_lo(ew[r]), bf_hi(ew[r]));
+                    }
                 }
                 par ^= 1;
                 PF_TICK(6);

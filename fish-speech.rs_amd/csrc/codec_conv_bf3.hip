@@ -55,7 +55,10 @@ void codec_mean3_planes(const float* a, const float* b, const float* c, int B, i
 void codec_range_reset(hipStream_t st);
 void codec_range_read(unsigned long long* out2, hipStream_t st);
 }  // namespace c3chk
-static bool g_c3_checked = false;
+// thread_local: the twin is selected at LAUNCH time on the calling thread, so a concurrent decode of another codec handle on another thread
+// keeps the plain kernels and cannot pollute this call's counts; two checked calls at once are serialised by the engine
+// (codec_engine.hip range_guard_mutex: the counters are one pair per device)
+static thread_local bool g_c3_checked = false;
 void codec_range_check(bool on) { g_c3_checked = on; }
 void codec_range_reset(hipStream_t st) { c3chk::codec_range_reset(st); }
 void codec_range_read(unsigned long long* out2, hipStream_t st) { c3chk::codec_range_read(out2, st); }

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -117,8 +118,18 @@ class Codec final : public CodecBase {
         out5[0] = range_act_[0]; out5[1] = range_act_[1]; out5[2] = range_w_[0]; out5[3] = range_w_[1]; out5[4] = range_fallbacks_;
         if (last_rms) *last_rms = range_last_rms_;
     }
+    // PCM samples per code frame = the product of the two quantizer upsamplings (2 x 2, k = stride = 2 transposed convs) and the HiFi-GAN stages' strides
+    // of the loaded topology (config.rs:196-202: 8 x 8 x 2 x 2 x 2), read from the conv specs instead of assumed
+    size_t samples_per_frame() const {
+        size_t h = 1;
+        for (int i = 0; i < 2; ++i) h *= (size_t)convs_[up_conv_[i]].stride;
+        for (int s2 = 0; s2 < 5; ++s2) h *= (size_t)convs_[ups_[s2]].stride;
+        return h;
+    }
+    static std::mutex& range_guard_mutex() { static std::mutex m; return m; }  // one checked call at a time per process (one counter pair per device)
     void scan_weight_range() {  // pack the f16 weight images again through the counting twin (same bytes)
         if (!packed16_.p) return;
+        std::lock_guard<std::mutex> g(range_guard_mutex());
         codec_range_check(true);
         codec_range_reset(st_);
         for (size_t i = 0; i < convs_.size(); ++i) {
@@ -135,14 +146,17 @@ class Codec final : public CodecBase {
     void decode(const uint32_t* codes, int B, int T, float* pcm_out) override {
         if (!(range_check_ && bf3_ && f16_)) { decode_impl(codes, B, T, pcm_out, false); return; }
         FS_HIP(hipSetDevice(device_));
-        codec_range_check(true);
-        codec_range_reset(st_);
-        try { decode_impl(codes, B, T, pcm_out, false); } catch (...) { codec_range_check(false); throw; }
-        codec_range_check(false);
         unsigned long long r[2] = {0, 0};
-        codec_range_read(r, st_);
+        {
+            std::lock_guard<std::mutex> g(range_guard_mutex());
+            codec_range_check(true);
+            codec_range_reset(st_);
+            try { decode_impl(codes, B, T, pcm_out, false); } catch (...) { codec_range_check(false); throw; }
+            codec_range_check(false);
+            codec_range_read(r, st_);
+        }
         range_act_[0] += r[0]; range_act_[1] += r[1];
-        std::vector<float> wide((size_t)B * T * 2048);  // 4 x 8 x 8 x 2 x 2 x 2 samples per frame (the upsample rates are fixed: config.rs:196-202)
+        std::vector<float> wide((size_t)B * T * samples_per_frame());  // (4 x 8 x 8 x 2 x 2 x 2 = 2048 for the Fish codec: config.rs:196-202)
         f16_ = false;
         try { decode_impl(codes, B, T, wide.data(), false); } catch (...) { f16_ = true; throw; }
         f16_ = true;
@@ -186,13 +200,16 @@ class Codec final : public CodecBase {
         FS_REQUIRE(precision() == stream_prec_, "the precision mode changed inside a stream");
         FS_REQUIRE(T >= kStreamMinFrames, "a streamed chunk needs >= 16 frames (64 samples at the vocoder's lowest rate)");
         const bool chk = range_check_ && bf3_ && f16_;
-        if (chk) { codec_range_check(true); codec_range_reset(st_); }
-        try { decode_impl(codes, 1, T, pcm_out, true); } catch (...) { codec_range_check(false); throw; }
         if (chk) {
+            std::lock_guard<std::mutex> g(range_guard_mutex());
+            codec_range_check(true); codec_range_reset(st_);
+            try { decode_impl(codes, 1, T, pcm_out, true); } catch (...) { codec_range_check(false); throw; }
             codec_range_check(false);
             unsigned long long r[2] = {0, 0};
             codec_range_read(r, st_);
             range_act_[0] += r[0]; range_act_[1] += r[1];
+        } else {
+            decode_impl(codes, 1, T, pcm_out, true);
         }
         ++stream_chunk_;
     }
@@ -618,6 +635,7 @@ class Codec final : public CodecBase {
             codec_pack_bf3(relaid_.f() + relaid_off_[i], packed16_.u16() + packed16_off_[i], convs_[i].cin_g, K, Cout, true, st_);
         }
         FS_HIP(hipStreamSynchronize(st_));
+        if (range_check_) scan_weight_range();  // (the check was switched on before the weights existed: ADVICE r5)
     }
 
     int device_, C_ = 512;

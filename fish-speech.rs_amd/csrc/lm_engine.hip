@@ -2045,10 +2045,11 @@ class LM final : public LMBase {
 
     // naps before the first sweep of each stage kind (64-clock units; tuned on MI355X, profiles/r03_poll_naps.txt); the environment
     // variables ("a,b,c,d,e,f") override them for tuning runs
-    static constexpr int kNapsFast[6] = {16, 16, 16, 16, 12, 16}, kNapsSlow[6] = {24, 16, 2, 32, 36, 12};  // (re-tuned in round 5 behind the publishing-wave epilogues and the early W13 request: 558.8 -> 551.1 us on the tuner's workload; again at the end of the round: 543.1 -> 542.2, and behind the matrix-core S4 of the slow kernel: 541.9 -> 540.3)
+    static constexpr int kNapsFast[6] = {16, 16, 16, 16, 16, 16}, kNapsSlow[6] = {20, 16, 6, 36, 36, 12};  // (round 6, behind the layer-0 qkv table: 530.0 -> 528.4 us, profiles/r06_tune_naps.txt)
+    // (re-tuned in round 5 behind the publishing-wave epilogues and the early W13 request: 558.8 -> 551.1 us on the tuner's workload; again at the end of the round: 543.1 -> 542.2, and behind the matrix-core S4 of the slow kernel: 541.9 -> 540.3)
     // the same coordinate descent on the in-launch-sampler instantiation of k_fast_persist (680 -> 662 us per sampled frame) and on the
     // e4m3 image of k_slow_persist (595 -> 585 us per fp8 frame): their stage arithmetic differs, so the edges complete at other times
-    static constexpr int kNapsFastSampled[6] = {12, 16, 12, 16, 12, 16}, kNapsSlowFp8[6] = {20, 4, 28, 24, 24, 0};  // (round 5 re-tune: profiles/r05_tune_naps.txt)
+    static constexpr int kNapsFastSampled[6] = {12, 16, 12, 20, 12, 16}, kNapsSlowFp8[6] = {20, 4, 28, 24, 24, 0};  // (round 5 re-tune: profiles/r05_tune_naps.txt)
     static void set_naps(int (&naps)[6], const char* env, const int (&dflt)[6]) {
         for (int i = 0; i < 6; ++i) naps[i] = dflt[i];
         if (const char* v = getenv(env)) {

@@ -308,3 +308,19 @@ def test_hard_checkpoint_weight_norm_scales_vs_f32_oracle(tmp_path):
         assert abs(rms(got) - e3) < 1e-9
     else:
         assert st["act_saturated"] == 0 and st["last_pcm_rms_diff"] <= 5e-5
+
+
+def test_range_check_switched_on_before_load_still_scans_the_weights(tmp_path):
+    """fs_codec_set_range_check(1) BEFORE the weights exist used to leave the weight counters at zero for good (the scan ran only inside
+    set_range_check).  The pack path now scans when the check is already on."""
+    import test_safetensors_gpu as tsf
+    t = {k: v.copy() for k, v in tsf._codec_tensors(64, 1234).items()}
+    t["head.resblocks.1.blocks.0.convs1.0.conv.weight"] *= np.float32(1e-10)
+    path = str(tmp_path / "c.safetensors")
+    tsf._save(t, path, False)
+    c = fishrt.FireflyCodec(0, channel_div=8, precision="f16")
+    c.set_range_check(True)
+    c.load_safetensors(path)
+    st = c.range_stats()
+    assert st["weights_flushed"] > 0 and st["weights_saturated"] == 0, st
+    c.close()

@@ -8,6 +8,11 @@ an agreement between the two pins the C++ restatement.  The reference itself (Ru
 executed here, so these are "second-implementation" goldens, not reference outputs (DESIGN.md "Oracle").
 
 Fixtures are data only: seeded inputs + expected outputs at a tiny configuration, plus weight-free known answers.
+
+NOT made by this script: tests/golden/default_voice_codes.npy.  It is a byte copy of the reference's voice fixture
+`voices-template/default.npy` ((8, 274) int64 code indices in [3, 999]: a DATA file the reference ships, not source), taken once in the
+build container.  The tests use it as a realistic code sequence for the vocoder and the prompt formats; bench.py builds the VQ span of the
+configs[1] "default voice" prompt from it -- it is the one piece of reference-held data that travels to the GPU box.
 """
 import math
 import os

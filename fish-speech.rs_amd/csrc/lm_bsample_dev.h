@@ -60,11 +60,12 @@ struct alignas(16) BSampLds {  // LDS scratch of one call (7.9 KB)
     float sp[BS_MAXK + 32];    // kept probabilities, descending (later: compacted survivors)
     int ki[BS_MAXK];           // token index of kept entry j
     int rnk[BS_MAXK];          // descending-order rank of kept entry j (later: position of survivor j)
+    int bkt[BS_MAXK];          // fast tail: entry index at each position of the bin-ordered scratch (the patterns sit in cumk)
     uint32_t hist[2][256];
     double wsum[16];
     float wmax[16];
     int wcnt[2][16];
-    int misc[16];  // 0 bin, 1 above, 2 cut, 3 first, 4 last, 5 n_surv, 6 sum bits, 7 chosen bits, 8 fast-tail result, 9 candidates in the selected bin, 10 / 11 their max / min pattern
+    int misc[16];  // 0 bin, 1 above, 2 cut, 3 first, 4 last, 5 n_surv, 6 sum bits, 7 chosen bits, 8 fast-tail result, 9 candidates in the selected bin, 10 / 11 their max / min pattern, 12 zero-probability entries of the kept set (fast tail)
 };
 
 #ifdef BS_PROF
@@ -145,6 +146,7 @@ __device__ int bsample(const float (&lv)[EPT], int n, int kk, float inv_t, float
     for (int i = tid; i < 512; i += NT) (&S.hist[0][0])[i] = 0u;
     if (tid == 0) { S.misc[3] = 0x7FFFFFFF; S.misc[4] = -1; S.misc[2] = kk; }
     uint32_t u[EPT];
+    uint32_t umax_bits = 0u;  // pattern of the largest probability (1 / denominator)
     {
         float v[EPT];
         float mx = -INFINITY;
@@ -180,6 +182,7 @@ __device__ int bsample(const float (&lv)[EPT], int n, int kk, float inv_t, float
         // consumes its word and returns that entry.  p_max = expf(0) / denom is known to every thread; only the lowest index carrying it
         // has to be found.  (Strict inequality: at top_p == sum the reference takes the no-cut branch.)
         const float pmax = 1.0f / denom;
+        umax_bits = __float_as_uint(pmax);
         const bool cut1 = batch ? (top_p64 > 0.0 && (double)pmax > top_p64 && pmax >= top_p) : (top_p > 0.f && pmax > top_p);
         if (cut1) {
             int mine = 0x7FFFFFFF;
@@ -241,6 +244,8 @@ __device__ int bsample(const float (&lv)[EPT], int n, int kk, float inv_t, float
     const uint32_t T = prefix;
     BS_TS(2);
     // ---- C: keep p > T and the first kk - #{p > T} ties in index order (thread-major, then slot)
+    if (tid == 0) S.misc[12] = 0;
+    if (tid < 256) S.hist[0][tid] = 0u;  // (the fast tail's counting sort; nobody reads the selection's histograms any more, and C's barriers come before its atomics)
     const int nvalid = min(max(n - base, 0), EPT);  // only matters for ties at T == 0
     int pos;
     uint32_t keepbits = 0u;
@@ -308,36 +313,49 @@ __device__ int bsample(const float (&lv)[EPT], int n, int kk, float inv_t, float
         const bool cut_sure = tp > 0.0 && tp < (double)approx * 0.9999, nocut_sure = !(tp > 0.0) || tp >= (double)approx * 1.0001;
         if (cut_sure || nocut_sure) {  // (uniform over the block)
             if (cut_sure) {
-                // descending-order ranks by counting, two threads per entry where the block has them (each counts one half of the entries)
-                constexpr int TPE = NT >= 2 * BS_MAXK ? 2 : 1;
-                const int kk8 = (kk + 7) & ~7, half = TPE == 2 ? (((kk8 >> 1) + 7) & ~7) : kk8;
-                const int part = TPE == 2 ? (tid >> 8) : 0, j = TPE == 2 ? (tid & (BS_MAXK - 1)) : tid;
-                int* part_rnk = reinterpret_cast<int*>(S.cumk);  // (cumk is not needed before the exact tail, which rewrites it)
-                int myr = 0;
-                const int pj = __float_as_int(S.kp[min(j, kk - 1)]);
-                if (tid < TPE * BS_MAXK && j < ((kk + 63) & ~63)) {
-                    const int lo = part == 0 ? 0 : half, hi = (TPE == 2 && part == 0) ? half : kk8;
-                    const int jb = __builtin_amdgcn_readfirstlane(j & ~63), pjm1 = pj - 1;
-                    int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-                    auto count8 = [&](int i, auto thr) {
-                        const float4 a = *reinterpret_cast<const float4*>(S.kp + i), b4 = *reinterpret_cast<const float4*>(S.kp + i + 4);
-                        r0 += __float_as_int(a.x) > thr(i) ? 1 : 0; r1 += __float_as_int(a.y) > thr(i + 1) ? 1 : 0;
-                        r2 += __float_as_int(a.z) > thr(i + 2) ? 1 : 0; r3 += __float_as_int(a.w) > thr(i + 3) ? 1 : 0;
-                        r0 += __float_as_int(b4.x) > thr(i + 4) ? 1 : 0; r1 += __float_as_int(b4.y) > thr(i + 5) ? 1 : 0;
-                        r2 += __float_as_int(b4.z) > thr(i + 6) ? 1 : 0; r3 += __float_as_int(b4.w) > thr(i + 7) ? 1 : 0;
-                    };
-                    const int lo_end = min(max(jb, lo), hi), mid_end = min(max(jb + 64, lo), hi);
-                    for (int i = lo; i < lo_end; i += 8) count8(i, [&](int) { return pjm1; });
-                    for (int i = lo_end; i < mid_end; i += 8) count8(i, [&](int ii) { return ii < j ? pjm1 : pj; });
-                    for (int i = mid_end; i < hi; i += 8) count8(i, [&](int) { return pj; });
-                    myr = (r0 + r1) + (r2 + r3);
-                    if (part == 1) part_rnk[j] = myr;
+                // Descending-order ranks by a counting sort on the kept patterns (round 6; the all-pairs count it replaces was 65 536 compares,
+                // ~4.5 k clocks).  The kept patterns lie in [T, umax] (umax = the pattern of 1 / denom); bin = the top 8 bits of (umax - u) at
+                // that range's scale, so a flat row spreads its 256 entries over ~256 bins and a bin holds 1-3 of them.  (1) LDS histogram +
+                // slot by ds_add_rtn, (2) wave 0 scans the bins, (3) entries scatter into bin order, (4) each entry ranks itself among its
+                // bin's members: rank = #{u > u_j} + #{u == u_j, index < j} -- exactly the order the exact tail uses.  Worst case (every
+                // entry in one bin: equal patterns) degenerates to the old all-pairs count.
+                const bool ent = tid < kk;
+                const uint32_t uj = ent ? __float_as_uint(S.kp[tid]) : T;
+                const uint32_t range = umax_bits - T;
+                const int sh = max(0, 24 - (int)__builtin_clz(range | 1u));  // (range >> sh) < 256
+                const int bin = 255 - (int)((uj - T) >> sh);
+                uint32_t* bk_u = reinterpret_cast<uint32_t*>(S.cumk);       // (cumk is not needed before the exact tail, which rewrites it)
+                // (zero probabilities -- underflowed candidates a sharp row keeps by the hundred -- would all land in one bin and each walk it:
+                // 20 k clocks measured.  They rank behind every positive entry and move no sum, so their order among themselves is free:
+                // a counter hands them the last ranks.)
+                const bool zent = ent && uj == 0u;
+                int slot = 0;
+                if (zent) slot = atomicAdd(&S.misc[12], 1);
+                else if (ent) slot = (int)atomicAdd(&S.hist[0][bin], 1u);   // (hist[0] and misc[12] were zeroed at the top of phase C)
+                __syncthreads();
+                if (wv == 0) {
+                    const uint4 hv = *reinterpret_cast<const uint4*>(S.hist[0] + lane * 4);
+                    const int mine = (int)((hv.x + hv.y) + (hv.z + hv.w));
+                    const int excl = bs_wave_scan(mine) - mine;
+                    *reinterpret_cast<uint4*>(S.hist[1] + lane * 4) = make_uint4((uint32_t)excl, (uint32_t)excl + hv.x, (uint32_t)excl + hv.x + hv.y, (uint32_t)excl + hv.x + hv.y + hv.z);
                 }
                 __syncthreads();
-                if (tid < kk) {
-                    const int r = myr + (TPE == 2 ? part_rnk[tid] : 0);
+                int start = 0, cnt = 0;
+                if (ent && !zent) {
+                    start = (int)S.hist[1][bin]; cnt = (int)S.hist[0][bin];
+                    bk_u[start + slot] = uj;
+                    S.bkt[start + slot] = tid;
+                }
+                __syncthreads();
+                if (ent) {
+                    int r = zent ? kk - S.misc[12] + slot : start;
+                    for (int e = 0; e < cnt; ++e) {  // (cnt == 0 for a zero entry)
+                        const uint32_t ue = bk_u[start + e];
+                        const int je = S.bkt[start + e];
+                        r += (ue > uj || (ue == uj && je < tid)) ? 1 : 0;
+                    }
                     S.rnk[tid] = r;
-                    S.sp[r] = __int_as_float(pj);
+                    S.sp[r] = __uint_as_float(uj);
                 }
                 __syncthreads();
             }

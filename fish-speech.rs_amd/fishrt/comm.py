@@ -19,6 +19,20 @@ def unique_id():
     return bytes(buf)
 
 
+def share_id(make_id, key="fishrt_comm_id"):
+    """The one step of the bring-up that is NOT in the C ABI: rank 0 calls make_id() (fs_comm_unique_id) and the 128 bytes reach every rank
+    through the launcher's key-value store (torchrun's MASTER_ADDR / MASTER_PORT; under torchrun the agent hosts it).  Returns
+    (id bytes, rank, world, store).  No torch process group is created.  (tests/test_fanout.py runs this with world 2 on CPU.)"""
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    if world == 1:
+        return make_id(), 0, 1, None
+    from torch.distributed import rendezvous
+    store, rank, world = next(rendezvous("env://", rank, world))
+    if rank == 0:
+        store.set(key, make_id())
+    return bytes(store.get(key)), rank, world, store
+
+
 class RcclComm:
     """one RCCL communicator of this process's GPU (fs_comm_t)"""
 
@@ -32,15 +46,8 @@ class RcclComm:
     @classmethod
     def from_env(cls, device=None, key="fishrt_comm_id"):
         """ranks started by torchrun (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT): rank 0 publishes the id in the launcher's store"""
-        rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
         dev = int(os.environ.get("LOCAL_RANK", 0)) if device is None else int(device)
-        if world == 1:
-            return cls(unique_id(), 0, 1, dev)
-        from torch.distributed import rendezvous  # key-value store only: no process group, no second communicator
-        store, rank, world = next(rendezvous("env://", rank, world))
-        if rank == 0:
-            store.set(key, unique_id())
-        uid = bytes(store.get(key))
+        uid, rank, world, store = share_id(unique_id, key)
         c = cls(uid, rank, world, dev)
         c._store = store  # (keeps the store's server on rank 0 alive for the slower ranks)
         return c

@@ -27,6 +27,19 @@ def test_gloo_world2_fanout():
     assert "FANOUT_OK 2" in p.stdout and "FANIN_OK 2" in p.stdout and "WEIGHTS_OK 2" in p.stdout
 
 
+def test_comm_id_travels_through_the_launcher_store():
+    """fishrt.comm.share_id: the one step of the RCCL bring-up outside the C ABI (rank 0's fs_comm_unique_id bytes -> every rank) through the
+    launcher's key-value store, world 2 under torch.distributed.run, no process group -- what RcclComm.from_env does on the GPU box"""
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29531", os.path.join(ROOT, "tests", "comm_store_worker.py")]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "COMM_STORE_OK rank 0" in p.stdout and "COMM_STORE_OK rank 1" in p.stdout
+
+
 def test_bench_gpus2_self_launch_dry_run():
     """`python bench.py --gpus 2` without torchrun starts its own ranks; on a box without an MI355X the ranks run the control path
     only (shard, prompt broadcast, code all-gather over gloo), print a JSON line flagged dry_run and exit 0."""

@@ -257,7 +257,8 @@ def main():
     # refuses two ranks on one GPU) -- together they run the whole N > 1 path, weight broadcast included, on device memory
     if "FISHRT_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["FISHRT_BENCH_DEVICE"])
-        torch.cuda.set_device(local_rank)
+    if have_gpu:
+        torch.cuda.set_device(local_rank)  # (the barriers' torch.cuda.synchronize() must mean THIS rank's GPU, not device 0 on every rank)
     backend = os.environ.get("FISHRT_BENCH_BACKEND", "rccl") if have_gpu else "gloo"
     # rccl: the fs_comm_* C entry points of libfishrt.so on librccl directly (request fan-out + the job's clock; no torch process group)
     dist = fanout.init(backend if world > 1 else None, device=local_rank)

@@ -48,7 +48,20 @@ class RcclComm:
         """ranks started by torchrun (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT): rank 0 publishes the id in the launcher's store"""
         dev = int(os.environ.get("LOCAL_RANK", 0)) if device is None else int(device)
         uid, rank, world, store = share_id(unique_id, key)
-        c = cls(uid, rank, world, dev)
+        c, err = None, None
+        try:
+            c = cls(uid, rank, world, dev)
+        except Exception as e:  # noqa: BLE001 -- voted on below: a rank that failed alone must not leave the others inside a collective
+            err = e
+        if store is not None:  # every rank learns whether EVERY rank has its communicator before anybody uses (or abandons) it
+            store.set(f"{key}_ok_{rank}", b"1" if c is not None else b"0")
+            ok = all(bytes(store.get(f"{key}_ok_{r}")) == b"1" for r in range(world))
+            if not ok:
+                if c is not None:
+                    c.close()
+                raise RuntimeError(f"fs_comm_create failed on at least one rank (this rank: {err or 'ok'})")
+        elif c is None:
+            raise err
         c._store = store  # (keeps the store's server on rank 0 alive for the slower ranks)
         return c
 

@@ -36,8 +36,18 @@ def init(backend=None, device=None):
     if backend is None:
         from . import _ffi
         backend = "rccl" if _ffi.lib().fs_device_count() > 0 else "gloo"
+    dev = local_rank if device is None else device
     if backend in ("nccl", "rccl"):
-        return RcclComm.from_env(device=local_rank if device is None else device)
+        try:
+            return RcclComm.from_env(device=dev)
+        except Exception as e:  # noqa: BLE001 -- agreed by every rank (RcclComm.from_env votes through the store): all fall back together
+            import sys
+            print(f"fishrt.fanout: fs_comm_* bring-up failed on rank {rank} ({e}); falling back to torch.distributed's RCCL backend", file=sys.stderr, flush=True)
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        return dist
     import torch.distributed as dist
     dist.init_process_group(backend)
     return dist
@@ -60,7 +70,7 @@ def _reduce(dist, value, op):
     if _is_rccl(dist):
         return float(dist.all_reduce([float(value)], op)[0])
     import torch
-    t = torch.tensor([float(value)], dtype=torch.float64)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_dev(dist))
     dist.all_reduce(t, op={MAX: dist.ReduceOp.MAX, MIN: dist.ReduceOp.MIN, SUM: dist.ReduceOp.SUM}[op])
     return float(t.item())
 
@@ -114,7 +124,7 @@ def gather_results(dist, n_requests, local_results):
 
 
 def _dev(dist):
-    return "cpu"  # (the torch carrier is gloo: host tensors; device arenas are staged through _DeviceBytes below)
+    return "cuda" if dist.get_backend() == "nccl" else "cpu"  # (gloo: host tensors; "nccl" only as the fallback carrier of init())
 
 
 class _DeviceBytes:

@@ -30,7 +30,7 @@ struct fs_comm { fs::Comm* impl; };
 extern "C" {
 
 const char* fs_last_error(void) { return g_err.c_str(); }
-const char* fs_version(void) { return "fishrt 0.3.0 (gfx950)"; }
+const char* fs_version(void) { return "fishrt 0.4.0 (gfx950)"; }
 int fs_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

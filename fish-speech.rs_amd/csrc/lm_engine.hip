@@ -2132,7 +2132,10 @@ class LM final : public LMBase {
         A.peer_stamps = (A.prof && d_ctl_.p) ? reinterpret_cast<const unsigned long long*>(d_ctl_.as<uint32_t>() + 16) + 16 : nullptr;
         set_naps(A.naps, "FISHRT_NAPS_SLOW", kFp8 ? kNapsSlowFp8 : kNapsSlow);
         A.prof_wg = getenv("FISHRT_PERSIST_PROF_WG") ? atoi(getenv("FISHRT_PERSIST_PROF_WG")) : 0;
-        A.l2_touch = getenv("FISHRT_SLOW_EARLY") ? atoi(getenv("FISHRT_SLOW_EARLY")) : 1;  // k_slow_persist early_mode bits
+        // k_slow_persist early_mode bits.  bit 3 (round 6, bf16 images): an attention workgroup requests its first K/V tile BEHIND S1's publish instead of
+        // in front of the Wqkv rows -- the publishing stores used to queue behind the tile's 32 KB of loads in the CU's vector-memory pipeline (S1 work
+        // 1.2 -> 0.7 us on those workgroups; 529.3 -> 526.1 us per frame, 614.5 -> 604.6 at 4100 cached tokens; fp8: no difference, left off)
+        A.l2_touch = getenv("FISHRT_SLOW_EARLY") ? atoi(getenv("FISHRT_SLOW_EARLY")) : (kFp8 ? 1 : 9);
         return A;
     }
     // the persistent fast decoder takes the slow-token decision in its prologue (no k_sample_slow node) whenever it runs

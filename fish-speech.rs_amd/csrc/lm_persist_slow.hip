@@ -369,7 +369,8 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
                 ++e;
                 PS_TICK(9);
             }
-            if (att && n_tok > 0) load_kv_tile0(l);  // this layer's first K/V tile, under the qkv stage
+            const bool kv_late = (early_mode & 8) != 0;  // (bit 3: the tile request BEHIND the publish, so that the publishing stores do not queue behind 32 KB of loads in the CU's vector-memory pipeline)
+            if (att && n_tok > 0 && !kv_late) load_kv_tile0(l);  // this layer's first K/V tile, under the qkv stage
             *reinterpret_cast<float2*>(xs + 2 * tid) = make_float2(x0, x1);
             const float xn0 = x0 * nw.x, xn1 = x1 * nw.y;
             float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -400,6 +401,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_slow_persist(SlowPersistArgs A) 
                     pub(e, k + 4, 5 * b + r, tag0 + e + 1, val);
                 }
             }
+            if (att && n_tok > 0 && kv_late) load_kv_tile0(l);
             if (early13) request_w13(wl);  // (nothing the compiler knows of is in flight here: the stage's own weights and norm vector have been consumed)
             if (early2) request_w2(wl);
             par ^= 1;

@@ -151,3 +151,25 @@ def test_wav_writer_header_and_samples():
     buf2 = io.BytesIO()
     fw.write_pcm_as_wav(buf2, np.array([1, -2, 3], np.int16), 8000)  # i16 passes through
     assert list(np.frombuffer(buf2.getvalue()[44:], "<i2")) == [1, -2, 3]
+
+
+def test_reference_dump_tooling_parses_what_llama_generate_prints(tmp_path):
+    """tools/make_reference_dumps.sh (the one-command pin): its second half turns the reference binary's stdout into prompt.npy + meta.json.  A
+    fabricated log in the format of fish_speech_core/src/bin/llama_generate.rs:70-88 (Debug print of a Vec<u32>, possibly wrapped) keeps it working."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("reference_dumps_meta", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "reference_dumps_meta.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    toks = [100257, 9125, 198, 96945, 704, 279, 3984, 1495, 100258, 100257, 882, 198, 15339, 100258, 100257, 78191, 198, 100264]
+    log = ("Text: \"hello\"\nSpeaker conditioning size: [9, 9]\nLoaded prompt with shape [9, 18]\nInput tokens:\n[" +
+           ", ".join(str(t) for t in toks[:9]) + ",\n " + ", ".join(str(t) for t in toks[9:]) + "]\nInput prompt:\n<|im_start|>system...\n")
+    (tmp_path / "llama_generate.log").write_text(log)
+    np.save(tmp_path / "ref_codes.npy", np.arange(8 * 5, dtype=np.uint32).reshape(8, 5))
+    meta, prompt = mod.write_meta(str(tmp_path), "/ckpt", "hello", "1.5", 256)
+    assert prompt.shape == (9, 18) and prompt.dtype == np.uint32 and prompt[0].tolist() == toks and not prompt[1:].any()
+    assert np.array_equal(np.load(tmp_path / "prompt.npy"), prompt)
+    m = json.load(open(tmp_path / "meta.json"))
+    assert m["frames"] == 5 and m["prompt_positions"] == 18 and m["fish_version"] == "1.5" and m["max_new_tokens"] == 256
+    with pytest.raises(ValueError):
+        mod.parse_input_tokens("no tokens here")

@@ -25,20 +25,4 @@ command -v cargo >/dev/null || { echo "cargo not found: run this where the refer
 ( cd "$REF" && cargo run --release --bin llama_generate -- --checkpoint "$CKPT" --fish-version "$VER" --temp 0 --text "$TEXT" \
       --max-new-tokens "$MAXNEW" --out-path "$OUT/ref_codes.npy" ) | tee "$OUT/llama_generate.log"
 ( cd "$REF" && cargo run --release --bin vocoder -- --checkpoint "$CKPT" --fish-version "$VER" -i "$OUT/ref_codes.npy" -o "$OUT/ref.wav" )
-python3 - "$OUT" "$CKPT" "$TEXT" "$VER" "$MAXNEW" <<'PY'
-import json, re, sys
-import numpy as np
-out, ckpt, text, ver, maxnew = sys.argv[1:6]
-log = open(f"{out}/llama_generate.log").read()
-m = re.search(r"Input tokens:\s*\[([0-9,\s]+)\]", log)
-assert m, "llama_generate did not print its input tokens"
-row0 = np.array([int(t) for t in m.group(1).replace("\n", " ").split(",") if t.strip()], np.uint32)
-prompt = np.zeros((9, row0.size), np.uint32)
-prompt[0] = row0
-np.save(f"{out}/prompt.npy", prompt)
-codes = np.load(f"{out}/ref_codes.npy")
-json.dump({"checkpoint": ckpt, "text": text, "fish_version": ver, "max_new_tokens": int(maxnew), "repetition_penalty": 1.2,
-           "frames": int(codes.shape[-1]), "prompt_positions": int(row0.size),
-           "made_by": "tools/make_reference_dumps.sh (reference binaries llama_generate --temp 0, vocoder; CPU f32)"}, open(f"{out}/meta.json", "w"), indent=1)
-print(f"wrote {out}: codes {codes.shape}, prompt (9, {row0.size})")
-PY
+python3 "$HERE/tools/reference_dumps_meta.py" "$OUT" "$CKPT" "$TEXT" "$VER" "$MAXNEW"
